@@ -1,0 +1,7 @@
+"""eagcn_amd: MI355X-native EAGCN forward/backward hot path (hand-written HIP behind a C ABI)."""
+from .layers import (AFM_BatchNorm, Ave_multi_view, Dense, GraphConv_base, GraphConv_block,  # noqa: F401
+                     GraphConv_Layer)
+from .models import EAGCN, Concate_GCN, Weighted_GCN, weights_init  # noqa: F401
+
+__all__ = ['EAGCN', 'Concate_GCN', 'Weighted_GCN', 'GraphConv_Layer', 'GraphConv_block', 'GraphConv_base',
+           'AFM_BatchNorm', 'Ave_multi_view', 'Dense', 'weights_init']

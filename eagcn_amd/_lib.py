@@ -1,0 +1,126 @@
+"""ctypes binding of libeagcn_hip.so (the C ABI declared in include/eagcn_hip.h).
+
+This is the reference-side stub a maintainer would add: plain pointers and sizes,
+no torch types cross the boundary.  There is no CPU fallback: if the library is missing or fails
+to load, importing the ops raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libeagcn_hip.so')
+
+MAX_VIEWS = 8
+MAX_SEGS = 8
+META_WORDS = 8
+META_T, META_NMAX, META_NTILES, META_BAD_ADJ, META_BAD_REL, META_NEDGE = range(6)
+STRUCT_CONCATE, STRUCT_WEIGHTED = 0, 1
+
+_fp = C.c_void_p   # device pointers travel as integers
+
+
+class Batch(C.Structure):
+    _fields_ = [('B', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('ldc', C.c_int32),
+                ('T', C.c_int32), ('n_max', C.c_int32), ('n_tiles', C.c_int32),
+                ('channels', C.c_int32 * MAX_VIEWS),
+                ('code', _fp), ('deg_bn', _fp), ('nat', _fp), ('row0', _fp), ('tile0', _fp),
+                ('meta', _fp), ('row_mol', _fp), ('row_loc', _fp), ('row_m', _fp), ('row_deg', _fp),
+                ('tile_mol', _fp)]
+
+
+class Layout(C.Structure):
+    _fields_ = [('nseg', C.c_int32), ('width', C.c_int32 * MAX_SEGS), ('pad', C.c_int32 * MAX_SEGS)]
+
+
+class LayerParams(C.Structure):
+    _fields_ = [('K', C.c_int32), ('structure', C.c_int32), ('training', C.c_int32),
+                ('width', C.c_int32 * MAX_VIEWS), ('inp', Layout),
+                ('dropout', C.c_float), ('bn_eps', C.c_float), ('bn_momentum', C.c_float),
+                ('seed', C.c_uint64),
+                ('att_w', _fp * MAX_VIEWS), ('self_r', _fp * MAX_VIEWS), ('W', _fp * MAX_VIEWS),
+                ('bias', _fp * MAX_VIEWS), ('gamma', _fp * MAX_VIEWS), ('beta', _fp * MAX_VIEWS),
+                ('run_mean', _fp * MAX_VIEWS), ('run_var', _fp * MAX_VIEWS), ('ave_w', _fp)]
+
+
+class LayerBufs(C.Structure):
+    _fields_ = [('x', _fp), ('P', _fp), ('Y', _fp), ('rscale', _fp), ('bn', _fp), ('xout', _fp),
+                ('pad_row', _fp), ('scratch', _fp), ('scratch_bytes', C.c_size_t)]
+
+
+class LayerGrads(C.Structure):
+    _fields_ = [('dW', _fp * MAX_VIEWS), ('dbias', _fp * MAX_VIEWS), ('dgamma', _fp * MAX_VIEWS),
+                ('dbeta', _fp * MAX_VIEWS), ('datt_w', _fp * MAX_VIEWS), ('dself_r', _fp * MAX_VIEWS),
+                ('dave_w', _fp)]
+
+
+# name -> (restype, argtypes); also the list the CPU test checks against include/eagcn_hip.h
+SIGNATURES = {
+    'eagcn_abi_version': (C.c_int, []),
+    'eagcn_last_error': (C.c_char_p, []),
+    'eagcn_pad16': (C.c_int, [C.c_int]),
+    'eagcn_layer_out_ld': (C.c_int, [C.POINTER(LayerParams)]),
+    'eagcn_layer_fp': (C.c_int, [C.POINTER(LayerParams)]),
+    'eagcn_layer_fwd_scratch_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(LayerParams)]),
+    'eagcn_layer_bwd_scratch_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(LayerParams)]),
+    'eagcn_index_build': (C.c_int, [_fp, C.POINTER(_fp), C.POINTER(Batch), _fp, _fp]),
+    'eagcn_index_rows': (C.c_int, [C.POINTER(Batch), _fp]),
+    'eagcn_pack_rows': (C.c_int, [C.POINTER(Batch), _fp, C.c_int, C.POINTER(Layout), _fp, _fp]),
+    'eagcn_unpack_rows': (C.c_int, [C.POINTER(Batch), _fp, C.POINTER(Layout), _fp, _fp, C.c_int, _fp]),
+    'eagcn_layer_forward': (C.c_int, [C.POINTER(Batch), C.POINTER(LayerParams), C.POINTER(LayerBufs), _fp]),
+    'eagcn_layer_backward': (C.c_int, [C.POINTER(Batch), C.POINTER(LayerParams), C.POINTER(LayerBufs),
+                                       _fp, _fp, _fp, C.POINTER(LayerGrads), _fp]),
+    'eagcn_attention_dense': (C.c_int, [C.POINTER(Batch), C.POINTER(LayerParams), _fp, _fp]),
+    'eagcn_readout_forward': (C.c_int, [C.POINTER(Batch), _fp, C.POINTER(Layout), _fp, _fp, C.c_int, _fp,
+                                        C.c_int, _fp]),
+    'eagcn_readout_backward': (C.c_int, [C.POINTER(Batch), _fp, C.POINTER(Layout), _fp, C.c_int, C.c_int,
+                                         _fp, _fp, _fp]),
+    'eagcn_gemm_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int,
+                                 _fp, C.c_int, _fp]),
+}
+
+_lib = None
+
+
+class EagcnHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library (once).  Raises if it is not built -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EagcnHipError(
+            'libeagcn_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
+            'or `python -m eagcn_amd.build`; eagcn_amd has no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().eagcn_last_error()
+        raise EagcnHipError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))
+
+
+def pad16(w):
+    return (int(w) + 15) & ~15
+
+
+def pad4(w):
+    return (int(w) + 3) & ~3
+
+
+def make_layout(widths, pads):
+    lay = Layout()
+    lay.nseg = len(widths)
+    for i, (w, p) in enumerate(zip(widths, pads)):
+        lay.width[i] = int(w)
+        lay.pad[i] = int(p)
+    return lay

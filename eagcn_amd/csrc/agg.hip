@@ -1,0 +1,266 @@
+// Multi-view edge-attention aggregation on the matrix cores, and its backward pieces.
+//
+// Reference semantics (layers.py:82-92 with the masks of layers.py:294-304), per molecule b and
+// view k, for the P_k = X.W_k slice produced by the flat GEMM (the reference computes (A.X).W,
+// layers.py:39-40; the product is re-associated):
+//     U[i,j]  = sigmoid(w_k[type(i,j)]) * adj[i,j] + sigmoid(self_r) * m_i * [i==j] + 1e-9*(1-adj[i,j])
+//     A^[i,j] = m_i * U[i,j] / sum_j' U[i,j']          (j' over all N padded columns)
+//     Y'[i,:] = sum_j A^[i,j] P_k[j,:]
+// One wavefront owns one (molecule, view, 16-row tile): it walks the molecule's nat[b] columns in
+// steps of 4 (the K extent of v_mfma_f32_16x16x4_f32), builds its A-operand value U[i, j0+q] on
+// the fly from the uint8 bond-type map (one 16-byte load covers four k-steps) and an LDS sigma
+// table, feeds the B operand straight from P (L1/L2 resident: a molecule's P slice is
+// nat x F_k floats), and keeps CT 16x16 accumulators so each A value is reused CT times.  The row
+// sum is accumulated in the same loop and applied once in the epilogue (row scaling commutes with
+// the product), where the per-channel BatchNorm partial sums (sum y, sum y^2 in fp64) are taken as
+// well.  No LDS tile, no barrier in the main loop, any molecule size.
+// Columns j >= nat[b] hold 1e-9/rowsum weights on rows whose features are zero (Concate) or on a
+// constant vector (Weighted_sum); they enter the row sum exactly and are dropped from the product
+// (relative contribution <= N*1e-9).
+#include <algorithm>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace eagcn {
+
+template <int CT, bool TRANS>
+__global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
+    __shared__ float sig_s[256];
+    __shared__ double st_s[TRANS ? 1 : CT * 16 * 2];
+    const int k = blockIdx.y / a.nchunk, cc = blockIdx.y % a.nchunk;
+    const int ntile_k = (a.vc.off[k + 1] - a.vc.off[k]) / 16;
+    const int ct0 = cc * CT;
+    if (ct0 >= ntile_k) return;                       // uniform for the whole workgroup
+    const int nct = min(CT, ntile_k - ct0);
+    const int c0 = a.vc.off[k] + ct0 * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    sig_s[tid] = a.sig[k * 256 + tid];
+    if (!TRANS) for (int i = tid; i < CT * 16 * 2; i += 256) st_s[i] = 0.0;
+    __syncthreads();
+    const float r = a.rsig[k];
+    const eagcn_batch& bt = a.bt;
+    double s1[CT], s2[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { s1[c] = 0.0; s2[c] = 0.0; }
+
+    for (int tile = blockIdx.x * 4 + wave; tile < bt.n_tiles; tile += gridDim.x * 4) {
+        const int b = bt.tile_mol[tile];
+        const int rt = tile - bt.tile0[b];
+        const int n = bt.nat[b], r0 = bt.row0[b];
+        const uint8_t* codeb = bt.code + ((size_t)k * bt.B + b) * bt.N * bt.ldc;
+        const int ia = rt * 16 + li;                  // A-operand row of this lane = output row
+        f32x4 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* sbase = a.src + (size_t)r0 * a.lds + c0 + li;
+
+        if (!TRANS) {
+            const float mi = (ia < n) ? bt.row_m[r0 + ia] : 0.0f;
+            float dsum = 0.0f;
+            for (int j0 = 0; j0 < n; j0 += 16) {
+                uint4 cw = make_uint4(0u, 0u, 0u, 0u);
+                if (ia < n) cw = *reinterpret_cast<const uint4*>(codeb + (size_t)ia * bt.ldc + j0);
+                const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int jb = j0 + 4 * t;
+                    if (jb < n) {
+                        const int j = jb + q;
+                        const uint32_t c = (w[t] >> (8 * q)) & 255u;
+                        float u = sig_s[c] + (c == 0u ? TINY : 0.0f);
+                        if (j == ia) u += r * mi;
+                        if (j >= n || ia >= n) u = 0.0f;
+                        dsum += u;
+                        const float* srow = sbase + (size_t)min(j, n - 1) * a.lds;
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            if (ct < nct) {
+                                const float bv = (j < n) ? srow[ct * 16] : 0.0f;
+                                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv, acc[ct], 0, 0, 0);
+                            }
+                    }
+                }
+            }
+            dsum += __shfl_xor(dsum, 16);
+            dsum += __shfl_xor(dsum, 32);
+            const float d = dsum + TINY * (float)(bt.N - n);
+            const float sc = (mi > 0.0f && ia < n) ? 1.0f / d : 0.0f;
+            if (cc == 0 && q == 0 && ia < n) a.rscale[(size_t)k * bt.T + r0 + ia] = sc;
+            float scr[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) scr[g] = __shfl(sc, q * 4 + g);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                if (ct < nct) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = rt * 16 + q * 4 + g;
+                        if (row < n) {
+                            const float y = acc[ct][g] * scr[g];
+                            a.dst[(size_t)(r0 + row) * a.ldd + c0 + ct * 16 + li] = y;
+                            s1[ct] += (double)y;
+                            s2[ct] += (double)y * (double)y;
+                        }
+                    }
+                }
+        } else {
+            // dP[j,:] = sum_i A^[i,j] dY'[i,:]  (rscale carries m_i / rowsum_i)
+            for (int i0 = 0; i0 < n; i0 += 4) {
+                const int i = i0 + q;
+                uint32_t c = 0u;
+                float rs = 0.0f;
+                if (i < n && ia < n) {
+                    c = codeb[(size_t)i * bt.ldc + ia];
+                    rs = a.rscale[(size_t)k * bt.T + r0 + i];
+                }
+                float u = sig_s[c] + (c == 0u ? TINY : 0.0f);
+                if (i == ia) u += r;
+                u *= rs;
+                const float* srow = sbase + (size_t)min(i, n - 1) * a.lds;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    if (ct < nct) {
+                        const float bv = (i < n) ? srow[ct * 16] : 0.0f;
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv, acc[ct], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                if (ct < nct) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = rt * 16 + q * 4 + g;
+                        if (row < n) a.dst[(size_t)(r0 + row) * a.ldd + c0 + ct * 16 + li] = acc[ct][g];
+                    }
+                }
+        }
+    }
+
+    if (!TRANS) {
+        // per-workgroup partial BatchNorm sums -> slab[blockIdx.x][column][2]
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            s1[ct] += __shfl_xor(s1[ct], 16);
+            s1[ct] += __shfl_xor(s1[ct], 32);
+            s2[ct] += __shfl_xor(s2[ct], 16);
+            s2[ct] += __shfl_xor(s2[ct], 32);
+        }
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w && q == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    st_s[(ct * 16 + li) * 2 + 0] += s1[ct];
+                    st_s[(ct * 16 + li) * 2 + 1] += s2[ct];
+                }
+            }
+            __syncthreads();
+        }
+        const int fp = a.vc.off[a.vc.K];
+        for (int i = tid; i < nct * 16 * 2; i += 256)
+            a.stats[((size_t)blockIdx.x * fp + c0) * 2 + i] = st_s[i];
+    }
+}
+
+template <bool TRANS>
+static int launch_agg_t(const AggArgs& a, int ct, dim3 grid, hipStream_t s) {
+    switch (ct) {
+#define EAGCN_AGG_CASE(N) case N: agg_kernel<N, TRANS><<<grid, 256, 0, s>>>(a); break;
+        EAGCN_AGG_CASE(1) EAGCN_AGG_CASE(2) EAGCN_AGG_CASE(3) EAGCN_AGG_CASE(4) EAGCN_AGG_CASE(5)
+        EAGCN_AGG_CASE(6) EAGCN_AGG_CASE(7) EAGCN_AGG_CASE(8) EAGCN_AGG_CASE(9) EAGCN_AGG_CASE(10)
+#undef EAGCN_AGG_CASE
+        default: set_error("agg: unsupported CT %d", ct); return EAGCN_ERR_ARG;
+    }
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+// number of workgroups along x (= number of stat partial slabs) used for a batch
+int agg_grid_x(const eagcn_batch* b) { return std::max(1, std::min(cdiv(b->n_tiles, 4), 512)); }
+
+int launch_agg(AggArgs a, bool trans, hipStream_t s) {
+    if (a.bt.n_tiles == 0) return EAGCN_OK;
+    int tmax = 0;
+    for (int k = 0; k < a.vc.K; ++k) tmax = std::max(tmax, (a.vc.off[k + 1] - a.vc.off[k]) / 16);
+    // balanced chunking: fewest chunks of at most 10 column tiles, then the smallest CT reaching it
+    const int nchunk = cdiv(tmax, 10);
+    const int ct = cdiv(tmax, nchunk);
+    a.nchunk = nchunk;
+    dim3 grid(agg_grid_x(&a.bt), a.vc.K * nchunk);
+    return trans ? launch_agg_t<true>(a, ct, grid, s) : launch_agg_t<false>(a, ct, grid, s);
+}
+
+// ---- edge gradients ------------------------------------------------------------------------------
+// Backward of the attention build (closed form in SURVEY.md 8a):
+//   dA^[i,j]  = <dY'[i,:], P[j,:]>            needed only where U depends on a parameter
+//   rowdot_i  = sum_l dA^[i,l] A^[i,l] = <dY'[i,:], Y'[i,:]>
+//   dU[i,j]   = (m_i / rowsum_i) (dA^[i,j] - rowdot_i)
+//   d w_k[c] += dU[i,j] s (1-s)  at bonds of type c ;   d self_r_k += dU[i,i] r (1-r)
+// one wavefront per (packed row, view); results accumulated in fp64.
+__global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
+    __shared__ float sig_s[256];
+    __shared__ double h_s[256];
+    __shared__ double dr_s[4];
+    const int k = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    sig_s[tid] = a.sig[k * 256 + tid];
+    h_s[tid] = 0.0;
+    if (tid < 4) dr_s[tid] = 0.0;
+    __syncthreads();
+    const eagcn_batch& bt = a.bt;
+    const int off = a.vc.off[k], fp = a.vc.off[k + 1] - a.vc.off[k];
+    double dr_acc = 0.0;
+    for (int r = blockIdx.x * 4 + wave; r < bt.T; r += gridDim.x * 4) {
+        const float rs = a.rscale[(size_t)k * bt.T + r];
+        if (rs == 0.0f) continue;                                  // m_i == 0: no dependence
+        const int b = bt.row_mol[r], i = bt.row_loc[r];
+        const int n = bt.nat[b], r0 = bt.row0[b];
+        const float* dy = a.dY + (size_t)r * a.ld + off;
+        const float* yr = a.Y + (size_t)r * a.ld + off;
+        float rd = 0.0f;
+        for (int c = lane; c < fp; c += 64) rd += dy[c] * yr[c];
+        rd = wave_sum(rd);
+        const uint8_t* crow = bt.code + (((size_t)k * bt.B + b) * bt.N + i) * bt.ldc;
+        for (int jb = 0; jb < n; jb += 64) {
+            const int j = jb + lane;
+            const uint32_t c = (j < n) ? crow[j] : 0u;
+            unsigned long long mask = __ballot((c != 0u) || (j == i && j < n));
+            while (mask) {
+                const int src = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int jj = jb + src;
+                const uint32_t cj = __shfl(c, src);
+                const float* pr = a.P + (size_t)(r0 + jj) * a.ld + off;
+                float g = 0.0f;
+                for (int c2 = lane; c2 < fp; c2 += 64) g += dy[c2] * pr[c2];
+                g = wave_sum(g);
+                const float dU = rs * (g - rd);
+                if (lane == 0) {
+                    if (cj) {
+                        const float s = sig_s[cj];
+                        atomicAdd(&h_s[cj], (double)(dU * s * (1.0f - s)));
+                    }
+                    if (jj == i) dr_acc += (double)dU;
+                }
+            }
+        }
+    }
+    if (lane == 0) dr_s[wave] = dr_acc;
+    __syncthreads();
+    if (h_s[tid] != 0.0) atomicAdd(&a.datt[k * 256 + tid], h_s[tid]);
+    if (tid == 0) {
+        const double t = dr_s[0] + dr_s[1] + dr_s[2] + dr_s[3];
+        if (t != 0.0) atomicAdd(&a.dr[k], t);
+    }
+}
+
+int launch_edge_grad(const EdgeArgs& a, hipStream_t s) {
+    if (a.bt.T == 0) return EAGCN_OK;
+    dim3 grid(std::min(cdiv(a.bt.T, 4), 1024), a.vc.K);
+    edge_grad_kernel<<<grid, 256, 0, s>>>(a);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+}  // namespace eagcn

@@ -1,0 +1,125 @@
+// Internal helpers shared by the HIP translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/eagcn_hip.h"
+
+namespace eagcn {
+
+constexpr float TINY = 1e-9f;   // reference layers.py:294
+constexpr int WAVE = 64;
+
+void set_error(const char* fmt, ...);
+
+#define EAGCN_CHECK_ARG(cond, ...)                 \
+    do {                                           \
+        if (!(cond)) {                             \
+            ::eagcn::set_error(__VA_ARGS__);       \
+            return EAGCN_ERR_ARG;                  \
+        }                                          \
+    } while (0)
+
+#define EAGCN_HIP(call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            ::eagcn::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call,              \
+                               hipGetErrorString(e_));                                    \
+            return EAGCN_ERR_HIP;                                                         \
+        }                                                                                 \
+    } while (0)
+
+#define EAGCN_LAUNCH_CHECK() EAGCN_HIP(hipGetLastError())
+
+inline int pad16(int w) { return (w + 15) & ~15; }
+inline int pad4(int w) { return (w + 3) & ~3; }
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- device helpers ----------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+// counter-based dropout stream: one 32-bit draw per (seed, element index)
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
+    uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+    z ^= z >> 32;
+    z *= 0xD6E8FEB86659FD93ull;
+    z ^= z >> 32;
+    z *= 0xD6E8FEB86659FD93ull;
+    z ^= z >> 32;
+    return (uint32_t)z;
+}
+// keep-scale of an element: 0 (dropped) or 1/(1-p); thr = p * 2^32
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
+    return rng_u32(seed, idx) >= thr ? inv_keep : 0.0f;
+}
+
+// ---- column map of a layer's Fp-wide buffers -----------------------------------------------------
+struct ViewCols {
+    int K;
+    int off[EAGCN_MAX_VIEWS + 1];   // padded column offsets, off[K] = Fp
+    int width[EAGCN_MAX_VIEWS];     // exact widths
+};
+inline ViewCols view_cols(const eagcn_layer_params* p) {
+    ViewCols v;
+    v.K = p->K;
+    int o = 0;
+    for (int k = 0; k < p->K; ++k) {
+        v.off[k] = o;
+        v.width[k] = p->width[k];
+        o += pad16(p->width[k]);
+    }
+    for (int k = p->K; k <= EAGCN_MAX_VIEWS; ++k) v.off[k] = o;
+    for (int k = p->K; k < EAGCN_MAX_VIEWS; ++k) v.width[k] = 0;
+    return v;
+}
+inline int layout_ld(const eagcn_layout* l) {
+    int s = 0;
+    for (int i = 0; i < l->nseg; ++i) s += l->pad[i];
+    return s;
+}
+inline int layout_width(const eagcn_layout* l) {
+    int s = 0;
+    for (int i = 0; i < l->nseg; ++i) s += l->width[i];
+    return s;
+}
+
+// ---- internal launchers (defined across the .hip files) -----------------------------------------
+struct GemmDesc {
+    int ta, tb;            // 0: stored as used ([M][K] / [K][N]); 1: transposed storage
+    int M, N, K;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    int splits;            // split-K: partial z written at C + z*slab
+    size_t slab;           // floats between partial slabs
+};
+int launch_gemm(const GemmDesc& g, hipStream_t s);
+
+}  // namespace eagcn

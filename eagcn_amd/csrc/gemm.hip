@@ -1,0 +1,194 @@
+// fp32 GEMM on the CDNA4 matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate, exact f32;
+// bitwise a k-ordered fmaf chain), LDS-staged, register-prefetched, double-buffered.
+//
+// Used for the flat feature transform of the hot path -- reference layers.py:40 (`torch.mm` over
+// all B*N rows) restated over the packed rows only -- and for its two backward products
+// (dX = dP.W^T, dW = X^T.dP, the latter split-K over the rows).
+//
+// Operand storage is described by (ta, tb): ta = 0 -> A is [M][K] (K contiguous), ta = 1 -> A is
+// stored [K][M]; tb = 0 -> B is [K][N] (N contiguous), tb = 1 -> B is stored [N][K].
+// LDS images: a K-contiguous operand is kept [row][BK+1] (odd stride: the 16 rows x 2 k of a
+// 32-lane ds_read_b32 group hit 32 distinct banks); an MN-contiguous operand is kept [k][R+16]
+// (stride = 16 mod 32: lanes 0-15 and 16-31 of a group land on disjoint bank halves).
+#include <algorithm>
+
+#include "common.h"
+
+namespace eagcn {
+
+template <int BM, int BN, int BK, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
+    constexpr int WM = BM / 2, WN = BN / 2;      // 2x2 waves
+    constexpr int MR = WM / 16, NR = WN / 16;
+    constexpr int LDA_S = A_KC ? (BK + 1) : (BM + 16);
+    constexpr int LDB_S = B_KC ? (BK + 1) : (BN + 16);
+    constexpr int A_SZ = A_KC ? BM * LDA_S : BK * LDA_S;
+    constexpr int B_SZ = B_KC ? BN * LDB_S : BK * LDB_S;
+    // loader geometry
+    constexpr int A_TPR = A_KC ? BK / 4 : BM / 4;     // threads per contiguous run
+    constexpr int A_RPP = 256 / A_TPR;                 // runs per pass
+    constexpr int A_PASS = (A_KC ? BM : BK) / A_RPP;
+    constexpr int B_TPR = B_KC ? BK / 4 : BN / 4;
+    constexpr int B_RPP = 256 / B_TPR;
+    constexpr int B_PASS = (B_KC ? BN : BK) / B_RPP;
+    static_assert(A_PASS >= 1 && B_PASS >= 1, "tile too small for 256 threads");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+    auto As = [&](int buf) -> float* { return smem + buf * (A_SZ + B_SZ); };
+    auto Bs = [&](int buf) -> float* { return smem + buf * (A_SZ + B_SZ) + A_SZ; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // split-K range
+    const int z = blockIdx.z;
+    const int kchunk = ((g.K + g.splits - 1) / g.splits + BK - 1) / BK * BK;
+    const int kbeg = z * kchunk;
+    const int kend = min(g.K, kbeg + kchunk);
+    float* C = g.C + (size_t)z * g.slab;
+
+    float4 ra[A_PASS], rb[B_PASS];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < A_PASS; ++p) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (A_KC) {
+                int row = p * A_RPP + tid / A_TPR, kq = (tid % A_TPR) * 4;
+                if (m0 + row < g.M && k0 + kq < kend)
+                    v = *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + row) * g.lda + k0 + kq);
+            } else {
+                int k = p * A_RPP + tid / A_TPR, mq = (tid % A_TPR) * 4;
+                if (k0 + k < kend && m0 + mq < g.M)
+                    v = *reinterpret_cast<const float4*>(g.A + (size_t)(k0 + k) * g.lda + m0 + mq);
+            }
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < B_PASS; ++p) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (B_KC) {
+                int row = p * B_RPP + tid / B_TPR, kq = (tid % B_TPR) * 4;
+                if (n0 + row < g.N && k0 + kq < kend)
+                    v = *reinterpret_cast<const float4*>(g.B + (size_t)(n0 + row) * g.ldb + k0 + kq);
+            } else {
+                int k = p * B_RPP + tid / B_TPR, nq = (tid % B_TPR) * 4;
+                if (k0 + k < kend && n0 + nq < g.N)
+                    v = *reinterpret_cast<const float4*>(g.B + (size_t)(k0 + k) * g.ldb + n0 + nq);
+            }
+            rb[p] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < A_PASS; ++p) {
+            if constexpr (A_KC) {
+                int row = p * A_RPP + tid / A_TPR, kq = (tid % A_TPR) * 4;
+                float* d = As(buf) + row * LDA_S + kq;
+                d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
+            } else {
+                int k = p * A_RPP + tid / A_TPR, mq = (tid % A_TPR) * 4;
+                *reinterpret_cast<float4*>(As(buf) + k * LDA_S + mq) = ra[p];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < B_PASS; ++p) {
+            if constexpr (B_KC) {
+                int row = p * B_RPP + tid / B_TPR, kq = (tid % B_TPR) * 4;
+                float* d = Bs(buf) + row * LDB_S + kq;
+                d[0] = rb[p].x; d[1] = rb[p].y; d[2] = rb[p].z; d[3] = rb[p].w;
+            } else {
+                int k = p * B_RPP + tid / B_TPR, nq = (tid % B_TPR) * 4;
+                *reinterpret_cast<float4*>(Bs(buf) + k * LDB_S + nq) = rb[p];
+            }
+        }
+    };
+
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+    if (nk > 0) {
+        load_tiles(kbeg);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
+        const float* a_s = As(cur);
+        const float* b_s = Bs(cur);
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            float af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                if constexpr (A_KC) af[i] = a_s[(wm + i * 16 + li) * LDA_S + ks * 4 + q];
+                else af[i] = a_s[(ks * 4 + q) * LDA_S + wm + i * 16 + li];
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                if constexpr (B_KC) bf[j] = b_s[(wn + j * 16 + li) * LDB_S + ks * 4 + q];
+                else bf[j] = b_s[(ks * 4 + q) * LDB_S + wn + j * 16 + li];
+            }
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+    // epilogue: D layout col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + wn + j * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm + i * 16 + q * 4 + r;
+                if (row < g.M && col < g.N) C[(size_t)row * g.ldc + col] = acc[i][j][r];
+            }
+        }
+}
+
+template <int BM, int BN, int BK>
+static int launch_cfg(const GemmDesc& g, hipStream_t s) {
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.splits);
+    if (g.ta == 0 && g.tb == 0) gemm_f32_kernel<BM, BN, BK, true, false><<<grid, 256, 0, s>>>(g);
+    else if (g.ta == 0 && g.tb == 1) gemm_f32_kernel<BM, BN, BK, true, true><<<grid, 256, 0, s>>>(g);
+    else if (g.ta == 1 && g.tb == 0) gemm_f32_kernel<BM, BN, BK, false, false><<<grid, 256, 0, s>>>(g);
+    else gemm_f32_kernel<BM, BN, BK, false, true><<<grid, 256, 0, s>>>(g);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+int launch_gemm(const GemmDesc& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return EAGCN_OK;
+    EAGCN_CHECK_ARG(g.splits >= 1, "gemm: splits must be >= 1");
+    // contiguous dimensions are loaded as float4
+    EAGCN_CHECK_ARG((g.lda % 4) == 0 && (g.ldb % 4) == 0, "gemm: lda/ldb must be multiples of 4");
+    EAGCN_CHECK_ARG(((g.ta ? g.M : g.K) % 4) == 0, "gemm: contiguous extent of A must be a multiple of 4");
+    EAGCN_CHECK_ARG(((g.tb ? g.K : g.N) % 4) == 0, "gemm: contiguous extent of B must be a multiple of 4");
+    EAGCN_CHECK_ARG((reinterpret_cast<uintptr_t>(g.A) % 16) == 0 && (reinterpret_cast<uintptr_t>(g.B) % 16) == 0,
+                    "gemm: operands must be 16-byte aligned");
+    const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.splits;
+    if (tiles128 >= 384) return launch_cfg<128, 128, 16>(g, s);
+    return launch_cfg<64, 64, 16>(g, s);
+}
+
+}  // namespace eagcn
+
+using namespace eagcn;
+
+extern "C" int eagcn_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
+                              int ldb, float* C, int ldc, void* stream) {
+    EAGCN_CHECK_ARG(A && B && C, "eagcn_gemm_f32: null operand");
+    GemmDesc g{ta, tb, M, N, K, A, lda, B, ldb, C, ldc, 1, 0};
+    return launch_gemm(g, (hipStream_t)stream);
+}

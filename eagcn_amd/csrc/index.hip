@@ -1,0 +1,258 @@
+// Batch index: turns the reference's dense collate tensors (utils.py:575-640) into the compact
+// structures every other kernel consumes.
+//
+// What the reference does with these inputs, per layer and per view (layers.py:82-83, 294-304):
+//   S = conv1x1(R_k) -> sigmoid -> * adj ;  mask = adj.max(dim=2) ; identity = mask * I
+// A1 = sigmoid(S) * adj is zero wherever adj is zero, so R_k only matters at bonded (i,j): this
+// kernel streams adj once (coalesced, HBM-bound, 4*N*N bytes per molecule) and gathers the C_k
+// channel values only at the non-zeros of adj, producing one uint8 bond-type code per (i,j,view).
+// With one-hot channels (neural_fp.py:111-120) the 1x1 conv is exactly a dictionary lookup
+// sigma(w_k[type]); the gather validates one-hotness and reports violations in meta[] so the host
+// side can fail loudly instead of computing something else.
+#include <algorithm>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace eagcn {
+
+struct RelPtrs {
+    const float* p[EAGCN_MAX_VIEWS];
+    int c[EAGCN_MAX_VIEWS];
+};
+
+// one workgroup per molecule, one wave per row (4 rows in flight)
+__global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict__ adj, RelPtrs rel,
+                                                          int B, int N, int K, int ldc,
+                                                          uint8_t* __restrict__ code,
+                                                          int32_t* __restrict__ deg_bn,
+                                                          int32_t* __restrict__ nat,
+                                                          int32_t* __restrict__ meta) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* adjb = adj + (size_t)b * N * N;
+    const size_t plane = (size_t)N * N;
+    __shared__ int s_last[4];
+    __shared__ int s_edges[4];
+    int last = -1, bad_adj = 0, bad_rel = 0, edges = 0;
+    for (int i = wave; i < N; i += 4) {
+        int deg = 0;
+        for (int j = lane; j < ldc; j += 64) {
+            float a = (j < N) ? adjb[(size_t)i * N + j] : 0.0f;
+            const bool bond = (a != 0.0f);
+            if (bond && a != 1.0f) ++bad_adj;
+            deg += bond ? 1 : 0;
+            for (int k = 0; k < K; ++k) {
+                int c = 0;
+                if (bond) {
+                    const float* r = rel.p[k] + (size_t)b * rel.c[k] * plane + (size_t)i * N + j;
+                    int ones = 0, other = 0, hot = 0;
+                    for (int ch = 0; ch < rel.c[k]; ++ch) {
+                        float v = r[(size_t)ch * plane];
+                        if (v == 1.0f) { ++ones; hot = ch; }
+                        else if (v != 0.0f) ++other;
+                    }
+                    if (ones != 1 || other != 0) ++bad_rel;
+                    c = hot + 1;
+                }
+                code[(((size_t)k * B + b) * N + i) * ldc + j] = (uint8_t)c;
+            }
+        }
+        deg = wave_sum(deg);
+        if (lane == 0) deg_bn[(size_t)b * N + i] = deg;
+        if (deg > 0) last = i;
+        edges += deg;
+    }
+    bad_adj = wave_sum(bad_adj);
+    bad_rel = wave_sum(bad_rel);
+    if (lane == 0) {
+        s_last[wave] = last;
+        s_edges[wave] = edges;
+        if (bad_adj) atomicAdd(&meta[EAGCN_META_BAD_ADJ], bad_adj);
+        if (bad_rel) atomicAdd(&meta[EAGCN_META_BAD_REL], bad_rel);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int l = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+        nat[b] = l + 1;
+        atomicAdd(&meta[EAGCN_META_NEDGE], s_edges[0] + s_edges[1] + s_edges[2] + s_edges[3]);
+    }
+}
+
+// single workgroup: exclusive prefix sums of nat[] and ceil(nat/16) -> row0, tile0, totals
+__global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __restrict__ nat, int B,
+                                                              int32_t* __restrict__ row0,
+                                                              int32_t* __restrict__ tile0,
+                                                              int32_t* __restrict__ meta) {
+    __shared__ int s_rows[1024], s_tiles[1024];
+    __shared__ int carry_r, carry_t, s_max;
+    const int t = threadIdx.x;
+    if (t == 0) { carry_r = 0; carry_t = 0; s_max = 0; }
+    __syncthreads();
+    int nmax = 0;
+    for (int base = 0; base < B; base += 1024) {
+        int idx = base + t;
+        int n = idx < B ? nat[idx] : 0;
+        nmax = max(nmax, n);
+        s_rows[t] = n;
+        s_tiles[t] = (n + 15) >> 4;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
+            int vr = t >= o ? s_rows[t - o] : 0;
+            int vt = t >= o ? s_tiles[t - o] : 0;
+            __syncthreads();
+            s_rows[t] += vr;
+            s_tiles[t] += vt;
+            __syncthreads();
+        }
+        if (idx < B) {
+            row0[idx] = carry_r + s_rows[t] - n;
+            tile0[idx] = carry_t + s_tiles[t] - ((n + 15) >> 4);
+        }
+        __syncthreads();
+        if (t == 1023) { carry_r += s_rows[t]; carry_t += s_tiles[t]; }
+        __syncthreads();
+    }
+    atomicMax(&s_max, nmax);
+    __syncthreads();
+    if (t == 0) {
+        row0[B] = carry_r;
+        tile0[B] = carry_t;
+        meta[EAGCN_META_T] = carry_r;
+        meta[EAGCN_META_NTILES] = carry_t;
+        meta[EAGCN_META_NMAX] = s_max;
+    }
+}
+
+__global__ __launch_bounds__(256) void index_rows_kernel(eagcn_batch bt) {
+    const int b = blockIdx.x;
+    const int n = bt.nat[b], r0 = bt.row0[b], t0 = bt.tile0[b];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int d = bt.deg_bn[(size_t)b * bt.N + i];
+        bt.row_mol[r0 + i] = b;
+        bt.row_loc[r0 + i] = i;
+        bt.row_deg[r0 + i] = d;
+        bt.row_m[r0 + i] = d > 0 ? 1.0f : 0.0f;
+    }
+    for (int t = threadIdx.x; t < (n + 15) / 16; t += blockDim.x) bt.tile_mol[t0 + t] = b;
+}
+
+// dense [B][N][F] -> packed [T][ld]; columns are re-grouped into the padded segments of `lay`
+typedef ColMapD ColMap;
+__device__ __forceinline__ int packed_to_exact(const ColMap& m, int cp) {
+    int eo = 0, po = 0;
+    for (int s = 0; s < m.nseg; ++s) {
+        if (cp < po + m.p[s]) return (cp - po < m.w[s]) ? eo + (cp - po) : -1;
+        eo += m.w[s];
+        po += m.p[s];
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void pack_rows_kernel(eagcn_batch bt, const float* __restrict__ dense,
+                                                         int F, ColMap m, int ld, float* __restrict__ packed) {
+    const size_t total = (size_t)bt.T * ld;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        int r = (int)(e / ld), cp = (int)(e % ld);
+        int ce = packed_to_exact(m, cp);
+        float v = 0.0f;
+        if (ce >= 0) v = dense[((size_t)bt.row_mol[r] * bt.N + bt.row_loc[r]) * F + ce];
+        packed[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_rows_kernel(eagcn_batch bt, const float* __restrict__ packed,
+                                                           ColMap m, int ld, const float* __restrict__ pad_row,
+                                                           float* __restrict__ dense, int F) {
+    // one thread per dense element; exact column -> packed column
+    const size_t total = (size_t)bt.B * bt.N * F;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        int ce = (int)(e % F);
+        size_t bi = e / F;
+        int i = (int)(bi % bt.N), b = (int)(bi / bt.N);
+        int eo = 0, po = 0, cp = -1;
+        for (int s = 0; s < m.nseg; ++s) {
+            if (ce < eo + m.w[s]) { cp = po + (ce - eo); break; }
+            eo += m.w[s];
+            po += m.p[s];
+        }
+        float v;
+        if (i < bt.nat[b]) v = packed[(size_t)(bt.row0[b] + i) * ld + cp];
+        else v = pad_row ? pad_row[cp] : 0.0f;
+        dense[e] = v;
+    }
+}
+
+}  // namespace eagcn
+
+using namespace eagcn;
+
+extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagcn_batch* b,
+                                 int32_t* host_meta, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    EAGCN_CHECK_ARG(adj && rel && b && host_meta, "eagcn_index_build: null argument");
+    EAGCN_CHECK_ARG(b->B > 0 && b->N > 0, "eagcn_index_build: B and N must be positive");
+    EAGCN_CHECK_ARG(b->K >= 1 && b->K <= EAGCN_MAX_VIEWS, "eagcn_index_build: K=%d out of range", b->K);
+    EAGCN_CHECK_ARG(b->ldc >= b->N && (b->ldc % 16) == 0, "eagcn_index_build: ldc must be a multiple of 16 >= N");
+    EAGCN_CHECK_ARG(b->code && b->deg_bn && b->nat && b->row0 && b->tile0 && b->meta,
+                    "eagcn_index_build: index buffers not allocated");
+    RelPtrs rp;
+    for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) {
+        rp.p[k] = k < b->K ? rel[k] : nullptr;
+        rp.c[k] = k < b->K ? b->channels[k] : 0;
+        if (k < b->K) {
+            EAGCN_CHECK_ARG(rel[k] != nullptr, "eagcn_index_build: relation tensor %d is null", k);
+            EAGCN_CHECK_ARG(rp.c[k] >= 1 && rp.c[k] <= EAGCN_MAX_CHANNELS,
+                            "eagcn_index_build: view %d has %d channels (1..%d supported)", k, rp.c[k],
+                            EAGCN_MAX_CHANNELS);
+        }
+    }
+    EAGCN_HIP(hipMemsetAsync(b->meta, 0, EAGCN_META_WORDS * sizeof(int32_t), s));
+    index_scan_kernel<<<b->B, 256, 0, s>>>(adj, rp, b->B, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->meta);
+    EAGCN_LAUNCH_CHECK();
+    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->row0, b->tile0, b->meta);
+    EAGCN_LAUNCH_CHECK();
+    EAGCN_HIP(hipMemcpyAsync(host_meta, b->meta, EAGCN_META_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_index_rows(const eagcn_batch* b, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    EAGCN_CHECK_ARG(b, "eagcn_index_rows: null batch");
+    if (b->T == 0) return EAGCN_OK;
+    EAGCN_CHECK_ARG(b->row_mol && b->row_loc && b->row_m && b->row_deg && b->tile_mol,
+                    "eagcn_index_rows: per-row buffers not allocated");
+    index_rows_kernel<<<b->B, 256, 0, s>>>(*b);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_pack_rows(const eagcn_batch* b, const float* dense, int F, const eagcn_layout* lay,
+                               float* packed, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    EAGCN_CHECK_ARG(b && dense && lay && packed, "eagcn_pack_rows: null argument");
+    EAGCN_CHECK_ARG(layout_width(lay) == F, "eagcn_pack_rows: layout width %d != F %d", layout_width(lay), F);
+    if (b->T == 0) return EAGCN_OK;
+    int ld = layout_ld(lay);
+    size_t total = (size_t)b->T * ld;
+    int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+    pack_rows_kernel<<<grid, 256, 0, s>>>(*b, dense, F, make_colmap(lay), ld, packed);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_unpack_rows(const eagcn_batch* b, const float* packed, const eagcn_layout* lay,
+                                 const float* pad_row, float* dense, int F, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    EAGCN_CHECK_ARG(b && lay && dense, "eagcn_unpack_rows: null argument");
+    EAGCN_CHECK_ARG(b->T == 0 || packed, "eagcn_unpack_rows: null packed matrix");
+    EAGCN_CHECK_ARG(layout_width(lay) == F, "eagcn_unpack_rows: layout width %d != F %d", layout_width(lay), F);
+    int ld = layout_ld(lay);
+    size_t total = (size_t)b->B * b->N * F;
+    int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+    unpack_rows_kernel<<<grid, 256, 0, s>>>(*b, packed, make_colmap(lay), ld, pad_row, dense, F);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}

@@ -1,0 +1,45 @@
+// Argument blocks and launchers shared between the HIP translation units.
+#pragma once
+#include "common.h"
+
+namespace eagcn {
+
+struct AggArgs {
+    eagcn_batch bt;
+    ViewCols vc;
+    const float* src; int lds;   // P (forward) or dY' (transposed) [T][lds]
+    float* dst; int ldd;         // Y' (forward) or dP (transposed)
+    const float* sig;            // [K][256] sigmoid(att weight) by bond code, entry 0 = 0
+    const float* rsig;           // [K] sigmoid(self_r)
+    float* rscale;               // [K][T] m_i/rowsum_i: written by forward, read by transposed
+    double* stats;               // forward: [grid.x][Fp][2] partial (sum y, sum y^2)
+    int nchunk;
+};
+int agg_grid_x(const eagcn_batch* b);
+int launch_agg(AggArgs a, bool trans, hipStream_t s);
+
+struct EdgeArgs {
+    eagcn_batch bt;
+    ViewCols vc;
+    const float* dY; const float* Y; const float* P; int ld;
+    const float* sig; const float* rsig; const float* rscale;
+    double* datt;                // [K][256] accumulated d/d(att weight) by code
+    double* dr;                  // [K] accumulated dU_ii sums
+};
+int launch_edge_grad(const EdgeArgs& a, hipStream_t s);
+
+struct ColMapD {                 // exact <-> packed column map of a layout
+    int nseg;
+    int w[EAGCN_MAX_SEGS], p[EAGCN_MAX_SEGS];
+};
+inline ColMapD make_colmap(const eagcn_layout* l) {
+    ColMapD m;
+    m.nseg = l->nseg;
+    for (int i = 0; i < EAGCN_MAX_SEGS; ++i) {
+        m.w[i] = i < l->nseg ? l->width[i] : 0;
+        m.p[i] = i < l->nseg ? l->pad[i] : 0;
+    }
+    return m;
+}
+
+}  // namespace eagcn

@@ -1,0 +1,617 @@
+// One multi-view graph-conv layer, forward and backward: parameter packing, the per-view
+// BatchNorm over all B*N_pad rows (reference layers.py:408-412) with its grid-wide reduction, the
+// relu / dropout / mask / view-merge epilogue (layers.py:93-94, 313-316), and the orchestration of
+// the GEMM and aggregation kernels behind the C ABI.
+//
+// BatchNorm over rows that are not stored: the reference normalises over every row of the padded
+// [B,N,F] tensor.  A padded (or bond-less) row has an all-zero attention row, so its pre-BN value
+// is exactly the bias.  Working with y' = y - bias (the GEMM output without bias) those rows are
+// exactly 0: they add nothing to sum(y') and sum(y'^2) and only enter through the row count
+// M = B*N.  The bias cancels inside a training-mode BatchNorm; it re-enters in the running mean
+// and in eval mode.
+#include <algorithm>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace eagcn {
+
+struct ParamPtrs {
+    const float* att_w[EAGCN_MAX_VIEWS];
+    const float* self_r[EAGCN_MAX_VIEWS];
+    const float* W[EAGCN_MAX_VIEWS];
+    const float* bias[EAGCN_MAX_VIEWS];
+    const float* gamma[EAGCN_MAX_VIEWS];
+    const float* beta[EAGCN_MAX_VIEWS];
+    float* run_mean[EAGCN_MAX_VIEWS];
+    float* run_var[EAGCN_MAX_VIEWS];
+    const float* ave_w;
+    int channels[EAGCN_MAX_VIEWS];
+};
+struct GradPtrs {
+    float* dW[EAGCN_MAX_VIEWS];
+    float* dbias[EAGCN_MAX_VIEWS];
+    float* dgamma[EAGCN_MAX_VIEWS];
+    float* dbeta[EAGCN_MAX_VIEWS];
+    float* datt_w[EAGCN_MAX_VIEWS];
+    float* dself_r[EAGCN_MAX_VIEWS];
+    float* dave_w;
+};
+
+// colp rows
+enum { CP_GAMMA = 0, CP_BETA, CP_BIAS, CP_RMEAN, CP_RVAR, CP_AVEW, CP_ROWS = 8 };
+// bn rows
+enum { BN_SC = 0, BN_SH, BN_MU, BN_INV };
+
+__device__ __forceinline__ int col_view(const ViewCols& vc, int cp) {
+    int k = 0;
+#pragma unroll
+    for (int v = 1; v < EAGCN_MAX_VIEWS; ++v) k += (v < vc.K && cp >= vc.off[v]) ? 1 : 0;
+    return k;
+}
+__device__ __forceinline__ int packed_to_exact(const ColMapD& m, int cp) {
+    int eo = 0, po = 0;
+    for (int s = 0; s < m.nseg; ++s) {
+        if (cp < po + m.p[s]) return (cp - po < m.w[s]) ? eo + (cp - po) : -1;
+        eo += m.w[s];
+        po += m.p[s];
+    }
+    return -1;
+}
+
+// ---- parameter packing -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_params_kernel(ParamPtrs pp, ViewCols vc, ColMapD in, int ld_in,
+                                                           int fp, float* __restrict__ Wcat,
+                                                           float* __restrict__ colp, float* __restrict__ sig,
+                                                           float* __restrict__ rsig) {
+    const int total = ld_in * fp;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int ip = e / fp, cp = e % fp;
+        const int k = col_view(vc, cp), f = cp - vc.off[k];
+        const int fi = packed_to_exact(in, ip);
+        float v = 0.0f;
+        if (fi >= 0 && f < vc.width[k]) v = pp.W[k][(size_t)fi * vc.width[k] + f];
+        Wcat[e] = v;
+    }
+    for (int cp = blockIdx.x * blockDim.x + threadIdx.x; cp < fp; cp += gridDim.x * blockDim.x) {
+        const int k = col_view(vc, cp), f = cp - vc.off[k];
+        const bool ok = f < vc.width[k];
+        colp[CP_GAMMA * fp + cp] = ok ? pp.gamma[k][f] : 0.0f;
+        colp[CP_BETA * fp + cp] = ok ? pp.beta[k][f] : 0.0f;
+        colp[CP_BIAS * fp + cp] = ok ? pp.bias[k][f] : 0.0f;
+        colp[CP_RMEAN * fp + cp] = ok ? pp.run_mean[k][f] : 0.0f;
+        colp[CP_RVAR * fp + cp] = ok ? pp.run_var[k][f] : 1.0f;
+        colp[CP_AVEW * fp + cp] = pp.ave_w ? pp.ave_w[k] : 1.0f;
+    }
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < vc.K * 256; e += gridDim.x * blockDim.x) {
+        const int k = e >> 8, c = e & 255;
+        sig[e] = (c >= 1 && c <= pp.channels[k]) ? sigmoidf_(pp.att_w[k][c - 1]) : 0.0f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < vc.K) rsig[threadIdx.x] = sigmoidf_(pp.self_r[threadIdx.x][0]);
+}
+
+// ---- BatchNorm forward ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ slab, int nslab, int fp,
+                                                           double M, int training, float eps, float momentum,
+                                                           const float* __restrict__ colp, ParamPtrs pp,
+                                                           ViewCols vc, float* __restrict__ bn) {
+    const int cp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cp >= fp) return;
+    const int k = col_view(vc, cp), f = cp - vc.off[k];
+    const float gamma = colp[CP_GAMMA * fp + cp], beta = colp[CP_BETA * fp + cp];
+    const float bias = colp[CP_BIAS * fp + cp];
+    float mu, inv;
+    if (training) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int s = 0; s < nslab; ++s) {
+            s1 += slab[((size_t)s * fp + cp) * 2 + 0];
+            s2 += slab[((size_t)s * fp + cp) * 2 + 1];
+        }
+        const double mean = s1 / M;
+        double var = s2 / M - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        mu = (float)mean;
+        inv = (float)(1.0 / sqrt(var + (double)eps));
+        if (f < vc.width[k]) {
+            const double unbiased = var * (M / (M - 1.0));
+            pp.run_mean[k][f] = (float)((1.0 - momentum) * (double)colp[CP_RMEAN * fp + cp] + momentum * (mean + (double)bias));
+            pp.run_var[k][f] = (float)((1.0 - momentum) * (double)colp[CP_RVAR * fp + cp] + momentum * unbiased);
+        }
+    } else {
+        mu = colp[CP_RMEAN * fp + cp] - bias;
+        inv = 1.0f / sqrtf(colp[CP_RVAR * fp + cp] + eps);
+    }
+    const float sc = gamma * inv;
+    bn[BN_SC * fp + cp] = sc;
+    bn[BN_SH * fp + cp] = beta - mu * sc;
+    bn[BN_MU * fp + cp] = mu;
+    bn[BN_INV * fp + cp] = inv;
+}
+
+struct ApplyArgs {
+    eagcn_batch bt;
+    ViewCols vc;
+    int structure, fp;
+    const float* Y; int ldy;
+    const float* bn;
+    const float* colp;
+    float* out; int ldo;
+    float* pad_row;
+    int do_drop; uint32_t thr; float inv_keep; uint64_t seed;
+};
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
+    const int fp = a.fp;
+    if (blockIdx.x == 0) {   // value of the rows that are not stored
+        for (int c = threadIdx.x; c < a.ldo; c += blockDim.x) {
+            float v = 0.0f;
+            if (a.structure == EAGCN_STRUCT_WEIGHTED)
+                for (int k = 0; k < a.vc.K; ++k) {
+                    const int cp = a.vc.off[k] + c;
+                    v += a.colp[CP_AVEW * fp + cp] * fmaxf(a.bn[BN_SH * fp + cp], 0.0f);
+                }
+            a.pad_row[c] = v;
+        }
+    }
+    const int T = a.bt.T;
+    if (a.structure == EAGCN_STRUCT_CONCATE) {
+        const int g4 = fp / 4;
+        const size_t total = (size_t)T * g4;
+        for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+            const int r = (int)(e / g4), c = (int)(e % g4) * 4;
+            const float4 y = *reinterpret_cast<const float4*>(a.Y + (size_t)r * a.ldy + c);
+            const float4 sc = *reinterpret_cast<const float4*>(a.bn + BN_SC * fp + c);
+            const float4 sh = *reinterpret_cast<const float4*>(a.bn + BN_SH * fp + c);
+            const float m = a.bt.row_m[r];
+            float4 o;
+            o.x = fmaxf(y.x * sc.x + sh.x, 0.0f) * m;
+            o.y = fmaxf(y.y * sc.y + sh.y, 0.0f) * m;
+            o.z = fmaxf(y.z * sc.z + sh.z, 0.0f) * m;
+            o.w = fmaxf(y.w * sc.w + sh.w, 0.0f) * m;
+            if (a.do_drop) {
+                const uint64_t idx = (uint64_t)r * fp + c;
+                o.x *= drop_scale(a.seed, idx + 0, a.thr, a.inv_keep);
+                o.y *= drop_scale(a.seed, idx + 1, a.thr, a.inv_keep);
+                o.z *= drop_scale(a.seed, idx + 2, a.thr, a.inv_keep);
+                o.w *= drop_scale(a.seed, idx + 3, a.thr, a.inv_keep);
+            }
+            *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + c) = o;
+        }
+    } else {
+        const size_t total = (size_t)T * a.ldo;
+        for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+            const int r = (int)(e / a.ldo), f = (int)(e % a.ldo);
+            float acc = 0.0f;
+            for (int k = 0; k < a.vc.K; ++k) {
+                const int cp = a.vc.off[k] + f;
+                float p = fmaxf(a.Y[(size_t)r * a.ldy + cp] * a.bn[BN_SC * fp + cp] + a.bn[BN_SH * fp + cp], 0.0f);
+                if (a.do_drop) p *= drop_scale(a.seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
+                acc += a.colp[CP_AVEW * fp + cp] * p;
+            }
+            a.out[e] = acc;
+        }
+    }
+}
+
+// ---- BatchNorm backward ----------------------------------------------------------------------------
+struct BwdArgs {
+    eagcn_batch bt;
+    ViewCols vc;
+    int structure, fp, nvirt;
+    const float* dxout; int ldo;
+    const float* dpad;           // [ldo] gradient of the common non-stored row, or null
+    const float* Y; int ldy;
+    const float* bn;
+    const float* colp;
+    float* dH;                   // [T][fp]
+    double* slab;                // [grid][fp][2]
+    double* slab_da;             // [grid][MAX_VIEWS]
+    int do_drop; uint32_t thr; float inv_keep; uint64_t seed;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
+    __shared__ double da_s[EAGCN_MAX_VIEWS];
+    const int fp = a.fp, T = a.bt.T;
+    if (threadIdx.x < EAGCN_MAX_VIEWS) da_s[threadIdx.x] = 0.0;
+    __syncthreads();
+    const bool weighted = a.structure == EAGCN_STRUCT_WEIGHTED;
+    double da[EAGCN_MAX_VIEWS];
+#pragma unroll
+    for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) da[k] = 0.0;
+    for (int cp = threadIdx.x; cp < fp; cp += blockDim.x) {
+        const int k = col_view(a.vc, cp), f = cp - a.vc.off[k];
+        const float sc = a.bn[BN_SC * fp + cp], sh = a.bn[BN_SH * fp + cp];
+        const float mu = a.bn[BN_MU * fp + cp], inv = a.bn[BN_INV * fp + cp];
+        const float aw = a.colp[CP_AVEW * fp + cp];
+        const int cu = weighted ? f : cp;           // column of the upstream gradient
+        double s1 = 0.0, s2 = 0.0, dak = 0.0;
+        for (int r = blockIdx.x; r < T + a.nvirt; r += gridDim.x) {
+            float y, up, ds = 1.0f;
+            if (r < T) {
+                y = a.Y[(size_t)r * a.ldy + cp];
+                up = a.dxout[(size_t)r * a.ldo + cu];
+                if (!weighted) up *= a.bt.row_m[r];
+                if (a.do_drop) ds = drop_scale(a.seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
+            } else {                                  // all non-stored rows share one value: one virtual row
+                y = 0.0f;
+                up = a.dpad[(size_t)(r - T) * a.ldo + cu];
+            }
+            const float h = y * sc + sh;
+            if (weighted) { dak += (double)(up * ds * fmaxf(h, 0.0f)); up *= aw; }
+            const float dh = h > 0.0f ? up * ds : 0.0f;
+            const float xh = (y - mu) * inv;
+            s1 += (double)dh;
+            s2 += (double)(dh * xh);
+            if (r < T) a.dH[(size_t)r * fp + cp] = dh;
+        }
+        a.slab[((size_t)blockIdx.x * fp + cp) * 2 + 0] = s1;
+        a.slab[((size_t)blockIdx.x * fp + cp) * 2 + 1] = s2;
+        if (weighted) {
+#pragma unroll
+            for (int v = 0; v < EAGCN_MAX_VIEWS; ++v) da[v] += (v == k) ? dak : 0.0;
+        }
+    }
+    if (weighted) {
+#pragma unroll
+        for (int v = 0; v < EAGCN_MAX_VIEWS; ++v) {
+            const double t = wave_sum(da[v]);
+            if ((threadIdx.x & 63) == 0 && t != 0.0) atomicAdd(&da_s[v], t);
+        }
+        __syncthreads();
+        if (threadIdx.x < EAGCN_MAX_VIEWS) a.slab_da[(size_t)blockIdx.x * EAGCN_MAX_VIEWS + threadIdx.x] = da_s[threadIdx.x];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ slab,
+                                                               const double* __restrict__ slab_da, int nslab,
+                                                               int fp, double M, int training,
+                                                               const float* __restrict__ bn, ViewCols vc,
+                                                               GradPtrs gp, float* __restrict__ cc) {
+    const int cp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < vc.K && gp.dave_w) {
+        double t = 0.0;
+        for (int s = 0; s < nslab; ++s) t += slab_da[(size_t)s * EAGCN_MAX_VIEWS + threadIdx.x];
+        gp.dave_w[threadIdx.x] = (float)t;
+    }
+    if (cp >= fp) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < nslab; ++s) {
+        s1 += slab[((size_t)s * fp + cp) * 2 + 0];
+        s2 += slab[((size_t)s * fp + cp) * 2 + 1];
+    }
+    cc[cp] = training ? (float)(s1 / M) : 0.0f;
+    cc[fp + cp] = training ? (float)(s2 / M) : 0.0f;
+    const int k = col_view(vc, cp), f = cp - vc.off[k];
+    if (f < vc.width[k]) {
+        gp.dgamma[k][f] = (float)s2;
+        gp.dbeta[k][f] = (float)s1;
+        // training: sum over ALL B*N rows of dY is identically zero (mean removal); eval: sc * sum(dH)
+        gp.dbias[k][f] = training ? 0.0f : (float)((double)bn[BN_SC * fp + cp] * s1);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int T, int fp, const float* __restrict__ Y, int ldy,
+                                                            const float* __restrict__ bn,
+                                                            const float* __restrict__ cc, float* __restrict__ dH) {
+    const int g4 = fp / 4;
+    const size_t total = (size_t)T * g4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / g4), c = (int)(e % g4) * 4;
+        const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)r * ldy + c);
+        float4 d = *reinterpret_cast<float4*>(dH + (size_t)r * fp + c);
+        const float4 sc = *reinterpret_cast<const float4*>(bn + BN_SC * fp + c);
+        const float4 mu = *reinterpret_cast<const float4*>(bn + BN_MU * fp + c);
+        const float4 iv = *reinterpret_cast<const float4*>(bn + BN_INV * fp + c);
+        const float4 c1 = *reinterpret_cast<const float4*>(cc + c);
+        const float4 c2 = *reinterpret_cast<const float4*>(cc + fp + c);
+        d.x = sc.x * (d.x - c1.x - (y.x - mu.x) * iv.x * c2.x);
+        d.y = sc.y * (d.y - c1.y - (y.y - mu.y) * iv.y * c2.y);
+        d.z = sc.z * (d.z - c1.z - (y.z - mu.z) * iv.z * c2.z);
+        d.w = sc.w * (d.w - c1.w - (y.w - mu.w) * iv.w * c2.w);
+        *reinterpret_cast<float4*>(dH + (size_t)r * fp + c) = d;
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtrs pp, ViewCols vc, ColMapD in,
+                                                            int ld_in, int fp, const float* __restrict__ dWcat,
+                                                            int nsplit, size_t slab, const double* __restrict__ datt,
+                                                            const double* __restrict__ dr,
+                                                            const float* __restrict__ rsig) {
+    const int total = ld_in * fp;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int ip = e / fp, cp = e % fp;
+        const int k = col_view(vc, cp), f = cp - vc.off[k];
+        const int fi = packed_to_exact(in, ip);
+        if (fi < 0 || f >= vc.width[k]) continue;
+        float s = 0.0f;
+        for (int z = 0; z < nsplit; ++z) s += dWcat[(size_t)z * slab + e];
+        gp.dW[k][(size_t)fi * vc.width[k] + f] = s;
+    }
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < vc.K * 256; e += gridDim.x * blockDim.x) {
+        const int k = e >> 8, c = e & 255;
+        if (c >= 1 && c <= pp.channels[k]) gp.datt_w[k][c - 1] = (float)datt[e];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < vc.K) {
+        const double r = (double)rsig[threadIdx.x];
+        gp.dself_r[threadIdx.x][0] = (float)(dr[threadIdx.x] * r * (1.0 - r));
+    }
+}
+
+// A1_k[b,i,j] = sigmoid(w_k[type]) * adj  -- the A_weight return value of layers.py:318 (stack of the
+// per-view A1 of layers.py:83), materialised only when a caller asks for it.
+__global__ __launch_bounds__(256) void attention_dense_kernel(eagcn_batch bt, ParamPtrs pp, float* __restrict__ out) {
+    const size_t total = (size_t)bt.K * bt.B * bt.N * bt.N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e % bt.N);
+        const size_t kbi = e / bt.N;                 // (k*B + b)*N + i
+        const int k = (int)(kbi / ((size_t)bt.B * bt.N));
+        const uint32_t c = bt.code[kbi * bt.ldc + j];
+        out[e] = (c >= 1 && (int)c <= pp.channels[k]) ? sigmoidf_(pp.att_w[k][c - 1]) : 0.0f;
+    }
+}
+
+// ---- scratch carving -------------------------------------------------------------------------------
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base((char*)p) {}
+    template <typename T>
+    T* take(size_t n) {
+        T* p = base ? (T*)(base + off) : nullptr;
+        off = align256(off + n * sizeof(T));
+        return p;
+    }
+};
+
+struct LayerDims {
+    ViewCols vc;
+    int fp, ld_in, fin, ldo, gx, gxb, nsplit;
+    size_t wslab;
+};
+static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
+    LayerDims d;
+    d.vc = view_cols(p);
+    d.fp = d.vc.off[p->K];
+    d.ld_in = layout_ld(&p->in);
+    d.fin = layout_width(&p->in);
+    d.ldo = p->structure == EAGCN_STRUCT_CONCATE ? d.fp : pad16(p->width[0]);
+    d.gx = agg_grid_x(b);
+    d.gxb = std::max(1, std::min(b->T + 1, 512));
+    const int tiles = cdiv(d.ld_in, 64) * cdiv(d.fp, 64);
+    d.nsplit = std::max(1, std::min(std::max(1, 1024 / tiles), cdiv(std::max(b->T, 1), 128)));
+    d.wslab = (size_t)d.ld_in * d.fp;
+    return d;
+}
+
+struct FwdScratch { float *Wcat, *colp, *sig, *rsig; double* stats; };
+struct BwdScratch {
+    float *Wcat, *colp, *sig, *rsig, *dY, *dP, *cc, *dWcat;
+    double *slab, *slab_da, *datt, *dr;
+};
+static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, FwdScratch* s) {
+    Carver c(base);
+    FwdScratch t;
+    t.Wcat = c.take<float>(d.wslab);
+    t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
+    t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
+    t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
+    t.stats = c.take<double>((size_t)d.gx * d.fp * 2);
+    if (s) *s = t;
+    return c.off;
+}
+static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, BwdScratch* s) {
+    Carver c(base);
+    BwdScratch t;
+    t.Wcat = c.take<float>(d.wslab);
+    t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
+    t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
+    t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
+    t.dY = c.take<float>((size_t)std::max(b->T, 1) * d.fp);
+    t.dP = c.take<float>((size_t)std::max(b->T, 1) * d.fp);
+    t.cc = c.take<float>((size_t)2 * d.fp);
+    t.dWcat = c.take<float>(d.wslab * d.nsplit);
+    t.slab = c.take<double>((size_t)d.gxb * d.fp * 2);
+    t.slab_da = c.take<double>((size_t)d.gxb * EAGCN_MAX_VIEWS);
+    t.datt = c.take<double>(EAGCN_MAX_VIEWS * 256);
+    t.dr = c.take<double>(EAGCN_MAX_VIEWS);
+    if (s) *s = t;
+    return c.off;
+}
+
+static int check_layer(const eagcn_batch* b, const eagcn_layer_params* p, const char* who) {
+    EAGCN_CHECK_ARG(b && p, "%s: null argument", who);
+    EAGCN_CHECK_ARG(p->K >= 1 && p->K <= EAGCN_MAX_VIEWS && p->K == b->K,
+                    "%s: layer has %d views, batch index has %d", who, p->K, b->K);
+    EAGCN_CHECK_ARG(p->structure == EAGCN_STRUCT_CONCATE || p->structure == EAGCN_STRUCT_WEIGHTED,
+                    "%s: unknown structure %d", who, p->structure);
+    EAGCN_CHECK_ARG(p->in.nseg >= 1 && p->in.nseg <= EAGCN_MAX_SEGS, "%s: bad input layout", who);
+    for (int s = 0; s < p->in.nseg; ++s)
+        EAGCN_CHECK_ARG(p->in.width[s] >= 1 && p->in.pad[s] >= p->in.width[s] && (p->in.pad[s] % 4) == 0,
+                        "%s: input segment %d: width %d pad %d (pad must be a multiple of 4 >= width)", who, s,
+                        p->in.width[s], p->in.pad[s]);
+    for (int k = 0; k < p->K; ++k) {
+        EAGCN_CHECK_ARG(p->width[k] >= 1, "%s: view %d has width %d", who, k, p->width[k]);
+        EAGCN_CHECK_ARG(p->att_w[k] && p->self_r[k] && p->W[k] && p->bias[k] && p->gamma[k] && p->beta[k] &&
+                            p->run_mean[k] && p->run_var[k], "%s: view %d has a null parameter", who, k);
+        if (p->structure == EAGCN_STRUCT_WEIGHTED)
+            EAGCN_CHECK_ARG(p->width[k] == p->width[0], "%s: Weighted_sum needs equal view widths", who);
+    }
+    if (p->structure == EAGCN_STRUCT_WEIGHTED) EAGCN_CHECK_ARG(p->ave_w, "%s: Weighted_sum needs ave_w", who);
+    EAGCN_CHECK_ARG(p->dropout >= 0.0f && p->dropout < 1.0f, "%s: dropout %f out of [0,1)", who, p->dropout);
+    return EAGCN_OK;
+}
+
+static ParamPtrs param_ptrs(const eagcn_batch* b, const eagcn_layer_params* p) {
+    ParamPtrs pp;
+    memset(&pp, 0, sizeof(pp));
+    for (int k = 0; k < p->K; ++k) {
+        pp.att_w[k] = p->att_w[k]; pp.self_r[k] = p->self_r[k]; pp.W[k] = p->W[k]; pp.bias[k] = p->bias[k];
+        pp.gamma[k] = p->gamma[k]; pp.beta[k] = p->beta[k]; pp.run_mean[k] = p->run_mean[k];
+        pp.run_var[k] = p->run_var[k]; pp.channels[k] = b->channels[k];
+    }
+    pp.ave_w = p->structure == EAGCN_STRUCT_WEIGHTED ? p->ave_w : nullptr;
+    return pp;
+}
+
+static inline int ew_grid(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 2048)); }
+
+}  // namespace eagcn
+
+using namespace eagcn;
+
+extern "C" int eagcn_pad16(int w) { return pad16(w); }
+extern "C" int eagcn_layer_fp(const eagcn_layer_params* p) { return view_cols(p).off[p->K]; }
+extern "C" int eagcn_layer_out_ld(const eagcn_layer_params* p) {
+    return p->structure == EAGCN_STRUCT_CONCATE ? eagcn_layer_fp(p) : pad16(p->width[0]);
+}
+extern "C" size_t eagcn_layer_fwd_scratch_bytes(const eagcn_batch* b, const eagcn_layer_params* p) {
+    LayerDims d = layer_dims(b, p);
+    return carve_fwd(nullptr, b, d, nullptr);
+}
+extern "C" size_t eagcn_layer_bwd_scratch_bytes(const eagcn_batch* b, const eagcn_layer_params* p) {
+    LayerDims d = layer_dims(b, p);
+    return carve_bwd(nullptr, b, d, nullptr);
+}
+
+extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
+                                   void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = check_layer(b, p, "eagcn_layer_forward");
+    if (rc) return rc;
+    EAGCN_CHECK_ARG(w && w->bn && w->xout && w->pad_row && w->scratch, "eagcn_layer_forward: null buffer");
+    EAGCN_CHECK_ARG(b->T == 0 || (w->x && w->P && w->Y && w->rscale), "eagcn_layer_forward: null activation buffer");
+    const LayerDims d = layer_dims(b, p);
+    FwdScratch sc;
+    const size_t need = carve_fwd(w->scratch, b, d, &sc);
+    if (need > w->scratch_bytes) {
+        set_error("eagcn_layer_forward: scratch too small (%zu < %zu)", w->scratch_bytes, need);
+        return EAGCN_ERR_SCRATCH;
+    }
+    const ParamPtrs pp = param_ptrs(b, p);
+    const ColMapD in = make_colmap(&p->in);
+    pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.colp, sc.sig, sc.rsig);
+    EAGCN_LAUNCH_CHECK();
+    int nslab = 0;
+    if (b->T > 0) {
+        GemmDesc g{0, 0, b->T, d.fp, d.ld_in, w->x, d.ld_in, sc.Wcat, d.fp, w->P, d.fp, 1, 0};
+        rc = launch_gemm(g, s);
+        if (rc) return rc;
+        AggArgs a;
+        a.bt = *b; a.vc = d.vc; a.src = w->P; a.lds = d.fp; a.dst = w->Y; a.ldd = d.fp;
+        a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = sc.stats; a.nchunk = 1;
+        rc = launch_agg(a, false, s);
+        if (rc) return rc;
+        nslab = d.gx;
+    }
+    const double M = (double)b->B * (double)b->N;
+    bn_finalize_kernel<<<cdiv(d.fp, 256), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
+                                                        p->bn_momentum, sc.colp, pp, d.vc, w->bn);
+    EAGCN_LAUNCH_CHECK();
+    ApplyArgs aa;
+    aa.bt = *b; aa.vc = d.vc; aa.structure = p->structure; aa.fp = d.fp; aa.Y = w->Y; aa.ldy = d.fp;
+    aa.bn = w->bn; aa.colp = sc.colp; aa.out = w->xout; aa.ldo = d.ldo; aa.pad_row = w->pad_row;
+    aa.do_drop = (p->training && p->dropout > 0.0f) ? 1 : 0;
+    aa.thr = (uint32_t)std::min(4294967295.0, (double)p->dropout * 4294967296.0);
+    aa.inv_keep = 1.0f / (1.0f - p->dropout);
+    aa.seed = p->seed;
+    bn_apply_kernel<<<ew_grid((size_t)std::max(b->T, 1) * d.ldo / 4), 256, 0, s>>>(aa);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
+                                    const float* dxout, const float* dpad_row, float* dx,
+                                    const eagcn_layer_grads* g, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = check_layer(b, p, "eagcn_layer_backward");
+    if (rc) return rc;
+    EAGCN_CHECK_ARG(w && g && w->bn && w->scratch, "eagcn_layer_backward: null buffer");
+    EAGCN_CHECK_ARG(b->T == 0 || (dxout && w->x && w->P && w->Y && w->rscale), "eagcn_layer_backward: null activation buffer");
+    for (int k = 0; k < p->K; ++k)
+        EAGCN_CHECK_ARG(g->dW[k] && g->dbias[k] && g->dgamma[k] && g->dbeta[k] && g->datt_w[k] && g->dself_r[k],
+                        "eagcn_layer_backward: view %d has a null gradient buffer", k);
+    const LayerDims d = layer_dims(b, p);
+    BwdScratch sc;
+    const size_t need = carve_bwd(w->scratch, b, d, &sc);
+    if (need > w->scratch_bytes) {
+        set_error("eagcn_layer_backward: scratch too small (%zu < %zu)", w->scratch_bytes, need);
+        return EAGCN_ERR_SCRATCH;
+    }
+    const ParamPtrs pp = param_ptrs(b, p);
+    GradPtrs gp;
+    memset(&gp, 0, sizeof(gp));
+    for (int k = 0; k < p->K; ++k) {
+        gp.dW[k] = g->dW[k]; gp.dbias[k] = g->dbias[k]; gp.dgamma[k] = g->dgamma[k]; gp.dbeta[k] = g->dbeta[k];
+        gp.datt_w[k] = g->datt_w[k]; gp.dself_r[k] = g->dself_r[k];
+    }
+    gp.dave_w = p->structure == EAGCN_STRUCT_WEIGHTED ? g->dave_w : nullptr;
+    const ColMapD in = make_colmap(&p->in);
+    pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.colp, sc.sig, sc.rsig);
+    EAGCN_LAUNCH_CHECK();
+    EAGCN_HIP(hipMemsetAsync(sc.datt, 0, (char*)(sc.dr + EAGCN_MAX_VIEWS) - (char*)sc.datt, s));
+
+    BwdArgs ba;
+    ba.bt = *b; ba.vc = d.vc; ba.structure = p->structure; ba.fp = d.fp;
+    ba.nvirt = (dpad_row && p->structure == EAGCN_STRUCT_WEIGHTED) ? 1 : 0;
+    ba.dxout = dxout; ba.ldo = d.ldo; ba.dpad = dpad_row; ba.Y = w->Y; ba.ldy = d.fp; ba.bn = w->bn;
+    ba.colp = sc.colp; ba.dH = sc.dY; ba.slab = sc.slab; ba.slab_da = sc.slab_da;
+    ba.do_drop = (p->training && p->dropout > 0.0f) ? 1 : 0;
+    ba.thr = (uint32_t)std::min(4294967295.0, (double)p->dropout * 4294967296.0);
+    ba.inv_keep = 1.0f / (1.0f - p->dropout);
+    ba.seed = p->seed;
+    const int rows = b->T + ba.nvirt;
+    const int gxb = std::max(1, std::min(rows, d.gxb));
+    bn_bwd_reduce_kernel<<<gxb, 256, 0, s>>>(ba);
+    EAGCN_LAUNCH_CHECK();
+    const double M = (double)b->B * (double)b->N;
+    bn_bwd_finalize_kernel<<<cdiv(d.fp, 256), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
+                                                            d.vc, gp, sc.cc);
+    EAGCN_LAUNCH_CHECK();
+    int nsplit = 0;
+    if (b->T > 0) {
+        bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(b->T, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
+        EAGCN_LAUNCH_CHECK();
+        AggArgs a;
+        a.bt = *b; a.vc = d.vc; a.src = sc.dY; a.lds = d.fp; a.dst = sc.dP; a.ldd = d.fp;
+        a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = nullptr; a.nchunk = 1;
+        rc = launch_agg(a, true, s);
+        if (rc) return rc;
+        EdgeArgs e;
+        e.bt = *b; e.vc = d.vc; e.dY = sc.dY; e.Y = w->Y; e.P = w->P; e.ld = d.fp; e.sig = sc.sig;
+        e.rsig = sc.rsig; e.rscale = w->rscale; e.datt = sc.datt; e.dr = sc.dr;
+        rc = launch_edge_grad(e, s);
+        if (rc) return rc;
+        nsplit = d.nsplit;
+        GemmDesc gw{1, 0, d.ld_in, d.fp, b->T, w->x, d.ld_in, sc.dP, d.fp, sc.dWcat, d.fp, nsplit, d.wslab};
+        rc = launch_gemm(gw, s);
+        if (rc) return rc;
+        if (dx) {
+            GemmDesc gx{0, 1, b->T, d.ld_in, d.fp, sc.dP, d.fp, sc.Wcat, d.fp, dx, d.ld_in, 1, 0};
+            rc = launch_gemm(gx, s);
+            if (rc) return rc;
+        }
+    }
+    unpack_grads_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat, nsplit, d.wslab,
+                                                        sc.datt, sc.dr, sc.rsig);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_attention_dense(const eagcn_batch* b, const eagcn_layer_params* p, float* out, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    EAGCN_CHECK_ARG(b && p && out, "eagcn_attention_dense: null argument");
+    EAGCN_CHECK_ARG(p->K == b->K, "eagcn_attention_dense: view count mismatch");
+    EAGCN_CHECK_ARG(b->code, "eagcn_attention_dense: batch has no code map");
+    ParamPtrs pp;
+    memset(&pp, 0, sizeof(pp));
+    for (int k = 0; k < p->K; ++k) {
+        EAGCN_CHECK_ARG(p->att_w[k], "eagcn_attention_dense: view %d has no attention weight", k);
+        pp.att_w[k] = p->att_w[k];
+        pp.channels[k] = b->channels[k];
+    }
+    const size_t total = (size_t)b->K * b->B * b->N * b->N;
+    attention_dense_kernel<<<ew_grid(total), 256, 0, s>>>(*b, pp, out);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}

@@ -1,0 +1,112 @@
+// Molecule read-out: g[b,:] = sum over ALL N padded rows of x[b,i,:]  (reference models.py:108),
+// optionally divided by the atom count (molfp_mode 'ave', models.py:109-111), and its backward.
+// Rows that are not stored in the packed layout are all equal to `pad_row` (zero for a Concate
+// layer, a constant vector for Weighted_sum, which has no mask: layers.py:315-316), so they
+// contribute (N - nat[b]) * pad_row.
+#include <algorithm>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace eagcn {
+
+__device__ __forceinline__ int exact_to_packed(const ColMapD& m, int ce) {
+    int eo = 0, po = 0;
+    for (int s = 0; s < m.nseg; ++s) {
+        if (ce < eo + m.w[s]) return po + (ce - eo);
+        eo += m.w[s];
+        po += m.p[s];
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void readout_fwd_kernel(eagcn_batch bt, const float* __restrict__ x, ColMapD m,
+                                                           int ld, const float* __restrict__ pad_row,
+                                                           const int64_t* __restrict__ size, int mode,
+                                                           float* __restrict__ g, int F) {
+    const int b = blockIdx.x;
+    const int n = bt.nat[b], r0 = bt.row0[b];
+    const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const int cp = exact_to_packed(m, f);
+        float s = 0.0f;
+        for (int i = 0; i < n; ++i) s += x[(size_t)(r0 + i) * ld + cp];
+        if (pad_row) s += (float)(bt.N - n) * pad_row[cp];
+        g[(size_t)b * F + f] = s * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void readout_bwd_kernel(eagcn_batch bt, const float* __restrict__ dg, ColMapD m,
+                                                           int ld, const int64_t* __restrict__ size, int mode,
+                                                           int F, float* __restrict__ dx) {
+    const int b = blockIdx.x;
+    const int n = bt.nat[b], r0 = bt.row0[b];
+    const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
+    for (int cp = threadIdx.x; cp < ld; cp += blockDim.x) {
+        // packed column -> exact column (or -1 for a padding column)
+        int eo = 0, po = 0, ce = -1;
+        for (int s = 0; s < m.nseg; ++s) {
+            if (cp < po + m.p[s]) { ce = (cp - po < m.w[s]) ? eo + (cp - po) : -1; break; }
+            eo += m.w[s];
+            po += m.p[s];
+        }
+        const float v = ce >= 0 ? dg[(size_t)b * F + ce] * inv : 0.0f;
+        for (int i = 0; i < n; ++i) dx[(size_t)(r0 + i) * ld + cp] = v;
+    }
+}
+
+// d pad_row[c] = sum_b (N - nat[b]) * dg[b][c] / size[b]
+__global__ __launch_bounds__(256) void readout_bwd_pad_kernel(eagcn_batch bt, const float* __restrict__ dg, ColMapD m,
+                                                               int ld, const int64_t* __restrict__ size, int mode,
+                                                               int F, float* __restrict__ dpad) {
+    const int cp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cp >= ld) return;
+    int eo = 0, po = 0, ce = -1;
+    for (int s = 0; s < m.nseg; ++s) {
+        if (cp < po + m.p[s]) { ce = (cp - po < m.w[s]) ? eo + (cp - po) : -1; break; }
+        eo += m.w[s];
+        po += m.p[s];
+    }
+    double acc = 0.0;
+    if (ce >= 0)
+        for (int b = 0; b < bt.B; ++b) {
+            const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
+            acc += (double)((float)(bt.N - bt.nat[b]) * dg[(size_t)b * F + ce] * inv);
+        }
+    dpad[cp] = (float)acc;
+}
+
+}  // namespace eagcn
+
+using namespace eagcn;
+
+extern "C" int eagcn_readout_forward(const eagcn_batch* b, const float* x, const eagcn_layout* lay,
+                                     const float* pad_row, const int64_t* size, int mode, float* g, int F,
+                                     void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    EAGCN_CHECK_ARG(b && lay && g, "eagcn_readout_forward: null argument");
+    EAGCN_CHECK_ARG(b->T == 0 || x, "eagcn_readout_forward: null activations");
+    EAGCN_CHECK_ARG(layout_width(lay) == F, "eagcn_readout_forward: layout width %d != F %d", layout_width(lay), F);
+    EAGCN_CHECK_ARG(mode == 0 || (mode == 1 && size), "eagcn_readout_forward: mode 1 ('ave') needs size");
+    readout_fwd_kernel<<<b->B, 256, 0, s>>>(*b, x, make_colmap(lay), layout_ld(lay), pad_row, size, mode, g, F);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_readout_backward(const eagcn_batch* b, const float* dg, const eagcn_layout* lay,
+                                      const int64_t* size, int mode, int F, float* dx, float* dpad_row,
+                                      void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    EAGCN_CHECK_ARG(b && lay && dg, "eagcn_readout_backward: null argument");
+    EAGCN_CHECK_ARG(b->T == 0 || dx, "eagcn_readout_backward: null dx");
+    EAGCN_CHECK_ARG(layout_width(lay) == F, "eagcn_readout_backward: layout width %d != F %d", layout_width(lay), F);
+    EAGCN_CHECK_ARG(mode == 0 || (mode == 1 && size), "eagcn_readout_backward: mode 1 ('ave') needs size");
+    readout_bwd_kernel<<<b->B, 256, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size, mode, F, dx);
+    EAGCN_LAUNCH_CHECK();
+    if (dpad_row) {
+        readout_bwd_pad_kernel<<<cdiv(layout_ld(lay), 256), 256, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size,
+                                                                       mode, F, dpad_row);
+        EAGCN_LAUNCH_CHECK();
+    }
+    return EAGCN_OK;
+}

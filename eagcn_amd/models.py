@@ -1,0 +1,151 @@
+"""EAGCN model (reference eagcn_pytorch/models.py:14-121) on the HIP hot path.
+
+Same constructor / forward signature and state_dict keys as the reference's ``EAGCN``; the class
+names used by BASELINE.json (``Concate_GCN``, ``Weighted_GCN``) are provided as thin subclasses
+that fix ``structure``.  Keyword-only extensions (defaults = reference behaviour):
+
+  n_layers      number of graph-conv layers, 1..4 (reference hard-codes 4, models.py:50-61);
+                BASELINE.json's configs use 2 and 3.  Layers 3/4 use twice the layer-2 widths.
+  rel_channels  channels of every relation tensor (default [n_bfeat,4,2,2,2]); with ``widths1`` /
+                ``widths2`` lists this allows K != 5 views.
+  atom_rep      'lazy' (default) | 'eager' | 'none': the reference copies the last layer's atom
+                representations to the host in EVERY forward (``x2.data.cpu()``, models.py:102), a
+                device->host copy plus a sync per step; 'lazy' returns an object that performs the
+                copy on first use, 'eager' reproduces the reference exactly.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .layers import Dense, GraphConv_Layer
+
+
+class LazyAtomRep:
+    """Deferred ``x2.data.cpu()`` (models.py:102): materialises the padded [B,N,F] host tensor on
+    first use.  Supports what train.py:213-266 does with it (.view / indexing / .numpy / .shape)."""
+
+    def __init__(self, index, layout, packed, pad_row):
+        self._args = (index, layout, packed.detach(), None if pad_row is None else pad_row.detach())
+        self._cpu = None
+
+    def cpu(self):
+        if self._cpu is None:
+            index, layout, packed, pad_row = self._args
+            with torch.no_grad():
+                self._cpu = ops.unpack_rows(index, layout, packed, pad_row).cpu()
+            self._args = None
+        return self._cpu
+
+    def __getattr__(self, name):
+        return getattr(self.cpu(), name)
+
+    def __getitem__(self, i):
+        return self.cpu()[i]
+
+
+class EAGCN(nn.Module):
+    def __init__(self, n_bfeat, n_afeat, n_sgc1_1=None, n_sgc1_2=None, n_sgc1_3=None, n_sgc1_4=None,
+                 n_sgc1_5=None, n_sgc2_1=None, n_sgc2_2=None, n_sgc2_3=None, n_sgc2_4=None, n_sgc2_5=None,
+                 n_den1=128, n_den2=64, nclass=1, dropout=0.0, structure='Concate', molfp_mode='sum',
+                 pool_num=5, *, n_layers=4, widths1=None, widths2=None, rel_channels=None, atom_rep='lazy'):
+        super().__init__()
+        if widths1 is None:
+            widths1 = [n_sgc1_1, n_sgc1_2, n_sgc1_3, n_sgc1_4, n_sgc1_5]
+        if widths2 is None:
+            widths2 = [n_sgc2_1, n_sgc2_2, n_sgc2_3, n_sgc2_4, n_sgc2_5]
+        widths1, widths2 = [int(w) for w in widths1], [int(w) for w in widths2]
+        K = len(widths1)
+        if len(widths2) != K:
+            raise ValueError('widths1 and widths2 need one entry per view')
+        if rel_channels is None:
+            rel_channels = [n_bfeat, 4, 2, 2, 2][:K]
+        if structure not in ('Concate', 'Weighted_sum'):
+            raise ValueError("the HIP hot path implements structure 'Concate' and 'Weighted_sum' "
+                             "(the GCN / GAT baselines of models.py:63-73 are outside its scope)")
+        if molfp_mode not in ('sum', 'ave'):
+            raise ValueError("molfp_mode 'sum' and 'ave' are implemented ('pool' = Diff_Pooling is "
+                             "outside the hot path, SURVEY.md 8f)")
+        if not 1 <= n_layers <= 4:
+            raise ValueError('n_layers must be 1..4')
+        if structure == 'Weighted_sum':                                   # models.py:33-47
+            widths1 = [sum(widths1)] * K
+            widths2 = [sum(widths2)] * K
+            self.ngc1, self.ngc2 = widths1[0], widths2[0]
+        else:
+            self.ngc1, self.ngc2 = sum(widths1), sum(widths2)
+        w3 = [2 * w for w in widths2]
+        plan = [(n_afeat, widths1, self.ngc1), (self.ngc1, widths2, self.ngc2),
+                (self.ngc2, w3, 2 * self.ngc2), (2 * self.ngc2, w3, 2 * self.ngc2)][:n_layers]
+        for i, (fin, ws, _) in enumerate(plan):
+            setattr(self, 'layer%d' % (i + 1),
+                    GraphConv_Layer(fin, n_bfeat, None, dropout=dropout, structure=structure, last=(i == 3),
+                                    widths=ws, rel_channels=rel_channels))
+        f_last = plan[-1][2]
+        self.n_layers, self.n_afeat, self.K = n_layers, n_afeat, K
+        self.structure, self.molfp_mode, self.dropout = structure, molfp_mode, dropout
+        self.atom_rep = atom_rep
+        self.den1 = Dense(f_last, n_den1)
+        self.den2 = Dense(n_den1, n_den2)
+        self.den3 = Dense(n_den2, nclass)
+        self.Graph_BN = nn.BatchNorm1d(f_last)
+        self.bn_den1 = nn.BatchNorm1d(n_den1)
+        self.bn_den2 = nn.BatchNorm1d(n_den2)
+
+    def graph_layers(self):
+        return [getattr(self, 'layer%d' % (i + 1)) for i in range(self.n_layers)]
+
+    def forward_layers(self, index, afms):
+        """Packed activations after every graph-conv layer: list of (x, pad_row, layout)."""
+        layout = ops.ColLayout.single(self.n_afeat)
+        x = ops.pack_rows(index, layout, afms)
+        outs = []
+        for layer in self.graph_layers():
+            x, pad_row, layout = layer.forward_packed(index, x, layout)
+            outs.append((x, pad_row, layout))
+        return outs
+
+    def forward(self, adjs, afms, *rels_and_size):
+        *rels, size = rels_and_size
+        index = ops.BatchIndex(adjs, rels)                       # once per batch, shared by all layers
+        x, pad_row, layout = self.forward_layers(index, afms)[-1]
+        pad = pad_row if self.structure == 'Weighted_sum' else None
+        if self.atom_rep == 'none':
+            atom_representations = None
+        else:
+            atom_representations = LazyAtomRep(index, layout, x, pad)
+            if self.atom_rep == 'eager':
+                atom_representations = atom_representations.cpu()
+        g = ops.readout(index, layout, x, pad, self.molfp_mode, size)      # models.py:108-111
+        g = self.Graph_BN(g)
+        h = F.relu(self.bn_den1(self.den1(g)))
+        h = F.dropout(h, p=self.dropout, training=self.training)
+        graph_representation = self.den2(h)
+        out = self.den3(F.relu(self.bn_den2(graph_representation)))
+        return out, atom_representations, graph_representation
+
+
+class Concate_GCN(EAGCN):
+    """``EAGCN(structure='Concate')`` under the name BASELINE.json uses."""
+
+    def __init__(self, *args, **kw):
+        kw['structure'] = 'Concate'
+        super().__init__(*args, **kw)
+
+
+class Weighted_GCN(EAGCN):
+    """``EAGCN(structure='Weighted_sum')`` under the name BASELINE.json uses."""
+
+    def __init__(self, *args, **kw):
+        kw['structure'] = 'Weighted_sum'
+        super().__init__(*args, **kw)
+
+
+def weights_init(m):
+    """reference utils.py:702-708 (class-name substring matching, kept verbatim in behaviour)."""
+    name = m.__class__.__name__
+    if name.find('GraphConv_base') != -1:
+        m.weight.data.normal_(0.0, 0.02)
+    elif name.find('BatchNorm') != -1:
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)

@@ -1,0 +1,384 @@
+"""Host side of the HIP hot path: batch index + autograd Functions over the C ABI.
+
+PyTorch is used here for device memory (caching allocator), the current HIP stream and autograd
+bookkeeping only; every computation is a call into libeagcn_hip.so.  There is no eager / CPU
+fallback: tensors that are not fp32 CUDA(HIP) tensors raise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need_cuda_f32(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise L.EagcnHipError('%s must be a tensor on the MI355X (got %s): eagcn_amd has no CPU path'
+                              % (name, getattr(t, 'device', type(t))))
+    if t.dtype != torch.float32:
+        raise L.EagcnHipError('%s must be float32 (got %s)' % (name, t.dtype))
+    return t.contiguous()
+
+
+_pinned_meta = {}
+
+
+def _host_meta(device):
+    key = device.index
+    if key not in _pinned_meta:
+        _pinned_meta[key] = torch.zeros(L.META_WORDS, dtype=torch.int32).pin_memory()
+    return _pinned_meta[key]
+
+
+class ColLayout:
+    """Column layout of a packed activation matrix: exact widths + padded widths per segment."""
+
+    def __init__(self, widths, pads):
+        self.widths = [int(w) for w in widths]
+        self.pads = [int(p) for p in pads]
+        self.ld = sum(self.pads)
+        self.width = sum(self.widths)
+        self.c = L.make_layout(self.widths, self.pads)
+
+    @staticmethod
+    def single(width, mult=4):
+        return ColLayout([width], [(int(width) + mult - 1) // mult * mult])
+
+    def __repr__(self):
+        return 'ColLayout(%s -> %s)' % (self.widths, self.pads)
+
+
+class BatchIndex:
+    """Compact description of one collated batch (reference utils.py:575-640 tensors).
+
+    Built once per batch and shared by every layer (the reference rebuilds its masks in every
+    layer, layers.py:294-304).  Construction runs two small kernels and one 32-byte D2H copy that
+    the host waits for: it returns the number of packed rows (buffer sizes / grid sizes) and the
+    input-validity counters -- non-binary adjacency or non-one-hot relation channels raise here.
+    """
+
+    def __init__(self, adj, rels):
+        lib = L.load()
+        adj = _need_cuda_f32(adj, 'adjs')
+        rels = [_need_cuda_f32(r, 'relation tensor %d' % i) for i, r in enumerate(rels)]
+        if adj.dim() != 3 or adj.shape[1] != adj.shape[2]:
+            raise L.EagcnHipError('adjs must be [B,N,N], got %s' % (tuple(adj.shape),))
+        B, N, _ = adj.shape
+        K = len(rels)
+        if not 1 <= K <= L.MAX_VIEWS:
+            raise L.EagcnHipError('between 1 and %d relation tensors supported, got %d' % (L.MAX_VIEWS, K))
+        for i, r in enumerate(rels):
+            if r.dim() != 4 or r.shape[0] != B or r.shape[2] != N or r.shape[3] != N:
+                raise L.EagcnHipError('relation tensor %d must be [B,C,N,N] = [%d,C,%d,%d], got %s'
+                                      % (i, B, N, N, tuple(r.shape)))
+        dev = adj.device
+        self.device, self.B, self.N, self.K = dev, B, N, K
+        self.channels = [int(r.shape[1]) for r in rels]
+        self.ldc = (N + 15) // 16 * 16
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.code = torch.empty((K, B, N, self.ldc), dtype=torch.uint8, device=dev)
+        self.deg_bn = torch.empty((B, N), **i32)
+        self.nat = torch.empty(B, **i32)
+        self.row0 = torch.empty(B + 1, **i32)
+        self.tile0 = torch.empty(B + 1, **i32)
+        self.meta = torch.empty(L.META_WORDS, **i32)
+        c = L.Batch()
+        c.B, c.N, c.K, c.ldc = B, N, K, self.ldc
+        for k in range(K):
+            c.channels[k] = self.channels[k]
+        c.code, c.deg_bn, c.nat = self.code.data_ptr(), self.deg_bn.data_ptr(), self.nat.data_ptr()
+        c.row0, c.tile0, c.meta = self.row0.data_ptr(), self.tile0.data_ptr(), self.meta.data_ptr()
+        rel_ptrs = (C.c_void_p * K)(*[r.data_ptr() for r in rels])
+        host = _host_meta(dev)
+        L.check(lib.eagcn_index_build(_ptr(adj), rel_ptrs, C.byref(c), C.c_void_p(host.data_ptr()), _stream()),
+                'eagcn_index_build')
+        torch.cuda.current_stream().synchronize()
+        meta = host.tolist()
+        if meta[L.META_BAD_ADJ]:
+            raise L.EagcnHipError('adjs holds %d entries outside {0,1}: the hot path requires a 0/1 '
+                                  'adjacency (reference neural_fp.py:85,109-110)' % meta[L.META_BAD_ADJ])
+        if meta[L.META_BAD_REL]:
+            raise L.EagcnHipError('%d bonded (i,j,view) positions are not one-hot over the relation channels '
+                                  '(reference neural_fp.py:111-120)' % meta[L.META_BAD_REL])
+        self.T, self.n_max, self.n_tiles = meta[L.META_T], meta[L.META_NMAX], meta[L.META_NTILES]
+        self.n_edges = meta[L.META_NEDGE]
+        T = self.T
+        self.row_mol = torch.empty(T, **i32)
+        self.row_loc = torch.empty(T, **i32)
+        self.row_deg = torch.empty(T, **i32)
+        self.row_m = torch.empty(T, dtype=torch.float32, device=dev)
+        self.tile_mol = torch.empty(self.n_tiles, **i32)
+        c.T, c.n_max, c.n_tiles = T, self.n_max, self.n_tiles
+        c.row_mol, c.row_loc, c.row_m = self.row_mol.data_ptr(), self.row_loc.data_ptr(), self.row_m.data_ptr()
+        c.row_deg, c.tile_mol = self.row_deg.data_ptr(), self.tile_mol.data_ptr()
+        L.check(lib.eagcn_index_rows(C.byref(c), _stream()), 'eagcn_index_rows')
+        self.c = c
+        self._keep = (adj, rels)
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+# ------------------------------------------------------------------------------------------------
+# layout conversion
+# ------------------------------------------------------------------------------------------------
+class _PackRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, index, layout, dense):
+        dense = _need_cuda_f32(dense, 'afms')
+        B, N, F = dense.shape
+        if B != index.B or N != index.N or F != layout.width:
+            raise L.EagcnHipError('activations %s do not match batch index [%d,%d,%d]'
+                                  % (tuple(dense.shape), index.B, index.N, layout.width))
+        out = torch.empty((index.T, layout.ld), dtype=torch.float32, device=dense.device)
+        L.check(L.load().eagcn_pack_rows(index.ref(), _ptr(dense), F, C.byref(layout.c), _ptr(out), _stream()),
+                'eagcn_pack_rows')
+        ctx.index, ctx.layout, ctx.F = index, layout, F
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        index, layout = ctx.index, ctx.layout
+        g = g.contiguous()
+        dense = torch.empty((index.B, index.N, ctx.F), dtype=torch.float32, device=g.device)
+        L.check(L.load().eagcn_unpack_rows(index.ref(), _ptr(g), C.byref(layout.c), C.c_void_p(0), _ptr(dense),
+                                           ctx.F, _stream()), 'eagcn_unpack_rows')
+        return None, None, dense
+
+
+class _UnpackRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, index, layout, packed, pad_row):
+        F = layout.width
+        dense = torch.empty((index.B, index.N, F), dtype=torch.float32, device=packed.device)
+        L.check(L.load().eagcn_unpack_rows(index.ref(), _ptr(packed), C.byref(layout.c), _ptr(pad_row),
+                                           _ptr(dense), F, _stream()), 'eagcn_unpack_rows')
+        ctx.index, ctx.layout = index, layout
+        ctx.has_pad = pad_row is not None
+        return dense
+
+    @staticmethod
+    def backward(ctx, g):
+        index, layout = ctx.index, ctx.layout
+        g = g.contiguous()
+        out = torch.empty((index.T, layout.ld), dtype=torch.float32, device=g.device)
+        L.check(L.load().eagcn_pack_rows(index.ref(), _ptr(g), layout.width, C.byref(layout.c), _ptr(out),
+                                         _stream()), 'eagcn_pack_rows')
+        dpad = None
+        if ctx.has_pad and ctx.needs_input_grad[3]:
+            # gradient of the shared non-stored row = sum of the dense gradient over those rows
+            nat = index.nat.to(torch.int64)
+            ar = torch.arange(index.N, device=g.device).view(1, -1)
+            mask = (ar >= nat.view(-1, 1)).to(g.dtype).unsqueeze(-1)
+            dsum = (g * mask).sum(dim=(0, 1))
+            dpad = torch.zeros(layout.ld, dtype=g.dtype, device=g.device)
+            o_e = o_p = 0
+            for w, p in zip(layout.widths, layout.pads):
+                dpad[o_p:o_p + w] = dsum[o_e:o_e + w]
+                o_e += w
+                o_p += p
+        return None, None, out, dpad
+
+
+def pack_rows(index, layout, dense):
+    return _PackRows.apply(index, layout, dense)
+
+
+def unpack_rows(index, layout, packed, pad_row=None):
+    return _UnpackRows.apply(index, layout, packed, pad_row)
+
+
+# ------------------------------------------------------------------------------------------------
+# graph-conv layer
+# ------------------------------------------------------------------------------------------------
+class LayerSpec:
+    """Static description of one multi-view layer (what the C struct needs besides pointers)."""
+
+    def __init__(self, structure, widths, in_layout, dropout, bn_eps=1e-5, bn_momentum=0.1):
+        self.structure = {'Concate': L.STRUCT_CONCATE, 'Weighted_sum': L.STRUCT_WEIGHTED}[structure]
+        self.structure_name = structure
+        self.widths = [int(w) for w in widths]
+        self.K = len(self.widths)
+        self.in_layout = in_layout
+        self.dropout = float(dropout)
+        self.bn_eps, self.bn_momentum = float(bn_eps), float(bn_momentum)
+        self.fp = sum(L.pad16(w) for w in self.widths)
+        if self.structure == L.STRUCT_CONCATE:
+            self.out_layout = ColLayout(self.widths, [L.pad16(w) for w in self.widths])
+        else:
+            self.out_layout = ColLayout([self.widths[0]], [L.pad16(self.widths[0])])
+
+    def cparams(self, training, seed, views, ave_w):
+        """views: list of K dicts of tensors (att_w, self_r, W, bias, gamma, beta, run_mean, run_var)."""
+        p = L.LayerParams()
+        p.K, p.structure, p.training = self.K, self.structure, int(bool(training))
+        for k, w in enumerate(self.widths):
+            p.width[k] = w
+        p.inp = self.in_layout.c
+        p.dropout, p.bn_eps, p.bn_momentum, p.seed = self.dropout, self.bn_eps, self.bn_momentum, int(seed)
+        for k, v in enumerate(views):
+            p.att_w[k], p.self_r[k], p.W[k] = v['att_w'].data_ptr(), v['self_r'].data_ptr(), v['W'].data_ptr()
+            p.bias[k], p.gamma[k], p.beta[k] = v['bias'].data_ptr(), v['gamma'].data_ptr(), v['beta'].data_ptr()
+            p.run_mean[k], p.run_var[k] = v['run_mean'].data_ptr(), v['run_var'].data_ptr()
+        p.ave_w = ave_w.data_ptr() if ave_w is not None else None
+        return p
+
+
+_PARAM_KEYS = ('att_w', 'self_r', 'W', 'bias', 'gamma', 'beta')
+
+
+class _LayerFn(torch.autograd.Function):
+    """x_packed, parameters -> (xout_packed, pad_row).  One C call forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, index, spec, training, seed, buffers, x, ave_w, *flat):
+        lib = L.load()
+        K = spec.K
+        x = x.contiguous()
+        if x.shape != (index.T, spec.in_layout.ld):
+            raise L.EagcnHipError('packed input is %s, expected %s' % (tuple(x.shape), (index.T, spec.in_layout.ld)))
+        views = []
+        for k in range(K):
+            v = {name: flat[k * 6 + i] for i, name in enumerate(_PARAM_KEYS)}
+            for name, t in v.items():
+                if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                    raise L.EagcnHipError('parameter %s of view %d must be a contiguous fp32 device tensor' % (name, k))
+            v['run_mean'], v['run_var'] = buffers[k]
+            fin = spec.in_layout.width
+            if tuple(v['W'].shape) != (fin, spec.widths[k]):
+                raise L.EagcnHipError('view %d weight is %s, expected %s' % (k, tuple(v['W'].shape), (fin, spec.widths[k])))
+            if v['att_w'].numel() != index.channels[k]:
+                raise L.EagcnHipError('view %d attention weight has %d channels, relation tensor has %d'
+                                      % (k, v['att_w'].numel(), index.channels[k]))
+            views.append(v)
+        p = spec.cparams(training, seed, views, ave_w)
+        dev, T, fp = x.device, index.T, spec.fp
+        f32 = dict(dtype=torch.float32, device=dev)
+        P = torch.empty((T, fp), **f32)
+        Y = torch.empty((T, fp), **f32)
+        rscale = torch.empty((K, T), **f32)
+        bn = torch.empty((4, fp), **f32)
+        xout = torch.empty((T, spec.out_layout.ld), **f32)
+        pad_row = torch.empty(spec.out_layout.ld, **f32)
+        nbytes = lib.eagcn_layer_fwd_scratch_bytes(index.ref(), C.byref(p))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        w = L.LayerBufs()
+        w.x, w.P, w.Y, w.rscale, w.bn = x.data_ptr(), P.data_ptr(), Y.data_ptr(), rscale.data_ptr(), bn.data_ptr()
+        w.xout, w.pad_row, w.scratch, w.scratch_bytes = xout.data_ptr(), pad_row.data_ptr(), scratch.data_ptr(), nbytes
+        L.check(lib.eagcn_layer_forward(index.ref(), C.byref(p), C.byref(w), _stream()), 'eagcn_layer_forward')
+        ctx.index, ctx.spec, ctx.training, ctx.seed, ctx.buffers = index, spec, training, seed, buffers
+        ctx.save_for_backward(x, P, Y, rscale, bn, ave_w, *flat)
+        if spec.structure == L.STRUCT_CONCATE:
+            ctx.mark_non_differentiable(pad_row)
+        return xout, pad_row
+
+    @staticmethod
+    def backward(ctx, dxout, dpad):
+        lib = L.load()
+        index, spec = ctx.index, ctx.spec
+        x, P, Y, rscale, bn, ave_w, *flat = ctx.saved_tensors
+        K = spec.K
+        views = []
+        for k in range(K):
+            v = {name: flat[k * 6 + i] for i, name in enumerate(_PARAM_KEYS)}
+            v['run_mean'], v['run_var'] = ctx.buffers[k]
+            views.append(v)
+        p = spec.cparams(ctx.training, ctx.seed, views, ave_w)
+        dev = x.device
+        dxout = dxout.contiguous()
+        grads = [torch.empty_like(t) for t in flat]
+        dave = torch.empty_like(ave_w) if ave_w is not None else None
+        g = L.LayerGrads()
+        for k in range(K):
+            gk = grads[k * 6:(k + 1) * 6]
+            g.datt_w[k], g.dself_r[k], g.dW[k] = gk[0].data_ptr(), gk[1].data_ptr(), gk[2].data_ptr()
+            g.dbias[k], g.dgamma[k], g.dbeta[k] = gk[3].data_ptr(), gk[4].data_ptr(), gk[5].data_ptr()
+        g.dave_w = dave.data_ptr() if dave is not None else None
+        need_dx = ctx.needs_input_grad[5]
+        dx = torch.empty_like(x) if need_dx else None
+        nbytes = lib.eagcn_layer_bwd_scratch_bytes(index.ref(), C.byref(p))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        w = L.LayerBufs()
+        w.x, w.P, w.Y, w.rscale, w.bn = x.data_ptr(), P.data_ptr(), Y.data_ptr(), rscale.data_ptr(), bn.data_ptr()
+        w.scratch, w.scratch_bytes = scratch.data_ptr(), nbytes
+        dpad_ptr = C.c_void_p(0)
+        if spec.structure == L.STRUCT_WEIGHTED and dpad is not None:
+            dpad = dpad.contiguous()
+            dpad_ptr = _ptr(dpad)
+        L.check(lib.eagcn_layer_backward(index.ref(), C.byref(p), C.byref(w), _ptr(dxout), dpad_ptr, _ptr(dx),
+                                         C.byref(g), _stream()), 'eagcn_layer_backward')
+        return (None, None, None, None, None, dx, dave, *grads)
+
+
+def layer_forward(index, spec, training, seed, buffers, x, ave_w, flat_params):
+    return _LayerFn.apply(index, spec, training, seed, buffers, x, ave_w, *flat_params)
+
+
+def attention_dense(index, att_weights):
+    """A_weight of layers.py:318: [K,B,N,N] stack of sigmoid(w_k[type]) * adj (no gradient)."""
+    lib = L.load()
+    p = L.LayerParams()
+    p.K = index.K
+    for k, a in enumerate(att_weights):
+        p.att_w[k] = a.data_ptr()
+    out = torch.empty((index.K, index.B, index.N, index.N), dtype=torch.float32, device=index.device)
+    L.check(lib.eagcn_attention_dense(index.ref(), C.byref(p), _ptr(out), _stream()), 'eagcn_attention_dense')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# read-out
+# ------------------------------------------------------------------------------------------------
+class _Readout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, index, layout, mode, size, x, pad_row):
+        F = layout.width
+        g = torch.empty((index.B, F), dtype=torch.float32, device=x.device)
+        if mode == 1:
+            size = size.to(device=x.device, dtype=torch.int64).contiguous()
+        L.check(L.load().eagcn_readout_forward(index.ref(), _ptr(x), C.byref(layout.c), _ptr(pad_row),
+                                               _ptr(size) if mode == 1 else C.c_void_p(0), mode, _ptr(g), F,
+                                               _stream()), 'eagcn_readout_forward')
+        ctx.index, ctx.layout, ctx.mode, ctx.size = index, layout, mode, size
+        ctx.has_pad = pad_row is not None
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        index, layout = ctx.index, ctx.layout
+        dg = dg.contiguous()
+        dx = torch.empty((index.T, layout.ld), dtype=torch.float32, device=dg.device)
+        dpad = None
+        if ctx.has_pad and ctx.needs_input_grad[5]:
+            dpad = torch.empty(layout.ld, dtype=torch.float32, device=dg.device)
+        L.check(L.load().eagcn_readout_backward(index.ref(), _ptr(dg), C.byref(layout.c),
+                                                _ptr(ctx.size) if ctx.mode == 1 else C.c_void_p(0), ctx.mode,
+                                                layout.width, _ptr(dx), _ptr(dpad), _stream()),
+                'eagcn_readout_backward')
+        return None, None, None, None, dx, dpad
+
+
+def readout(index, layout, x, pad_row, mode='sum', size=None):
+    return _Readout.apply(index, layout, 1 if mode == 'ave' else 0, size, x, pad_row)
+
+
+def gemm(a, b, ta=False, tb=False):
+    """C = op(A) @ op(B) on the fp32 matrix cores (no autograd; used by tests and the head)."""
+    a, b = a.contiguous(), b.contiguous()
+    M = a.shape[1] if ta else a.shape[0]
+    Ka = a.shape[0] if ta else a.shape[1]
+    N = b.shape[0] if tb else b.shape[1]
+    Kb = b.shape[1] if tb else b.shape[0]
+    assert Ka == Kb
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    L.check(L.load().eagcn_gemm_f32(int(ta), int(tb), M, N, Ka, _ptr(a), a.shape[1], _ptr(b), b.shape[1],
+                                    _ptr(c), N, _stream()), 'eagcn_gemm_f32')
+    return c

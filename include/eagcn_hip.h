@@ -1,0 +1,184 @@
+/*
+ * eagcn_hip.h -- C ABI of the MI355X (gfx950) EAGCN hot path.
+ *
+ * Drop-in boundary.  The reference (Luckick/EAGCN) has no FFI of its own: the hot path is the
+ * Python nn.Module surface of eagcn_pytorch/layers.py and models.py, whose bodies are chains of
+ * ATen calls.  Each entry point below replaces one such body; the reference-side binding a
+ * maintainer would add is a ctypes stub inside the module's forward (shown in INTEGRATION.md,
+ * implemented in eagcn_amd/_lib.py + eagcn_amd/layers.py).
+ *
+ *   eagcn_index_*        <- layers.py:294-304 (masks), layers.py:82 (1x1 conv over one-hot
+ *                           relation tensors == dictionary lookup), utils.py:575-640 (layout)
+ *   eagcn_pack_rows / eagcn_unpack_rows
+ *                        <- the padded [B,N,F] activation layout of layers.py:293 / models.py:96
+ *   eagcn_layer_forward  <- GraphConv_Layer.forward, layers.py:293-316 with
+ *                           GraphConv_block.forward layers.py:81-95, GraphConv_base.forward
+ *                           layers.py:38-45, AFM_BatchNorm.forward layers.py:408-412,
+ *                           Ave_multi_view.forward layers.py:431-437
+ *   eagcn_layer_backward <- autograd of the above (the reference has no hand-written backward)
+ *   eagcn_attention_dense<- the A_weight return value, layers.py:318 (stack of A1, layers.py:83)
+ *   eagcn_readout_*      <- models.py:108-111 (sum / ave over atoms)
+ *   eagcn_gemm_f32       <- Dense.forward layers.py:382-387 (x @ W), used by models.py:114-120
+ *
+ * Conventions: all pointers are device pointers unless named host_*; tensors are fp32,
+ * contiguous, row-major; `stream` is a hipStream_t passed as void*; functions return 0 on
+ * success and a negative code on failure with a message available from eagcn_last_error().
+ * No function synchronises the stream.  Nothing here falls back to a CPU path.
+ *
+ * Packed ("compact") activation layout: molecule b occupies rows row0[b] .. row0[b]+nat[b]-1 of a
+ * [T, ld] matrix, nat[b] = 1 + (largest atom index that has a bond).  Rows of the padded
+ * reference tensor beyond nat[b] (padding and trailing bond-less atoms) are never stored: every
+ * one of them has the same value, which the kernels account for analytically.  Feature columns
+ * are grouped in segments (one per view for a Concate layer output), each segment padded with zero
+ * columns to a multiple of 16.
+ */
+#ifndef EAGCN_HIP_H
+#define EAGCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EAGCN_MAX_VIEWS 8
+#define EAGCN_MAX_SEGS 8
+#define EAGCN_MAX_CHANNELS 255
+#define EAGCN_STRUCT_CONCATE 0
+#define EAGCN_STRUCT_WEIGHTED 1
+
+#define EAGCN_OK 0
+#define EAGCN_ERR_ARG (-1)
+#define EAGCN_ERR_HIP (-2)
+#define EAGCN_ERR_SCRATCH (-3)
+
+/* meta[] slots written by eagcn_index_build (device) and mirrored to host_meta */
+#define EAGCN_META_T 0        /* packed rows                                   */
+#define EAGCN_META_NMAX 1     /* max nat[b]                                    */
+#define EAGCN_META_NTILES 2   /* sum_b ceil(nat[b]/16)                         */
+#define EAGCN_META_BAD_ADJ 3  /* # adjacency entries not in {0,1}              */
+#define EAGCN_META_BAD_REL 4  /* # bonded (i,j,view) whose channels are not one-hot */
+#define EAGCN_META_NEDGE 5    /* # directed edges                              */
+#define EAGCN_META_WORDS 8
+
+typedef struct eagcn_batch {
+    int32_t B, N, K;
+    int32_t ldc;                            /* row stride of code maps in bytes, multiple of 16 */
+    int32_t T, n_max, n_tiles;              /* filled by the caller from host_meta              */
+    int32_t channels[EAGCN_MAX_VIEWS];
+    uint8_t* code;                          /* [K][B][N][ldc] 0 = no bond, c+1 = bond type c    */
+    int32_t* deg_bn;                        /* [B][N] degree of every padded row                */
+    int32_t* nat;                           /* [B]                                              */
+    int32_t* row0;                          /* [B+1] exclusive prefix of nat                    */
+    int32_t* tile0;                         /* [B+1] exclusive prefix of ceil(nat/16)           */
+    int32_t* meta;                          /* [EAGCN_META_WORDS]                               */
+    int32_t* row_mol;                       /* [T]                                              */
+    int32_t* row_loc;                       /* [T] atom index inside the molecule               */
+    float* row_m;                           /* [T] row mask m_i = max_j adj[i,j]                */
+    int32_t* row_deg;                       /* [T]                                              */
+    int32_t* tile_mol;                      /* [n_tiles]                                        */
+} eagcn_batch;
+
+/* column layout of a packed activation matrix */
+typedef struct eagcn_layout {
+    int32_t nseg;
+    int32_t width[EAGCN_MAX_SEGS];          /* exact widths                                     */
+    int32_t pad[EAGCN_MAX_SEGS];            /* padded widths (sum = ld)                         */
+} eagcn_layout;
+
+typedef struct eagcn_layer_params {
+    int32_t K;                              /* views                                            */
+    int32_t structure;                      /* EAGCN_STRUCT_*                                   */
+    int32_t training;                       /* BatchNorm batch statistics + dropout             */
+    int32_t width[EAGCN_MAX_VIEWS];         /* F_k                                              */
+    eagcn_layout in;                        /* layout of x                                      */
+    float dropout;
+    float bn_eps, bn_momentum;
+    uint64_t seed;                          /* dropout stream for this call                     */
+    const float* att_w[EAGCN_MAX_VIEWS];    /* [C_k]    blockK.att.weight                       */
+    const float* self_r[EAGCN_MAX_VIEWS];   /* [1]      blockK.self_r                           */
+    const float* W[EAGCN_MAX_VIEWS];        /* [fin,F_k] blockK.graph_conv.weight               */
+    const float* bias[EAGCN_MAX_VIEWS];     /* [F_k]    blockK.graph_conv.bias                  */
+    const float* gamma[EAGCN_MAX_VIEWS];    /* [F_k]    blockK.batch_norm.bn.weight             */
+    const float* beta[EAGCN_MAX_VIEWS];     /* [F_k]    blockK.batch_norm.bn.bias               */
+    float* run_mean[EAGCN_MAX_VIEWS];       /* [F_k]    updated in place when training          */
+    float* run_var[EAGCN_MAX_VIEWS];
+    const float* ave_w;                     /* [K]      layer.ave.weight (Weighted_sum)         */
+} eagcn_layer_params;
+
+typedef struct eagcn_layer_bufs {
+    const float* x;                         /* [T][ld_in]                                       */
+    float* P;                               /* [T][Fp]  X.[W_1|..|W_K]            (saved)       */
+    float* Y;                               /* [T][Fp]  A_k.P_k, pre-bias, pre-BN (saved)       */
+    float* rscale;                          /* [K][T]   m_i / rowsum_i            (saved)       */
+    float* bn;                              /* [4][Fp]  scale, shift, mean, invstd (saved)      */
+    float* xout;                            /* [T][ld_out]                                      */
+    float* pad_row;                         /* [ld_out] value of every non-stored row of xout   */
+    void* scratch;
+    size_t scratch_bytes;
+} eagcn_layer_bufs;
+
+typedef struct eagcn_layer_grads {
+    float* dW[EAGCN_MAX_VIEWS];
+    float* dbias[EAGCN_MAX_VIEWS];
+    float* dgamma[EAGCN_MAX_VIEWS];
+    float* dbeta[EAGCN_MAX_VIEWS];
+    float* datt_w[EAGCN_MAX_VIEWS];
+    float* dself_r[EAGCN_MAX_VIEWS];
+    float* dave_w;                          /* [K] or NULL                                      */
+} eagcn_layer_grads;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int eagcn_abi_version(void);
+const char* eagcn_last_error(void);
+int eagcn_pad16(int width);
+int eagcn_layer_out_ld(const eagcn_layer_params* p);   /* ld of xout                            */
+int eagcn_layer_fp(const eagcn_layer_params* p);       /* Fp = sum_k pad16(F_k)                 */
+size_t eagcn_layer_fwd_scratch_bytes(const eagcn_batch* b, const eagcn_layer_params* p);
+size_t eagcn_layer_bwd_scratch_bytes(const eagcn_batch* b, const eagcn_layer_params* p);
+
+/* ---- batch index ----------------------------------------------------------------------------- */
+/* stage 1: needs code, deg_bn, nat, row0, tile0, meta; copies meta to host_meta (pinned) async */
+int eagcn_index_build(const float* adj, const float* const* rel, eagcn_batch* b,
+                      int32_t* host_meta, void* stream);
+/* stage 2 (after the caller read host_meta and allocated the per-row arrays) */
+int eagcn_index_rows(const eagcn_batch* b, void* stream);
+
+/* ---- layout conversion ----------------------------------------------------------------------- */
+int eagcn_pack_rows(const eagcn_batch* b, const float* dense, int F, const eagcn_layout* lay,
+                    float* packed, void* stream);
+int eagcn_unpack_rows(const eagcn_batch* b, const float* packed, const eagcn_layout* lay,
+                      const float* pad_row, float* dense, int F, void* stream);
+
+/* ---- graph-conv layer ------------------------------------------------------------------------ */
+int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_params* p,
+                        const eagcn_layer_bufs* w, void* stream);
+/* dxout: [T][ld_out]; dpad_row: [ld_out] gradient w.r.t. bufs.pad_row (the common value of all
+ * non-stored rows; Weighted_sum only) or NULL; dx: [T][ld_in] or NULL */
+int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_params* p,
+                         const eagcn_layer_bufs* w, const float* dxout, const float* dpad_row,
+                         float* dx, const eagcn_layer_grads* g, void* stream);
+/* A1_k = sigmoid(w_k[type]) * adj for every view: out [K][B][N][N] */
+int eagcn_attention_dense(const eagcn_batch* b, const eagcn_layer_params* p, float* out,
+                          void* stream);
+
+/* ---- read-out -------------------------------------------------------------------------------- */
+/* g[b][f] = sum_i x[b,i,f] (all N rows; non-stored rows contribute pad_row) ; mode 1: / size[b] */
+int eagcn_readout_forward(const eagcn_batch* b, const float* x, const eagcn_layout* lay,
+                          const float* pad_row, const int64_t* size, int mode, float* g, int F,
+                          void* stream);
+/* dx: [T][ld]; dpad_row: [ld] or NULL */
+int eagcn_readout_backward(const eagcn_batch* b, const float* dg, const eagcn_layout* lay,
+                           const int64_t* size, int mode, int F, float* dx, float* dpad_row,
+                           void* stream);
+
+/* ---- plain fp32 MFMA GEMM (head / tests) ------------------------------------------------------ */
+/* C[M,N] = op(A).op(B); ta/tb: 0 = as stored, 1 = transposed; leading dimensions in floats */
+int eagcn_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
+                   int ldb, float* C, int ldc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAGCN_HIP_H */

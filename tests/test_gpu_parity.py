@@ -1,0 +1,161 @@
+"""GPU parity: the HIP path (through the C ABI) vs the committed golden vectors of the unmodified
+reference and vs the CPU oracle on the same seeded inputs.  fp32, tolerance 1e-5 relative
+(max|d| / max|ref|), as BASELINE.json's north_star states."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden, assert_grad_close, build_oracle_model, golden_cases, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _dev(tensors):
+    return [t.cuda() for t in tensors]
+
+
+def _hip_model(meta, n_layers=4):
+    from eagcn_amd import EAGCN
+    return EAGCN(meta['n_bfeat'], meta['n_afeat'], *meta['widths1'], *meta['widths2'], meta['dens'][0],
+                 meta['dens'][1], meta['nclass'], 0.0, structure=meta['structure'], molfp_mode=meta['molfp'],
+                 n_layers=n_layers)
+
+
+@pytest.mark.parametrize('name', golden_cases('layer'))
+def test_layer_golden(name):
+    from eagcn_amd import GraphConv_Layer
+    g = Golden(name)
+    m = g.meta
+    layer = GraphConv_Layer(m['fin'], m['n_bfeat'], *m['widths'], 0.0, m['structure'])
+    layer.load_state_dict(g.state_dict(), strict=True)
+    layer.cuda().train(m['training'])
+    dense = _dev(g.batch.dense())
+    adj, rels = dense[0], dense[2:-1]
+    x_in = torch.from_numpy(g.z['x_in'].copy()).cuda().requires_grad_(True)
+    y, a_w = layer(adj, x_in, *rels)
+    assert rel_err(y.detach().cpu(), g.z['out/x']) < TOL
+    assert rel_err(a_w.cpu(), g.z['out/A_weight']) < TOL
+    (y * torch.from_numpy(g.z['gout']).cuda()).sum().backward()
+    grads = g.group('grad/')
+    scale = max(np.abs(v).max() for v in grads.values())
+    assert_grad_close(x_in.grad, grads.pop('x_in'), scale, 'x_in', rtol=2e-5)
+    params = dict(layer.named_parameters())
+    for k, ref in grads.items():
+        assert params[k].grad is not None, k
+        assert_grad_close(params[k].grad, ref, scale, k, rtol=2e-5)
+    sd = layer.state_dict()
+    for k, ref in g.group('sd_after/').items():
+        assert rel_err(sd[k].double().cpu(), ref) < TOL, k
+
+
+@pytest.mark.parametrize('name', golden_cases('model'))
+def test_model_golden(name):
+    from eagcn_amd import ops
+    from oracle.eagcn_ref import classification_loss, regression_loss
+    g = Golden(name)
+    model = _hip_model(g.meta)
+    model.load_state_dict(g.state_dict(), strict=True)
+    model.cuda().train(g.meta['training'])
+    dense = _dev(g.batch.dense())
+    adj, afm, rels, size = dense[0], dense[1], dense[2:-1], dense[-1]
+    # per-layer outputs (no running-stat side effects: probe on a copy)
+    import copy
+    probe = copy.deepcopy(model)
+    with torch.no_grad():
+        index = ops.BatchIndex(adj, rels)
+        for i, (x, pad_row, layout) in enumerate(probe.forward_layers(index, afm)):
+            pad = pad_row if g.meta['structure'] == 'Weighted_sum' else None
+            dense_x = ops.unpack_rows(index, layout, x, pad)
+            assert rel_err(dense_x.cpu(), g.z['out/layer%d' % (i + 1)]) < TOL, 'layer%d' % (i + 1)
+    out, atom_rep, graph_rep = model(adj, afm, *rels, size)
+    assert rel_err(out.detach().cpu(), g.z['out/out']) < TOL
+    assert rel_err(graph_rep.detach().cpu(), g.z['out/graph_rep']) < TOL
+    assert rel_err(atom_rep.cpu(), g.z['out/atom_rep']) < TOL
+    kind = g.meta['loss']
+    if kind == 'proj':
+        loss = (out * torch.from_numpy(g.z['gout']).cuda()).sum() + \
+               (graph_rep * torch.from_numpy(g.z['gout_graph_rep']).cuda()).sum()
+    elif kind == 'bce':
+        labels = torch.from_numpy(g.z['labels']).cuda()
+        w = torch.tensor(g.z['bce_weight'], device='cuda')
+        weights = ((labels == 1).float() * w[:, 0].view(1, -1) + (labels == 0).float() * w[:, 1].view(1, -1)).view(-1)
+        non_nan = ((labels == 1).sum() + (labels == 0).sum()).float()
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(
+            out.view(-1), labels.view(-1), weight=weights, reduction='sum') / non_nan
+    else:
+        loss = torch.nn.functional.mse_loss(out.view(-1), torch.from_numpy(g.z['labels']).cuda().view(-1))
+    assert abs(float(loss.detach()) - float(g.z['out/loss'])) <= 2e-5 * max(1.0, abs(float(g.z['out/loss'])))
+    loss.backward()
+    grads = g.group('grad/')
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(grads), set(got) ^ set(grads)
+    scale = max(np.abs(v).max() for v in grads.values())
+    for k, ref in grads.items():
+        assert_grad_close(got[k], ref, scale, k, rtol=5e-5, floor=2e-6)
+    sd = model.state_dict()
+    for k, ref in g.group('sd_after/').items():
+        assert rel_err(sd[k].double().cpu(), ref) < TOL, k
+
+
+@pytest.mark.parametrize('structure,n_layers,B,n_max', [('Concate', 2, 24, 132), ('Concate', 3, 16, 60),
+                                                        ('Weighted_sum', 2, 12, 70)])
+def test_model_vs_oracle_tox21_shape(structure, n_layers, B, n_max):
+    """Tox21-like widths, large padding, against the CPU oracle on identical seeded inputs."""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    from oracle.eagcn_ref import RefEAGCN, weights_init_
+    torch.manual_seed(5)
+    w1, w2 = ([80] * 5, [140] * 5) if structure == 'Concate' else ([12] * 5, [20] * 5)
+    mb = make_batch(B=B, n_max=n_max, n_med=16, rel_channels=(28, 4, 2, 2, 2), seed=11)
+    ref = RefEAGCN(28, 24, w1, w2, 256, 64, 12, 0.0, structure=structure, n_layers=n_layers)
+    weights_init_(ref)
+    hip = EAGCN(28, 24, *w1, *w2, 256, 64, 12, 0.0, structure=structure, n_layers=n_layers).cuda()
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    cpu = mb.dense()
+    out_r, _, gr_r = ref(*cpu)
+    out_h, _, gr_h = hip(*_dev(cpu))
+    assert rel_err(out_h.detach().cpu(), out_r.detach()) < TOL
+    assert rel_err(gr_h.detach().cpu(), gr_r.detach()) < TOL
+    gsel = torch.randn(out_r.shape)
+    (out_r * gsel).sum().backward()
+    (out_h * gsel.cuda()).sum().backward()
+    gr = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    gh = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    assert set(gr) == set(gh)
+    scale = max(v.abs().max().item() for v in gr.values())
+    for k in gr:
+        assert_grad_close(gh[k], gr[k], scale, k, rtol=1e-4, floor=5e-6)
+
+
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0)])
+@pytest.mark.parametrize('M,N,K', [(100, 64, 24), (1000, 704, 400), (37, 16, 8), (4608, 400, 704)])
+def test_gemm_f32(ta, tb, M, N, K):
+    from eagcn_amd import ops
+    if ta and M % 4:
+        M = (M + 3) // 4 * 4
+    torch.manual_seed(1)
+    a = torch.randn((K, M) if ta else (M, K), device='cuda')
+    b = torch.randn((N, K) if tb else (K, N), device='cuda')
+    c = ops.gemm(a, b, bool(ta), bool(tb))
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    assert rel_err(c.double().cpu(), ref.cpu()) < 2e-6
+
+
+def test_bad_inputs_raise():
+    from eagcn_amd import ops
+    from eagcn_amd._lib import EagcnHipError
+    from eagcn_amd.synthetic import make_batch
+    mb = make_batch(B=3, n_max=9, n_med=5, rel_channels=(4, 4, 2, 2, 2), seed=2)
+    d = _dev(mb.dense())
+    adj = d[0].clone()
+    adj[0, 0, 1] = 0.5
+    with pytest.raises(EagcnHipError):
+        ops.BatchIndex(adj, d[2:-1])
+    r = d[2].clone()
+    e = mb.edges[0]
+    r[e[0], :, e[1], e[2]] = 1.0                     # two hot channels on a bond
+    with pytest.raises(EagcnHipError):
+        ops.BatchIndex(d[0], [r] + d[3:-1])
+    with pytest.raises(EagcnHipError):
+        ops.BatchIndex(d[0].cpu(), [t.cpu() for t in d[2:-1]])       # no CPU path
