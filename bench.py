@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: molecules/sec, forward + backward, 2-layer 5-view Concate EAGCN on a
+Tox21-shaped synthetic batch (BASELINE.json metric; SURVEY.md 8d measurement plan).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch resident in HBM: batch index build from the
+reference's dense collate tensors, all graph-conv layers forward, read-out + head, the train.py loss,
+full backward (gradients of every parameter), and for N > 1 the gradient all-reduce.  The optimizer
+is excluded.  Weak scaling: every rank processes its own batch of `--batch` molecules.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: Tox21 12-task, 2-layer 5-view Concate, batch 256 (fp32 here)
+    'tox21_c2': dict(structure='Concate', n_layers=2, widths1=[80] * 5, widths2=[140] * 5, dens=(256, 64),
+                     nclass=12, n_bfeat=28, batch=256, n_max=132, n_med=16, task='class'),
+    # configs[2]: HIV, 2-layer Weighted_sum, batch 1024, N=222
+    'hiv_c3': dict(structure='Weighted_sum', n_layers=2, widths1=[100] * 5, widths2=[250] * 5, dens=(512, 128),
+                   nclass=1, n_bfeat=28, batch=1024, n_max=222, n_med=23, task='class'),
+    # configs[3]: Lipophilicity regression, 3-layer Concate, batch 4096 over 8 GPUs (512 / GPU)
+    'lipo_c4': dict(structure='Concate', n_layers=3, widths1=[60] * 5, widths2=[100] * 5, dens=(128, 64),
+                    nclass=1, n_bfeat=18, batch=512, n_max=115, n_med=27, task='reg'),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(cfg, dropout, device):
+    from eagcn_amd import EAGCN, weights_init
+    m = EAGCN(cfg['n_bfeat'], 24, *cfg['widths1'], *cfg['widths2'], cfg['dens'][0], cfg['dens'][1], cfg['nclass'],
+              dropout, structure=cfg['structure'], n_layers=cfg['n_layers'], atom_rep='lazy')
+    m.apply(weights_init)
+    return m.to(device)
+
+
+def algorithmic_flops(cfg, sizes):
+    """per molecule, true atom count n, cheaper association per layer, bwd = 2x fwd."""
+    K = len(cfg['widths1'])
+    w1, w2 = list(cfg['widths1']), list(cfg['widths2'])
+    if cfg['structure'] == 'Weighted_sum':
+        w1, w2 = [sum(w1)] * K, [sum(w2)] * K
+        f1, f2 = w1[0], w2[0]
+    else:
+        f1, f2 = sum(w1), sum(w2)
+    w3 = [2 * w for w in w2]
+    plan = [(24, w1, f1), (f1, w2, f2), (f2, w3, 2 * f2), (2 * f2, w3, 2 * f2)][:cfg['n_layers']]
+    total = 0.0
+    for n in sizes:
+        n = float(n)
+        for fin, ws, _ in plan:
+            for fk in ws:
+                total += min(2 * n * n * fin + 2 * n * fin * fk, 2 * n * fin * fk + 2 * n * n * fk)
+        f_last = plan[-1][2]
+        total += 2 * (f_last * cfg['dens'][0] + cfg['dens'][0] * cfg['dens'][1] + cfg['dens'][1] * cfg['nclass'])
+    return 3.0 * total
+
+
+def cpu_baseline(cfg, mb, dropout, bce_w, steps=5, warmup=2):
+    """The CPU oracle (oracle/eagcn_ref.py, kind 'port') timed on this host, same workload."""
+    from oracle.eagcn_ref import RefEAGCN, classification_loss, regression_loss, weights_init_
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    model = RefEAGCN(cfg['n_bfeat'], 24, cfg['widths1'], cfg['widths2'], cfg['dens'][0], cfg['dens'][1],
+                     cfg['nclass'], dropout, structure=cfg['structure'], n_layers=cfg['n_layers'])
+    weights_init_(model)
+    dense = mb.dense('cpu')
+    labels = torch.from_numpy(mb.labels)
+    ts = []
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
+        model.zero_grad(set_to_none=True)
+        out, _, _ = model(*dense)
+        loss = classification_loss(out, labels, bce_w) if cfg['task'] == 'class' else regression_loss(out, labels)
+        loss.backward()
+        if i >= warmup:
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    model_name = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    model_name = line.split(':', 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    return {'value': mb.B / med, 'unit': 'molecules/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed fwd+bwd steps (median, after %d warm-up) of the same %d-molecule batch, '
+                      'oracle/eagcn_ref.py RefEAGCN on torch %s CPU, %d threads, %s'
+                      % (steps, warmup, mb.B, torch.__version__, cores, model_name or 'unknown CPU')}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='tox21_c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=None, help='molecules per GPU (default: the config\'s)')
+    ap.add_argument('--dropout', type=float, default=0.3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=5)
+    args = ap.parse_args()
+
+    from eagcn_amd import _lib
+    from eagcn_amd.losses import classification_loss, regression_loss
+    from eagcn_amd.parallel import GradientAllReducer, init_distributed
+    from eagcn_amd.synthetic import bce_weights, make_batch
+    lib = _lib.load()                                    # fail loudly if the HIP library is missing
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU path')
+    rank, world, local = init_distributed()
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    cfg = dict(WORKLOADS[args.workload])
+    B = args.batch or cfg['batch']
+    torch.manual_seed(1234 + rank)
+    mb = make_batch(B=B, n_max=cfg['n_max'], n_med=cfg['n_med'], rel_channels=(cfg['n_bfeat'], 4, 2, 2, 2),
+                    seed=1234 + rank, n_tasks=cfg['nclass'], task=cfg['task'])
+    dense = mb.dense(dev)
+    labels = torch.from_numpy(mb.labels).to(dev)
+    bce_w = bce_weights(cfg['nclass'])
+    bce_w_dev = torch.tensor(bce_w, dtype=torch.float32, device=dev)
+    model = build_model(cfg, args.dropout, dev)
+    model.train()
+    reducer = GradientAllReducer(model.parameters())
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out, _, _ = model(*dense)
+        if cfg['task'] == 'class':
+            loss = classification_loss(out, labels, bce_w_dev)
+        else:
+            loss = regression_loss(out, labels)
+        loss.backward()
+        reducer()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lib.eagcn_prof_reset()
+    lib.eagcn_prof_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lib.eagcn_prof_enable(0)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if not torch.isfinite(loss.detach()).item():
+        raise SystemExit('non-finite loss')
+
+    # per-kernel-class time from HIP events recorded on the launch stream inside the timed region
+    kern = {}
+    for tag in range(lib.eagcn_prof_ntags()):
+        ms, work, n = C.c_double(), C.c_double(), C.c_int64()
+        lib.eagcn_prof_read(tag, C.byref(ms), C.byref(work), C.byref(n))
+        kern[lib.eagcn_prof_tag_name(tag).decode()] = (ms.value, work.value, n.value)
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        g_ms, g_work, g_n = kern['gemm']
+        achieved = (g_work / (g_ms * 1e-3)) / 1e12 if g_ms > 0 else 0.0
+        out = {
+            'metric': 'molecules/sec fwd+bwd, 2-layer 5-view EAGCN, Tox21 batch' if args.workload == 'tox21_c2'
+                      else 'molecules/sec fwd+bwd, EAGCN %s' % args.workload,
+            'value': round(value, 1), 'unit': 'molecules/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s: %s, %d-layer %d-view, widths %s/%s, %d tasks, batch %d per GPU, '
+                                   'N_pad %d, dropout %.2f, loss %s' %
+                                   (args.workload, cfg['structure'], cfg['n_layers'], len(cfg['widths1']),
+                                    cfg['widths1'][0], cfg['widths2'][0], cfg['nclass'], B, mb.N, args.dropout,
+                                    'weighted BCE' if cfg['task'] == 'class' else 'MSE'),
+                       'global_batch': world * B, 'atoms_per_batch': int(mb.sizes.sum()),
+                       'parallelism': 'dp%d' % world},
+            'algorithmic_gflop_per_step': round(algorithmic_flops(cfg, mb.sizes) / 1e9, 3),
+            'roofline': {'kernel': 'gemm_f32_kernel (flat X.[W_1..W_K] transform + its two backward products)',
+                         'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'launches': int(g_n), 'avg_launch_us': round(g_ms * 1e3 / max(g_n, 1), 3)},
+            'kernel_ms_per_step': {k: round(v[0] / args.steps, 4) for k, v in kern.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg, mb, args.dropout, bce_w, steps=args.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

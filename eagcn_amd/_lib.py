@@ -76,6 +76,11 @@ SIGNATURES = {
                                          _fp, _fp, _fp]),
     'eagcn_gemm_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int,
                                  _fp, C.c_int, _fp]),
+    'eagcn_prof_enable': (None, [C.c_int]),
+    'eagcn_prof_reset': (None, []),
+    'eagcn_prof_ntags': (C.c_int, []),
+    'eagcn_prof_tag_name': (C.c_char_p, [C.c_int]),
+    'eagcn_prof_read': (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -188,6 +188,7 @@ int launch_agg(AggArgs a, bool trans, hipStream_t s) {
     const int ct = cdiv(tmax, nchunk);
     a.nchunk = nchunk;
     dim3 grid(agg_grid_x(&a.bt), a.vc.K * nchunk);
+    ProfScope ps(PROF_AGG, s);
     return trans ? launch_agg_t<true>(a, ct, grid, s) : launch_agg_t<false>(a, ct, grid, s);
 }
 
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
 int launch_edge_grad(const EdgeArgs& a, hipStream_t s) {
     if (a.bt.T == 0) return EAGCN_OK;
     dim3 grid(std::min(cdiv(a.bt.T, 4), 1024), a.vc.K);
+    ProfScope ps(PROF_EDGE, s);
     edge_grad_kernel<<<grid, 256, 0, s>>>(a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;

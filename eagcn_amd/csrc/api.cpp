@@ -1,6 +1,10 @@
 // Library-level pieces of the C ABI: version, error string.
+#include <hip/hip_runtime_api.h>
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
+
+#include <vector>
 
 #include "../../include/eagcn_hip.h"
 
@@ -12,7 +16,61 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- per-kernel-class timing ---------------------------------------------------------------------
+enum { PROF_NTAGS = 7 };
+static const char* kTagNames[PROF_NTAGS] = {"index", "pack", "gemm", "agg", "bn", "edge", "readout"};
+struct ProfRec { hipEvent_t a, b; };
+struct ProfState {
+    bool on = false;
+    std::vector<ProfRec> pool[PROF_NTAGS];
+    size_t used[PROF_NTAGS] = {0};
+    double work[PROF_NTAGS] = {0};
+};
+static ProfState g_prof;
+bool prof_on() { return g_prof.on; }
+void prof_begin(int tag, hipStream_t s, double work) {
+    ProfState& p = g_prof;
+    if (p.used[tag] == p.pool[tag].size()) {
+        ProfRec r;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        p.pool[tag].push_back(r);
+    }
+    p.work[tag] += work;
+    (void)hipEventRecord(p.pool[tag][p.used[tag]].a, s);
+}
+void prof_end(int tag, hipStream_t s) {
+    ProfState& p = g_prof;
+    if (p.used[tag] >= p.pool[tag].size()) return;
+    (void)hipEventRecord(p.pool[tag][p.used[tag]].b, s);
+    p.used[tag]++;
+}
 }  // namespace eagcn
+
+extern "C" void eagcn_prof_enable(int on) { eagcn::g_prof.on = on != 0; }
+extern "C" void eagcn_prof_reset(void) {
+    for (int t = 0; t < eagcn::PROF_NTAGS; ++t) { eagcn::g_prof.used[t] = 0; eagcn::g_prof.work[t] = 0.0; }
+}
+extern "C" int eagcn_prof_ntags(void) { return eagcn::PROF_NTAGS; }
+extern "C" const char* eagcn_prof_tag_name(int tag) {
+    return (tag >= 0 && tag < eagcn::PROF_NTAGS) ? eagcn::kTagNames[tag] : "";
+}
+/* blocks until the recorded events have completed */
+extern "C" int eagcn_prof_read(int tag, double* total_ms, double* work, int64_t* launches) {
+    if (tag < 0 || tag >= eagcn::PROF_NTAGS) return -1;
+    eagcn::ProfState& p = eagcn::g_prof;
+    double ms = 0.0;
+    for (size_t i = 0; i < p.used[tag]; ++i) {
+        float e = 0.f;
+        if (hipEventSynchronize(p.pool[tag][i].b) != hipSuccess) return -2;
+        if (hipEventElapsedTime(&e, p.pool[tag][i].a, p.pool[tag][i].b) != hipSuccess) return -2;
+        ms += e;
+    }
+    if (total_ms) *total_ms = ms;
+    if (work) *work = p.work[tag];
+    if (launches) *launches = (int64_t)p.used[tag];
+    return 0;
+}
 
 extern "C" int eagcn_abi_version(void) { return 1; }
 extern "C" const char* eagcn_last_error(void) { return eagcn::g_err; }

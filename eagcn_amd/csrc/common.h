@@ -110,6 +110,17 @@ inline int layout_width(const eagcn_layout* l) {
     return s;
 }
 
+// ---- optional per-kernel-class timing (HIP events on the launch stream), off by default --------
+enum ProfTag { PROF_INDEX = 0, PROF_PACK, PROF_GEMM, PROF_AGG, PROF_BN, PROF_EDGE, PROF_READOUT, PROF_NTAGS };
+bool prof_on();
+void prof_begin(int tag, hipStream_t s, double work);
+void prof_end(int tag, hipStream_t s);
+struct ProfScope {
+    int tag; hipStream_t s; bool on;
+    ProfScope(int t, hipStream_t st, double work = 0.0) : tag(t), s(st), on(prof_on()) { if (on) prof_begin(tag, s, work); }
+    ~ProfScope() { if (on) prof_end(tag, s); }
+};
+
 // ---- internal launchers (defined across the .hip files) -----------------------------------------
 struct GemmDesc {
     int ta, tb;            // 0: stored as used ([M][K] / [K][N]); 1: transposed storage
@@ -119,6 +130,7 @@ struct GemmDesc {
     float* C; int ldc;
     int splits;            // split-K: partial z written at C + z*slab
     size_t slab;           // floats between partial slabs
+    double work = 0.0;     // algorithmic flops of this product (0 -> 2*M*N*K)
 };
 int launch_gemm(const GemmDesc& g, hipStream_t s);
 

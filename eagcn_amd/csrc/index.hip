@@ -209,6 +209,7 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
                             EAGCN_MAX_CHANNELS);
         }
     }
+    ProfScope ps(PROF_INDEX, s);
     EAGCN_HIP(hipMemsetAsync(b->meta, 0, EAGCN_META_WORDS * sizeof(int32_t), s));
     index_scan_kernel<<<b->B, 256, 0, s>>>(adj, rp, b->B, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->meta);
     EAGCN_LAUNCH_CHECK();
@@ -224,6 +225,7 @@ extern "C" int eagcn_index_rows(const eagcn_batch* b, void* stream) {
     if (b->T == 0) return EAGCN_OK;
     EAGCN_CHECK_ARG(b->row_mol && b->row_loc && b->row_m && b->row_deg && b->tile_mol,
                     "eagcn_index_rows: per-row buffers not allocated");
+    ProfScope ps(PROF_INDEX, s);
     index_rows_kernel<<<b->B, 256, 0, s>>>(*b);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
@@ -238,6 +240,7 @@ extern "C" int eagcn_pack_rows(const eagcn_batch* b, const float* dense, int F, 
     int ld = layout_ld(lay);
     size_t total = (size_t)b->T * ld;
     int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+    ProfScope ps(PROF_PACK, s);
     pack_rows_kernel<<<grid, 256, 0, s>>>(*b, dense, F, make_colmap(lay), ld, packed);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
@@ -252,6 +255,7 @@ extern "C" int eagcn_unpack_rows(const eagcn_batch* b, const float* packed, cons
     int ld = layout_ld(lay);
     size_t total = (size_t)b->B * b->N * F;
     int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+    ProfScope ps(PROF_PACK, s);
     unpack_rows_kernel<<<grid, 256, 0, s>>>(*b, packed, make_colmap(lay), ld, pad_row, dense, F);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;

@@ -490,11 +490,18 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
     }
     const ParamPtrs pp = param_ptrs(b, p);
     const ColMapD in = make_colmap(&p->in);
-    pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.colp, sc.sig, sc.rsig);
+    {
+        ProfScope ps(PROF_PACK, s);
+        pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.colp, sc.sig, sc.rsig);
+    }
     EAGCN_LAUNCH_CHECK();
+    // algorithmic flops of the flat transform: exact widths, packed rows
+    double fsum = 0.0;
+    for (int k = 0; k < p->K; ++k) fsum += p->width[k];
+    const double gemm_work = 2.0 * (double)b->T * (double)d.fin * fsum;
     int nslab = 0;
     if (b->T > 0) {
-        GemmDesc g{0, 0, b->T, d.fp, d.ld_in, w->x, d.ld_in, sc.Wcat, d.fp, w->P, d.fp, 1, 0};
+        GemmDesc g{0, 0, b->T, d.fp, d.ld_in, w->x, d.ld_in, sc.Wcat, d.fp, w->P, d.fp, 1, 0, gemm_work};
         rc = launch_gemm(g, s);
         if (rc) return rc;
         AggArgs a;
@@ -505,6 +512,7 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
         nslab = d.gx;
     }
     const double M = (double)b->B * (double)b->N;
+    ProfScope psbn(PROF_BN, s);
     bn_finalize_kernel<<<cdiv(d.fp, 256), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
                                                         p->bn_momentum, sc.colp, pp, d.vc, w->bn);
     EAGCN_LAUNCH_CHECK();
@@ -547,8 +555,14 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
     }
     gp.dave_w = p->structure == EAGCN_STRUCT_WEIGHTED ? g->dave_w : nullptr;
     const ColMapD in = make_colmap(&p->in);
-    pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.colp, sc.sig, sc.rsig);
+    {
+        ProfScope ps(PROF_PACK, s);
+        pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.colp, sc.sig, sc.rsig);
+    }
     EAGCN_LAUNCH_CHECK();
+    double fsum = 0.0;
+    for (int k = 0; k < p->K; ++k) fsum += p->width[k];
+    const double gemm_work = 2.0 * (double)b->T * (double)d.fin * fsum;
     EAGCN_HIP(hipMemsetAsync(sc.datt, 0, (char*)(sc.dr + EAGCN_MAX_VIEWS) - (char*)sc.datt, s));
 
     BwdArgs ba;
@@ -562,16 +576,21 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
     ba.seed = p->seed;
     const int rows = b->T + ba.nvirt;
     const int gxb = std::max(1, std::min(rows, d.gxb));
-    bn_bwd_reduce_kernel<<<gxb, 256, 0, s>>>(ba);
-    EAGCN_LAUNCH_CHECK();
     const double M = (double)b->B * (double)b->N;
-    bn_bwd_finalize_kernel<<<cdiv(d.fp, 256), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
-                                                            d.vc, gp, sc.cc);
-    EAGCN_LAUNCH_CHECK();
+    {
+        ProfScope ps(PROF_BN, s);
+        bn_bwd_reduce_kernel<<<gxb, 256, 0, s>>>(ba);
+        EAGCN_LAUNCH_CHECK();
+        bn_bwd_finalize_kernel<<<cdiv(d.fp, 256), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
+                                                                d.vc, gp, sc.cc);
+        EAGCN_LAUNCH_CHECK();
+        if (b->T > 0) {
+            bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(b->T, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
+            EAGCN_LAUNCH_CHECK();
+        }
+    }
     int nsplit = 0;
     if (b->T > 0) {
-        bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(b->T, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
-        EAGCN_LAUNCH_CHECK();
         AggArgs a;
         a.bt = *b; a.vc = d.vc; a.src = sc.dY; a.lds = d.fp; a.dst = sc.dP; a.ldd = d.fp;
         a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = nullptr; a.nchunk = 1;
@@ -583,15 +602,16 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
         rc = launch_edge_grad(e, s);
         if (rc) return rc;
         nsplit = d.nsplit;
-        GemmDesc gw{1, 0, d.ld_in, d.fp, b->T, w->x, d.ld_in, sc.dP, d.fp, sc.dWcat, d.fp, nsplit, d.wslab};
+        GemmDesc gw{1, 0, d.ld_in, d.fp, b->T, w->x, d.ld_in, sc.dP, d.fp, sc.dWcat, d.fp, nsplit, d.wslab, gemm_work};
         rc = launch_gemm(gw, s);
         if (rc) return rc;
         if (dx) {
-            GemmDesc gx{0, 1, b->T, d.ld_in, d.fp, sc.dP, d.fp, sc.Wcat, d.fp, dx, d.ld_in, 1, 0};
+            GemmDesc gx{0, 1, b->T, d.ld_in, d.fp, sc.dP, d.fp, sc.Wcat, d.fp, dx, d.ld_in, 1, 0, gemm_work};
             rc = launch_gemm(gx, s);
             if (rc) return rc;
         }
     }
+    ProfScope psu(PROF_PACK, s);
     unpack_grads_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat, nsplit, d.wslab,
                                                         sc.datt, sc.dr, sc.rsig);
     EAGCN_LAUNCH_CHECK();

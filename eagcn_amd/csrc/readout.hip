@@ -88,6 +88,7 @@ extern "C" int eagcn_readout_forward(const eagcn_batch* b, const float* x, const
     EAGCN_CHECK_ARG(b->T == 0 || x, "eagcn_readout_forward: null activations");
     EAGCN_CHECK_ARG(layout_width(lay) == F, "eagcn_readout_forward: layout width %d != F %d", layout_width(lay), F);
     EAGCN_CHECK_ARG(mode == 0 || (mode == 1 && size), "eagcn_readout_forward: mode 1 ('ave') needs size");
+    ProfScope ps(PROF_READOUT, s);
     readout_fwd_kernel<<<b->B, 256, 0, s>>>(*b, x, make_colmap(lay), layout_ld(lay), pad_row, size, mode, g, F);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
@@ -101,6 +102,7 @@ extern "C" int eagcn_readout_backward(const eagcn_batch* b, const float* dg, con
     EAGCN_CHECK_ARG(b->T == 0 || dx, "eagcn_readout_backward: null dx");
     EAGCN_CHECK_ARG(layout_width(lay) == F, "eagcn_readout_backward: layout width %d != F %d", layout_width(lay), F);
     EAGCN_CHECK_ARG(mode == 0 || (mode == 1 && size), "eagcn_readout_backward: mode 1 ('ave') needs size");
+    ProfScope ps(PROF_READOUT, s);
     readout_bwd_kernel<<<b->B, 256, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size, mode, F, dx);
     EAGCN_LAUNCH_CHECK();
     if (dpad_row) {

@@ -178,6 +178,15 @@ int eagcn_readout_backward(const eagcn_batch* b, const float* dg, const eagcn_la
 int eagcn_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
                    int ldb, float* C, int ldc, void* stream);
 
+/* ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline) -- */
+void eagcn_prof_enable(int on);
+void eagcn_prof_reset(void);
+int eagcn_prof_ntags(void);
+const char* eagcn_prof_tag_name(int tag);
+/* sums event-pair durations of class `tag` since the last reset (waits for them); work = summed
+ * algorithmic flops for the gemm class */
+int eagcn_prof_read(int tag, double* total_ms, double* work, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,32 @@ def _hip_model(meta, n_layers=4):
                  n_layers=n_layers)
 
 
+def _f64_grads(g):
+    """Parameter gradients of a golden model case evaluated by the oracle in float64."""
+    from oracle.eagcn_ref import classification_loss, regression_loss
+    model = build_oracle_model(g.meta).double()
+    model.load_state_dict({k: v.double() for k, v in g.state_dict().items()}, strict=True)
+    model.train(g.meta['training'])
+    dense = g.batch.dense()
+    adj, afm, rels, size = dense[0].double(), dense[1].double(), [r.double() for r in dense[2:-1]], dense[-1]
+    out, _, graph_rep = model(adj, afm, *rels, size)
+    kind = g.meta['loss']
+    if kind == 'proj':
+        loss = (out * torch.from_numpy(g.z['gout']).double()).sum() + \
+               (graph_rep * torch.from_numpy(g.z['gout_graph_rep']).double()).sum()
+    elif kind == 'bce':
+        labels = torch.from_numpy(g.z['labels'])
+        w = torch.tensor(g.z['bce_weight']).double()
+        weights = ((labels == 1).double() * w[:, 0].view(1, -1) + (labels == 0).double() * w[:, 1].view(1, -1)).view(-1)
+        non_nan = ((labels == 1).sum() + (labels == 0).sum()).double()
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(
+            out.view(-1), labels.double().view(-1), weight=weights, reduction='sum') / non_nan
+    else:
+        loss = torch.nn.functional.mse_loss(out.view(-1), torch.from_numpy(g.z['labels']).double().view(-1))
+    loss.backward()
+    return {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+
+
 @pytest.mark.parametrize('name', golden_cases('layer'))
 def test_layer_golden(name):
     from eagcn_amd import GraphConv_Layer
@@ -91,8 +117,19 @@ def test_model_golden(name):
     got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
     assert set(got) == set(grads), set(got) ^ set(grads)
     scale = max(np.abs(v).max() for v in grads.values())
+    f64 = None
     for k, ref in grads.items():
-        assert_grad_close(got[k], ref, scale, k, rtol=5e-5, floor=2e-6)
+        try:
+            assert_grad_close(got[k], ref, scale, k, rtol=2e-5, floor=2e-6)
+        except AssertionError:
+            # ill-conditioned case (BatchNorm over a few dozen rows, 4 layers deep): arbitrate with the
+            # oracle in float64 -- the HIP result may not be further from the exact gradient than
+            # 4x the reference's own fp32 rounding error
+            if f64 is None:
+                f64 = _f64_grads(g)
+            e_ref = (torch.from_numpy(ref).double() - f64[k]).abs().max().item()
+            e_hip = (got[k].double().cpu() - f64[k]).abs().max().item()
+            assert e_hip <= 4.0 * e_ref + 2e-6 * scale, (k, e_hip, e_ref)
     sd = model.state_dict()
     for k, ref in g.group('sd_after/').items():
         assert rel_err(sd[k].double().cpu(), ref) < TOL, k
