@@ -39,7 +39,7 @@ def build_library(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, 'obj')
     os.makedirs(objdir, exist_ok=True)
-    flags = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+    flags = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-munsafe-fp-atomics']
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')

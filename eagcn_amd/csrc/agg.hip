@@ -63,6 +63,16 @@ __global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
                 uint4 cw = make_uint4(0u, 0u, 0u, 0u);
                 if (ia < n) cw = *reinterpret_cast<const uint4*>(codeb + (size_t)ia * bt.ldc + j0);
                 const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+                // all B-operand loads of the next four k-steps are issued before the first MFMA so
+                // the L1/L2 latency is paid once per 16 columns, not once per k-step
+                float bv[4][CT];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int j = j0 + 4 * t + q;
+                    const float* srow = sbase + (size_t)min(j, n - 1) * a.lds;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) bv[t][ct] = (j < n && ct < nct) ? srow[ct * 16] : 0.0f;
+                }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int jb = j0 + 4 * t;
@@ -73,13 +83,9 @@ __global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
                         if (j == ia) u += r * mi;
                         if (j >= n || ia >= n) u = 0.0f;
                         dsum += u;
-                        const float* srow = sbase + (size_t)min(j, n - 1) * a.lds;
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct)
-                            if (ct < nct) {
-                                const float bv = (j < n) ? srow[ct * 16] : 0.0f;
-                                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv, acc[ct], 0, 0, 0);
-                            }
+                            if (ct < nct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv[t][ct], acc[ct], 0, 0, 0);
                     }
                 }
             }
@@ -107,24 +113,34 @@ __global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
                 }
         } else {
             // dP[j,:] = sum_i A^[i,j] dY'[i,:]  (rscale carries m_i / rowsum_i)
-            for (int i0 = 0; i0 < n; i0 += 4) {
-                const int i = i0 + q;
-                uint32_t c = 0u;
-                float rs = 0.0f;
-                if (i < n && ia < n) {
-                    c = codeb[(size_t)i * bt.ldc + ia];
-                    rs = a.rscale[(size_t)k * bt.T + r0 + i];
-                }
-                float u = sig_s[c] + (c == 0u ? TINY : 0.0f);
-                if (i == ia) u += r;
-                u *= rs;
-                const float* srow = sbase + (size_t)min(i, n - 1) * a.lds;
+            for (int i0 = 0; i0 < n; i0 += 16) {
+                uint32_t cc4[4];
+                float rs4[4], bv[4][CT];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    if (ct < nct) {
-                        const float bv = (i < n) ? srow[ct * 16] : 0.0f;
-                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv, acc[ct], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) {
+                    const int i = i0 + 4 * t + q;
+                    cc4[t] = 0u;
+                    rs4[t] = 0.0f;
+                    if (i < n && ia < n) {
+                        cc4[t] = codeb[(size_t)i * bt.ldc + ia];
+                        rs4[t] = a.rscale[(size_t)k * bt.T + r0 + i];
                     }
+                    const float* srow = sbase + (size_t)min(i, n - 1) * a.lds;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) bv[t][ct] = (i < n && ct < nct) ? srow[ct * 16] : 0.0f;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (i0 + 4 * t < n) {
+                        const int i = i0 + 4 * t + q;
+                        float u = sig_s[cc4[t]] + (cc4[t] == 0u ? TINY : 0.0f);
+                        if (i == ia) u += r;
+                        u *= rs4[t];
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            if (ct < nct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv[t][ct], acc[ct], 0, 0, 0);
+                    }
+                }
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
@@ -249,16 +265,17 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
     }
     if (lane == 0) dr_s[wave] = dr_acc;
     __syncthreads();
-    if (h_s[tid] != 0.0) atomicAdd(&a.datt[k * 256 + tid], h_s[tid]);
-    if (tid == 0) {
-        const double t = dr_s[0] + dr_s[1] + dr_s[2] + dr_s[3];
-        if (t != 0.0) atomicAdd(&a.dr[k], t);
-    }
+    // slab[blockIdx.x][k][0..255] = bond-type histogram, slab[..][k][256] = self term
+    double* out = a.datt + ((size_t)blockIdx.x * a.vc.K + k) * EDGE_SLAB;
+    out[tid] = h_s[tid];
+    if (tid == 0) out[256] = dr_s[0] + dr_s[1] + dr_s[2] + dr_s[3];
 }
+
+int edge_grid_x(const eagcn_batch* b) { return std::max(1, std::min(cdiv(b->T, 4), 256)); }
 
 int launch_edge_grad(const EdgeArgs& a, hipStream_t s) {
     if (a.bt.T == 0) return EAGCN_OK;
-    dim3 grid(std::min(cdiv(a.bt.T, 4), 1024), a.vc.K);
+    dim3 grid(edge_grid_x(&a.bt), a.vc.K);
     ProfScope ps(PROF_EDGE, s);
     edge_grad_kernel<<<grid, 256, 0, s>>>(a);
     EAGCN_LAUNCH_CHECK();

@@ -21,61 +21,57 @@ struct RelPtrs {
     int c[EAGCN_MAX_VIEWS];
 };
 
-// one workgroup per molecule, one wave per row (4 rows in flight)
+// one wavefront per padded row (b,i): B*N independent waves keep the adj stream and the sparse
+// channel gather in flight (a one-workgroup-per-molecule version was latency-bound at 650 us).
 __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict__ adj, RelPtrs rel,
                                                           int B, int N, int K, int ldc,
                                                           uint8_t* __restrict__ code,
                                                           int32_t* __restrict__ deg_bn,
                                                           int32_t* __restrict__ nat,
                                                           int32_t* __restrict__ meta) {
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* adjb = adj + (size_t)b * N * N;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // b*N + i
+    if (row >= (long)B * N) return;
+    const int b = (int)(row / N), i = (int)(row % N);
+    const float* arow = adj + (size_t)row * N;
     const size_t plane = (size_t)N * N;
-    __shared__ int s_last[4];
-    __shared__ int s_edges[4];
-    int last = -1, bad_adj = 0, bad_rel = 0, edges = 0;
-    for (int i = wave; i < N; i += 4) {
-        int deg = 0;
-        for (int j = lane; j < ldc; j += 64) {
-            float a = (j < N) ? adjb[(size_t)i * N + j] : 0.0f;
-            const bool bond = (a != 0.0f);
-            if (bond && a != 1.0f) ++bad_adj;
-            deg += bond ? 1 : 0;
-            for (int k = 0; k < K; ++k) {
-                int c = 0;
-                if (bond) {
-                    const float* r = rel.p[k] + (size_t)b * rel.c[k] * plane + (size_t)i * N + j;
-                    int ones = 0, other = 0, hot = 0;
-                    for (int ch = 0; ch < rel.c[k]; ++ch) {
-                        float v = r[(size_t)ch * plane];
-                        if (v == 1.0f) { ++ones; hot = ch; }
-                        else if (v != 0.0f) ++other;
-                    }
-                    if (ones != 1 || other != 0) ++bad_rel;
-                    c = hot + 1;
+    int deg = 0, bad_adj = 0, bad_rel = 0;
+    for (int j = lane; j < ldc; j += 64) {
+        const float a = (j < N) ? arow[j] : 0.0f;
+        const bool bond = (a != 0.0f);
+        if (bond && a != 1.0f) ++bad_adj;
+        deg += bond ? 1 : 0;
+        for (int k = 0; k < K; ++k) {
+            int c = 0;
+            if (bond) {
+                const float* r = rel.p[k] + (size_t)b * rel.c[k] * plane + (size_t)i * N + j;
+                int ones = 0, other = 0, hot = 0;
+                // branch-free and unrolled: 8 independent strided loads in flight per lane
+#pragma unroll 8
+                for (int ch = 0; ch < rel.c[k]; ++ch) {
+                    const float v = r[(size_t)ch * plane];
+                    const bool one = (v == 1.0f);
+                    ones += one ? 1 : 0;
+                    hot = one ? ch : hot;
+                    other += (v != 0.0f && !one) ? 1 : 0;
                 }
-                code[(((size_t)k * B + b) * N + i) * ldc + j] = (uint8_t)c;
+                if (ones != 1 || other != 0) ++bad_rel;
+                c = hot + 1;
             }
+            code[(((size_t)k * B + b) * N + i) * ldc + j] = (uint8_t)c;
         }
-        deg = wave_sum(deg);
-        if (lane == 0) deg_bn[(size_t)b * N + i] = deg;
-        if (deg > 0) last = i;
-        edges += deg;
     }
+    deg = wave_sum(deg);
     bad_adj = wave_sum(bad_adj);
     bad_rel = wave_sum(bad_rel);
     if (lane == 0) {
-        s_last[wave] = last;
-        s_edges[wave] = edges;
+        deg_bn[row] = deg;
+        if (deg > 0) {
+            atomicMax(&nat[b], i + 1);
+            atomicAdd(&meta[EAGCN_META_NEDGE], deg);
+        }
         if (bad_adj) atomicAdd(&meta[EAGCN_META_BAD_ADJ], bad_adj);
         if (bad_rel) atomicAdd(&meta[EAGCN_META_BAD_REL], bad_rel);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int l = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-        nat[b] = l + 1;
-        atomicAdd(&meta[EAGCN_META_NEDGE], s_edges[0] + s_edges[1] + s_edges[2] + s_edges[3]);
     }
 }
 
@@ -211,7 +207,9 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     }
     ProfScope ps(PROF_INDEX, s);
     EAGCN_HIP(hipMemsetAsync(b->meta, 0, EAGCN_META_WORDS * sizeof(int32_t), s));
-    index_scan_kernel<<<b->B, 256, 0, s>>>(adj, rp, b->B, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->meta);
+    EAGCN_HIP(hipMemsetAsync(b->nat, 0, (size_t)b->B * sizeof(int32_t), s));
+    const long rows = (long)b->B * b->N;
+    index_scan_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(adj, rp, b->B, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->meta);
     EAGCN_LAUNCH_CHECK();
     index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->row0, b->tile0, b->meta);
     EAGCN_LAUNCH_CHECK();

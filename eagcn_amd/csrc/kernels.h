@@ -23,9 +23,10 @@ struct EdgeArgs {
     ViewCols vc;
     const float* dY; const float* Y; const float* P; int ld;
     const float* sig; const float* rsig; const float* rscale;
-    double* datt;                // [K][256] accumulated d/d(att weight) by code
-    double* dr;                  // [K] accumulated dU_ii sums
+    double* datt;                // [grid.x][K][EDGE_SLAB] per-workgroup partials: 256 codes + self term
 };
+constexpr int EDGE_SLAB = 264;
+int edge_grid_x(const eagcn_batch* b);
 int launch_edge_grad(const EdgeArgs& a, hipStream_t s);
 
 struct ColMapD {                 // exact <-> packed column map of a layout

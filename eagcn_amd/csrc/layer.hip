@@ -90,23 +90,38 @@ __global__ __launch_bounds__(256) void pack_params_kernel(ParamPtrs pp, ViewCols
     if (blockIdx.x == 0 && threadIdx.x < vc.K) rsig[threadIdx.x] = sigmoidf_(pp.self_r[threadIdx.x][0]);
 }
 
+// sum of per-workgroup partial pairs slab[s][cp][0..1] over s, 16 lanes per column
+__device__ __forceinline__ void slab_sum16(const double* __restrict__ slab, int nslab, int fp, int cp, int sl,
+                                           double& s1, double& s2) {
+    s1 = 0.0;
+    s2 = 0.0;
+    for (int s = sl; s < nslab; s += 16) {
+        s1 += slab[((size_t)s * fp + cp) * 2 + 0];
+        s2 += slab[((size_t)s * fp + cp) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+}
+
 // ---- BatchNorm forward ---------------------------------------------------------------------------
+// 16 columns per workgroup, 16 lanes per column
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ slab, int nslab, int fp,
                                                            double M, int training, float eps, float momentum,
                                                            const float* __restrict__ colp, ParamPtrs pp,
                                                            ViewCols vc, float* __restrict__ bn) {
-    const int cp = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cp >= fp) return;
+    const int cpr = blockIdx.x * 16 + (threadIdx.x >> 4), sl = threadIdx.x & 15;
+    const int cp = min(cpr, fp - 1);
+    double s1 = 0.0, s2 = 0.0;
+    if (training) slab_sum16(slab, nslab, fp, cp, sl, s1, s2);
+    if (cpr >= fp || sl != 0) return;
     const int k = col_view(vc, cp), f = cp - vc.off[k];
     const float gamma = colp[CP_GAMMA * fp + cp], beta = colp[CP_BETA * fp + cp];
     const float bias = colp[CP_BIAS * fp + cp];
     float mu, inv;
     if (training) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int s = 0; s < nslab; ++s) {
-            s1 += slab[((size_t)s * fp + cp) * 2 + 0];
-            s2 += slab[((size_t)s * fp + cp) * 2 + 1];
-        }
         const double mean = s1 / M;
         double var = s2 / M - mean * mean;
         var = var > 0.0 ? var : 0.0;
@@ -267,18 +282,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
                                                                int fp, double M, int training,
                                                                const float* __restrict__ bn, ViewCols vc,
                                                                GradPtrs gp, float* __restrict__ cc) {
-    const int cp = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cpr = blockIdx.x * 16 + (threadIdx.x >> 4), sl = threadIdx.x & 15;
+    const int cp = min(cpr, fp - 1);
     if (blockIdx.x == 0 && threadIdx.x < vc.K && gp.dave_w) {
         double t = 0.0;
         for (int s = 0; s < nslab; ++s) t += slab_da[(size_t)s * EAGCN_MAX_VIEWS + threadIdx.x];
         gp.dave_w[threadIdx.x] = (float)t;
     }
-    if (cp >= fp) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < nslab; ++s) {
-        s1 += slab[((size_t)s * fp + cp) * 2 + 0];
-        s2 += slab[((size_t)s * fp + cp) * 2 + 1];
-    }
+    double s1, s2;
+    slab_sum16(slab, nslab, fp, cp, sl, s1, s2);
+    if (cpr >= fp || sl != 0) return;
     cc[cp] = training ? (float)(s1 / M) : 0.0f;
     cc[fp + cp] = training ? (float)(s2 / M) : 0.0f;
     const int k = col_view(vc, cp), f = cp - vc.off[k];
@@ -312,28 +325,45 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int T, int fp, const 
     }
 }
 
+// grid.x = ceil(ld_in*fp / 256) blocks for dW (one thread per element, sum over the split-K slabs) followed by
+// ceil(K*EDGE_SLAB / 16) blocks for the edge-gradient partials (16 lanes per entry)
 __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtrs pp, ViewCols vc, ColMapD in,
                                                             int ld_in, int fp, const float* __restrict__ dWcat,
                                                             int nsplit, size_t slab, const double* __restrict__ datt,
-                                                            const double* __restrict__ dr,
-                                                            const float* __restrict__ rsig) {
-    const int total = ld_in * fp;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+                                                            int nedge, const float* __restrict__ rsig, int wblocks) {
+    if ((int)blockIdx.x < wblocks) {
+        const int e = blockIdx.x * blockDim.x + threadIdx.x;
+        if (e >= ld_in * fp) return;
         const int ip = e / fp, cp = e % fp;
         const int k = col_view(vc, cp), f = cp - vc.off[k];
         const int fi = packed_to_exact(in, ip);
-        if (fi < 0 || f >= vc.width[k]) continue;
-        float s = 0.0f;
-        for (int z = 0; z < nsplit; ++z) s += dWcat[(size_t)z * slab + e];
-        gp.dW[k][(size_t)fi * vc.width[k] + f] = s;
+        if (fi < 0 || f >= vc.width[k]) return;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        int z = 0;
+        for (; z + 4 <= nsplit; z += 4) {
+            s0 += dWcat[(size_t)(z + 0) * slab + e];
+            s1 += dWcat[(size_t)(z + 1) * slab + e];
+            s2 += dWcat[(size_t)(z + 2) * slab + e];
+            s3 += dWcat[(size_t)(z + 3) * slab + e];
+        }
+        for (; z < nsplit; ++z) s0 += dWcat[(size_t)z * slab + e];
+        gp.dW[k][(size_t)fi * vc.width[k] + f] = (s0 + s1) + (s2 + s3);
+        return;
     }
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < vc.K * 256; e += gridDim.x * blockDim.x) {
-        const int k = e >> 8, c = e & 255;
-        if (c >= 1 && c <= pp.channels[k]) gp.datt_w[k][c - 1] = (float)datt[e];
-    }
-    if (blockIdx.x == 0 && threadIdx.x < vc.K) {
-        const double r = (double)rsig[threadIdx.x];
-        gp.dself_r[threadIdx.x][0] = (float)(dr[threadIdx.x] * r * (1.0 - r));
+    // edge-gradient partials [nedge][K][EDGE_SLAB]: entry c in 1..C_k -> d att_w[c-1]; entry 256 -> self term
+    const int er = ((int)blockIdx.x - wblocks) * 16 + (threadIdx.x >> 4), sl = threadIdx.x & 15;
+    const int tot = vc.K * EDGE_SLAB;
+    const int e = min(er, tot - 1);
+    double t = 0.0;
+    for (int z = sl; z < nedge; z += 16) t += datt[(size_t)z * tot + e];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (er >= tot || sl != 0) return;
+    const int k = e / EDGE_SLAB, c = e % EDGE_SLAB;
+    if (c >= 1 && c <= pp.channels[k]) gp.datt_w[k][c - 1] = (float)t;
+    else if (c == 256) {
+        const double r = (double)rsig[k];
+        gp.dself_r[k][0] = (float)(t * r * (1.0 - r));
     }
 }
 
@@ -387,7 +417,7 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
 struct FwdScratch { float *Wcat, *colp, *sig, *rsig; double* stats; };
 struct BwdScratch {
     float *Wcat, *colp, *sig, *rsig, *dY, *dP, *cc, *dWcat;
-    double *slab, *slab_da, *datt, *dr;
+    double *slab, *slab_da, *datt;
 };
 static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, FwdScratch* s) {
     Carver c(base);
@@ -413,8 +443,7 @@ static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, Bw
     t.dWcat = c.take<float>(d.wslab * d.nsplit);
     t.slab = c.take<double>((size_t)d.gxb * d.fp * 2);
     t.slab_da = c.take<double>((size_t)d.gxb * EAGCN_MAX_VIEWS);
-    t.datt = c.take<double>(EAGCN_MAX_VIEWS * 256);
-    t.dr = c.take<double>(EAGCN_MAX_VIEWS);
+    t.datt = c.take<double>((size_t)edge_grid_x(b) * EAGCN_MAX_VIEWS * EDGE_SLAB);
     if (s) *s = t;
     return c.off;
 }
@@ -513,7 +542,7 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
     }
     const double M = (double)b->B * (double)b->N;
     ProfScope psbn(PROF_BN, s);
-    bn_finalize_kernel<<<cdiv(d.fp, 256), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
+    bn_finalize_kernel<<<cdiv(d.fp, 16), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
                                                         p->bn_momentum, sc.colp, pp, d.vc, w->bn);
     EAGCN_LAUNCH_CHECK();
     ApplyArgs aa;
@@ -563,7 +592,6 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
     double fsum = 0.0;
     for (int k = 0; k < p->K; ++k) fsum += p->width[k];
     const double gemm_work = 2.0 * (double)b->T * (double)d.fin * fsum;
-    EAGCN_HIP(hipMemsetAsync(sc.datt, 0, (char*)(sc.dr + EAGCN_MAX_VIEWS) - (char*)sc.datt, s));
 
     BwdArgs ba;
     ba.bt = *b; ba.vc = d.vc; ba.structure = p->structure; ba.fp = d.fp;
@@ -581,7 +609,7 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
         ProfScope ps(PROF_BN, s);
         bn_bwd_reduce_kernel<<<gxb, 256, 0, s>>>(ba);
         EAGCN_LAUNCH_CHECK();
-        bn_bwd_finalize_kernel<<<cdiv(d.fp, 256), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
+        bn_bwd_finalize_kernel<<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
                                                                 d.vc, gp, sc.cc);
         EAGCN_LAUNCH_CHECK();
         if (b->T > 0) {
@@ -589,7 +617,7 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
             EAGCN_LAUNCH_CHECK();
         }
     }
-    int nsplit = 0;
+    int nsplit = 0, nedge = 0;
     if (b->T > 0) {
         AggArgs a;
         a.bt = *b; a.vc = d.vc; a.src = sc.dY; a.lds = d.fp; a.dst = sc.dP; a.ldd = d.fp;
@@ -598,9 +626,10 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
         if (rc) return rc;
         EdgeArgs e;
         e.bt = *b; e.vc = d.vc; e.dY = sc.dY; e.Y = w->Y; e.P = w->P; e.ld = d.fp; e.sig = sc.sig;
-        e.rsig = sc.rsig; e.rscale = w->rscale; e.datt = sc.datt; e.dr = sc.dr;
+        e.rsig = sc.rsig; e.rscale = w->rscale; e.datt = sc.datt;
         rc = launch_edge_grad(e, s);
         if (rc) return rc;
+        nedge = edge_grid_x(b);
         nsplit = d.nsplit;
         GemmDesc gw{1, 0, d.ld_in, d.fp, b->T, w->x, d.ld_in, sc.dP, d.fp, sc.dWcat, d.fp, nsplit, d.wslab, gemm_work};
         rc = launch_gemm(gw, s);
@@ -612,8 +641,10 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
         }
     }
     ProfScope psu(PROF_PACK, s);
-    unpack_grads_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat, nsplit, d.wslab,
-                                                        sc.datt, sc.dr, sc.rsig);
+    const int wblocks = cdiv((int)d.wslab, 256);
+    unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, s>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
+                                                                             nsplit, d.wslab, sc.datt, nedge, sc.rsig,
+                                                                             wblocks);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

@@ -20,18 +20,26 @@ __device__ __forceinline__ int exact_to_packed(const ColMapD& m, int ce) {
     return -1;
 }
 
+// grid (B, ceil(F/64)); 4 wavefronts split the molecule's rows, 64 lanes own 64 exact columns
 __global__ __launch_bounds__(256) void readout_fwd_kernel(eagcn_batch bt, const float* __restrict__ x, ColMapD m,
                                                            int ld, const float* __restrict__ pad_row,
                                                            const int64_t* __restrict__ size, int mode,
                                                            float* __restrict__ g, int F) {
+    __shared__ float part[4][64];
     const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = blockIdx.y * 64 + lane;
     const int n = bt.nat[b], r0 = bt.row0[b];
-    const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
-    for (int f = threadIdx.x; f < F; f += blockDim.x) {
-        const int cp = exact_to_packed(m, f);
-        float s = 0.0f;
-        for (int i = 0; i < n; ++i) s += x[(size_t)(r0 + i) * ld + cp];
+    const int cp = f < F ? exact_to_packed(m, f) : 0;
+    float s = 0.0f;
+    if (f < F)
+        for (int i = wave; i < n; i += 4) s += x[(size_t)(r0 + i) * ld + cp];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && f < F) {
+        s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
         if (pad_row) s += (float)(bt.N - n) * pad_row[cp];
+        const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
         g[(size_t)b * F + f] = s * inv;
     }
 }
@@ -89,7 +97,7 @@ extern "C" int eagcn_readout_forward(const eagcn_batch* b, const float* x, const
     EAGCN_CHECK_ARG(layout_width(lay) == F, "eagcn_readout_forward: layout width %d != F %d", layout_width(lay), F);
     EAGCN_CHECK_ARG(mode == 0 || (mode == 1 && size), "eagcn_readout_forward: mode 1 ('ave') needs size");
     ProfScope ps(PROF_READOUT, s);
-    readout_fwd_kernel<<<b->B, 256, 0, s>>>(*b, x, make_colmap(lay), layout_ld(lay), pad_row, size, mode, g, F);
+    readout_fwd_kernel<<<dim3(b->B, cdiv(F, 64)), 256, 0, s>>>(*b, x, make_colmap(lay), layout_ld(lay), pad_row, size, mode, g, F);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

@@ -205,5 +205,5 @@ class Dense(nn.Module):
             self.bias.data.uniform_(-s, s)
 
     def forward(self, x):
-        out = torch.mm(x, self.weight)
+        out = ops.dense_mm(x, self.weight)           # fp32 MFMA GEMM through the C ABI, no rocBLAS
         return out + self.bias if self.bias is not None else out

@@ -370,15 +370,53 @@ def readout(index, layout, x, pad_row, mode='sum', size=None):
     return _Readout.apply(index, layout, 1 if mode == 'ave' else 0, size, x, pad_row)
 
 
+class _DenseMM(torch.autograd.Function):
+    """y = x @ W on the fp32 matrix cores (reference Dense.forward, layers.py:382-387) with its
+    two backward products (dx = dy @ W^T, dW = x^T @ dy)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x = _need_cuda_f32(x, 'dense input')
+        w = _need_cuda_f32(w, 'dense weight')
+        ctx.save_for_backward(x, w)
+        return gemm(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = gemm(dy, w, tb=True) if ctx.needs_input_grad[0] else None
+        dw = gemm(x, dy, ta=True) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def dense_mm(x, w):
+    return _DenseMM.apply(x, w)
+
+
+def _pad2(t, rows, cols):
+    """Zero-pad a matrix so that the flagged dimensions are multiples of 4 (the GEMM loads
+    contiguous runs as float4 and walks K in steps of 4); zero padding leaves the product unchanged."""
+    pr = (-t.shape[0]) % 4 if rows else 0
+    pc = (-t.shape[1]) % 4 if cols else 0
+    return t if (pr == 0 and pc == 0) else torch.nn.functional.pad(t, (0, pc, 0, pr))
+
+
 def gemm(a, b, ta=False, tb=False):
-    """C = op(A) @ op(B) on the fp32 matrix cores (no autograd; used by tests and the head)."""
-    a, b = a.contiguous(), b.contiguous()
+    """C = op(A) @ op(B) on the fp32 matrix cores (no autograd; used by the head and by tests).
+    ta: A is stored [K,M]; tb: B is stored [N,K]."""
     M = a.shape[1] if ta else a.shape[0]
     Ka = a.shape[0] if ta else a.shape[1]
     N = b.shape[0] if tb else b.shape[1]
     Kb = b.shape[1] if tb else b.shape[0]
-    assert Ka == Kb
-    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    L.check(L.load().eagcn_gemm_f32(int(ta), int(tb), M, N, Ka, _ptr(a), a.shape[1], _ptr(b), b.shape[1],
-                                    _ptr(c), N, _stream()), 'eagcn_gemm_f32')
-    return c
+    if Ka != Kb:
+        raise L.EagcnHipError('gemm: inner dimensions differ (%d vs %d)' % (Ka, Kb))
+    a = _pad2(a.contiguous(), rows=ta, cols=True)         # [M,K]: pad K ; [K,M]: pad K and M
+    b = _pad2(b.contiguous(), rows=not tb, cols=True)     # [K,N]: pad K and N ; [N,K]: pad K
+    Mp = a.shape[1] if ta else M
+    Np = N if tb else b.shape[1]
+    Kp = a.shape[0] if ta else a.shape[1]
+    c = torch.empty((Mp, Np), dtype=torch.float32, device=a.device)
+    L.check(L.load().eagcn_gemm_f32(int(ta), int(tb), Mp, Np, Kp, _ptr(a), a.shape[1], _ptr(b), b.shape[1],
+                                    _ptr(c), Np, _stream()), 'eagcn_gemm_f32')
+    return c if (Mp == M and Np == N) else c[:M, :N].contiguous()
