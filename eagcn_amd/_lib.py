@@ -56,6 +56,7 @@ class LayerGrads(C.Structure):
 # name -> (restype, argtypes); also the list the CPU test checks against include/eagcn_hip.h
 SIGNATURES = {
     'eagcn_abi_version': (C.c_int, []),
+    'eagcn_struct_size': (C.c_size_t, [C.c_int]),
     'eagcn_last_error': (C.c_char_p, []),
     'eagcn_pad16': (C.c_int, [C.c_int]),
     'eagcn_layer_out_ld': (C.c_int, [C.POINTER(LayerParams)]),
@@ -104,6 +105,10 @@ def load():
         fn = getattr(lib, name)        # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    for which, cls in enumerate((Batch, Layout, LayerParams, LayerBufs, LayerGrads)):
+        if lib.eagcn_struct_size(which) != C.sizeof(cls):
+            raise EagcnHipError('ABI mismatch: %s is %d bytes here, %d in libeagcn_hip.so'
+                                % (cls.__name__, C.sizeof(cls), lib.eagcn_struct_size(which)))
     _lib = lib
     return lib
 

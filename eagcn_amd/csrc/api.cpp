@@ -73,4 +73,16 @@ extern "C" int eagcn_prof_read(int tag, double* total_ms, double* work, int64_t*
 }
 
 extern "C" int eagcn_abi_version(void) { return 1; }
+/* sizeof() of the ABI structs, so a binding can verify its own struct layout (which: 0 batch,
+ * 1 layout, 2 layer_params, 3 layer_bufs, 4 layer_grads) */
+extern "C" size_t eagcn_struct_size(int which) {
+    switch (which) {
+        case 0: return sizeof(eagcn_batch);
+        case 1: return sizeof(eagcn_layout);
+        case 2: return sizeof(eagcn_layer_params);
+        case 3: return sizeof(eagcn_layer_bufs);
+        case 4: return sizeof(eagcn_layer_grads);
+        default: return 0;
+    }
+}
 extern "C" const char* eagcn_last_error(void) { return eagcn::g_err; }

@@ -131,6 +131,7 @@ typedef struct eagcn_layer_grads {
 
 /* ---- library ------------------------------------------------------------------------------- */
 int eagcn_abi_version(void);
+size_t eagcn_struct_size(int which);   /* 0 batch, 1 layout, 2 layer_params, 3 layer_bufs, 4 layer_grads */
 const char* eagcn_last_error(void);
 int eagcn_pad16(int width);
 int eagcn_layer_out_ld(const eagcn_layer_params* p);   /* ld of xout                            */
