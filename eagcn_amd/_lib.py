@@ -44,13 +44,33 @@ class LayerParams(C.Structure):
 
 class LayerBufs(C.Structure):
     _fields_ = [('x', _fp), ('P', _fp), ('Y', _fp), ('rscale', _fp), ('bn', _fp), ('xout', _fp),
-                ('pad_row', _fp), ('scratch', _fp), ('scratch_bytes', C.c_size_t)]
+                ('pad_row', _fp), ('scratch', _fp), ('scratch_bytes', C.c_size_t),
+                ('packed', _fp), ('packed_bytes', C.c_size_t)]
 
 
 class LayerGrads(C.Structure):
     _fields_ = [('dW', _fp * MAX_VIEWS), ('dbias', _fp * MAX_VIEWS), ('dgamma', _fp * MAX_VIEWS),
                 ('dbeta', _fp * MAX_VIEWS), ('datt_w', _fp * MAX_VIEWS), ('dself_r', _fp * MAX_VIEWS),
                 ('dave_w', _fp)]
+
+
+class HeadParams(C.Structure):
+    _fields_ = [('f_in', C.c_int32), ('n_den1', C.c_int32), ('n_den2', C.c_int32), ('nclass', C.c_int32),
+                ('dropout', C.c_float), ('bn_eps', C.c_float), ('bn_momentum', C.c_float),
+                ('den1_w', _fp), ('den2_w', _fp), ('den3_w', _fp),
+                ('gbn_w', _fp), ('gbn_b', _fp), ('gbn_rm', _fp), ('gbn_rv', _fp),
+                ('bn1_w', _fp), ('bn1_b', _fp), ('bn1_rm', _fp), ('bn1_rv', _fp),
+                ('bn2_w', _fp), ('bn2_b', _fp), ('bn2_rm', _fp), ('bn2_rv', _fp)]
+
+
+class HeadGrads(C.Structure):
+    _fields_ = [(n, _fp) for n in ('d_den1_w', 'd_den2_w', 'd_den3_w', 'd_gbn_w', 'd_gbn_b', 'd_bn1_w', 'd_bn1_b',
+                                   'd_bn2_w', 'd_bn2_b')]
+
+
+class Model(C.Structure):
+    _fields_ = [('n_layers', C.c_int32), ('molfp_mode', C.c_int32), ('training', C.c_int32),
+                ('head_seed', C.c_uint64), ('layer', LayerParams * 4), ('head', HeadParams)]
 
 
 # name -> (restype, argtypes); also the list the CPU test checks against include/eagcn_hip.h
@@ -61,6 +81,7 @@ SIGNATURES = {
     'eagcn_pad16': (C.c_int, [C.c_int]),
     'eagcn_layer_out_ld': (C.c_int, [C.POINTER(LayerParams)]),
     'eagcn_layer_fp': (C.c_int, [C.POINTER(LayerParams)]),
+    'eagcn_layer_packed_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(LayerParams)]),
     'eagcn_layer_fwd_scratch_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(LayerParams)]),
     'eagcn_layer_bwd_scratch_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(LayerParams)]),
     'eagcn_index_build': (C.c_int, [_fp, C.POINTER(_fp), C.POINTER(Batch), _fp, _fp]),
@@ -77,6 +98,14 @@ SIGNATURES = {
                                          _fp, _fp, _fp]),
     'eagcn_gemm_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int,
                                  _fp, C.c_int, _fp]),
+    'eagcn_model_saved_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(Model)]),
+    'eagcn_model_scratch_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(Model)]),
+    'eagcn_model_atom_rep': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), C.POINTER(C.c_size_t),
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    'eagcn_model_forward': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, _fp, C.c_size_t, _fp,
+                                      C.c_size_t, _fp, _fp, _fp]),
+    'eagcn_model_backward': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, C.c_size_t, _fp, C.c_size_t,
+                                       _fp, _fp, C.POINTER(LayerGrads), C.POINTER(HeadGrads), _fp]),
     'eagcn_prof_enable': (None, [C.c_int]),
     'eagcn_prof_reset': (None, []),
     'eagcn_prof_ntags': (C.c_int, []),
@@ -105,7 +134,7 @@ def load():
         fn = getattr(lib, name)        # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    for which, cls in enumerate((Batch, Layout, LayerParams, LayerBufs, LayerGrads)):
+    for which, cls in enumerate((Batch, Layout, LayerParams, LayerBufs, LayerGrads, HeadParams, HeadGrads, Model)):
         if lib.eagcn_struct_size(which) != C.sizeof(cls):
             raise EagcnHipError('ABI mismatch: %s is %d bytes here, %d in libeagcn_hip.so'
                                 % (cls.__name__, C.sizeof(cls), lib.eagcn_struct_size(which)))

@@ -82,6 +82,9 @@ extern "C" size_t eagcn_struct_size(int which) {
         case 2: return sizeof(eagcn_layer_params);
         case 3: return sizeof(eagcn_layer_bufs);
         case 4: return sizeof(eagcn_layer_grads);
+        case 5: return sizeof(eagcn_head_params);
+        case 6: return sizeof(eagcn_head_grads);
+        case 7: return sizeof(eagcn_model);
         default: return 0;
     }
 }

@@ -131,6 +131,7 @@ struct GemmDesc {
     int splits;            // split-K: partial z written at C + z*slab
     size_t slab;           // floats between partial slabs
     double work = 0.0;     // algorithmic flops of this product (0 -> 2*M*N*K)
+    int vecA = 1, vecB = 1; // set by launch_gemm: float4 loads allowed for A / B
 };
 int launch_gemm(const GemmDesc& g, hipStream_t s);
 

@@ -55,12 +55,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (A_KC) {
                 int row = p * A_RPP + tid / A_TPR, kq = (tid % A_TPR) * 4;
-                if (m0 + row < g.M && k0 + kq < kend)
-                    v = *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + row) * g.lda + k0 + kq);
+                if (m0 + row < g.M && k0 + kq < kend) {
+                    const float* src = g.A + (size_t)(m0 + row) * g.lda + k0 + kq;
+                    if (g.vecA) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        v.x = src[0];
+                        if (k0 + kq + 1 < kend) v.y = src[1];
+                        if (k0 + kq + 2 < kend) v.z = src[2];
+                        if (k0 + kq + 3 < kend) v.w = src[3];
+                    }
+                }
             } else {
                 int k = p * A_RPP + tid / A_TPR, mq = (tid % A_TPR) * 4;
-                if (k0 + k < kend && m0 + mq < g.M)
-                    v = *reinterpret_cast<const float4*>(g.A + (size_t)(k0 + k) * g.lda + m0 + mq);
+                if (k0 + k < kend && m0 + mq < g.M) {
+                    const float* src = g.A + (size_t)(k0 + k) * g.lda + m0 + mq;
+                    if (g.vecA) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        v.x = src[0];
+                        if (m0 + mq + 1 < g.M) v.y = src[1];
+                        if (m0 + mq + 2 < g.M) v.z = src[2];
+                        if (m0 + mq + 3 < g.M) v.w = src[3];
+                    }
+                }
             }
             ra[p] = v;
         }
@@ -69,12 +85,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (B_KC) {
                 int row = p * B_RPP + tid / B_TPR, kq = (tid % B_TPR) * 4;
-                if (n0 + row < g.N && k0 + kq < kend)
-                    v = *reinterpret_cast<const float4*>(g.B + (size_t)(n0 + row) * g.ldb + k0 + kq);
+                if (n0 + row < g.N && k0 + kq < kend) {
+                    const float* src = g.B + (size_t)(n0 + row) * g.ldb + k0 + kq;
+                    if (g.vecB) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        v.x = src[0];
+                        if (k0 + kq + 1 < kend) v.y = src[1];
+                        if (k0 + kq + 2 < kend) v.z = src[2];
+                        if (k0 + kq + 3 < kend) v.w = src[3];
+                    }
+                }
             } else {
                 int k = p * B_RPP + tid / B_TPR, nq = (tid % B_TPR) * 4;
-                if (k0 + k < kend && n0 + nq < g.N)
-                    v = *reinterpret_cast<const float4*>(g.B + (size_t)(k0 + k) * g.ldb + n0 + nq);
+                if (k0 + k < kend && n0 + nq < g.N) {
+                    const float* src = g.B + (size_t)(k0 + k) * g.ldb + n0 + nq;
+                    if (g.vecB) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        v.x = src[0];
+                        if (n0 + nq + 1 < g.N) v.y = src[1];
+                        if (n0 + nq + 2 < g.N) v.z = src[2];
+                        if (n0 + nq + 3 < g.N) v.w = src[3];
+                    }
+                }
             }
             rb[p] = v;
         }
@@ -169,15 +201,14 @@ static int launch_cfg(const GemmDesc& g, hipStream_t s) {
     return EAGCN_OK;
 }
 
-int launch_gemm(const GemmDesc& g, hipStream_t s) {
-    if (g.M <= 0 || g.N <= 0) return EAGCN_OK;
-    EAGCN_CHECK_ARG(g.splits >= 1, "gemm: splits must be >= 1");
-    // contiguous dimensions are loaded as float4
-    EAGCN_CHECK_ARG((g.lda % 4) == 0 && (g.ldb % 4) == 0, "gemm: lda/ldb must be multiples of 4");
-    EAGCN_CHECK_ARG(((g.ta ? g.M : g.K) % 4) == 0, "gemm: contiguous extent of A must be a multiple of 4");
-    EAGCN_CHECK_ARG(((g.tb ? g.K : g.N) % 4) == 0, "gemm: contiguous extent of B must be a multiple of 4");
-    EAGCN_CHECK_ARG((reinterpret_cast<uintptr_t>(g.A) % 16) == 0 && (reinterpret_cast<uintptr_t>(g.B) % 16) == 0,
-                    "gemm: operands must be 16-byte aligned");
+int launch_gemm(const GemmDesc& g0, hipStream_t s) {
+    if (g0.M <= 0 || g0.N <= 0) return EAGCN_OK;
+    EAGCN_CHECK_ARG(g0.splits >= 1, "gemm: splits must be >= 1");
+    GemmDesc g = g0;
+    // contiguous runs are loaded as float4 when every run is 16-byte aligned and whole, else scalar
+    g.vecA = (g.lda % 4) == 0 && ((g.ta ? g.M : g.K) % 4) == 0 && (reinterpret_cast<uintptr_t>(g.A) % 16) == 0;
+    g.vecB = (g.ldb % 4) == 0 && ((g.tb ? g.K : g.N) % 4) == 0 && (reinterpret_cast<uintptr_t>(g.B) % 16) == 0;
+    if (g.splits > 1) EAGCN_CHECK_ARG(g.vecA && g.vecB, "gemm: split-K needs float4-aligned operands");
     const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.splits;
     if (tiles128 >= 384) return launch_cfg<128, 128, 16>(g, s);
     return launch_cfg<64, 64, 16>(g, s);

@@ -1,0 +1,392 @@
+// Model-level entry points: the whole EAGCN forward (reference models.py:96-121) and its whole
+// backward as ONE C call each, so the host issues a fixed, short launch sequence per step instead of
+// walking an autograd graph of small ops.
+//
+//   forward : pack afm -> layer 1..L (layer.hip) -> read-out (models.py:108-111) -> Graph_BN ->
+//             den1 -> bn_den1 -> relu -> dropout -> den2 (= graph_representation) -> bn_den2 -> relu
+//             -> den3                                                      (models.py:112-120)
+//   backward: the exact reverse, producing every parameter gradient.
+//
+// The head's BatchNorm1d layers work on [B, F] matrices.  BatchNorm over rows is independent per
+// column, so one workgroup that owns 16 columns does statistics AND normalisation for them in a
+// single kernel (no grid-wide reduction): rowbn_fwd_kernel / rowbn_bwd_kernel.
+#include <algorithm>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace eagcn {
+
+enum { RB_SC = 0, RB_SH, RB_MU, RB_INV };
+
+struct RowBnFwd {
+    int R, F;
+    const float* x; float* y;            // [R][F]
+    const float* gamma; const float* beta;
+    float* run_mean; float* run_var;
+    float* bn;                           // [4][F]
+    int training, relu, do_drop;
+    float eps, momentum;
+    uint32_t thr; float inv_keep; uint64_t seed;
+};
+
+// 16 columns x 16 row-lanes per workgroup
+__global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnFwd a) {
+    const int cr = blockIdx.x * 16 + (threadIdx.x >> 4), rl = threadIdx.x & 15;
+    const int c = min(cr, a.F - 1);
+    float mu, inv;
+    if (a.training) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = rl; r < a.R; r += 16) {
+            const double v = (double)a.x[(size_t)r * a.F + c];
+            s1 += v;
+            s2 += v * v;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        const double mean = s1 / a.R;
+        double var = s2 / a.R - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        mu = (float)mean;
+        inv = (float)(1.0 / sqrt(var + (double)a.eps));
+        if (rl == 0 && cr < a.F) {
+            const double unbiased = var * ((double)a.R / ((double)a.R - 1.0));
+            a.run_mean[c] = (float)((1.0 - a.momentum) * (double)a.run_mean[c] + a.momentum * mean);
+            a.run_var[c] = (float)((1.0 - a.momentum) * (double)a.run_var[c] + a.momentum * unbiased);
+        }
+    } else {
+        mu = a.run_mean[c];
+        inv = 1.0f / sqrtf(a.run_var[c] + a.eps);
+    }
+    const float sc = a.gamma[c] * inv, sh = a.beta[c] - mu * sc;
+    if (cr >= a.F) return;
+    if (rl == 0) {
+        a.bn[RB_SC * a.F + c] = sc;
+        a.bn[RB_SH * a.F + c] = sh;
+        a.bn[RB_MU * a.F + c] = mu;
+        a.bn[RB_INV * a.F + c] = inv;
+    }
+    for (int r = rl; r < a.R; r += 16) {
+        float h = a.x[(size_t)r * a.F + c] * sc + sh;
+        if (a.relu) h = fmaxf(h, 0.0f);
+        if (a.do_drop) h *= drop_scale(a.seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
+        a.y[(size_t)r * a.F + c] = h;
+    }
+}
+
+struct RowBnBwd {
+    int R, F;
+    const float* dy; const float* x; const float* bn;
+    const float* extra;                  // added to dx (gradient that reaches x directly), or null
+    float* dx; float* dgamma; float* dbeta;
+    int training, relu, do_drop;
+    uint32_t thr; float inv_keep; uint64_t seed;
+};
+
+__global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwd a) {
+    const int cr = blockIdx.x * 16 + (threadIdx.x >> 4), rl = threadIdx.x & 15;
+    const int c = min(cr, a.F - 1);
+    const float sc = a.bn[RB_SC * a.F + c], sh = a.bn[RB_SH * a.F + c];
+    const float mu = a.bn[RB_MU * a.F + c], inv = a.bn[RB_INV * a.F + c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = rl; r < a.R; r += 16) {
+        const float xv = a.x[(size_t)r * a.F + c];
+        float dh = a.dy[(size_t)r * a.F + c];
+        if (a.do_drop) dh *= drop_scale(a.seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
+        if (a.relu && !(xv * sc + sh > 0.0f)) dh = 0.0f;
+        s1 += (double)dh;
+        s2 += (double)(dh * ((xv - mu) * inv));
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (cr >= a.F) return;
+    if (rl == 0) {
+        a.dgamma[c] = (float)s2;
+        a.dbeta[c] = (float)s1;
+    }
+    const float c1 = a.training ? (float)(s1 / a.R) : 0.0f, c2 = a.training ? (float)(s2 / a.R) : 0.0f;
+    for (int r = rl; r < a.R; r += 16) {
+        const float xv = a.x[(size_t)r * a.F + c];
+        float dh = a.dy[(size_t)r * a.F + c];
+        if (a.do_drop) dh *= drop_scale(a.seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
+        if (a.relu && !(xv * sc + sh > 0.0f)) dh = 0.0f;
+        float d = sc * (dh - c1 - (xv - mu) * inv * c2);
+        if (a.extra) d += a.extra[(size_t)r * a.F + c];
+        a.dx[(size_t)r * a.F + c] = d;
+    }
+}
+
+// ---- carving of the saved-for-backward block and of the transient scratch ---------------------------
+struct Carver2 {
+    char* base;
+    size_t off = 0;
+    explicit Carver2(void* p) : base((char*)p) {}
+    template <typename T>
+    T* take(size_t n) {
+        T* p = base ? (T*)(base + off) : nullptr;
+        off = align256(off + std::max<size_t>(n, 1) * sizeof(T));
+        return p;
+    }
+};
+
+struct LayerSaved { float *P, *Y, *rscale, *bn, *xout, *pad_row; void* packed; size_t packed_bytes; int fp, ldo, ld_in; };
+struct ModelSaved {
+    float* x0;
+    LayerSaved L[4];
+    float *g, *gn, *h1, *a1, *h2, *a2, *bn_g, *bn_1, *bn_2;
+    size_t xout_last_off, pad_last_off;
+};
+
+static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m, ModelSaved* out) {
+    Carver2 c(base);
+    ModelSaved s;
+    const size_t T = (size_t)b->T;
+    s.x0 = c.take<float>(T * layout_ld(&m->layer[0].in));
+    for (int l = 0; l < m->n_layers; ++l) {
+        const eagcn_layer_params* p = &m->layer[l];
+        LayerSaved& L = s.L[l];
+        L.fp = eagcn_layer_fp(p);
+        L.ldo = eagcn_layer_out_ld(p);
+        L.ld_in = layout_ld(&p->in);
+        L.P = c.take<float>(T * L.fp);
+        L.Y = c.take<float>(T * L.fp);
+        L.rscale = c.take<float>((size_t)p->K * T);
+        L.bn = c.take<float>((size_t)4 * L.fp);
+        if (l == m->n_layers - 1) s.xout_last_off = c.off;
+        L.xout = c.take<float>(T * L.ldo);
+        if (l == m->n_layers - 1) s.pad_last_off = c.off;
+        L.pad_row = c.take<float>(L.ldo);
+        L.packed_bytes = eagcn_layer_packed_bytes(b, p);
+        L.packed = c.take<char>(L.packed_bytes);
+    }
+    const eagcn_head_params* h = &m->head;
+    const size_t B = (size_t)b->B;
+    s.g = c.take<float>(B * h->f_in);
+    s.gn = c.take<float>(B * h->f_in);
+    s.h1 = c.take<float>(B * h->n_den1);
+    s.a1 = c.take<float>(B * h->n_den1);
+    s.h2 = c.take<float>(B * h->n_den2);
+    s.a2 = c.take<float>(B * h->n_den2);
+    s.bn_g = c.take<float>((size_t)4 * h->f_in);
+    s.bn_1 = c.take<float>((size_t)4 * h->n_den1);
+    s.bn_2 = c.take<float>((size_t)4 * h->n_den2);
+    if (out) *out = s;
+    return c.off;
+}
+
+struct ModelScratch {
+    float *da2, *dh2, *da1, *dh1, *dgn, *dg, *dxa, *dxb, *dpad;
+    void* layer; size_t layer_bytes;
+};
+static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model* m, ModelScratch* out) {
+    Carver2 c(base);
+    ModelScratch s;
+    const eagcn_head_params* h = &m->head;
+    const size_t B = (size_t)b->B, T = (size_t)b->T;
+    s.da2 = c.take<float>(B * h->n_den2);
+    s.dh2 = c.take<float>(B * h->n_den2);
+    s.da1 = c.take<float>(B * h->n_den1);
+    s.dh1 = c.take<float>(B * h->n_den1);
+    s.dgn = c.take<float>(B * h->f_in);
+    s.dg = c.take<float>(B * h->f_in);
+    int ldmax = 0;
+    size_t lbytes = 0;
+    for (int l = 0; l < m->n_layers; ++l) {
+        ldmax = std::max(ldmax, eagcn_layer_out_ld(&m->layer[l]));
+        lbytes = std::max(lbytes, eagcn_layer_fwd_scratch_bytes(b, &m->layer[l]));
+        lbytes = std::max(lbytes, eagcn_layer_bwd_scratch_bytes(b, &m->layer[l]));
+    }
+    s.dxa = c.take<float>(T * ldmax);
+    s.dxb = c.take<float>(T * ldmax);
+    s.dpad = c.take<float>(ldmax);
+    s.layer_bytes = lbytes;
+    s.layer = c.take<char>(lbytes);
+    if (out) *out = s;
+    return c.off;
+}
+
+static int check_model(const eagcn_batch* b, const eagcn_model* m, const char* who) {
+    EAGCN_CHECK_ARG(b && m, "%s: null argument", who);
+    EAGCN_CHECK_ARG(m->n_layers >= 1 && m->n_layers <= 4, "%s: n_layers=%d", who, m->n_layers);
+    const eagcn_head_params* h = &m->head;
+    EAGCN_CHECK_ARG(h->f_in >= 1 && h->n_den1 >= 1 && h->n_den2 >= 1 && h->nclass >= 1, "%s: bad head sizes", who);
+    EAGCN_CHECK_ARG(h->den1_w && h->den2_w && h->den3_w && h->gbn_w && h->gbn_b && h->gbn_rm && h->gbn_rv &&
+                        h->bn1_w && h->bn1_b && h->bn1_rm && h->bn1_rv && h->bn2_w && h->bn2_b && h->bn2_rm &&
+                        h->bn2_rv, "%s: null head parameter", who);
+    const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
+    const int f_last = last->structure == EAGCN_STRUCT_CONCATE ? [&] { int s = 0; for (int k = 0; k < last->K; ++k) s += last->width[k]; return s; }()
+                                                                 : last->width[0];
+    EAGCN_CHECK_ARG(f_last == h->f_in, "%s: head expects %d features, last layer yields %d", who, h->f_in, f_last);
+    EAGCN_CHECK_ARG(!m->training || b->B > 1, "%s: BatchNorm in training mode needs more than one molecule", who);
+    return EAGCN_OK;
+}
+
+static eagcn_layout out_layout(const eagcn_layer_params* p) {
+    eagcn_layout l;
+    memset(&l, 0, sizeof(l));
+    if (p->structure == EAGCN_STRUCT_CONCATE) {
+        l.nseg = p->K;
+        for (int k = 0; k < p->K; ++k) { l.width[k] = p->width[k]; l.pad[k] = pad16(p->width[k]); }
+    } else {
+        l.nseg = 1;
+        l.width[0] = p->width[0];
+        l.pad[0] = pad16(p->width[0]);
+    }
+    return l;
+}
+
+static void fill_drop(float p, int training, int* do_drop, uint32_t* thr, float* inv_keep) {
+    *do_drop = (training && p > 0.0f) ? 1 : 0;
+    *thr = (uint32_t)std::min(4294967295.0, (double)p * 4294967296.0);
+    *inv_keep = 1.0f / (1.0f - p);
+}
+
+static int rowbn_fwd(hipStream_t s, int R, int F, const float* x, float* y, const float* g, const float* be,
+                     float* rm, float* rv, float* bn, int training, int relu, float dropout, uint64_t seed,
+                     float eps, float mom) {
+    RowBnFwd a;
+    a.R = R; a.F = F; a.x = x; a.y = y; a.gamma = g; a.beta = be; a.run_mean = rm; a.run_var = rv; a.bn = bn;
+    a.training = training; a.relu = relu; a.eps = eps; a.momentum = mom; a.seed = seed;
+    fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
+    ProfScope ps(PROF_BN, s);
+    rowbn_fwd_kernel<<<cdiv(F, 16), 256, 0, s>>>(a);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+static int rowbn_bwd(hipStream_t s, int R, int F, const float* dy, const float* x, const float* bn,
+                     const float* extra, float* dx, float* dgamma, float* dbeta, int training, int relu,
+                     float dropout, uint64_t seed) {
+    RowBnBwd a;
+    a.R = R; a.F = F; a.dy = dy; a.x = x; a.bn = bn; a.extra = extra; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.training = training; a.relu = relu; a.seed = seed;
+    fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
+    ProfScope ps(PROF_BN, s);
+    rowbn_bwd_kernel<<<cdiv(F, 16), 256, 0, s>>>(a);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+static int mm(hipStream_t s, int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
+              int ldb, float* C, int ldc) {
+    GemmDesc g{ta, tb, M, N, K, A, lda, B, ldb, C, ldc, 1, 0};
+    return launch_gemm(g, s);
+}
+
+}  // namespace eagcn
+
+using namespace eagcn;
+
+#define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+extern "C" size_t eagcn_model_saved_bytes(const eagcn_batch* b, const eagcn_model* m) {
+    return carve_saved(nullptr, b, m, nullptr);
+}
+extern "C" size_t eagcn_model_scratch_bytes(const eagcn_batch* b, const eagcn_model* m) {
+    return carve_scratch(nullptr, b, m, nullptr);
+}
+extern "C" int eagcn_model_atom_rep(const eagcn_batch* b, const eagcn_model* m, size_t* xout_offset,
+                                    size_t* pad_row_offset, int* ld) {
+    EAGCN_CHECK_ARG(b && m && xout_offset && pad_row_offset && ld, "eagcn_model_atom_rep: null argument");
+    ModelSaved s;
+    carve_saved(nullptr, b, m, &s);
+    *xout_offset = s.xout_last_off;
+    *pad_row_offset = s.pad_last_off;
+    *ld = eagcn_layer_out_ld(&m->layer[m->n_layers - 1]);
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, const float* afm,
+                                   const int64_t* size, void* saved, size_t saved_bytes, void* scratch,
+                                   size_t scratch_bytes, float* out, float* graph_rep, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    RC(check_model(b, m, "eagcn_model_forward"));
+    EAGCN_CHECK_ARG(afm && saved && scratch && out && graph_rep, "eagcn_model_forward: null buffer");
+    EAGCN_CHECK_ARG(m->molfp_mode == 0 || size, "eagcn_model_forward: 'ave' read-out needs size");
+    ModelSaved sv;
+    ModelScratch sc;
+    EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "eagcn_model_forward: saved block too small");
+    EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_forward: scratch too small");
+    const eagcn_head_params* h = &m->head;
+    RC(eagcn_pack_rows(b, afm, layout_width(&m->layer[0].in), &m->layer[0].in, sv.x0, stream));
+    const float* x = sv.x0;
+    for (int l = 0; l < m->n_layers; ++l) {
+        LayerSaved& L = sv.L[l];
+        eagcn_layer_bufs w;
+        memset(&w, 0, sizeof(w));
+        w.x = x; w.P = L.P; w.Y = L.Y; w.rscale = L.rscale; w.bn = L.bn; w.xout = L.xout; w.pad_row = L.pad_row;
+        w.scratch = sc.layer; w.scratch_bytes = sc.layer_bytes; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
+        RC(eagcn_layer_forward(b, &m->layer[l], &w, stream));
+        x = L.xout;
+    }
+    const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
+    const LayerSaved& LL = sv.L[m->n_layers - 1];
+    const eagcn_layout lay = out_layout(last);
+    const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
+    RC(eagcn_readout_forward(b, LL.xout, &lay, last->structure == EAGCN_STRUCT_WEIGHTED ? LL.pad_row : nullptr,
+                             size, m->molfp_mode, sv.g, F, stream));
+    RC(rowbn_fwd(s, B, F, sv.g, sv.gn, h->gbn_w, h->gbn_b, h->gbn_rm, h->gbn_rv, sv.bn_g, m->training, 0, 0.0f, 0,
+                 h->bn_eps, h->bn_momentum));
+    RC(mm(s, 0, 0, B, n1, F, sv.gn, F, h->den1_w, n1, sv.h1, n1));
+    RC(rowbn_fwd(s, B, n1, sv.h1, sv.a1, h->bn1_w, h->bn1_b, h->bn1_rm, h->bn1_rv, sv.bn_1, m->training, 1,
+                 h->dropout, m->head_seed, h->bn_eps, h->bn_momentum));
+    RC(mm(s, 0, 0, B, n2, n1, sv.a1, n1, h->den2_w, n2, sv.h2, n2));
+    EAGCN_HIP(hipMemcpyAsync(graph_rep, sv.h2, (size_t)B * n2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    RC(rowbn_fwd(s, B, n2, sv.h2, sv.a2, h->bn2_w, h->bn2_b, h->bn2_rm, h->bn2_rv, sv.bn_2, m->training, 1, 0.0f, 0,
+                 h->bn_eps, h->bn_momentum));
+    RC(mm(s, 0, 0, B, nc, n2, sv.a2, n2, h->den3_w, nc, out, nc));
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, const int64_t* size, void* saved,
+                                    size_t saved_bytes, void* scratch, size_t scratch_bytes, const float* dout,
+                                    const float* dgraph_rep, const eagcn_layer_grads* lg,
+                                    const eagcn_head_grads* hg, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    RC(check_model(b, m, "eagcn_model_backward"));
+    EAGCN_CHECK_ARG(saved && scratch && dout && lg && hg, "eagcn_model_backward: null buffer");
+    EAGCN_CHECK_ARG(hg->d_den1_w && hg->d_den2_w && hg->d_den3_w && hg->d_gbn_w && hg->d_gbn_b && hg->d_bn1_w &&
+                        hg->d_bn1_b && hg->d_bn2_w && hg->d_bn2_b, "eagcn_model_backward: null head gradient");
+    ModelSaved sv;
+    ModelScratch sc;
+    EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "eagcn_model_backward: saved block too small");
+    EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_backward: scratch too small");
+    const eagcn_head_params* h = &m->head;
+    const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
+    // den3
+    RC(mm(s, 1, 0, n2, nc, B, sv.a2, n2, dout, nc, hg->d_den3_w, nc));
+    RC(mm(s, 0, 1, B, n2, nc, dout, nc, h->den3_w, nc, sc.da2, n2));
+    RC(rowbn_bwd(s, B, n2, sc.da2, sv.h2, sv.bn_2, dgraph_rep, sc.dh2, hg->d_bn2_w, hg->d_bn2_b, m->training, 1, 0.0f, 0));
+    // den2
+    RC(mm(s, 1, 0, n1, n2, B, sv.a1, n1, sc.dh2, n2, hg->d_den2_w, n2));
+    RC(mm(s, 0, 1, B, n1, n2, sc.dh2, n2, h->den2_w, n2, sc.da1, n1));
+    RC(rowbn_bwd(s, B, n1, sc.da1, sv.h1, sv.bn_1, nullptr, sc.dh1, hg->d_bn1_w, hg->d_bn1_b, m->training, 1, h->dropout,
+                 m->head_seed));
+    // den1
+    RC(mm(s, 1, 0, F, n1, B, sv.gn, F, sc.dh1, n1, hg->d_den1_w, n1));
+    RC(mm(s, 0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, sc.dgn, F));
+    RC(rowbn_bwd(s, B, F, sc.dgn, sv.g, sv.bn_g, nullptr, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training, 0, 0.0f, 0));
+    // read-out
+    const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
+    const eagcn_layout lay = out_layout(last);
+    const bool weighted = last->structure == EAGCN_STRUCT_WEIGHTED;
+    float* cur = sc.dxa;
+    float* other = sc.dxb;
+    RC(eagcn_readout_backward(b, sc.dg, &lay, size, m->molfp_mode, F, cur, weighted ? sc.dpad : nullptr, stream));
+    for (int l = m->n_layers - 1; l >= 0; --l) {
+        LayerSaved& L = sv.L[l];
+        eagcn_layer_bufs w;
+        memset(&w, 0, sizeof(w));
+        w.x = l == 0 ? sv.x0 : sv.L[l - 1].xout;
+        w.P = L.P; w.Y = L.Y; w.rscale = L.rscale; w.bn = L.bn; w.xout = L.xout; w.pad_row = L.pad_row;
+        w.scratch = sc.layer; w.scratch_bytes = sc.layer_bytes; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
+        const float* dpad = (weighted && l == m->n_layers - 1) ? sc.dpad : nullptr;
+        RC(eagcn_layer_backward(b, &m->layer[l], &w, cur, dpad, l > 0 ? other : nullptr, &lg[l], stream));
+        std::swap(cur, other);
+    }
+    return EAGCN_OK;
+}

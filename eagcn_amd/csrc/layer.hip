@@ -414,7 +414,18 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     return d;
 }
 
+struct Packed { float *Wcat, *colp, *sig, *rsig; };
 struct FwdScratch { float *Wcat, *colp, *sig, *rsig; double* stats; };
+static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
+    Carver c(base);
+    Packed t;
+    t.Wcat = c.take<float>(d.wslab);
+    t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
+    t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
+    t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
+    if (s) *s = t;
+    return c.off;
+}
 struct BwdScratch {
     float *Wcat, *colp, *sig, *rsig, *dY, *dP, *cc, *dWcat;
     double *slab, *slab_da, *datt;
@@ -494,6 +505,10 @@ extern "C" int eagcn_layer_fp(const eagcn_layer_params* p) { return view_cols(p)
 extern "C" int eagcn_layer_out_ld(const eagcn_layer_params* p) {
     return p->structure == EAGCN_STRUCT_CONCATE ? eagcn_layer_fp(p) : pad16(p->width[0]);
 }
+extern "C" size_t eagcn_layer_packed_bytes(const eagcn_batch* b, const eagcn_layer_params* p) {
+    LayerDims d = layer_dims(b, p);
+    return carve_packed(nullptr, d, nullptr);
+}
 extern "C" size_t eagcn_layer_fwd_scratch_bytes(const eagcn_batch* b, const eagcn_layer_params* p) {
     LayerDims d = layer_dims(b, p);
     return carve_fwd(nullptr, b, d, nullptr);
@@ -519,6 +534,15 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
     }
     const ParamPtrs pp = param_ptrs(b, p);
     const ColMapD in = make_colmap(&p->in);
+    if (w->packed) {
+        Packed pk;
+        const size_t pneed = carve_packed(w->packed, d, &pk);
+        if (pneed > w->packed_bytes) {
+            set_error("eagcn_layer_forward: packed buffer too small (%zu < %zu)", w->packed_bytes, pneed);
+            return EAGCN_ERR_SCRATCH;
+        }
+        sc.Wcat = pk.Wcat; sc.colp = pk.colp; sc.sig = pk.sig; sc.rsig = pk.rsig;
+    }
     {
         ProfScope ps(PROF_PACK, s);
         pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.colp, sc.sig, sc.rsig);
@@ -584,7 +608,15 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
     }
     gp.dave_w = p->structure == EAGCN_STRUCT_WEIGHTED ? g->dave_w : nullptr;
     const ColMapD in = make_colmap(&p->in);
-    {
+    if (w->packed) {          // parameters were re-laid by the forward call and kept
+        Packed pk;
+        const size_t pneed = carve_packed(w->packed, d, &pk);
+        if (pneed > w->packed_bytes) {
+            set_error("eagcn_layer_backward: packed buffer too small (%zu < %zu)", w->packed_bytes, pneed);
+            return EAGCN_ERR_SCRATCH;
+        }
+        sc.Wcat = pk.Wcat; sc.colp = pk.colp; sc.sig = pk.sig; sc.rsig = pk.rsig;
+    } else {
         ProfScope ps(PROF_PACK, s);
         pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.colp, sc.sig, sc.rsig);
     }

@@ -29,6 +29,12 @@ class LazyAtomRep:
         self._args = (index, layout, packed.detach(), None if pad_row is None else pad_row.detach())
         self._cpu = None
 
+    @property
+    def packed(self):
+        """(packed [T, ld] device tensor, pad_row, layout) without the padded host copy."""
+        index, layout, packed, pad_row = self._args
+        return packed, pad_row, layout
+
     def cpu(self):
         if self._cpu is None:
             index, layout, packed, pad_row = self._args
@@ -91,6 +97,7 @@ class EAGCN(nn.Module):
         self.Graph_BN = nn.BatchNorm1d(f_last)
         self.bn_den1 = nn.BatchNorm1d(n_den1)
         self.bn_den2 = nn.BatchNorm1d(n_den2)
+        self._plan = None
 
     def graph_layers(self):
         return [getattr(self, 'layer%d' % (i + 1)) for i in range(self.n_layers)]
@@ -105,24 +112,53 @@ class EAGCN(nn.Module):
             outs.append((x, pad_row, layout))
         return outs
 
+    def plan(self):
+        if self._plan is None:
+            head = {n: getattr(self, n) for n in ('den1', 'den2', 'den3', 'Graph_BN', 'bn_den1', 'bn_den2')}
+            self._plan = ops.ModelPlan(self.graph_layers(), head, self.n_afeat, self.molfp_mode, self.dropout)
+        return self._plan
+
+    def _apply(self, fn, *a, **kw):                     # .cuda() / .to(): parameters are re-created
+        self._plan = None
+        return super()._apply(fn, *a, **kw)
+
     def forward(self, adjs, afms, *rels_and_size):
+        """Reference signature (models.py:96): (adjs, afms, TypeAtt, OrderAtt, AromAtt, ConjAtt, RingAtt,
+        size) -> (x, atom_representations, graph_representation).  The whole forward is one call into
+        eagcn_model_forward (layers, read-out and head); backward is one call into eagcn_model_backward."""
         *rels, size = rels_and_size
         index = ops.BatchIndex(adjs, rels)                       # once per batch, shared by all layers
-        x, pad_row, layout = self.forward_layers(index, afms)[-1]
-        pad = pad_row if self.structure == 'Weighted_sum' else None
-        if self.atom_rep == 'none':
-            atom_representations = None
-        else:
-            atom_representations = LazyAtomRep(index, layout, x, pad)
+        plan = self.plan()
+        seed = 0
+        if self.training and self.dropout > 0:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        holder = {} if self.atom_rep != 'none' else None
+        out, graph_representation = ops.model_forward(plan, index, holder, self.training, seed, self.dropout,
+                                                      size, afms)
+        if self.training:
+            torch._foreach_add_(plan.nbt, 1)
+        atom_representations = None
+        if holder is not None:
+            pad = holder['pad_row'] if self.structure == 'Weighted_sum' else None
+            atom_representations = LazyAtomRep(index, plan.last_layout, holder['xout'], pad)
             if self.atom_rep == 'eager':
                 atom_representations = atom_representations.cpu()
+        return out, atom_representations, graph_representation
+
+    def forward_composed(self, adjs, afms, *rels_and_size):
+        """Same computation composed from the layer-level entry points (one autograd node per layer,
+        head as separate ops); kept for tests that cross-check the model-level engine."""
+        *rels, size = rels_and_size
+        index = ops.BatchIndex(adjs, rels)
+        x, pad_row, layout = self.forward_layers(index, afms)[-1]
+        pad = pad_row if self.structure == 'Weighted_sum' else None
         g = ops.readout(index, layout, x, pad, self.molfp_mode, size)      # models.py:108-111
         g = self.Graph_BN(g)
         h = F.relu(self.bn_den1(self.den1(g)))
         h = F.dropout(h, p=self.dropout, training=self.training)
         graph_representation = self.den2(h)
         out = self.den3(F.relu(self.bn_den2(graph_representation)))
-        return out, atom_representations, graph_representation
+        return out, LazyAtomRep(index, layout, x, pad), graph_representation
 
 
 class Concate_GCN(EAGCN):

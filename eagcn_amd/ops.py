@@ -420,3 +420,166 @@ def gemm(a, b, ta=False, tb=False):
     L.check(L.load().eagcn_gemm_f32(int(ta), int(tb), Mp, Np, Kp, _ptr(a), a.shape[1], _ptr(b), b.shape[1],
                                     _ptr(c), Np, _stream()), 'eagcn_gemm_f32')
     return c if (Mp == M and Np == N) else c[:M, :N].contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# whole model: one C call forward, one backward
+# ------------------------------------------------------------------------------------------------
+_scratch_cache = {}
+
+
+def _scratch(device, nbytes):
+    """Transient workspace, reused across calls on the same (device, stream): all users are
+    stream-ordered, so the previous call's kernels are done with it before the next ones start."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    t = _scratch_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _scratch_cache[key] = t
+    return t
+
+
+class ModelPlan:
+    """Static description of an EAGCN module for the model-level entry points: parameter order,
+    layer specs with their chained column layouts, gradient-buffer offsets."""
+
+    def __init__(self, layers, head, n_afeat, molfp_mode, dropout):
+        # layers: list of GraphConv_Layer modules; head: dict of modules
+        self.layers = layers
+        self.head = head
+        self.molfp = 1 if molfp_mode == 'ave' else 0
+        self.specs = []
+        layout = ColLayout.single(n_afeat)
+        for layer in layers:
+            spec = layer.spec_for(layout)
+            self.specs.append(spec)
+            layout = spec.out_layout
+        self.last_layout = layout
+        self.params = []          # flat, fixed order
+        self.layer_slices = []    # per layer: (start index of view params, index of ave_w or None)
+        for layer in layers:
+            start = len(self.params)
+            for blk in layer.blocks():
+                self.params.extend(blk.hot_params())
+            ave = None
+            if layer.structure == 'Weighted_sum':
+                ave = len(self.params)
+                self.params.append(layer.ave.weight)
+            self.layer_slices.append((start, ave))
+        self.head_start = len(self.params)
+        h = head
+        self.params.extend([h['den1'].weight, h['den2'].weight, h['den3'].weight,
+                            h['Graph_BN'].weight, h['Graph_BN'].bias, h['bn_den1'].weight, h['bn_den1'].bias,
+                            h['bn_den2'].weight, h['bn_den2'].bias])
+        self.sizes = [p.numel() for p in self.params]
+        self.shapes = [tuple(p.shape) for p in self.params]
+        self.offsets = [0]
+        for n in self.sizes:
+            self.offsets.append(self.offsets[-1] + n)
+        self.nbt = [blk.batch_norm.bn.num_batches_tracked for layer in layers for blk in layer.blocks()] + \
+                   [h['Graph_BN'].num_batches_tracked, h['bn_den1'].num_batches_tracked,
+                    h['bn_den2'].num_batches_tracked]
+
+    def cmodel(self, training, seed, dropout):
+        m = L.Model()
+        m.n_layers, m.molfp_mode, m.training = len(self.layers), self.molfp, int(bool(training))
+        m.head_seed = (int(seed) + 0x51ED27) & (2 ** 63 - 1)
+        for l, (layer, spec) in enumerate(zip(self.layers, self.specs)):
+            spec.dropout = float(layer.dropout)
+            views = []
+            for blk in layer.blocks():
+                bn = blk.batch_norm.bn
+                views.append({'att_w': blk.att.weight, 'self_r': blk.self_r, 'W': blk.graph_conv.weight,
+                              'bias': blk.graph_conv.bias, 'gamma': bn.weight, 'beta': bn.bias,
+                              'run_mean': bn.running_mean, 'run_var': bn.running_var})
+            ave = layer.ave.weight if layer.structure == 'Weighted_sum' else None
+            m.layer[l] = spec.cparams(training, (int(seed) + 7919 * (l + 1)) & (2 ** 63 - 1), views, ave)
+        h, hp = self.head, m.head
+        hp.f_in, hp.n_den1 = h['den1'].weight.shape
+        hp.n_den2, hp.nclass = h['den3'].weight.shape
+        hp.dropout = float(dropout)
+        hp.bn_eps, hp.bn_momentum = float(h['Graph_BN'].eps), float(h['Graph_BN'].momentum)
+        hp.den1_w, hp.den2_w, hp.den3_w = (h['den1'].weight.data_ptr(), h['den2'].weight.data_ptr(),
+                                           h['den3'].weight.data_ptr())
+        for pre, mod in (('gbn', h['Graph_BN']), ('bn1', h['bn_den1']), ('bn2', h['bn_den2'])):
+            setattr(hp, pre + '_w', mod.weight.data_ptr())
+            setattr(hp, pre + '_b', mod.bias.data_ptr())
+            setattr(hp, pre + '_rm', mod.running_mean.data_ptr())
+            setattr(hp, pre + '_rv', mod.running_var.data_ptr())
+        return m
+
+
+class _ModelFn(torch.autograd.Function):
+    """(afm, every hot parameter) -> (out, graph_representation): one call into
+    eagcn_model_forward, one into eagcn_model_backward."""
+
+    @staticmethod
+    def forward(ctx, plan, index, holder, training, seed, dropout, size, afm, *params):
+        lib = L.load()
+        afm = _need_cuda_f32(afm, 'afms')
+        for i, t in enumerate(params):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                raise L.EagcnHipError('parameter %d must be a contiguous fp32 device tensor' % i)
+        if afm.shape != (index.B, index.N, plan.specs[0].in_layout.width):
+            raise L.EagcnHipError('afms is %s, expected %s' % (tuple(afm.shape), (index.B, index.N, plan.specs[0].in_layout.width)))
+        m = plan.cmodel(training, seed, dropout)
+        dev = afm.device
+        if plan.molfp:
+            size = size.to(device=dev, dtype=torch.int64).contiguous()
+        sbytes = lib.eagcn_model_saved_bytes(index.ref(), C.byref(m))
+        wbytes = lib.eagcn_model_scratch_bytes(index.ref(), C.byref(m))
+        saved = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+        scratch = _scratch(dev, wbytes)
+        out = torch.empty((index.B, m.head.nclass), dtype=torch.float32, device=dev)
+        graph_rep = torch.empty((index.B, m.head.n_den2), dtype=torch.float32, device=dev)
+        L.check(lib.eagcn_model_forward(index.ref(), C.byref(m), _ptr(afm), _ptr(size) if plan.molfp else C.c_void_p(0),
+                                        _ptr(saved), sbytes, _ptr(scratch), scratch.numel(), _ptr(out),
+                                        _ptr(graph_rep), _stream()), 'eagcn_model_forward')
+        if holder is not None:
+            xo, po, ld = C.c_size_t(), C.c_size_t(), C.c_int()
+            lib.eagcn_model_atom_rep(index.ref(), C.byref(m), C.byref(xo), C.byref(po), C.byref(ld))
+            T = index.T
+            holder['xout'] = saved[xo.value:xo.value + 4 * T * ld.value].view(torch.float32).view(T, ld.value)
+            holder['pad_row'] = saved[po.value:po.value + 4 * ld.value].view(torch.float32)
+        ctx.plan, ctx.index, ctx.cmodel, ctx.saved_blob, ctx.size = plan, index, m, saved, size
+        ctx.save_for_backward(*params)
+        return out, graph_rep
+
+    @staticmethod
+    def backward(ctx, dout, dgraph_rep):
+        lib = L.load()
+        plan, index, m, saved = ctx.plan, ctx.index, ctx.cmodel, ctx.saved_blob
+        params = ctx.saved_tensors                     # version-checked by autograd
+        dev = saved.device
+        dout = dout.contiguous()
+        dgr = dgraph_rep.contiguous() if dgraph_rep is not None else None
+        flat = torch.empty(plan.offsets[-1], dtype=torch.float32, device=dev)
+        base = flat.data_ptr()
+
+        def gptr(i):
+            return base + 4 * plan.offsets[i]
+        lg = (L.LayerGrads * len(plan.layers))()
+        for l, (layer, (start, ave)) in enumerate(zip(plan.layers, plan.layer_slices)):
+            g = lg[l]
+            for k in range(layer.K):
+                i = start + 6 * k
+                g.datt_w[k], g.dself_r[k], g.dW[k] = gptr(i), gptr(i + 1), gptr(i + 2)
+                g.dbias[k], g.dgamma[k], g.dbeta[k] = gptr(i + 3), gptr(i + 4), gptr(i + 5)
+            g.dave_w = gptr(ave) if ave is not None else None
+        hg = L.HeadGrads()
+        hs = plan.head_start
+        for j, name in enumerate(('d_den1_w', 'd_den2_w', 'd_den3_w', 'd_gbn_w', 'd_gbn_b', 'd_bn1_w', 'd_bn1_b',
+                                  'd_bn2_w', 'd_bn2_b')):
+            setattr(hg, name, gptr(hs + j))
+        scratch = _scratch(dev, lib.eagcn_model_scratch_bytes(index.ref(), C.byref(m)))
+        L.check(lib.eagcn_model_backward(index.ref(), C.byref(m), _ptr(ctx.size) if plan.molfp else C.c_void_p(0),
+                                         _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(), _ptr(dout),
+                                         _ptr(dgr), lg, C.byref(hg), _stream()), 'eagcn_model_backward')
+        ctx.saved_blob = None
+        pieces = flat.split(plan.sizes)
+        grads = [p if len(sh) == 1 else p.view(sh) for p, sh in zip(pieces, plan.shapes)]
+        return (None, None, None, None, None, None, None, None, *grads)
+
+
+def model_forward(plan, index, holder, training, seed, dropout, size, afm):
+    return _ModelFn.apply(plan, index, holder, training, seed, dropout, size, afm, *plan.params)

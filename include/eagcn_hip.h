@@ -19,6 +19,9 @@
  *   eagcn_attention_dense<- the A_weight return value, layers.py:318 (stack of A1, layers.py:83)
  *   eagcn_readout_*      <- models.py:108-111 (sum / ave over atoms)
  *   eagcn_gemm_f32       <- Dense.forward layers.py:382-387 (x @ W), used by models.py:114-120
+ *   eagcn_model_forward / eagcn_model_backward
+ *                        <- EAGCN.forward models.py:96-121 end to end (layers, read-out, Graph_BN,
+ *                           den1/bn_den1/relu/dropout/den2/bn_den2/relu/den3) and its autograd backward
  *
  * Conventions: all pointers are device pointers unless named host_*; tensors are fp32,
  * contiguous, row-major; `stream` is a hipStream_t passed as void*; functions return 0 on
@@ -117,6 +120,8 @@ typedef struct eagcn_layer_bufs {
     float* pad_row;                         /* [ld_out] value of every non-stored row of xout   */
     void* scratch;
     size_t scratch_bytes;
+    void* packed;                           /* optional, eagcn_layer_packed_bytes(): forward keeps  */
+    size_t packed_bytes;                    /* the re-laid parameters here and backward reuses them */
 } eagcn_layer_bufs;
 
 typedef struct eagcn_layer_grads {
@@ -131,11 +136,13 @@ typedef struct eagcn_layer_grads {
 
 /* ---- library ------------------------------------------------------------------------------- */
 int eagcn_abi_version(void);
-size_t eagcn_struct_size(int which);   /* 0 batch, 1 layout, 2 layer_params, 3 layer_bufs, 4 layer_grads */
+size_t eagcn_struct_size(int which);   /* 0 batch, 1 layout, 2 layer_params, 3 layer_bufs, 4 layer_grads,
+                                          5 head_params, 6 head_grads, 7 model */
 const char* eagcn_last_error(void);
 int eagcn_pad16(int width);
 int eagcn_layer_out_ld(const eagcn_layer_params* p);   /* ld of xout                            */
 int eagcn_layer_fp(const eagcn_layer_params* p);       /* Fp = sum_k pad16(F_k)                 */
+size_t eagcn_layer_packed_bytes(const eagcn_batch* b, const eagcn_layer_params* p);
 size_t eagcn_layer_fwd_scratch_bytes(const eagcn_batch* b, const eagcn_layer_params* p);
 size_t eagcn_layer_bwd_scratch_bytes(const eagcn_batch* b, const eagcn_layer_params* p);
 
@@ -173,6 +180,44 @@ int eagcn_readout_forward(const eagcn_batch* b, const float* x, const eagcn_layo
 int eagcn_readout_backward(const eagcn_batch* b, const float* dg, const eagcn_layout* lay,
                            const int64_t* size, int mode, int F, float* dx, float* dpad_row,
                            void* stream);
+
+/* ---- whole model: one call forward, one call backward (reference models.py:96-121) -------------- */
+typedef struct eagcn_head_params {
+    int32_t f_in, n_den1, n_den2, nclass;
+    float dropout, bn_eps, bn_momentum;
+    const float *den1_w, *den2_w, *den3_w;          /* [f_in,n_den1] [n_den1,n_den2] [n_den2,nclass]   */
+    const float *gbn_w, *gbn_b;  float *gbn_rm, *gbn_rv;   /* Graph_BN   (models.py:80-88, 112)        */
+    const float *bn1_w, *bn1_b;  float *bn1_rm, *bn1_rv;   /* bn_den1    (models.py:115)               */
+    const float *bn2_w, *bn2_b;  float *bn2_rm, *bn2_rv;   /* bn_den2    (models.py:119)               */
+} eagcn_head_params;
+
+typedef struct eagcn_head_grads {
+    float *d_den1_w, *d_den2_w, *d_den3_w, *d_gbn_w, *d_gbn_b, *d_bn1_w, *d_bn1_b, *d_bn2_w, *d_bn2_b;
+} eagcn_head_grads;
+
+typedef struct eagcn_model {
+    int32_t n_layers;                       /* 1..4                                                    */
+    int32_t molfp_mode;                     /* 0 = 'sum', 1 = 'ave' (models.py:108-111)                */
+    int32_t training;
+    uint64_t head_seed;                     /* dropout stream of the head (models.py:116)              */
+    eagcn_layer_params layer[4];            /* layer[l].in must equal the output layout of layer l-1   */
+    eagcn_head_params head;
+} eagcn_model;
+
+size_t eagcn_model_saved_bytes(const eagcn_batch* b, const eagcn_model* m);    /* kept forward -> backward */
+size_t eagcn_model_scratch_bytes(const eagcn_batch* b, const eagcn_model* m);  /* transient, either call  */
+/* where the last layer's packed activations [T][ld] and pad_row [ld] live inside `saved` */
+int eagcn_model_atom_rep(const eagcn_batch* b, const eagcn_model* m, size_t* xout_offset,
+                         size_t* pad_row_offset, int* ld);
+/* afm: dense [B][N][n_afeat]; out: [B][nclass]; graph_rep: [B][n_den2] (den2 output, models.py:118) */
+int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, const float* afm, const int64_t* size,
+                        void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, float* out,
+                        float* graph_rep, void* stream);
+/* dgraph_rep may be NULL; lg: n_layers entries */
+int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, const int64_t* size, void* saved,
+                         size_t saved_bytes, void* scratch, size_t scratch_bytes, const float* dout,
+                         const float* dgraph_rep, const eagcn_layer_grads* lg, const eagcn_head_grads* hg,
+                         void* stream);
 
 /* ---- plain fp32 MFMA GEMM (head / tests) ------------------------------------------------------ */
 /* C[M,N] = op(A).op(B); ta/tb: 0 = as stored, 1 = transposed; leading dimensions in floats */

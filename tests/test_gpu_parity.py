@@ -196,3 +196,66 @@ def test_bad_inputs_raise():
         ops.BatchIndex(d[0], [r] + d[3:-1])
     with pytest.raises(EagcnHipError):
         ops.BatchIndex(d[0].cpu(), [t.cpu() for t in d[2:-1]])       # no CPU path
+
+
+@pytest.mark.parametrize('structure', ['Concate', 'Weighted_sum'])
+def test_engine_equals_layerwise_composition(structure):
+    """The one-call model engine and the layer-by-layer composition are the same computation."""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    torch.manual_seed(3)
+    w1, w2 = ([9, 7, 5, 5, 6], [12, 8, 6, 6, 8]) if structure == 'Concate' else ([3] * 5, [4] * 5)
+    mb = make_batch(B=10, n_max=40, n_med=11, rel_channels=(6, 4, 2, 2, 2), seed=21, isolated_frac=0.1)
+    a = EAGCN(6, 24, *w1, *w2, 24, 12, 3, 0.0, structure=structure, n_layers=3, molfp_mode='ave').cuda()
+    b = EAGCN(6, 24, *w1, *w2, 24, 12, 3, 0.0, structure=structure, n_layers=3, molfp_mode='ave').cuda()
+    b.load_state_dict(a.state_dict())
+    d = _dev(mb.dense())
+    gsel = torch.randn(10, 3, device='cuda')
+    oa, ra, ga = a(*d)
+    ob, rb, gb = b.forward_composed(*d)
+    assert rel_err(oa.detach().cpu(), ob.detach().cpu()) < 1e-6
+    assert rel_err(ga.detach().cpu(), gb.detach().cpu()) < 1e-6
+    assert rel_err(ra.cpu(), rb.cpu()) < 1e-6
+    ((oa * gsel).sum() + ga.sum()).backward()
+    ((ob * gsel).sum() + gb.sum()).backward()
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    scale = max(p.grad.abs().max().item() for p in pb.values() if p.grad is not None)
+    for k in pb:
+        assert (pa[k].grad is None) == (pb[k].grad is None), k
+        if pb[k].grad is not None:
+            # floor: Graph_BN.bias & co. sit in front of a training-mode BatchNorm -> analytically zero
+            assert_grad_close(pa[k].grad, pb[k].grad.cpu(), scale, k, rtol=1e-5, floor=1e-5)
+    for k, v in b.state_dict().items():
+        assert rel_err(a.state_dict()[k].double().cpu(), v.double().cpu()) < 1e-6, k
+
+
+def test_dropout_stream_is_seeded_and_consistent():
+    """Training-mode dropout: deterministic under torch.manual_seed, different across seeds, keeps
+    ~ (1-p) of the activations, and backward uses the same mask (gradient is finite and reproducible)."""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    mb = make_batch(B=32, n_max=50, n_med=14, rel_channels=(8, 4, 2, 2, 2), seed=4)
+    d = _dev(mb.dense())
+    model = EAGCN(8, 24, *[16] * 5, *[16] * 5, 32, 16, 2, 0.3, n_layers=2).cuda().train()
+
+    def run(seed):
+        torch.manual_seed(seed)
+        model.zero_grad(set_to_none=True)
+        out, rep, _ = model(*d)
+        out.sum().backward()
+        x, _, _ = rep.packed
+        return out.detach().clone(), x.clone(), model.layer1.block1.graph_conv.weight.grad.clone()
+    o1, x1, g1 = run(11)
+    o2, x2, g2 = run(11)
+    o3, x3, g3 = run(12)
+    assert torch.equal(o1, o2) and torch.equal(g1, g2)
+    assert not torch.equal(x1, x3)
+    assert torch.isfinite(g1).all()
+    model.eval()
+    with torch.no_grad():
+        _, rep_eval, _ = model(*d)
+    xe = rep_eval.packed[0]
+    live = xe > 0                                  # positions that relu keeps in eval mode
+    model.train()
+    kept = (x1[live] > 0).float().mean().item()    # BN statistics differ slightly train/eval: loose bound
+    assert 0.55 < kept < 0.85, kept

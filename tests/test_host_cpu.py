@@ -38,7 +38,8 @@ def test_ctypes_structs_match_c_layout():
     import ctypes as C
     from eagcn_amd import _lib
     lib = _lib.load()
-    for which, cls in enumerate((_lib.Batch, _lib.Layout, _lib.LayerParams, _lib.LayerBufs, _lib.LayerGrads)):
+    for which, cls in enumerate((_lib.Batch, _lib.Layout, _lib.LayerParams, _lib.LayerBufs, _lib.LayerGrads,
+                                 _lib.HeadParams, _lib.HeadGrads, _lib.Model)):
         assert lib.eagcn_struct_size(which) == C.sizeof(cls), cls.__name__
 
 
