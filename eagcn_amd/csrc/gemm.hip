@@ -7,9 +7,12 @@
 //
 // Operand storage is described by (ta, tb): ta = 0 -> A is [M][K] (K contiguous), ta = 1 -> A is
 // stored [K][M]; tb = 0 -> B is [K][N] (N contiguous), tb = 1 -> B is stored [N][K].
-// LDS images: a K-contiguous operand is kept [row][BK+1] (odd stride: the 16 rows x 2 k of a
-// 32-lane ds_read_b32 group hit 32 distinct banks); an MN-contiguous operand is kept [k][R+16]
+// LDS images: a K-contiguous operand is kept [row][BK+2] (stride = 2*odd: the 16 rows x 2 k of a
+// 32-lane ds_read_b32 group hit 32 distinct banks -- rows land on the 16 even banks, k+1 on the odd
+// ones; BK+1 measured 33-50 % bank-conflict cycles); an MN-contiguous operand is kept [k][R+16]
 // (stride = 16 mod 32: lanes 0-15 and 16-31 of a group land on disjoint bank halves).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -20,8 +23,8 @@ template <int BM, int BN, int BK, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
     constexpr int WM = BM / 2, WN = BN / 2;      // 2x2 waves
     constexpr int MR = WM / 16, NR = WN / 16;
-    constexpr int LDA_S = A_KC ? (BK + 1) : (BM + 16);
-    constexpr int LDB_S = B_KC ? (BK + 1) : (BN + 16);
+    constexpr int LDA_S = A_KC ? (BK + 2) : (BM + 16);
+    constexpr int LDB_S = B_KC ? (BK + 2) : (BN + 16);
     constexpr int A_SZ = A_KC ? BM * LDA_S : BK * LDA_S;
     constexpr int B_SZ = B_KC ? BN * LDB_S : BK * LDB_S;
     // loader geometry
@@ -116,8 +119,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
         for (int p = 0; p < A_PASS; ++p) {
             if constexpr (A_KC) {
                 int row = p * A_RPP + tid / A_TPR, kq = (tid % A_TPR) * 4;
-                float* d = As(buf) + row * LDA_S + kq;
-                d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
+                float2* d = reinterpret_cast<float2*>(As(buf) + row * LDA_S + kq);   // 8-byte aligned: LDA_S even
+                d[0] = make_float2(ra[p].x, ra[p].y);
+                d[1] = make_float2(ra[p].z, ra[p].w);
             } else {
                 int k = p * A_RPP + tid / A_TPR, mq = (tid % A_TPR) * 4;
                 *reinterpret_cast<float4*>(As(buf) + k * LDA_S + mq) = ra[p];
@@ -127,8 +131,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
         for (int p = 0; p < B_PASS; ++p) {
             if constexpr (B_KC) {
                 int row = p * B_RPP + tid / B_TPR, kq = (tid % B_TPR) * 4;
-                float* d = Bs(buf) + row * LDB_S + kq;
-                d[0] = rb[p].x; d[1] = rb[p].y; d[2] = rb[p].z; d[3] = rb[p].w;
+                float2* d = reinterpret_cast<float2*>(Bs(buf) + row * LDB_S + kq);
+                d[0] = make_float2(rb[p].x, rb[p].y);
+                d[1] = make_float2(rb[p].z, rb[p].w);
             } else {
                 int k = p * B_RPP + tid / B_TPR, nq = (tid % B_TPR) * 4;
                 *reinterpret_cast<float4*>(Bs(buf) + k * LDB_S + nq) = rb[p];
@@ -209,9 +214,21 @@ int launch_gemm(const GemmDesc& g0, hipStream_t s) {
     g.vecA = (g.lda % 4) == 0 && ((g.ta ? g.M : g.K) % 4) == 0 && (reinterpret_cast<uintptr_t>(g.A) % 16) == 0;
     g.vecB = (g.ldb % 4) == 0 && ((g.tb ? g.K : g.N) % 4) == 0 && (reinterpret_cast<uintptr_t>(g.B) % 16) == 0;
     if (g.splits > 1) EAGCN_CHECK_ARG(g.vecA && g.vecB, "gemm: split-K needs float4-aligned operands");
-    const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.splits;
-    if (tiles128 >= 384) return launch_cfg<128, 128, 16>(g, s);
-    return launch_cfg<64, 64, 16>(g, s);
+    // tile choice: EAGCN_GEMM_CFG=<id> forces one configuration (tools/gemm_bench.py)
+    static const int forced = [] { const char* e = getenv("EAGCN_GEMM_CFG"); return e ? atoi(e) : -1; }();
+    int cfg = forced;
+    if (cfg < 0) {
+        const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.splits;
+        cfg = tiles128 >= 384 ? 3 : 0;
+    }
+    switch (cfg) {
+        case 1: return launch_cfg<64, 64, 32>(g, s);
+        case 2: return launch_cfg<128, 64, 16>(g, s);
+        case 3: return launch_cfg<128, 128, 16>(g, s);
+        case 4: return launch_cfg<128, 128, 32>(g, s);
+        case 5: return launch_cfg<128, 64, 32>(g, s);
+        default: return launch_cfg<64, 64, 16>(g, s);
+    }
 }
 
 }  // namespace eagcn

@@ -18,7 +18,8 @@ def init_distributed(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('EAGCN_FORCE_DIST', '0') == '1'      # exercise the RCCL path on one GPU
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -50,7 +51,9 @@ class GradientAllReducer:
         self._flat = None
 
     def __call__(self):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not dist.is_initialized():
+            return
+        if dist.get_world_size(self.group) == 1 and os.environ.get('EAGCN_FORCE_DIST', '0') != '1':
             return
         grads = [p.grad for p in self.params if p.grad is not None]
         if not grads:

@@ -226,7 +226,9 @@ def test_engine_equals_layerwise_composition(structure):
             # floor: Graph_BN.bias & co. sit in front of a training-mode BatchNorm -> analytically zero
             assert_grad_close(pa[k].grad, pb[k].grad.cpu(), scale, k, rtol=1e-5, floor=1e-5)
     for k, v in b.state_dict().items():
-        assert rel_err(a.state_dict()[k].double().cpu(), v.double().cpu()) < 1e-6, k
+        # absolute floor: bn_den1.running_mean is analytically zero (its input is a BatchNorm output times W)
+        d = (a.state_dict()[k].double().cpu() - v.double().cpu()).abs().max().item()
+        assert d <= 1e-6 * max(v.double().abs().max().item(), 1.0), (k, d)
 
 
 def test_dropout_stream_is_seeded_and_consistent():
@@ -251,11 +253,17 @@ def test_dropout_stream_is_seeded_and_consistent():
     assert torch.equal(o1, o2) and torch.equal(g1, g2)
     assert not torch.equal(x1, x3)
     assert torch.isfinite(g1).all()
-    model.eval()
+    # keep-rate and scaling on a 1-layer model, where BatchNorm statistics do not depend on dropout
+    m1 = EAGCN(8, 24, *[16] * 5, *[16] * 5, 32, 16, 2, 0.3, n_layers=1).cuda().train()
+    torch.manual_seed(5)
     with torch.no_grad():
-        _, rep_eval, _ = model(*d)
-    xe = rep_eval.packed[0]
-    live = xe > 0                                  # positions that relu keeps in eval mode
-    model.train()
-    kept = (x1[live] > 0).float().mean().item()    # BN statistics differ slightly train/eval: loose bound
-    assert 0.55 < kept < 0.85, kept
+        xd = m1(*d)[1].packed[0].clone()
+        m1.dropout = 0.0
+        m1.layer1.dropout = 0.0
+        x0 = m1(*d)[1].packed[0].clone()
+    live = x0 > 0
+    kept = (xd[live] != 0).float().mean().item()
+    assert 0.68 < kept < 0.72, kept
+    both = live & (xd != 0)
+    assert torch.allclose(xd[both], x0[both] / 0.7, rtol=1e-5, atol=1e-6)
+    assert (xd[~live] == 0).all()
