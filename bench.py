@@ -43,7 +43,7 @@ PEAK_HBM_GBS = 8000.0
 def build_model(cfg, dropout, device):
     from eagcn_amd import EAGCN, weights_init
     m = EAGCN(cfg['n_bfeat'], 24, *cfg['widths1'], *cfg['widths2'], cfg['dens'][0], cfg['dens'][1], cfg['nclass'],
-              dropout, structure=cfg['structure'], n_layers=cfg['n_layers'], atom_rep='lazy')
+              dropout, structure=cfg['structure'], n_layers=cfg['n_layers'], atom_rep='lazy', grad_mode='direct')
     m.apply(weights_init)
     return m.to(device)
 
@@ -142,7 +142,7 @@ def main():
     args = ap.parse_args()
 
     from eagcn_amd import _lib
-    from eagcn_amd.losses import classification_loss, regression_loss
+    from eagcn_amd.losses import fused_classification_loss, fused_regression_loss
     from eagcn_amd.parallel import GradientAllReducer, init_distributed
     from eagcn_amd.synthetic import bce_weights, make_batch
     lib = _lib.load()                                    # fail loudly if the HIP library is missing
@@ -172,9 +172,9 @@ def main():
             p.grad = None
         out, _, _ = model(*dense)
         if cfg['task'] == 'class':
-            loss = classification_loss(out, labels, bce_w_dev)
+            loss = fused_classification_loss(out, labels, bce_w_dev)
         else:
-            loss = regression_loss(out, labels)
+            loss = fused_regression_loss(out, labels)
         loss.backward()
         reducer()
         return loss

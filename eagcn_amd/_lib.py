@@ -106,6 +106,8 @@ SIGNATURES = {
                                       C.c_size_t, _fp, _fp, _fp]),
     'eagcn_model_backward': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, C.c_size_t, _fp, C.c_size_t,
                                        _fp, _fp, C.POINTER(LayerGrads), C.POINTER(HeadGrads), _fp]),
+    'eagcn_bce_loss': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
+    'eagcn_mse_loss': (C.c_int, [_fp, _fp, C.c_int, _fp, _fp, _fp]),
     'eagcn_prof_enable': (None, [C.c_int]),
     'eagcn_prof_reset': (None, []),
     'eagcn_prof_ntags': (C.c_int, []),

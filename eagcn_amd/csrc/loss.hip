@@ -1,0 +1,84 @@
+// Losses of the reference training loop, fused: value and gradient w.r.t. the logits in one launch.
+//   classification (train.py:326-331 + utils.py:653-679): weight[b,t] = w[t][0] if label == 1,
+//   w[t][1] if label == 0, else 0 (missing label); loss = sum_i weight_i * bce_with_logits(x_i, y_i)
+//   / #labels in {0,1}.   regression (train.py:321-325): mean squared error.
+// The reference builds the weight tensor with a B x T Python double loop (10 ms per 64x12 batch).
+#include "common.h"
+
+namespace eagcn {
+
+// single workgroup: B*T is at most a few 10^4 elements
+__global__ __launch_bounds__(1024) void bce_loss_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ w, int B, int T,
+                                                         float* __restrict__ loss, float* __restrict__ dx) {
+    __shared__ double s_sum[16];
+    __shared__ int s_cnt[16];
+    const int n = B * T;
+    double acc = 0.0;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float yi = y[i], xi = x[i];
+        const int t = i % T;
+        const float wi = yi == 1.0f ? w[t * 2 + 0] : (yi == 0.0f ? w[t * 2 + 1] : 0.0f);
+        cnt += (yi == 1.0f || yi == 0.0f) ? 1 : 0;
+        // max(x,0) - x*y + log1p(exp(-|x|)): the numerically stable form ATen uses
+        const float l = fmaxf(xi, 0.0f) - xi * yi + log1pf(expf(-fabsf(xi)));
+        acc += (double)(wi * l);
+    }
+    acc = wave_sum(acc);
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = acc; s_cnt[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    double tot = 0.0;
+    int c = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { tot += s_sum[k]; c += s_cnt[k]; }
+    const float inv = 1.0f / (float)c;
+    if (threadIdx.x == 0) loss[0] = (float)(tot / (double)c);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float yi = y[i], xi = x[i];
+        const int t = i % T;
+        const float wi = yi == 1.0f ? w[t * 2 + 0] : (yi == 0.0f ? w[t * 2 + 1] : 0.0f);
+        dx[i] = wi * (1.0f / (1.0f + expf(-xi)) - yi) * inv;
+    }
+}
+
+__global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         int n, float* __restrict__ loss, float* __restrict__ dx) {
+    __shared__ double s_sum[16];
+    double acc = 0.0;
+    const float inv = 1.0f / (float)n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float d = x[i] - y[i];
+        acc += (double)d * (double)d;
+        dx[i] = 2.0f * d * inv;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) tot += s_sum[k];
+        loss[0] = (float)(tot / (double)n);
+    }
+}
+
+}  // namespace eagcn
+
+using namespace eagcn;
+
+extern "C" int eagcn_bce_loss(const float* logits, const float* labels, const float* class_weight, int B, int T,
+                              float* loss, float* dlogits, void* stream) {
+    EAGCN_CHECK_ARG(logits && labels && class_weight && loss && dlogits, "eagcn_bce_loss: null argument");
+    EAGCN_CHECK_ARG(B > 0 && T > 0, "eagcn_bce_loss: empty batch");
+    bce_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, labels, class_weight, B, T, loss, dlogits);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_mse_loss(const float* pred, const float* target, int n, float* loss, float* dpred, void* stream) {
+    EAGCN_CHECK_ARG(pred && target && loss && dpred, "eagcn_mse_loss: null argument");
+    EAGCN_CHECK_ARG(n > 0, "eagcn_mse_loss: empty batch");
+    mse_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(pred, target, n, loss, dpred);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}

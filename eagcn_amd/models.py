@@ -8,6 +8,10 @@ that fix ``structure``.  Keyword-only extensions (defaults = reference behaviour
                 BASELINE.json's configs use 2 and 3.  Layers 3/4 use twice the layer-2 widths.
   rel_channels  channels of every relation tensor (default [n_bfeat,4,2,2,2]); with ``widths1`` /
                 ``widths2`` lists this allows K != 5 views.
+  grad_mode     'autograd' (default): parameter gradients are returned through autograd as usual;
+                'direct': the backward call writes them into ONE flat buffer and sets ``p.grad`` to
+                views of it (accumulating into an existing ``.grad``), which skips ~70 AccumulateGrad
+                nodes per step.  Same values; tensor hooks on parameters do not fire in this mode.
   atom_rep      'lazy' (default) | 'eager' | 'none': the reference copies the last layer's atom
                 representations to the host in EVERY forward (``x2.data.cpu()``, models.py:102), a
                 device->host copy plus a sync per step; 'lazy' returns an object that performs the
@@ -54,7 +58,8 @@ class EAGCN(nn.Module):
     def __init__(self, n_bfeat, n_afeat, n_sgc1_1=None, n_sgc1_2=None, n_sgc1_3=None, n_sgc1_4=None,
                  n_sgc1_5=None, n_sgc2_1=None, n_sgc2_2=None, n_sgc2_3=None, n_sgc2_4=None, n_sgc2_5=None,
                  n_den1=128, n_den2=64, nclass=1, dropout=0.0, structure='Concate', molfp_mode='sum',
-                 pool_num=5, *, n_layers=4, widths1=None, widths2=None, rel_channels=None, atom_rep='lazy'):
+                 pool_num=5, *, n_layers=4, widths1=None, widths2=None, rel_channels=None, atom_rep='lazy',
+                 grad_mode='autograd'):
         super().__init__()
         if widths1 is None:
             widths1 = [n_sgc1_1, n_sgc1_2, n_sgc1_3, n_sgc1_4, n_sgc1_5]
@@ -91,6 +96,9 @@ class EAGCN(nn.Module):
         self.n_layers, self.n_afeat, self.K = n_layers, n_afeat, K
         self.structure, self.molfp_mode, self.dropout = structure, molfp_mode, dropout
         self.atom_rep = atom_rep
+        if grad_mode not in ('autograd', 'direct'):
+            raise ValueError("grad_mode must be 'autograd' or 'direct'")
+        self.grad_mode = grad_mode
         self.den1 = Dense(f_last, n_den1)
         self.den2 = Dense(n_den1, n_den2)
         self.den3 = Dense(n_den2, nclass)
@@ -134,7 +142,7 @@ class EAGCN(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         holder = {} if self.atom_rep != 'none' else None
         out, graph_representation = ops.model_forward(plan, index, holder, self.training, seed, self.dropout,
-                                                      size, afms)
+                                                      size, afms, direct=(self.grad_mode == 'direct'))
         if self.training:
             torch._foreach_add_(plan.nbt, 1)
         atom_representations = None

@@ -85,17 +85,23 @@ class BatchIndex:
         self.ldc = (N + 15) // 16 * 16
         i32 = dict(dtype=torch.int32, device=dev)
         self.code = torch.empty((K, B, N, self.ldc), dtype=torch.uint8, device=dev)
-        self.deg_bn = torch.empty((B, N), **i32)
-        self.nat = torch.empty(B, **i32)
-        self.row0 = torch.empty(B + 1, **i32)
-        self.tile0 = torch.empty(B + 1, **i32)
-        self.meta = torch.empty(L.META_WORDS, **i32)
+        # one allocation for the small int32 arrays: [deg_bn B*N | nat B | row0 B+1 | tile0 B+1 | meta]
+        blob = torch.empty(B * N + 3 * B + 2 + L.META_WORDS, **i32)
+        o = 0
+        self.deg_bn = blob[o:o + B * N]; o += B * N
+        self.nat = blob[o:o + B]; o += B
+        self.row0 = blob[o:o + B + 1]; o += B + 1
+        self.tile0 = blob[o:o + B + 1]; o += B + 1
+        self.meta = blob[o:o + L.META_WORDS]
+        self._blob = blob
         c = L.Batch()
         c.B, c.N, c.K, c.ldc = B, N, K, self.ldc
         for k in range(K):
             c.channels[k] = self.channels[k]
-        c.code, c.deg_bn, c.nat = self.code.data_ptr(), self.deg_bn.data_ptr(), self.nat.data_ptr()
-        c.row0, c.tile0, c.meta = self.row0.data_ptr(), self.tile0.data_ptr(), self.meta.data_ptr()
+        base = blob.data_ptr()
+        c.code, c.deg_bn, c.nat = self.code.data_ptr(), base, base + 4 * B * N
+        c.row0, c.tile0 = base + 4 * (B * N + B), base + 4 * (B * N + 2 * B + 1)
+        c.meta = base + 4 * (B * N + 3 * B + 2)
         rel_ptrs = (C.c_void_p * K)(*[r.data_ptr() for r in rels])
         host = _host_meta(dev)
         L.check(lib.eagcn_index_build(_ptr(adj), rel_ptrs, C.byref(c), C.c_void_p(host.data_ptr()), _stream()),
@@ -111,14 +117,14 @@ class BatchIndex:
         self.T, self.n_max, self.n_tiles = meta[L.META_T], meta[L.META_NMAX], meta[L.META_NTILES]
         self.n_edges = meta[L.META_NEDGE]
         T = self.T
-        self.row_mol = torch.empty(T, **i32)
-        self.row_loc = torch.empty(T, **i32)
-        self.row_deg = torch.empty(T, **i32)
-        self.row_m = torch.empty(T, dtype=torch.float32, device=dev)
-        self.tile_mol = torch.empty(self.n_tiles, **i32)
+        rows = torch.empty(4 * T + self.n_tiles, **i32)          # [row_mol | row_loc | row_deg | row_m(f32) | tile_mol]
+        self.row_mol, self.row_loc, self.row_deg = rows[0:T], rows[T:2 * T], rows[2 * T:3 * T]
+        self.row_m = rows[3 * T:4 * T].view(torch.float32)
+        self.tile_mol = rows[4 * T:]
+        self._rows = rows
         c.T, c.n_max, c.n_tiles = T, self.n_max, self.n_tiles
-        c.row_mol, c.row_loc, c.row_m = self.row_mol.data_ptr(), self.row_loc.data_ptr(), self.row_m.data_ptr()
-        c.row_deg, c.tile_mol = self.row_deg.data_ptr(), self.tile_mol.data_ptr()
+        rb = rows.data_ptr()
+        c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = rb, rb + 4 * T, rb + 8 * T, rb + 12 * T, rb + 16 * T
         L.check(lib.eagcn_index_rows(C.byref(c), _stream()), 'eagcn_index_rows')
         self.c = c
         self._keep = (adj, rels)
@@ -476,6 +482,8 @@ class ModelPlan:
         self.offsets = [0]
         for n in self.sizes:
             self.offsets.append(self.offsets[-1] + n)
+        self.trigger = None
+        self.flat_grad = None
         self.nbt = [blk.batch_norm.bn.num_batches_tracked for layer in layers for blk in layer.blocks()] + \
                    [h['Graph_BN'].num_batches_tracked, h['bn_den1'].num_batches_tracked,
                     h['bn_den2'].num_batches_tracked]
@@ -514,9 +522,12 @@ class _ModelFn(torch.autograd.Function):
     eagcn_model_forward, one into eagcn_model_backward."""
 
     @staticmethod
-    def forward(ctx, plan, index, holder, training, seed, dropout, size, afm, *params):
+    def forward(ctx, plan, index, holder, training, seed, dropout, size, afm, trigger, *params):
         lib = L.load()
         afm = _need_cuda_f32(afm, 'afms')
+        ctx.direct = trigger is not None
+        if ctx.direct:
+            params = plan.params
         for i, t in enumerate(params):
             if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
                 raise L.EagcnHipError('parameter %d must be a contiguous fp32 device tensor' % i)
@@ -542,14 +553,16 @@ class _ModelFn(torch.autograd.Function):
             holder['xout'] = saved[xo.value:xo.value + 4 * T * ld.value].view(torch.float32).view(T, ld.value)
             holder['pad_row'] = saved[po.value:po.value + 4 * ld.value].view(torch.float32)
         ctx.plan, ctx.index, ctx.cmodel, ctx.saved_blob, ctx.size = plan, index, m, saved, size
-        ctx.save_for_backward(*params)
+        if not ctx.direct:
+            ctx.save_for_backward(*params)
         return out, graph_rep
 
     @staticmethod
     def backward(ctx, dout, dgraph_rep):
         lib = L.load()
         plan, index, m, saved = ctx.plan, ctx.index, ctx.cmodel, ctx.saved_blob
-        params = ctx.saved_tensors                     # version-checked by autograd
+        if not ctx.direct:
+            ctx.saved_tensors                          # version check of the parameters by autograd
         dev = saved.device
         dout = dout.contiguous()
         dgr = dgraph_rep.contiguous() if dgraph_rep is not None else None
@@ -578,8 +591,22 @@ class _ModelFn(torch.autograd.Function):
         ctx.saved_blob = None
         pieces = flat.split(plan.sizes)
         grads = [p if len(sh) == 1 else p.view(sh) for p, sh in zip(pieces, plan.shapes)]
-        return (None, None, None, None, None, None, None, None, *grads)
+        if ctx.direct:
+            # gradients are delivered straight into .grad as views of ONE flat buffer (accumulating if a
+            # gradient is already there), bypassing ~70 AccumulateGrad nodes
+            for p, g in zip(plan.params, grads):
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
+            plan.flat_grad = flat
+            return (None,) * 10
+        return (None, None, None, None, None, None, None, None, None, *grads)
 
 
-def model_forward(plan, index, holder, training, seed, dropout, size, afm):
-    return _ModelFn.apply(plan, index, holder, training, seed, dropout, size, afm, *plan.params)
+def model_forward(plan, index, holder, training, seed, dropout, size, afm, direct=False):
+    if direct and torch.is_grad_enabled():
+        if plan.trigger is None or plan.trigger.device != afm.device:
+            plan.trigger = torch.zeros((), dtype=torch.float32, device=afm.device, requires_grad=True)
+        return _ModelFn.apply(plan, index, holder, training, seed, dropout, size, afm, plan.trigger)
+    return _ModelFn.apply(plan, index, holder, training, seed, dropout, size, afm, None, *plan.params)

@@ -19,6 +19,8 @@
  *   eagcn_attention_dense<- the A_weight return value, layers.py:318 (stack of A1, layers.py:83)
  *   eagcn_readout_*      <- models.py:108-111 (sum / ave over atoms)
  *   eagcn_gemm_f32       <- Dense.forward layers.py:382-387 (x @ W), used by models.py:114-120
+ *   eagcn_bce_loss / eagcn_mse_loss
+ *                        <- the loss of train.py:321-331 incl. weight_tensor utils.py:653-679
  *   eagcn_model_forward / eagcn_model_backward
  *                        <- EAGCN.forward models.py:96-121 end to end (layers, read-out, Graph_BN,
  *                           den1/bn_den1/relu/dropout/den2/bn_den2/relu/den3) and its autograd backward
@@ -218,6 +220,12 @@ int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, const int64
                          size_t saved_bytes, void* scratch, size_t scratch_bytes, const float* dout,
                          const float* dgraph_rep, const eagcn_layer_grads* lg, const eagcn_head_grads* hg,
                          void* stream);
+
+/* ---- losses of the training loop (train.py:321-331), value + d/dlogits in one launch --------------- */
+/* labels [B][T] with 1 / 0 / anything else = missing; class_weight [T][2] = {w_pos, w_neg} (utils.py:681-700) */
+int eagcn_bce_loss(const float* logits, const float* labels, const float* class_weight, int B, int T,
+                   float* loss, float* dlogits, void* stream);
+int eagcn_mse_loss(const float* pred, const float* target, int n, float* loss, float* dpred, void* stream);
 
 /* ---- plain fp32 MFMA GEMM (head / tests) ------------------------------------------------------ */
 /* C[M,N] = op(A).op(B); ta/tb: 0 = as stored, 1 = transposed; leading dimensions in floats */

@@ -267,3 +267,38 @@ def test_dropout_stream_is_seeded_and_consistent():
     both = live & (xd != 0)
     assert torch.allclose(xd[both], x0[both] / 0.7, rtol=1e-5, atol=1e-6)
     assert (xd[~live] == 0).all()
+
+
+def test_direct_grad_mode_and_fused_losses_match_autograd():
+    """grad_mode='direct' + the fused loss kernels give the same loss and .grad as the autograd path
+    with tensor-op losses, including accumulation over two backward passes."""
+    from eagcn_amd import EAGCN, losses
+    from eagcn_amd.synthetic import bce_weights, make_batch
+    torch.manual_seed(9)
+    mb = make_batch(B=12, n_max=30, n_med=9, rel_channels=(6, 4, 2, 2, 2), seed=8, n_tasks=5)
+    d = _dev(mb.dense())
+    labels = torch.from_numpy(mb.labels).cuda()
+    bw = torch.tensor(bce_weights(5), device='cuda')
+    a = EAGCN(6, 24, *[8] * 5, *[12] * 5, 16, 8, 5, 0.0, n_layers=2).cuda()
+    b = EAGCN(6, 24, *[8] * 5, *[12] * 5, 16, 8, 5, 0.0, n_layers=2, grad_mode='direct').cuda()
+    b.load_state_dict(a.state_dict())
+    for rep in range(2):                                    # second pass accumulates into .grad
+        la = losses.classification_loss(a(*d)[0], labels, bw)
+        lb = losses.fused_classification_loss(b(*d)[0], labels, bw)
+        assert abs(float(la) - float(lb)) < 1e-5 * max(1.0, abs(float(la)))
+        la.backward()
+        lb.backward()
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    scale = max(p.grad.abs().max().item() for p in pa.values() if p.grad is not None)
+    for k in pa:
+        assert (pa[k].grad is None) == (pb[k].grad is None), k
+        if pa[k].grad is not None:
+            assert_grad_close(pb[k].grad, pa[k].grad.cpu(), scale, k, rtol=1e-5, floor=1e-5)
+    # regression loss
+    out = torch.randn(12, 1, device='cuda', requires_grad=True)
+    tgt = torch.randn(12, 1, device='cuda')
+    l1 = losses.regression_loss(out, tgt)
+    g1, = torch.autograd.grad(l1, out)
+    l2 = losses.fused_regression_loss(out, tgt)
+    g2, = torch.autograd.grad(l2, out)
+    assert abs(float(l1) - float(l2)) < 1e-6 and rel_err(g2.cpu(), g1.cpu()) < 1e-6
