@@ -43,7 +43,7 @@ PEAK_HBM_GBS = 8000.0
 def build_model(cfg, dropout, device):
     from eagcn_amd import EAGCN, weights_init
     m = EAGCN(cfg['n_bfeat'], 24, *cfg['widths1'], *cfg['widths2'], cfg['dens'][0], cfg['dens'][1], cfg['nclass'],
-              dropout, structure=cfg['structure'], n_layers=cfg['n_layers'], atom_rep='lazy', grad_mode='direct')
+              dropout, structure=cfg['structure'], n_layers=cfg['n_layers'], atom_rep='lazy', grad_mode='direct', overlap_index=True)
     m.apply(weights_init)
     return m.to(device)
 

@@ -216,44 +216,66 @@ int launch_agg(AggArgs a, bool trans, hipStream_t s) {
 //   d w_k[c] += dU[i,j] s (1-s)  at bonds of type c ;   d self_r_k += dU[i,i] r (1-r)
 // one wavefront per (packed row, view); results accumulated in fp64.
 __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
+    // each 16-lane group of a wavefront owns one packed row: 4 rows in flight per wave, dot products
+    // reduced inside the group (lanes of a group read 64 contiguous bytes per step)
     __shared__ float sig_s[256];
     __shared__ double h_s[256];
-    __shared__ double dr_s[4];
+    __shared__ double dr_s[16];
     const int k = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane >> 4, sl = lane & 15;
     sig_s[tid] = a.sig[k * 256 + tid];
     h_s[tid] = 0.0;
-    if (tid < 4) dr_s[tid] = 0.0;
+    if (tid < 16) dr_s[tid] = 0.0;
     __syncthreads();
     const eagcn_batch& bt = a.bt;
     const int off = a.vc.off[k], fp = a.vc.off[k + 1] - a.vc.off[k];
     double dr_acc = 0.0;
-    for (int r = blockIdx.x * 4 + wave; r < bt.T; r += gridDim.x * 4) {
-        const float rs = a.rscale[(size_t)k * bt.T + r];
-        if (rs == 0.0f) continue;                                  // m_i == 0: no dependence
-        const int b = bt.row_mol[r], i = bt.row_loc[r];
-        const int n = bt.nat[b], r0 = bt.row0[b];
-        const float* dy = a.dY + (size_t)r * a.ld + off;
-        const float* yr = a.Y + (size_t)r * a.ld + off;
+    for (int rbase = (blockIdx.x * 4 + wave) * 4; rbase < bt.T; rbase += gridDim.x * 16) {
+        const int r = rbase + grp;
+        float rs = 0.0f;
+        int b = 0, i = 0, n = 0, r0 = 0;
+        if (r < bt.T) {
+            rs = a.rscale[(size_t)k * bt.T + r];
+            b = bt.row_mol[r];
+            i = bt.row_loc[r];
+            n = bt.nat[b];
+            r0 = bt.row0[b];
+        }
+        const bool live = rs != 0.0f;                              // m_i == 0 rows carry no dependence
+        const int rr = live ? r : 0;
+        const float* dy = a.dY + (size_t)rr * a.ld + off;
+        const float* yr = a.Y + (size_t)rr * a.ld + off;
         float rd = 0.0f;
-        for (int c = lane; c < fp; c += 64) rd += dy[c] * yr[c];
-        rd = wave_sum(rd);
+        if (live)
+            for (int c = sl; c < fp; c += 16) rd += dy[c] * yr[c];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) rd += __shfl_xor(rd, o);
         const uint8_t* crow = bt.code + (((size_t)k * bt.B + b) * bt.N + i) * bt.ldc;
-        for (int jb = 0; jb < n; jb += 64) {
-            const int j = jb + lane;
-            const uint32_t c = (j < n) ? crow[j] : 0u;
-            unsigned long long mask = __ballot((c != 0u) || (j == i && j < n));
-            while (mask) {
-                const int src = __builtin_ctzll(mask);
+        const int nmax = max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48)));
+        for (int jb = 0; jb < nmax; jb += 16) {
+            const int j = jb + sl;
+            const uint32_t c = (live && j < n) ? crow[j] : 0u;
+            const bool want = live && j < n && (c != 0u || j == i);
+            unsigned long long ball = __ballot(want);
+            uint32_t mask = (uint32_t)(ball >> (grp * 16)) & 0xFFFFu;           // this group's hits
+            // the groups iterate their own hit lists in lock step (uniform trip count = longest list)
+            int cnt = __popc(mask);
+            const int cmax = max(max(__shfl(cnt, 0), __shfl(cnt, 16)), max(__shfl(cnt, 32), __shfl(cnt, 48)));
+            for (int it = 0; it < cmax; ++it) {
+                const bool act = mask != 0u;
+                const int src = act ? (__ffs(mask) - 1) : 0;
                 mask &= mask - 1;
                 const int jj = jb + src;
-                const uint32_t cj = __shfl(c, src);
-                const float* pr = a.P + (size_t)(r0 + jj) * a.ld + off;
+                const uint32_t cj = __shfl(c, grp * 16 + src);
+                const float* pr = a.P + (size_t)(act ? (r0 + jj) : 0) * a.ld + off;
                 float g = 0.0f;
-                for (int c2 = lane; c2 < fp; c2 += 64) g += dy[c2] * pr[c2];
-                g = wave_sum(g);
-                const float dU = rs * (g - rd);
-                if (lane == 0) {
+                if (act)
+                    for (int c2 = sl; c2 < fp; c2 += 16) g += dy[c2] * pr[c2];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) g += __shfl_xor(g, o);
+                if (act && sl == 0) {
+                    const float dU = rs * (g - rd);
                     if (cj) {
                         const float s = sig_s[cj];
                         atomicAdd(&h_s[cj], (double)(dU * s * (1.0f - s)));
@@ -263,15 +285,19 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
             }
         }
     }
-    if (lane == 0) dr_s[wave] = dr_acc;
+    if (sl == 0) dr_s[wave * 4 + grp] = dr_acc;
     __syncthreads();
     // slab[blockIdx.x][k][0..255] = bond-type histogram, slab[..][k][256] = self term
     double* out = a.datt + ((size_t)blockIdx.x * a.vc.K + k) * EDGE_SLAB;
     out[tid] = h_s[tid];
-    if (tid == 0) out[256] = dr_s[0] + dr_s[1] + dr_s[2] + dr_s[3];
+    if (tid == 0) {
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += dr_s[q];
+        out[256] = t;
+    }
 }
 
-int edge_grid_x(const eagcn_batch* b) { return std::max(1, std::min(cdiv(b->T, 4), 256)); }
+int edge_grid_x(const eagcn_batch* b) { return std::max(1, std::min(cdiv(b->T, 16), 256)); }
 
 int launch_edge_grad(const EdgeArgs& a, hipStream_t s) {
     if (a.bt.T == 0) return EAGCN_OK;

@@ -30,17 +30,31 @@ struct RowBnFwd {
     uint32_t thr; float inv_keep; uint64_t seed;
 };
 
-// 16 columns x 16 row-lanes per workgroup
+// 16 columns x 16 row-lanes per workgroup; each lane keeps up to RB_CACHE of its rows in registers so
+// the statistics pass and the normalisation pass share ONE set of loads, all issued back to back
+constexpr int RB_CACHE = 16;          // rows per lane kept in registers -> R <= 256 needs no second read
+
 __global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnFwd a) {
     const int cr = blockIdx.x * 16 + (threadIdx.x >> 4), rl = threadIdx.x & 15;
     const int c = min(cr, a.F - 1);
+    float v[RB_CACHE];
+#pragma unroll
+    for (int t = 0; t < RB_CACHE; ++t) {
+        const int r = rl + 16 * t;
+        v[t] = r < a.R ? a.x[(size_t)r * a.F + c] : 0.0f;
+    }
     float mu, inv;
     if (a.training) {
         double s1 = 0.0, s2 = 0.0;
-        for (int r = rl; r < a.R; r += 16) {
-            const double v = (double)a.x[(size_t)r * a.F + c];
-            s1 += v;
-            s2 += v * v;
+#pragma unroll
+        for (int t = 0; t < RB_CACHE; ++t) {
+            s1 += (double)v[t];
+            s2 += (double)v[t] * (double)v[t];
+        }
+        for (int r = rl + 16 * RB_CACHE; r < a.R; r += 16) {
+            const double x = (double)a.x[(size_t)r * a.F + c];
+            s1 += x;
+            s2 += x * x;
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) {
@@ -69,12 +83,18 @@ __global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnFwd a) {
         a.bn[RB_MU * a.F + c] = mu;
         a.bn[RB_INV * a.F + c] = inv;
     }
-    for (int r = rl; r < a.R; r += 16) {
-        float h = a.x[(size_t)r * a.F + c] * sc + sh;
+    auto emit = [&](int r, float x) {
+        float h = x * sc + sh;
         if (a.relu) h = fmaxf(h, 0.0f);
         if (a.do_drop) h *= drop_scale(a.seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
         a.y[(size_t)r * a.F + c] = h;
+    };
+#pragma unroll
+    for (int t = 0; t < RB_CACHE; ++t) {
+        const int r = rl + 16 * t;
+        if (r < a.R) emit(r, v[t]);
     }
+    for (int r = rl + 16 * RB_CACHE; r < a.R; r += 16) emit(r, a.x[(size_t)r * a.F + c]);
 }
 
 struct RowBnBwd {
@@ -91,14 +111,32 @@ __global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwd a) {
     const int c = min(cr, a.F - 1);
     const float sc = a.bn[RB_SC * a.F + c], sh = a.bn[RB_SH * a.F + c];
     const float mu = a.bn[RB_MU * a.F + c], inv = a.bn[RB_INV * a.F + c];
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = rl; r < a.R; r += 16) {
-        const float xv = a.x[(size_t)r * a.F + c];
-        float dh = a.dy[(size_t)r * a.F + c];
+    auto upstream = [&](int r, float xv, float dyv) {      // gradient that reaches the BatchNorm output
+        float dh = dyv;
         if (a.do_drop) dh *= drop_scale(a.seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
         if (a.relu && !(xv * sc + sh > 0.0f)) dh = 0.0f;
-        s1 += (double)dh;
-        s2 += (double)(dh * ((xv - mu) * inv));
+        return dh;
+    };
+    float xv[RB_CACHE], dh[RB_CACHE];
+#pragma unroll
+    for (int t = 0; t < RB_CACHE; ++t) {
+        const int r = rl + 16 * t;
+        xv[t] = r < a.R ? a.x[(size_t)r * a.F + c] : 0.0f;
+        dh[t] = r < a.R ? a.dy[(size_t)r * a.F + c] : 0.0f;
+    }
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < RB_CACHE; ++t) {
+        const int r = rl + 16 * t;
+        dh[t] = r < a.R ? upstream(r, xv[t], dh[t]) : 0.0f;
+        s1 += (double)dh[t];
+        s2 += (double)(dh[t] * ((xv[t] - mu) * inv));
+    }
+    for (int r = rl + 16 * RB_CACHE; r < a.R; r += 16) {
+        const float x = a.x[(size_t)r * a.F + c];
+        const float d = upstream(r, x, a.dy[(size_t)r * a.F + c]);
+        s1 += (double)d;
+        s2 += (double)(d * ((x - mu) * inv));
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
@@ -111,14 +149,19 @@ __global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwd a) {
         a.dbeta[c] = (float)s1;
     }
     const float c1 = a.training ? (float)(s1 / a.R) : 0.0f, c2 = a.training ? (float)(s2 / a.R) : 0.0f;
-    for (int r = rl; r < a.R; r += 16) {
-        const float xv = a.x[(size_t)r * a.F + c];
-        float dh = a.dy[(size_t)r * a.F + c];
-        if (a.do_drop) dh *= drop_scale(a.seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
-        if (a.relu && !(xv * sc + sh > 0.0f)) dh = 0.0f;
-        float d = sc * (dh - c1 - (xv - mu) * inv * c2);
-        if (a.extra) d += a.extra[(size_t)r * a.F + c];
-        a.dx[(size_t)r * a.F + c] = d;
+    auto emit = [&](int r, float x, float d) {
+        float o = sc * (d - c1 - (x - mu) * inv * c2);
+        if (a.extra) o += a.extra[(size_t)r * a.F + c];
+        a.dx[(size_t)r * a.F + c] = o;
+    };
+#pragma unroll
+    for (int t = 0; t < RB_CACHE; ++t) {
+        const int r = rl + 16 * t;
+        if (r < a.R) emit(r, xv[t], dh[t]);
+    }
+    for (int r = rl + 16 * RB_CACHE; r < a.R; r += 16) {
+        const float x = a.x[(size_t)r * a.F + c];
+        emit(r, x, upstream(r, x, a.dy[(size_t)r * a.F + c]));
     }
 }
 

@@ -21,8 +21,10 @@ struct RelPtrs {
     int c[EAGCN_MAX_VIEWS];
 };
 
-// one wavefront per padded row (b,i): B*N independent waves keep the adj stream and the sparse
-// channel gather in flight (a one-workgroup-per-molecule version was latency-bound at 650 us).
+// one wavefront per padded row (b,i): B*N independent waves; the NIT = ceil(ldc/64) adjacency loads of
+// the row are issued together (memory-level parallelism: a rolled loop kept ONE 256-byte load in
+// flight per wave and ran at 0.5 TB/s), then codes are produced and stored.
+template <int NIT>
 __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict__ adj, RelPtrs rel,
                                                           int B, int N, int K, int ldc,
                                                           uint8_t* __restrict__ code,
@@ -35,11 +37,18 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
     const int b = (int)(row / N), i = (int)(row % N);
     const float* arow = adj + (size_t)row * N;
     const size_t plane = (size_t)N * N;
+    float a[NIT];
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) {
+        const int j = lane + 64 * t;
+        a[t] = (j < N) ? arow[j] : 0.0f;
+    }
     int deg = 0, bad_adj = 0, bad_rel = 0;
-    for (int j = lane; j < ldc; j += 64) {
-        const float a = (j < N) ? arow[j] : 0.0f;
-        const bool bond = (a != 0.0f);
-        if (bond && a != 1.0f) ++bad_adj;
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) {
+        const int j = lane + 64 * t;
+        const bool bond = (a[t] != 0.0f);
+        if (bond && a[t] != 1.0f) ++bad_adj;
         deg += bond ? 1 : 0;
         for (int k = 0; k < K; ++k) {
             int c = 0;
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
                 if (ones != 1 || other != 0) ++bad_rel;
                 c = hot + 1;
             }
-            code[(((size_t)k * B + b) * N + i) * ldc + j] = (uint8_t)c;
+            if (j < ldc) code[(((size_t)k * B + b) * N + i) * ldc + j] = (uint8_t)c;
         }
     }
     deg = wave_sum(deg);
@@ -66,10 +75,7 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
     bad_rel = wave_sum(bad_rel);
     if (lane == 0) {
         deg_bn[row] = deg;
-        if (deg > 0) {
-            atomicMax(&nat[b], i + 1);
-            atomicAdd(&meta[EAGCN_META_NEDGE], deg);
-        }
+        if (deg > 0) atomicMax(&nat[b], i + 1);      // (no single-word counters here: 5k same-address atomics cost 60 us)
         if (bad_adj) atomicAdd(&meta[EAGCN_META_BAD_ADJ], bad_adj);
         if (bad_rel) atomicAdd(&meta[EAGCN_META_BAD_REL], bad_rel);
     }
@@ -77,6 +83,7 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
 
 // single workgroup: exclusive prefix sums of nat[] and ceil(nat/16) -> row0, tile0, totals
 __global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __restrict__ nat, int B,
+                                                              const int32_t* __restrict__ deg_bn, int BN,
                                                               int32_t* __restrict__ row0,
                                                               int32_t* __restrict__ tile0,
                                                               int32_t* __restrict__ meta) {
@@ -110,6 +117,10 @@ __global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __re
         __syncthreads();
     }
     atomicMax(&s_max, nmax);
+    int edges = 0;
+    for (int r = t; r < BN; r += 1024) edges += deg_bn[r];
+    edges = wave_sum(edges);
+    if ((t & 63) == 0 && edges) atomicAdd(&meta[EAGCN_META_NEDGE], edges);
     __syncthreads();
     if (t == 0) {
         row0[B] = carry_r;
@@ -209,9 +220,20 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     EAGCN_HIP(hipMemsetAsync(b->meta, 0, EAGCN_META_WORDS * sizeof(int32_t), s));
     EAGCN_HIP(hipMemsetAsync(b->nat, 0, (size_t)b->B * sizeof(int32_t), s));
     const long rows = (long)b->B * b->N;
-    index_scan_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(adj, rp, b->B, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->meta);
+    const unsigned sgrid = (unsigned)((rows + 3) / 4);
+    const int nit = cdiv(b->ldc, 64);
+    EAGCN_CHECK_ARG(nit <= 8, "eagcn_index_build: N=%d exceeds the supported 512 atoms", b->N);
+#define EAGCN_SCAN(NIT) index_scan_kernel<NIT><<<sgrid, 256, 0, s>>>(adj, rp, b->B, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->meta)
+    switch (nit) {
+        case 1: EAGCN_SCAN(1); break;
+        case 2: EAGCN_SCAN(2); break;
+        case 3: EAGCN_SCAN(3); break;
+        case 4: EAGCN_SCAN(4); break;
+        default: EAGCN_SCAN(8); break;
+    }
+#undef EAGCN_SCAN
     EAGCN_LAUNCH_CHECK();
-    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->row0, b->tile0, b->meta);
+    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta);
     EAGCN_LAUNCH_CHECK();
     EAGCN_HIP(hipMemcpyAsync(host_meta, b->meta, EAGCN_META_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     return EAGCN_OK;

@@ -12,6 +12,9 @@ that fix ``structure``.  Keyword-only extensions (defaults = reference behaviour
                 'direct': the backward call writes them into ONE flat buffer and sets ``p.grad`` to
                 views of it (accumulating into an existing ``.grad``), which skips ~70 AccumulateGrad
                 nodes per step.  Same values; tensor hooks on parameters do not fire in this mode.
+  overlap_index False (default) | True: declare that the batch tensors are already resident in HBM when
+                forward is called (prefetched batches); the batch index then runs on a side stream
+                without waiting for the previous step's queued work (see ops.BatchIndex).
   atom_rep      'lazy' (default) | 'eager' | 'none': the reference copies the last layer's atom
                 representations to the host in EVERY forward (``x2.data.cpu()``, models.py:102), a
                 device->host copy plus a sync per step; 'lazy' returns an object that performs the
@@ -59,7 +62,7 @@ class EAGCN(nn.Module):
                  n_sgc1_5=None, n_sgc2_1=None, n_sgc2_2=None, n_sgc2_3=None, n_sgc2_4=None, n_sgc2_5=None,
                  n_den1=128, n_den2=64, nclass=1, dropout=0.0, structure='Concate', molfp_mode='sum',
                  pool_num=5, *, n_layers=4, widths1=None, widths2=None, rel_channels=None, atom_rep='lazy',
-                 grad_mode='autograd'):
+                 grad_mode='autograd', overlap_index=False):
         super().__init__()
         if widths1 is None:
             widths1 = [n_sgc1_1, n_sgc1_2, n_sgc1_3, n_sgc1_4, n_sgc1_5]
@@ -99,6 +102,7 @@ class EAGCN(nn.Module):
         if grad_mode not in ('autograd', 'direct'):
             raise ValueError("grad_mode must be 'autograd' or 'direct'")
         self.grad_mode = grad_mode
+        self.overlap_index = bool(overlap_index)
         self.den1 = Dense(f_last, n_den1)
         self.den2 = Dense(n_den1, n_den2)
         self.den3 = Dense(n_den2, nclass)
@@ -135,7 +139,7 @@ class EAGCN(nn.Module):
         size) -> (x, atom_representations, graph_representation).  The whole forward is one call into
         eagcn_model_forward (layers, read-out and head); backward is one call into eagcn_model_backward."""
         *rels, size = rels_and_size
-        index = ops.BatchIndex(adjs, rels)                       # once per batch, shared by all layers
+        index = ops.BatchIndex(adjs, rels, overlap=self.overlap_index)   # once per batch, shared by all layers
         plan = self.plan()
         seed = 0
         if self.training and self.dropout > 0:

@@ -29,6 +29,7 @@ def _need_cuda_f32(t, name):
 
 
 _pinned_meta = {}
+_index_streams = {}
 
 
 def _host_meta(device):
@@ -36,6 +37,17 @@ def _host_meta(device):
     if key not in _pinned_meta:
         _pinned_meta[key] = torch.zeros(L.META_WORDS, dtype=torch.int32).pin_memory()
     return _pinned_meta[key]
+
+
+def _index_stream(device):
+    """Side stream for the batch-index kernels.  The host has to read the packed row count before it
+    can size the rest of the step; waiting on the MAIN stream would drain everything queued there (the
+    previous step's backward).  On a side stream the wait covers the two index kernels only, so the
+    host keeps running one step ahead of the GPU."""
+    key = device.index
+    if key not in _index_streams:
+        _index_streams[key] = torch.cuda.Stream(device=device, priority=-1)
+    return _index_streams[key]
 
 
 class ColLayout:
@@ -65,7 +77,11 @@ class BatchIndex:
     input-validity counters -- non-binary adjacency or non-one-hot relation channels raise here.
     """
 
-    def __init__(self, adj, rels):
+    def __init__(self, adj, rels, overlap=False):
+        """overlap=True: the inputs are already materialised in HBM (prefetched batches), so the index
+        kernels may run on a side stream WITHOUT waiting for the main stream's backlog; the host then
+        only waits for those two kernels and keeps running one step ahead of the GPU.  Default False:
+        the side stream first waits for everything queued on the current stream (always safe)."""
         lib = L.load()
         adj = _need_cuda_f32(adj, 'adjs')
         rels = [_need_cuda_f32(r, 'relation tensor %d' % i) for i, r in enumerate(rels)]
@@ -84,9 +100,14 @@ class BatchIndex:
         self.channels = [int(r.shape[1]) for r in rels]
         self.ldc = (N + 15) // 16 * 16
         i32 = dict(dtype=torch.int32, device=dev)
-        self.code = torch.empty((K, B, N, self.ldc), dtype=torch.uint8, device=dev)
-        # one allocation for the small int32 arrays: [deg_bn B*N | nat B | row0 B+1 | tile0 B+1 | meta]
-        blob = torch.empty(B * N + 3 * B + 2 + L.META_WORDS, **i32)
+        main = torch.cuda.current_stream()
+        side = _index_stream(dev)
+        # buffers written on the side stream are allocated on it (the caching allocator recycles blocks
+        # per stream: a block freed on `main` may still be read by kernels queued there)
+        with torch.cuda.stream(side):
+            self.code = torch.empty((K, B, N, self.ldc), dtype=torch.uint8, device=dev)
+            # one allocation for the small int32 arrays: [deg_bn B*N | nat B | row0 B+1 | tile0 B+1 | meta]
+            blob = torch.empty(B * N + 3 * B + 2 + L.META_WORDS, **i32)
         o = 0
         self.deg_bn = blob[o:o + B * N]; o += B * N
         self.nat = blob[o:o + B]; o += B
@@ -104,9 +125,12 @@ class BatchIndex:
         c.meta = base + 4 * (B * N + 3 * B + 2)
         rel_ptrs = (C.c_void_p * K)(*[r.data_ptr() for r in rels])
         host = _host_meta(dev)
-        L.check(lib.eagcn_index_build(_ptr(adj), rel_ptrs, C.byref(c), C.c_void_p(host.data_ptr()), _stream()),
+        if not overlap:
+            side.wait_stream(main)        # inputs may have been produced by work still queued on `main`
+        sptr = C.c_void_p(side.cuda_stream)
+        L.check(lib.eagcn_index_build(_ptr(adj), rel_ptrs, C.byref(c), C.c_void_p(host.data_ptr()), sptr),
                 'eagcn_index_build')
-        torch.cuda.current_stream().synchronize()
+        side.synchronize()                # waits for the index kernels only, not for the main stream's backlog
         meta = host.tolist()
         if meta[L.META_BAD_ADJ]:
             raise L.EagcnHipError('adjs holds %d entries outside {0,1}: the hot path requires a 0/1 '
@@ -117,6 +141,7 @@ class BatchIndex:
         self.T, self.n_max, self.n_tiles = meta[L.META_T], meta[L.META_NMAX], meta[L.META_NTILES]
         self.n_edges = meta[L.META_NEDGE]
         T = self.T
+        main.wait_stream(side)            # everything below (and every consumer) runs on `main`
         rows = torch.empty(4 * T + self.n_tiles, **i32)          # [row_mol | row_loc | row_deg | row_m(f32) | tile_mol]
         self.row_mol, self.row_loc, self.row_deg = rows[0:T], rows[T:2 * T], rows[2 * T:3 * T]
         self.row_m = rows[3 * T:4 * T].view(torch.float32)
@@ -126,6 +151,8 @@ class BatchIndex:
         rb = rows.data_ptr()
         c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = rb, rb + 4 * T, rb + 8 * T, rb + 12 * T, rb + 16 * T
         L.check(lib.eagcn_index_rows(C.byref(c), _stream()), 'eagcn_index_rows')
+        for t in (self.code, blob):
+            t.record_stream(main)         # allocated on `side`, consumed on `main`
         self.c = c
         self._keep = (adj, rels)
 
