@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
 #pragma unroll
     for (int c = 0; c < CT; ++c) { s1[c] = 0.0; s2[c] = 0.0; }
 
-    for (int tile = blockIdx.x * 4 + wave; tile < bt.n_tiles; tile += gridDim.x * 4) {
+    const int ntiles = dev_tiles(bt);
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const int b = bt.tile_mol[tile];
         const int rt = tile - bt.tile0[b];
         const int n = bt.nat[b], r0 = bt.row0[b];
@@ -231,11 +232,12 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
     const eagcn_batch& bt = a.bt;
     const int off = a.vc.off[k], fp = a.vc.off[k + 1] - a.vc.off[k];
     double dr_acc = 0.0;
-    for (int rbase = (blockIdx.x * 4 + wave) * 4; rbase < bt.T; rbase += gridDim.x * 16) {
+    const int Tn = dev_rows(bt);
+    for (int rbase = (blockIdx.x * 4 + wave) * 4; rbase < Tn; rbase += gridDim.x * 16) {
         const int r = rbase + grp;
         float rs = 0.0f;
         int b = 0, i = 0, n = 0, r0 = 0;
-        if (r < bt.T) {
+        if (r < Tn) {
             rs = a.rscale[(size_t)k * bt.T + r];
             b = bt.row_mol[r];
             i = bt.row_loc[r];

@@ -80,6 +80,12 @@ __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_
     return rng_u32(seed, idx) >= thr ? inv_keep : 0.0f;
 }
 
+// ---- actual extents live in device memory ----------------------------------------------------------
+// eagcn_batch.T / .n_tiles are CAPACITIES (buffer strides, grid sizing); the actual packed row count
+// and tile count are read from meta[] on the device, so no launch depends on a host read-back.
+__device__ __forceinline__ int dev_rows(const eagcn_batch& bt) { return min(bt.meta[EAGCN_META_T], bt.T); }
+__device__ __forceinline__ int dev_tiles(const eagcn_batch& bt) { return min(bt.meta[EAGCN_META_NTILES], bt.n_tiles); }
+
 // ---- column map of a layer's Fp-wide buffers -----------------------------------------------------
 struct ViewCols {
     int K;
@@ -132,6 +138,8 @@ struct GemmDesc {
     size_t slab;           // floats between partial slabs
     double work = 0.0;     // algorithmic flops of this product (0 -> 2*M*N*K)
     int vecA = 1, vecB = 1; // set by launch_gemm: float4 loads allowed for A / B
+    const int* M_dev = nullptr;   // if set: actual M (<= M) read on the device; M is then the capacity
+    const int* K_dev = nullptr;   // if set: actual K (<= K), used by the split-K row reduction
 };
 int launch_gemm(const GemmDesc& g, hipStream_t s);
 

@@ -44,6 +44,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
     const int li = lane & 15, q = lane >> 4;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (g.M_dev) g.M = min(*g.M_dev, g.M);          // extents known only on the device (packed row count)
+    if (g.K_dev) g.K = min(*g.K_dev, g.K);
+    if (m0 >= g.M && g.splits == 1) return;         // uniform: nothing to do for this tile
     // split-K range
     const int z = blockIdx.z;
     const int kchunk = ((g.K + g.splits - 1) / g.splits + BK - 1) / BK * BK;

@@ -158,7 +158,7 @@ __device__ __forceinline__ int packed_to_exact(const ColMap& m, int cp) {
 
 __global__ __launch_bounds__(256) void pack_rows_kernel(eagcn_batch bt, const float* __restrict__ dense,
                                                          int F, ColMap m, int ld, float* __restrict__ packed) {
-    const size_t total = (size_t)bt.T * ld;
+    const size_t total = (size_t)dev_rows(bt) * ld;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (size_t)gridDim.x * blockDim.x) {
         int r = (int)(e / ld), cp = (int)(e % ld);

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
             a.pad_row[c] = v;
         }
     }
-    const int T = a.bt.T;
+    const int T = dev_rows(a.bt);
     if (a.structure == EAGCN_STRUCT_CONCATE) {
         const int g4 = fp / 4;
         const size_t total = (size_t)T * g4;
@@ -226,7 +226,7 @@ struct BwdArgs {
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     __shared__ double da_s[EAGCN_MAX_VIEWS];
-    const int fp = a.fp, T = a.bt.T;
+    const int fp = a.fp, T = dev_rows(a.bt);
     if (threadIdx.x < EAGCN_MAX_VIEWS) da_s[threadIdx.x] = 0.0;
     __syncthreads();
     const bool weighted = a.structure == EAGCN_STRUCT_WEIGHTED;
@@ -303,11 +303,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int T, int fp, const float* __restrict__ Y, int ldy,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(eagcn_batch bt, int fp, const float* __restrict__ Y, int ldy,
                                                             const float* __restrict__ bn,
                                                             const float* __restrict__ cc, float* __restrict__ dH) {
     const int g4 = fp / 4;
-    const size_t total = (size_t)T * g4;
+    const size_t total = (size_t)dev_rows(bt) * g4;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(e / g4), c = (int)(e % g4) * 4;
         const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)r * ldy + c);
@@ -555,6 +555,7 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
     int nslab = 0;
     if (b->T > 0) {
         GemmDesc g{0, 0, b->T, d.fp, d.ld_in, w->x, d.ld_in, sc.Wcat, d.fp, w->P, d.fp, 1, 0, gemm_work};
+        g.M_dev = b->meta + EAGCN_META_T;
         rc = launch_gemm(g, s);
         if (rc) return rc;
         AggArgs a;
@@ -645,7 +646,7 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
                                                                 d.vc, gp, sc.cc);
         EAGCN_LAUNCH_CHECK();
         if (b->T > 0) {
-            bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(b->T, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
+            bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
             EAGCN_LAUNCH_CHECK();
         }
     }
@@ -664,10 +665,12 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
         nedge = edge_grid_x(b);
         nsplit = d.nsplit;
         GemmDesc gw{1, 0, d.ld_in, d.fp, b->T, w->x, d.ld_in, sc.dP, d.fp, sc.dWcat, d.fp, nsplit, d.wslab, gemm_work};
+        gw.K_dev = b->meta + EAGCN_META_T;
         rc = launch_gemm(gw, s);
         if (rc) return rc;
         if (dx) {
             GemmDesc gx{0, 1, b->T, d.ld_in, d.fp, sc.dP, d.fp, sc.Wcat, d.fp, dx, d.ld_in, 1, 0, gemm_work};
+            gx.M_dev = b->meta + EAGCN_META_T;
             rc = launch_gemm(gx, s);
             if (rc) return rc;
         }

@@ -77,8 +77,10 @@ class BatchIndex:
     input-validity counters -- non-binary adjacency or non-one-hot relation channels raise here.
     """
 
-    def __init__(self, adj, rels, overlap=False):
-        """overlap=True: the inputs are already materialised in HBM (prefetched batches), so the index
+    def __init__(self, adj, rels, overlap=False, row_cap=None):
+        """row_cap: size every packed buffer / grid for `row_cap` rows instead of the exact packed row
+        count (kernels read the exact count from device memory); used by tests and by graph mode.
+        overlap=True: the inputs are already materialised in HBM (prefetched batches), so the index
         kernels may run on a side stream WITHOUT waiting for the main stream's backlog; the host then
         only waits for those two kernels and keeps running one step ahead of the GPU.  Default False:
         the side stream first waits for everything queued on the current stream (always safe)."""
@@ -100,7 +102,7 @@ class BatchIndex:
         self.channels = [int(r.shape[1]) for r in rels]
         self.ldc = (N + 15) // 16 * 16
         i32 = dict(dtype=torch.int32, device=dev)
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(dev)
         side = _index_stream(dev)
         # buffers written on the side stream are allocated on it (the caching allocator recycles blocks
         # per stream: a block freed on `main` may still be read by kernels queued there)
@@ -140,6 +142,12 @@ class BatchIndex:
                                   '(reference neural_fp.py:111-120)' % meta[L.META_BAD_REL])
         self.T, self.n_max, self.n_tiles = meta[L.META_T], meta[L.META_NMAX], meta[L.META_NTILES]
         self.n_edges = meta[L.META_NEDGE]
+        self.rows = self.T                                   # exact packed row count
+        if row_cap is not None:
+            if row_cap < self.T:
+                raise L.EagcnHipError('row_cap %d is smaller than the packed row count %d' % (row_cap, self.T))
+            self.T = int(row_cap)                            # capacity from here on
+            self.n_tiles = B * ((N + 15) // 16)
         T = self.T
         main.wait_stream(side)            # everything below (and every consumer) runs on `main`
         rows = torch.empty(4 * T + self.n_tiles, **i32)          # [row_mol | row_loc | row_deg | row_m(f32) | tile_mol]
@@ -150,7 +158,7 @@ class BatchIndex:
         c.T, c.n_max, c.n_tiles = T, self.n_max, self.n_tiles
         rb = rows.data_ptr()
         c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = rb, rb + 4 * T, rb + 8 * T, rb + 12 * T, rb + 16 * T
-        L.check(lib.eagcn_index_rows(C.byref(c), _stream()), 'eagcn_index_rows')
+        L.check(lib.eagcn_index_rows(C.byref(c), C.c_void_p(main.cuda_stream)), 'eagcn_index_rows')
         for t in (self.code, blob):
             t.record_stream(main)         # allocated on `side`, consumed on `main`
         self.c = c
@@ -511,11 +519,36 @@ class ModelPlan:
             self.offsets.append(self.offsets[-1] + n)
         self.trigger = None
         self.flat_grad = None
+        self._cm_cache = {}
+        self._ptr_tensors = list(self.params)
+        for layer in layers:
+            for blk in layer.blocks():
+                self._ptr_tensors += [blk.batch_norm.bn.running_mean, blk.batch_norm.bn.running_var]
+        for n in ('Graph_BN', 'bn_den1', 'bn_den2'):
+            self._ptr_tensors += [head[n].running_mean, head[n].running_var]
         self.nbt = [blk.batch_norm.bn.num_batches_tracked for layer in layers for blk in layer.blocks()] + \
                    [h['Graph_BN'].num_batches_tracked, h['bn_den1'].num_batches_tracked,
                     h['bn_den2'].num_batches_tracked]
 
     def cmodel(self, training, seed, dropout):
+        """The C description of the model for this call.  The struct is cached per (training, dropout)
+        and rebuilt only when a parameter / buffer pointer changed (e.g. after .to() or a re-assigned
+        .data); per call only the dropout seeds are refreshed."""
+        key = (bool(training), float(dropout), tuple(float(l.dropout) for l in self.layers))
+        ptrs = [t.data_ptr() for t in self._ptr_tensors]
+        hit = self._cm_cache.get(key)
+        if hit is None or hit[1] != ptrs:
+            hit = (self._build_cmodel(training, dropout), ptrs)
+            self._cm_cache[key] = hit
+        m = hit[0]
+        seed = int(seed)
+        m.head_seed = (seed + 0x51ED27) & (2 ** 63 - 1)
+        for l in range(len(self.layers)):
+            m.layer[l].seed = (seed + 7919 * (l + 1)) & (2 ** 63 - 1)
+        return m
+
+    def _build_cmodel(self, training, dropout):
+        seed = 0
         m = L.Model()
         m.n_layers, m.molfp_mode, m.training = len(self.layers), self.molfp, int(bool(training))
         m.head_seed = (int(seed) + 0x51ED27) & (2 ** 63 - 1)
@@ -579,7 +612,8 @@ class _ModelFn(torch.autograd.Function):
             T = index.T
             holder['xout'] = saved[xo.value:xo.value + 4 * T * ld.value].view(torch.float32).view(T, ld.value)
             holder['pad_row'] = saved[po.value:po.value + 4 * ld.value].view(torch.float32)
-        ctx.plan, ctx.index, ctx.cmodel, ctx.saved_blob, ctx.size = plan, index, m, saved, size
+        # private copy: the cached struct is re-seeded by the next forward call
+        ctx.plan, ctx.index, ctx.cmodel, ctx.saved_blob, ctx.size = plan, index, L.Model.from_buffer_copy(m), saved, size
         if not ctx.direct:
             ctx.save_for_backward(*params)
         return out, graph_rep

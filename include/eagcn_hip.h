@@ -70,7 +70,10 @@ extern "C" {
 typedef struct eagcn_batch {
     int32_t B, N, K;
     int32_t ldc;                            /* row stride of code maps in bytes, multiple of 16 */
-    int32_t T, n_max, n_tiles;              /* filled by the caller from host_meta              */
+    int32_t T, n_max, n_tiles;              /* T / n_tiles: CAPACITIES (row stride of [K][T] buffers,
+                                               grid sizing); the actual counts are meta[T], meta[NTILES]
+                                               on the device and every kernel reads them there, so the
+                                               caller may pass upper bounds without a host read-back  */
     int32_t channels[EAGCN_MAX_VIEWS];
     uint8_t* code;                          /* [K][B][N][ldc] 0 = no bond, c+1 = bond type c    */
     int32_t* deg_bn;                        /* [B][N] degree of every padded row                */

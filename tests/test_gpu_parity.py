@@ -302,3 +302,27 @@ def test_direct_grad_mode_and_fused_losses_match_autograd():
     l2 = losses.fused_regression_loss(out, tgt)
     g2, = torch.autograd.grad(l2, out)
     assert abs(float(l1) - float(l2)) < 1e-6 and rel_err(g2.cpu(), g1.cpu()) < 1e-6
+
+
+def test_row_capacity_larger_than_row_count():
+    """Kernels take the packed row count from device memory: sizing buffers and grids for a capacity
+    (here B*N) instead of the exact count must not change any result."""
+    from eagcn_amd import EAGCN, ops
+    from eagcn_amd.synthetic import make_batch
+    torch.manual_seed(2)
+    mb = make_batch(B=9, n_max=37, n_med=10, rel_channels=(6, 4, 2, 2, 2), seed=5, isolated_frac=0.1)
+    d = _dev(mb.dense())
+    adj, afm, rels, size = d[0], d[1], d[2:-1], d[-1]
+    model = EAGCN(6, 24, *[10, 8, 6, 6, 7], *[12, 9, 7, 7, 9], 24, 12, 3, 0.0, n_layers=2).cuda()
+    res = []
+    for cap in (None, 9 * 37):
+        model.zero_grad(set_to_none=True)
+        index = ops.BatchIndex(adj, rels, row_cap=cap)
+        x, pad_row, layout = model.forward_layers(index, afm)[-1]
+        g = ops.readout(index, layout, x, None, 'sum', size)
+        (g * g).sum().backward()
+        res.append((g.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert rel_err(res[1][0].cpu(), res[0][0].cpu()) < 1e-6
+    scale = max(v.abs().max().item() for v in res[0][1].values())
+    for k, v in res[0][1].items():
+        assert_grad_close(res[1][1][k], v.cpu(), scale, k, rtol=1e-5, floor=1e-6)
