@@ -40,10 +40,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32
 PEAK_HBM_GBS = 8000.0
 
 
-def build_model(cfg, dropout, device):
+def build_model(cfg, dropout, device, graph=False):
     from eagcn_amd import EAGCN, weights_init
     m = EAGCN(cfg['n_bfeat'], 24, *cfg['widths1'], *cfg['widths2'], cfg['dens'][0], cfg['dens'][1], cfg['nclass'],
-              dropout, structure=cfg['structure'], n_layers=cfg['n_layers'], atom_rep='lazy', grad_mode='direct', overlap_index=True)
+              dropout, structure=cfg['structure'], n_layers=cfg['n_layers'], atom_rep='lazy', grad_mode='direct', overlap_index=True, graph=graph)
     m.apply(weights_init)
     return m.to(device)
 
@@ -138,6 +138,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='molecules per GPU (default: the config\'s)')
     ap.add_argument('--dropout', type=float, default=0.3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--cpu-steps', type=int, default=5)
     args = ap.parse_args()
 
@@ -162,7 +163,7 @@ def main():
     labels = torch.from_numpy(mb.labels).to(dev)
     bce_w = bce_weights(cfg['nclass'])
     bce_w_dev = torch.tensor(bce_w, dtype=torch.float32, device=dev)
-    model = build_model(cfg, args.dropout, dev)
+    model = build_model(cfg, args.dropout, dev, graph=not args.eager)
     model.train()
     reducer = GradientAllReducer(model.parameters())
     params = list(model.parameters())

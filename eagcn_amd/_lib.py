@@ -36,7 +36,7 @@ class LayerParams(C.Structure):
     _fields_ = [('K', C.c_int32), ('structure', C.c_int32), ('training', C.c_int32),
                 ('width', C.c_int32 * MAX_VIEWS), ('inp', Layout),
                 ('dropout', C.c_float), ('bn_eps', C.c_float), ('bn_momentum', C.c_float),
-                ('seed', C.c_uint64),
+                ('seed', C.c_uint64), ('seed_dev', _fp),
                 ('att_w', _fp * MAX_VIEWS), ('self_r', _fp * MAX_VIEWS), ('W', _fp * MAX_VIEWS),
                 ('bias', _fp * MAX_VIEWS), ('gamma', _fp * MAX_VIEWS), ('beta', _fp * MAX_VIEWS),
                 ('run_mean', _fp * MAX_VIEWS), ('run_var', _fp * MAX_VIEWS), ('ave_w', _fp)]
@@ -70,7 +70,8 @@ class HeadGrads(C.Structure):
 
 class Model(C.Structure):
     _fields_ = [('n_layers', C.c_int32), ('molfp_mode', C.c_int32), ('training', C.c_int32),
-                ('head_seed', C.c_uint64), ('layer', LayerParams * 4), ('head', HeadParams)]
+                ('head_seed', C.c_uint64), ('head_seed_dev', _fp), ('input_packed', C.c_int32),
+                ('layer', LayerParams * 4), ('head', HeadParams)]
 
 
 # name -> (restype, argtypes); also the list the CPU test checks against include/eagcn_hip.h
@@ -102,6 +103,7 @@ SIGNATURES = {
     'eagcn_model_scratch_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(Model)]),
     'eagcn_model_atom_rep': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), C.POINTER(C.c_size_t),
                                        C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    'eagcn_model_pack_input': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, C.c_size_t, _fp]),
     'eagcn_model_forward': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, _fp, C.c_size_t, _fp,
                                       C.c_size_t, _fp, _fp, _fp]),
     'eagcn_model_backward': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, C.c_size_t, _fp, C.c_size_t,

@@ -27,7 +27,7 @@ struct RowBnFwd {
     float* bn;                           // [4][F]
     int training, relu, do_drop;
     float eps, momentum;
-    uint32_t thr; float inv_keep; uint64_t seed;
+    uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
 };
 
 // 16 columns x 16 row-lanes per workgroup; each lane keeps up to RB_CACHE of its rows in registers so
@@ -35,6 +35,7 @@ struct RowBnFwd {
 constexpr int RB_CACHE = 16;          // rows per lane kept in registers -> R <= 256 needs no second read
 
 __global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnFwd a) {
+    if (a.seed_dev) a.seed = *a.seed_dev;
     const int cr = blockIdx.x * 16 + (threadIdx.x >> 4), rl = threadIdx.x & 15;
     const int c = min(cr, a.F - 1);
     float v[RB_CACHE];
@@ -103,10 +104,11 @@ struct RowBnBwd {
     const float* extra;                  // added to dx (gradient that reaches x directly), or null
     float* dx; float* dgamma; float* dbeta;
     int training, relu, do_drop;
-    uint32_t thr; float inv_keep; uint64_t seed;
+    uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
 };
 
 __global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwd a) {
+    if (a.seed_dev) a.seed = *a.seed_dev;
     const int cr = blockIdx.x * 16 + (threadIdx.x >> 4), rl = threadIdx.x & 15;
     const int c = min(cr, a.F - 1);
     const float sc = a.bn[RB_SC * a.F + c], sh = a.bn[RB_SH * a.F + c];
@@ -292,10 +294,10 @@ static void fill_drop(float p, int training, int* do_drop, uint32_t* thr, float*
 
 static int rowbn_fwd(hipStream_t s, int R, int F, const float* x, float* y, const float* g, const float* be,
                      float* rm, float* rv, float* bn, int training, int relu, float dropout, uint64_t seed,
-                     float eps, float mom) {
+                     const uint64_t* seed_dev, float eps, float mom) {
     RowBnFwd a;
     a.R = R; a.F = F; a.x = x; a.y = y; a.gamma = g; a.beta = be; a.run_mean = rm; a.run_var = rv; a.bn = bn;
-    a.training = training; a.relu = relu; a.eps = eps; a.momentum = mom; a.seed = seed;
+    a.training = training; a.relu = relu; a.eps = eps; a.momentum = mom; a.seed = seed; a.seed_dev = seed_dev;
     fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
     ProfScope ps(PROF_BN, s);
     rowbn_fwd_kernel<<<cdiv(F, 16), 256, 0, s>>>(a);
@@ -304,10 +306,10 @@ static int rowbn_fwd(hipStream_t s, int R, int F, const float* x, float* y, cons
 }
 static int rowbn_bwd(hipStream_t s, int R, int F, const float* dy, const float* x, const float* bn,
                      const float* extra, float* dx, float* dgamma, float* dbeta, int training, int relu,
-                     float dropout, uint64_t seed) {
+                     float dropout, uint64_t seed, const uint64_t* seed_dev) {
     RowBnBwd a;
     a.R = R; a.F = F; a.dy = dy; a.x = x; a.bn = bn; a.extra = extra; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta;
-    a.training = training; a.relu = relu; a.seed = seed;
+    a.training = training; a.relu = relu; a.seed = seed; a.seed_dev = seed_dev;
     fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
     ProfScope ps(PROF_BN, s);
     rowbn_bwd_kernel<<<cdiv(F, 16), 256, 0, s>>>(a);
@@ -343,19 +345,28 @@ extern "C" int eagcn_model_atom_rep(const eagcn_batch* b, const eagcn_model* m, 
     return EAGCN_OK;
 }
 
+extern "C" int eagcn_model_pack_input(const eagcn_batch* b, const eagcn_model* m, const float* afm, void* saved,
+                                      size_t saved_bytes, void* stream) {
+    EAGCN_CHECK_ARG(b && m && afm && saved, "eagcn_model_pack_input: null argument");
+    ModelSaved sv;
+    EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "eagcn_model_pack_input: saved block too small");
+    return eagcn_pack_rows(b, afm, layout_width(&m->layer[0].in), &m->layer[0].in, sv.x0, stream);
+}
+
 extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, const float* afm,
                                    const int64_t* size, void* saved, size_t saved_bytes, void* scratch,
                                    size_t scratch_bytes, float* out, float* graph_rep, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     RC(check_model(b, m, "eagcn_model_forward"));
-    EAGCN_CHECK_ARG(afm && saved && scratch && out && graph_rep, "eagcn_model_forward: null buffer");
+    EAGCN_CHECK_ARG((afm || m->input_packed) && saved && scratch && out && graph_rep, "eagcn_model_forward: null buffer");
     EAGCN_CHECK_ARG(m->molfp_mode == 0 || size, "eagcn_model_forward: 'ave' read-out needs size");
     ModelSaved sv;
     ModelScratch sc;
     EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "eagcn_model_forward: saved block too small");
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_forward: scratch too small");
     const eagcn_head_params* h = &m->head;
-    RC(eagcn_pack_rows(b, afm, layout_width(&m->layer[0].in), &m->layer[0].in, sv.x0, stream));
+    if (!m->input_packed)
+        RC(eagcn_pack_rows(b, afm, layout_width(&m->layer[0].in), &m->layer[0].in, sv.x0, stream));
     const float* x = sv.x0;
     for (int l = 0; l < m->n_layers; ++l) {
         LayerSaved& L = sv.L[l];
@@ -373,14 +384,14 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     RC(eagcn_readout_forward(b, LL.xout, &lay, last->structure == EAGCN_STRUCT_WEIGHTED ? LL.pad_row : nullptr,
                              size, m->molfp_mode, sv.g, F, stream));
     RC(rowbn_fwd(s, B, F, sv.g, sv.gn, h->gbn_w, h->gbn_b, h->gbn_rm, h->gbn_rv, sv.bn_g, m->training, 0, 0.0f, 0,
-                 h->bn_eps, h->bn_momentum));
+                 nullptr, h->bn_eps, h->bn_momentum));
     RC(mm(s, 0, 0, B, n1, F, sv.gn, F, h->den1_w, n1, sv.h1, n1));
     RC(rowbn_fwd(s, B, n1, sv.h1, sv.a1, h->bn1_w, h->bn1_b, h->bn1_rm, h->bn1_rv, sv.bn_1, m->training, 1,
-                 h->dropout, m->head_seed, h->bn_eps, h->bn_momentum));
+                 h->dropout, m->head_seed, m->head_seed_dev, h->bn_eps, h->bn_momentum));
     RC(mm(s, 0, 0, B, n2, n1, sv.a1, n1, h->den2_w, n2, sv.h2, n2));
     EAGCN_HIP(hipMemcpyAsync(graph_rep, sv.h2, (size_t)B * n2 * sizeof(float), hipMemcpyDeviceToDevice, s));
     RC(rowbn_fwd(s, B, n2, sv.h2, sv.a2, h->bn2_w, h->bn2_b, h->bn2_rm, h->bn2_rv, sv.bn_2, m->training, 1, 0.0f, 0,
-                 h->bn_eps, h->bn_momentum));
+                 nullptr, h->bn_eps, h->bn_momentum));
     RC(mm(s, 0, 0, B, nc, n2, sv.a2, n2, h->den3_w, nc, out, nc));
     return EAGCN_OK;
 }
@@ -403,16 +414,16 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
     // den3
     RC(mm(s, 1, 0, n2, nc, B, sv.a2, n2, dout, nc, hg->d_den3_w, nc));
     RC(mm(s, 0, 1, B, n2, nc, dout, nc, h->den3_w, nc, sc.da2, n2));
-    RC(rowbn_bwd(s, B, n2, sc.da2, sv.h2, sv.bn_2, dgraph_rep, sc.dh2, hg->d_bn2_w, hg->d_bn2_b, m->training, 1, 0.0f, 0));
+    RC(rowbn_bwd(s, B, n2, sc.da2, sv.h2, sv.bn_2, dgraph_rep, sc.dh2, hg->d_bn2_w, hg->d_bn2_b, m->training, 1, 0.0f, 0, nullptr));
     // den2
     RC(mm(s, 1, 0, n1, n2, B, sv.a1, n1, sc.dh2, n2, hg->d_den2_w, n2));
     RC(mm(s, 0, 1, B, n1, n2, sc.dh2, n2, h->den2_w, n2, sc.da1, n1));
     RC(rowbn_bwd(s, B, n1, sc.da1, sv.h1, sv.bn_1, nullptr, sc.dh1, hg->d_bn1_w, hg->d_bn1_b, m->training, 1, h->dropout,
-                 m->head_seed));
+                 m->head_seed, m->head_seed_dev));
     // den1
     RC(mm(s, 1, 0, F, n1, B, sv.gn, F, sc.dh1, n1, hg->d_den1_w, n1));
     RC(mm(s, 0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, sc.dgn, F));
-    RC(rowbn_bwd(s, B, F, sc.dgn, sv.g, sv.bn_g, nullptr, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training, 0, 0.0f, 0));
+    RC(rowbn_bwd(s, B, F, sc.dgn, sv.g, sv.bn_g, nullptr, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training, 0, 0.0f, 0, nullptr));
     // read-out
     const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
     const eagcn_layout lay = out_layout(last);

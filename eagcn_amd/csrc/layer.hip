@@ -152,11 +152,12 @@ struct ApplyArgs {
     const float* colp;
     float* out; int ldo;
     float* pad_row;
-    int do_drop; uint32_t thr; float inv_keep; uint64_t seed;
+    int do_drop; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
 };
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
     const int fp = a.fp;
+    if (a.seed_dev) a.seed = *a.seed_dev;
     if (blockIdx.x == 0) {   // value of the rows that are not stored
         for (int c = threadIdx.x; c < a.ldo; c += blockDim.x) {
             float v = 0.0f;
@@ -221,11 +222,12 @@ struct BwdArgs {
     float* dH;                   // [T][fp]
     double* slab;                // [grid][fp][2]
     double* slab_da;             // [grid][MAX_VIEWS]
-    int do_drop; uint32_t thr; float inv_keep; uint64_t seed;
+    int do_drop; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     __shared__ double da_s[EAGCN_MAX_VIEWS];
+    if (a.seed_dev) a.seed = *a.seed_dev;
     const int fp = a.fp, T = dev_rows(a.bt);
     if (threadIdx.x < EAGCN_MAX_VIEWS) da_s[threadIdx.x] = 0.0;
     __syncthreads();
@@ -577,6 +579,7 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
     aa.thr = (uint32_t)std::min(4294967295.0, (double)p->dropout * 4294967296.0);
     aa.inv_keep = 1.0f / (1.0f - p->dropout);
     aa.seed = p->seed;
+    aa.seed_dev = p->seed_dev;
     bn_apply_kernel<<<ew_grid((size_t)std::max(b->T, 1) * d.ldo / 4), 256, 0, s>>>(aa);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
@@ -635,6 +638,7 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
     ba.thr = (uint32_t)std::min(4294967295.0, (double)p->dropout * 4294967296.0);
     ba.inv_keep = 1.0f / (1.0f - p->dropout);
     ba.seed = p->seed;
+    ba.seed_dev = p->seed_dev;
     const int rows = b->T + ba.nvirt;
     const int gxb = std::max(1, std::min(rows, d.gxb));
     const double M = (double)b->B * (double)b->N;

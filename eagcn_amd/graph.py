@@ -1,0 +1,269 @@
+"""HIP-graph execution of the training step.
+
+The eager engine issues ~60 kernel launches per step; at Tox21 batch sizes the host cannot issue
+them as fast as the MI355X retires them.  Every kernel takes its row / tile counts from device
+memory and its grid from static capacities, so for a fixed (model, B, N) the launch sequence of the
+whole forward and of the whole backward is IDENTICAL from batch to batch: it is captured once into two
+HIP graphs and replayed.  What stays eager is only what reads the caller's tensors: the batch-index
+kernels (adj / relation tensors) and the packing of ``afms``.  There is no host read-back on the
+path; the input-validity counters of batch k are checked (and raised) when batch k+2 is submitted.
+
+Static buffers are sized for ``row_cap`` packed rows (default B*N, which can never overflow).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .ops import _ptr, _stream
+
+_RING = 4
+
+
+class StaticIndex:
+    """BatchIndex-compatible view of the runner's static index buffers (capacities, no host values)."""
+
+    def __init__(self, B, N, channels, device, row_cap):
+        K = len(channels)
+        self.device, self.B, self.N, self.K = device, B, N, K
+        self.channels = list(channels)
+        self.ldc = (N + 15) // 16 * 16
+        self.T = int(row_cap)
+        self.n_tiles = B * ((N + 15) // 16)
+        self.n_max = N
+        i32 = dict(dtype=torch.int32, device=device)
+        self.code = torch.empty((K, B, N, self.ldc), dtype=torch.uint8, device=device)
+        blob = torch.zeros(B * N + 3 * B + 2 + L.META_WORDS, **i32)
+        rows = torch.zeros(4 * self.T + self.n_tiles, **i32)
+        self._blob, self._rows = blob, rows
+        o = B * N
+        self.nat = blob[o:o + B]
+        c = L.Batch()
+        c.B, c.N, c.K, c.ldc = B, N, K, self.ldc
+        c.T, c.n_max, c.n_tiles = self.T, N, self.n_tiles
+        for k in range(K):
+            c.channels[k] = self.channels[k]
+        base = blob.data_ptr()
+        c.code, c.deg_bn, c.nat = self.code.data_ptr(), base, base + 4 * B * N
+        c.row0, c.tile0 = base + 4 * (B * N + B), base + 4 * (B * N + 2 * B + 1)
+        c.meta = base + 4 * (B * N + 3 * B + 2)
+        rb, T = rows.data_ptr(), self.T
+        c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = rb, rb + 4 * T, rb + 8 * T, rb + 12 * T, rb + 16 * T
+        self.c = c
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+class GraphRunner:
+    """One captured (forward, backward) pair for a fixed (model plan, B, N, channels)."""
+
+    def __init__(self, plan, B, N, channels, device, dropout, row_cap=None):
+        lib = L.load()
+        self.plan, self.device = plan, device
+        self.key = (B, N, tuple(channels))
+        self.index = StaticIndex(B, N, channels, device, row_cap if row_cap else B * N)
+        self.dropout = float(dropout)
+        self.seeds_dev = torch.zeros(8, dtype=torch.int64, device=device)
+        self.seeds_host = torch.zeros(8, dtype=torch.int64).pin_memory()
+        self.seeds_np = self.seeds_host.numpy()
+        self.meta_host = [torch.zeros(L.META_WORDS, dtype=torch.int32).pin_memory() for _ in range(_RING)]
+        self.meta_event = [None] * _RING
+        self.step = 0
+        self.generation = 0
+        self.size_static = torch.ones(B, dtype=torch.int64, device=device)
+        m = self._cmodel()
+        self.saved_bytes = lib.eagcn_model_saved_bytes(self.index.ref(), C.byref(m))
+        self.scratch_bytes = lib.eagcn_model_scratch_bytes(self.index.ref(), C.byref(m))
+        self.saved = torch.empty(self.saved_bytes, dtype=torch.uint8, device=device)
+        self.scratch = torch.empty(self.scratch_bytes, dtype=torch.uint8, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.out = torch.zeros((B, m.head.nclass), **f32)
+        self.graph_rep = torch.zeros((B, m.head.n_den2), **f32)
+        self.dout = torch.zeros((B, m.head.nclass), **f32)
+        self.dgr = torch.zeros((B, m.head.n_den2), **f32)
+        self.dgr_is_zero = True
+        n = plan.offsets[-1]
+        self.flat_new = torch.zeros(n, **f32)
+        self.flat_acc = torch.zeros(n, **f32)
+        pieces = self.flat_acc.split(plan.sizes)
+        self.acc_views = [p if len(sh) == 1 else p.view(sh) for p, sh in zip(pieces, plan.shapes)]
+        self._grads_struct()
+        xo, po, ld = C.c_size_t(), C.c_size_t(), C.c_int()
+        lib.eagcn_model_atom_rep(self.index.ref(), C.byref(m), C.byref(xo), C.byref(po), C.byref(ld))
+        T = self.index.T
+        self.xout_view = self.saved[xo.value:xo.value + 4 * T * ld.value].view(torch.float32).view(T, ld.value)
+        self.pad_view = self.saved[po.value:po.value + 4 * ld.value].view(torch.float32)
+        self.fwd_graph = self.bwd_graph = None
+        self.ptrs = [t.data_ptr() for t in plan._ptr_tensors]
+
+    # -- C descriptors -------------------------------------------------------------------------------
+    def _cmodel(self):
+        m = L.Model.from_buffer_copy(self.plan.cmodel(True, 0, self.dropout))
+        sd = self.seeds_dev.data_ptr()
+        for l in range(len(self.plan.layers)):
+            m.layer[l].seed_dev = sd + 8 * l
+        m.head_seed_dev = sd + 8 * 4
+        m.input_packed = 1
+        self.cm = m
+        return m
+
+    def _grads_struct(self):
+        plan = self.plan
+        base = self.flat_new.data_ptr()
+
+        def gptr(i):
+            return base + 4 * plan.offsets[i]
+        lg = (L.LayerGrads * len(plan.layers))()
+        for l, (layer, (start, ave)) in enumerate(zip(plan.layers, plan.layer_slices)):
+            g = lg[l]
+            for k in range(layer.K):
+                i = start + 6 * k
+                g.datt_w[k], g.dself_r[k], g.dW[k] = gptr(i), gptr(i + 1), gptr(i + 2)
+                g.dbias[k], g.dgamma[k], g.dbeta[k] = gptr(i + 3), gptr(i + 4), gptr(i + 5)
+            g.dave_w = gptr(ave) if ave is not None else None
+        hg = L.HeadGrads()
+        for j, name in enumerate(('d_den1_w', 'd_den2_w', 'd_den3_w', 'd_gbn_w', 'd_gbn_b', 'd_bn1_w', 'd_bn1_b',
+                                  'd_bn2_w', 'd_bn2_b')):
+            setattr(hg, name, gptr(plan.head_start + j))
+        self.lg, self.hg = lg, hg
+
+    def stale(self):
+        """Parameter / buffer storage moved (e.g. .to()): the captured pointers are no longer valid."""
+        return [t.data_ptr() for t in self.plan._ptr_tensors] != self.ptrs
+
+    # -- the two launch sequences --------------------------------------------------------------------
+    def _call_forward(self):
+        lib = L.load()
+        size_ptr = _ptr(self.size_static) if self.plan.molfp else C.c_void_p(0)
+        L.check(lib.eagcn_model_forward(self.index.ref(), C.byref(self.cm), C.c_void_p(0), size_ptr, _ptr(self.saved),
+                                        self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.out),
+                                        _ptr(self.graph_rep), _stream()), 'eagcn_model_forward')
+        torch._foreach_add_(self.plan.nbt, 1)
+
+    def _call_backward(self):
+        lib = L.load()
+        size_ptr = _ptr(self.size_static) if self.plan.molfp else C.c_void_p(0)
+        L.check(lib.eagcn_model_backward(self.index.ref(), C.byref(self.cm), size_ptr, _ptr(self.saved),
+                                         self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.dout),
+                                         _ptr(self.dgr), self.lg, C.byref(self.hg), _stream()), 'eagcn_model_backward')
+
+    def _capture(self):
+        """Capture both sequences (nothing executes during capture).  Called after the first step ran
+        eagerly, which also serves as the warm-up HIP needs before a capture."""
+        lib = L.load()
+        lib.eagcn_prof_enable(0)
+        torch.cuda.synchronize(self.device)
+        self.fwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd_graph):
+            self._call_forward()
+        self.bwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.bwd_graph):
+            self._call_backward()
+
+    # -- per-step entry points -----------------------------------------------------------------------
+    def _check_old_batches(self, force=False):
+        for slot in range(_RING):
+            ev = self.meta_event[slot]
+            if ev is None or not (force or ev.query()):
+                continue
+            if force:
+                ev.synchronize()
+            meta = self.meta_host[slot].tolist()
+            self.meta_event[slot] = None
+            if meta[L.META_BAD_ADJ]:
+                raise L.EagcnHipError('a previous batch held %d adjacency entries outside {0,1}' % meta[L.META_BAD_ADJ])
+            if meta[L.META_BAD_REL]:
+                raise L.EagcnHipError('a previous batch held %d bonds whose relation channels are not one-hot'
+                                      % meta[L.META_BAD_REL])
+            if meta[L.META_T] > self.index.T:
+                raise L.EagcnHipError('a previous batch packed %d rows, more than row_cap=%d'
+                                      % (meta[L.META_T], self.index.T))
+
+    def forward(self, adj, rels, afm, size, seed):
+        lib = L.load()
+        self._check_old_batches()
+        idx = self.index
+        stream = _stream()
+        slot = self.step % _RING
+        if self.meta_event[slot] is not None:                 # ring wrapped: this slot must be consumed first
+            self._check_old_batches(force=True)
+        rel_ptrs = (C.c_void_p * idx.K)(*[r.data_ptr() for r in rels])
+        L.check(lib.eagcn_index_build(_ptr(adj), rel_ptrs, idx.ref(), C.c_void_p(self.meta_host[slot].data_ptr()),
+                                      stream), 'eagcn_index_build')
+        ev = torch.cuda.Event()
+        ev.record()
+        self.meta_event[slot] = ev
+        L.check(lib.eagcn_index_rows(idx.ref(), stream), 'eagcn_index_rows')
+        L.check(lib.eagcn_model_pack_input(idx.ref(), C.byref(self.cm), _ptr(afm), _ptr(self.saved), self.saved_bytes,
+                                           stream), 'eagcn_model_pack_input')
+        sn = self.seeds_np                                    # same derivation as ModelPlan.cmodel
+        for l in range(4):
+            sn[l] = (seed + 7919 * (l + 1)) & (2 ** 63 - 1)
+        sn[4] = (seed + 0x51ED27) & (2 ** 63 - 1)
+        self.seeds_dev.copy_(self.seeds_host, non_blocking=True)
+        if self.plan.molfp:
+            self.size_static.copy_(size, non_blocking=True)
+        self.step += 1
+        self.generation += 1
+        if self.fwd_graph is None:
+            self._call_forward()                              # first step: eager (and the capture warm-up)
+            self._capture()
+        else:
+            self.fwd_graph.replay()
+        return self.generation
+
+    def backward(self, dout, dgr, generation):
+        if generation != self.generation:
+            raise L.EagcnHipError('graph mode keeps ONE forward in flight: backward() of an older forward was '
+                                  'called after a newer training forward overwrote the saved activations')
+        self.dout.copy_(dout)
+        if dgr is not None:
+            self.dgr.copy_(dgr)
+            self.dgr_is_zero = False
+        elif not self.dgr_is_zero:
+            self.dgr.zero_()
+            self.dgr_is_zero = True
+        if self.bwd_graph is None:
+            self._call_backward()
+        else:
+            self.bwd_graph.replay()
+        params, views = self.plan.params, self.acc_views
+        grads = [p.grad for p in params]
+        if all(g is None for g in grads):
+            self.flat_acc.copy_(self.flat_new)
+            for p, v in zip(params, views):
+                p.grad = v
+        elif all(g is v for g, v in zip(grads, views)):
+            self.flat_acc.add_(self.flat_new)                 # gradient accumulation across backward passes
+        else:
+            pieces = self.flat_new.split(self.plan.sizes)
+            for p, g, piece, sh in zip(params, grads, pieces, self.plan.shapes):
+                piece = piece if len(sh) == 1 else piece.view(sh)
+                if g is None:
+                    p.grad = piece.clone()
+                else:
+                    g.add_(piece)
+
+
+class _GraphFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner, adj, rels, afm, size, seed, trigger):
+        ctx.set_materialize_grads(False)
+        ctx.runner = runner
+        ctx.generation = runner.forward(adj, rels, afm, size, seed)
+        return runner.out.detach(), runner.graph_rep.detach()
+
+    @staticmethod
+    def backward(ctx, dout, dgr):
+        if dout is None:
+            dout = torch.zeros_like(ctx.runner.out)
+        ctx.runner.backward(dout.contiguous(), None if dgr is None else dgr.contiguous(), ctx.generation)
+        return (None,) * 7
+
+
+def graph_forward(runner, adj, rels, afm, size, seed):
+    plan = runner.plan
+    if plan.trigger is None or plan.trigger.device != afm.device:
+        plan.trigger = torch.zeros((), dtype=torch.float32, device=afm.device, requires_grad=True)
+    return _GraphFn.apply(runner, adj, rels, afm, size, seed, plan.trigger)

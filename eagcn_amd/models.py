@@ -12,6 +12,12 @@ that fix ``structure``.  Keyword-only extensions (defaults = reference behaviour
                 'direct': the backward call writes them into ONE flat buffer and sets ``p.grad`` to
                 views of it (accumulating into an existing ``.grad``), which skips ~70 AccumulateGrad
                 nodes per step.  Same values; tensor hooks on parameters do not fire in this mode.
+  graph         False (default) | True: replay the training step as two captured HIP graphs (forward,
+                backward) instead of ~60 eager launches; see eagcn_amd/graph.py.  Needs a fixed (B, N)
+                per captured pair (a new pair is captured for every new shape), delivers gradients
+                as in grad_mode='direct', keeps ONE training forward in flight, and the lazy atom
+                representations are valid until the next forward.  ``row_cap`` bounds the packed rows
+                the static buffers are sized for (default B*N).
   overlap_index False (default) | True: declare that the batch tensors are already resident in HBM when
                 forward is called (prefetched batches); the batch index then runs on a side stream
                 without waiting for the previous step's queued work (see ops.BatchIndex).
@@ -62,7 +68,7 @@ class EAGCN(nn.Module):
                  n_sgc1_5=None, n_sgc2_1=None, n_sgc2_2=None, n_sgc2_3=None, n_sgc2_4=None, n_sgc2_5=None,
                  n_den1=128, n_den2=64, nclass=1, dropout=0.0, structure='Concate', molfp_mode='sum',
                  pool_num=5, *, n_layers=4, widths1=None, widths2=None, rel_channels=None, atom_rep='lazy',
-                 grad_mode='autograd', overlap_index=False):
+                 grad_mode='autograd', overlap_index=False, graph=False, row_cap=None):
         super().__init__()
         if widths1 is None:
             widths1 = [n_sgc1_1, n_sgc1_2, n_sgc1_3, n_sgc1_4, n_sgc1_5]
@@ -103,6 +109,8 @@ class EAGCN(nn.Module):
             raise ValueError("grad_mode must be 'autograd' or 'direct'")
         self.grad_mode = grad_mode
         self.overlap_index = bool(overlap_index)
+        self.graph, self.row_cap = bool(graph), row_cap
+        self._runners = {}
         self.den1 = Dense(f_last, n_den1)
         self.den2 = Dense(n_den1, n_den2)
         self.den3 = Dense(n_den2, nclass)
@@ -132,13 +140,47 @@ class EAGCN(nn.Module):
 
     def _apply(self, fn, *a, **kw):                     # .cuda() / .to(): parameters are re-created
         self._plan = None
+        self._runners = {}
         return super()._apply(fn, *a, **kw)
+
+    def _graph_forward(self, adjs, afms, rels, size):
+        from . import graph as G
+        adjs = ops._need_cuda_f32(adjs, 'adjs')
+        afms = ops._need_cuda_f32(afms, 'afms')
+        rels = [ops._need_cuda_f32(r, 'relation tensor %d' % i) for i, r in enumerate(rels)]
+        B, N = adjs.shape[0], adjs.shape[1]
+        if adjs.dim() != 3 or adjs.shape[2] != N or afms.shape != (B, N, self.n_afeat) or len(rels) != self.K:
+            raise ops.L.EagcnHipError('inconsistent batch tensors: adjs %s afms %s, %d relation tensors'
+                                      % (tuple(adjs.shape), tuple(afms.shape), len(rels)))
+        for i, r in enumerate(rels):
+            if r.dim() != 4 or r.shape[0] != B or r.shape[2] != N or r.shape[3] != N:
+                raise ops.L.EagcnHipError('relation tensor %d must be [B,C,N,N], got %s' % (i, tuple(r.shape)))
+        plan = self.plan()
+        channels = tuple(int(r.shape[1]) for r in rels)
+        key = (B, N, channels, float(self.dropout))
+        runner = self._runners.get(key)
+        if runner is None or runner.stale():
+            runner = G.GraphRunner(plan, B, N, channels, adjs.device, self.dropout, self.row_cap)
+            self._runners[key] = runner
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.dropout > 0 else 0
+        if self.molfp_mode == 'ave':
+            size = size.to(device=adjs.device, dtype=torch.int64)
+        out, graph_representation = G.graph_forward(runner, adjs, rels, afms, size, seed)
+        atom_representations = None
+        if self.atom_rep != 'none':
+            pad = runner.pad_view if self.structure == 'Weighted_sum' else None
+            atom_representations = LazyAtomRep(runner.index, plan.last_layout, runner.xout_view, pad)
+            if self.atom_rep == 'eager':
+                atom_representations = atom_representations.cpu()
+        return out, atom_representations, graph_representation
 
     def forward(self, adjs, afms, *rels_and_size):
         """Reference signature (models.py:96): (adjs, afms, TypeAtt, OrderAtt, AromAtt, ConjAtt, RingAtt,
         size) -> (x, atom_representations, graph_representation).  The whole forward is one call into
         eagcn_model_forward (layers, read-out and head); backward is one call into eagcn_model_backward."""
         *rels, size = rels_and_size
+        if self.graph and self.training and torch.is_grad_enabled():
+            return self._graph_forward(adjs, afms, rels, size)
         index = ops.BatchIndex(adjs, rels, overlap=self.overlap_index)   # once per batch, shared by all layers
         plan = self.plan()
         seed = 0

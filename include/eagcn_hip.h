@@ -104,6 +104,9 @@ typedef struct eagcn_layer_params {
     float dropout;
     float bn_eps, bn_momentum;
     uint64_t seed;                          /* dropout stream for this call                     */
+    const uint64_t* seed_dev;               /* if non-NULL the seed is read from this DEVICE word  */
+                                            /* instead (a replayed HIP graph cannot change by-value */
+                                            /* arguments)                                          */
     const float* att_w[EAGCN_MAX_VIEWS];    /* [C_k]    blockK.att.weight                       */
     const float* self_r[EAGCN_MAX_VIEWS];   /* [1]      blockK.self_r                           */
     const float* W[EAGCN_MAX_VIEWS];        /* [fin,F_k] blockK.graph_conv.weight               */
@@ -205,6 +208,8 @@ typedef struct eagcn_model {
     int32_t molfp_mode;                     /* 0 = 'sum', 1 = 'ave' (models.py:108-111)                */
     int32_t training;
     uint64_t head_seed;                     /* dropout stream of the head (models.py:116)              */
+    const uint64_t* head_seed_dev;          /* device-resident alternative (see eagcn_layer_params)    */
+    int32_t input_packed;                   /* 1: saved already holds the packed input (eagcn_model_pack_input) */
     eagcn_layer_params layer[4];            /* layer[l].in must equal the output layout of layer l-1   */
     eagcn_head_params head;
 } eagcn_model;
@@ -214,6 +219,9 @@ size_t eagcn_model_scratch_bytes(const eagcn_batch* b, const eagcn_model* m);  /
 /* where the last layer's packed activations [T][ld] and pad_row [ld] live inside `saved` */
 int eagcn_model_atom_rep(const eagcn_batch* b, const eagcn_model* m, size_t* xout_offset,
                          size_t* pad_row_offset, int* ld);
+/* packs afm [B][N][n_afeat] into the input slot of `saved` (the first step of eagcn_model_forward) */
+int eagcn_model_pack_input(const eagcn_batch* b, const eagcn_model* m, const float* afm, void* saved,
+                           size_t saved_bytes, void* stream);
 /* afm: dense [B][N][n_afeat]; out: [B][nclass]; graph_rep: [B][n_den2] (den2 output, models.py:118) */
 int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, const float* afm, const int64_t* size,
                         void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, float* out,

@@ -326,3 +326,49 @@ def test_row_capacity_larger_than_row_count():
     scale = max(v.abs().max().item() for v in res[0][1].values())
     for k, v in res[0][1].items():
         assert_grad_close(res[1][1][k], v.cpu(), scale, k, rtol=1e-5, floor=1e-6)
+
+
+@pytest.mark.parametrize('structure,dropout', [('Concate', 0.0), ('Concate', 0.3), ('Weighted_sum', 0.0)])
+def test_graph_mode_equals_eager_engine(structure, dropout):
+    """Captured-graph replay vs eager launches over several steps with DIFFERENT batches of the same
+    (B, N): outputs, gradients and BatchNorm buffers must agree step by step (same dropout seeds)."""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    w1, w2 = ([9, 7, 5, 5, 6], [12, 8, 6, 6, 8]) if structure == 'Concate' else ([3] * 5, [4] * 5)
+    kw = dict(structure=structure, n_layers=2, molfp_mode='ave', grad_mode='direct')
+    torch.manual_seed(1)
+    a = EAGCN(6, 24, *w1, *w2, 24, 12, 3, dropout, **kw).cuda().train()
+    b = EAGCN(6, 24, *w1, *w2, 24, 12, 3, dropout, graph=True, **kw).cuda().train()
+    b.load_state_dict(a.state_dict())
+    gsel = torch.randn(11, 3, device='cuda')
+    for step in range(4):
+        mb = make_batch(B=11, n_max=29, n_med=8 + 2 * step, rel_channels=(6, 4, 2, 2, 2), seed=30 + step,
+                        isolated_frac=0.1 if step == 2 else 0.0)
+        d = _dev(mb.dense())
+        outs = []
+        for m in (a, b):
+            torch.manual_seed(100 + step)                       # same dropout seed draw for both
+            for p in m.parameters():
+                p.grad = None
+            out, rep, gr = m(*d)
+            ((out * gsel).sum() + gr.sum()).backward()
+            outs.append((out.detach().clone(), gr.detach().clone(), rep.packed[0][:int(mb.sizes.sum())].clone()))
+        assert rel_err(outs[1][0].cpu(), outs[0][0].cpu()) < 2e-6, step
+        assert rel_err(outs[1][1].cpu(), outs[0][1].cpu()) < 2e-6, step
+        pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+        scale = max(p.grad.abs().max().item() for p in pa.values() if p.grad is not None)
+        for k in pa:
+            assert (pa[k].grad is None) == (pb[k].grad is None), k
+            if pa[k].grad is not None:
+                assert_grad_close(pb[k].grad, pa[k].grad.cpu(), scale, '%s step %d' % (k, step), rtol=1e-5, floor=1e-5)
+        for k, v in a.state_dict().items():
+            dd = (b.state_dict()[k].double().cpu() - v.double().cpu()).abs().max().item()
+            assert dd <= 2e-6 * max(v.double().abs().max().item(), 1.0), (k, step, dd)
+    # invalid input is reported (one or two steps later: no host read-back on the graph path)
+    bad = [t.clone() for t in d]
+    bad[0][0, 0, 1] = 0.5
+    from eagcn_amd._lib import EagcnHipError
+    with pytest.raises(EagcnHipError):
+        for _ in range(3):
+            b(*bad)
+            torch.cuda.synchronize()
