@@ -44,14 +44,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
     const int li = lane & 15, q = lane >> 4;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    if (g.M_dev) g.M = min(*g.M_dev, g.M);          // extents known only on the device (packed row count)
-    if (g.K_dev) g.K = min(*g.K_dev, g.K);
-    if (m0 >= g.M && g.splits == 1) return;         // uniform: nothing to do for this tile
+    // extents that are known only on the device (packed row count); locals, never written back into
+    // the by-value argument block (that would demote it to scratch memory)
+    const int Mx = g.M_dev ? min(*g.M_dev, g.M) : g.M;
+    const int Kx = g.K_dev ? min(*g.K_dev, g.K) : g.K;
+    if (m0 >= Mx && g.splits == 1) return;          // uniform: nothing to do for this tile
     // split-K range
     const int z = blockIdx.z;
-    const int kchunk = ((g.K + g.splits - 1) / g.splits + BK - 1) / BK * BK;
+    const int kchunk = ((Kx + g.splits - 1) / g.splits + BK - 1) / BK * BK;
     const int kbeg = z * kchunk;
-    const int kend = min(g.K, kbeg + kchunk);
+    const int kend = min(Kx, kbeg + kchunk);
     float* C = g.C + (size_t)z * g.slab;
 
     float4 ra[A_PASS], rb[B_PASS];
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (A_KC) {
                 int row = p * A_RPP + tid / A_TPR, kq = (tid % A_TPR) * 4;
-                if (m0 + row < g.M && k0 + kq < kend) {
+                if (m0 + row < Mx && k0 + kq < kend) {
                     const float* src = g.A + (size_t)(m0 + row) * g.lda + k0 + kq;
                     if (g.vecA) v = *reinterpret_cast<const float4*>(src);
                     else {
@@ -73,14 +75,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
                 }
             } else {
                 int k = p * A_RPP + tid / A_TPR, mq = (tid % A_TPR) * 4;
-                if (k0 + k < kend && m0 + mq < g.M) {
+                if (k0 + k < kend && m0 + mq < Mx) {
                     const float* src = g.A + (size_t)(k0 + k) * g.lda + m0 + mq;
                     if (g.vecA) v = *reinterpret_cast<const float4*>(src);
                     else {
                         v.x = src[0];
-                        if (m0 + mq + 1 < g.M) v.y = src[1];
-                        if (m0 + mq + 2 < g.M) v.z = src[2];
-                        if (m0 + mq + 3 < g.M) v.w = src[3];
+                        if (m0 + mq + 1 < Mx) v.y = src[1];
+                        if (m0 + mq + 2 < Mx) v.z = src[2];
+                        if (m0 + mq + 3 < Mx) v.w = src[3];
                     }
                 }
             }
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm + i * 16 + q * 4 + r;
-                if (row < g.M && col < g.N) C[(size_t)row * g.ldc + col] = acc[i][j][r];
+                if (row < Mx && col < g.N) C[(size_t)row * g.ldc + col] = acc[i][j][r];
             }
         }
 }
@@ -222,7 +224,10 @@ int launch_gemm(const GemmDesc& g0, hipStream_t s) {
     int cfg = forced;
     if (cfg < 0) {
         const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.splits;
-        cfg = tiles128 >= 384 ? 3 : 0;
+        // measured on MI355X (tools/gemm_bench.py, gemm_big.py): 128x128 tiles win only for long-K, many-tile
+        // problems (4096^3: 113 vs 98 TF); at the layer shapes (K = 24..704) 64x64 is equal or better, and in
+        // graph mode M is only a capacity, so do not let it pick the large tile
+        cfg = (g.K >= 1024 && tiles128 >= 512) ? 3 : 0;
     }
     switch (cfg) {
         case 1: return launch_cfg<64, 64, 32>(g, s);

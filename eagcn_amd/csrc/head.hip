@@ -35,7 +35,7 @@ struct RowBnFwd {
 constexpr int RB_CACHE = 16;          // rows per lane kept in registers -> R <= 256 needs no second read
 
 __global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnFwd a) {
-    if (a.seed_dev) a.seed = *a.seed_dev;
+    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
     const int cr = blockIdx.x * 16 + (threadIdx.x >> 4), rl = threadIdx.x & 15;
     const int c = min(cr, a.F - 1);
     float v[RB_CACHE];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnFwd a) {
     auto emit = [&](int r, float x) {
         float h = x * sc + sh;
         if (a.relu) h = fmaxf(h, 0.0f);
-        if (a.do_drop) h *= drop_scale(a.seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
+        if (a.do_drop) h *= drop_scale(seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
         a.y[(size_t)r * a.F + c] = h;
     };
 #pragma unroll
@@ -108,14 +108,14 @@ struct RowBnBwd {
 };
 
 __global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwd a) {
-    if (a.seed_dev) a.seed = *a.seed_dev;
+    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
     const int cr = blockIdx.x * 16 + (threadIdx.x >> 4), rl = threadIdx.x & 15;
     const int c = min(cr, a.F - 1);
     const float sc = a.bn[RB_SC * a.F + c], sh = a.bn[RB_SH * a.F + c];
     const float mu = a.bn[RB_MU * a.F + c], inv = a.bn[RB_INV * a.F + c];
     auto upstream = [&](int r, float xv, float dyv) {      // gradient that reaches the BatchNorm output
         float dh = dyv;
-        if (a.do_drop) dh *= drop_scale(a.seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
+        if (a.do_drop) dh *= drop_scale(seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
         if (a.relu && !(xv * sc + sh > 0.0f)) dh = 0.0f;
         return dh;
     };

@@ -157,7 +157,8 @@ struct ApplyArgs {
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
     const int fp = a.fp;
-    if (a.seed_dev) a.seed = *a.seed_dev;
+    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;   // (never write to the by-value argument block:
+                                                               //  that would demote it to scratch memory)
     if (blockIdx.x == 0) {   // value of the rows that are not stored
         for (int c = threadIdx.x; c < a.ldo; c += blockDim.x) {
             float v = 0.0f;
@@ -186,10 +187,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
             o.w = fmaxf(y.w * sc.w + sh.w, 0.0f) * m;
             if (a.do_drop) {
                 const uint64_t idx = (uint64_t)r * fp + c;
-                o.x *= drop_scale(a.seed, idx + 0, a.thr, a.inv_keep);
-                o.y *= drop_scale(a.seed, idx + 1, a.thr, a.inv_keep);
-                o.z *= drop_scale(a.seed, idx + 2, a.thr, a.inv_keep);
-                o.w *= drop_scale(a.seed, idx + 3, a.thr, a.inv_keep);
+                o.x *= drop_scale(seed, idx + 0, a.thr, a.inv_keep);
+                o.y *= drop_scale(seed, idx + 1, a.thr, a.inv_keep);
+                o.z *= drop_scale(seed, idx + 2, a.thr, a.inv_keep);
+                o.w *= drop_scale(seed, idx + 3, a.thr, a.inv_keep);
             }
             *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + c) = o;
         }
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
             for (int k = 0; k < a.vc.K; ++k) {
                 const int cp = a.vc.off[k] + f;
                 float p = fmaxf(a.Y[(size_t)r * a.ldy + cp] * a.bn[BN_SC * fp + cp] + a.bn[BN_SH * fp + cp], 0.0f);
-                if (a.do_drop) p *= drop_scale(a.seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
+                if (a.do_drop) p *= drop_scale(seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
                 acc += a.colp[CP_AVEW * fp + cp] * p;
             }
             a.out[e] = acc;
@@ -227,7 +228,7 @@ struct BwdArgs {
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     __shared__ double da_s[EAGCN_MAX_VIEWS];
-    if (a.seed_dev) a.seed = *a.seed_dev;
+    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
     const int fp = a.fp, T = dev_rows(a.bt);
     if (threadIdx.x < EAGCN_MAX_VIEWS) da_s[threadIdx.x] = 0.0;
     __syncthreads();
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
                 y = a.Y[(size_t)r * a.ldy + cp];
                 up = a.dxout[(size_t)r * a.ldo + cu];
                 if (!weighted) up *= a.bt.row_m[r];
-                if (a.do_drop) ds = drop_scale(a.seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
+                if (a.do_drop) ds = drop_scale(seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
             } else {                                  // all non-stored rows share one value: one virtual row
                 y = 0.0f;
                 up = a.dpad[(size_t)(r - T) * a.ldo + cu];
