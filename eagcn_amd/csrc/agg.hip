@@ -32,6 +32,9 @@ __global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
     const int ntile_k = (a.vc.off[k + 1] - a.vc.off[k]) / 16;
     const int ct0 = cc * CT;
     if (ct0 >= ntile_k) return;                       // uniform for the whole workgroup
+    const int ntiles = dev_tiles(a.bt);
+    if ((int)blockIdx.x * 4 >= ntiles) return;        // capacity-sized grid: no tile for this workgroup (its
+                                                      // stats slab is not read either: bn_finalize counts live slabs)
     const int nct = min(CT, ntile_k - ct0);
     const int c0 = a.vc.off[k] + ct0 * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -45,7 +48,6 @@ __global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
 #pragma unroll
     for (int c = 0; c < CT; ++c) { s1[c] = 0.0; s2[c] = 0.0; }
 
-    const int ntiles = dev_tiles(bt);
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const int b = bt.tile_mol[tile];
         const int rt = tile - bt.tile0[b];
@@ -217,11 +219,15 @@ int launch_agg(AggArgs a, bool trans, hipStream_t s) {
 //   d w_k[c] += dU[i,j] s (1-s)  at bonds of type c ;   d self_r_k += dU[i,i] r (1-r)
 // one wavefront per (packed row, view); results accumulated in fp64.
 __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
-    // each 16-lane group of a wavefront owns one packed row: 4 rows in flight per wave, dot products
-    // reduced inside the group (lanes of a group read 64 contiguous bytes per step)
+    // one packed row per 16-lane group (4 rows per wavefront, 16 per workgroup), no persistent loop.
+    // Dependent-load hops per row: {row_info, rscale} -> {code row, dY row, Y row} -> one hop per bond.
+    // The whole code row arrives with ONE 16-byte load per lane (16 lanes x 16 bytes = 256 columns).
     __shared__ float sig_s[256];
     __shared__ double h_s[256];
     __shared__ double dr_s[16];
+    const eagcn_batch& bt = a.bt;
+    const int Tn = dev_rows(bt);
+    if ((int)blockIdx.x * 16 >= Tn) return;                        // capacity-sized grid (slab not read either)
     const int k = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane >> 4, sl = lane & 15;
@@ -229,46 +235,47 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
     h_s[tid] = 0.0;
     if (tid < 16) dr_s[tid] = 0.0;
     __syncthreads();
-    const eagcn_batch& bt = a.bt;
     const int off = a.vc.off[k], fp = a.vc.off[k + 1] - a.vc.off[k];
     double dr_acc = 0.0;
-    const int Tn = dev_rows(bt);
-    for (int rbase = (blockIdx.x * 4 + wave) * 4; rbase < Tn; rbase += gridDim.x * 16) {
-        const int r = rbase + grp;
-        float rs = 0.0f;
-        int b = 0, i = 0, n = 0, r0 = 0;
-        if (r < Tn) {
-            rs = a.rscale[(size_t)k * bt.T + r];
-            b = bt.row_mol[r];
-            i = bt.row_loc[r];
-            n = bt.nat[b];
-            r0 = bt.row0[b];
-        }
-        const bool live = rs != 0.0f;                              // m_i == 0 rows carry no dependence
-        const int rr = live ? r : 0;
-        const float* dy = a.dY + (size_t)rr * a.ld + off;
-        const float* yr = a.Y + (size_t)rr * a.ld + off;
-        float rd = 0.0f;
-        if (live)
-            for (int c = sl; c < fp; c += 16) rd += dy[c] * yr[c];
+    const int r = (blockIdx.x * 4 + wave) * 4 + grp;
+    int4 info = make_int4(0, 0, 0, 0);
+    float rs = 0.0f;
+    if (r < Tn) {
+        info = reinterpret_cast<const int4*>(bt.row_info)[r];
+        rs = a.rscale[(size_t)k * bt.T + r];
+    }
+    const bool live = rs != 0.0f;                                  // m_i == 0 rows carry no dependence
+    const int b = info.x, i = info.y, n = live ? info.z : 0, r0 = info.w;
+    const int rr = live ? r : 0;
+    const float* dy = a.dY + (size_t)rr * a.ld + off;
+    const float* yr = a.Y + (size_t)rr * a.ld + off;
+    const uint8_t* crow = bt.code + (((size_t)k * bt.B + b) * bt.N + i) * bt.ldc;
+    const int nmax = max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48)));
+    float rd = 0.0f;
+    if (live)
+        for (int c = sl; c < fp; c += 16) rd += dy[c] * yr[c];
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) rd += __shfl_xor(rd, o);
-        const uint8_t* crow = bt.code + (((size_t)k * bt.B + b) * bt.N + i) * bt.ldc;
-        const int nmax = max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48)));
-        for (int jb = 0; jb < nmax; jb += 16) {
-            const int j = jb + sl;
-            const uint32_t c = (live && j < n) ? crow[j] : 0u;
-            const bool want = live && j < n && (c != 0u || j == i);
+    for (int o = 8; o > 0; o >>= 1) rd += __shfl_xor(rd, o);
+    for (int seg = 0; seg * 256 < nmax; ++seg) {
+        const int jb = seg * 256 + sl * 16;
+        uint4 cw = make_uint4(0u, 0u, 0u, 0u);
+        if (jb < n) cw = *reinterpret_cast<const uint4*>(crow + jb);
+        const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t c = (w[t >> 2] >> (8 * (t & 3))) & 255u;
+            const int j = jb + t;
+            const bool want = j < n && (c != 0u || j == i);
             unsigned long long ball = __ballot(want);
-            uint32_t mask = (uint32_t)(ball >> (grp * 16)) & 0xFFFFu;           // this group's hits
-            // the groups iterate their own hit lists in lock step (uniform trip count = longest list)
-            int cnt = __popc(mask);
+            if (ball == 0ull) continue;                                // wave-uniform
+            uint32_t mask = (uint32_t)(ball >> (grp * 16)) & 0xFFFFu;       // this group's lanes with a hit at byte t
+            const int cnt = __popc(mask);
             const int cmax = max(max(__shfl(cnt, 0), __shfl(cnt, 16)), max(__shfl(cnt, 32), __shfl(cnt, 48)));
             for (int it = 0; it < cmax; ++it) {
                 const bool act = mask != 0u;
                 const int src = act ? (__ffs(mask) - 1) : 0;
                 mask &= mask - 1;
-                const int jj = jb + src;
+                const int jj = seg * 256 + src * 16 + t;
                 const uint32_t cj = __shfl(c, grp * 16 + src);
                 const float* pr = a.P + (size_t)(act ? (r0 + jj) : 0) * a.ld + off;
                 float g = 0.0f;
@@ -299,7 +306,8 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
     }
 }
 
-int edge_grid_x(const eagcn_batch* b) { return std::max(1, std::min(cdiv(b->T, 16), 256)); }
+// one workgroup per 16 packed rows; workgroups beyond the actual row count exit at once
+int edge_grid_x(const eagcn_batch* b) { return std::max(1, cdiv(b->T, 16)); }
 
 int launch_edge_grad(const EdgeArgs& a, hipStream_t s) {
     if (a.bt.T == 0) return EAGCN_OK;

@@ -18,8 +18,8 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- per-kernel-class timing ---------------------------------------------------------------------
-enum { PROF_NTAGS = 7 };
-static const char* kTagNames[PROF_NTAGS] = {"index", "pack", "gemm", "agg", "bn", "edge", "readout"};
+enum { PROF_NTAGS = 8 };
+static const char* kTagNames[PROF_NTAGS] = {"index", "pack", "gemm", "agg", "bn", "edge", "readout", "head"};
 struct ProfRec { hipEvent_t a, b; };
 struct ProfState {
     bool on = false;

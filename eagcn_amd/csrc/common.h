@@ -117,7 +117,7 @@ inline int layout_width(const eagcn_layout* l) {
 }
 
 // ---- optional per-kernel-class timing (HIP events on the launch stream), off by default --------
-enum ProfTag { PROF_INDEX = 0, PROF_PACK, PROF_GEMM, PROF_AGG, PROF_BN, PROF_EDGE, PROF_READOUT, PROF_NTAGS };
+enum ProfTag { PROF_INDEX = 0, PROF_PACK, PROF_GEMM, PROF_AGG, PROF_BN, PROF_EDGE, PROF_READOUT, PROF_HEAD, PROF_NTAGS };
 bool prof_on();
 void prof_begin(int tag, hipStream_t s, double work);
 void prof_end(int tag, hipStream_t s);
@@ -140,6 +140,7 @@ struct GemmDesc {
     int vecA = 1, vecB = 1; // set by launch_gemm: float4 loads allowed for A / B
     const int* M_dev = nullptr;   // if set: actual M (<= M) read on the device; M is then the capacity
     const int* K_dev = nullptr;   // if set: actual K (<= K), used by the split-K row reduction
+    int prof_tag = PROF_GEMM;     // timing class (the head's small GEMMs are kept apart from the layer GEMMs)
 };
 int launch_gemm(const GemmDesc& g, hipStream_t s);
 

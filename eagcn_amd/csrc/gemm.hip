@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
 template <int BM, int BN, int BK>
 static int launch_cfg(const GemmDesc& g, hipStream_t s) {
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.splits);
-    ProfScope ps(PROF_GEMM, s, g.work > 0.0 ? g.work : 2.0 * g.M * g.N * g.K);
+    ProfScope ps(g.prof_tag, s, g.work > 0.0 ? g.work : 2.0 * g.M * g.N * g.K);
     if (g.ta == 0 && g.tb == 0) gemm_f32_kernel<BM, BN, BK, true, false><<<grid, 256, 0, s>>>(g);
     else if (g.ta == 0 && g.tb == 1) gemm_f32_kernel<BM, BN, BK, true, true><<<grid, 256, 0, s>>>(g);
     else if (g.ta == 1 && g.tb == 0) gemm_f32_kernel<BM, BN, BK, false, false><<<grid, 256, 0, s>>>(g);

@@ -299,7 +299,7 @@ static int rowbn_fwd(hipStream_t s, int R, int F, const float* x, float* y, cons
     a.R = R; a.F = F; a.x = x; a.y = y; a.gamma = g; a.beta = be; a.run_mean = rm; a.run_var = rv; a.bn = bn;
     a.training = training; a.relu = relu; a.eps = eps; a.momentum = mom; a.seed = seed; a.seed_dev = seed_dev;
     fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
-    ProfScope ps(PROF_BN, s);
+    ProfScope ps(PROF_HEAD, s);
     rowbn_fwd_kernel<<<cdiv(F, 16), 256, 0, s>>>(a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
@@ -311,7 +311,7 @@ static int rowbn_bwd(hipStream_t s, int R, int F, const float* dy, const float* 
     a.R = R; a.F = F; a.dy = dy; a.x = x; a.bn = bn; a.extra = extra; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta;
     a.training = training; a.relu = relu; a.seed = seed; a.seed_dev = seed_dev;
     fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
-    ProfScope ps(PROF_BN, s);
+    ProfScope ps(PROF_HEAD, s);
     rowbn_bwd_kernel<<<cdiv(F, 16), 256, 0, s>>>(a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
@@ -319,6 +319,7 @@ static int rowbn_bwd(hipStream_t s, int R, int F, const float* dy, const float* 
 static int mm(hipStream_t s, int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
               int ldb, float* C, int ldc) {
     GemmDesc g{ta, tb, M, N, K, A, lda, B, ldb, C, ldc, 1, 0};
+    g.prof_tag = PROF_HEAD;
     return launch_gemm(g, s);
 }
 

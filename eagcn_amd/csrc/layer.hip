@@ -111,7 +111,10 @@ __device__ __forceinline__ void slab_sum16(const double* __restrict__ slab, int 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ slab, int nslab, int fp,
                                                            double M, int training, float eps, float momentum,
                                                            const float* __restrict__ colp, ParamPtrs pp,
-                                                           ViewCols vc, float* __restrict__ bn) {
+                                                           ViewCols vc, float* __restrict__ bn,
+                                                           const int32_t* __restrict__ meta) {
+    // aggregation workgroups beyond the actual tile count exit without writing their slab
+    nslab = min(nslab, (meta[EAGCN_META_NTILES] + 3) / 4);
     const int cpr = blockIdx.x * 16 + (threadIdx.x >> 4), sl = threadIdx.x & 15;
     const int cp = min(cpr, fp - 1);
     double s1 = 0.0, s2 = 0.0;
@@ -333,7 +336,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(eagcn_batch bt, int f
 __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtrs pp, ViewCols vc, ColMapD in,
                                                             int ld_in, int fp, const float* __restrict__ dWcat,
                                                             int nsplit, size_t slab, const double* __restrict__ datt,
-                                                            int nedge, const float* __restrict__ rsig, int wblocks) {
+                                                            int nedge, const float* __restrict__ rsig, int wblocks,
+                                                            const int32_t* __restrict__ meta) {
+    nedge = min(nedge, (meta[EAGCN_META_T] + 15) / 16);        // edge-gradient workgroups that had rows
     if ((int)blockIdx.x < wblocks) {
         const int e = blockIdx.x * blockDim.x + threadIdx.x;
         if (e >= ld_in * fp) return;
@@ -571,7 +576,7 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
     const double M = (double)b->B * (double)b->N;
     ProfScope psbn(PROF_BN, s);
     bn_finalize_kernel<<<cdiv(d.fp, 16), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
-                                                        p->bn_momentum, sc.colp, pp, d.vc, w->bn);
+                                                        p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta);
     EAGCN_LAUNCH_CHECK();
     ApplyArgs aa;
     aa.bt = *b; aa.vc = d.vc; aa.structure = p->structure; aa.fp = d.fp; aa.Y = w->Y; aa.ldy = d.fp;
@@ -684,7 +689,7 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
     const int wblocks = cdiv((int)d.wslab, 256);
     unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, s>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
                                                                              nsplit, d.wslab, sc.datt, nedge, sc.rsig,
-                                                                             wblocks);
+                                                                             wblocks, b->meta);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

@@ -150,14 +150,17 @@ class BatchIndex:
             self.n_tiles = B * ((N + 15) // 16)
         T = self.T
         main.wait_stream(side)            # everything below (and every consumer) runs on `main`
-        rows = torch.empty(4 * T + self.n_tiles, **i32)          # [row_mol | row_loc | row_deg | row_m(f32) | tile_mol]
-        self.row_mol, self.row_loc, self.row_deg = rows[0:T], rows[T:2 * T], rows[2 * T:3 * T]
-        self.row_m = rows[3 * T:4 * T].view(torch.float32)
-        self.tile_mol = rows[4 * T:]
+        # [row_info 4T (16-byte aligned first) | row_mol | row_loc | row_deg | row_m(f32) | tile_mol]
+        rows = torch.empty(8 * T + self.n_tiles, **i32)
+        self.row_mol, self.row_loc, self.row_deg = rows[4 * T:5 * T], rows[5 * T:6 * T], rows[6 * T:7 * T]
+        self.row_m = rows[7 * T:8 * T].view(torch.float32)
+        self.tile_mol = rows[8 * T:]
         self._rows = rows
         c.T, c.n_max, c.n_tiles = T, self.n_max, self.n_tiles
         rb = rows.data_ptr()
-        c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = rb, rb + 4 * T, rb + 8 * T, rb + 12 * T, rb + 16 * T
+        c.row_info = rb
+        c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = (rb + 16 * T, rb + 20 * T, rb + 24 * T, rb + 28 * T,
+                                                                rb + 32 * T)
         L.check(lib.eagcn_index_rows(C.byref(c), C.c_void_p(main.cuda_stream)), 'eagcn_index_rows')
         for t in (self.code, blob):
             t.record_stream(main)         # allocated on `side`, consumed on `main`

@@ -86,6 +86,8 @@ typedef struct eagcn_batch {
     float* row_m;                           /* [T] row mask m_i = max_j adj[i,j]                */
     int32_t* row_deg;                       /* [T]                                              */
     int32_t* tile_mol;                      /* [n_tiles]                                        */
+    int32_t* row_info;                      /* [T][4] {molecule, atom, nat[mol], row0[mol]}: one
+                                               16-byte load instead of a two-hop lookup          */
 } eagcn_batch;
 
 /* column layout of a packed activation matrix */
