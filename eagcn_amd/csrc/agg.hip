@@ -251,9 +251,7 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
     const float* yr = a.Y + (size_t)rr * a.ld + off;
     const uint8_t* crow = bt.code + (((size_t)k * bt.B + b) * bt.N + i) * bt.ldc;
     const int nmax = max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48)));
-    float rd = 0.0f;
-    if (live)
-        for (int c = sl; c < fp; c += 16) rd += dy[c] * yr[c];
+    float rd = live ? dot16(dy, yr, sl, fp) : 0.0f;
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) rd += __shfl_xor(rd, o);
     for (int seg = 0; seg * 256 < nmax; ++seg) {
@@ -278,9 +276,7 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
                 const int jj = seg * 256 + src * 16 + t;
                 const uint32_t cj = __shfl(c, grp * 16 + src);
                 const float* pr = a.P + (size_t)(act ? (r0 + jj) : 0) * a.ld + off;
-                float g = 0.0f;
-                if (act)
-                    for (int c2 = sl; c2 < fp; c2 += 16) g += dy[c2] * pr[c2];
+                float g = act ? dot16(dy, pr, sl, fp) : 0.0f;
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) g += __shfl_xor(g, o);
                 if (act && sl == 0) {

@@ -65,6 +65,27 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
+// partial dot product of two rows over columns sl, sl+16, ... < n (16-lane group, lane sl): the loads of
+// DOT_U column steps are issued together before any FMA, so a group has 2*DOT_U loads in flight instead
+// of paying one memory round trip per step (measured: a rolled loop left edge_grad 84 % in s_waitcnt)
+constexpr int DOT_U = 10;
+__device__ __forceinline__ float dot16(const float* __restrict__ a, const float* __restrict__ b, int sl, int n) {
+    float acc = 0.0f;
+    for (int c0 = sl; c0 < n; c0 += 16 * DOT_U) {
+        float x[DOT_U], y[DOT_U];
+#pragma unroll
+        for (int u = 0; u < DOT_U; ++u) {
+            const int c = c0 + 16 * u;
+            const bool ok = c < n;
+            x[u] = ok ? a[c] : 0.0f;
+            y[u] = ok ? b[c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < DOT_U; ++u) acc += x[u] * y[u];
+    }
+    return acc;
+}
+
 // counter-based dropout stream: one 32-bit draw per (seed, element index)
 __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
     uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;

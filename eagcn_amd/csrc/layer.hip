@@ -95,9 +95,15 @@ __device__ __forceinline__ void slab_sum16(const double* __restrict__ slab, int 
                                            double& s1, double& s2) {
     s1 = 0.0;
     s2 = 0.0;
-    for (int s = sl; s < nslab; s += 16) {
-        s1 += slab[((size_t)s * fp + cp) * 2 + 0];
-        s2 += slab[((size_t)s * fp + cp) * 2 + 1];
+    for (int s0 = sl; s0 < nslab; s0 += 16 * 8) {          // 8 slab pairs in flight per lane
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = s0 + 16 * u;
+            v[u] = s < nslab ? *reinterpret_cast<const double2*>(slab + ((size_t)s * fp + cp) * 2) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += v[u].x; s2 += v[u].y; }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
@@ -246,24 +252,39 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
         const float aw = a.colp[CP_AVEW * fp + cp];
         const int cu = weighted ? f : cp;           // column of the upstream gradient
         double s1 = 0.0, s2 = 0.0, dak = 0.0;
-        for (int r = blockIdx.x; r < T + a.nvirt; r += gridDim.x) {
-            float y, up, ds = 1.0f;
-            if (r < T) {
-                y = a.Y[(size_t)r * a.ldy + cp];
-                up = a.dxout[(size_t)r * a.ldo + cu];
-                if (!weighted) up *= a.bt.row_m[r];
-                if (a.do_drop) ds = drop_scale(seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
-            } else {                                  // all non-stored rows share one value: one virtual row
-                y = 0.0f;
-                up = a.dpad[(size_t)(r - T) * a.ldo + cu];
+        const int rows = T + a.nvirt;
+        // rows r = blockIdx.x + u*gridDim.x: RU of them per trip, loads issued together
+        constexpr int RU = 4;
+        for (int rb = blockIdx.x; rb < rows; rb += RU * gridDim.x) {
+            float yv[RU], upv[RU], dsv[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int r = rb + u * gridDim.x;
+                yv[u] = 0.0f; upv[u] = 0.0f; dsv[u] = 1.0f;
+                if (r < T) {
+                    yv[u] = a.Y[(size_t)r * a.ldy + cp];
+                    upv[u] = a.dxout[(size_t)r * a.ldo + cu];
+                    if (!weighted) upv[u] *= a.bt.row_m[r];
+                    if (a.do_drop) dsv[u] = drop_scale(seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
+                } else if (r < rows) {                 // the one virtual row standing for all non-stored rows
+                    upv[u] = a.dpad[(size_t)(r - T) * a.ldo + cu];
+                }
             }
-            const float h = y * sc + sh;
-            if (weighted) { dak += (double)(up * ds * fmaxf(h, 0.0f)); up *= aw; }
-            const float dh = h > 0.0f ? up * ds : 0.0f;
-            const float xh = (y - mu) * inv;
-            s1 += (double)dh;
-            s2 += (double)(dh * xh);
-            if (r < T) a.dH[(size_t)r * fp + cp] = dh;
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int r = rb + u * gridDim.x;
+                if (r >= rows) continue;
+                const float y = yv[u];
+                float up = upv[u];
+                const float ds = dsv[u];
+                const float h = y * sc + sh;
+                if (weighted) { dak += (double)(up * ds * fmaxf(h, 0.0f)); up *= aw; }
+                const float dh = h > 0.0f ? up * ds : 0.0f;
+                const float xh = (y - mu) * inv;
+                s1 += (double)dh;
+                s2 += (double)(dh * xh);
+                if (r < T) a.dH[(size_t)r * fp + cp] = dh;
+            }
         }
         a.slab[((size_t)blockIdx.x * fp + cp) * 2 + 0] = s1;
         a.slab[((size_t)blockIdx.x * fp + cp) * 2 + 1] = s2;
@@ -363,7 +384,16 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
     const int tot = vc.K * EDGE_SLAB;
     const int e = min(er, tot - 1);
     double t = 0.0;
-    for (int z = sl; z < nedge; z += 16) t += datt[(size_t)z * tot + e];
+    for (int z0 = sl; z0 < nedge; z0 += 16 * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int z = z0 + 16 * u;
+            v[u] = z < nedge ? datt[(size_t)z * tot + e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+    }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);
     if (er >= tot || sl != 0) return;

@@ -33,7 +33,15 @@ __global__ __launch_bounds__(256) void readout_fwd_kernel(eagcn_batch bt, const 
     const int cp = f < F ? exact_to_packed(m, f) : 0;
     float s = 0.0f;
     if (f < F)
-        for (int i = wave; i < n; i += 4) s += x[(size_t)(r0 + i) * ld + cp];
+        for (int i0 = wave; i0 < n; i0 += 16) {           // rows i0, i0+4, i0+8, i0+12 loaded together
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 4 * u;
+                v[u] = i < n ? x[(size_t)(r0 + i) * ld + cp] : 0.0f;
+            }
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
     part[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && f < F) {
