@@ -166,7 +166,7 @@ def main():
     model = build_model(cfg, args.dropout, dev, graph=not args.eager)
     model.train()
     model._debug_eager_cap = os.environ.get('EAGCN_EAGER_CAP', '0') == '1'
-    reducer = GradientAllReducer(model.parameters())
+    reducer = GradientAllReducer(model.parameters(), model=model)
     params = list(model.parameters())
 
     def step():

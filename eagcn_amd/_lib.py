@@ -45,7 +45,7 @@ class LayerParams(C.Structure):
 class LayerBufs(C.Structure):
     _fields_ = [('x', _fp), ('P', _fp), ('Y', _fp), ('rscale', _fp), ('bn', _fp), ('xout', _fp),
                 ('pad_row', _fp), ('scratch', _fp), ('scratch_bytes', C.c_size_t),
-                ('packed', _fp), ('packed_bytes', C.c_size_t)]
+                ('aux_stream', _fp), ('packed', _fp), ('packed_bytes', C.c_size_t)]
 
 
 class LayerGrads(C.Structure):
@@ -70,7 +70,7 @@ class HeadGrads(C.Structure):
 
 class Model(C.Structure):
     _fields_ = [('n_layers', C.c_int32), ('molfp_mode', C.c_int32), ('training', C.c_int32),
-                ('head_seed', C.c_uint64), ('head_seed_dev', _fp), ('input_packed', C.c_int32),
+                ('head_seed', C.c_uint64), ('head_seed_dev', _fp), ('input_packed', C.c_int32), ('aux_stream', _fp),
                 ('layer', LayerParams * 4), ('head', HeadParams)]
 
 

@@ -17,6 +17,21 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- event pool for fork/join between streams ------------------------------------------------------
+hipEvent_t pool_event() {
+    static std::vector<hipEvent_t> pool;
+    static size_t next = 0;
+    constexpr size_t kPool = 256;                 // far more than the forks of one step
+    if (pool.empty()) {
+        pool.resize(kPool, nullptr);
+        for (auto& e : pool)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; }
+    }
+    hipEvent_t e = pool[next % kPool];
+    ++next;
+    return e;
+}
+
 // ---- per-kernel-class timing ---------------------------------------------------------------------
 enum { PROF_NTAGS = 8 };
 static const char* kTagNames[PROF_NTAGS] = {"index", "pack", "gemm", "agg", "bn", "edge", "readout", "head"};

@@ -148,6 +148,17 @@ struct ProfScope {
     ~ProfScope() { if (on) prof_end(tag, s); }
 };
 
+// ---- fork / join between the main stream and an auxiliary stream (events from a small pool; the
+// record/wait pairs are legal inside stream capture and become graph dependencies) ---------------
+hipEvent_t pool_event();
+inline int stream_after(hipStream_t waiter, hipStream_t producer) {
+    hipEvent_t e = pool_event();
+    if (!e) return EAGCN_ERR_HIP;
+    if (hipEventRecord(e, producer) != hipSuccess) return EAGCN_ERR_HIP;
+    if (hipStreamWaitEvent(waiter, e, 0) != hipSuccess) return EAGCN_ERR_HIP;
+    return EAGCN_OK;
+}
+
 // ---- internal launchers (defined across the .hip files) -----------------------------------------
 struct GemmDesc {
     int ta, tb;            // 0: stored as used ([M][K] / [K][N]); 1: transposed storage

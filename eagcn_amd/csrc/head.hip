@@ -412,17 +412,23 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_backward: scratch too small");
     const eagcn_head_params* h = &m->head;
     const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
+    // weight-gradient products are off the critical path: they go to the auxiliary stream when there is one
+    hipStream_t side = m->aux_stream ? (hipStream_t)m->aux_stream : s;
+    const bool forked = side != s;
+    if (forked) RC(stream_after(side, s));
     // den3
-    RC(mm(s, 1, 0, n2, nc, B, sv.a2, n2, dout, nc, hg->d_den3_w, nc));
+    RC(mm(side, 1, 0, n2, nc, B, sv.a2, n2, dout, nc, hg->d_den3_w, nc));
     RC(mm(s, 0, 1, B, n2, nc, dout, nc, h->den3_w, nc, sc.da2, n2));
     RC(rowbn_bwd(s, B, n2, sc.da2, sv.h2, sv.bn_2, dgraph_rep, sc.dh2, hg->d_bn2_w, hg->d_bn2_b, m->training, 1, 0.0f, 0, nullptr));
     // den2
-    RC(mm(s, 1, 0, n1, n2, B, sv.a1, n1, sc.dh2, n2, hg->d_den2_w, n2));
+    if (forked) RC(stream_after(side, s));                       // dh2 is ready
+    RC(mm(side, 1, 0, n1, n2, B, sv.a1, n1, sc.dh2, n2, hg->d_den2_w, n2));
     RC(mm(s, 0, 1, B, n1, n2, sc.dh2, n2, h->den2_w, n2, sc.da1, n1));
     RC(rowbn_bwd(s, B, n1, sc.da1, sv.h1, sv.bn_1, nullptr, sc.dh1, hg->d_bn1_w, hg->d_bn1_b, m->training, 1, h->dropout,
                  m->head_seed, m->head_seed_dev));
     // den1
-    RC(mm(s, 1, 0, F, n1, B, sv.gn, F, sc.dh1, n1, hg->d_den1_w, n1));
+    if (forked) RC(stream_after(side, s));                       // dh1 is ready
+    RC(mm(side, 1, 0, F, n1, B, sv.gn, F, sc.dh1, n1, hg->d_den1_w, n1));
     RC(mm(s, 0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, sc.dgn, F));
     RC(rowbn_bwd(s, B, F, sc.dgn, sv.g, sv.bn_g, nullptr, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training, 0, 0.0f, 0, nullptr));
     // read-out
@@ -439,9 +445,11 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
         w.x = l == 0 ? sv.x0 : sv.L[l - 1].xout;
         w.P = L.P; w.Y = L.Y; w.rscale = L.rscale; w.bn = L.bn; w.xout = L.xout; w.pad_row = L.pad_row;
         w.scratch = sc.layer; w.scratch_bytes = sc.layer_bytes; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
+        w.aux_stream = m->aux_stream;
         const float* dpad = (weighted && l == m->n_layers - 1) ? sc.dpad : nullptr;
         RC(eagcn_layer_backward(b, &m->layer[l], &w, cur, dpad, l > 0 ? other : nullptr, &lg[l], stream));
         std::swap(cur, other);
     }
+    if (forked) RC(stream_after(s, side));                       // join: every gradient is complete on s
     return EAGCN_OK;
 }

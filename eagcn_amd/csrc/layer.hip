@@ -691,22 +691,28 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
         }
     }
     int nsplit = 0, nedge = 0;
+    // side = stream for work that is off the dX critical path (edge gradients, dW product, gradient
+    // unpacking); with no auxiliary stream everything stays in order on s
+    hipStream_t side = w->aux_stream ? (hipStream_t)w->aux_stream : s;
+    const bool forked = side != s;
     if (b->T > 0) {
         AggArgs a;
         a.bt = *b; a.vc = d.vc; a.src = sc.dY; a.lds = d.fp; a.dst = sc.dP; a.ldd = d.fp;
         a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = nullptr; a.nchunk = 1;
-        rc = launch_agg(a, true, s);
-        if (rc) return rc;
         EdgeArgs e;
         e.bt = *b; e.vc = d.vc; e.dY = sc.dY; e.Y = w->Y; e.P = w->P; e.ld = d.fp; e.sig = sc.sig;
         e.rsig = sc.rsig; e.rscale = w->rscale; e.datt = sc.datt;
-        rc = launch_edge_grad(e, s);
+        if (forked) { rc = stream_after(side, s); if (rc) return rc; }          // dY' is ready
+        rc = launch_edge_grad(e, side);
         if (rc) return rc;
         nedge = edge_grid_x(b);
+        rc = launch_agg(a, true, s);
+        if (rc) return rc;
+        if (forked) { rc = stream_after(side, s); if (rc) return rc; }          // dP is ready
         nsplit = d.nsplit;
         GemmDesc gw{1, 0, d.ld_in, d.fp, b->T, w->x, d.ld_in, sc.dP, d.fp, sc.dWcat, d.fp, nsplit, d.wslab, gemm_work};
         gw.K_dev = b->meta + EAGCN_META_T;
-        rc = launch_gemm(gw, s);
+        rc = launch_gemm(gw, side);
         if (rc) return rc;
         if (dx) {
             GemmDesc gx{0, 1, b->T, d.ld_in, d.fp, sc.dP, d.fp, sc.Wcat, d.fp, dx, d.ld_in, 1, 0, gemm_work};
@@ -715,12 +721,16 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
             if (rc) return rc;
         }
     }
-    ProfScope psu(PROF_PACK, s);
-    const int wblocks = cdiv((int)d.wslab, 256);
-    unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, s>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
-                                                                             nsplit, d.wslab, sc.datt, nedge, sc.rsig,
-                                                                             wblocks, b->meta);
-    EAGCN_LAUNCH_CHECK();
+    {
+        const int wblocks = cdiv((int)d.wslab, 256);
+        ProfScope psu(PROF_PACK, side);
+        unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, side>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
+                                                                                    nsplit, d.wslab, sc.datt, nedge, sc.rsig,
+                                                                                    wblocks, b->meta);
+        EAGCN_LAUNCH_CHECK();
+    }
+    // join: the caller reuses the scratch block (dY', dP, partial slabs) for the next layer
+    if (forked) { rc = stream_after(s, side); if (rc) return rc; }
     return EAGCN_OK;
 }
 

@@ -11,6 +11,7 @@ path; the input-validity counters of batch k are checked (and raised) when batch
 Static buffers are sized for ``row_cap`` packed rows (default B*N, which can never overflow).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -106,6 +107,12 @@ class GraphRunner:
             m.layer[l].seed_dev = sd + 8 * l
         m.head_seed_dev = sd + 8 * 4
         m.input_packed = 1
+        # optional fork of off-critical-path backward work onto a second stream (graph branches).
+        # Measured on MI355X at the Tox21 shape: replay got SLOWER (0.85 vs 0.77 ms/step), so off by default.
+        self.aux = None
+        if os.environ.get('EAGCN_AUX_STREAM', '0') == '1':
+            self.aux = torch.cuda.Stream(device=self.device)
+            m.aux_stream = self.aux.cuda_stream
         self.cm = m
         return m
 

@@ -200,6 +200,19 @@ class EAGCN(nn.Module):
                 atom_representations = atom_representations.cpu()
         return out, atom_representations, graph_representation
 
+    def flat_grad_buffer(self):
+        """The single fp32 buffer that holds every hot-path parameter gradient after a backward in
+        grad_mode='direct' or graph mode (``p.grad`` are views of it); None otherwise."""
+        if self.graph and self._runners:
+            for r in self._runners.values():
+                if r.plan.params and r.plan.params[0].grad is r.acc_views[0]:
+                    return r.flat_acc
+        if self._plan is not None and self._plan.flat_grad is not None:
+            g0 = self._plan.params[0].grad
+            if g0 is not None and g0.data_ptr() == self._plan.flat_grad.data_ptr():
+                return self._plan.flat_grad
+        return None
+
     def forward_composed(self, adjs, afms, *rels_and_size):
         """Same computation composed from the layer-level entry points (one autograd node per layer,
         head as separate ops); kept for tests that cross-check the model-level engine."""

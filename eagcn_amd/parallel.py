@@ -45,15 +45,34 @@ class GradientAllReducer:
     skipped; the set must be the same on all ranks, which holds because it is structural.
     """
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, model=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        self.model = model
         self._flat = None
+
+    def _model_flat_buffer(self):
+        """grad_mode='direct' / graph mode keep every hot-path gradient in ONE flat buffer that the
+        .grad tensors are views of: reduce it in place, no gather / scatter copies."""
+        fn = getattr(self.model, 'flat_grad_buffer', None)
+        flat = fn() if fn is not None else None
+        if flat is None:
+            return None
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        for p in self.params:
+            if p.grad is not None and not (lo <= p.grad.data_ptr() < hi):
+                return None                       # some gradient lives elsewhere: use the generic path
+        return flat
 
     def __call__(self):
         if not dist.is_initialized():
             return
         if dist.get_world_size(self.group) == 1 and os.environ.get('EAGCN_FORCE_DIST', '0') != '1':
+            return
+        flat = self._model_flat_buffer()
+        if flat is not None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(dist.get_world_size(self.group))
             return
         grads = [p.grad for p in self.params if p.grad is not None]
         if not grads:

@@ -130,6 +130,9 @@ typedef struct eagcn_layer_bufs {
     float* pad_row;                         /* [ld_out] value of every non-stored row of xout   */
     void* scratch;
     size_t scratch_bytes;
+    void* aux_stream;                       /* optional second hipStream_t: backward runs the edge  */
+                                            /* gradients and the dW product there, concurrently     */
+                                            /* with the dX chain (fork/join by events; capturable)  */
     void* packed;                           /* optional, eagcn_layer_packed_bytes(): forward keeps  */
     size_t packed_bytes;                    /* the re-laid parameters here and backward reuses them */
 } eagcn_layer_bufs;
@@ -212,6 +215,7 @@ typedef struct eagcn_model {
     uint64_t head_seed;                     /* dropout stream of the head (models.py:116)              */
     const uint64_t* head_seed_dev;          /* device-resident alternative (see eagcn_layer_params)    */
     int32_t input_packed;                   /* 1: saved already holds the packed input (eagcn_model_pack_input) */
+    void* aux_stream;                       /* optional second stream for off-critical-path backward work */
     eagcn_layer_params layer[4];            /* layer[l].in must equal the output layout of layer l-1   */
     eagcn_head_params head;
 } eagcn_model;
