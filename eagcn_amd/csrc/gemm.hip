@@ -43,12 +43,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     // extents that are known only on the device (packed row count); locals, never written back into
     // the by-value argument block (that would demote it to scratch memory)
     const int Mx = g.M_dev ? min(*g.M_dev, g.M) : g.M;
     const int Kx = g.K_dev ? min(*g.K_dev, g.K) : g.K;
-    if (m0 >= Mx && g.splits == 1) return;          // uniform: nothing to do for this tile
+    // XCD-aware tile order (workgroup b runs on XCD b % 8, each XCD has a private L2): every XCD gets a
+    // contiguous run of the REAL tiles (the grid may be sized for a row capacity), so the column tiles
+    // that share an A row panel hit the same L2.  Bijective for any tile count; affects speed only.
+    int tile_x, tile_y;
+    {
+        const int gx = gridDim.x;
+        const int nwg = gx * ((Mx + BM - 1) / BM);             // tiles that have rows
+        const int bid = blockIdx.y * gx + blockIdx.x;
+        if (bid >= nwg) return;                                // uniform: capacity-only workgroup
+        const int xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+        const int nid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+        tile_y = nid / gx;
+        tile_x = nid - tile_y * gx;
+    }
+    const int m0 = tile_y * BM, n0 = tile_x * BN;
     // split-K range
     const int z = blockIdx.z;
     const int kchunk = ((Kx + g.splits - 1) / g.splits + BK - 1) / BK * BK;
