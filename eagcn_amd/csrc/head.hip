@@ -38,24 +38,25 @@ __global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnFwd a) {
     const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
     const int cr = blockIdx.x * 16 + (threadIdx.x >> 4), rl = threadIdx.x & 15;
     const int c = min(cr, a.F - 1);
+    constexpr int CH = 16 * RB_CACHE;                 // rows per chunk (one batch of loads per lane)
     float v[RB_CACHE];
+    auto load_chunk = [&](int base) {
 #pragma unroll
-    for (int t = 0; t < RB_CACHE; ++t) {
-        const int r = rl + 16 * t;
-        v[t] = r < a.R ? a.x[(size_t)r * a.F + c] : 0.0f;
-    }
+        for (int t = 0; t < RB_CACHE; ++t) {
+            const int r = base + rl + 16 * t;
+            v[t] = r < a.R ? a.x[(size_t)r * a.F + c] : 0.0f;
+        }
+    };
     float mu, inv;
     if (a.training) {
         double s1 = 0.0, s2 = 0.0;
+        for (int base = 0; base < a.R; base += CH) {
+            load_chunk(base);
 #pragma unroll
-        for (int t = 0; t < RB_CACHE; ++t) {
-            s1 += (double)v[t];
-            s2 += (double)v[t] * (double)v[t];
-        }
-        for (int r = rl + 16 * RB_CACHE; r < a.R; r += 16) {
-            const double x = (double)a.x[(size_t)r * a.F + c];
-            s1 += x;
-            s2 += x * x;
+            for (int t = 0; t < RB_CACHE; ++t) {
+                s1 += (double)v[t];
+                s2 += (double)v[t] * (double)v[t];
+            }
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) {
@@ -84,18 +85,19 @@ __global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnFwd a) {
         a.bn[RB_MU * a.F + c] = mu;
         a.bn[RB_INV * a.F + c] = inv;
     }
-    auto emit = [&](int r, float x) {
-        float h = x * sc + sh;
-        if (a.relu) h = fmaxf(h, 0.0f);
-        if (a.do_drop) h *= drop_scale(seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
-        a.y[(size_t)r * a.F + c] = h;
-    };
+    for (int base = 0; base < a.R; base += CH) {
+        if (a.R > CH || !a.training) load_chunk(base);    // a single chunk is still in registers
 #pragma unroll
-    for (int t = 0; t < RB_CACHE; ++t) {
-        const int r = rl + 16 * t;
-        if (r < a.R) emit(r, v[t]);
+        for (int t = 0; t < RB_CACHE; ++t) {
+            const int r = base + rl + 16 * t;
+            if (r < a.R) {
+                float h = v[t] * sc + sh;
+                if (a.relu) h = fmaxf(h, 0.0f);
+                if (a.do_drop) h *= drop_scale(seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
+                a.y[(size_t)r * a.F + c] = h;
+            }
+        }
     }
-    for (int r = rl + 16 * RB_CACHE; r < a.R; r += 16) emit(r, a.x[(size_t)r * a.F + c]);
 }
 
 struct RowBnBwd {
@@ -113,32 +115,30 @@ __global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwd a) {
     const int c = min(cr, a.F - 1);
     const float sc = a.bn[RB_SC * a.F + c], sh = a.bn[RB_SH * a.F + c];
     const float mu = a.bn[RB_MU * a.F + c], inv = a.bn[RB_INV * a.F + c];
-    auto upstream = [&](int r, float xv, float dyv) {      // gradient that reaches the BatchNorm output
-        float dh = dyv;
-        if (a.do_drop) dh *= drop_scale(seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
-        if (a.relu && !(xv * sc + sh > 0.0f)) dh = 0.0f;
-        return dh;
-    };
+    constexpr int CH = 16 * RB_CACHE;
     float xv[RB_CACHE], dh[RB_CACHE];
+    auto load_chunk = [&](int base) {                  // x and the gradient that reaches the BatchNorm output
 #pragma unroll
-    for (int t = 0; t < RB_CACHE; ++t) {
-        const int r = rl + 16 * t;
-        xv[t] = r < a.R ? a.x[(size_t)r * a.F + c] : 0.0f;
-        dh[t] = r < a.R ? a.dy[(size_t)r * a.F + c] : 0.0f;
-    }
+        for (int t = 0; t < RB_CACHE; ++t) {
+            const int r = base + rl + 16 * t;
+            xv[t] = r < a.R ? a.x[(size_t)r * a.F + c] : 0.0f;
+            dh[t] = r < a.R ? a.dy[(size_t)r * a.F + c] : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < RB_CACHE; ++t) {
+            const int r = base + rl + 16 * t;
+            if (a.do_drop && r < a.R) dh[t] *= drop_scale(seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
+            if (a.relu && !(xv[t] * sc + sh > 0.0f)) dh[t] = 0.0f;
+        }
+    };
     double s1 = 0.0, s2 = 0.0;
+    for (int base = 0; base < a.R; base += CH) {
+        load_chunk(base);
 #pragma unroll
-    for (int t = 0; t < RB_CACHE; ++t) {
-        const int r = rl + 16 * t;
-        dh[t] = r < a.R ? upstream(r, xv[t], dh[t]) : 0.0f;
-        s1 += (double)dh[t];
-        s2 += (double)(dh[t] * ((xv[t] - mu) * inv));
-    }
-    for (int r = rl + 16 * RB_CACHE; r < a.R; r += 16) {
-        const float x = a.x[(size_t)r * a.F + c];
-        const float d = upstream(r, x, a.dy[(size_t)r * a.F + c]);
-        s1 += (double)d;
-        s2 += (double)(d * ((x - mu) * inv));
+        for (int t = 0; t < RB_CACHE; ++t) {
+            s1 += (double)dh[t];
+            s2 += (double)(dh[t] * ((xv[t] - mu) * inv));
+        }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
@@ -151,19 +151,17 @@ __global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwd a) {
         a.dbeta[c] = (float)s1;
     }
     const float c1 = a.training ? (float)(s1 / a.R) : 0.0f, c2 = a.training ? (float)(s2 / a.R) : 0.0f;
-    auto emit = [&](int r, float x, float d) {
-        float o = sc * (d - c1 - (x - mu) * inv * c2);
-        if (a.extra) o += a.extra[(size_t)r * a.F + c];
-        a.dx[(size_t)r * a.F + c] = o;
-    };
+    for (int base = 0; base < a.R; base += CH) {
+        if (a.R > CH) load_chunk(base);                    // a single chunk is still in registers
 #pragma unroll
-    for (int t = 0; t < RB_CACHE; ++t) {
-        const int r = rl + 16 * t;
-        if (r < a.R) emit(r, xv[t], dh[t]);
-    }
-    for (int r = rl + 16 * RB_CACHE; r < a.R; r += 16) {
-        const float x = a.x[(size_t)r * a.F + c];
-        emit(r, x, upstream(r, x, a.dy[(size_t)r * a.F + c]));
+        for (int t = 0; t < RB_CACHE; ++t) {
+            const int r = base + rl + 16 * t;
+            if (r < a.R) {
+                float o = sc * (dh[t] - c1 - (xv[t] - mu) * inv * c2);
+                if (a.extra) o += a.extra[(size_t)r * a.F + c];
+                a.dx[(size_t)r * a.F + c] = o;
+            }
+        }
     }
 }
 

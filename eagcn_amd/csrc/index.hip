@@ -21,9 +21,9 @@ struct RelPtrs {
     int c[EAGCN_MAX_VIEWS];
 };
 
-// one wavefront per padded row (b,i): B*N independent waves; the NIT = ceil(ldc/64) adjacency loads of
-// the row are issued together (memory-level parallelism: a rolled loop kept ONE 256-byte load in
-// flight per wave and ran at 0.5 TB/s), then codes are produced and stored.
+// one wavefront per padded row (b,i).  Every lane owns 4 consecutive columns per trip (NIT =
+// ceil(ldc/256) trips, all adjacency loads issued up front), so the codes of a view leave as ONE
+// coalesced 32-bit store per lane instead of four byte stores (ldc is a multiple of 16).
 template <int NIT>
 __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict__ adj, RelPtrs rel,
                                                           int B, int N, int K, int ldc,
@@ -37,37 +37,54 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
     const int b = (int)(row / N), i = (int)(row % N);
     const float* arow = adj + (size_t)row * N;
     const size_t plane = (size_t)N * N;
-    float a[NIT];
+    float a[NIT][4];
 #pragma unroll
-    for (int t = 0; t < NIT; ++t) {
-        const int j = lane + 64 * t;
-        a[t] = (j < N) ? arow[j] : 0.0f;
-    }
+    for (int t = 0; t < NIT; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = (lane + 64 * t) * 4 + u;
+            a[t][u] = (j < N) ? arow[j] : 0.0f;
+        }
     int deg = 0, bad_adj = 0, bad_rel = 0;
 #pragma unroll
     for (int t = 0; t < NIT; ++t) {
-        const int j = lane + 64 * t;
-        const bool bond = (a[t] != 0.0f);
-        if (bond && a[t] != 1.0f) ++bad_adj;
-        deg += bond ? 1 : 0;
-        for (int k = 0; k < K; ++k) {
-            int c = 0;
+        const int j0 = (lane + 64 * t) * 4;
+        uint32_t packed[EAGCN_MAX_VIEWS];
+#pragma unroll
+        for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) packed[k] = 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float av = a[t][u];
+            const bool bond = (av != 0.0f);
+            if (bond && av != 1.0f) ++bad_adj;
+            deg += bond ? 1 : 0;
             if (bond) {
-                const float* r = rel.p[k] + (size_t)b * rel.c[k] * plane + (size_t)i * N + j;
-                int ones = 0, other = 0, hot = 0;
-                // branch-free and unrolled: 8 independent strided loads in flight per lane
+                const int j = j0 + u;
+#pragma unroll
+                for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) {
+                    if (k < K) {
+                        const float* r = rel.p[k] + (size_t)b * rel.c[k] * plane + (size_t)i * N + j;
+                        int ones = 0, other = 0, hot = 0;
+                        // branch-free and unrolled: 8 independent strided loads in flight per lane
 #pragma unroll 8
-                for (int ch = 0; ch < rel.c[k]; ++ch) {
-                    const float v = r[(size_t)ch * plane];
-                    const bool one = (v == 1.0f);
-                    ones += one ? 1 : 0;
-                    hot = one ? ch : hot;
-                    other += (v != 0.0f && !one) ? 1 : 0;
+                        for (int ch = 0; ch < rel.c[k]; ++ch) {
+                            const float v = r[(size_t)ch * plane];
+                            const bool one = (v == 1.0f);
+                            ones += one ? 1 : 0;
+                            hot = one ? ch : hot;
+                            other += (v != 0.0f && !one) ? 1 : 0;
+                        }
+                        if (ones != 1 || other != 0) ++bad_rel;
+                        packed[k] |= (uint32_t)(hot + 1) << (8 * u);
+                    }
                 }
-                if (ones != 1 || other != 0) ++bad_rel;
-                c = hot + 1;
             }
-            if (j < ldc) code[(((size_t)k * B + b) * N + i) * ldc + j] = (uint8_t)c;
+        }
+        if (j0 < ldc) {
+#pragma unroll
+            for (int k = 0; k < EAGCN_MAX_VIEWS; ++k)
+                if (k < K)
+                    *reinterpret_cast<uint32_t*>(code + (((size_t)k * B + b) * N + i) * ldc + j0) = packed[k];
         }
     }
     deg = wave_sum(deg);
@@ -222,15 +239,14 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     EAGCN_HIP(hipMemsetAsync(b->nat, 0, (size_t)b->B * sizeof(int32_t), s));
     const long rows = (long)b->B * b->N;
     const unsigned sgrid = (unsigned)((rows + 3) / 4);
-    const int nit = cdiv(b->ldc, 64);
-    EAGCN_CHECK_ARG(nit <= 8, "eagcn_index_build: N=%d exceeds the supported 512 atoms", b->N);
+    const int nit = cdiv(b->ldc, 256);
+    EAGCN_CHECK_ARG(nit <= 4, "eagcn_index_build: N=%d exceeds the supported 1024 atoms", b->N);
 #define EAGCN_SCAN(NIT) index_scan_kernel<NIT><<<sgrid, 256, 0, s>>>(adj, rp, b->B, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->meta)
     switch (nit) {
         case 1: EAGCN_SCAN(1); break;
         case 2: EAGCN_SCAN(2); break;
         case 3: EAGCN_SCAN(3); break;
-        case 4: EAGCN_SCAN(4); break;
-        default: EAGCN_SCAN(8); break;
+        default: EAGCN_SCAN(4); break;
     }
 #undef EAGCN_SCAN
     EAGCN_LAUNCH_CHECK();
