@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
     const eagcn_batch& bt = a.bt;
     const int Tn = dev_rows(bt);
     if ((int)blockIdx.x * 16 >= Tn) return;                        // capacity-sized grid (slab not read either)
+    const int nwg = min((int)gridDim.x, (Tn + 15) / 16);           // workgroups that have rows
     const int k = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane >> 4, sl = lane & 15;
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
     __syncthreads();
     const int off = a.vc.off[k], fp = a.vc.off[k + 1] - a.vc.off[k];
     double dr_acc = 0.0;
-    const int r = (blockIdx.x * 4 + wave) * 4 + grp;
+    for (int rblk = blockIdx.x; rblk * 16 < Tn; rblk += nwg) {     // one trip unless the grid was capped
+    const int r = (rblk * 4 + wave) * 4 + grp;
     int4 info = make_int4(0, 0, 0, 0);
     float rs = 0.0f;
     if (r < Tn) {
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
             }
         }
     }
+    }   // rblk
     if (sl == 0) dr_s[wave * 4 + grp] = dr_acc;
     __syncthreads();
     // slab[blockIdx.x][k][0..255] = bond-type histogram, slab[..][k][256] = self term
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
 }
 
 // one workgroup per 16 packed rows; workgroups beyond the actual row count exit at once
-int edge_grid_x(const eagcn_batch* b) { return std::max(1, cdiv(b->T, 16)); }
+int edge_grid_x(const eagcn_batch* b) { return std::max(1, std::min(cdiv(b->T, 16), 1024)); }
 
 int launch_edge_grad(const EdgeArgs& a, hipStream_t s) {
     if (a.bt.T == 0) return EAGCN_OK;

@@ -18,6 +18,7 @@
 namespace eagcn {
 
 enum { RB_SC = 0, RB_SH, RB_MU, RB_INV };
+constexpr int HEAD_MAX_SPLITS = 16;   // split-K factor bound of the head's weight-gradient products
 
 struct RowBnFwd {
     int R, F;
@@ -30,20 +31,26 @@ struct RowBnFwd {
     uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
 };
 
-// 16 columns x 16 row-lanes per workgroup; each lane keeps up to RB_CACHE of its rows in registers so
-// the statistics pass and the normalisation pass share ONE set of loads, all issued back to back
-constexpr int RB_CACHE = 16;          // rows per lane kept in registers -> R <= 256 needs no second read
+// Row BatchNorm: a workgroup owns 16 columns and RL "row lanes" per column (thread = 16*row_lane + column,
+// so 16 adjacent lanes read 64 contiguous bytes of one row).  Every lane keeps RB_CACHE of its rows in
+// registers: the statistics pass and the normalisation pass share ONE batch of loads when R <= RL*RB_CACHE.
+// RL = 16 (256 threads) for small row counts, 64 (1024 threads) beyond 512 rows.
+constexpr int RB_CACHE = 16;
 
-__global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnFwd a) {
+template <int RL>
+__global__ __launch_bounds__(16 * RL) void rowbn_fwd_kernel(RowBnFwd a) {
+    __shared__ double red[RL / 4][16][2];
+    __shared__ float par[16][2];
     const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
-    const int cr = blockIdx.x * 16 + (threadIdx.x >> 4), rl = threadIdx.x & 15;
+    const int col_l = threadIdx.x & 15, rl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    const int cr = blockIdx.x * 16 + col_l;
     const int c = min(cr, a.F - 1);
-    constexpr int CH = 16 * RB_CACHE;                 // rows per chunk (one batch of loads per lane)
+    constexpr int CH = RL * RB_CACHE;                 // rows per chunk (one batch of loads per lane)
     float v[RB_CACHE];
     auto load_chunk = [&](int base) {
 #pragma unroll
         for (int t = 0; t < RB_CACHE; ++t) {
-            const int r = base + rl + 16 * t;
+            const int r = base + rl + RL * t;
             v[t] = r < a.R ? a.x[(size_t)r * a.F + c] : 0.0f;
         }
     };
@@ -58,21 +65,28 @@ __global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnFwd a) {
                 s2 += (double)v[t] * (double)v[t];
             }
         }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if ((threadIdx.x & 63) < 16) { red[wave][col_l][0] = s1; red[wave][col_l][1] = s2; }
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            s1 += __shfl_xor(s1, o);
-            s2 += __shfl_xor(s2, o);
+            for (int w = 0; w < RL / 4; ++w) { t1 += red[w][col_l][0]; t2 += red[w][col_l][1]; }
+            const double mean = t1 / a.R;
+            double var = t2 / a.R - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            par[col_l][0] = (float)mean;
+            par[col_l][1] = (float)(1.0 / sqrt(var + (double)a.eps));
+            if (cr < a.F) {
+                const double unbiased = var * ((double)a.R / ((double)a.R - 1.0));
+                a.run_mean[c] = (float)((1.0 - a.momentum) * (double)a.run_mean[c] + a.momentum * mean);
+                a.run_var[c] = (float)((1.0 - a.momentum) * (double)a.run_var[c] + a.momentum * unbiased);
+            }
         }
-        const double mean = s1 / a.R;
-        double var = s2 / a.R - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        mu = (float)mean;
-        inv = (float)(1.0 / sqrt(var + (double)a.eps));
-        if (rl == 0 && cr < a.F) {
-            const double unbiased = var * ((double)a.R / ((double)a.R - 1.0));
-            a.run_mean[c] = (float)((1.0 - a.momentum) * (double)a.run_mean[c] + a.momentum * mean);
-            a.run_var[c] = (float)((1.0 - a.momentum) * (double)a.run_var[c] + a.momentum * unbiased);
-        }
+        __syncthreads();
+        mu = par[col_l][0];
+        inv = par[col_l][1];
     } else {
         mu = a.run_mean[c];
         inv = 1.0f / sqrtf(a.run_var[c] + a.eps);
@@ -89,7 +103,7 @@ __global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnFwd a) {
         if (a.R > CH || !a.training) load_chunk(base);    // a single chunk is still in registers
 #pragma unroll
         for (int t = 0; t < RB_CACHE; ++t) {
-            const int r = base + rl + 16 * t;
+            const int r = base + rl + RL * t;
             if (r < a.R) {
                 float h = v[t] * sc + sh;
                 if (a.relu) h = fmaxf(h, 0.0f);
@@ -109,24 +123,28 @@ struct RowBnBwd {
     uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
 };
 
-__global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwd a) {
+template <int RL>
+__global__ __launch_bounds__(16 * RL) void rowbn_bwd_kernel(RowBnBwd a) {
+    __shared__ double red[RL / 4][16][2];
+    __shared__ double tot[16][2];
     const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
-    const int cr = blockIdx.x * 16 + (threadIdx.x >> 4), rl = threadIdx.x & 15;
+    const int col_l = threadIdx.x & 15, rl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    const int cr = blockIdx.x * 16 + col_l;
     const int c = min(cr, a.F - 1);
     const float sc = a.bn[RB_SC * a.F + c], sh = a.bn[RB_SH * a.F + c];
     const float mu = a.bn[RB_MU * a.F + c], inv = a.bn[RB_INV * a.F + c];
-    constexpr int CH = 16 * RB_CACHE;
+    constexpr int CH = RL * RB_CACHE;
     float xv[RB_CACHE], dh[RB_CACHE];
     auto load_chunk = [&](int base) {                  // x and the gradient that reaches the BatchNorm output
 #pragma unroll
         for (int t = 0; t < RB_CACHE; ++t) {
-            const int r = base + rl + 16 * t;
+            const int r = base + rl + RL * t;
             xv[t] = r < a.R ? a.x[(size_t)r * a.F + c] : 0.0f;
             dh[t] = r < a.R ? a.dy[(size_t)r * a.F + c] : 0.0f;
         }
 #pragma unroll
         for (int t = 0; t < RB_CACHE; ++t) {
-            const int r = base + rl + 16 * t;
+            const int r = base + rl + RL * t;
             if (a.do_drop && r < a.R) dh[t] *= drop_scale(seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
             if (a.relu && !(xv[t] * sc + sh > 0.0f)) dh[t] = 0.0f;
         }
@@ -140,28 +158,51 @@ __global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwd a) {
             s2 += (double)(dh[t] * ((xv[t] - mu) * inv));
         }
     }
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if ((threadIdx.x & 63) < 16) { red[wave][col_l][0] = s1; red[wave][col_l][1] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o);
-        s2 += __shfl_xor(s2, o);
+        for (int w = 0; w < RL / 4; ++w) { t1 += red[w][col_l][0]; t2 += red[w][col_l][1]; }
+        tot[col_l][0] = t1;
+        tot[col_l][1] = t2;
+        if (cr < a.F) {
+            a.dgamma[c] = (float)t2;
+            a.dbeta[c] = (float)t1;
+        }
     }
+    __syncthreads();
     if (cr >= a.F) return;
-    if (rl == 0) {
-        a.dgamma[c] = (float)s2;
-        a.dbeta[c] = (float)s1;
-    }
-    const float c1 = a.training ? (float)(s1 / a.R) : 0.0f, c2 = a.training ? (float)(s2 / a.R) : 0.0f;
+    const float c1 = a.training ? (float)(tot[col_l][0] / a.R) : 0.0f;
+    const float c2 = a.training ? (float)(tot[col_l][1] / a.R) : 0.0f;
     for (int base = 0; base < a.R; base += CH) {
         if (a.R > CH) load_chunk(base);                    // a single chunk is still in registers
 #pragma unroll
         for (int t = 0; t < RB_CACHE; ++t) {
-            const int r = base + rl + 16 * t;
+            const int r = base + rl + RL * t;
             if (r < a.R) {
                 float o = sc * (dh[t] - c1 - (xv[t] - mu) * inv * c2);
                 if (a.extra) o += a.extra[(size_t)r * a.F + c];
                 a.dx[(size_t)r * a.F + c] = o;
             }
         }
+    }
+}
+
+// C[i] = sum_z slab[z][i]  (split-K partials of the head's weight-gradient products)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int n, int splits,
+                                                             float* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float s0 = 0.0f, s1 = 0.0f;
+        int z = 0;
+        for (; z + 2 <= splits; z += 2) {
+            s0 += slab[(size_t)z * n + i];
+            s1 += slab[(size_t)(z + 1) * n + i];
+        }
+        if (z < splits) s0 += slab[(size_t)z * n + i];
+        out[i] = s0 + s1;
     }
 }
 
@@ -224,7 +265,7 @@ static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m
 }
 
 struct ModelScratch {
-    float *da2, *dh2, *da1, *dh1, *dgn, *dg, *dxa, *dxb, *dpad;
+    float *da2, *dh2, *da1, *dh1, *dgn, *dg, *dxa, *dxb, *dpad, *gsplit;
     void* layer; size_t layer_bytes;
 };
 static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model* m, ModelScratch* out) {
@@ -238,6 +279,7 @@ static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model*
     s.dh1 = c.take<float>(B * h->n_den1);
     s.dgn = c.take<float>(B * h->f_in);
     s.dg = c.take<float>(B * h->f_in);
+    s.gsplit = c.take<float>((size_t)HEAD_MAX_SPLITS * std::max((size_t)h->f_in * h->n_den1, (size_t)h->n_den1 * h->n_den2));
     int ldmax = 0;
     size_t lbytes = 0;
     for (int l = 0; l < m->n_layers; ++l) {
@@ -298,7 +340,8 @@ static int rowbn_fwd(hipStream_t s, int R, int F, const float* x, float* y, cons
     a.training = training; a.relu = relu; a.eps = eps; a.momentum = mom; a.seed = seed; a.seed_dev = seed_dev;
     fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
     ProfScope ps(PROF_HEAD, s);
-    rowbn_fwd_kernel<<<cdiv(F, 16), 256, 0, s>>>(a);
+    if (R > 512) rowbn_fwd_kernel<64><<<cdiv(F, 16), 1024, 0, s>>>(a);
+    else rowbn_fwd_kernel<16><<<cdiv(F, 16), 256, 0, s>>>(a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
@@ -310,7 +353,8 @@ static int rowbn_bwd(hipStream_t s, int R, int F, const float* dy, const float* 
     a.training = training; a.relu = relu; a.seed = seed; a.seed_dev = seed_dev;
     fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
     ProfScope ps(PROF_HEAD, s);
-    rowbn_bwd_kernel<<<cdiv(F, 16), 256, 0, s>>>(a);
+    if (R > 512) rowbn_bwd_kernel<64><<<cdiv(F, 16), 1024, 0, s>>>(a);
+    else rowbn_bwd_kernel<16><<<cdiv(F, 16), 256, 0, s>>>(a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
@@ -319,6 +363,26 @@ static int mm(hipStream_t s, int ta, int tb, int M, int N, int K, const float* A
     GemmDesc g{ta, tb, M, N, K, A, lda, B, ldb, C, ldc, 1, 0};
     g.prof_tag = PROF_HEAD;
     return launch_gemm(g, s);
+}
+
+// dW = A^T.dY with K = B rows: few output tiles and a long K -> split K over workgroups, then reduce
+static int head_splits(int M, int N, int K) {
+    const int tiles = cdiv(M, 64) * cdiv(N, 64);
+    if (tiles >= 128 || K < 512) return 1;
+    return std::max(1, std::min(std::min(HEAD_MAX_SPLITS, K / 256), 256 / std::max(tiles, 1)));
+}
+static int mm_dw(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                 float* slab) {
+    const int splits = head_splits(M, N, K);
+    if (splits == 1 || (M * N) % 4 != 0 || (lda % 4) || (ldb % 4) || (N % 4)) return mm(s, 1, 0, M, N, K, A, lda, B, ldb, C, N);
+    GemmDesc g{1, 0, M, N, K, A, lda, B, ldb, slab, N, splits, (size_t)M * N};
+    g.prof_tag = PROF_HEAD;
+    int rc = launch_gemm(g, s);
+    if (rc) return rc;
+    ProfScope ps(PROF_HEAD, s);
+    splitk_reduce_kernel<<<std::min(cdiv(M * N, 256), 1024), 256, 0, s>>>(slab, M * N, splits, C);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
 }
 
 }  // namespace eagcn
@@ -415,18 +479,18 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
     const bool forked = side != s;
     if (forked) RC(stream_after(side, s));
     // den3
-    RC(mm(side, 1, 0, n2, nc, B, sv.a2, n2, dout, nc, hg->d_den3_w, nc));
+    RC(mm_dw(side, n2, nc, B, sv.a2, n2, dout, nc, hg->d_den3_w, sc.gsplit));
     RC(mm(s, 0, 1, B, n2, nc, dout, nc, h->den3_w, nc, sc.da2, n2));
     RC(rowbn_bwd(s, B, n2, sc.da2, sv.h2, sv.bn_2, dgraph_rep, sc.dh2, hg->d_bn2_w, hg->d_bn2_b, m->training, 1, 0.0f, 0, nullptr));
     // den2
     if (forked) RC(stream_after(side, s));                       // dh2 is ready
-    RC(mm(side, 1, 0, n1, n2, B, sv.a1, n1, sc.dh2, n2, hg->d_den2_w, n2));
+    RC(mm_dw(side, n1, n2, B, sv.a1, n1, sc.dh2, n2, hg->d_den2_w, sc.gsplit));
     RC(mm(s, 0, 1, B, n1, n2, sc.dh2, n2, h->den2_w, n2, sc.da1, n1));
     RC(rowbn_bwd(s, B, n1, sc.da1, sv.h1, sv.bn_1, nullptr, sc.dh1, hg->d_bn1_w, hg->d_bn1_b, m->training, 1, h->dropout,
                  m->head_seed, m->head_seed_dev));
     // den1
     if (forked) RC(stream_after(side, s));                       // dh1 is ready
-    RC(mm(side, 1, 0, F, n1, B, sv.gn, F, sc.dh1, n1, hg->d_den1_w, n1));
+    RC(mm_dw(side, F, n1, B, sv.gn, F, sc.dh1, n1, hg->d_den1_w, sc.gsplit));
     RC(mm(s, 0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, sc.dgn, F));
     RC(rowbn_bwd(s, B, F, sc.dgn, sv.g, sv.bn_g, nullptr, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training, 0, 0.0f, 0, nullptr));
     // read-out

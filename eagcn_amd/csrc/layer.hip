@@ -445,7 +445,13 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     d.fin = layout_width(&p->in);
     d.ldo = p->structure == EAGCN_STRUCT_CONCATE ? d.fp : pad16(p->width[0]);
     d.gx = agg_grid_x(b);
-    d.gxb = std::max(1, std::min(b->T + 1, 512));
+    // row-partial slabs of the BatchNorm backward: 8 rows per workgroup, at most 2048 workgroups and at most
+    // 32 MB of fp64 partials (wide layers: Fp = 6320 -> 331 workgroups)
+    {
+        const long by_rows = cdiv(b->T + 1, 8);
+        const long by_bytes = std::max<long>(64, (32L << 20) / ((long)d.fp * 16));
+        d.gxb = (int)std::max<long>(1, std::min<long>(std::min<long>(by_rows, 2048), by_bytes));
+    }
     const int tiles = cdiv(d.ld_in, 64) * cdiv(d.fp, 64);
     d.nsplit = std::max(1, std::min(std::max(1, 1024 / tiles), cdiv(std::max(b->T, 1), 128)));
     d.wslab = (size_t)d.ld_in * d.fp;
