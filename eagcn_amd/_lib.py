@@ -25,7 +25,7 @@ class Batch(C.Structure):
                 ('channels', C.c_int32 * MAX_VIEWS),
                 ('code', _fp), ('deg_bn', _fp), ('nat', _fp), ('row0', _fp), ('tile0', _fp),
                 ('meta', _fp), ('row_mol', _fp), ('row_loc', _fp), ('row_m', _fp), ('row_deg', _fp),
-                ('tile_mol', _fp), ('row_info', _fp)]
+                ('tile_mol', _fp), ('row_info', _fp), ('tile_info', _fp)]
 
 
 class Layout(C.Structure):

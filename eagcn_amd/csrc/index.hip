@@ -173,7 +173,10 @@ __global__ __launch_bounds__(256) void index_rows_kernel(eagcn_batch bt) {
         bt.row_m[r0 + i] = d > 0 ? 1.0f : 0.0f;
         reinterpret_cast<int4*>(bt.row_info)[r0 + i] = make_int4(b, i, n, r0);
     }
-    for (int t = threadIdx.x; t < (n + 15) / 16; t += blockDim.x) bt.tile_mol[t0 + t] = b;
+    for (int t = threadIdx.x; t < (n + 15) / 16; t += blockDim.x) {
+        bt.tile_mol[t0 + t] = b;
+        reinterpret_cast<int4*>(bt.tile_info)[t0 + t] = make_int4(b, t, n, r0);
+    }
 }
 
 // dense [B][N][F] -> packed [T][ld]; columns are re-grouped into the padded segments of `lay`
@@ -277,7 +280,7 @@ extern "C" int eagcn_index_rows(const eagcn_batch* b, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     EAGCN_CHECK_ARG(b, "eagcn_index_rows: null batch");
     if (b->T == 0) return EAGCN_OK;
-    EAGCN_CHECK_ARG(b->row_mol && b->row_loc && b->row_m && b->row_deg && b->tile_mol && b->row_info,
+    EAGCN_CHECK_ARG(b->row_mol && b->row_loc && b->row_m && b->row_deg && b->tile_mol && b->row_info && b->tile_info,
                     "eagcn_index_rows: per-row buffers not allocated");
     ProfScope ps(PROF_INDEX, s);
     index_rows_kernel<<<b->B, 256, 0, s>>>(*b);

@@ -16,6 +16,7 @@ struct AggArgs {
     int nchunk;
 };
 int agg_grid_x(const eagcn_batch* b);
+bool agg_ksplit(const eagcn_batch* b);
 int launch_agg(AggArgs a, bool trans, hipStream_t s);
 
 struct EdgeArgs {

@@ -118,9 +118,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                            double M, int training, float eps, float momentum,
                                                            const float* __restrict__ colp, ParamPtrs pp,
                                                            ViewCols vc, float* __restrict__ bn,
-                                                           const int32_t* __restrict__ meta) {
+                                                           const int32_t* __restrict__ meta, int tiles_per_wg) {
     // aggregation workgroups beyond the actual tile count exit without writing their slab
-    nslab = min(nslab, (meta[EAGCN_META_NTILES] + 3) / 4);
+    nslab = min(nslab, (meta[EAGCN_META_NTILES] + tiles_per_wg - 1) / tiles_per_wg);
     const int cpr = blockIdx.x * 16 + (threadIdx.x >> 4), sl = threadIdx.x & 15;
     const int cp = min(cpr, fp - 1);
     double s1 = 0.0, s2 = 0.0;
@@ -612,7 +612,7 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
     const double M = (double)b->B * (double)b->N;
     ProfScope psbn(PROF_BN, s);
     bn_finalize_kernel<<<cdiv(d.fp, 16), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
-                                                        p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta);
+                                                        p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, agg_ksplit(b) ? 1 : 4);
     EAGCN_LAUNCH_CHECK();
     ApplyArgs aa;
     aa.bt = *b; aa.vc = d.vc; aa.structure = p->structure; aa.fp = d.fp; aa.Y = w->Y; aa.ldy = d.fp;

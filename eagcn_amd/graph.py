@@ -35,7 +35,7 @@ class StaticIndex:
         i32 = dict(dtype=torch.int32, device=device)
         self.code = torch.empty((K, B, N, self.ldc), dtype=torch.uint8, device=device)
         blob = torch.zeros(B * N + 3 * B + 2 + L.META_WORDS, **i32)
-        rows = torch.zeros(8 * self.T + self.n_tiles, **i32)
+        rows = torch.zeros(8 * self.T + 5 * self.n_tiles, **i32)
         self._blob, self._rows = blob, rows
         o = B * N
         self.nat = blob[o:o + B]
@@ -49,8 +49,9 @@ class StaticIndex:
         c.row0, c.tile0 = base + 4 * (B * N + B), base + 4 * (B * N + 2 * B + 1)
         c.meta = base + 4 * (B * N + 3 * B + 2)
         rb, T = rows.data_ptr(), self.T
-        c.row_info = rb
-        c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = rb + 16 * T, rb + 20 * T, rb + 24 * T, rb + 28 * T, rb + 32 * T
+        c.row_info, c.tile_info = rb, rb + 16 * T
+        ob = rb + 16 * T + 16 * self.n_tiles
+        c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = ob, ob + 4 * T, ob + 8 * T, ob + 12 * T, ob + 16 * T
         self.c = c
 
     def ref(self):

@@ -150,17 +150,19 @@ class BatchIndex:
             self.n_tiles = B * ((N + 15) // 16)
         T = self.T
         main.wait_stream(side)            # everything below (and every consumer) runs on `main`
-        # [row_info 4T (16-byte aligned first) | row_mol | row_loc | row_deg | row_m(f32) | tile_mol]
-        rows = torch.empty(8 * T + self.n_tiles, **i32)
-        self.row_mol, self.row_loc, self.row_deg = rows[4 * T:5 * T], rows[5 * T:6 * T], rows[6 * T:7 * T]
-        self.row_m = rows[7 * T:8 * T].view(torch.float32)
-        self.tile_mol = rows[8 * T:]
+        # [row_info 4T | tile_info 4*n_tiles (both 16-byte aligned) | row_mol | row_loc | row_deg | row_m(f32) | tile_mol]
+        nt = self.n_tiles
+        rows = torch.empty(8 * T + 5 * nt, **i32)
+        o = 4 * T + 4 * nt
+        self.row_mol, self.row_loc, self.row_deg = rows[o:o + T], rows[o + T:o + 2 * T], rows[o + 2 * T:o + 3 * T]
+        self.row_m = rows[o + 3 * T:o + 4 * T].view(torch.float32)
+        self.tile_mol = rows[o + 4 * T:]
         self._rows = rows
         c.T, c.n_max, c.n_tiles = T, self.n_max, self.n_tiles
         rb = rows.data_ptr()
-        c.row_info = rb
-        c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = (rb + 16 * T, rb + 20 * T, rb + 24 * T, rb + 28 * T,
-                                                                rb + 32 * T)
+        c.row_info, c.tile_info = rb, rb + 16 * T
+        ob = rb + 4 * o
+        c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = ob, ob + 4 * T, ob + 8 * T, ob + 12 * T, ob + 16 * T
         L.check(lib.eagcn_index_rows(C.byref(c), C.c_void_p(main.cuda_stream)), 'eagcn_index_rows')
         for t in (self.code, blob):
             t.record_stream(main)         # allocated on `side`, consumed on `main`

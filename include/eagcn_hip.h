@@ -88,6 +88,7 @@ typedef struct eagcn_batch {
     int32_t* tile_mol;                      /* [n_tiles]                                        */
     int32_t* row_info;                      /* [T][4] {molecule, atom, nat[mol], row0[mol]}: one
                                                16-byte load instead of a two-hop lookup          */
+    int32_t* tile_info;                     /* [n_tiles][4] {molecule, row tile, nat[mol], row0[mol]} */
 } eagcn_batch;
 
 /* column layout of a packed activation matrix */
