@@ -70,6 +70,21 @@ def algorithmic_flops(cfg, sizes):
     return 3.0 * total
 
 
+def committed_traffic():
+    """HBM-side bytes per launch of the layer GEMMs from the committed PMC passes of this command
+    (tools/pmc_traffic.py -> profiles/r01_pmc_traffic.json; rocprofv3 cannot run inside bench.py)."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None, None
+    big = [v for k, v in table.items() if 'gemm_f32_kernel' in k and '>=256 workgroups' in k]
+    n = sum(v['launches'] for v in big)
+    if not n:
+        return None, None
+    return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in big) / n, 'profiles/r01_pmc_traffic.json'
+
+
 def cpu_baseline(cfg, mb, dropout, bce_w, steps=5, warmup=2):
     """The CPU oracle (oracle/eagcn_ref.py, kind 'port') timed on this host, same workload."""
     from oracle.eagcn_ref import RefEAGCN, classification_loss, regression_loss, weights_init_
@@ -233,6 +248,7 @@ def main():
         value = world * B * args.steps / elapsed
         g_ms, g_work, g_n = kern['gemm']
         achieved = (g_work / (g_ms * 1e-3)) / 1e12 if g_ms > 0 else 0.0
+        traffic, traffic_src = committed_traffic() if args.workload == 'tox21_c2' and B == 256 else (None, None)
         out = {
             'metric': 'molecules/sec fwd+bwd, 2-layer 5-view EAGCN, Tox21 batch' if args.workload == 'tox21_c2'
                       else 'molecules/sec fwd+bwd, EAGCN %s' % args.workload,
@@ -249,7 +265,11 @@ def main():
             'algorithmic_gflop_per_step': round(algorithmic_flops(cfg, mb.sizes) / 1e9, 3),
             'roofline': {'kernel': 'gemm_f32_kernel (flat X.[W_1..W_K] transform + its two backward products)',
                          'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'traffic': None if traffic is None else round(traffic),
+                         'traffic_note': None if traffic is None else
+                         'bytes per launch of the layer-2 GEMMs (>=256 workgroups), memory-side FETCH_SIZE x2 + WRITE_SIZE '
+                         'from %s; algorithmic operand bytes are 22-29 MB' % traffic_src,
                          'launches': int(g_n), 'avg_launch_us': round(g_ms * 1e3 / max(g_n, 1), 3),
                          'measured': 'HIP events on the launch stream, %s' % ('inside the timed region' if profile_in_loop else
                                      '%d eager steps of the same workload right after the timed graph-replay region' % prof_steps)},

@@ -50,20 +50,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
     // XCD-aware tile order (workgroup b runs on XCD b % 8, each XCD has a private L2): every XCD gets a
     // contiguous run of the REAL tiles (the grid may be sized for a row capacity), so the column tiles
     // that share an A row panel hit the same L2.  Bijective for any tile count; affects speed only.
-    int tile_x, tile_y;
+    int tile_x, tile_y, z;
     {
         const int gx = gridDim.x;
-        const int nwg = gx * ((Mx + BM - 1) / BM);             // tiles that have rows
-        const int bid = blockIdx.y * gx + blockIdx.x;
-        if (bid >= nwg) return;                                // uniform: capacity-only workgroup
-        const int xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
-        const int nid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
-        tile_y = nid / gx;
-        tile_x = nid - tile_y * gx;
+        const int per_z = gx * ((Mx + BM - 1) / BM);           // tiles that have rows, per split
+        const int nwg = per_z * g.splits;
+        const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
+        if (blockIdx.y * gx + blockIdx.x >= per_z) return;     // uniform: capacity-only workgroup
+        // linear dispatch index of the REAL workgroups (capacity-only ones were skipped above)
+        const int lin = blockIdx.z * per_z + blockIdx.y * gx + blockIdx.x;
+        (void)bid;
+        const int xcd = lin & 7, qn = nwg >> 3, rn = nwg & 7;
+        const int nid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lin >> 3);
+        z = nid / per_z;                                       // all tiles of one K-split land on one or two XCDs
+        const int rem = nid - z * per_z;
+        tile_y = rem / gx;
+        tile_x = rem - tile_y * gx;
     }
     const int m0 = tile_y * BM, n0 = tile_x * BN;
     // split-K range
-    const int z = blockIdx.z;
     const int kchunk = ((Kx + g.splits - 1) / g.splits + BK - 1) / BK * BK;
     const int kbeg = z * kchunk;
     const int kend = min(Kx, kbeg + kchunk);
