@@ -136,3 +136,21 @@ def test_algorithmic_flops_match_survey_table():
     per_mol = bench.algorithmic_flops(cfg, [132]) / 1e6
     assert abs(per_mol - 315) < 5, per_mol                      # 315 MF at n = 132
     assert abs(bench.algorithmic_flops(cfg, [53]) / 1e6 - 106) < 3
+
+
+def test_compat_modules_expose_reference_names():
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'compat'))
+    try:
+        for n in ('models', 'layers'):
+            sys.modules.pop(n, None)
+        models = importlib.import_module('models')
+        layers = importlib.import_module('layers')
+        assert models.EAGCN.__module__ == 'eagcn_amd.models'
+        for name in ('GraphConv_Layer', 'GraphConv_block', 'GraphConv_base', 'AFM_BatchNorm', 'Ave_multi_view', 'Dense'):
+            assert hasattr(layers, name)
+    finally:
+        sys.path.remove(os.path.join(ROOT, 'compat'))
+        sys.modules.pop('models', None)
+        sys.modules.pop('layers', None)
