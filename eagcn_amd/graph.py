@@ -9,6 +9,11 @@ kernels (adj / relation tensors) and the packing of ``afms``.  There is no host 
 path; the input-validity counters of batch k are checked (and raised) when batch k+2 is submitted.
 
 Static buffers are sized for ``row_cap`` packed rows (default B*N, which can never overflow).
+
+The static index is double-buffered (two slots, one captured graph pair each): with ``overlap=True``
+(inputs already resident in HBM) the index kernels of batch k+1 run on a side stream while the GPU is
+still executing the backward of batch k; they only have to wait for the backward of batch k-1, the
+previous user of their slot.
 """
 import ctypes as C
 import os
@@ -16,7 +21,7 @@ import os
 import torch
 
 from . import _lib as L
-from .ops import _ptr, _stream
+from .ops import _index_stream, _ptr, _stream
 
 _RING = 4
 
@@ -65,7 +70,10 @@ class GraphRunner:
         lib = L.load()
         self.plan, self.device = plan, device
         self.key = (B, N, tuple(channels))
-        self.index = StaticIndex(B, N, channels, device, row_cap if row_cap else B * N)
+        self.slots = [StaticIndex(B, N, channels, device, row_cap if row_cap else B * N) for _ in range(2)]
+        self.index = self.slots[0]
+        self.graphs = [[None, None], [None, None]]            # per slot: [forward graph, backward graph]
+        self.entry_events = [None, None]                      # main-stream position at the last two forward entries
         self.dropout = float(dropout)
         self.seeds_dev = torch.zeros(8, dtype=torch.int64, device=device)
         self.seeds_host = torch.zeros(8, dtype=torch.int64).pin_memory()
@@ -97,7 +105,6 @@ class GraphRunner:
         T = self.index.T
         self.xout_view = self.saved[xo.value:xo.value + 4 * T * ld.value].view(torch.float32).view(T, ld.value)
         self.pad_view = self.saved[po.value:po.value + 4 * ld.value].view(torch.float32)
-        self.fwd_graph = self.bwd_graph = None
         self.ptrs = [t.data_ptr() for t in plan._ptr_tensors]
 
     # -- C descriptors -------------------------------------------------------------------------------
@@ -163,12 +170,13 @@ class GraphRunner:
         lib = L.load()
         lib.eagcn_prof_enable(0)
         torch.cuda.synchronize(self.device)
-        self.fwd_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.fwd_graph):
+        fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(fwd):
             self._call_forward()
-        self.bwd_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.bwd_graph):
+        bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(bwd):
             self._call_backward()
+        self.graphs[self.cur] = [fwd, bwd]
 
     # -- per-step entry points -----------------------------------------------------------------------
     def _check_old_batches(self, force=False):
@@ -189,21 +197,41 @@ class GraphRunner:
                 raise L.EagcnHipError('a previous batch packed %d rows, more than row_cap=%d'
                                       % (meta[L.META_T], self.index.T))
 
-    def forward(self, adj, rels, afm, size, seed):
+    def forward(self, adj, rels, afm, size, seed, overlap=False):
         lib = L.load()
         self._check_old_batches()
-        idx = self.index
-        stream = _stream()
+        self.cur = self.step % 2
+        idx = self.index = self.slots[self.cur]
+        main = torch.cuda.current_stream(self.device)
         slot = self.step % _RING
         if self.meta_event[slot] is not None:                 # ring wrapped: this slot must be consumed first
             self._check_old_batches(force=True)
         rel_ptrs = (C.c_void_p * idx.K)(*[r.data_ptr() for r in rels])
+        # main-stream position now = after the backward of the previous step; the position recorded at the
+        # PREVIOUS forward entry = after the backward of the step before it, the last user of this index slot
+        entry = torch.cuda.Event()
+        entry.record(main)
+        slot_free = self.entry_events[1]
+        self.entry_events = [self.entry_events[1], entry]
+        if overlap:
+            side = _index_stream(self.device)
+            if slot_free is not None:
+                side.wait_event(slot_free)
+            istream = C.c_void_p(side.cuda_stream)
+        else:
+            side = main
+            istream = C.c_void_p(main.cuda_stream)
         L.check(lib.eagcn_index_build(_ptr(adj), rel_ptrs, idx.ref(), C.c_void_p(self.meta_host[slot].data_ptr()),
-                                      stream), 'eagcn_index_build')
+                                      istream), 'eagcn_index_build')
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(side)
         self.meta_event[slot] = ev
-        L.check(lib.eagcn_index_rows(idx.ref(), stream), 'eagcn_index_rows')
+        L.check(lib.eagcn_index_rows(idx.ref(), istream), 'eagcn_index_rows')
+        if overlap:
+            done = torch.cuda.Event()
+            done.record(side)
+            main.wait_event(done)
+        stream = C.c_void_p(main.cuda_stream)
         L.check(lib.eagcn_model_pack_input(idx.ref(), C.byref(self.cm), _ptr(afm), _ptr(self.saved), self.saved_bytes,
                                            stream), 'eagcn_model_pack_input')
         sn = self.seeds_np                                    # same derivation as ModelPlan.cmodel
@@ -215,11 +243,11 @@ class GraphRunner:
             self.size_static.copy_(size, non_blocking=True)
         self.step += 1
         self.generation += 1
-        if self.fwd_graph is None:
-            self._call_forward()                              # first step: eager (and the capture warm-up)
+        if self.graphs[self.cur][0] is None:
+            self._call_forward()                              # first use of a slot: eager (and the capture warm-up)
             self._capture()
         else:
-            self.fwd_graph.replay()
+            self.graphs[self.cur][0].replay()
         return self.generation
 
     def backward(self, dout, dgr, generation):
@@ -233,10 +261,10 @@ class GraphRunner:
         elif not self.dgr_is_zero:
             self.dgr.zero_()
             self.dgr_is_zero = True
-        if self.bwd_graph is None:
+        if self.graphs[self.cur][1] is None:
             self._call_backward()
         else:
-            self.bwd_graph.replay()
+            self.graphs[self.cur][1].replay()
         params, views = self.plan.params, self.acc_views
         grads = [p.grad for p in params]
         if all(g is None for g in grads):
@@ -257,10 +285,10 @@ class GraphRunner:
 
 class _GraphFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, runner, adj, rels, afm, size, seed, trigger):
+    def forward(ctx, runner, adj, rels, afm, size, seed, overlap, trigger):
         ctx.set_materialize_grads(False)
         ctx.runner = runner
-        ctx.generation = runner.forward(adj, rels, afm, size, seed)
+        ctx.generation = runner.forward(adj, rels, afm, size, seed, overlap)
         return runner.out.detach(), runner.graph_rep.detach()
 
     @staticmethod
@@ -268,11 +296,11 @@ class _GraphFn(torch.autograd.Function):
         if dout is None:
             dout = torch.zeros_like(ctx.runner.out)
         ctx.runner.backward(dout.contiguous(), None if dgr is None else dgr.contiguous(), ctx.generation)
-        return (None,) * 7
+        return (None,) * 8
 
 
-def graph_forward(runner, adj, rels, afm, size, seed):
+def graph_forward(runner, adj, rels, afm, size, seed, overlap=False):
     plan = runner.plan
     if plan.trigger is None or plan.trigger.device != afm.device:
         plan.trigger = torch.zeros((), dtype=torch.float32, device=afm.device, requires_grad=True)
-    return _GraphFn.apply(runner, adj, rels, afm, size, seed, plan.trigger)
+    return _GraphFn.apply(runner, adj, rels, afm, size, seed, overlap, plan.trigger)

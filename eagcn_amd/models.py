@@ -165,7 +165,7 @@ class EAGCN(nn.Module):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.dropout > 0 else 0
         if self.molfp_mode == 'ave':
             size = size.to(device=adjs.device, dtype=torch.int64)
-        out, graph_representation = G.graph_forward(runner, adjs, rels, afms, size, seed)
+        out, graph_representation = G.graph_forward(runner, adjs, rels, afms, size, seed, self.overlap_index)
         atom_representations = None
         if self.atom_rep != 'none':
             pad = runner.pad_view if self.structure == 'Weighted_sum' else None
