@@ -265,7 +265,7 @@ static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m
 }
 
 struct ModelScratch {
-    float *da2, *dh2, *da1, *dh1, *dgn, *dg, *dxa, *dxb, *dpad, *gsplit;
+    float *da2, *dh2, *da1, *dh1, *dgn, *dg, *dxa, *dxb, *dpad, *gsplit, *gsplit2;
     void* layer; size_t layer_bytes;
 };
 static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model* m, ModelScratch* out) {
@@ -279,7 +279,13 @@ static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model*
     s.dh1 = c.take<float>(B * h->n_den1);
     s.dgn = c.take<float>(B * h->f_in);
     s.dg = c.take<float>(B * h->f_in);
-    s.gsplit = c.take<float>((size_t)HEAD_MAX_SPLITS * std::max((size_t)h->f_in * h->n_den1, (size_t)h->n_den1 * h->n_den2));
+    {
+        const size_t Bn = (size_t)b->B;
+        size_t mx = std::max((size_t)h->f_in * h->n_den1, (size_t)h->n_den1 * h->n_den2);
+        mx = std::max(mx, Bn * (size_t)std::max(h->f_in, std::max(h->n_den1, h->n_den2)));
+        s.gsplit = c.take<float>((size_t)HEAD_MAX_SPLITS * mx);
+        s.gsplit2 = c.take<float>((size_t)HEAD_MAX_SPLITS * mx);
+    }
     int ldmax = 0;
     size_t lbytes = 0;
     for (int l = 0; l < m->n_layers; ++l) {
@@ -365,17 +371,23 @@ static int mm(hipStream_t s, int ta, int tb, int M, int N, int K, const float* A
     return launch_gemm(g, s);
 }
 
-// dW = A^T.dY with K = B rows: few output tiles and a long K -> split K over workgroups, then reduce
+// The head's products have few output tiles (B x 256, 700 x 256, ...) and a comparatively long K: with one
+// workgroup per tile they occupy a few percent of the chip and are a serial chain of k-tiles (256x256x700:
+// 16 workgroups, 28 us).  Split K over more workgroups and sum the partial slabs in a second tiny launch.
 static int head_splits(int M, int N, int K) {
     const int tiles = cdiv(M, 64) * cdiv(N, 64);
-    if (tiles >= 128 || K < 512) return 1;
-    return std::max(1, std::min(std::min(HEAD_MAX_SPLITS, K / 256), 256 / std::max(tiles, 1)));
+    if (tiles >= 96 || K < 128) return 1;
+    const int by_k = K / 64;                                  // at least four k-tiles per split
+    const int by_fill = cdiv(256, std::max(tiles, 1));        // aim at ~one workgroup per CU
+    return std::max(1, std::min(std::min(HEAD_MAX_SPLITS, by_k), by_fill));
 }
-static int mm_dw(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                 float* slab) {
+static int mm_split(hipStream_t s, int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
+                    int ldb, float* C, float* slab) {
     const int splits = head_splits(M, N, K);
-    if (splits == 1 || (M * N) % 4 != 0 || (lda % 4) || (ldb % 4) || (N % 4)) return mm(s, 1, 0, M, N, K, A, lda, B, ldb, C, N);
-    GemmDesc g{1, 0, M, N, K, A, lda, B, ldb, slab, N, splits, (size_t)M * N};
+    // split-K needs float4-aligned operands and a dense [M][N] result
+    const bool vec = (lda % 4) == 0 && (ldb % 4) == 0 && ((ta ? M : K) % 4) == 0 && ((tb ? K : N) % 4) == 0;
+    if (splits == 1 || !vec) return mm(s, ta, tb, M, N, K, A, lda, B, ldb, C, N);
+    GemmDesc g{ta, tb, M, N, K, A, lda, B, ldb, slab, N, splits, (size_t)M * N};
     g.prof_tag = PROF_HEAD;
     int rc = launch_gemm(g, s);
     if (rc) return rc;
@@ -383,6 +395,10 @@ static int mm_dw(hipStream_t s, int M, int N, int K, const float* A, int lda, co
     splitk_reduce_kernel<<<std::min(cdiv(M * N, 256), 1024), 256, 0, s>>>(slab, M * N, splits, C);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
+}
+static int mm_dw(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                 float* slab) {
+    return mm_split(s, 1, 0, M, N, K, A, lda, B, ldb, C, slab);
 }
 
 }  // namespace eagcn
@@ -448,10 +464,10 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
                              size, m->molfp_mode, sv.g, F, stream));
     RC(rowbn_fwd(s, B, F, sv.g, sv.gn, h->gbn_w, h->gbn_b, h->gbn_rm, h->gbn_rv, sv.bn_g, m->training, 0, 0.0f, 0,
                  nullptr, h->bn_eps, h->bn_momentum));
-    RC(mm(s, 0, 0, B, n1, F, sv.gn, F, h->den1_w, n1, sv.h1, n1));
+    RC(mm_split(s, 0, 0, B, n1, F, sv.gn, F, h->den1_w, n1, sv.h1, sc.gsplit));
     RC(rowbn_fwd(s, B, n1, sv.h1, sv.a1, h->bn1_w, h->bn1_b, h->bn1_rm, h->bn1_rv, sv.bn_1, m->training, 1,
                  h->dropout, m->head_seed, m->head_seed_dev, h->bn_eps, h->bn_momentum));
-    RC(mm(s, 0, 0, B, n2, n1, sv.a1, n1, h->den2_w, n2, sv.h2, n2));
+    RC(mm_split(s, 0, 0, B, n2, n1, sv.a1, n1, h->den2_w, n2, sv.h2, sc.gsplit));
     EAGCN_HIP(hipMemcpyAsync(graph_rep, sv.h2, (size_t)B * n2 * sizeof(float), hipMemcpyDeviceToDevice, s));
     RC(rowbn_fwd(s, B, n2, sv.h2, sv.a2, h->bn2_w, h->bn2_b, h->bn2_rm, h->bn2_rv, sv.bn_2, m->training, 1, 0.0f, 0,
                  nullptr, h->bn_eps, h->bn_momentum));
@@ -485,13 +501,13 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
     // den2
     if (forked) RC(stream_after(side, s));                       // dh2 is ready
     RC(mm_dw(side, n1, n2, B, sv.a1, n1, sc.dh2, n2, hg->d_den2_w, sc.gsplit));
-    RC(mm(s, 0, 1, B, n1, n2, sc.dh2, n2, h->den2_w, n2, sc.da1, n1));
+    RC(mm_split(s, 0, 1, B, n1, n2, sc.dh2, n2, h->den2_w, n2, sc.da1, sc.gsplit2));
     RC(rowbn_bwd(s, B, n1, sc.da1, sv.h1, sv.bn_1, nullptr, sc.dh1, hg->d_bn1_w, hg->d_bn1_b, m->training, 1, h->dropout,
                  m->head_seed, m->head_seed_dev));
     // den1
     if (forked) RC(stream_after(side, s));                       // dh1 is ready
     RC(mm_dw(side, F, n1, B, sv.gn, F, sc.dh1, n1, hg->d_den1_w, sc.gsplit));
-    RC(mm(s, 0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, sc.dgn, F));
+    RC(mm_split(s, 0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, sc.dgn, sc.gsplit2));
     RC(rowbn_bwd(s, B, F, sc.dgn, sv.g, sv.bn_g, nullptr, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training, 0, 0.0f, 0, nullptr));
     // read-out
     const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
