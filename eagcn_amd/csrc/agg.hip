@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void agg_wave_kernel(AggArgs a) {
 template <int CT, bool TRANS>
 __global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
     __shared__ float sig_s[256];
-    __shared__ float red_s[3][CT][4][64];
+    __shared__ float red_s[CT][4][64];                // ONE partial-accumulator buffer, reused wave by wave
     __shared__ float dred_s[4][16];
     __shared__ double st_s[TRANS ? 1 : CT * 16 * 2];
     const int k = blockIdx.y / a.nchunk, cc = blockIdx.y % a.nchunk;
@@ -296,28 +296,30 @@ __global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
             }
         }
 
-        // combine the waves' partials in wave 0
+        // combine the waves' partials in wave 0: waves 1..nw-1 hand their accumulators over one after the other
+        // through a single LDS buffer (9 KB for CT = 9; three parallel buffers would cap residency at 5 WG/CU)
         if (nw > 1) {
-            if (wave > 0 && wave < nw) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    if (ct < nct) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) red_s[wave - 1][ct][g][lane] = acc[ct][g];
-                    }
-            }
             if (!TRANS && q == 0 && wave < nw) dred_s[wave][li] = dsum;
-            __syncthreads();
-            if (wave == 0) {
-                for (int w2 = 1; w2 < nw; ++w2) {
+            for (int w2 = 1; w2 < nw; ++w2) {
+                if (wave == w2) {
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
                         if (ct < nct) {
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) acc[ct][g] += red_s[w2 - 1][ct][g][lane];
+                            for (int g = 0; g < 4; ++g) red_s[ct][g][lane] = acc[ct][g];
+                        }
+                }
+                __syncthreads();
+                if (wave == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        if (ct < nct) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) acc[ct][g] += red_s[ct][g][lane];
                         }
                     if (!TRANS) dsum += dred_s[w2][li];
                 }
+                if (w2 + 1 < nw) __syncthreads();
             }
         }
         if (wave == 0) {

@@ -149,7 +149,16 @@ __global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __re
     }
     atomicMax(&s_max, nmax);
     int edges = 0;
-    for (int r = t; r < BN; r += 1024) edges += deg_bn[r];
+    for (int r0 = t; r0 < BN; r0 += 1024 * 8) {            // 8 loads in flight per thread
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 1024 * u;
+            v[u] = r < BN ? deg_bn[r] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) edges += v[u];
+    }
     edges = wave_sum(edges);
     if ((t & 63) == 0 && edges) atomicAdd(&meta[EAGCN_META_NEDGE], edges);
     __syncthreads();

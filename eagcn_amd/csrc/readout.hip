@@ -52,22 +52,22 @@ __global__ __launch_bounds__(256) void readout_fwd_kernel(eagcn_batch bt, const 
     }
 }
 
+// dx[r][cp] = dg[mol(r)][exact(cp)] / size: one thread per packed element, fully parallel
 __global__ __launch_bounds__(256) void readout_bwd_kernel(eagcn_batch bt, const float* __restrict__ dg, ColMapD m,
                                                            int ld, const int64_t* __restrict__ size, int mode,
                                                            int F, float* __restrict__ dx) {
-    const int b = blockIdx.x;
-    const int n = bt.nat[b], r0 = bt.row0[b];
-    const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
-    for (int cp = threadIdx.x; cp < ld; cp += blockDim.x) {
-        // packed column -> exact column (or -1 for a padding column)
+    const size_t total = (size_t)dev_rows(bt) * ld;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / ld), cp = (int)(e % ld);
         int eo = 0, po = 0, ce = -1;
         for (int s = 0; s < m.nseg; ++s) {
             if (cp < po + m.p[s]) { ce = (cp - po < m.w[s]) ? eo + (cp - po) : -1; break; }
             eo += m.w[s];
             po += m.p[s];
         }
-        const float v = ce >= 0 ? dg[(size_t)b * F + ce] * inv : 0.0f;
-        for (int i = 0; i < n; ++i) dx[(size_t)(r0 + i) * ld + cp] = v;
+        const int b = bt.row_mol[r];
+        const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
+        dx[e] = ce >= 0 ? dg[(size_t)b * F + ce] * inv : 0.0f;
     }
 }
 
@@ -119,7 +119,11 @@ extern "C" int eagcn_readout_backward(const eagcn_batch* b, const float* dg, con
     EAGCN_CHECK_ARG(layout_width(lay) == F, "eagcn_readout_backward: layout width %d != F %d", layout_width(lay), F);
     EAGCN_CHECK_ARG(mode == 0 || (mode == 1 && size), "eagcn_readout_backward: mode 1 ('ave') needs size");
     ProfScope ps(PROF_READOUT, s);
-    readout_bwd_kernel<<<b->B, 256, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size, mode, F, dx);
+    {
+        const size_t total = (size_t)std::max(b->T, 1) * layout_ld(lay);
+        const int grid = (int)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 2048));
+        readout_bwd_kernel<<<grid, 256, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size, mode, F, dx);
+    }
     EAGCN_LAUNCH_CHECK();
     if (dpad_row) {
         readout_bwd_pad_kernel<<<cdiv(layout_ld(lay), 256), 256, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size,

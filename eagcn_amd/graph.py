@@ -171,10 +171,11 @@ class GraphRunner:
         lib.eagcn_prof_enable(0)
         torch.cuda.synchronize(self.device)
         fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(fwd):
+        # thread_local: other threads (e.g. the RCCL watchdog of torch.distributed) may touch the HIP API during capture
+        with torch.cuda.graph(fwd, capture_error_mode='thread_local'):
             self._call_forward()
         bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(bwd):
+        with torch.cuda.graph(bwd, capture_error_mode='thread_local'):
             self._call_backward()
         self.graphs[self.cur] = [fwd, bwd]
 
