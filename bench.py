@@ -180,7 +180,6 @@ def main():
     bce_w_dev = torch.tensor(bce_w, dtype=torch.float32, device=dev)
     model = build_model(cfg, args.dropout, dev, graph=not args.eager)
     model.train()
-    model._debug_eager_cap = os.environ.get('EAGCN_EAGER_CAP', '0') == '1'
     reducer = GradientAllReducer(model.parameters(), model=model)
     params = list(model.parameters())
 

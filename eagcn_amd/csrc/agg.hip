@@ -431,12 +431,15 @@ int launch_agg(AggArgs a, bool trans, hipStream_t s) {
 //   d w_k[c] += dU[i,j] s (1-s)  at bonds of type c ;   d self_r_k += dU[i,i] r (1-r)
 // one wavefront per (packed row, view); results accumulated in fp64.
 __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
-    // one packed row per 16-lane group (4 rows per wavefront, 16 per workgroup), no persistent loop.
-    // Dependent-load hops per row: {row_info, rscale} -> {code row, dY row, Y row} -> one hop per bond.
-    // The whole code row arrives with ONE 16-byte load per lane (16 lanes x 16 bytes = 256 columns).
+    // one packed row per 16-lane group (4 rows per wavefront, 16 per workgroup).
+    // Dependent-load hops per row: {row_info, rscale} -> {code row, dY row, Y row} -> {P rows of up to four
+    // bonds at once}.  The code row arrives with ONE 16-byte load per lane (16 lanes x 16 bytes = 256 columns);
+    // the bonds found in it are queued in LDS and their dot products are taken four at a time.
+    constexpr int HMAX = 64;                                       // queue slots per row (flushed when full)
     __shared__ float sig_s[256];
     __shared__ double h_s[256];
     __shared__ double dr_s[16];
+    __shared__ int hit_s[16][HMAX];                                // (column << 8) | bond code
     const eagcn_batch& bt = a.bt;
     const int Tn = dev_rows(bt);
     if ((int)blockIdx.x * 16 >= Tn) return;                        // capacity-sized grid (slab not read either)
@@ -444,6 +447,7 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
     const int k = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane >> 4, sl = lane & 15;
+    const int gq = wave * 4 + grp;                                 // group index inside the workgroup
     sig_s[tid] = a.sig[k * 256 + tid];
     h_s[tid] = 0.0;
     if (tid < 16) dr_s[tid] = 0.0;
@@ -451,60 +455,80 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
     const int off = a.vc.off[k], fp = a.vc.off[k + 1] - a.vc.off[k];
     double dr_acc = 0.0;
     for (int rblk = blockIdx.x; rblk * 16 < Tn; rblk += nwg) {     // one trip unless the grid was capped
-    const int r = (rblk * 4 + wave) * 4 + grp;
-    int4 info = make_int4(0, 0, 0, 0);
-    float rs = 0.0f;
-    if (r < Tn) {
-        info = reinterpret_cast<const int4*>(bt.row_info)[r];
-        rs = a.rscale[(size_t)k * bt.T + r];
-    }
-    const bool live = rs != 0.0f;                                  // m_i == 0 rows carry no dependence
-    const int b = info.x, i = info.y, n = live ? info.z : 0, r0 = info.w;
-    const int rr = live ? r : 0;
-    const float* dy = a.dY + (size_t)rr * a.ld + off;
-    const float* yr = a.Y + (size_t)rr * a.ld + off;
-    const uint8_t* crow = bt.code + (((size_t)k * bt.B + b) * bt.N + i) * bt.ldc;
-    const int nmax = max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48)));
-    float rd = live ? dot16(dy, yr, sl, fp) : 0.0f;
+        const int r = (rblk * 4 + wave) * 4 + grp;
+        int4 info = make_int4(0, 0, 0, 0);
+        float rs = 0.0f;
+        if (r < Tn) {
+            info = reinterpret_cast<const int4*>(bt.row_info)[r];
+            rs = a.rscale[(size_t)k * bt.T + r];
+        }
+        const bool live = rs != 0.0f;                              // m_i == 0 rows carry no dependence
+        const int b = info.x, i = info.y, n = live ? info.z : 0, r0 = info.w;
+        const int rr = live ? r : 0;
+        const float* dy = a.dY + (size_t)rr * a.ld + off;
+        const float* yr = a.Y + (size_t)rr * a.ld + off;
+        const uint8_t* crow = bt.code + (((size_t)k * bt.B + b) * bt.N + i) * bt.ldc;
+        const int nmax = max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48)));
+        float rd = live ? dot16(dy, yr, sl, fp) : 0.0f;
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) rd += __shfl_xor(rd, o);
-    for (int seg = 0; seg * 256 < nmax; ++seg) {
-        const int jb = seg * 256 + sl * 16;
-        uint4 cw = make_uint4(0u, 0u, 0u, 0u);
-        if (jb < n) cw = *reinterpret_cast<const uint4*>(crow + jb);
-        const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+        for (int o = 8; o > 0; o >>= 1) rd += __shfl_xor(rd, o);
+        int nh = 0;                                                // queued hits of this group (group-uniform)
+        auto flush = [&]() {                                       // dot products of the queued bonds, 4 at a time
+            // the queue was written by other lanes of this wavefront: LDS operations of one wave complete in
+            // order; the fence keeps the compiler from moving the reads above the writes
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int h0 = 0; h0 < nh; h0 += 4) {
+                int hv[4];
+                const float* pr[4];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const uint32_t c = (w[t >> 2] >> (8 * (t & 3))) & 255u;
-            const int j = jb + t;
-            const bool want = j < n && (c != 0u || j == i);
-            unsigned long long ball = __ballot(want);
-            if (ball == 0ull) continue;                                // wave-uniform
-            uint32_t mask = (uint32_t)(ball >> (grp * 16)) & 0xFFFFu;       // this group's lanes with a hit at byte t
-            const int cnt = __popc(mask);
-            const int cmax = max(max(__shfl(cnt, 0), __shfl(cnt, 16)), max(__shfl(cnt, 32), __shfl(cnt, 48)));
-            for (int it = 0; it < cmax; ++it) {
-                const bool act = mask != 0u;
-                const int src = act ? (__ffs(mask) - 1) : 0;
-                mask &= mask - 1;
-                const int jj = seg * 256 + src * 16 + t;
-                const uint32_t cj = __shfl(c, grp * 16 + src);
-                const float* pr = a.P + (size_t)(act ? (r0 + jj) : 0) * a.ld + off;
-                float g = act ? dot16(dy, pr, sl, fp) : 0.0f;
+                for (int h = 0; h < 4; ++h) {
+                    hv[h] = (h0 + h < nh) ? hit_s[gq][h0 + h] : -1;
+                    pr[h] = a.P + (size_t)(hv[h] >= 0 ? (r0 + (hv[h] >> 8)) : rr) * a.ld + off;
+                }
+                float g[4];
+                dot16x4(dy, pr, sl, fp, g);
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) g += __shfl_xor(g, o);
-                if (act && sl == 0) {
-                    const float dU = rs * (g - rd);
-                    if (cj) {
-                        const float s = sig_s[cj];
-                        atomicAdd(&h_s[cj], (double)(dU * s * (1.0f - s)));
+                for (int h = 0; h < 4; ++h) {
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) g[h] += __shfl_xor(g[h], o);
+                    if (hv[h] >= 0 && sl == 0) {
+                        const float dU = rs * (g[h] - rd);
+                        const uint32_t cj = (uint32_t)hv[h] & 255u;
+                        if (cj) {
+                            const float sg = sig_s[cj];
+                            atomicAdd(&h_s[cj], (double)(dU * sg * (1.0f - sg)));
+                        }
+                        if ((hv[h] >> 8) == i) dr_acc += (double)dU;
                     }
-                    if (jj == i) dr_acc += (double)dU;
                 }
             }
+            nh = 0;
+        };
+        for (int seg = 0; seg * 256 < nmax; ++seg) {
+            const int jb = seg * 256 + sl * 16;
+            uint4 cw = make_uint4(0u, 0u, 0u, 0u);
+            if (jb < n) cw = *reinterpret_cast<const uint4*>(crow + jb);
+            const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const uint32_t c = (w[t >> 2] >> (8 * (t & 3))) & 255u;
+                const int j = jb + t;
+                const bool want = j < n && (c != 0u || j == i);
+                const unsigned long long ball = __ballot(want);
+                if (ball == 0ull) continue;                            // wave-uniform
+                const uint32_t mask = (uint32_t)(ball >> (grp * 16)) & 0xFFFFu;   // this group's lanes with a hit at byte t
+                if (mask) {
+                    // lane `sl` with a hit takes slot nh + (number of hit lanes below it)
+                    const int pos = nh + __popc(mask & ((1u << sl) - 1u));
+                    if (want && pos < HMAX) hit_s[gq][pos] = (j << 8) | (int)c;
+                    nh = min(nh + __popc(mask), HMAX);
+                }
+                if (nh > HMAX - 16) flush();                           // keep room for the next byte position
+            }
         }
+        flush();
     }
-    }   // rblk
     if (sl == 0) dr_s[wave * 4 + grp] = dr_acc;
     __syncthreads();
     // slab[blockIdx.x][k][0..255] = bond-type histogram, slab[..][k][256] = self term

@@ -86,6 +86,30 @@ __device__ __forceinline__ float dot16(const float* __restrict__ a, const float*
     return acc;
 }
 
+// four partial dot products of row `a` with rows p[0..3] at once (same lane layout as dot16): the loads of
+// `a` are shared and the four P rows are requested together, so several bonds of an atom cost ONE memory
+// round trip instead of one each
+__device__ __forceinline__ void dot16x4(const float* __restrict__ a, const float* const (&p)[4], int sl, int n,
+                                        float (&out)[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    constexpr int U = 5;
+    for (int c0 = sl; c0 < n; c0 += 16 * U) {
+        float x[U], y[4][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + 16 * u;
+            const bool ok = c < n;
+            x[u] = ok ? a[c] : 0.0f;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) y[h][u] = ok ? p[h][c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) out[h] += x[u] * y[h][u];
+    }
+}
+
 // counter-based dropout stream: one 32-bit draw per (seed, element index)
 __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
     uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;

@@ -181,8 +181,7 @@ class EAGCN(nn.Module):
         *rels, size = rels_and_size
         if self.graph and self.training and torch.is_grad_enabled():
             return self._graph_forward(adjs, afms, rels, size)
-        cap = adjs.shape[0] * adjs.shape[1] if getattr(self, '_debug_eager_cap', False) else None
-        index = ops.BatchIndex(adjs, rels, overlap=self.overlap_index, row_cap=cap)   # once per batch
+        index = ops.BatchIndex(adjs, rels, overlap=self.overlap_index)   # once per batch, shared by all layers
         plan = self.plan()
         seed = 0
         if self.training and self.dropout > 0:

@@ -71,8 +71,11 @@ class GradientAllReducer:
             return
         flat = self._model_flat_buffer()
         if flat is not None:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.div_(dist.get_world_size(self.group))
+            if flat.is_cuda:            # RCCL averages in the collective itself: no separate scaling launch
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                flat.div_(dist.get_world_size(self.group))
             return
         grads = [p.grad for p in self.params if p.grad is not None]
         if not grads:
