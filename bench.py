@@ -155,6 +155,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--input', default='dense', choices=('dense', 'compact'),
+                    help="dense: the reference's collate tensors (headline); compact: bond list via forward_compact")
     args = ap.parse_args()
 
     from eagcn_amd import _lib
@@ -174,7 +176,8 @@ def main():
     torch.manual_seed(1234 + rank)
     mb = make_batch(B=B, n_max=cfg['n_max'], n_med=cfg['n_med'], rel_channels=(cfg['n_bfeat'], 4, 2, 2, 2),
                     seed=1234 + rank, n_tasks=cfg['nclass'], task=cfg['task'])
-    dense = mb.dense(dev)
+    dense = mb.dense(dev) if args.input == 'dense' else None
+    compact = mb.compact(dev) if args.input == 'compact' else None
     labels = torch.from_numpy(mb.labels).to(dev)
     bce_w = bce_weights(cfg['nclass'])
     bce_w_dev = torch.tensor(bce_w, dtype=torch.float32, device=dev)
@@ -186,7 +189,7 @@ def main():
     def step():
         for p in params:            # optimizer.zero_grad(set_to_none=True) of the reference loop (train.py:317)
             p.grad = None
-        out, _, _ = model(*dense)
+        out, _, _ = model(*dense) if compact is None else model.forward_compact(*compact)
         if cfg['task'] == 'class':
             loss = fused_classification_loss(out, labels, bce_w_dev)
         else:
@@ -259,7 +262,7 @@ def main():
                                    (args.workload, cfg['structure'], cfg['n_layers'], len(cfg['widths1']),
                                     cfg['widths1'][0], cfg['widths2'][0], cfg['nclass'], B, mb.N, args.dropout,
                                     'weighted BCE' if cfg['task'] == 'class' else 'MSE'),
-                       'global_batch': world * B, 'atoms_per_batch': int(mb.sizes.sum()),
+                       'input': args.input, 'global_batch': world * B, 'atoms_per_batch': int(mb.sizes.sum()),
                        'parallelism': 'dp%d' % world},
             'algorithmic_gflop_per_step': round(algorithmic_flops(cfg, mb.sizes) / 1e9, 3),
             'roofline': {'kernel': 'gemm_f32_kernel (flat X.[W_1..W_K] transform + its two backward products)',

@@ -112,6 +112,31 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
     }
 }
 
+// compact input: one thread per directed bond writes its K codes and bumps the row degree
+__global__ __launch_bounds__(256) void index_bonds_kernel(const int32_t* __restrict__ bm, const int32_t* __restrict__ bi,
+                                                           const int32_t* __restrict__ bj,
+                                                           const uint8_t* __restrict__ bc, long E, int B, int N, int K,
+                                                           int ldc, RelPtrs rel, uint8_t* __restrict__ code,
+                                                           int32_t* __restrict__ deg_bn, int32_t* __restrict__ nat,
+                                                           int32_t* __restrict__ meta) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
+        const int b = bm[e], i = bi[e], j = bj[e];
+        if (b < 0 || b >= B || i < 0 || i >= N || j < 0 || j >= N || i == j) {
+            atomicAdd(&meta[EAGCN_META_BAD_ADJ], 1);
+            continue;
+        }
+        bool bad = false;
+        for (int k = 0; k < K; ++k) {
+            const int c = bc[e * K + k];
+            if (c >= rel.c[k]) bad = true;
+            code[(((size_t)k * B + b) * N + i) * ldc + j] = (uint8_t)(c + 1);
+        }
+        if (bad) atomicAdd(&meta[EAGCN_META_BAD_REL], 1);
+        atomicAdd(&deg_bn[(size_t)b * N + i], 1);
+        atomicMax(&nat[b], i + 1);
+    }
+}
+
 // single workgroup: exclusive prefix sums of nat[] and ceil(nat/16) -> row0, tile0, totals
 __global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __restrict__ nat, int B,
                                                               const int32_t* __restrict__ deg_bn, int BN,
@@ -279,6 +304,35 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     }
 #undef EAGCN_SCAN
     EAGCN_LAUNCH_CHECK();
+    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta);
+    EAGCN_LAUNCH_CHECK();
+    EAGCN_HIP(hipMemcpyAsync(host_meta, b->meta, EAGCN_META_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_index_from_bonds(const int32_t* bond_mol, const int32_t* bond_i, const int32_t* bond_j,
+                                      const uint8_t* bond_code, int64_t E, eagcn_batch* b, int32_t* host_meta,
+                                      void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    EAGCN_CHECK_ARG(b && host_meta, "eagcn_index_from_bonds: null argument");
+    EAGCN_CHECK_ARG(E == 0 || (bond_mol && bond_i && bond_j && bond_code), "eagcn_index_from_bonds: null bond arrays");
+    EAGCN_CHECK_ARG(b->B > 0 && b->N > 0 && b->K >= 1 && b->K <= EAGCN_MAX_VIEWS, "eagcn_index_from_bonds: bad batch shape");
+    EAGCN_CHECK_ARG(b->ldc >= b->N && (b->ldc % 16) == 0, "eagcn_index_from_bonds: ldc must be a multiple of 16 >= N");
+    EAGCN_CHECK_ARG(b->code && b->deg_bn && b->nat && b->row0 && b->tile0 && b->meta,
+                    "eagcn_index_from_bonds: index buffers not allocated");
+    RelPtrs rp;
+    for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) { rp.p[k] = nullptr; rp.c[k] = k < b->K ? b->channels[k] : 0; }
+    ProfScope ps(PROF_INDEX, s);
+    EAGCN_HIP(hipMemsetAsync(b->meta, 0, EAGCN_META_WORDS * sizeof(int32_t), s));
+    EAGCN_HIP(hipMemsetAsync(b->nat, 0, (size_t)b->B * sizeof(int32_t), s));
+    EAGCN_HIP(hipMemsetAsync(b->deg_bn, 0, (size_t)b->B * b->N * sizeof(int32_t), s));
+    EAGCN_HIP(hipMemsetAsync(b->code, 0, (size_t)b->K * b->B * b->N * b->ldc, s));
+    if (E > 0) {
+        const int grid = (int)std::min<long>((E + 255) / 256, 4096);
+        index_bonds_kernel<<<grid, 256, 0, s>>>(bond_mol, bond_i, bond_j, bond_code, (long)E, b->B, b->N, b->K, b->ldc, rp,
+                                                b->code, b->deg_bn, b->nat, b->meta);
+        EAGCN_LAUNCH_CHECK();
+    }
     index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta);
     EAGCN_LAUNCH_CHECK();
     EAGCN_HIP(hipMemcpyAsync(host_meta, b->meta, EAGCN_META_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, s));

@@ -198,7 +198,7 @@ class GraphRunner:
                 raise L.EagcnHipError('a previous batch packed %d rows, more than row_cap=%d'
                                       % (meta[L.META_T], self.index.T))
 
-    def forward(self, adj, rels, afm, size, seed, overlap=False):
+    def forward(self, adj, rels, afm, size, seed, overlap=False, bonds=None):
         lib = L.load()
         self._check_old_batches()
         self.cur = self.step % 2
@@ -207,7 +207,6 @@ class GraphRunner:
         slot = self.step % _RING
         if self.meta_event[slot] is not None:                 # ring wrapped: this slot must be consumed first
             self._check_old_batches(force=True)
-        rel_ptrs = (C.c_void_p * idx.K)(*[r.data_ptr() for r in rels])
         # main-stream position now = after the backward of the previous step; the position recorded at the
         # PREVIOUS forward entry = after the backward of the step before it, the last user of this index slot
         entry = torch.cuda.Event()
@@ -222,8 +221,15 @@ class GraphRunner:
         else:
             side = main
             istream = C.c_void_p(main.cuda_stream)
-        L.check(lib.eagcn_index_build(_ptr(adj), rel_ptrs, idx.ref(), C.c_void_p(self.meta_host[slot].data_ptr()),
-                                      istream), 'eagcn_index_build')
+        if bonds is None:
+            rel_ptrs = (C.c_void_p * idx.K)(*[r.data_ptr() for r in rels])
+            L.check(lib.eagcn_index_build(_ptr(adj), rel_ptrs, idx.ref(), C.c_void_p(self.meta_host[slot].data_ptr()),
+                                          istream), 'eagcn_index_build')
+        else:                                                 # compact batch: O(bonds) input instead of the dense tensors
+            bm, bi, bj, bc = bonds
+            L.check(lib.eagcn_index_from_bonds(_ptr(bm), _ptr(bi), _ptr(bj), _ptr(bc), bm.numel(), idx.ref(),
+                                               C.c_void_p(self.meta_host[slot].data_ptr()), istream),
+                    'eagcn_index_from_bonds')
         ev = torch.cuda.Event()
         ev.record(side)
         self.meta_event[slot] = ev
@@ -286,10 +292,10 @@ class GraphRunner:
 
 class _GraphFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, runner, adj, rels, afm, size, seed, overlap, trigger):
+    def forward(ctx, runner, adj, rels, afm, size, seed, overlap, trigger, bonds=None):
         ctx.set_materialize_grads(False)
         ctx.runner = runner
-        ctx.generation = runner.forward(adj, rels, afm, size, seed, overlap)
+        ctx.generation = runner.forward(adj, rels, afm, size, seed, overlap, bonds)
         return runner.out.detach(), runner.graph_rep.detach()
 
     @staticmethod
@@ -297,11 +303,11 @@ class _GraphFn(torch.autograd.Function):
         if dout is None:
             dout = torch.zeros_like(ctx.runner.out)
         ctx.runner.backward(dout.contiguous(), None if dgr is None else dgr.contiguous(), ctx.generation)
-        return (None,) * 8
+        return (None,) * 9
 
 
-def graph_forward(runner, adj, rels, afm, size, seed, overlap=False):
+def graph_forward(runner, adj, rels, afm, size, seed, overlap=False, bonds=None):
     plan = runner.plan
     if plan.trigger is None or plan.trigger.device != afm.device:
         plan.trigger = torch.zeros((), dtype=torch.float32, device=afm.device, requires_grad=True)
-    return _GraphFn.apply(runner, adj, rels, afm, size, seed, overlap, plan.trigger)
+    return _GraphFn.apply(runner, adj, rels, afm, size, seed, overlap, plan.trigger, bonds)

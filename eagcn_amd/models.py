@@ -143,29 +143,37 @@ class EAGCN(nn.Module):
         self._runners = {}
         return super()._apply(fn, *a, **kw)
 
-    def _graph_forward(self, adjs, afms, rels, size):
+    def _graph_forward(self, adjs, afms, rels, size, bonds=None):
         from . import graph as G
-        adjs = ops._need_cuda_f32(adjs, 'adjs')
         afms = ops._need_cuda_f32(afms, 'afms')
-        rels = [ops._need_cuda_f32(r, 'relation tensor %d' % i) for i, r in enumerate(rels)]
-        B, N = adjs.shape[0], adjs.shape[1]
-        if adjs.dim() != 3 or adjs.shape[2] != N or afms.shape != (B, N, self.n_afeat) or len(rels) != self.K:
-            raise ops.L.EagcnHipError('inconsistent batch tensors: adjs %s afms %s, %d relation tensors'
-                                      % (tuple(adjs.shape), tuple(afms.shape), len(rels)))
-        for i, r in enumerate(rels):
-            if r.dim() != 4 or r.shape[0] != B or r.shape[2] != N or r.shape[3] != N:
-                raise ops.L.EagcnHipError('relation tensor %d must be [B,C,N,N], got %s' % (i, tuple(r.shape)))
+        if bonds is None:
+            adjs = ops._need_cuda_f32(adjs, 'adjs')
+            rels = [ops._need_cuda_f32(r, 'relation tensor %d' % i) for i, r in enumerate(rels)]
+            B, N = adjs.shape[0], adjs.shape[1]
+            if adjs.dim() != 3 or adjs.shape[2] != N or afms.shape != (B, N, self.n_afeat) or len(rels) != self.K:
+                raise ops.L.EagcnHipError('inconsistent batch tensors: adjs %s afms %s, %d relation tensors'
+                                          % (tuple(adjs.shape), tuple(afms.shape), len(rels)))
+            for i, r in enumerate(rels):
+                if r.dim() != 4 or r.shape[0] != B or r.shape[2] != N or r.shape[3] != N:
+                    raise ops.L.EagcnHipError('relation tensor %d must be [B,C,N,N], got %s' % (i, tuple(r.shape)))
+            channels = tuple(int(r.shape[1]) for r in rels)
+            btuple = None
+        else:
+            B, N, channels = bonds.B, bonds.N, tuple(bonds.channels)
+            if afms.shape != (B, N, self.n_afeat) or len(channels) != self.K:
+                raise ops.L.EagcnHipError('inconsistent compact batch: afms %s for B=%d N=%d, %d views'
+                                          % (tuple(afms.shape), B, N, len(channels)))
+            btuple = bonds.checked()
         plan = self.plan()
-        channels = tuple(int(r.shape[1]) for r in rels)
         key = (B, N, channels, float(self.dropout))
         runner = self._runners.get(key)
         if runner is None or runner.stale():
-            runner = G.GraphRunner(plan, B, N, channels, adjs.device, self.dropout, self.row_cap)
+            runner = G.GraphRunner(plan, B, N, channels, afms.device, self.dropout, self.row_cap)
             self._runners[key] = runner
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.dropout > 0 else 0
         if self.molfp_mode == 'ave':
-            size = size.to(device=adjs.device, dtype=torch.int64)
-        out, graph_representation = G.graph_forward(runner, adjs, rels, afms, size, seed, self.overlap_index)
+            size = size.to(device=afms.device, dtype=torch.int64)
+        out, graph_representation = G.graph_forward(runner, adjs, rels, afms, size, seed, self.overlap_index, btuple)
         atom_representations = None
         if self.atom_rep != 'none':
             pad = runner.pad_view if self.structure == 'Weighted_sum' else None
@@ -182,6 +190,19 @@ class EAGCN(nn.Module):
         if self.graph and self.training and torch.is_grad_enabled():
             return self._graph_forward(adjs, afms, rels, size)
         index = ops.BatchIndex(adjs, rels, overlap=self.overlap_index)   # once per batch, shared by all layers
+        return self._forward_index(index, afms, size)
+
+    def forward_compact(self, bonds, afms, size):
+        """The same forward from a COMPACT batch: ``bonds`` is an ``eagcn_amd.synthetic.CompactBonds``
+        (directed bond list + per-view bond type), ``afms`` the padded [B,N,n_afeat] atom features.  Results are
+        identical to ``forward`` on the dense tensors the reference's collate (utils.py:575-640) would build for
+        the same molecules; the adjacency / relation tensors are never materialised."""
+        if self.graph and self.training and torch.is_grad_enabled():
+            return self._graph_forward(None, afms, None, size, bonds)
+        index = ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, *bonds.checked())
+        return self._forward_index(index, afms, size)
+
+    def _forward_index(self, index, afms, size):
         plan = self.plan()
         seed = 0
         if self.training and self.dropout > 0:

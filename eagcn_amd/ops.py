@@ -77,6 +77,17 @@ class BatchIndex:
     input-validity counters -- non-binary adjacency or non-one-hot relation channels raise here.
     """
 
+    @classmethod
+    def from_bonds(cls, B, N, channels, bond_mol, bond_i, bond_j, bond_code, row_cap=None):
+        """Index of a COMPACT batch: directed bonds as int32 device vectors bond_mol / bond_i /
+        bond_j [E] plus their type per view bond_code [E,K] (uint8).  Equivalent to BatchIndex(adj, rels) on
+        the dense tensors the reference's collate would build from the same molecules, without ever
+        materialising them (O(E) input bytes instead of 4*(1+sum C_k)*B*N*N)."""
+        self = cls.__new__(cls)
+        self._build(None, None, B, N, list(channels), bond_mol.device, False, row_cap,
+                    bonds=(bond_mol, bond_i, bond_j, bond_code))
+        return self
+
     def __init__(self, adj, rels, overlap=False, row_cap=None):
         """row_cap: size every packed buffer / grid for `row_cap` rows instead of the exact packed row
         count (kernels read the exact count from device memory); used by tests and by graph mode.
@@ -97,9 +108,13 @@ class BatchIndex:
             if r.dim() != 4 or r.shape[0] != B or r.shape[2] != N or r.shape[3] != N:
                 raise L.EagcnHipError('relation tensor %d must be [B,C,N,N] = [%d,C,%d,%d], got %s'
                                       % (i, B, N, N, tuple(r.shape)))
-        dev = adj.device
+        self._build(adj, rels, B, N, [int(r.shape[1]) for r in rels], adj.device, overlap, row_cap)
+
+    def _build(self, adj, rels, B, N, channels, dev, overlap, row_cap, bonds=None):
+        lib = L.load()
+        K = len(channels)
         self.device, self.B, self.N, self.K = dev, B, N, K
-        self.channels = [int(r.shape[1]) for r in rels]
+        self.channels = channels
         self.ldc = (N + 15) // 16 * 16
         i32 = dict(dtype=torch.int32, device=dev)
         main = torch.cuda.current_stream(dev)
@@ -125,15 +140,29 @@ class BatchIndex:
         c.code, c.deg_bn, c.nat = self.code.data_ptr(), base, base + 4 * B * N
         c.row0, c.tile0 = base + 4 * (B * N + B), base + 4 * (B * N + 2 * B + 1)
         c.meta = base + 4 * (B * N + 3 * B + 2)
-        rel_ptrs = (C.c_void_p * K)(*[r.data_ptr() for r in rels])
         host = _host_meta(dev)
         if not overlap:
             side.wait_stream(main)        # inputs may have been produced by work still queued on `main`
         sptr = C.c_void_p(side.cuda_stream)
-        L.check(lib.eagcn_index_build(_ptr(adj), rel_ptrs, C.byref(c), C.c_void_p(host.data_ptr()), sptr),
-                'eagcn_index_build')
+        if bonds is None:
+            rel_ptrs = (C.c_void_p * K)(*[r.data_ptr() for r in rels])
+            L.check(lib.eagcn_index_build(_ptr(adj), rel_ptrs, C.byref(c), C.c_void_p(host.data_ptr()), sptr),
+                    'eagcn_index_build')
+        else:
+            bm, bi, bj, bc = bonds
+            for t, dt, name in ((bm, torch.int32, 'bond_mol'), (bi, torch.int32, 'bond_i'), (bj, torch.int32, 'bond_j'),
+                                (bc, torch.uint8, 'bond_code')):
+                if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+                    raise L.EagcnHipError('%s must be a contiguous %s device tensor' % (name, dt))
+            E = bm.numel()
+            if bi.numel() != E or bj.numel() != E or tuple(bc.shape) != (E, K):
+                raise L.EagcnHipError('bond arrays disagree: %d / %d / %d bonds, codes %s' % (E, bi.numel(), bj.numel(), tuple(bc.shape)))
+            L.check(lib.eagcn_index_from_bonds(_ptr(bm), _ptr(bi), _ptr(bj), _ptr(bc), E, C.byref(c),
+                                               C.c_void_p(host.data_ptr()), sptr), 'eagcn_index_from_bonds')
         side.synchronize()                # waits for the index kernels only, not for the main stream's backlog
         meta = host.tolist()
+        if meta[L.META_BAD_ADJ] and bonds is not None:
+            raise L.EagcnHipError('%d bonds are out of range or self-loops' % meta[L.META_BAD_ADJ])
         if meta[L.META_BAD_ADJ]:
             raise L.EagcnHipError('adjs holds %d entries outside {0,1}: the hot path requires a 0/1 '
                                   'adjacency (reference neural_fp.py:85,109-110)' % meta[L.META_BAD_ADJ])
@@ -167,7 +196,7 @@ class BatchIndex:
         for t in (self.code, blob):
             t.record_stream(main)         # allocated on `side`, consumed on `main`
         self.c = c
-        self._keep = (adj, rels)
+        self._keep = (adj, rels, bonds)
 
     def ref(self):
         return C.byref(self.c)

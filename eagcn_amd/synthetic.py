@@ -60,6 +60,40 @@ class MolBatch:
     def drop_cache(self):
         self._dense.clear()
 
+    def compact(self, device):
+        """(CompactBonds, afm, size): the same molecules without the dense adjacency / relation tensors."""
+        e = self.edges
+        def dev(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)
+        bonds = CompactBonds(self.B, self.N, list(self.rel_channels), dev(e[:, 0], torch.int32), dev(e[:, 1], torch.int32),
+                             dev(e[:, 2], torch.int32), dev(self.codes, torch.uint8))
+        afm = torch.from_numpy(self.afm).to(device=device, dtype=torch.float32)
+        return bonds, afm, torch.from_numpy(self.sizes).to(device)
+
+
+@dataclass
+class CompactBonds:
+    """Compact description of a batch's bonds for ``EAGCN.forward_compact`` / ``BatchIndex.from_bonds``:
+    every DIRECTED bond exactly once (so both (i,j) and (j,i) are listed), int32 molecule / row / column
+    indices and the bond's type per attention view as uint8 [E,K] (values < channels[k])."""
+    B: int
+    N: int
+    channels: List[int]
+    bond_mol: torch.Tensor
+    bond_i: torch.Tensor
+    bond_j: torch.Tensor
+    bond_code: torch.Tensor
+
+    def checked(self):
+        E = self.bond_mol.numel()
+        for t, dt, name in ((self.bond_mol, torch.int32, 'bond_mol'), (self.bond_i, torch.int32, 'bond_i'),
+                            (self.bond_j, torch.int32, 'bond_j'), (self.bond_code, torch.uint8, 'bond_code')):
+            if t.dtype != dt or not t.is_contiguous() or not t.is_cuda:
+                raise ValueError('%s must be a contiguous %s device tensor' % (name, dt))
+        if self.bond_i.numel() != E or self.bond_j.numel() != E or tuple(self.bond_code.shape) != (E, len(self.channels)):
+            raise ValueError('bond arrays disagree in length')
+        return self.bond_mol, self.bond_i, self.bond_j, self.bond_code
+
 
 def _sample_sizes(rng, B, n_med, n_max, sigma=0.45, force_max=True, n_min=2):
     n = np.rint(rng.lognormal(np.log(n_med), sigma, size=B)).astype(np.int64)

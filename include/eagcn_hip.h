@@ -9,6 +9,8 @@
  *
  *   eagcn_index_*        <- layers.py:294-304 (masks), layers.py:82 (1x1 conv over one-hot
  *                           relation tensors == dictionary lookup), utils.py:575-640 (layout)
+ *   eagcn_index_from_bonds <- the same index from a compact bond list: replaces the dense padding of
+ *                           utils.py:586-640 + neural_fp.py:57-122 on the device side
  *   eagcn_pack_rows / eagcn_unpack_rows
  *                        <- the padded [B,N,F] activation layout of layers.py:293 / models.py:96
  *   eagcn_layer_forward  <- GraphConv_Layer.forward, layers.py:293-316 with
@@ -164,6 +166,12 @@ size_t eagcn_layer_bwd_scratch_bytes(const eagcn_batch* b, const eagcn_layer_par
 /* stage 1: needs code, deg_bn, nat, row0, tile0, meta; copies meta to host_meta (pinned) async */
 int eagcn_index_build(const float* adj, const float* const* rel, eagcn_batch* b,
                       int32_t* host_meta, void* stream);
+/* stage 1 from a COMPACT batch instead of the dense collate tensors: E directed bonds given as
+ * bond_mol/bond_i/bond_j [E] (int32) and bond_code [E][K] (uint8, type index per view, < channels[k]).
+ * Produces exactly the index eagcn_index_build derives from adj + one-hot relation tensors; touches
+ * O(E) input bytes instead of 4*(1+sum C_k)*B*N*N. */
+int eagcn_index_from_bonds(const int32_t* bond_mol, const int32_t* bond_i, const int32_t* bond_j,
+                           const uint8_t* bond_code, int64_t E, eagcn_batch* b, int32_t* host_meta, void* stream);
 /* stage 2 (after the caller read host_meta and allocated the per-row arrays) */
 int eagcn_index_rows(const eagcn_batch* b, void* stream);
 

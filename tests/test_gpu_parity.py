@@ -372,3 +372,56 @@ def test_graph_mode_equals_eager_engine(structure, dropout):
         for _ in range(3):
             b(*bad)
             torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_compact_input_equals_dense_collate(graph):
+    """the batch index built from a compact bond list must equal, bit for bit, the one scanned
+    from the dense collate tensors, and forward_compact must reproduce forward (outputs, gradients, BN)."""
+    from eagcn_amd import EAGCN, ops
+    from eagcn_amd._lib import EagcnHipError
+    from eagcn_amd.synthetic import CompactBonds, make_batch
+    w1, w2 = [9, 7, 5, 5, 6], [12, 8, 6, 6, 8]
+    kw = dict(structure='Concate', n_layers=2, grad_mode='direct', graph=graph)
+    torch.manual_seed(4)
+    a = EAGCN(6, 24, *w1, *w2, 24, 12, 3, 0.2, **kw).cuda().train()
+    b = EAGCN(6, 24, *w1, *w2, 24, 12, 3, 0.2, **kw).cuda().train()
+    b.load_state_dict(a.state_dict())
+    for step in range(3):
+        mb = make_batch(B=13, n_max=33, n_med=9 + step, rel_channels=(6, 4, 2, 2, 2), seed=70 + step,
+                        isolated_frac=0.15 if step == 1 else 0.0)
+        d = _dev(mb.dense())
+        bonds, afm, size = mb.compact('cuda')
+        i_dense = ops.BatchIndex(d[0], d[2:-1])
+        i_comp = ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, *bonds.checked())
+        assert (i_dense.T, i_dense.n_max, i_dense.n_tiles, i_dense.n_edges) == \
+               (i_comp.T, i_comp.n_max, i_comp.n_tiles, i_comp.n_edges)
+        for name in ('code', 'deg_bn', 'nat', 'row0', 'tile0', 'row_mol', 'row_loc', 'row_deg', 'row_m', 'tile_mol'):
+            assert torch.equal(getattr(i_dense, name), getattr(i_comp, name)), name
+        res = []
+        for m, call in ((a, lambda: a(*d)), (b, lambda: b.forward_compact(bonds, afm, size))):
+            torch.manual_seed(200 + step)
+            for p in m.parameters():
+                p.grad = None
+            out, _, gr = call()
+            (out.sum() + (gr * gr).sum()).backward()
+            res.append((out.detach().clone(), gr.detach().clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), step
+        pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+        scale = max(p.grad.abs().max().item() for p in pa.values() if p.grad is not None)
+        for k in pa:
+            if pa[k].grad is not None:      # float atomics reorder sums between runs: tolerance, not equality
+                assert_grad_close(pb[k].grad, pa[k].grad.cpu(), scale, '%s step %d' % (k, step), rtol=1e-5, floor=1e-5)
+    # malformed bond lists are rejected: out-of-range atom, self-loop, type beyond the view's channels
+    bm, bi, bj, bc = bonds.checked()
+    for field, val in (('bond_i', 33), ('bond_j', -1), ('bond_code', 6)):
+        t = {'bond_i': bi.clone(), 'bond_j': bj.clone(), 'bond_code': bc.clone()}
+        if field == 'bond_code':
+            t[field][0, 0] = val
+        else:
+            t[field][0] = val
+        with pytest.raises(EagcnHipError):
+            ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, bm, t['bond_i'], t['bond_j'], t['bond_code'])
+    loop = bi.clone(); loop[0] = int(bj[0])
+    with pytest.raises(EagcnHipError):
+        ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, bm, loop, bj, bc)
