@@ -199,5 +199,7 @@ struct GemmDesc {
     int prof_tag = PROF_GEMM;     // timing class (the head's small GEMMs are kept apart from the layer GEMMs)
 };
 int launch_gemm(const GemmDesc& g, hipStream_t s);
+// up to three products with ta = 1, tb = 0 in one launch (falls back to one launch each otherwise)
+int launch_gemm_group(const GemmDesc* descs, int n, hipStream_t s);
 
 }  // namespace eagcn

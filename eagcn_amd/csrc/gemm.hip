@@ -19,8 +19,10 @@
 
 namespace eagcn {
 
+// one BM x BN output tile of split z; Mx / Kx are the actual extents (<= g.M / g.K)
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, int D>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
+__device__ __forceinline__ void gemm_tile(const GemmDesc& g, const int Mx, const int Kx, const int tile_x,
+                                          const int tile_y, const int z) {
     constexpr int WM = BM / 2, WN = BN / 2;      // 2x2 waves
     constexpr int MR = WM / 16, NR = WN / 16;
     constexpr int LDA_S = A_KC ? (BK + 2) : (BM + 16);
@@ -43,30 +45,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
-    // extents that are known only on the device (packed row count); locals, never written back into
-    // the by-value argument block (that would demote it to scratch memory)
-    const int Mx = g.M_dev ? min(*g.M_dev, g.M) : g.M;
-    const int Kx = g.K_dev ? min(*g.K_dev, g.K) : g.K;
-    // XCD-aware tile order (workgroup b runs on XCD b % 8, each XCD has a private L2): every XCD gets a
-    // contiguous run of the REAL tiles (the grid may be sized for a row capacity), so the column tiles
-    // that share an A row panel hit the same L2.  Bijective for any tile count; affects speed only.
-    int tile_x, tile_y, z;
-    {
-        const int gx = gridDim.x;
-        const int per_z = gx * ((Mx + BM - 1) / BM);           // tiles that have rows, per split
-        const int nwg = per_z * g.splits;
-        const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
-        if (blockIdx.y * gx + blockIdx.x >= per_z) return;     // uniform: capacity-only workgroup
-        // linear dispatch index of the REAL workgroups (capacity-only ones were skipped above)
-        const int lin = blockIdx.z * per_z + blockIdx.y * gx + blockIdx.x;
-        (void)bid;
-        const int xcd = lin & 7, qn = nwg >> 3, rn = nwg & 7;
-        const int nid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lin >> 3);
-        z = nid / per_z;                                       // all tiles of one K-split land on one or two XCDs
-        const int rem = nid - z * per_z;
-        tile_y = rem / gx;
-        tile_x = rem - tile_y * gx;
-    }
     const int m0 = tile_y * BM, n0 = tile_x * BN;
     // split-K range
     const int kchunk = ((Kx + g.splits - 1) / g.splits + BK - 1) / BK * BK;
@@ -227,6 +205,56 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
         }
 }
 
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int D>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
+    // extents that are known only on the device (packed row count); locals, never written back into
+    // the by-value argument block (that would demote it to scratch memory)
+    const int Mx = g.M_dev ? min(*g.M_dev, g.M) : g.M;
+    const int Kx = g.K_dev ? min(*g.K_dev, g.K) : g.K;
+    // XCD-aware tile order (workgroup b runs on XCD b % 8, each XCD has a private L2): every XCD gets a
+    // contiguous run of the REAL tiles (the grid may be sized for a row capacity), so the column tiles
+    // that share an A row panel hit the same L2.  Bijective for any tile count; affects speed only.
+    int tile_x, tile_y, z;
+    {
+        const int gx = gridDim.x;
+        const int per_z = gx * ((Mx + BM - 1) / BM);           // tiles that have rows, per split
+        const int nwg = per_z * g.splits;
+        const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
+        if (blockIdx.y * gx + blockIdx.x >= per_z) return;     // uniform: capacity-only workgroup
+        // linear dispatch index of the REAL workgroups (capacity-only ones were skipped above)
+        const int lin = blockIdx.z * per_z + blockIdx.y * gx + blockIdx.x;
+        (void)bid;
+        const int xcd = lin & 7, qn = nwg >> 3, rn = nwg & 7;
+        const int nid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lin >> 3);
+        z = nid / per_z;                                       // all tiles of one K-split land on one or two XCDs
+        const int rem = nid - z * per_z;
+        tile_y = rem / gx;
+        tile_x = rem - tile_y * gx;
+    }
+    gemm_tile<BM, BN, BK, A_KC, B_KC, D>(g, Mx, Kx, tile_x, tile_y, z);
+}
+
+// Up to three independent products of the dW form (A stored [K][M], B stored [K][N]) in ONE launch: the head's
+// three weight-gradient products are each a handful of tiles, so one grid covers them all.
+struct GemmGroup {
+    GemmDesc d0, d1, d2;
+    int first1, first2;     // first workgroup of problem 1 / 2 (problem 0 starts at 0)
+};
+template <int BM, int BN, int BK, int D>
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroup gg) {
+    auto run = [&](const GemmDesc& g, int lin) {
+        const int gx = (g.N + BN - 1) / BN;
+        const int per_z = gx * ((g.M + BM - 1) / BM);
+        const int z = lin / per_z, rem = lin - z * per_z;
+        const int ty = rem / gx;
+        gemm_tile<BM, BN, BK, false, false, D>(g, g.M, g.K, rem - ty * gx, ty, z);
+    };
+    const int b = blockIdx.x;
+    if (b < gg.first1) run(gg.d0, b);
+    else if (b < gg.first2) run(gg.d1, b - gg.first1);
+    else run(gg.d2, b - gg.first2);
+}
+
 template <int BM, int BN, int BK, int D>
 static int launch_cfg(const GemmDesc& g, hipStream_t s) {
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.splits);
@@ -265,6 +293,35 @@ int launch_gemm(const GemmDesc& g0, hipStream_t s) {
         case 5: return launch_cfg<64, 64, 16, 1>(g, s);
         default: return launch_cfg<64, 64, 16, 4>(g, s);
     }
+}
+
+int launch_gemm_group(const GemmDesc* descs, int n, hipStream_t s) {
+    EAGCN_CHECK_ARG(n >= 1 && n <= 3, "gemm group: 1..3 products");
+    GemmGroup gg;
+    GemmDesc d[3];
+    int wgs[3] = {0, 0, 0};
+    bool ok = true;
+    for (int i = 0; i < 3; ++i) {
+        d[i] = descs[i < n ? i : n - 1];
+        GemmDesc& g = d[i];
+        g.vecA = (g.lda % 4) == 0 && (g.M % 4) == 0 && (reinterpret_cast<uintptr_t>(g.A) % 16) == 0;
+        g.vecB = (g.ldb % 4) == 0 && (g.N % 4) == 0 && (reinterpret_cast<uintptr_t>(g.B) % 16) == 0;
+        ok = ok && g.ta == 1 && g.tb == 0 && !g.M_dev && !g.K_dev && g.M > 0 && g.N > 0 && (g.splits == 1 || (g.vecA && g.vecB));
+        if (i < n) wgs[i] = cdiv(g.M, 64) * cdiv(g.N, 64) * g.splits;
+    }
+    if (!ok) {                     // not the grouped form: one launch per product
+        for (int i = 0; i < n; ++i) { int rc = launch_gemm(descs[i], s); if (rc) return rc; }
+        return EAGCN_OK;
+    }
+    gg.d0 = d[0]; gg.d1 = d[1]; gg.d2 = d[2];
+    gg.first1 = wgs[0];
+    gg.first2 = wgs[0] + wgs[1];
+    double work = 0.0;
+    for (int i = 0; i < n; ++i) work += d[i].work > 0.0 ? d[i].work : 2.0 * d[i].M * d[i].N * d[i].K;
+    ProfScope ps(d[0].prof_tag, s, work);
+    gemm_f32_group_kernel<64, 64, 16, 4><<<wgs[0] + wgs[1] + wgs[2], 256, 0, s>>>(gg);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
 }
 
 }  // namespace eagcn

@@ -10,6 +10,8 @@
 // The head's BatchNorm1d layers work on [B, F] matrices.  BatchNorm over rows is independent per
 // column, so one workgroup that owns 16 columns does statistics AND normalisation for them in a
 // single kernel (no grid-wide reduction): rowbn_fwd_kernel / rowbn_bwd_kernel.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -23,6 +25,9 @@ constexpr int HEAD_MAX_SPLITS = 16;   // split-K factor bound of the head's weig
 struct RowBnFwd {
     int R, F;
     const float* x; float* y;            // [R][F]
+    int splits; size_t stride;           // x is the sum of `splits` partial matrices `stride` floats apart (split-K)
+    float* xs;                           // splits > 1: the summed x is stored here (kept for backward)
+    float* x2;                           // optional second copy of x (graph_representation)
     const float* gamma; const float* beta;
     float* run_mean; float* run_var;
     float* bn;                           // [4][F]
@@ -52,6 +57,13 @@ __global__ __launch_bounds__(16 * RL) void rowbn_fwd_kernel(RowBnFwd a) {
         for (int t = 0; t < RB_CACHE; ++t) {
             const int r = base + rl + RL * t;
             v[t] = r < a.R ? a.x[(size_t)r * a.F + c] : 0.0f;
+        }
+        for (int z = 1; z < a.splits; ++z) {           // fixed order: deterministic sum of the split-K partials
+#pragma unroll
+            for (int t = 0; t < RB_CACHE; ++t) {
+                const int r = base + rl + RL * t;
+                if (r < a.R) v[t] += a.x[(size_t)z * a.stride + (size_t)r * a.F + c];
+            }
         }
     };
     float mu, inv;
@@ -105,6 +117,8 @@ __global__ __launch_bounds__(16 * RL) void rowbn_fwd_kernel(RowBnFwd a) {
         for (int t = 0; t < RB_CACHE; ++t) {
             const int r = base + rl + RL * t;
             if (r < a.R) {
+                if (a.splits > 1) a.xs[(size_t)r * a.F + c] = v[t];
+                if (a.x2) a.x2[(size_t)r * a.F + c] = v[t];
                 float h = v[t] * sc + sh;
                 if (a.relu) h = fmaxf(h, 0.0f);
                 if (a.do_drop) h *= drop_scale(seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
@@ -117,6 +131,7 @@ __global__ __launch_bounds__(16 * RL) void rowbn_fwd_kernel(RowBnFwd a) {
 struct RowBnBwd {
     int R, F;
     const float* dy; const float* x; const float* bn;
+    int splits; size_t stride;           // dy is the sum of `splits` split-K partials `stride` floats apart
     const float* extra;                  // added to dx (gradient that reaches x directly), or null
     float* dx; float* dgamma; float* dbeta;
     int training, relu, do_drop;
@@ -141,6 +156,13 @@ __global__ __launch_bounds__(16 * RL) void rowbn_bwd_kernel(RowBnBwd a) {
             const int r = base + rl + RL * t;
             xv[t] = r < a.R ? a.x[(size_t)r * a.F + c] : 0.0f;
             dh[t] = r < a.R ? a.dy[(size_t)r * a.F + c] : 0.0f;
+        }
+        for (int z = 1; z < a.splits; ++z) {
+#pragma unroll
+            for (int t = 0; t < RB_CACHE; ++t) {
+                const int r = base + rl + RL * t;
+                if (r < a.R) dh[t] += a.dy[(size_t)z * a.stride + (size_t)r * a.F + c];
+            }
         }
 #pragma unroll
         for (int t = 0; t < RB_CACHE; ++t) {
@@ -206,6 +228,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// the same for up to three result matrices in one launch (the head's three weight gradients)
+struct Reduce3 { const float* slab[3]; float* out[3]; int n[3]; int splits[3]; };
+__global__ __launch_bounds__(256) void splitk_reduce3_kernel(Reduce3 a) {
+    const int n0 = a.n[0], n1 = a.n[1], n2 = a.n[2];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1 + n2; i += gridDim.x * blockDim.x) {
+        const int w = i < n0 ? 0 : (i < n0 + n1 ? 1 : 2);
+        const int e = i - (w == 0 ? 0 : (w == 1 ? n0 : n0 + n1));
+        const float* slab = w == 0 ? a.slab[0] : (w == 1 ? a.slab[1] : a.slab[2]);
+        float* out = w == 0 ? a.out[0] : (w == 1 ? a.out[1] : a.out[2]);
+        const int n = w == 0 ? n0 : (w == 1 ? n1 : n2);
+        const int splits = w == 0 ? a.splits[0] : (w == 1 ? a.splits[1] : a.splits[2]);
+        float s0 = 0.0f;
+        for (int z = 0; z < splits; ++z) s0 += slab[(size_t)z * n + e];
+        out[e] = s0;
+    }
+}
+
 // ---- carving of the saved-for-backward block and of the transient scratch ---------------------------
 struct Carver2 {
     char* base;
@@ -265,7 +304,7 @@ static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m
 }
 
 struct ModelScratch {
-    float *da2, *dh2, *da1, *dh1, *dgn, *dg, *dxa, *dxb, *dpad, *gsplit, *gsplit2;
+    float *da2, *dh2, *da1, *dh1, *dgn, *dg, *dxa, *dxb, *dpad, *gsplit, *gsplit2, *gw1, *gw2, *gw3;
     void* layer; size_t layer_bytes;
 };
 static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model* m, ModelScratch* out) {
@@ -285,6 +324,10 @@ static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model*
         mx = std::max(mx, Bn * (size_t)std::max(h->f_in, std::max(h->n_den1, h->n_den2)));
         s.gsplit = c.take<float>((size_t)HEAD_MAX_SPLITS * mx);
         s.gsplit2 = c.take<float>((size_t)HEAD_MAX_SPLITS * mx);
+        // split-K partials of the three weight gradients (alive together: one grouped launch)
+        s.gw1 = c.take<float>((size_t)HEAD_MAX_SPLITS * h->f_in * h->n_den1);
+        s.gw2 = c.take<float>((size_t)HEAD_MAX_SPLITS * h->n_den1 * h->n_den2);
+        s.gw3 = c.take<float>((size_t)HEAD_MAX_SPLITS * h->n_den2 * h->nclass);
     }
     int ldmax = 0;
     size_t lbytes = 0;
@@ -338,11 +381,15 @@ static void fill_drop(float p, int training, int* do_drop, uint32_t* thr, float*
     *inv_keep = 1.0f / (1.0f - p);
 }
 
-static int rowbn_fwd(hipStream_t s, int R, int F, const float* x, float* y, const float* g, const float* be,
-                     float* rm, float* rv, float* bn, int training, int relu, float dropout, uint64_t seed,
-                     const uint64_t* seed_dev, float eps, float mom) {
+// a matrix that may still be `splits` split-K partials `stride` floats apart (summed by its consumer)
+struct Partial { const float* p; int splits; size_t stride; };
+
+static int rowbn_fwd(hipStream_t s, int R, int F, Partial x, float* xs, float* x2, float* y, const float* g,
+                     const float* be, float* rm, float* rv, float* bn, int training, int relu, float dropout,
+                     uint64_t seed, const uint64_t* seed_dev, float eps, float mom) {
     RowBnFwd a;
-    a.R = R; a.F = F; a.x = x; a.y = y; a.gamma = g; a.beta = be; a.run_mean = rm; a.run_var = rv; a.bn = bn;
+    a.R = R; a.F = F; a.x = x.p; a.splits = x.splits; a.stride = x.stride; a.xs = xs; a.x2 = x2; a.y = y;
+    a.gamma = g; a.beta = be; a.run_mean = rm; a.run_var = rv; a.bn = bn;
     a.training = training; a.relu = relu; a.eps = eps; a.momentum = mom; a.seed = seed; a.seed_dev = seed_dev;
     fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
     ProfScope ps(PROF_HEAD, s);
@@ -351,11 +398,12 @@ static int rowbn_fwd(hipStream_t s, int R, int F, const float* x, float* y, cons
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
-static int rowbn_bwd(hipStream_t s, int R, int F, const float* dy, const float* x, const float* bn,
+static int rowbn_bwd(hipStream_t s, int R, int F, Partial dy, const float* x, const float* bn,
                      const float* extra, float* dx, float* dgamma, float* dbeta, int training, int relu,
                      float dropout, uint64_t seed, const uint64_t* seed_dev) {
     RowBnBwd a;
-    a.R = R; a.F = F; a.dy = dy; a.x = x; a.bn = bn; a.extra = extra; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.R = R; a.F = F; a.dy = dy.p; a.splits = dy.splits; a.stride = dy.stride; a.x = x; a.bn = bn; a.extra = extra;
+    a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta;
     a.training = training; a.relu = relu; a.seed = seed; a.seed_dev = seed_dev;
     fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
     ProfScope ps(PROF_HEAD, s);
@@ -373,32 +421,60 @@ static int mm(hipStream_t s, int ta, int tb, int M, int N, int K, const float* A
 
 // The head's products have few output tiles (B x 256, 700 x 256, ...) and a comparatively long K: with one
 // workgroup per tile they occupy a few percent of the chip and are a serial chain of k-tiles (256x256x700:
-// 16 workgroups, 28 us).  Split K over more workgroups and sum the partial slabs in a second tiny launch.
-static int head_splits(int M, int N, int K) {
-    const int tiles = cdiv(M, 64) * cdiv(N, 64);
-    if (tiles >= 96 || K < 128) return 1;
-    const int by_k = K / 64;                                  // at least four k-tiles per split
+// 16 workgroups, 28 us).  Split K over more workgroups; the partial slabs are summed by the CONSUMER of the
+// product (the row-BatchNorm kernels read `splits` partials), so no separate reduction launch exists on the
+// activation path.
+static int head_splits(int tiles, int K) {
+    static const int div = [] { const char* e = getenv("EAGCN_HEAD_KDIV"); return e ? atoi(e) : 128; }();
+    if (tiles >= 96 || K < 2 * div) return 1;
+    const int by_k = K / div;                                 // at least div/16 k-tiles per split
     const int by_fill = cdiv(256, std::max(tiles, 1));        // aim at ~one workgroup per CU
     return std::max(1, std::min(std::min(HEAD_MAX_SPLITS, by_k), by_fill));
 }
-static int mm_split(hipStream_t s, int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
-                    int ldb, float* C, float* slab) {
-    const int splits = head_splits(M, N, K);
+static bool split_ok(int ta, int tb, int M, int N, int K, int lda, int ldb) {
     // split-K needs float4-aligned operands and a dense [M][N] result
-    const bool vec = (lda % 4) == 0 && (ldb % 4) == 0 && ((ta ? M : K) % 4) == 0 && ((tb ? K : N) % 4) == 0;
-    if (splits == 1 || !vec) return mm(s, ta, tb, M, N, K, A, lda, B, ldb, C, N);
+    return (lda % 4) == 0 && (ldb % 4) == 0 && ((ta ? M : K) % 4) == 0 && ((tb ? K : N) % 4) == 0;
+}
+// C = A.B, or its split-K partials in `slab` (then *out describes them and C is NOT written)
+static int mm_partial(hipStream_t s, int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
+                      int ldb, float* C, float* slab, Partial* out) {
+    const int splits = split_ok(ta, tb, M, N, K, lda, ldb) ? head_splits(cdiv(M, 64) * cdiv(N, 64), K) : 1;
+    if (splits == 1) {
+        *out = Partial{C, 1, 0};
+        return mm(s, ta, tb, M, N, K, A, lda, B, ldb, C, N);
+    }
     GemmDesc g{ta, tb, M, N, K, A, lda, B, ldb, slab, N, splits, (size_t)M * N};
     g.prof_tag = PROF_HEAD;
-    int rc = launch_gemm(g, s);
-    if (rc) return rc;
+    *out = Partial{slab, splits, (size_t)M * N};
+    return launch_gemm(g, s);
+}
+// the three weight gradients dW_i = A_i^T . B_i (rows = batch) as one grouped launch + one reduction launch
+struct DwProblem { int M, N; const float* A; const float* B; float* C; float* slab; };
+static int head_dw(hipStream_t s, int K, const DwProblem* pr) {
+    int tiles = 0;
+    bool ok = true;
+    for (int i = 0; i < 3; ++i) {
+        tiles += cdiv(pr[i].M, 64) * cdiv(pr[i].N, 64);
+        ok = ok && split_ok(1, 0, pr[i].M, pr[i].N, K, pr[i].M, pr[i].N);
+    }
+    const int splits = ok ? head_splits(tiles, K) : 1;
+    GemmDesc d[3];
+    Reduce3 r;
+    int total = 0;
+    for (int i = 0; i < 3; ++i) {
+        float* dst = splits > 1 ? pr[i].slab : pr[i].C;
+        d[i] = GemmDesc{1, 0, pr[i].M, pr[i].N, K, pr[i].A, pr[i].M, pr[i].B, pr[i].N, dst, pr[i].N, splits,
+                        (size_t)pr[i].M * pr[i].N};
+        d[i].prof_tag = PROF_HEAD;
+        r.slab[i] = pr[i].slab; r.out[i] = pr[i].C; r.n[i] = pr[i].M * pr[i].N; r.splits[i] = splits;
+        total += r.n[i];
+    }
+    int rc = launch_gemm_group(d, 3, s);
+    if (rc || splits == 1) return rc;
     ProfScope ps(PROF_HEAD, s);
-    splitk_reduce_kernel<<<std::min(cdiv(M * N, 256), 1024), 256, 0, s>>>(slab, M * N, splits, C);
+    splitk_reduce3_kernel<<<std::min(cdiv(total, 256), 1024), 256, 0, s>>>(r);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
-}
-static int mm_dw(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                 float* slab) {
-    return mm_split(s, 1, 0, M, N, K, A, lda, B, ldb, C, slab);
 }
 
 }  // namespace eagcn
@@ -462,15 +538,16 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
     RC(eagcn_readout_forward(b, LL.xout, &lay, last->structure == EAGCN_STRUCT_WEIGHTED ? LL.pad_row : nullptr,
                              size, m->molfp_mode, sv.g, F, stream));
-    RC(rowbn_fwd(s, B, F, sv.g, sv.gn, h->gbn_w, h->gbn_b, h->gbn_rm, h->gbn_rv, sv.bn_g, m->training, 0, 0.0f, 0,
-                 nullptr, h->bn_eps, h->bn_momentum));
-    RC(mm_split(s, 0, 0, B, n1, F, sv.gn, F, h->den1_w, n1, sv.h1, sc.gsplit));
-    RC(rowbn_fwd(s, B, n1, sv.h1, sv.a1, h->bn1_w, h->bn1_b, h->bn1_rm, h->bn1_rv, sv.bn_1, m->training, 1,
+    Partial ph;
+    RC(rowbn_fwd(s, B, F, Partial{sv.g, 1, 0}, nullptr, nullptr, sv.gn, h->gbn_w, h->gbn_b, h->gbn_rm, h->gbn_rv, sv.bn_g,
+                 m->training, 0, 0.0f, 0, nullptr, h->bn_eps, h->bn_momentum));
+    RC(mm_partial(s, 0, 0, B, n1, F, sv.gn, F, h->den1_w, n1, sv.h1, sc.gsplit, &ph));
+    RC(rowbn_fwd(s, B, n1, ph, sv.h1, nullptr, sv.a1, h->bn1_w, h->bn1_b, h->bn1_rm, h->bn1_rv, sv.bn_1, m->training, 1,
                  h->dropout, m->head_seed, m->head_seed_dev, h->bn_eps, h->bn_momentum));
-    RC(mm_split(s, 0, 0, B, n2, n1, sv.a1, n1, h->den2_w, n2, sv.h2, sc.gsplit));
-    EAGCN_HIP(hipMemcpyAsync(graph_rep, sv.h2, (size_t)B * n2 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    RC(rowbn_fwd(s, B, n2, sv.h2, sv.a2, h->bn2_w, h->bn2_b, h->bn2_rm, h->bn2_rv, sv.bn_2, m->training, 1, 0.0f, 0,
-                 nullptr, h->bn_eps, h->bn_momentum));
+    RC(mm_partial(s, 0, 0, B, n2, n1, sv.a1, n1, h->den2_w, n2, sv.h2, sc.gsplit, &ph));
+    // bn_den2 also sums the partials of den2 into h2 and writes the graph_representation copy
+    RC(rowbn_fwd(s, B, n2, ph, sv.h2, graph_rep, sv.a2, h->bn2_w, h->bn2_b, h->bn2_rm, h->bn2_rv, sv.bn_2, m->training, 1,
+                 0.0f, 0, nullptr, h->bn_eps, h->bn_momentum));
     RC(mm(s, 0, 0, B, nc, n2, sv.a2, n2, h->den3_w, nc, out, nc));
     return EAGCN_OK;
 }
@@ -490,25 +567,26 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_backward: scratch too small");
     const eagcn_head_params* h = &m->head;
     const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
-    // weight-gradient products are off the critical path: they go to the auxiliary stream when there is one
     hipStream_t side = m->aux_stream ? (hipStream_t)m->aux_stream : s;
     const bool forked = side != s;
-    if (forked) RC(stream_after(side, s));
-    // den3
-    RC(mm_dw(side, n2, nc, B, sv.a2, n2, dout, nc, hg->d_den3_w, sc.gsplit));
+    Partial pd;
+    // den3 -> bn_den2 -> den2 -> bn_den1 -> den1 -> Graph_BN: the dX chain
     RC(mm(s, 0, 1, B, n2, nc, dout, nc, h->den3_w, nc, sc.da2, n2));
-    RC(rowbn_bwd(s, B, n2, sc.da2, sv.h2, sv.bn_2, dgraph_rep, sc.dh2, hg->d_bn2_w, hg->d_bn2_b, m->training, 1, 0.0f, 0, nullptr));
-    // den2
-    if (forked) RC(stream_after(side, s));                       // dh2 is ready
-    RC(mm_dw(side, n1, n2, B, sv.a1, n1, sc.dh2, n2, hg->d_den2_w, sc.gsplit));
-    RC(mm_split(s, 0, 1, B, n1, n2, sc.dh2, n2, h->den2_w, n2, sc.da1, sc.gsplit2));
-    RC(rowbn_bwd(s, B, n1, sc.da1, sv.h1, sv.bn_1, nullptr, sc.dh1, hg->d_bn1_w, hg->d_bn1_b, m->training, 1, h->dropout,
+    RC(rowbn_bwd(s, B, n2, Partial{sc.da2, 1, 0}, sv.h2, sv.bn_2, dgraph_rep, sc.dh2, hg->d_bn2_w, hg->d_bn2_b, m->training,
+                 1, 0.0f, 0, nullptr));
+    RC(mm_partial(s, 0, 1, B, n1, n2, sc.dh2, n2, h->den2_w, n2, sc.da1, sc.gsplit2, &pd));
+    RC(rowbn_bwd(s, B, n1, pd, sv.h1, sv.bn_1, nullptr, sc.dh1, hg->d_bn1_w, hg->d_bn1_b, m->training, 1, h->dropout,
                  m->head_seed, m->head_seed_dev));
-    // den1
-    if (forked) RC(stream_after(side, s));                       // dh1 is ready
-    RC(mm_dw(side, F, n1, B, sv.gn, F, sc.dh1, n1, hg->d_den1_w, sc.gsplit));
-    RC(mm_split(s, 0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, sc.dgn, sc.gsplit2));
-    RC(rowbn_bwd(s, B, F, sc.dgn, sv.g, sv.bn_g, nullptr, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training, 0, 0.0f, 0, nullptr));
+    // the three weight gradients need dout, dh2, dh1: one grouped launch, off the dX critical path
+    if (forked) RC(stream_after(side, s));
+    {
+        const DwProblem pr[3] = {{F, n1, sv.gn, sc.dh1, hg->d_den1_w, sc.gw1},
+                                 {n1, n2, sv.a1, sc.dh2, hg->d_den2_w, sc.gw2},
+                                 {n2, nc, sv.a2, dout, hg->d_den3_w, sc.gw3}};
+        RC(head_dw(side, B, pr));
+    }
+    RC(mm_partial(s, 0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, sc.dgn, sc.gsplit2, &pd));
+    RC(rowbn_bwd(s, B, F, pd, sv.g, sv.bn_g, nullptr, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training, 0, 0.0f, 0, nullptr));
     // read-out
     const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
     const eagcn_layout lay = out_layout(last);
