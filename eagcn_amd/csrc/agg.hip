@@ -27,15 +27,15 @@ namespace eagcn {
 // Variant for large batches: one WAVEFRONT per tile (four tiles per workgroup in flight); with thousands of
 // small tiles this keeps 4x more tiles in flight than the K-split variant below.
 template <int CT, bool TRANS>
-__global__ __launch_bounds__(256) void agg_wave_kernel(AggArgs a) {
+__device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, const int by, const int gx) {
     __shared__ float sig_s[256];
     __shared__ double st_s[TRANS ? 1 : CT * 16 * 2];
-    const int k = blockIdx.y / a.nchunk, cc = blockIdx.y % a.nchunk;
+    const int k = by / a.nchunk, cc = by % a.nchunk;
     const int ntile_k = (a.vc.off[k + 1] - a.vc.off[k]) / 16;
     const int ct0 = cc * CT;
     if (ct0 >= ntile_k) return;                       // uniform for the whole workgroup
     const int ntiles = dev_tiles(a.bt);
-    if ((int)blockIdx.x * 4 >= ntiles) return;        // capacity-sized grid: no tile for this workgroup (its
+    if (bx * 4 >= ntiles) return;        // capacity-sized grid: no tile for this workgroup (its
                                                       // stats slab is not read either: bn_finalize counts live slabs)
     const int nct = min(CT, ntile_k - ct0);
     const int c0 = a.vc.off[k] + ct0 * 16;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void agg_wave_kernel(AggArgs a) {
 #pragma unroll
     for (int c = 0; c < CT; ++c) { s1[c] = 0.0; s2[c] = 0.0; }
 
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    for (int tile = bx * 4 + wave; tile < ntiles; tile += gx * 4) {
         const int b = bt.tile_mol[tile];
         const int rt = tile - bt.tile0[b];
         const int n = bt.nat[b], r0 = bt.row0[b];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void agg_wave_kernel(AggArgs a) {
     }
 
     if (!TRANS) {
-        // per-workgroup partial BatchNorm sums -> slab[blockIdx.x][column][2]
+        // per-workgroup partial BatchNorm sums -> slab[bx][column][2]
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             s1[ct] += __shfl_xor(s1[ct], 16);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void agg_wave_kernel(AggArgs a) {
         }
         const int fp = a.vc.off[a.vc.K];
         for (int i = tid; i < nct * 16 * 2; i += 256)
-            a.stats[((size_t)blockIdx.x * fp + c0) * 2 + i] = st_s[i];
+            a.stats[((size_t)bx * fp + c0) * 2 + i] = st_s[i];
     }
 }
 
@@ -190,17 +190,17 @@ __global__ __launch_bounds__(256) void agg_wave_kernel(AggArgs a) {
 // done after 2); splitting the groups over the waves cuts that chain 4x.  Partial accumulators and partial
 // row sums are combined through LDS by wave 0, which also runs the epilogue.
 template <int CT, bool TRANS>
-__global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
+__device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const int by, const int gx) {
     __shared__ float sig_s[256];
     __shared__ float red_s[CT][4][64];                // ONE partial-accumulator buffer, reused wave by wave
     __shared__ float dred_s[4][16];
     __shared__ double st_s[TRANS ? 1 : CT * 16 * 2];
-    const int k = blockIdx.y / a.nchunk, cc = blockIdx.y % a.nchunk;
+    const int k = by / a.nchunk, cc = by % a.nchunk;
     const int ntile_k = (a.vc.off[k + 1] - a.vc.off[k]) / 16;
     const int ct0 = cc * CT;
     if (ct0 >= ntile_k) return;                       // uniform for the whole workgroup
     const int ntiles = dev_tiles(a.bt);
-    if ((int)blockIdx.x >= ntiles) return;            // capacity-sized grid: no tile for this workgroup (its
+    if (bx >= ntiles) return;            // capacity-sized grid: no tile for this workgroup (its
                                                       // stats slab is not read either: bn_finalize counts live slabs)
     const int nct = min(CT, ntile_k - ct0);
     const int c0 = a.vc.off[k] + ct0 * 16;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
 #pragma unroll
     for (int c = 0; c < CT; ++c) { s1[c] = 0.0; s2[c] = 0.0; }
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = bx; tile < ntiles; tile += gx) {
         const int4 ti = reinterpret_cast<const int4*>(bt.tile_info)[tile];
         const int b = ti.x, rt = ti.y, n = ti.z, r0 = ti.w;
         const uint8_t* codeb = bt.code + ((size_t)k * bt.B + b) * bt.N * bt.ldc;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
     }
 
     if (!TRANS) {
-        // per-workgroup partial BatchNorm sums (held by wave 0) -> slab[blockIdx.x][column][2]
+        // per-workgroup partial BatchNorm sums (held by wave 0) -> slab[bx][column][2]
         if (wave == 0) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
@@ -381,9 +381,14 @@ __global__ __launch_bounds__(256) void agg_kernel(AggArgs a) {
         __syncthreads();
         const int fp = a.vc.off[a.vc.K];
         for (int i = tid; i < nct * 16 * 2; i += 256)
-            a.stats[((size_t)blockIdx.x * fp + c0) * 2 + i] = st_s[i];
+            a.stats[((size_t)bx * fp + c0) * 2 + i] = st_s[i];
     }
 }
+
+template <int CT, bool TRANS>
+__global__ __launch_bounds__(256) void agg_wave_kernel(AggArgs a) { agg_wave_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
+template <int CT, bool TRANS>
+__global__ __launch_bounds__(256) void agg_kernel(AggArgs a) { agg_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 template <bool TRANS>
 static int launch_agg_t(const AggArgs& a, int ct, dim3 grid, bool ksplit, hipStream_t s) {
@@ -430,7 +435,7 @@ int launch_agg(AggArgs a, bool trans, hipStream_t s) {
 //   dU[i,j]   = (m_i / rowsum_i) (dA^[i,j] - rowdot_i)
 //   d w_k[c] += dU[i,j] s (1-s)  at bonds of type c ;   d self_r_k += dU[i,i] r (1-r)
 // one wavefront per (packed row, view); results accumulated in fp64.
-__global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
+__device__ __forceinline__ void edge_grad_body(const EdgeArgs& a, const int bx, const int by, const int gx) {
     // one packed row per 16-lane group (4 rows per wavefront, 16 per workgroup).
     // Dependent-load hops per row: {row_info, rscale} -> {code row, dY row, Y row} -> {P rows of up to four
     // bonds at once}.  The code row arrives with ONE 16-byte load per lane (16 lanes x 16 bytes = 256 columns);
@@ -442,9 +447,9 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
     __shared__ int hit_s[16][HMAX];                                // (column << 8) | bond code
     const eagcn_batch& bt = a.bt;
     const int Tn = dev_rows(bt);
-    if ((int)blockIdx.x * 16 >= Tn) return;                        // capacity-sized grid (slab not read either)
-    const int nwg = min((int)gridDim.x, (Tn + 15) / 16);           // workgroups that have rows
-    const int k = blockIdx.y;
+    if (bx * 16 >= Tn) return;                        // capacity-sized grid (slab not read either)
+    const int nwg = min(gx, (Tn + 15) / 16);           // workgroups that have rows
+    const int k = by;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane >> 4, sl = lane & 15;
     const int gq = wave * 4 + grp;                                 // group index inside the workgroup
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
     __syncthreads();
     const int off = a.vc.off[k], fp = a.vc.off[k + 1] - a.vc.off[k];
     double dr_acc = 0.0;
-    for (int rblk = blockIdx.x; rblk * 16 < Tn; rblk += nwg) {     // one trip unless the grid was capped
+    for (int rblk = bx; rblk * 16 < Tn; rblk += nwg) {     // one trip unless the grid was capped
         const int r = (rblk * 4 + wave) * 4 + grp;
         int4 info = make_int4(0, 0, 0, 0);
         float rs = 0.0f;
@@ -531,13 +536,30 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) {
     }
     if (sl == 0) dr_s[wave * 4 + grp] = dr_acc;
     __syncthreads();
-    // slab[blockIdx.x][k][0..255] = bond-type histogram, slab[..][k][256] = self term
-    double* out = a.datt + ((size_t)blockIdx.x * a.vc.K + k) * EDGE_SLAB;
+    // slab[bx][k][0..255] = bond-type histogram, slab[..][k][256] = self term
+    double* out = a.datt + ((size_t)bx * a.vc.K + k) * EDGE_SLAB;
     out[tid] = h_s[tid];
     if (tid == 0) {
         double t = 0.0;
         for (int q = 0; q < 16; ++q) t += dr_s[q];
         out[256] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) { edge_grad_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
+
+// Transposed aggregation and edge gradients of one layer in ONE grid: both only read dY' (and saved
+// activations), both are chains of dependent loads that leave most of a CU idle, and neither fills the chip
+// alone -- side by side they overlap instead of running back to back.  Workgroups [0, agg_gx) of every grid row
+// run the aggregation, the rest the edge gradients (grid rows beyond the view count have none).
+template <int CT, bool KSPLIT>
+__global__ __launch_bounds__(256) void agg_edge_kernel(AggArgs a, EdgeArgs e, int agg_gx) {
+    const int bx = blockIdx.x;
+    if (bx < agg_gx) {
+        if constexpr (KSPLIT) agg_body<CT, true>(a, bx, blockIdx.y, agg_gx);
+        else agg_wave_body<CT, true>(a, bx, blockIdx.y, agg_gx);
+    } else if ((int)blockIdx.y < e.vc.K) {
+        edge_grad_body(e, bx - agg_gx, blockIdx.y, (int)gridDim.x - agg_gx);
     }
 }
 
@@ -549,6 +571,30 @@ int launch_edge_grad(const EdgeArgs& a, hipStream_t s) {
     dim3 grid(edge_grid_x(&a.bt), a.vc.K);
     ProfScope ps(PROF_EDGE, s);
     edge_grad_kernel<<<grid, 256, 0, s>>>(a);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+// transposed aggregation + edge gradients in one launch (see agg_edge_kernel)
+int launch_agg_edge(AggArgs a, const EdgeArgs& e, hipStream_t s) {
+    if (a.bt.n_tiles == 0 || a.bt.T == 0) return EAGCN_OK;
+    int tmax = 0;
+    for (int k = 0; k < a.vc.K; ++k) tmax = std::max(tmax, (a.vc.off[k + 1] - a.vc.off[k]) / 16);
+    const int nchunk = cdiv(tmax, 10);
+    const int ct = cdiv(tmax, nchunk);
+    a.nchunk = nchunk;
+    const int agx = agg_grid_x(&a.bt), egx = edge_grid_x(&a.bt);
+    dim3 grid(agx + egx, a.vc.K * nchunk);
+    const bool ks = agg_ksplit(&a.bt);
+    ProfScope ps(PROF_AGG, s);
+    switch (ct) {
+#define EAGCN_AE_CASE(N) case N: if (ks) agg_edge_kernel<N, true><<<grid, 256, 0, s>>>(a, e, agx); \
+                                 else agg_edge_kernel<N, false><<<grid, 256, 0, s>>>(a, e, agx); break;
+        EAGCN_AE_CASE(1) EAGCN_AE_CASE(2) EAGCN_AE_CASE(3) EAGCN_AE_CASE(4) EAGCN_AE_CASE(5)
+        EAGCN_AE_CASE(6) EAGCN_AE_CASE(7) EAGCN_AE_CASE(8) EAGCN_AE_CASE(9) EAGCN_AE_CASE(10)
+#undef EAGCN_AE_CASE
+        default: set_error("agg: unsupported CT %d", ct); return EAGCN_ERR_ARG;
+    }
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

@@ -593,7 +593,11 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
     const bool weighted = last->structure == EAGCN_STRUCT_WEIGHTED;
     float* cur = sc.dxa;
     float* other = sc.dxb;
-    RC(eagcn_readout_backward(b, sc.dg, &lay, size, m->molfp_mode, F, cur, weighted ? sc.dpad : nullptr, stream));
+    // read-out backward: evaluated inside the last layer's first backward kernel (ReadoutGrad); only the
+    // gradient of the common non-stored row of Weighted_sum needs a (tiny) launch of its own
+    ReadoutGrad rgd;
+    rgd.dg = sc.dg; rgd.F = F; rgd.size = size; rgd.mode = m->molfp_mode; rgd.map = make_colmap(&lay);
+    if (weighted) RC(readout_backward_pad(b, sc.dg, &lay, size, m->molfp_mode, F, sc.dpad, stream));
     for (int l = m->n_layers - 1; l >= 0; --l) {
         LayerSaved& L = sv.L[l];
         eagcn_layer_bufs w;
@@ -602,8 +606,10 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
         w.P = L.P; w.Y = L.Y; w.rscale = L.rscale; w.bn = L.bn; w.xout = L.xout; w.pad_row = L.pad_row;
         w.scratch = sc.layer; w.scratch_bytes = sc.layer_bytes; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
         w.aux_stream = m->aux_stream;
-        const float* dpad = (weighted && l == m->n_layers - 1) ? sc.dpad : nullptr;
-        RC(eagcn_layer_backward(b, &m->layer[l], &w, cur, dpad, l > 0 ? other : nullptr, &lg[l], stream));
+        const bool top = l == m->n_layers - 1;
+        const float* dpad = (weighted && top) ? sc.dpad : nullptr;
+        RC(layer_backward_impl(b, &m->layer[l], &w, top ? nullptr : cur, top ? &rgd : nullptr, dpad,
+                               l > 0 ? other : nullptr, &lg[l], stream));
         std::swap(cur, other);
     }
     if (forked) RC(stream_after(s, side));                       // join: every gradient is complete on s

@@ -29,6 +29,7 @@ struct EdgeArgs {
 constexpr int EDGE_SLAB = 264;
 int edge_grid_x(const eagcn_batch* b);
 int launch_edge_grad(const EdgeArgs& a, hipStream_t s);
+int launch_agg_edge(AggArgs a, const EdgeArgs& e, hipStream_t s);   // transposed aggregation + edge gradients, one grid
 
 struct ColMapD {                 // exact <-> packed column map of a layout
     int nseg;
@@ -43,5 +44,19 @@ inline ColMapD make_colmap(const eagcn_layout* l) {
     }
     return m;
 }
+
+// Upstream gradient of the LAST layer given per molecule instead of per row: the read-out backward
+// (dx[r] = dg[mol(r)] / size, reference models.py:108-111) evaluated inside the layer's first backward
+// kernel, so the [T][ldo] broadcast is never written or read.
+struct ReadoutGrad {
+    const float* dg; int F;      // [B][F] gradient of the molecule fingerprints
+    const int64_t* size; int mode;
+    ColMapD map;                 // layout of the layer output (packed column -> exact column)
+};
+int layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
+                        const float* dxout, const ReadoutGrad* rg, const float* dpad_row, float* dx,
+                        const eagcn_layer_grads* g, void* stream);
+int readout_backward_pad(const eagcn_batch* b, const float* dg, const eagcn_layout* lay, const int64_t* size,
+                         int mode, int F, float* dpad_row, void* stream);
 
 }  // namespace eagcn

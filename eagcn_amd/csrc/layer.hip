@@ -11,6 +11,8 @@
 // and in eval mode.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -225,6 +227,7 @@ struct BwdArgs {
     ViewCols vc;
     int structure, fp, nvirt;
     const float* dxout; int ldo;
+    ReadoutGrad rg;              // rg.dg != null: the upstream gradient is dg[row_mol[r]] (dxout unused)
     const float* dpad;           // [ldo] gradient of the common non-stored row, or null
     const float* Y; int ldy;
     const float* bn;
@@ -251,6 +254,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
         const float mu = a.bn[BN_MU * fp + cp], inv = a.bn[BN_INV * fp + cp];
         const float aw = a.colp[CP_AVEW * fp + cp];
         const int cu = weighted ? f : cp;           // column of the upstream gradient
+        int ce = -1;                                // ... and its exact column when that gradient is per molecule
+        if (a.rg.dg) {
+            int eo = 0, po = 0;
+            for (int sg = 0; sg < a.rg.map.nseg; ++sg) {
+                if (cu < po + a.rg.map.p[sg]) { ce = (cu - po < a.rg.map.w[sg]) ? eo + (cu - po) : -1; break; }
+                eo += a.rg.map.w[sg];
+                po += a.rg.map.p[sg];
+            }
+        }
         double s1 = 0.0, s2 = 0.0, dak = 0.0;
         const int rows = T + a.nvirt;
         // rows r = blockIdx.x + u*gridDim.x: RU of them per trip, loads issued together
@@ -263,7 +275,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
                 yv[u] = 0.0f; upv[u] = 0.0f; dsv[u] = 1.0f;
                 if (r < T) {
                     yv[u] = a.Y[(size_t)r * a.ldy + cp];
-                    upv[u] = a.dxout[(size_t)r * a.ldo + cu];
+                    if (a.rg.dg) {
+                        const int mol = a.bt.row_mol[r];
+                        float v = ce >= 0 ? a.rg.dg[(size_t)mol * a.rg.F + ce] : 0.0f;
+                        if (a.rg.mode == 1) v *= 1.0f / (float)a.rg.size[mol];
+                        upv[u] = v;
+                    } else {
+                        upv[u] = a.dxout[(size_t)r * a.ldo + cu];
+                    }
                     if (!weighted) upv[u] *= a.bt.row_m[r];
                     if (a.do_drop) dsv[u] = drop_scale(seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
                 } else if (r < rows) {                 // the one virtual row standing for all non-stored rows
@@ -630,11 +649,17 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
 extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                                     const float* dxout, const float* dpad_row, float* dx,
                                     const eagcn_layer_grads* g, void* stream) {
+    return layer_backward_impl(b, p, w, dxout, nullptr, dpad_row, dx, g, stream);
+}
+
+int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
+                               const float* dxout, const ReadoutGrad* rg, const float* dpad_row, float* dx,
+                               const eagcn_layer_grads* g, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = check_layer(b, p, "eagcn_layer_backward");
     if (rc) return rc;
     EAGCN_CHECK_ARG(w && g && w->bn && w->scratch, "eagcn_layer_backward: null buffer");
-    EAGCN_CHECK_ARG(b->T == 0 || (dxout && w->x && w->P && w->Y && w->rscale), "eagcn_layer_backward: null activation buffer");
+    EAGCN_CHECK_ARG(b->T == 0 || ((dxout || rg) && w->x && w->P && w->Y && w->rscale), "eagcn_layer_backward: null activation buffer");
     for (int k = 0; k < p->K; ++k)
         EAGCN_CHECK_ARG(g->dW[k] && g->dbias[k] && g->dgamma[k] && g->dbeta[k] && g->datt_w[k] && g->dself_r[k],
                         "eagcn_layer_backward: view %d has a null gradient buffer", k);
@@ -674,7 +699,8 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
     BwdArgs ba;
     ba.bt = *b; ba.vc = d.vc; ba.structure = p->structure; ba.fp = d.fp;
     ba.nvirt = (dpad_row && p->structure == EAGCN_STRUCT_WEIGHTED) ? 1 : 0;
-    ba.dxout = dxout; ba.ldo = d.ldo; ba.dpad = dpad_row; ba.Y = w->Y; ba.ldy = d.fp; ba.bn = w->bn;
+    ba.dxout = dxout; ba.ldo = d.ldo; ba.dpad = dpad_row;
+    if (rg) ba.rg = *rg; else memset(&ba.rg, 0, sizeof(ba.rg)); ba.Y = w->Y; ba.ldy = d.fp; ba.bn = w->bn;
     ba.colp = sc.colp; ba.dH = sc.dY; ba.slab = sc.slab; ba.slab_da = sc.slab_da;
     ba.do_drop = (p->training && p->dropout > 0.0f) ? 1 : 0;
     ba.thr = (uint32_t)std::min(4294967295.0, (double)p->dropout * 4294967296.0);
@@ -708,12 +734,18 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
         EdgeArgs e;
         e.bt = *b; e.vc = d.vc; e.dY = sc.dY; e.Y = w->Y; e.P = w->P; e.ld = d.fp; e.sig = sc.sig;
         e.rsig = sc.rsig; e.rscale = w->rscale; e.datt = sc.datt;
-        if (forked) { rc = stream_after(side, s); if (rc) return rc; }          // dY' is ready
-        rc = launch_edge_grad(e, side);
-        if (rc) return rc;
+        static const bool colaunch = [] { const char* v = getenv("EAGCN_NO_COLAUNCH"); return !(v && v[0] == '1'); }();
         nedge = edge_grid_x(b);
-        rc = launch_agg(a, true, s);
-        if (rc) return rc;
+        if (!forked && colaunch) {
+            rc = launch_agg_edge(a, e, s);                                       // one grid for both
+            if (rc) return rc;
+        } else {
+            if (forked) { rc = stream_after(side, s); if (rc) return rc; }      // dY' is ready
+            rc = launch_edge_grad(e, side);
+            if (rc) return rc;
+            rc = launch_agg(a, true, s);
+            if (rc) return rc;
+        }
         if (forked) { rc = stream_after(side, s); if (rc) return rc; }          // dP is ready
         nsplit = d.nsplit;
         GemmDesc gw{1, 0, d.ld_in, d.fp, b->T, w->x, d.ld_in, sc.dP, d.fp, sc.dWcat, d.fp, nsplit, d.wslab, gemm_work};

@@ -92,6 +92,16 @@ __global__ __launch_bounds__(256) void readout_bwd_pad_kernel(eagcn_batch bt, co
     dpad[cp] = (float)acc;
 }
 
+int readout_backward_pad(const eagcn_batch* b, const float* dg, const eagcn_layout* lay, const int64_t* size,
+                         int mode, int F, float* dpad_row, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_READOUT, s);
+    readout_bwd_pad_kernel<<<cdiv(layout_ld(lay), 256), 256, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size,
+                                                                   mode, F, dpad_row);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
 }  // namespace eagcn
 
 using namespace eagcn;
