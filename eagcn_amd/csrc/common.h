@@ -199,6 +199,8 @@ struct GemmDesc {
     int prof_tag = PROF_GEMM;     // timing class (the head's small GEMMs are kept apart from the layer GEMMs)
 };
 int launch_gemm(const GemmDesc& g, hipStream_t s);
+// dX (ta=0,tb=1) and dW (ta=1,tb=0) of one layer in one launch (falls back to two launches otherwise)
+int launch_gemm_pair(const GemmDesc& dx, const GemmDesc& dw, hipStream_t s);
 // up to three products with ta = 1, tb = 0 in one launch (falls back to one launch each otherwise)
 int launch_gemm_group(const GemmDesc* descs, int n, hipStream_t s);
 

@@ -205,6 +205,13 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& g, const int Mx, const
         }
 }
 
+// XCD-aware order of `nwg` real workgroups: dispatch slot `lin` runs on XCD lin % 8; give every XCD a contiguous
+// run of tiles.  Bijective on [0, nwg).
+__device__ __forceinline__ int xcd_remap(int lin, int nwg) {
+    const int xcd = lin & 7, qn = nwg >> 3, rn = nwg & 7;
+    return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lin >> 3);
+}
+
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, int D>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
     // extents that are known only on the device (packed row count); locals, never written back into
@@ -224,14 +231,41 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
         // linear dispatch index of the REAL workgroups (capacity-only ones were skipped above)
         const int lin = blockIdx.z * per_z + blockIdx.y * gx + blockIdx.x;
         (void)bid;
-        const int xcd = lin & 7, qn = nwg >> 3, rn = nwg & 7;
-        const int nid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lin >> 3);
+        const int nid = xcd_remap(lin, nwg);
         z = nid / per_z;                                       // all tiles of one K-split land on one or two XCDs
         const int rem = nid - z * per_z;
         tile_y = rem / gx;
         tile_x = rem - tile_y * gx;
     }
     gemm_tile<BM, BN, BK, A_KC, B_KC, D>(g, Mx, Kx, tile_x, tile_y, z);
+}
+
+// The two backward products of a layer, dX = dP.W^T (rows = packed rows, capacity-sized) and dW = X^T.dP
+// (split-K over the rows), in ONE grid: each alone leaves a partly filled last round of workgroups (532 tiles on
+// 256 CUs); together the second fills the tail of the first.  Workgroups [0, first1) belong to dX.
+template <int BM, int BN, int BK, int D>
+__global__ __launch_bounds__(256) void gemm_f32_pair_kernel(GemmDesc g0, GemmDesc g1, int first1) {
+    const int b = blockIdx.x;
+    if (b < first1) {
+        const int Mx = g0.M_dev ? min(*g0.M_dev, g0.M) : g0.M;
+        const int gx = (g0.N + BN - 1) / BN;
+        const int nreal = gx * ((Mx + BM - 1) / BM);
+        if (b >= nreal) return;
+        const int nid = xcd_remap(b, nreal);
+        const int ty = nid / gx;
+        gemm_tile<BM, BN, BK, true, true, D>(g0, Mx, g0.K, nid - ty * gx, ty, 0);
+    } else {
+        const int lin = b - first1;                                 // first1 is a multiple of 8
+        const int Kx = g1.K_dev ? min(*g1.K_dev, g1.K) : g1.K;
+        const int gx = (g1.N + BN - 1) / BN;
+        const int per_z = gx * ((g1.M + BM - 1) / BM);
+        const int nwg = per_z * g1.splits;
+        if (lin >= nwg) return;
+        const int nid = xcd_remap(lin, nwg);
+        const int z = nid / per_z, rem = nid - z * per_z;
+        const int ty = rem / gx;
+        gemm_tile<BM, BN, BK, false, false, D>(g1, g1.M, Kx, rem - ty * gx, ty, z);
+    }
 }
 
 // Up to three independent products of the dW form (A stored [K][M], B stored [K][N]) in ONE launch: the head's
@@ -293,6 +327,28 @@ int launch_gemm(const GemmDesc& g0, hipStream_t s) {
         case 5: return launch_cfg<64, 64, 16, 1>(g, s);
         default: return launch_cfg<64, 64, 16, 4>(g, s);
     }
+}
+
+int launch_gemm_pair(const GemmDesc& dx, const GemmDesc& dw, hipStream_t s) {
+    GemmDesc g0 = dx, g1 = dw;
+    g0.vecA = (g0.lda % 4) == 0 && (g0.K % 4) == 0 && (reinterpret_cast<uintptr_t>(g0.A) % 16) == 0;
+    g0.vecB = (g0.ldb % 4) == 0 && (g0.K % 4) == 0 && (reinterpret_cast<uintptr_t>(g0.B) % 16) == 0;
+    g1.vecA = (g1.lda % 4) == 0 && (g1.M % 4) == 0 && (reinterpret_cast<uintptr_t>(g1.A) % 16) == 0;
+    g1.vecB = (g1.ldb % 4) == 0 && (g1.N % 4) == 0 && (reinterpret_cast<uintptr_t>(g1.B) % 16) == 0;
+    const bool ok = g0.ta == 0 && g0.tb == 1 && g0.splits == 1 && !g0.K_dev && g1.ta == 1 && g1.tb == 0 && !g1.M_dev &&
+                    (g1.splits == 1 || (g1.vecA && g1.vecB)) && g0.M > 0 && g0.N > 0 && g1.M > 0 && g1.N > 0;
+    if (!ok) {
+        int rc = launch_gemm(dw, s);
+        return rc ? rc : launch_gemm(dx, s);
+    }
+    const int first1 = (cdiv(g0.M, 64) * cdiv(g0.N, 64) + 7) / 8 * 8;
+    const int n1 = cdiv(g1.M, 64) * cdiv(g1.N, 64) * g1.splits;
+    const double w0 = g0.work > 0.0 ? g0.work : 2.0 * g0.M * g0.N * g0.K;
+    const double w1 = g1.work > 0.0 ? g1.work : 2.0 * g1.M * g1.N * g1.K;
+    ProfScope ps(g0.prof_tag, s, w0 + w1);
+    gemm_f32_pair_kernel<64, 64, 16, 4><<<first1 + n1, 256, 0, s>>>(g0, g1, first1);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
 }
 
 int launch_gemm_group(const GemmDesc* descs, int n, hipStream_t s) {

@@ -381,6 +381,10 @@ static void fill_drop(float p, int training, int* do_drop, uint32_t* thr, float*
     *inv_keep = 1.0f / (1.0f - p);
 }
 
+static int rowbn_wide_rows() {
+    static const int v = [] { const char* e = getenv("EAGCN_ROWBN_WIDE"); return e ? atoi(e) : 64; }();
+    return v;
+}
 // a matrix that may still be `splits` split-K partials `stride` floats apart (summed by its consumer)
 struct Partial { const float* p; int splits; size_t stride; };
 
@@ -393,7 +397,7 @@ static int rowbn_fwd(hipStream_t s, int R, int F, Partial x, float* xs, float* x
     a.training = training; a.relu = relu; a.eps = eps; a.momentum = mom; a.seed = seed; a.seed_dev = seed_dev;
     fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
     ProfScope ps(PROF_HEAD, s);
-    if (R > 512) rowbn_fwd_kernel<64><<<cdiv(F, 16), 1024, 0, s>>>(a);
+    if (R > rowbn_wide_rows()) rowbn_fwd_kernel<64><<<cdiv(F, 16), 1024, 0, s>>>(a);
     else rowbn_fwd_kernel<16><<<cdiv(F, 16), 256, 0, s>>>(a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
@@ -407,7 +411,7 @@ static int rowbn_bwd(hipStream_t s, int R, int F, Partial dy, const float* x, co
     a.training = training; a.relu = relu; a.seed = seed; a.seed_dev = seed_dev;
     fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
     ProfScope ps(PROF_HEAD, s);
-    if (R > 512) rowbn_bwd_kernel<64><<<cdiv(F, 16), 1024, 0, s>>>(a);
+    if (R > rowbn_wide_rows()) rowbn_bwd_kernel<64><<<cdiv(F, 16), 1024, 0, s>>>(a);
     else rowbn_bwd_kernel<16><<<cdiv(F, 16), 256, 0, s>>>(a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;

@@ -92,30 +92,33 @@ __global__ __launch_bounds__(256) void pack_params_kernel(ParamPtrs pp, ViewCols
     if (blockIdx.x == 0 && threadIdx.x < vc.K) rsig[threadIdx.x] = sigmoidf_(pp.self_r[threadIdx.x][0]);
 }
 
-// sum of per-workgroup partial pairs slab[s][cp][0..1] over s, 16 lanes per column
-__device__ __forceinline__ void slab_sum16(const double* __restrict__ slab, int nslab, int fp, int cp, int sl,
+// sum of per-workgroup partial pairs slab[s][cp][0..1] over s, L (16 or 64) lanes per column: with hundreds of
+// slabs, 64 lanes per column turn five dependent batches of loads per lane into one or two
+template <int L>
+__device__ __forceinline__ void slab_sum(const double* __restrict__ slab, int nslab, int fp, int cp, int sl,
                                            double& s1, double& s2) {
     s1 = 0.0;
     s2 = 0.0;
-    for (int s0 = sl; s0 < nslab; s0 += 16 * 8) {          // 8 slab pairs in flight per lane
+    for (int s0 = sl; s0 < nslab; s0 += L * 8) {           // 8 slab pairs in flight per lane
         double2 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int s = s0 + 16 * u;
+            const int s = s0 + L * u;
             v[u] = s < nslab ? *reinterpret_cast<const double2*>(slab + ((size_t)s * fp + cp) * 2) : make_double2(0.0, 0.0);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) { s1 += v[u].x; s2 += v[u].y; }
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
+    for (int o = L / 2; o > 0; o >>= 1) {
         s1 += __shfl_xor(s1, o);
         s2 += __shfl_xor(s2, o);
     }
 }
 
 // ---- BatchNorm forward ---------------------------------------------------------------------------
-// 16 columns per workgroup, 16 lanes per column
+// 256/L columns per workgroup, L lanes per column
+template <int L>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ slab, int nslab, int fp,
                                                            double M, int training, float eps, float momentum,
                                                            const float* __restrict__ colp, ParamPtrs pp,
@@ -123,10 +126,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                            const int32_t* __restrict__ meta, int tiles_per_wg) {
     // aggregation workgroups beyond the actual tile count exit without writing their slab
     nslab = min(nslab, (meta[EAGCN_META_NTILES] + tiles_per_wg - 1) / tiles_per_wg);
-    const int cpr = blockIdx.x * 16 + (threadIdx.x >> 4), sl = threadIdx.x & 15;
+    const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
     const int cp = min(cpr, fp - 1);
     double s1 = 0.0, s2 = 0.0;
-    if (training) slab_sum16(slab, nslab, fp, cp, sl, s1, s2);
+    if (training) slab_sum<L>(slab, nslab, fp, cp, sl, s1, s2);
     if (cpr >= fp || sl != 0) return;
     const int k = col_view(vc, cp), f = cp - vc.off[k];
     const float gamma = colp[CP_GAMMA * fp + cp], beta = colp[CP_BETA * fp + cp];
@@ -323,12 +326,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     }
 }
 
+template <int L>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ slab,
                                                                const double* __restrict__ slab_da, int nslab,
                                                                int fp, double M, int training,
                                                                const float* __restrict__ bn, ViewCols vc,
                                                                GradPtrs gp, float* __restrict__ cc) {
-    const int cpr = blockIdx.x * 16 + (threadIdx.x >> 4), sl = threadIdx.x & 15;
+    const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
     const int cp = min(cpr, fp - 1);
     if (blockIdx.x == 0 && threadIdx.x < vc.K && gp.dave_w) {
         double t = 0.0;
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
         gp.dave_w[threadIdx.x] = (float)t;
     }
     double s1, s2;
-    slab_sum16(slab, nslab, fp, cp, sl, s1, s2);
+    slab_sum<L>(slab, nslab, fp, cp, sl, s1, s2);
     if (cpr >= fp || sl != 0) return;
     cc[cp] = training ? (float)(s1 / M) : 0.0f;
     cc[fp + cp] = training ? (float)(s2 / M) : 0.0f;
@@ -630,8 +634,12 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
     }
     const double M = (double)b->B * (double)b->N;
     ProfScope psbn(PROF_BN, s);
-    bn_finalize_kernel<<<cdiv(d.fp, 16), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
-                                                        p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, agg_ksplit(b) ? 1 : 4);
+    if (nslab > 64)
+        bn_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
+                                                               p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, agg_ksplit(b) ? 1 : 4);
+    else
+        bn_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
+                                                                p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, agg_ksplit(b) ? 1 : 4);
     EAGCN_LAUNCH_CHECK();
     ApplyArgs aa;
     aa.bt = *b; aa.vc = d.vc; aa.structure = p->structure; aa.fp = d.fp; aa.Y = w->Y; aa.ldy = d.fp;
@@ -714,8 +722,12 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         ProfScope ps(PROF_BN, s);
         bn_bwd_reduce_kernel<<<gxb, 256, 0, s>>>(ba);
         EAGCN_LAUNCH_CHECK();
-        bn_bwd_finalize_kernel<<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
-                                                                d.vc, gp, sc.cc);
+        if (gxb > 64)
+            bn_bwd_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
+                                                                       d.vc, gp, sc.cc);
+        else
+            bn_bwd_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
+                                                                        d.vc, gp, sc.cc);
         EAGCN_LAUNCH_CHECK();
         if (b->T > 0) {
             bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
@@ -750,13 +762,15 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         nsplit = d.nsplit;
         GemmDesc gw{1, 0, d.ld_in, d.fp, b->T, w->x, d.ld_in, sc.dP, d.fp, sc.dWcat, d.fp, nsplit, d.wslab, gemm_work};
         gw.K_dev = b->meta + EAGCN_META_T;
-        rc = launch_gemm(gw, side);
-        if (rc) return rc;
-        if (dx) {
-            GemmDesc gx{0, 1, b->T, d.ld_in, d.fp, sc.dP, d.fp, sc.Wcat, d.fp, dx, d.ld_in, 1, 0, gemm_work};
-            gx.M_dev = b->meta + EAGCN_META_T;
-            rc = launch_gemm(gx, s);
+        GemmDesc gx{0, 1, b->T, d.ld_in, d.fp, sc.dP, d.fp, sc.Wcat, d.fp, dx, d.ld_in, 1, 0, gemm_work};
+        gx.M_dev = b->meta + EAGCN_META_T;
+        if (dx && !forked && colaunch) {
+            rc = launch_gemm_pair(gx, gw, s);                                    // dX and dW share one grid
             if (rc) return rc;
+        } else {
+            rc = launch_gemm(gw, side);
+            if (rc) return rc;
+            if (dx) { rc = launch_gemm(gx, s); if (rc) return rc; }
         }
     }
     {
