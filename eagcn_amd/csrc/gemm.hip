@@ -317,7 +317,7 @@ int launch_gemm(const GemmDesc& g0, hipStream_t s) {
         // measured on MI355X (tools/gemm_bench.py, gemm_big.py): 128x128 tiles win only for long-K, many-tile
         // problems (4096^3: 113 vs 98 TF); at the layer shapes (K = 24..704) 64x64 is equal or better, and in
         // graph mode M is only a capacity, so do not let it pick the large tile
-        cfg = (g.K >= 1024 && tiles128 >= 512) ? 3 : 0;
+        cfg = (g.K >= 1024 && tiles128 >= 512 && g.M > 64 && g.N > 64) ? 3 : 0;
     }
     switch (cfg) {
         case 1: return launch_cfg<64, 64, 32, 3>(g, s);

@@ -241,75 +241,107 @@ struct BwdArgs {
     int do_drop; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
 };
 
+// One workgroup owns BWD_ROWS consecutive-strided rows; a thread owns FOUR adjacent columns (one float4 per row
+// and operand) and has all BWD_ROWS rows in flight at once: a single batch of independent 16-byte loads
+// instead of a column loop of scalar ones.  View column ranges are multiples of 16, so the four columns share
+// their view.
+constexpr int BWD_ROWS = 8;
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     __shared__ double da_s[EAGCN_MAX_VIEWS];
     const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
     const int fp = a.fp, T = dev_rows(a.bt);
+    const int rows = T + a.nvirt;
+    // the grid is sized for the row CAPACITY: only the first ceil(rows / BWD_ROWS) workgroups work (and write a
+    // slab); bn_bwd_finalize derives the same count from the device-side row count
+    const int nwg = max(1, min((int)gridDim.x, (rows + BWD_ROWS - 1) / BWD_ROWS));
+    if ((int)blockIdx.x >= nwg) return;
     if (threadIdx.x < EAGCN_MAX_VIEWS) da_s[threadIdx.x] = 0.0;
     __syncthreads();
     const bool weighted = a.structure == EAGCN_STRUCT_WEIGHTED;
     double da[EAGCN_MAX_VIEWS];
 #pragma unroll
     for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) da[k] = 0.0;
-    for (int cp = threadIdx.x; cp < fp; cp += blockDim.x) {
+    for (int cp = threadIdx.x * 4; cp < fp; cp += blockDim.x * 4) {
         const int k = col_view(a.vc, cp), f = cp - a.vc.off[k];
-        const float sc = a.bn[BN_SC * fp + cp], sh = a.bn[BN_SH * fp + cp];
-        const float mu = a.bn[BN_MU * fp + cp], inv = a.bn[BN_INV * fp + cp];
-        const float aw = a.colp[CP_AVEW * fp + cp];
-        const int cu = weighted ? f : cp;           // column of the upstream gradient
-        int ce = -1;                                // ... and its exact column when that gradient is per molecule
+        const float4 sc = *reinterpret_cast<const float4*>(a.bn + BN_SC * fp + cp);
+        const float4 sh = *reinterpret_cast<const float4*>(a.bn + BN_SH * fp + cp);
+        const float4 mu = *reinterpret_cast<const float4*>(a.bn + BN_MU * fp + cp);
+        const float4 iv = *reinterpret_cast<const float4*>(a.bn + BN_INV * fp + cp);
+        const float4 aw = *reinterpret_cast<const float4*>(a.colp + CP_AVEW * fp + cp);
+        const int cu = weighted ? f : cp;           // first column of the upstream gradient
+        int ce[4] = {-1, -1, -1, -1};               // ... and the exact columns when that gradient is per molecule
         if (a.rg.dg) {
-            int eo = 0, po = 0;
-            for (int sg = 0; sg < a.rg.map.nseg; ++sg) {
-                if (cu < po + a.rg.map.p[sg]) { ce = (cu - po < a.rg.map.w[sg]) ? eo + (cu - po) : -1; break; }
-                eo += a.rg.map.w[sg];
-                po += a.rg.map.p[sg];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int eo = 0, po = 0;
+                for (int sg = 0; sg < a.rg.map.nseg; ++sg) {
+                    if (cu + j < po + a.rg.map.p[sg]) { ce[j] = (cu + j - po < a.rg.map.w[sg]) ? eo + (cu + j - po) : -1; break; }
+                    eo += a.rg.map.w[sg];
+                    po += a.rg.map.p[sg];
+                }
             }
         }
-        double s1 = 0.0, s2 = 0.0, dak = 0.0;
-        const int rows = T + a.nvirt;
-        // rows r = blockIdx.x + u*gridDim.x: RU of them per trip, loads issued together
-        constexpr int RU = 4;
-        for (int rb = blockIdx.x; rb < rows; rb += RU * gridDim.x) {
-            float yv[RU], upv[RU], dsv[RU];
+        double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, dak = 0.0;
+        for (int rb = blockIdx.x; rb < rows; rb += BWD_ROWS * nwg) {
+            float4 yv[BWD_ROWS], upv[BWD_ROWS];
 #pragma unroll
-            for (int u = 0; u < RU; ++u) {
-                const int r = rb + u * gridDim.x;
-                yv[u] = 0.0f; upv[u] = 0.0f; dsv[u] = 1.0f;
+            for (int u = 0; u < BWD_ROWS; ++u) {
+                const int r = rb + u * nwg;
+                yv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                upv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < T) {
-                    yv[u] = a.Y[(size_t)r * a.ldy + cp];
+                    yv[u] = *reinterpret_cast<const float4*>(a.Y + (size_t)r * a.ldy + cp);
                     if (a.rg.dg) {
                         const int mol = a.bt.row_mol[r];
-                        float v = ce >= 0 ? a.rg.dg[(size_t)mol * a.rg.F + ce] : 0.0f;
-                        if (a.rg.mode == 1) v *= 1.0f / (float)a.rg.size[mol];
+                        const float* g = a.rg.dg + (size_t)mol * a.rg.F;
+                        float4 v;
+                        v.x = ce[0] >= 0 ? g[ce[0]] : 0.0f;
+                        v.y = ce[1] >= 0 ? g[ce[1]] : 0.0f;
+                        v.z = ce[2] >= 0 ? g[ce[2]] : 0.0f;
+                        v.w = ce[3] >= 0 ? g[ce[3]] : 0.0f;
+                        if (a.rg.mode == 1) {
+                            const float is = 1.0f / (float)a.rg.size[mol];
+                            v.x *= is; v.y *= is; v.z *= is; v.w *= is;
+                        }
                         upv[u] = v;
                     } else {
-                        upv[u] = a.dxout[(size_t)r * a.ldo + cu];
+                        upv[u] = *reinterpret_cast<const float4*>(a.dxout + (size_t)r * a.ldo + cu);
                     }
-                    if (!weighted) upv[u] *= a.bt.row_m[r];
-                    if (a.do_drop) dsv[u] = drop_scale(seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
+                    if (!weighted) {
+                        const float m = a.bt.row_m[r];
+                        upv[u].x *= m; upv[u].y *= m; upv[u].z *= m; upv[u].w *= m;
+                    }
                 } else if (r < rows) {                 // the one virtual row standing for all non-stored rows
-                    upv[u] = a.dpad[(size_t)(r - T) * a.ldo + cu];
+                    upv[u] = *reinterpret_cast<const float4*>(a.dpad + (size_t)(r - T) * a.ldo + cu);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < RU; ++u) {
-                const int r = rb + u * gridDim.x;
+            for (int u = 0; u < BWD_ROWS; ++u) {
+                const int r = rb + u * nwg;
                 if (r >= rows) continue;
-                const float y = yv[u];
-                float up = upv[u];
-                const float ds = dsv[u];
-                const float h = y * sc + sh;
-                if (weighted) { dak += (double)(up * ds * fmaxf(h, 0.0f)); up *= aw; }
-                const float dh = h > 0.0f ? up * ds : 0.0f;
-                const float xh = (y - mu) * inv;
-                s1 += (double)dh;
-                s2 += (double)(dh * xh);
-                if (r < T) a.dH[(size_t)r * fp + cp] = dh;
+                const float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+                const float uu[4] = {upv[u].x, upv[u].y, upv[u].z, upv[u].w};
+                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, ivv[4] = {iv.x, iv.y, iv.z, iv.w};
+                const float awv[4] = {aw.x, aw.y, aw.z, aw.w};
+                float dh[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float up = uu[j];
+                    const float ds = (a.do_drop && r < T) ? drop_scale(seed, (uint64_t)r * fp + cp + j, a.thr, a.inv_keep) : 1.0f;
+                    const float h = yy[j] * scv[j] + shv[j];
+                    if (weighted) { dak += (double)(up * ds * fmaxf(h, 0.0f)); up *= awv[j]; }
+                    dh[j] = h > 0.0f ? up * ds : 0.0f;
+                    const float xh = (yy[j] - muv[j]) * ivv[j];
+                    s1[j] += (double)dh[j];
+                    s2[j] += (double)(dh[j] * xh);
+                }
+                if (r < T) *reinterpret_cast<float4*>(a.dH + (size_t)r * fp + cp) = make_float4(dh[0], dh[1], dh[2], dh[3]);
             }
         }
-        a.slab[((size_t)blockIdx.x * fp + cp) * 2 + 0] = s1;
-        a.slab[((size_t)blockIdx.x * fp + cp) * 2 + 1] = s2;
+        double* sl = a.slab + ((size_t)blockIdx.x * fp + cp) * 2;
+        *reinterpret_cast<double4*>(sl) = make_double4(s1[0], s2[0], s1[1], s2[1]);
+        *reinterpret_cast<double4*>(sl + 4) = make_double4(s1[2], s2[2], s1[3], s2[3]);
         if (weighted) {
 #pragma unroll
             for (int v = 0; v < EAGCN_MAX_VIEWS; ++v) da[v] += (v == k) ? dak : 0.0;
@@ -331,7 +363,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
                                                                const double* __restrict__ slab_da, int nslab,
                                                                int fp, double M, int training,
                                                                const float* __restrict__ bn, ViewCols vc,
-                                                               GradPtrs gp, float* __restrict__ cc) {
+                                                               GradPtrs gp, float* __restrict__ cc, const int32_t* __restrict__ meta, int nvirt) {
+    nslab = max(1, min(nslab, (meta[EAGCN_META_T] + nvirt + BWD_ROWS - 1) / BWD_ROWS));   // slabs actually written
     const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
     const int cp = min(cpr, fp - 1);
     if (blockIdx.x == 0 && threadIdx.x < vc.K && gp.dave_w) {
@@ -724,10 +757,10 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         EAGCN_LAUNCH_CHECK();
         if (gxb > 64)
             bn_bwd_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
-                                                                       d.vc, gp, sc.cc);
+                                                                       d.vc, gp, sc.cc, b->meta, ba.nvirt);
         else
             bn_bwd_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
-                                                                        d.vc, gp, sc.cc);
+                                                                        d.vc, gp, sc.cc, b->meta, ba.nvirt);
         EAGCN_LAUNCH_CHECK();
         if (b->T > 0) {
             bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);

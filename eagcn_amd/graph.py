@@ -155,7 +155,6 @@ class GraphRunner:
         L.check(lib.eagcn_model_forward(self.index.ref(), C.byref(self.cm), C.c_void_p(0), size_ptr, _ptr(self.saved),
                                         self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.out),
                                         _ptr(self.graph_rep), _stream()), 'eagcn_model_forward')
-        torch._foreach_add_(self.plan.nbt, 1)
 
     def _call_backward(self):
         lib = L.load()
@@ -250,6 +249,7 @@ class GraphRunner:
             self.size_static.copy_(size, non_blocking=True)
         self.step += 1
         self.generation += 1
+        self.plan.nbt_pending += 1        # num_batches_tracked: counted on the host, written by ModelPlan.flush_nbt()
         if self.graphs[self.cur][0] is None:
             self._call_forward()                              # first use of a slot: eager (and the capture warm-up)
             self._capture()
@@ -261,7 +261,8 @@ class GraphRunner:
         if generation != self.generation:
             raise L.EagcnHipError('graph mode keeps ONE forward in flight: backward() of an older forward was '
                                   'called after a newer training forward overwrote the saved activations')
-        self.dout.copy_(dout)
+        if dout.data_ptr() != self.dout.data_ptr():          # the fused losses write straight into self.dout
+            self.dout.copy_(dout)
         if dgr is not None:
             self.dgr.copy_(dgr)
             self.dgr_is_zero = False
@@ -310,4 +311,6 @@ def graph_forward(runner, adj, rels, afm, size, seed, overlap=False, bonds=None)
     plan = runner.plan
     if plan.trigger is None or plan.trigger.device != afm.device:
         plan.trigger = torch.zeros((), dtype=torch.float32, device=afm.device, requires_grad=True)
-    return _GraphFn.apply(runner, adj, rels, afm, size, seed, overlap, plan.trigger, bonds)
+    out, graph_rep = _GraphFn.apply(runner, adj, rels, afm, size, seed, overlap, plan.trigger, bonds)
+    out._eagcn_grad_slot = runner.dout    # hint for eagcn_amd.losses: where d(loss)/d(out) is consumed
+    return out, graph_rep

@@ -56,11 +56,17 @@ class _FusedLoss(torch.autograd.Function):
             L.check(lib.eagcn_mse_loss(x.data_ptr(), y.data_ptr(), x.numel(), loss.data_ptr(), dx.data_ptr(), stream),
                     'eagcn_mse_loss')
         ctx.save_for_backward(dx)
+        # graph mode hands over the buffer its captured backward reads d(loss)/d(out) from: scaling into it
+        # saves the copy (eagcn_amd/graph.py)
+        slot = getattr(outputs, '_eagcn_grad_slot', None)
+        ctx.slot = slot if (slot is not None and slot.shape == x.shape and slot.device == x.device) else None
         return loss
 
     @staticmethod
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
+        if ctx.slot is not None:
+            return None, torch.mul(dx, g, out=ctx.slot), None, None
         return None, dx * g, None, None
 
 

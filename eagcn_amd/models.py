@@ -138,7 +138,19 @@ class EAGCN(nn.Module):
             self._plan = ops.ModelPlan(self.graph_layers(), head, self.n_afeat, self.molfp_mode, self.dropout)
         return self._plan
 
+    def state_dict(self, *a, **kw):
+        if self._plan is not None:
+            self._plan.flush_nbt()                      # graph mode counts num_batches_tracked on the host
+        return super().state_dict(*a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        if self._plan is not None:
+            self._plan.flush_nbt()                      # pending counts belong to the values being replaced
+        return super().load_state_dict(*a, **kw)
+
     def _apply(self, fn, *a, **kw):                     # .cuda() / .to(): parameters are re-created
+        if self._plan is not None:
+            self._plan.flush_nbt()
         self._plan = None
         self._runners = {}
         return super()._apply(fn, *a, **kw)

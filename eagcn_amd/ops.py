@@ -563,6 +563,14 @@ class ModelPlan:
         self.nbt = [blk.batch_norm.bn.num_batches_tracked for layer in layers for blk in layer.blocks()] + \
                    [h['Graph_BN'].num_batches_tracked, h['bn_den1'].num_batches_tracked,
                     h['bn_den2'].num_batches_tracked]
+        self.nbt_pending = 0          # graph mode counts batches on the host (see flush_nbt)
+
+    def flush_nbt(self):
+        """Write the batches counted on the host by graph mode into the num_batches_tracked buffers (they are not
+        read by the computation: momentum is a number, reference layers.py:403).  Called by EAGCN.state_dict()."""
+        if self.nbt_pending:
+            torch._foreach_add_(self.nbt, self.nbt_pending)
+            self.nbt_pending = 0
 
     def cmodel(self, training, seed, dropout):
         """The C description of the model for this call.  The struct is cached per (training, dropout)
