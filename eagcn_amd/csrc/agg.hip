@@ -199,24 +199,31 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
     const int ntile_k = (a.vc.off[k + 1] - a.vc.off[k]) / 16;
     const int ct0 = cc * CT;
     if (ct0 >= ntile_k) return;                       // uniform for the whole workgroup
+    const eagcn_batch& bt = a.bt;
+    // Independent loads at the head of every workgroup are requested together instead of one dependent round
+    // trip after the other: the first tile's descriptor (bx is inside the tile CAPACITY, so the address is
+    // valid even when this workgroup turns out to have no tile), the device-side tile count, sigmoid(self_r)
+    // and the sigmoid table.
+    int4 ti_next = reinterpret_cast<const int4*>(bt.tile_info)[bx];
+    const float r = a.rsig[k];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float sig_v = a.sig[k * 256 + tid];
     const int ntiles = dev_tiles(a.bt);
     if (bx >= ntiles) return;            // capacity-sized grid: no tile for this workgroup (its
                                                       // stats slab is not read either: bn_finalize counts live slabs)
     const int nct = min(CT, ntile_k - ct0);
     const int c0 = a.vc.off[k] + ct0 * 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
-    sig_s[tid] = a.sig[k * 256 + tid];
+    sig_s[tid] = sig_v;
     if (!TRANS) for (int i = tid; i < CT * 16 * 2; i += 256) st_s[i] = 0.0;
     __syncthreads();
-    const float r = a.rsig[k];
-    const eagcn_batch& bt = a.bt;
     double s1[CT], s2[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) { s1[c] = 0.0; s2[c] = 0.0; }
 
     for (int tile = bx; tile < ntiles; tile += gx) {
-        const int4 ti = reinterpret_cast<const int4*>(bt.tile_info)[tile];
+        const int4 ti = ti_next;
+        if (tile + gx < ntiles) ti_next = reinterpret_cast<const int4*>(bt.tile_info)[tile + gx];
         const int b = ti.x, rt = ti.y, n = ti.z, r0 = ti.w;
         const uint8_t* codeb = bt.code + ((size_t)k * bt.B + b) * bt.N * bt.ldc;
         const int ia = rt * 16 + li;                  // A-operand row of this lane = output row
@@ -446,14 +453,24 @@ __device__ __forceinline__ void edge_grad_body(const EdgeArgs& a, const int bx, 
     __shared__ double dr_s[16];
     __shared__ int hit_s[16][HMAX];                                // (column << 8) | bond code
     const eagcn_batch& bt = a.bt;
-    const int Tn = dev_rows(bt);
-    if (bx * 16 >= Tn) return;                        // capacity-sized grid (slab not read either)
-    const int nwg = min(gx, (Tn + 15) / 16);           // workgroups that have rows
     const int k = by;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane >> 4, sl = lane & 15;
     const int gq = wave * 4 + grp;                                 // group index inside the workgroup
-    sig_s[tid] = a.sig[k * 256 + tid];
+    // first row's descriptor and scale, the sigmoid table and the device-side row count are independent:
+    // request them together (the row index is inside the row CAPACITY, so the loads are always legal)
+    const int r_first = (bx * 4 + wave) * 4 + grp;
+    int4 info_first = make_int4(0, 0, 0, 0);
+    float rs_first = 0.0f;
+    if (r_first < bt.T) {
+        info_first = reinterpret_cast<const int4*>(bt.row_info)[r_first];
+        rs_first = a.rscale[(size_t)k * bt.T + r_first];
+    }
+    const float sig_v = a.sig[k * 256 + tid];
+    const int Tn = dev_rows(bt);
+    if (bx * 16 >= Tn) return;                        // capacity-sized grid (slab not read either)
+    const int nwg = min(gx, (Tn + 15) / 16);           // workgroups that have rows
+    sig_s[tid] = sig_v;
     h_s[tid] = 0.0;
     if (tid < 16) dr_s[tid] = 0.0;
     __syncthreads();
@@ -464,8 +481,11 @@ __device__ __forceinline__ void edge_grad_body(const EdgeArgs& a, const int bx, 
         int4 info = make_int4(0, 0, 0, 0);
         float rs = 0.0f;
         if (r < Tn) {
-            info = reinterpret_cast<const int4*>(bt.row_info)[r];
-            rs = a.rscale[(size_t)k * bt.T + r];
+            if (rblk == bx) { info = info_first; rs = rs_first; }
+            else {
+                info = reinterpret_cast<const int4*>(bt.row_info)[r];
+                rs = a.rscale[(size_t)k * bt.T + r];
+            }
         }
         const bool live = rs != 0.0f;                              // m_i == 0 rows carry no dependence
         const int b = info.x, i = info.y, n = live ? info.z : 0, r0 = info.w;
