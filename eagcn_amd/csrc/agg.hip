@@ -217,9 +217,8 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
     sig_s[tid] = sig_v;
     if (!TRANS) for (int i = tid; i < CT * 16 * 2; i += 256) st_s[i] = 0.0;
     __syncthreads();
-    double s1[CT], s2[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) { s1[c] = 0.0; s2[c] = 0.0; }
+    // (BatchNorm partial sums live in LDS, st_s, not in registers: 36 VGPRs less for CT = 9, i.e. one more
+    //  resident workgroup per CU for a kernel whose speed is the number of round trips in flight)
 
     for (int tile = bx; tile < ntiles; tile += gx) {
         const int4 ti = ti_next;
@@ -341,15 +340,22 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
                     if (ct < nct) {
+                        double t1 = 0.0, t2 = 0.0;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int row = rt * 16 + q * 4 + g;
                             if (row < n) {
                                 const float y = acc[ct][g] * scr[g];
                                 a.dst[(size_t)(r0 + row) * a.ldd + c0 + ct * 16 + li] = y;
-                                s1[ct] += (double)y;
-                                s2[ct] += (double)y * (double)y;
+                                t1 += (double)y;
+                                t2 += (double)y * (double)y;
                             }
+                        }
+                        t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+                        t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+                        if (q == 0) {                 // only wave 0 touches st_s between the barriers
+                            st_s[(ct * 16 + li) * 2 + 0] += t1;
+                            st_s[(ct * 16 + li) * 2 + 1] += t2;
                         }
                     }
             } else {
@@ -368,23 +374,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
     }
 
     if (!TRANS) {
-        // per-workgroup partial BatchNorm sums (held by wave 0) -> slab[bx][column][2]
-        if (wave == 0) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                s1[ct] += __shfl_xor(s1[ct], 16);
-                s1[ct] += __shfl_xor(s1[ct], 32);
-                s2[ct] += __shfl_xor(s2[ct], 16);
-                s2[ct] += __shfl_xor(s2[ct], 32);
-            }
-            if (q == 0) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    st_s[(ct * 16 + li) * 2 + 0] = s1[ct];
-                    st_s[(ct * 16 + li) * 2 + 1] = s2[ct];
-                }
-            }
-        }
+        // per-workgroup partial BatchNorm sums (accumulated in st_s by wave 0) -> slab[bx][column][2]
         __syncthreads();
         const int fp = a.vc.off[a.vc.K];
         for (int i = tid; i < nct * 16 * 2; i += 256)
