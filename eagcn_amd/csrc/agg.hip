@@ -385,7 +385,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
 template <int CT, bool TRANS>
 __global__ __launch_bounds__(256) void agg_wave_kernel(AggArgs a) { agg_wave_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 template <int CT, bool TRANS>
-__global__ __launch_bounds__(256) void agg_kernel(AggArgs a) { agg_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg_kernel(AggArgs a) { agg_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 template <bool TRANS>
 static int launch_agg_t(const AggArgs& a, int ct, dim3 grid, bool ksplit, hipStream_t s) {
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) { edge_grad_
 // alone -- side by side they overlap instead of running back to back.  Workgroups [0, agg_gx) of every grid row
 // run the aggregation, the rest the edge gradients (grid rows beyond the view count have none).
 template <int CT, bool KSPLIT>
-__global__ __launch_bounds__(256) void agg_edge_kernel(AggArgs a, EdgeArgs e, int agg_gx) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg_edge_kernel(AggArgs a, EdgeArgs e, int agg_gx) {
     const int bx = blockIdx.x;
     if (bx < agg_gx) {
         if constexpr (KSPLIT) agg_body<CT, true>(a, bx, blockIdx.y, agg_gx);
