@@ -10,10 +10,13 @@ path; the input-validity counters of batch k are checked (and raised) when batch
 
 Static buffers are sized for ``row_cap`` packed rows (default B*N, which can never overflow).
 
-The static index is double-buffered (two slots, one captured graph pair each): with ``overlap=True``
-(inputs already resident in HBM) the index kernels of batch k+1 run on a side stream while the GPU is
-still executing the backward of batch k; they only have to wait for the backward of batch k-1, the
-previous user of their slot.
+Everything a batch brings with it is double-buffered (two slots, one captured graph pair each): the
+static index, the saved-activation block (whose first region is the packed input), the dropout seeds
+and the molecule sizes.  With ``overlap=True`` (inputs already resident in HBM) ALL eager per-batch work
+of batch k+1 -- index kernels, packing of ``afms``, seed upload -- runs on a side stream while the GPU is
+still executing the backward of batch k; it only has to wait for the backward of batch k-1, the previous
+user of its slot.  The main stream then sees nothing but graph launches and the caller's loss.
+The captured backward writes the parameter gradients straight into the buffer ``p.grad`` are views of.
 """
 import ctypes as C
 import os
@@ -75,18 +78,24 @@ class GraphRunner:
         self.graphs = [[None, None], [None, None]]            # per slot: [forward graph, backward graph]
         self.entry_events = [None, None]                      # main-stream position at the last two forward entries
         self.dropout = float(dropout)
-        self.seeds_dev = torch.zeros(8, dtype=torch.int64, device=device)
-        self.seeds_host = torch.zeros(8, dtype=torch.int64).pin_memory()
-        self.seeds_np = self.seeds_host.numpy()
+        self.seeds_dev = [torch.zeros(8, dtype=torch.int64, device=device) for _ in range(2)]
+        self.seeds_host = [torch.zeros(8, dtype=torch.int64).pin_memory() for _ in range(_RING)]
         self.meta_host = [torch.zeros(L.META_WORDS, dtype=torch.int32).pin_memory() for _ in range(_RING)]
         self.meta_event = [None] * _RING
         self.step = 0
+        self.cur = 0
         self.generation = 0
-        self.size_static = torch.ones(B, dtype=torch.int64, device=device)
-        m = self._cmodel()
+        self.size_static = [torch.ones(B, dtype=torch.int64, device=device) for _ in range(2)]
+        self.aux = None
+        # optional fork of off-critical-path backward work onto a second stream (graph branches).
+        # Measured on MI355X at the Tox21 shape: replay got SLOWER (0.85 vs 0.77 ms/step), so off by default.
+        if os.environ.get('EAGCN_AUX_STREAM', '0') == '1':
+            self.aux = torch.cuda.Stream(device=self.device)
+        self.cms = [self._cmodel(i) for i in range(2)]
+        m = self.cms[0]
         self.saved_bytes = lib.eagcn_model_saved_bytes(self.index.ref(), C.byref(m))
         self.scratch_bytes = lib.eagcn_model_scratch_bytes(self.index.ref(), C.byref(m))
-        self.saved = torch.empty(self.saved_bytes, dtype=torch.uint8, device=device)
+        self.saved = [torch.empty(self.saved_bytes, dtype=torch.uint8, device=device) for _ in range(2)]
         self.scratch = torch.empty(self.scratch_bytes, dtype=torch.uint8, device=device)
         f32 = dict(dtype=torch.float32, device=device)
         self.out = torch.zeros((B, m.head.nclass), **f32)
@@ -95,38 +104,40 @@ class GraphRunner:
         self.dgr = torch.zeros((B, m.head.n_den2), **f32)
         self.dgr_is_zero = True
         n = plan.offsets[-1]
-        self.flat_new = torch.zeros(n, **f32)
-        self.flat_acc = torch.zeros(n, **f32)
+        self.flat_acc = torch.zeros(n, **f32)               # the captured backward writes here; p.grad are views of it
         pieces = self.flat_acc.split(plan.sizes)
         self.acc_views = [p if len(sh) == 1 else p.view(sh) for p, sh in zip(pieces, plan.shapes)]
         self._grads_struct()
         xo, po, ld = C.c_size_t(), C.c_size_t(), C.c_int()
         lib.eagcn_model_atom_rep(self.index.ref(), C.byref(m), C.byref(xo), C.byref(po), C.byref(ld))
         T = self.index.T
-        self.xout_view = self.saved[xo.value:xo.value + 4 * T * ld.value].view(torch.float32).view(T, ld.value)
-        self.pad_view = self.saved[po.value:po.value + 4 * ld.value].view(torch.float32)
+        self._xout_views = [sv[xo.value:xo.value + 4 * T * ld.value].view(torch.float32).view(T, ld.value) for sv in self.saved]
+        self._pad_views = [sv[po.value:po.value + 4 * ld.value].view(torch.float32) for sv in self.saved]
         self.ptrs = [t.data_ptr() for t in plan._ptr_tensors]
 
+    @property
+    def xout_view(self):
+        return self._xout_views[self.cur]
+
+    @property
+    def pad_view(self):
+        return self._pad_views[self.cur]
+
     # -- C descriptors -------------------------------------------------------------------------------
-    def _cmodel(self):
+    def _cmodel(self, slot):
         m = L.Model.from_buffer_copy(self.plan.cmodel(True, 0, self.dropout))
-        sd = self.seeds_dev.data_ptr()
+        sd = self.seeds_dev[slot].data_ptr()
         for l in range(len(self.plan.layers)):
             m.layer[l].seed_dev = sd + 8 * l
         m.head_seed_dev = sd + 8 * 4
         m.input_packed = 1
-        # optional fork of off-critical-path backward work onto a second stream (graph branches).
-        # Measured on MI355X at the Tox21 shape: replay got SLOWER (0.85 vs 0.77 ms/step), so off by default.
-        self.aux = None
-        if os.environ.get('EAGCN_AUX_STREAM', '0') == '1':
-            self.aux = torch.cuda.Stream(device=self.device)
+        if self.aux is not None:
             m.aux_stream = self.aux.cuda_stream
-        self.cm = m
         return m
 
     def _grads_struct(self):
         plan = self.plan
-        base = self.flat_new.data_ptr()
+        base = self.flat_acc.data_ptr()
 
         def gptr(i):
             return base + 4 * plan.offsets[i]
@@ -151,15 +162,15 @@ class GraphRunner:
     # -- the two launch sequences --------------------------------------------------------------------
     def _call_forward(self):
         lib = L.load()
-        size_ptr = _ptr(self.size_static) if self.plan.molfp else C.c_void_p(0)
-        L.check(lib.eagcn_model_forward(self.index.ref(), C.byref(self.cm), C.c_void_p(0), size_ptr, _ptr(self.saved),
-                                        self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.out),
+        size_ptr = _ptr(self.size_static[self.cur]) if self.plan.molfp else C.c_void_p(0)
+        L.check(lib.eagcn_model_forward(self.index.ref(), C.byref(self.cms[self.cur]), C.c_void_p(0), size_ptr,
+                                        _ptr(self.saved[self.cur]), self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.out),
                                         _ptr(self.graph_rep), _stream()), 'eagcn_model_forward')
 
     def _call_backward(self):
         lib = L.load()
-        size_ptr = _ptr(self.size_static) if self.plan.molfp else C.c_void_p(0)
-        L.check(lib.eagcn_model_backward(self.index.ref(), C.byref(self.cm), size_ptr, _ptr(self.saved),
+        size_ptr = _ptr(self.size_static[self.cur]) if self.plan.molfp else C.c_void_p(0)
+        L.check(lib.eagcn_model_backward(self.index.ref(), C.byref(self.cms[self.cur]), size_ptr, _ptr(self.saved[self.cur]),
                                          self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.dout),
                                          _ptr(self.dgr), self.lg, C.byref(self.hg), _stream()), 'eagcn_model_backward')
 
@@ -200,14 +211,14 @@ class GraphRunner:
     def forward(self, adj, rels, afm, size, seed, overlap=False, bonds=None):
         lib = L.load()
         self._check_old_batches()
-        self.cur = self.step % 2
-        idx = self.index = self.slots[self.cur]
+        self.cur = cur = self.step % 2
+        idx = self.index = self.slots[cur]
         main = torch.cuda.current_stream(self.device)
         slot = self.step % _RING
         if self.meta_event[slot] is not None:                 # ring wrapped: this slot must be consumed first
             self._check_old_batches(force=True)
         # main-stream position now = after the backward of the previous step; the position recorded at the
-        # PREVIOUS forward entry = after the backward of the step before it, the last user of this index slot
+        # PREVIOUS forward entry = after the backward of the step before it, the last user of this slot
         entry = torch.cuda.Event()
         entry.record(main)
         slot_free = self.entry_events[1]
@@ -216,10 +227,13 @@ class GraphRunner:
             side = _index_stream(self.device)
             if slot_free is not None:
                 side.wait_event(slot_free)
-            istream = C.c_void_p(side.cuda_stream)
+            for t in (afm, adj, size) + tuple(rels or ()) + tuple(bonds or ()):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(side)                     # read on the side stream after this call returns
         else:
             side = main
-            istream = C.c_void_p(main.cuda_stream)
+        istream = C.c_void_p(side.cuda_stream)
+        # ---- everything that reads the caller's tensors: index, packed input, seeds, sizes -----------------
         if bonds is None:
             rel_ptrs = (C.c_void_p * idx.K)(*[r.data_ptr() for r in rels])
             L.check(lib.eagcn_index_build(_ptr(adj), rel_ptrs, idx.ref(), C.c_void_p(self.meta_host[slot].data_ptr()),
@@ -229,32 +243,33 @@ class GraphRunner:
             L.check(lib.eagcn_index_from_bonds(_ptr(bm), _ptr(bi), _ptr(bj), _ptr(bc), bm.numel(), idx.ref(),
                                                C.c_void_p(self.meta_host[slot].data_ptr()), istream),
                     'eagcn_index_from_bonds')
-        ev = torch.cuda.Event()
+        L.check(lib.eagcn_index_rows(idx.ref(), istream), 'eagcn_index_rows')
+        L.check(lib.eagcn_model_pack_input(idx.ref(), C.byref(self.cms[cur]), _ptr(afm), _ptr(self.saved[cur]),
+                                           self.saved_bytes, istream), 'eagcn_model_pack_input')
+        sh = self.seeds_host[slot]                            # pinned staging, one per ring slot (async copy source)
+        sn = sh.numpy()                                       # same derivation as ModelPlan.cmodel
+        for l in range(4):
+            sn[l] = (seed + 7919 * (l + 1)) & (2 ** 63 - 1)
+        sn[4] = (seed + 0x51ED27) & (2 ** 63 - 1)
+        with torch.cuda.stream(side):
+            self.seeds_dev[cur].copy_(sh, non_blocking=True)
+            if self.plan.molfp:
+                self.size_static[cur].copy_(size, non_blocking=True)
+        ev = torch.cuda.Event()           # meta_host[slot] is valid and seeds_host[slot] is free again after this point
         ev.record(side)
         self.meta_event[slot] = ev
-        L.check(lib.eagcn_index_rows(idx.ref(), istream), 'eagcn_index_rows')
         if overlap:
             done = torch.cuda.Event()
             done.record(side)
             main.wait_event(done)
-        stream = C.c_void_p(main.cuda_stream)
-        L.check(lib.eagcn_model_pack_input(idx.ref(), C.byref(self.cm), _ptr(afm), _ptr(self.saved), self.saved_bytes,
-                                           stream), 'eagcn_model_pack_input')
-        sn = self.seeds_np                                    # same derivation as ModelPlan.cmodel
-        for l in range(4):
-            sn[l] = (seed + 7919 * (l + 1)) & (2 ** 63 - 1)
-        sn[4] = (seed + 0x51ED27) & (2 ** 63 - 1)
-        self.seeds_dev.copy_(self.seeds_host, non_blocking=True)
-        if self.plan.molfp:
-            self.size_static.copy_(size, non_blocking=True)
         self.step += 1
         self.generation += 1
         self.plan.nbt_pending += 1        # num_batches_tracked: counted on the host, written by ModelPlan.flush_nbt()
-        if self.graphs[self.cur][0] is None:
+        if self.graphs[cur][0] is None:
             self._call_forward()                              # first use of a slot: eager (and the capture warm-up)
             self._capture()
         else:
-            self.graphs[self.cur][0].replay()
+            self.graphs[cur][0].replay()
         return self.generation
 
     def backward(self, dout, dgr, generation):
@@ -269,26 +284,29 @@ class GraphRunner:
         elif not self.dgr_is_zero:
             self.dgr.zero_()
             self.dgr_is_zero = True
+        params, views = self.plan.params, self.acc_views
+        grads = [p.grad for p in params]
+        # the captured backward OVERWRITES flat_acc (the storage p.grad are views of); if gradients of an earlier
+        # backward are still attached (accumulation across backward calls) keep them and add afterwards
+        keep = None
+        if any(g is v for g, v in zip(grads, views)):
+            keep = self.flat_acc.clone()
         if self.graphs[self.cur][1] is None:
             self._call_backward()
         else:
             self.graphs[self.cur][1].replay()
-        params, views = self.plan.params, self.acc_views
-        grads = [p.grad for p in params]
-        if all(g is None for g in grads):
-            self.flat_acc.copy_(self.flat_new)
+        if keep is None and all(g is None for g in grads):
             for p, v in zip(params, views):
                 p.grad = v
-        elif all(g is v for g, v in zip(grads, views)):
-            self.flat_acc.add_(self.flat_new)                 # gradient accumulation across backward passes
-        else:
-            pieces = self.flat_new.split(self.plan.sizes)
-            for p, g, piece, sh in zip(params, grads, pieces, self.plan.shapes):
-                piece = piece if len(sh) == 1 else piece.view(sh)
-                if g is None:
-                    p.grad = piece.clone()
-                else:
-                    g.add_(piece)
+            return
+        kept = keep.split(self.plan.sizes) if keep is not None else None
+        for i, (p, g, v) in enumerate(zip(params, grads, views)):
+            if g is None:
+                p.grad = v
+            elif g is v:
+                v.add_(kept[i] if v.dim() == 1 else kept[i].view(v.shape))
+            else:
+                g.add_(v)                                     # a gradient tensor of the caller's: accumulate into it
 
 
 class _GraphFn(torch.autograd.Function):
