@@ -22,7 +22,7 @@ namespace eagcn {
 // one BM x BN output tile of split z; Mx / Kx are the actual extents (<= g.M / g.K)
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, int D>
 __device__ __forceinline__ void gemm_tile(const GemmDesc& g, const int Mx, const int Kx, const int tile_x,
-                                          const int tile_y, const int z) {
+                                          const int tile_y, const int z, const int nsp) {
     constexpr int WM = BM / 2, WN = BN / 2;      // 2x2 waves
     constexpr int MR = WM / 16, NR = WN / 16;
     constexpr int LDA_S = A_KC ? (BK + 2) : (BM + 16);
@@ -47,7 +47,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& g, const int Mx, const
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
     const int m0 = tile_y * BM, n0 = tile_x * BN;
     // split-K range
-    const int kchunk = ((Kx + g.splits - 1) / g.splits + BK - 1) / BK * BK;
+    const int kchunk = ((Kx + nsp - 1) / nsp + BK - 1) / BK * BK;
     const int kbeg = z * kchunk;
     const int kend = min(Kx, kbeg + kchunk);
     float* C = g.C + (size_t)z * g.slab;
@@ -205,6 +205,13 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& g, const int Mx, const
         }
 }
 
+// Split-K factor actually used.  When the K extent is only known on the device (dW = X^T.dP over the packed
+// rows, sized on the host for the row CAPACITY) every split keeps at least 8 k-tiles of 16: the remaining
+// partial slabs are neither written nor read (unpack_grads applies the same rule, eagcn_eff_splits).
+__device__ __forceinline__ int eff_splits(const GemmDesc& g, int Kx) {
+    return g.K_dev ? max(1, min(g.splits, Kx >> 7)) : g.splits;
+}
+
 // XCD-aware order of `nwg` real workgroups: dispatch slot `lin` runs on XCD lin % 8; give every XCD a contiguous
 // run of tiles.  Bijective on [0, nwg).
 __device__ __forceinline__ int xcd_remap(int lin, int nwg) {
@@ -221,13 +228,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
     // XCD-aware tile order (workgroup b runs on XCD b % 8, each XCD has a private L2): every XCD gets a
     // contiguous run of the REAL tiles (the grid may be sized for a row capacity), so the column tiles
     // that share an A row panel hit the same L2.  Bijective for any tile count; affects speed only.
+    const int nsp = eff_splits(g, Kx);
     int tile_x, tile_y, z;
     {
         const int gx = gridDim.x;
         const int per_z = gx * ((Mx + BM - 1) / BM);           // tiles that have rows, per split
-        const int nwg = per_z * g.splits;
+        const int nwg = per_z * nsp;
         const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
-        if (blockIdx.y * gx + blockIdx.x >= per_z) return;     // uniform: capacity-only workgroup
+        if (blockIdx.y * gx + blockIdx.x >= per_z || (int)blockIdx.z >= nsp) return;   // uniform: capacity-only workgroup
         // linear dispatch index of the REAL workgroups (capacity-only ones were skipped above)
         const int lin = blockIdx.z * per_z + blockIdx.y * gx + blockIdx.x;
         (void)bid;
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
         tile_y = rem / gx;
         tile_x = rem - tile_y * gx;
     }
-    gemm_tile<BM, BN, BK, A_KC, B_KC, D>(g, Mx, Kx, tile_x, tile_y, z);
+    gemm_tile<BM, BN, BK, A_KC, B_KC, D>(g, Mx, Kx, tile_x, tile_y, z, nsp);
 }
 
 // The two backward products of a layer, dX = dP.W^T (rows = packed rows, capacity-sized) and dW = X^T.dP
@@ -253,18 +261,19 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(GemmDesc g0, GemmDes
         if (b >= nreal) return;
         const int nid = xcd_remap(b, nreal);
         const int ty = nid / gx;
-        gemm_tile<BM, BN, BK, true, true, D>(g0, Mx, g0.K, nid - ty * gx, ty, 0);
+        gemm_tile<BM, BN, BK, true, true, D>(g0, Mx, g0.K, nid - ty * gx, ty, 0, 1);
     } else {
         const int lin = b - first1;                                 // first1 is a multiple of 8
         const int Kx = g1.K_dev ? min(*g1.K_dev, g1.K) : g1.K;
         const int gx = (g1.N + BN - 1) / BN;
         const int per_z = gx * ((g1.M + BM - 1) / BM);
-        const int nwg = per_z * g1.splits;
+        const int nsp = eff_splits(g1, Kx);
+        const int nwg = per_z * nsp;
         if (lin >= nwg) return;
         const int nid = xcd_remap(lin, nwg);
         const int z = nid / per_z, rem = nid - z * per_z;
         const int ty = rem / gx;
-        gemm_tile<BM, BN, BK, false, false, D>(g1, g1.M, Kx, rem - ty * gx, ty, z);
+        gemm_tile<BM, BN, BK, false, false, D>(g1, g1.M, Kx, rem - ty * gx, ty, z, nsp);
     }
 }
 
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroup gg) {
         const int per_z = gx * ((g.M + BM - 1) / BM);
         const int z = lin / per_z, rem = lin - z * per_z;
         const int ty = rem / gx;
-        gemm_tile<BM, BN, BK, false, false, D>(g, g.M, g.K, rem - ty * gx, ty, z);
+        gemm_tile<BM, BN, BK, false, false, D>(g, g.M, g.K, rem - ty * gx, ty, z, g.splits);
     };
     const int b = blockIdx.x;
     if (b < gg.first1) run(gg.d0, b);

@@ -39,10 +39,9 @@ struct RowBnFwd {
 // Row BatchNorm: a workgroup owns 16 columns and RL "row lanes" per column (thread = 16*row_lane + column,
 // so 16 adjacent lanes read 64 contiguous bytes of one row).  Every lane keeps RB_CACHE of its rows in
 // registers: the statistics pass and the normalisation pass share ONE batch of loads when R <= RL*RB_CACHE.
-// RL = 16 (256 threads) for small row counts, 64 (1024 threads) beyond 512 rows.
-constexpr int RB_CACHE = 16;
+// RL = 16 (256 threads) up to 64 rows, 64 (1024 threads) beyond; 4 cached rows per lane up to 256 rows, 16 beyond.
 
-template <int RL>
+template <int RL, int RB_CACHE>
 __global__ __launch_bounds__(16 * RL) void rowbn_fwd_kernel(RowBnFwd a) {
     __shared__ double red[RL / 4][16][2];
     __shared__ float par[16][2];
@@ -138,7 +137,7 @@ struct RowBnBwd {
     uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
 };
 
-template <int RL>
+template <int RL, int RB_CACHE>
 __global__ __launch_bounds__(16 * RL) void rowbn_bwd_kernel(RowBnBwd a) {
     __shared__ double red[RL / 4][16][2];
     __shared__ double tot[16][2];
@@ -397,8 +396,10 @@ static int rowbn_fwd(hipStream_t s, int R, int F, Partial x, float* xs, float* x
     a.training = training; a.relu = relu; a.eps = eps; a.momentum = mom; a.seed = seed; a.seed_dev = seed_dev;
     fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
     ProfScope ps(PROF_HEAD, s);
-    if (R > rowbn_wide_rows()) rowbn_fwd_kernel<64><<<cdiv(F, 16), 1024, 0, s>>>(a);
-    else rowbn_fwd_kernel<16><<<cdiv(F, 16), 256, 0, s>>>(a);
+    // row lanes x rows cached per lane: one batch of loads covers all R rows whenever R <= RL * cache
+    if (R <= rowbn_wide_rows()) rowbn_fwd_kernel<16, 4><<<cdiv(F, 16), 256, 0, s>>>(a);
+    else if (R <= 256) rowbn_fwd_kernel<64, 4><<<cdiv(F, 16), 1024, 0, s>>>(a);
+    else rowbn_fwd_kernel<64, 16><<<cdiv(F, 16), 1024, 0, s>>>(a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
@@ -411,8 +412,9 @@ static int rowbn_bwd(hipStream_t s, int R, int F, Partial dy, const float* x, co
     a.training = training; a.relu = relu; a.seed = seed; a.seed_dev = seed_dev;
     fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
     ProfScope ps(PROF_HEAD, s);
-    if (R > rowbn_wide_rows()) rowbn_bwd_kernel<64><<<cdiv(F, 16), 1024, 0, s>>>(a);
-    else rowbn_bwd_kernel<16><<<cdiv(F, 16), 256, 0, s>>>(a);
+    if (R <= rowbn_wide_rows()) rowbn_bwd_kernel<16, 4><<<cdiv(F, 16), 256, 0, s>>>(a);
+    else if (R <= 256) rowbn_bwd_kernel<64, 4><<<cdiv(F, 16), 1024, 0, s>>>(a);
+    else rowbn_bwd_kernel<64, 16><<<cdiv(F, 16), 1024, 0, s>>>(a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

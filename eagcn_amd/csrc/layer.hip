@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
                                                             int nedge, const float* __restrict__ rsig, int wblocks,
                                                             const int32_t* __restrict__ meta) {
     nedge = min(nedge, (meta[EAGCN_META_T] + 15) / 16);        // edge-gradient workgroups that had rows
+    nsplit = max(1, min(nsplit, meta[EAGCN_META_T] >> 7));     // split-K partials actually written (gemm.hip eff_splits)
     if ((int)blockIdx.x < wblocks) {
         const int e = blockIdx.x * blockDim.x + threadIdx.x;
         if (e >= ld_in * fp) return;
@@ -797,7 +798,8 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         gw.K_dev = b->meta + EAGCN_META_T;
         GemmDesc gx{0, 1, b->T, d.ld_in, d.fp, sc.dP, d.fp, sc.Wcat, d.fp, dx, d.ld_in, 1, 0, gemm_work};
         gx.M_dev = b->meta + EAGCN_META_T;
-        if (dx && !forked && colaunch) {
+        static const bool pair = [] { const char* v = getenv("EAGCN_NO_PAIR"); return !(v && v[0] == '1'); }();
+        if (dx && !forked && colaunch && pair) {
             rc = launch_gemm_pair(gx, gw, s);                                    // dX and dW share one grid
             if (rc) return rc;
         } else {
