@@ -463,7 +463,9 @@ static int head_dw(hipStream_t s, int K, const DwProblem* pr) {
         tiles += cdiv(pr[i].M, 64) * cdiv(pr[i].N, 64);
         ok = ok && split_ok(1, 0, pr[i].M, pr[i].N, K, pr[i].M, pr[i].N);
     }
-    const int splits = ok ? head_splits(tiles, K) : 1;
+    // one grouped launch already fills ~50 workgroups; splitting K only pays once the chain of k-tiles is long
+    // (K = batch size: 256 -> 16 k-tiles, shorter than a reduction launch)
+    const int splits = (ok && K >= 1024) ? head_splits(tiles, K) : 1;
     GemmDesc d[3];
     Reduce3 r;
     int total = 0;
@@ -529,13 +531,20 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     if (!m->input_packed)
         RC(eagcn_pack_rows(b, afm, layout_width(&m->layer[0].in), &m->layer[0].in, sv.x0, stream));
     const float* x = sv.x0;
+    {   // the parameters of every layer are re-laid by one launch
+        const eagcn_layer_params* ps[4];
+        void* pk[4];
+        size_t pkb[4];
+        for (int l = 0; l < m->n_layers; ++l) { ps[l] = &m->layer[l]; pk[l] = sv.L[l].packed; pkb[l] = sv.L[l].packed_bytes; }
+        RC(pack_params_all(b, ps, pk, pkb, m->n_layers, stream));
+    }
     for (int l = 0; l < m->n_layers; ++l) {
         LayerSaved& L = sv.L[l];
         eagcn_layer_bufs w;
         memset(&w, 0, sizeof(w));
         w.x = x; w.P = L.P; w.Y = L.Y; w.rscale = L.rscale; w.bn = L.bn; w.xout = L.xout; w.pad_row = L.pad_row;
         w.scratch = sc.layer; w.scratch_bytes = sc.layer_bytes; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
-        RC(eagcn_layer_forward(b, &m->layer[l], &w, stream));
+        RC(layer_forward_impl(b, &m->layer[l], &w, stream, true));
         x = L.xout;
     }
     const eagcn_layer_params* last = &m->layer[m->n_layers - 1];

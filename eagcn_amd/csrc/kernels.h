@@ -56,6 +56,10 @@ struct ReadoutGrad {
 int layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                         const float* dxout, const ReadoutGrad* rg, const float* dpad_row, float* dx,
                         const eagcn_layer_grads* g, void* stream);
+int layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, void* stream,
+                       bool prepacked);
+int pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const* ps, void* const* packed,
+                    const size_t* packed_bytes, int n, void* stream);
 int readout_backward_pad(const eagcn_batch* b, const float* dg, const eagcn_layout* lay, const int64_t* size,
                          int mode, int F, float* dpad_row, void* stream);
 

@@ -62,10 +62,9 @@ __device__ __forceinline__ int packed_to_exact(const ColMapD& m, int cp) {
 }
 
 // ---- parameter packing -------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_params_kernel(ParamPtrs pp, ViewCols vc, ColMapD in, int ld_in,
-                                                           int fp, float* __restrict__ Wcat,
-                                                           float* __restrict__ colp, float* __restrict__ sig,
-                                                           float* __restrict__ rsig) {
+__device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const ViewCols& vc, const ColMapD& in, int ld_in,
+                                                 int fp, float* __restrict__ Wcat, float* __restrict__ colp,
+                                                 float* __restrict__ sig, float* __restrict__ rsig) {
     const int total = ld_in * fp;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int ip = e / fp, cp = e % fp;
@@ -90,6 +89,25 @@ __global__ __launch_bounds__(256) void pack_params_kernel(ParamPtrs pp, ViewCols
         sig[e] = (c >= 1 && c <= pp.channels[k]) ? sigmoidf_(pp.att_w[k][c - 1]) : 0.0f;
     }
     if (blockIdx.x == 0 && threadIdx.x < vc.K) rsig[threadIdx.x] = sigmoidf_(pp.self_r[threadIdx.x][0]);
+}
+__global__ __launch_bounds__(256) void pack_params_kernel(ParamPtrs pp, ViewCols vc, ColMapD in, int ld_in, int fp,
+                                                           float* __restrict__ Wcat, float* __restrict__ colp,
+                                                           float* __restrict__ sig, float* __restrict__ rsig) {
+    pack_params_body(pp, vc, in, ld_in, fp, Wcat, colp, sig, rsig);
+}
+// every layer of a model in one launch (blockIdx.y = layer): the parameters of all layers are known before the
+// first layer runs, and each packing launch is a few microseconds of fixed cost on the critical path
+struct PackJob {
+    ParamPtrs pp; ViewCols vc; ColMapD in; int ld_in, fp;
+    float *Wcat, *colp, *sig, *rsig;
+};
+struct PackJobs { PackJob j0, j1, j2, j3; };
+__global__ __launch_bounds__(256) void pack_params_multi_kernel(PackJobs jobs) {
+    // (an if-chain, not an indexed array: indexing the by-value argument block dynamically would move it to scratch)
+    if (blockIdx.y == 0) pack_params_body(jobs.j0.pp, jobs.j0.vc, jobs.j0.in, jobs.j0.ld_in, jobs.j0.fp, jobs.j0.Wcat, jobs.j0.colp, jobs.j0.sig, jobs.j0.rsig);
+    else if (blockIdx.y == 1) pack_params_body(jobs.j1.pp, jobs.j1.vc, jobs.j1.in, jobs.j1.ld_in, jobs.j1.fp, jobs.j1.Wcat, jobs.j1.colp, jobs.j1.sig, jobs.j1.rsig);
+    else if (blockIdx.y == 2) pack_params_body(jobs.j2.pp, jobs.j2.vc, jobs.j2.in, jobs.j2.ld_in, jobs.j2.fp, jobs.j2.Wcat, jobs.j2.colp, jobs.j2.sig, jobs.j2.rsig);
+    else pack_params_body(jobs.j3.pp, jobs.j3.vc, jobs.j3.in, jobs.j3.ld_in, jobs.j3.fp, jobs.j3.Wcat, jobs.j3.colp, jobs.j3.sig, jobs.j3.rsig);
 }
 
 // sum of per-workgroup partial pairs slab[s][cp][0..1] over s, L (16 or 64) lanes per column: with hundreds of
@@ -245,7 +263,7 @@ struct BwdArgs {
 // and operand) and has all BWD_ROWS rows in flight at once: a single batch of independent 16-byte loads
 // instead of a column loop of scalar ones.  View column ranges are multiples of 16, so the four columns share
 // their view.
-constexpr int BWD_ROWS = 8;
+constexpr int BWD_ROWS = 7;
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     __shared__ double da_s[EAGCN_MAX_VIEWS];
     const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
@@ -269,17 +287,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
         const float4 iv = *reinterpret_cast<const float4*>(a.bn + BN_INV * fp + cp);
         const float4 aw = *reinterpret_cast<const float4*>(a.colp + CP_AVEW * fp + cp);
         const int cu = weighted ? f : cp;           // first column of the upstream gradient
-        int ce[4] = {-1, -1, -1, -1};               // ... and the exact columns when that gradient is per molecule
-        if (a.rg.dg) {
+        // ... and its exact column when that gradient is per molecule (ce4: the four columns are consecutive
+        // exact columns, 16-byte aligned -> one load; otherwise each is looked up on its own)
+        auto exact = [&](int c) {
+            int eo = 0, po = 0, res = -1;
+            bool done = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int eo = 0, po = 0;
-                for (int sg = 0; sg < a.rg.map.nseg; ++sg) {
-                    if (cu + j < po + a.rg.map.p[sg]) { ce[j] = (cu + j - po < a.rg.map.w[sg]) ? eo + (cu + j - po) : -1; break; }
+            for (int sg = 0; sg < EAGCN_MAX_SEGS; ++sg) {     // unrolled: constant indices into the argument block
+                if (sg < a.rg.map.nseg && !done) {
+                    if (c < po + a.rg.map.p[sg]) { res = (c - po < a.rg.map.w[sg]) ? eo + (c - po) : -1; done = true; }
                     eo += a.rg.map.w[sg];
                     po += a.rg.map.p[sg];
                 }
             }
+            return res;
+        };
+        int ce0 = -1;
+        bool ce4 = false;
+        if (a.rg.dg) {
+            ce0 = exact(cu);
+            ce4 = ce0 >= 0 && exact(cu + 3) == ce0 + 3 && (ce0 & 3) == 0 && (a.rg.F & 3) == 0 &&
+                  (reinterpret_cast<uintptr_t>(a.rg.dg) & 15) == 0;
         }
         double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, dak = 0.0;
         for (int rb = blockIdx.x; rb < rows; rb += BWD_ROWS * nwg) {
@@ -295,10 +323,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
                         const int mol = a.bt.row_mol[r];
                         const float* g = a.rg.dg + (size_t)mol * a.rg.F;
                         float4 v;
-                        v.x = ce[0] >= 0 ? g[ce[0]] : 0.0f;
-                        v.y = ce[1] >= 0 ? g[ce[1]] : 0.0f;
-                        v.z = ce[2] >= 0 ? g[ce[2]] : 0.0f;
-                        v.w = ce[3] >= 0 ? g[ce[3]] : 0.0f;
+                        if (ce4) {
+                            v = *reinterpret_cast<const float4*>(g + ce0);
+                        } else {
+                            const int e1 = exact(cu + 1), e2 = exact(cu + 2), e3 = exact(cu + 3);
+                            v.x = ce0 >= 0 ? g[ce0] : 0.0f;
+                            v.y = e1 >= 0 ? g[e1] : 0.0f;
+                            v.z = e2 >= 0 ? g[e2] : 0.0f;
+                            v.w = e3 >= 0 ? g[e3] : 0.0f;
+                        }
                         if (a.rg.mode == 1) {
                             const float is = 1.0f / (float)a.rg.size[mol];
                             v.x *= is; v.y *= is; v.z *= is; v.w *= is;
@@ -505,7 +538,7 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     // row-partial slabs of the BatchNorm backward: 8 rows per workgroup, at most 2048 workgroups and at most
     // 32 MB of fp64 partials (wide layers: Fp = 6320 -> 331 workgroups)
     {
-        const long by_rows = cdiv(b->T + 1, 8);
+        const long by_rows = cdiv(b->T + 1, BWD_ROWS);
         const long by_bytes = std::max<long>(64, (32L << 20) / ((long)d.fp * 16));
         d.gxb = (int)std::max<long>(1, std::min<long>(std::min<long>(by_rows, 2048), by_bytes));
     }
@@ -621,6 +654,41 @@ extern "C" size_t eagcn_layer_bwd_scratch_bytes(const eagcn_batch* b, const eagc
 
 extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                                    void* stream) {
+    return layer_forward_impl(b, p, w, stream, false);
+}
+
+// parameters of up to four layers re-laid into their `packed` blocks by ONE launch (model engine)
+int eagcn::pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const* ps, void* const* packed,
+                           const size_t* packed_bytes, int n, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    EAGCN_CHECK_ARG(n >= 1 && n <= 4, "pack_params_all: 1..4 layers");
+    PackJob jobs[4];
+    size_t wmax = 0;
+    for (int l = 0; l < 4; ++l) {
+        const int ll = l < n ? l : n - 1;
+        int rc = check_layer(b, ps[ll], "eagcn_model_forward");
+        if (rc) return rc;
+        const LayerDims d = layer_dims(b, ps[ll]);
+        Packed pk;
+        const size_t pneed = carve_packed(packed[ll], d, &pk);
+        if (pneed > packed_bytes[ll]) {
+            set_error("pack_params_all: packed buffer of layer %d too small (%zu < %zu)", ll, packed_bytes[ll], pneed);
+            return EAGCN_ERR_SCRATCH;
+        }
+        jobs[l].pp = param_ptrs(b, ps[ll]); jobs[l].vc = d.vc; jobs[l].in = make_colmap(&ps[ll]->in);
+        jobs[l].ld_in = d.ld_in; jobs[l].fp = d.fp;
+        jobs[l].Wcat = pk.Wcat; jobs[l].colp = pk.colp; jobs[l].sig = pk.sig; jobs[l].rsig = pk.rsig;
+        if (l < n) wmax = std::max(wmax, d.wslab);
+    }
+    PackJobs pj{jobs[0], jobs[1], jobs[2], jobs[3]};
+    ProfScope ps_(PROF_PACK, s);
+    pack_params_multi_kernel<<<dim3(ew_grid(wmax), n), 256, 0, s>>>(pj);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
+                              void* stream, bool prepacked) {
     hipStream_t s = (hipStream_t)stream;
     int rc = check_layer(b, p, "eagcn_layer_forward");
     if (rc) return rc;
@@ -644,7 +712,8 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
         }
         sc.Wcat = pk.Wcat; sc.colp = pk.colp; sc.sig = pk.sig; sc.rsig = pk.rsig;
     }
-    {
+    EAGCN_CHECK_ARG(!prepacked || w->packed, "eagcn_layer_forward: prepacked parameters need the packed block");
+    if (!prepacked) {
         ProfScope ps(PROF_PACK, s);
         pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.colp, sc.sig, sc.rsig);
     }
