@@ -71,14 +71,14 @@ def algorithmic_flops(cfg, sizes):
 
 
 def committed_traffic():
-    """HBM-side bytes per launch of the layer GEMMs from the committed PMC passes of this command
+    """HBM-side bytes per launch of the dominant kernel (gemm_f32_pair_kernel) from the committed PMC passes of this command
     (tools/pmc_traffic.py -> profiles/r01_pmc_traffic.json; rocprofv3 cannot run inside bench.py)."""
     path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
     try:
         table = json.load(open(path))
     except Exception:
         return None, None
-    big = [v for k, v in table.items() if 'gemm_f32_kernel' in k and '>=256 workgroups' in k]
+    big = [v for k, v in table.items() if 'gemm_f32_pair_kernel' in k]
     n = sum(v['launches'] for v in big)
     if not n:
         return None, None
@@ -248,7 +248,10 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        g_ms, g_work, g_n = kern['gemm']
+        # dominant kernel: the paired backward products of the hidden layers (dX = dP.W^T and dW = X^T.dP in one grid);
+        # models without a hidden layer below the top have no such launch -> the plain layer GEMMs
+        pair = kern.get('gemm_pair', (0.0, 0.0, 0))[2] > 0
+        g_ms, g_work, g_n = kern['gemm_pair'] if pair else kern['gemm']
         achieved = (g_work / (g_ms * 1e-3)) / 1e12 if g_ms > 0 else 0.0
         traffic, traffic_src = committed_traffic() if args.workload == 'tox21_c2' and B == 256 else (None, None)
         out = {
@@ -265,16 +268,20 @@ def main():
                        'input': args.input, 'global_batch': world * B, 'atoms_per_batch': int(mb.sizes.sum()),
                        'parallelism': 'dp%d' % world},
             'algorithmic_gflop_per_step': round(algorithmic_flops(cfg, mb.sizes) / 1e9, 3),
-            'roofline': {'kernel': 'gemm_f32_kernel (flat X.[W_1..W_K] transform + its two backward products)',
+            'roofline': {'kernel': 'gemm_f32_pair_kernel<64,64,16,4> (dX = dP.W^T and dW = X^T.dP of a layer in one grid, fp32 MFMA)'
+                                   if pair else 'gemm_f32_kernel (flat X.[W_1..W_K] transform and its backward products)',
                          'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          'traffic': None if traffic is None else round(traffic),
                          'traffic_note': None if traffic is None else
-                         'bytes per launch of the layer-2 GEMMs (>=256 workgroups), memory-side FETCH_SIZE x2 + WRITE_SIZE '
-                         'from %s; algorithmic operand bytes are 22-29 MB' % traffic_src,
+                         'bytes per launch of gemm_f32_pair_kernel, memory-side FETCH_SIZE x2 + WRITE_SIZE from %s; '
+                         'algorithmic operand bytes are 44.6 MB (dP 13.5, X 7.7, W 1.1 read; dX 7.7 and 13 split-K '
+                         'partials of dW 14.6 written)' % traffic_src,
                          'launches': int(g_n), 'avg_launch_us': round(g_ms * 1e3 / max(g_n, 1), 3),
                          'measured': 'HIP events on the launch stream, %s' % ('inside the timed region' if profile_in_loop else
                                      '%d eager steps of the same workload right after the timed graph-replay region' % prof_steps)},
+            'layer_gemm_tflops_all': round(((kern['gemm'][1] + kern.get('gemm_pair', (0, 0, 0))[1]) /
+                                            max((kern['gemm'][0] + kern.get('gemm_pair', (0, 0, 0))[0]) * 1e-3, 1e-12)) / 1e12, 3),
             'kernel_ms_per_step': {k: round(v[0] / prof_steps, 4) for k, v in kern.items()},
             'execution': 'eager launches' if args.eager else 'HIP graph replay (forward + backward), eager batch index',
         }

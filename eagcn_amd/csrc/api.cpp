@@ -33,8 +33,8 @@ hipEvent_t pool_event() {
 }
 
 // ---- per-kernel-class timing ---------------------------------------------------------------------
-enum { PROF_NTAGS = 8 };
-static const char* kTagNames[PROF_NTAGS] = {"index", "pack", "gemm", "agg", "bn", "edge", "readout", "head"};
+enum { PROF_NTAGS = 9 };
+static const char* kTagNames[PROF_NTAGS] = {"index", "pack", "gemm", "agg", "bn", "edge", "readout", "head", "gemm_pair"};
 struct ProfRec { hipEvent_t a, b; };
 struct ProfState {
     bool on = false;

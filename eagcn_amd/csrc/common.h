@@ -162,7 +162,8 @@ inline int layout_width(const eagcn_layout* l) {
 }
 
 // ---- optional per-kernel-class timing (HIP events on the launch stream), off by default --------
-enum ProfTag { PROF_INDEX = 0, PROF_PACK, PROF_GEMM, PROF_AGG, PROF_BN, PROF_EDGE, PROF_READOUT, PROF_HEAD, PROF_NTAGS };
+enum ProfTag { PROF_INDEX = 0, PROF_PACK, PROF_GEMM, PROF_AGG, PROF_BN, PROF_EDGE, PROF_READOUT, PROF_HEAD, PROF_GEMM_PAIR,
+               PROF_NTAGS };
 bool prof_on();
 void prof_begin(int tag, hipStream_t s, double work);
 void prof_end(int tag, hipStream_t s);

@@ -354,7 +354,7 @@ int launch_gemm_pair(const GemmDesc& dx, const GemmDesc& dw, hipStream_t s) {
     const int n1 = cdiv(g1.M, 64) * cdiv(g1.N, 64) * g1.splits;
     const double w0 = g0.work > 0.0 ? g0.work : 2.0 * g0.M * g0.N * g0.K;
     const double w1 = g1.work > 0.0 ? g1.work : 2.0 * g1.M * g1.N * g1.K;
-    ProfScope ps(g0.prof_tag, s, w0 + w1);
+    ProfScope ps(PROF_GEMM_PAIR, s, w0 + w1);
     gemm_f32_pair_kernel<64, 64, 16, 4><<<first1 + n1, 256, 0, s>>>(g0, g1, first1);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
