@@ -19,6 +19,8 @@
 // (relative contribution <= N*1e-9).
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -189,10 +191,10 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
 // batch (a 132-atom molecule = 9 dependent column groups in one wave, while a typical 18-atom tile is
 // done after 2); splitting the groups over the waves cuts that chain 4x.  Partial accumulators and partial
 // row sums are combined through LDS by wave 0, which also runs the epilogue.
-template <int CT, bool TRANS>
+template <int CT, bool TRANS, int NW = 4>
 __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const int by, const int gx) {
     __shared__ float sig_s[256];
-    __shared__ float red_s[CT][4][64];                // ONE partial-accumulator buffer, reused wave by wave
+    __shared__ float red_s[CT][4][64];                // [accumulator register g][lane]                // ONE partial-accumulator buffer, reused wave by wave
     __shared__ float dred_s[4][16];
     __shared__ double st_s[TRANS ? 1 : CT * 16 * 2];
     const int k = by / a.nchunk, cc = by % a.nchunk;
@@ -207,15 +209,40 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
     int4 ti_next = reinterpret_cast<const int4*>(bt.tile_info)[bx];
     const float r = a.rsig[k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float sig_v = a.sig[k * 256 + tid];
+    float sig_v[4 / NW];                              // NW*64 threads fetch the 256-entry table
+#pragma unroll
+    for (int i = 0; i < 4 / NW; ++i) sig_v[i] = a.sig[k * 256 + tid + i * NW * 64];
     const int ntiles = dev_tiles(a.bt);
     if (bx >= ntiles) return;            // capacity-sized grid: no tile for this workgroup (its
                                                       // stats slab is not read either: bn_finalize counts live slabs)
     const int nct = min(CT, ntile_k - ct0);
     const int c0 = a.vc.off[k] + ct0 * 16;
     const int li = lane & 15, q = lane >> 4;
-    sig_s[tid] = sig_v;
-    if (!TRANS) for (int i = tid; i < CT * 16 * 2; i += 256) st_s[i] = 0.0;
+    // Column map of the CT 16-wide MFMA tiles: tiles are taken four at a time so that a lane's four B-operand
+    // values (and its four results) are ONE float4 = 16 adjacent lanes cover 256 contiguous bytes of a row
+    // instead of four 64-byte pieces (half the memory requests, whole 128-byte lines):
+    //   ct <  4Q: column = 64*(ct/4) + 4*li + ct%4         ct >= 4Q: column = 64*Q + 16*(ct-4Q) + li
+    constexpr int Q = CT / 4;
+    const int ncol = nct * 16;                        // valid columns of this chunk
+    auto tile_col0 = [&](int ct) { return ct < 4 * Q ? (ct >> 2) * 64 : Q * 64 + (ct - 4 * Q) * 16; };   // first column a tile touches
+    auto lane_col = [&](int ct) { return ct < 4 * Q ? (ct >> 2) * 64 + 4 * li + (ct & 3) : Q * 64 + (ct - 4 * Q) * 16 + li; };
+    // B operands of one source row for all tiles (zero where the column is outside the chunk)
+    auto load_row = [&](const float* rowp, bool ok, float (&bv)[CT]) {
+#pragma unroll
+        for (int m = 0; m < Q; ++m) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && m * 64 + 4 * li < ncol) v = *reinterpret_cast<const float4*>(rowp + m * 64 + 4 * li);
+            bv[4 * m + 0] = v.x; bv[4 * m + 1] = v.y; bv[4 * m + 2] = v.z; bv[4 * m + 3] = v.w;
+        }
+#pragma unroll
+        for (int ct = 4 * Q; ct < CT; ++ct) {
+            const int c = Q * 64 + (ct - 4 * Q) * 16 + li;
+            bv[ct] = (ok && c < ncol) ? rowp[c] : 0.0f;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 4 / NW; ++i) sig_s[tid + i * NW * 64] = sig_v[i];
+    if (!TRANS) for (int i = tid; i < CT * 16 * 2; i += NW * 64) st_s[i] = 0.0;
     __syncthreads();
     // (BatchNorm partial sums live in LDS, st_s, not in registers: 36 VGPRs less for CT = 9, i.e. one more
     //  resident workgroup per CU for a kernel whose speed is the number of round trips in flight)
@@ -227,16 +254,16 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
         const uint8_t* codeb = bt.code + ((size_t)k * bt.B + b) * bt.N * bt.ldc;
         const int ia = rt * 16 + li;                  // A-operand row of this lane = output row
         const int ngroups = (n + 15) >> 4;
-        const int nw = min(4, ngroups);               // waves that have a share of the K range
+        const int nw = min(NW, ngroups);               // waves that have a share of the K range
         f32x4 acc[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* sbase = a.src + (size_t)r0 * a.lds + c0 + li;
+        const float* sbase = a.src + (size_t)r0 * a.lds + c0;
         float dsum = 0.0f;
 
         if (!TRANS) {
             const float mi = (ia < n) ? bt.row_m[r0 + ia] : 0.0f;
-            for (int grp = wave; grp < ngroups; grp += 4) {
+            for (int grp = wave; grp < ngroups; grp += NW) {
                 const int j0 = grp * 16;
                 uint4 cw = make_uint4(0u, 0u, 0u, 0u);
                 if (ia < n) cw = *reinterpret_cast<const uint4*>(codeb + (size_t)ia * bt.ldc + j0);
@@ -246,9 +273,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int j = j0 + 4 * t + q;
-                    const float* srow = sbase + (size_t)min(j, n - 1) * a.lds;
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) bv[t][ct] = (j < n && ct < nct) ? srow[ct * 16] : 0.0f;
+                    load_row(sbase + (size_t)min(j, n - 1) * a.lds, j < n, bv[t]);
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -262,7 +287,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
                         dsum += u;
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct)
-                            if (ct < nct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv[t][ct], acc[ct], 0, 0, 0);
+                            if (tile_col0(ct) < ncol) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv[t][ct], acc[ct], 0, 0, 0);
                     }
                 }
             }
@@ -270,7 +295,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
             dsum += __shfl_xor(dsum, 32);
         } else {
             // dP[j,:] = sum_i A^[i,j] dY'[i,:]  (rscale carries m_i / rowsum_i)
-            for (int grp = wave; grp < ngroups; grp += 4) {
+            for (int grp = wave; grp < ngroups; grp += NW) {
                 const int i0 = grp * 16;
                 uint32_t cc4[4];
                 float rs4[4], bv[4][CT];
@@ -283,9 +308,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
                         cc4[t] = codeb[(size_t)i * bt.ldc + ia];
                         rs4[t] = a.rscale[(size_t)k * bt.T + r0 + i];
                     }
-                    const float* srow = sbase + (size_t)min(i, n - 1) * a.lds;
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) bv[t][ct] = (i < n && ct < nct) ? srow[ct * 16] : 0.0f;
+                    load_row(sbase + (size_t)min(i, n - 1) * a.lds, i < n, bv[t]);
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -296,7 +319,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
                         u *= rs4[t];
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct)
-                            if (ct < nct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv[t][ct], acc[ct], 0, 0, 0);
+                            if (tile_col0(ct) < ncol) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv[t][ct], acc[ct], 0, 0, 0);
                     }
                 }
             }
@@ -310,7 +333,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
                 if (wave == w2) {
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
-                        if (ct < nct) {
+                        if (tile_col0(ct) < ncol) {
 #pragma unroll
                             for (int g = 0; g < 4; ++g) red_s[ct][g][lane] = acc[ct][g];
                         }
@@ -319,7 +342,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
                 if (wave == 0) {
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
-                        if (ct < nct) {
+                        if (tile_col0(ct) < ncol) {
 #pragma unroll
                             for (int g = 0; g < 4; ++g) acc[ct][g] += red_s[ct][g][lane];
                         }
@@ -337,37 +360,58 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
                 float scr[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) scr[g] = __shfl(sc, q * 4 + g);
+                // results scaled in place, BatchNorm partial sums per column, then float4 / scalar stores
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    if (ct < nct) {
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int lc = lane_col(ct);
+                    if (lc < ncol) {
                         double t1 = 0.0, t2 = 0.0;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int row = rt * 16 + q * 4 + g;
-                            if (row < n) {
-                                const float y = acc[ct][g] * scr[g];
-                                a.dst[(size_t)(r0 + row) * a.ldd + c0 + ct * 16 + li] = y;
-                                t1 += (double)y;
-                                t2 += (double)y * (double)y;
-                            }
+                            const float y = acc[ct][g] * scr[g];
+                            acc[ct][g] = y;
+                            if (row < n) { t1 += (double)y; t2 += (double)y * (double)y; }
                         }
                         t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
                         t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
                         if (q == 0) {                 // only wave 0 touches st_s between the barriers
-                            st_s[(ct * 16 + li) * 2 + 0] += t1;
-                            st_s[(ct * 16 + li) * 2 + 1] += t2;
+                            st_s[lc * 2 + 0] += t1;
+                            st_s[lc * 2 + 1] += t2;
                         }
                     }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = rt * 16 + q * 4 + g;
+                    if (row < n) {
+                        float* drow = a.dst + (size_t)(r0 + row) * a.ldd + c0;
+#pragma unroll
+                        for (int m = 0; m < Q; ++m)
+                            if (m * 64 + 4 * li < ncol)
+                                *reinterpret_cast<float4*>(drow + m * 64 + 4 * li) =
+                                    make_float4(acc[4 * m][g], acc[4 * m + 1][g], acc[4 * m + 2][g], acc[4 * m + 3][g]);
+#pragma unroll
+                        for (int ct = 4 * Q; ct < CT; ++ct)
+                            if (lane_col(ct) < ncol) drow[lane_col(ct)] = acc[ct][g];
+                    }
+                }
             } else {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    if (ct < nct) {
+                for (int g = 0; g < 4; ++g) {
+                    const int row = rt * 16 + q * 4 + g;
+                    if (row < n) {
+                        float* drow = a.dst + (size_t)(r0 + row) * a.ldd + c0;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int row = rt * 16 + q * 4 + g;
-                            if (row < n) a.dst[(size_t)(r0 + row) * a.ldd + c0 + ct * 16 + li] = acc[ct][g];
-                        }
+                        for (int m = 0; m < Q; ++m)
+                            if (m * 64 + 4 * li < ncol)
+                                *reinterpret_cast<float4*>(drow + m * 64 + 4 * li) =
+                                    make_float4(acc[4 * m][g], acc[4 * m + 1][g], acc[4 * m + 2][g], acc[4 * m + 3][g]);
+#pragma unroll
+                        for (int ct = 4 * Q; ct < CT; ++ct)
+                            if (lane_col(ct) < ncol) drow[lane_col(ct)] = acc[ct][g];
                     }
+                }
             }
         }
         if (nw > 1) __syncthreads();                  // red_s / dred_s are reused by the next tile
@@ -377,7 +421,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
         // per-workgroup partial BatchNorm sums (accumulated in st_s by wave 0) -> slab[bx][column][2]
         __syncthreads();
         const int fp = a.vc.off[a.vc.K];
-        for (int i = tid; i < nct * 16 * 2; i += 256)
+        for (int i = tid; i < nct * 16 * 2; i += NW * 64)
             a.stats[((size_t)bx * fp + c0) * 2 + i] = st_s[i];
     }
 }
@@ -386,11 +430,16 @@ template <int CT, bool TRANS>
 __global__ __launch_bounds__(256) void agg_wave_kernel(AggArgs a) { agg_wave_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 template <int CT, bool TRANS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg_kernel(AggArgs a) { agg_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
+// two waves per workgroup: most tiles have one or two column groups, so two of four waves would idle
+template <int CT, bool TRANS>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg2_kernel(AggArgs a) { agg_body<CT, TRANS, 2>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 template <bool TRANS>
 static int launch_agg_t(const AggArgs& a, int ct, dim3 grid, bool ksplit, hipStream_t s) {
     switch (ct) {
-#define EAGCN_AGG_CASE(N) case N: if (ksplit) agg_kernel<N, TRANS><<<grid, 256, 0, s>>>(a); \
+    static const int nw2 = [] { const char* e = getenv("EAGCN_AGG_NW"); return e ? atoi(e) : 4; }();
+#define EAGCN_AGG_CASE(N) case N: if (ksplit && nw2 == 2) agg2_kernel<N, TRANS><<<grid, 128, 0, s>>>(a); \
+                                  else if (ksplit) agg_kernel<N, TRANS><<<grid, 256, 0, s>>>(a); \
                                   else agg_wave_kernel<N, TRANS><<<grid, 256, 0, s>>>(a); break;
         EAGCN_AGG_CASE(1) EAGCN_AGG_CASE(2) EAGCN_AGG_CASE(3) EAGCN_AGG_CASE(4) EAGCN_AGG_CASE(5)
         EAGCN_AGG_CASE(6) EAGCN_AGG_CASE(7) EAGCN_AGG_CASE(8) EAGCN_AGG_CASE(9) EAGCN_AGG_CASE(10)
