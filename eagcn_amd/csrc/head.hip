@@ -65,6 +65,10 @@ __global__ __launch_bounds__(16 * RL) void rowbn_fwd_kernel(RowBnFwd a) {
             }
         }
     };
+    // per-column parameters are requested before the statistics pass: together with the first chunk of rows
+    // they are ONE round trip (they used to be a second and a third one after the reduction)
+    const float gam = a.gamma[c], bet = a.beta[c];
+    const float rm0 = a.run_mean[c], rv0 = a.run_var[c];
     float mu, inv;
     if (a.training) {
         double s1 = 0.0, s2 = 0.0;
@@ -91,18 +95,18 @@ __global__ __launch_bounds__(16 * RL) void rowbn_fwd_kernel(RowBnFwd a) {
             par[col_l][1] = (float)(1.0 / sqrt(var + (double)a.eps));
             if (cr < a.F) {
                 const double unbiased = var * ((double)a.R / ((double)a.R - 1.0));
-                a.run_mean[c] = (float)((1.0 - a.momentum) * (double)a.run_mean[c] + a.momentum * mean);
-                a.run_var[c] = (float)((1.0 - a.momentum) * (double)a.run_var[c] + a.momentum * unbiased);
+                a.run_mean[c] = (float)((1.0 - a.momentum) * (double)rm0 + a.momentum * mean);
+                a.run_var[c] = (float)((1.0 - a.momentum) * (double)rv0 + a.momentum * unbiased);
             }
         }
         __syncthreads();
         mu = par[col_l][0];
         inv = par[col_l][1];
     } else {
-        mu = a.run_mean[c];
-        inv = 1.0f / sqrtf(a.run_var[c] + a.eps);
+        mu = rm0;
+        inv = 1.0f / sqrtf(rv0 + a.eps);
     }
-    const float sc = a.gamma[c] * inv, sh = a.beta[c] - mu * sc;
+    const float sc = gam * inv, sh = bet - mu * sc;
     if (cr >= a.F) return;
     if (rl == 0) {
         a.bn[RB_SC * a.F + c] = sc;

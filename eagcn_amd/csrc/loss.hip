@@ -7,23 +7,42 @@
 
 namespace eagcn {
 
-// single workgroup: B*T is at most a few 10^4 elements
+// single workgroup: B*T is at most a few 10^4 elements.  A thread keeps up to LOSS_CACHE of its elements (logit,
+// label, both class weights) in registers: all loads of the kernel are ONE batch, and the gradient pass reuses
+// them (a loop of dependent load pairs per element made this 8 us for 3072 elements).
+constexpr int LOSS_CACHE = 4;
 __global__ __launch_bounds__(1024) void bce_loss_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ w, int B, int T,
                                                          float* __restrict__ loss, float* __restrict__ dx) {
     __shared__ double s_sum[16];
     __shared__ int s_cnt[16];
     const int n = B * T;
+    const int nthr = blockDim.x;
+    float xc[LOSS_CACHE], yc[LOSS_CACHE], w1c[LOSS_CACHE], w0c[LOSS_CACHE];
+#pragma unroll
+    for (int u = 0; u < LOSS_CACHE; ++u) {
+        const int i = threadIdx.x + u * nthr;
+        const bool ok = i < n;
+        const int t = ok ? i % T : 0;
+        xc[u] = ok ? x[i] : 0.0f;
+        yc[u] = ok ? y[i] : -1.0f;                     // -1 = "no label": weight 0, not counted
+        w1c[u] = w[t * 2 + 0];
+        w0c[u] = w[t * 2 + 1];
+    }
     double acc = 0.0;
     int cnt = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float yi = y[i], xi = x[i];
-        const int t = i % T;
-        const float wi = yi == 1.0f ? w[t * 2 + 0] : (yi == 0.0f ? w[t * 2 + 1] : 0.0f);
+    auto term = [&](float xi, float yi, float w1, float w0) {
+        const float wi = yi == 1.0f ? w1 : (yi == 0.0f ? w0 : 0.0f);
         cnt += (yi == 1.0f || yi == 0.0f) ? 1 : 0;
         // max(x,0) - x*y + log1p(exp(-|x|)): the numerically stable form ATen uses
         const float l = fmaxf(xi, 0.0f) - xi * yi + log1pf(expf(-fabsf(xi)));
         acc += (double)(wi * l);
+    };
+#pragma unroll
+    for (int u = 0; u < LOSS_CACHE; ++u) term(xc[u], yc[u], w1c[u], w0c[u]);
+    for (int i = threadIdx.x + LOSS_CACHE * nthr; i < n; i += nthr) {      // beyond the cache (large B*T)
+        const int t = i % T;
+        term(x[i], y[i], w[t * 2 + 0], w[t * 2 + 1]);
     }
     acc = wave_sum(acc);
     cnt = wave_sum(cnt);
@@ -34,11 +53,18 @@ __global__ __launch_bounds__(1024) void bce_loss_kernel(const float* __restrict_
     for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { tot += s_sum[k]; c += s_cnt[k]; }
     const float inv = 1.0f / (float)c;
     if (threadIdx.x == 0) loss[0] = (float)(tot / (double)c);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float yi = y[i], xi = x[i];
+    auto grad = [&](float xi, float yi, float w1, float w0) {
+        const float wi = yi == 1.0f ? w1 : (yi == 0.0f ? w0 : 0.0f);
+        return wi * (1.0f / (1.0f + expf(-xi)) - yi) * inv;
+    };
+#pragma unroll
+    for (int u = 0; u < LOSS_CACHE; ++u) {
+        const int i = threadIdx.x + u * nthr;
+        if (i < n) dx[i] = grad(xc[u], yc[u], w1c[u], w0c[u]);
+    }
+    for (int i = threadIdx.x + LOSS_CACHE * nthr; i < n; i += nthr) {
         const int t = i % T;
-        const float wi = yi == 1.0f ? w[t * 2 + 0] : (yi == 0.0f ? w[t * 2 + 1] : 0.0f);
-        dx[i] = wi * (1.0f / (1.0f + expf(-xi)) - yi) * inv;
+        dx[i] = grad(x[i], y[i], w[t * 2 + 0], w[t * 2 + 1]);
     }
 }
 
