@@ -27,6 +27,7 @@ from . import _lib as L
 from .ops import _index_stream, _ptr, _stream
 
 _RING = 4
+_SIDE_AFTER_FWD = os.environ.get('EAGCN_SIDE_AFTER_FWD', '0') == '1'   # measured: no difference (0.553 ms either way)
 
 
 class StaticIndex:
@@ -77,6 +78,7 @@ class GraphRunner:
         self.index = self.slots[0]
         self.graphs = [[None, None], [None, None]]            # per slot: [forward graph, backward graph]
         self.entry_events = [None, None]                      # main-stream position at the last two forward entries
+        self.fwd_done = None                                  # main-stream position after the last forward graph
         self.dropout = float(dropout)
         self.seeds_dev = [torch.zeros(8, dtype=torch.int64, device=device) for _ in range(2)]
         self.seeds_host = [torch.zeros(8, dtype=torch.int64).pin_memory() for _ in range(_RING)]
@@ -227,6 +229,12 @@ class GraphRunner:
             side = _index_stream(self.device)
             if slot_free is not None:
                 side.wait_event(slot_free)
+            # ... and it is held back until the FORWARD of the previous step has finished: from there on the main
+            # stream runs the caller's loss and the head's backward -- short kernels on a few CUs -- under which
+            # the HBM-streaming index scan costs nothing (at the start of a step it would compete with the
+            # layer GEMMs and aggregations)
+            if self.fwd_done is not None and _SIDE_AFTER_FWD:
+                side.wait_event(self.fwd_done)
             for t in (afm, adj, size) + tuple(rels or ()) + tuple(bonds or ()):
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(side)                     # read on the side stream after this call returns
@@ -270,6 +278,9 @@ class GraphRunner:
             self._capture()
         else:
             self.graphs[cur][0].replay()
+        if overlap:
+            self.fwd_done = torch.cuda.Event()
+            self.fwd_done.record(main)
         return self.generation
 
     def backward(self, dout, dgr, generation):
