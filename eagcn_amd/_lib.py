@@ -88,6 +88,7 @@ SIGNATURES = {
     'eagcn_index_build': (C.c_int, [_fp, C.POINTER(_fp), C.POINTER(Batch), _fp, _fp]),
     'eagcn_index_from_bonds': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.POINTER(Batch), _fp, _fp]),
     'eagcn_index_rows': (C.c_int, [C.POINTER(Batch), _fp]),
+    'eagcn_set_gemm_mode': (C.c_int, [C.c_int]),
     'eagcn_pack_rows': (C.c_int, [C.POINTER(Batch), _fp, C.c_int, C.POINTER(Layout), _fp, _fp]),
     'eagcn_unpack_rows': (C.c_int, [C.POINTER(Batch), _fp, C.POINTER(Layout), _fp, _fp, C.c_int, _fp]),
     'eagcn_layer_forward': (C.c_int, [C.POINTER(Batch), C.POINTER(LayerParams), C.POINTER(LayerBufs), _fp]),

@@ -253,6 +253,11 @@ int eagcn_bce_loss(const float* logits, const float* labels, const float* class_
                    float* loss, float* dlogits, void* stream);
 int eagcn_mse_loss(const float* pred, const float* target, int n, float* loss, float* dpred, void* stream);
 
+/* Matrix-core path of the layer products: 0 = fp32 MFMA (default: exact fp32 products, the reference's torch.mm
+ * semantics, layers.py:40), 1 = every fp32 operand split exactly into three bf16 pieces and six bf16 MFMA
+ * products accumulated in fp32 (same accuracy, see csrc/gemm_x6.h).  Returns the previous mode. */
+int eagcn_set_gemm_mode(int mode);
+
 /* ---- plain fp32 MFMA GEMM (head / tests) ------------------------------------------------------ */
 /* C[M,N] = op(A).op(B); ta/tb: 0 = as stored, 1 = transposed; leading dimensions in floats */
 int eagcn_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,

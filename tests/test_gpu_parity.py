@@ -179,6 +179,34 @@ def test_gemm_f32(ta, tb, M, N, K):
     assert rel_err(c.double().cpu(), ref.cpu()) < 2e-6
 
 
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(1000, 704, 400), (4608, 400, 704), (133, 72, 100)])
+def test_gemm_bf16x6_mode(ta, tb, M, N, K):
+    """Opt-in matrix-core path (eagcn_set_gemm_mode(1)): fp32 operands split exactly into three bf16 pieces, six
+    bf16 MFMA products, fp32 accumulation.  Must be as accurate as the fp32 MFMA path, incl. ragged M / N / K
+    tails and operands with a wide dynamic range."""
+    from eagcn_amd import _lib, ops
+    lib = _lib.load()
+    if ta and M % 4:
+        M = (M + 3) // 4 * 4
+    torch.manual_seed(2)
+    a = torch.randn((K, M) if ta else (M, K), device='cuda') * torch.exp(2.0 * torch.randn(1, device='cuda'))
+    b = torch.randn((N, K) if tb else (K, N), device='cuda')
+    b = b * torch.exp(3.0 * torch.randn_like(b))                      # wide dynamic range
+    A = a.double().t() if ta else a.double()
+    Bm = b.double().t() if tb else b.double()
+    ref, mag = A @ Bm, A.abs() @ Bm.abs()
+    old = lib.eagcn_set_gemm_mode(1)
+    try:
+        c6 = ops.gemm(a, b, bool(ta), bool(tb)).double()
+    finally:
+        lib.eagcn_set_gemm_mode(old)
+    c32 = ops.gemm(a, b, bool(ta), bool(tb)).double()
+    e6 = ((c6 - ref).abs() / mag).max().item() / 2.0 ** -24
+    e32 = ((c32 - ref).abs() / mag).max().item() / 2.0 ** -24
+    assert e6 < max(2.0 * e32, 16.0), (e6, e32)                       # in units of fp32 epsilon of sum |a||b|
+
+
 def test_bad_inputs_raise():
     from eagcn_amd import ops
     from eagcn_amd._lib import EagcnHipError
