@@ -194,7 +194,7 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
 template <int CT, bool TRANS, int NW = 4>
 __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const int by, const int gx) {
     __shared__ float sig_s[256];
-    __shared__ float red_s[CT][4][64];                // [accumulator register g][lane]                // ONE partial-accumulator buffer, reused wave by wave
+    __shared__ float red_s[CT][4][64];                // ONE partial-accumulator buffer [tile][register][lane], reused wave by wave
     __shared__ float dred_s[4][16];
     __shared__ double st_s[TRANS ? 1 : CT * 16 * 2];
     const int k = by / a.nchunk, cc = by % a.nchunk;

@@ -235,11 +235,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
         const int gx = gridDim.x;
         const int per_z = gx * ((Mx + BM - 1) / BM);           // tiles that have rows, per split
         const int nwg = per_z * nsp;
-        const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
         if (blockIdx.y * gx + blockIdx.x >= per_z || (int)blockIdx.z >= nsp) return;   // uniform: capacity-only workgroup
         // linear dispatch index of the REAL workgroups (capacity-only ones were skipped above)
         const int lin = blockIdx.z * per_z + blockIdx.y * gx + blockIdx.x;
-        (void)bid;
         const int nid = xcd_remap(lin, nwg);
         z = nid / per_z;                                       // all tiles of one K-split land on one or two XCDs
         const int rem = nid - z * per_z;

@@ -216,22 +216,8 @@ __global__ __launch_bounds__(16 * RL) void rowbn_bwd_kernel(RowBnBwd a) {
     }
 }
 
-// C[i] = sum_z slab[z][i]  (split-K partials of the head's weight-gradient products)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int n, int splits,
-                                                             float* __restrict__ out) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float s0 = 0.0f, s1 = 0.0f;
-        int z = 0;
-        for (; z + 2 <= splits; z += 2) {
-            s0 += slab[(size_t)z * n + i];
-            s1 += slab[(size_t)(z + 1) * n + i];
-        }
-        if (z < splits) s0 += slab[(size_t)z * n + i];
-        out[i] = s0 + s1;
-    }
-}
-
-// the same for up to three result matrices in one launch (the head's three weight gradients)
+// C[i] = sum_z slab[z][i] for up to three result matrices in one launch (split-K partials of the head's three
+// weight-gradient products)
 struct Reduce3 { const float* slab[3]; float* out[3]; int n[3]; int splits[3]; };
 __global__ __launch_bounds__(256) void splitk_reduce3_kernel(Reduce3 a) {
     const int n0 = a.n[0], n1 = a.n[1], n2 = a.n[2];
