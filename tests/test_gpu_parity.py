@@ -453,3 +453,38 @@ def test_compact_input_equals_dense_collate(graph):
     loop = bi.clone(); loop[0] = int(bj[0])
     with pytest.raises(EagcnHipError):
         ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, bm, loop, bj, bc)
+
+
+def test_graph_mode_gradient_accumulation_and_foreign_grads():
+    """The captured backward writes straight into the storage ``p.grad`` are views of.  Two backward passes
+    without zeroing in between must ACCUMULATE (as autograd does), also when the caller put its own gradient
+    tensors on some parameters, and an eval-mode forward in between must not disturb the saved activations."""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    kw = dict(structure='Concate', n_layers=2, grad_mode='direct')
+    torch.manual_seed(5)
+    a = EAGCN(6, 24, *[9, 7, 5, 5, 6], *[12, 8, 6, 6, 8], 24, 12, 3, 0.0, **kw).cuda().train()
+    b = EAGCN(6, 24, *[9, 7, 5, 5, 6], *[12, 8, 6, 6, 8], 24, 12, 3, 0.0, graph=True, **kw).cuda().train()
+    b.load_state_dict(a.state_dict())
+    batches = [_dev(make_batch(B=10, n_max=27, n_med=9, rel_channels=(6, 4, 2, 2, 2), seed=90 + i).dense()) for i in range(3)]
+    for m in (a, b):
+        for p in m.parameters():
+            p.grad = None
+    first = b.den1.weight
+    for i, d in enumerate(batches):
+        for m in (a, b):
+            out, _, gr = m(*d)
+            if m is b and i == 1:               # an eval forward between forward and backward of a training step
+                m.eval()
+                with torch.no_grad():
+                    m(*batches[0])
+                m.train()
+            (out.sum() + gr.sum()).backward()
+        if i == 0:                              # from now on one parameter of the graph model carries a foreign tensor
+            first.grad = first.grad.clone()
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    scale = max(p.grad.abs().max().item() for p in pa.values() if p.grad is not None)
+    for k in pa:
+        assert (pa[k].grad is None) == (pb[k].grad is None), k
+        if pa[k].grad is not None:
+            assert_grad_close(pb[k].grad, pa[k].grad.cpu(), scale, k, rtol=1e-5, floor=1e-5)
