@@ -48,9 +48,8 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
     __syncthreads();
     const float r = a.rsig[k];
     const eagcn_batch& bt = a.bt;
-    double s1[CT], s2[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) { s1[c] = 0.0; s2[c] = 0.0; }
+    // (BatchNorm partial sums are accumulated in LDS with fp64 atomics, not in 4*CT registers per lane: that keeps
+    //  the kernel at four waves per SIMD)
 
     for (int tile = bx * 4 + wave; tile < ntiles; tile += gx * 4) {
         const int b = bt.tile_mol[tile];
@@ -107,15 +106,22 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
                 if (ct < nct) {
+                    double t1 = 0.0, t2 = 0.0;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int row = rt * 16 + q * 4 + g;
                         if (row < n) {
                             const float y = acc[ct][g] * scr[g];
                             a.dst[(size_t)(r0 + row) * a.ldd + c0 + ct * 16 + li] = y;
-                            s1[ct] += (double)y;
-                            s2[ct] += (double)y * (double)y;
+                            t1 += (double)y;
+                            t2 += (double)y * (double)y;
                         }
+                    }
+                    t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+                    t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+                    if (q == 0) {                     // the four waves of the workgroup add concurrently
+                        atomicAdd(&st_s[(ct * 16 + li) * 2 + 0], t1);
+                        atomicAdd(&st_s[(ct * 16 + li) * 2 + 1], t2);
                     }
                 }
         } else {
@@ -162,24 +168,8 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
     }
 
     if (!TRANS) {
-        // per-workgroup partial BatchNorm sums -> slab[bx][column][2]
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            s1[ct] += __shfl_xor(s1[ct], 16);
-            s1[ct] += __shfl_xor(s1[ct], 32);
-            s2[ct] += __shfl_xor(s2[ct], 16);
-            s2[ct] += __shfl_xor(s2[ct], 32);
-        }
-        for (int w = 0; w < 4; ++w) {
-            if (wave == w && q == 0) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    st_s[(ct * 16 + li) * 2 + 0] += s1[ct];
-                    st_s[(ct * 16 + li) * 2 + 1] += s2[ct];
-                }
-            }
-            __syncthreads();
-        }
+        // per-workgroup partial BatchNorm sums (accumulated in st_s) -> slab[bx][column][2]
+        __syncthreads();
         const int fp = a.vc.off[a.vc.K];
         for (int i = tid; i < nct * 16 * 2; i += 256)
             a.stats[((size_t)bx * fp + c0) * 2 + i] = st_s[i];
@@ -427,7 +417,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
 }
 
 template <int CT, bool TRANS>
-__global__ __launch_bounds__(256) void agg_wave_kernel(AggArgs a) { agg_wave_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg_wave_kernel(AggArgs a) { agg_wave_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 template <int CT, bool TRANS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg_kernel(AggArgs a) { agg_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 // two waves per workgroup: most tiles have one or two column groups, so two of four waves would idle
