@@ -400,10 +400,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     nslab = max(1, min(nslab, (meta[EAGCN_META_T] + nvirt + BWD_ROWS - 1) / BWD_ROWS));   // slabs actually written
     const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
     const int cp = min(cpr, fp - 1);
-    if (blockIdx.x == 0 && threadIdx.x < vc.K && gp.dave_w) {
+    if (blockIdx.x == 0 && gp.dave_w) {                 // d ave.weight: 32 lanes per view over the row-partial slabs
+        const int v = threadIdx.x >> 5, l = threadIdx.x & 31;
         double t = 0.0;
-        for (int s = 0; s < nslab; ++s) t += slab_da[(size_t)s * EAGCN_MAX_VIEWS + threadIdx.x];
-        gp.dave_w[threadIdx.x] = (float)t;
+        if (v < vc.K)
+            for (int s = l; s < nslab; s += 32) t += slab_da[(size_t)s * EAGCN_MAX_VIEWS + v];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (v < vc.K && l == 0) gp.dave_w[v] = (float)t;
     }
     double s1, s2;
     slab_sum<L>(slab, nslab, fp, cp, sl, s1, s2);
