@@ -268,7 +268,7 @@ def main():
                        'input': args.input, 'global_batch': world * B, 'atoms_per_batch': int(mb.sizes.sum()),
                        'parallelism': 'dp%d' % world},
             'algorithmic_gflop_per_step': round(algorithmic_flops(cfg, mb.sizes) / 1e9, 3),
-            'roofline': {'kernel': 'gemm_f32_pair_kernel<64,64,16,4> (dX = dP.W^T and dW = X^T.dP of a layer in one grid, fp32 MFMA)'
+            'roofline': {'kernel': 'gemm_f32_pair_kernel<64, 64, 16, 4, false> (dX = dP.W^T and dW = X^T.dP of a layer in one grid, fp32 MFMA)'
                                    if pair else 'gemm_f32_kernel (flat X.[W_1..W_K] transform and its backward products)',
                          'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
