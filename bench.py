@@ -155,6 +155,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--eval-throughput', action='store_true',
+                    help='also time the eval-mode forward (forward-only graph under no_grad); reported as an extra field')
     ap.add_argument('--input', default='dense', choices=('dense', 'compact'),
                     help="dense: the reference's collate tensors (headline); compact: bond list via forward_compact")
     args = ap.parse_args()
@@ -285,6 +287,20 @@ def main():
             'kernel_ms_per_step': {k: round(v[0] / prof_steps, 4) for k, v in kern.items()},
             'execution': 'eager launches' if args.eager else 'HIP graph replay (forward + backward), eager batch index',
         }
+        if args.eval_throughput and not args.eager:
+            model.eval()
+            with torch.no_grad():
+                for _ in range(10):
+                    model(*dense) if compact is None else model.forward_compact(*compact)
+                torch.cuda.synchronize()
+                te = time.perf_counter()
+                for _ in range(args.steps):
+                    model(*dense) if compact is None else model.forward_compact(*compact)
+                torch.cuda.synchronize()
+                te = time.perf_counter() - te
+            model.train()
+            out['eval_forward'] = {'molecules_per_s': round(B * args.steps / te, 1), 'ms_per_batch': round(te / args.steps * 1e3, 4),
+                                   'execution': 'forward-only HIP graph, eval mode, no_grad'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, mb, args.dropout, bce_w, steps=args.cpu_steps)
         print(json.dumps(out))

@@ -68,11 +68,13 @@ class StaticIndex:
 
 
 class GraphRunner:
-    """One captured (forward, backward) pair for a fixed (model plan, B, N, channels)."""
+    """One captured (forward, backward) pair for a fixed (model plan, B, N, channels); with ``training=False``
+    a forward-only graph of the eval-mode model (running BatchNorm statistics, no dropout, no backward)."""
 
-    def __init__(self, plan, B, N, channels, device, dropout, row_cap=None):
+    def __init__(self, plan, B, N, channels, device, dropout, row_cap=None, training=True):
         lib = L.load()
         self.plan, self.device = plan, device
+        self.training = bool(training)
         self.key = (B, N, tuple(channels))
         self.slots = [StaticIndex(B, N, channels, device, row_cap if row_cap else B * N) for _ in range(2)]
         self.index = self.slots[0]
@@ -127,7 +129,7 @@ class GraphRunner:
 
     # -- C descriptors -------------------------------------------------------------------------------
     def _cmodel(self, slot):
-        m = L.Model.from_buffer_copy(self.plan.cmodel(True, 0, self.dropout))
+        m = L.Model.from_buffer_copy(self.plan.cmodel(self.training, 0, self.dropout))
         sd = self.seeds_dev[slot].data_ptr()
         for l in range(len(self.plan.layers)):
             m.layer[l].seed_dev = sd + 8 * l
@@ -186,9 +188,11 @@ class GraphRunner:
         # thread_local: other threads (e.g. the RCCL watchdog of torch.distributed) may touch the HIP API during capture
         with torch.cuda.graph(fwd, capture_error_mode='thread_local'):
             self._call_forward()
-        bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(bwd, capture_error_mode='thread_local'):
-            self._call_backward()
+        bwd = None
+        if self.training:
+            bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(bwd, capture_error_mode='thread_local'):
+                self._call_backward()
         self.graphs[self.cur] = [fwd, bwd]
 
     # -- per-step entry points -----------------------------------------------------------------------
@@ -272,7 +276,8 @@ class GraphRunner:
             main.wait_event(done)
         self.step += 1
         self.generation += 1
-        self.plan.nbt_pending += 1        # num_batches_tracked: counted on the host, written by ModelPlan.flush_nbt()
+        if self.training:
+            self.plan.nbt_pending += 1    # num_batches_tracked: counted on the host, written by ModelPlan.flush_nbt()
         if self.graphs[cur][0] is None:
             self._call_forward()                              # first use of a slot: eager (and the capture warm-up)
             self._capture()
@@ -337,6 +342,9 @@ class _GraphFn(torch.autograd.Function):
 
 
 def graph_forward(runner, adj, rels, afm, size, seed, overlap=False, bonds=None):
+    if not runner.training:               # eval: forward-only graph, nothing to differentiate
+        runner.forward(adj, rels, afm, size, seed, overlap, bonds)
+        return runner.out.detach(), runner.graph_rep.detach()
     plan = runner.plan
     if plan.trigger is None or plan.trigger.device != afm.device:
         plan.trigger = torch.zeros((), dtype=torch.float32, device=afm.device, requires_grad=True)

@@ -177,12 +177,12 @@ class EAGCN(nn.Module):
                                           % (tuple(afms.shape), B, N, len(channels)))
             btuple = bonds.checked()
         plan = self.plan()
-        key = (B, N, channels, float(self.dropout))
+        key = (B, N, channels, float(self.dropout), self.training)
         runner = self._runners.get(key)
         if runner is None or runner.stale():
-            runner = G.GraphRunner(plan, B, N, channels, afms.device, self.dropout, self.row_cap)
+            runner = G.GraphRunner(plan, B, N, channels, afms.device, self.dropout, self.row_cap, training=self.training)
             self._runners[key] = runner
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.dropout > 0 else 0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (self.dropout > 0 and self.training) else 0
         if self.molfp_mode == 'ave':
             size = size.to(device=afms.device, dtype=torch.int64)
         out, graph_representation = G.graph_forward(runner, adjs, rels, afms, size, seed, self.overlap_index, btuple)
@@ -199,8 +199,8 @@ class EAGCN(nn.Module):
         size) -> (x, atom_representations, graph_representation).  The whole forward is one call into
         eagcn_model_forward (layers, read-out and head); backward is one call into eagcn_model_backward."""
         *rels, size = rels_and_size
-        if self.graph and self.training and torch.is_grad_enabled():
-            return self._graph_forward(adjs, afms, rels, size)
+        if self.graph and (self.training and torch.is_grad_enabled() or not self.training and not torch.is_grad_enabled()):
+            return self._graph_forward(adjs, afms, rels, size)       # training step, or eval under no_grad (train.py:130-211)
         index = ops.BatchIndex(adjs, rels, overlap=self.overlap_index)   # once per batch, shared by all layers
         return self._forward_index(index, afms, size)
 
@@ -209,7 +209,7 @@ class EAGCN(nn.Module):
         (directed bond list + per-view bond type), ``afms`` the padded [B,N,n_afeat] atom features.  Results are
         identical to ``forward`` on the dense tensors the reference's collate (utils.py:575-640) would build for
         the same molecules; the adjacency / relation tensors are never materialised."""
-        if self.graph and self.training and torch.is_grad_enabled():
+        if self.graph and (self.training and torch.is_grad_enabled() or not self.training and not torch.is_grad_enabled()):
             return self._graph_forward(None, afms, None, size, bonds)
         index = ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, *bonds.checked())
         return self._forward_index(index, afms, size)

@@ -488,3 +488,38 @@ def test_graph_mode_gradient_accumulation_and_foreign_grads():
         assert (pa[k].grad is None) == (pb[k].grad is None), k
         if pa[k].grad is not None:
             assert_grad_close(pb[k].grad, pa[k].grad.cpu(), scale, k, rtol=1e-5, floor=1e-5)
+
+
+@pytest.mark.parametrize('structure', ['Concate', 'Weighted_sum'])
+def test_eval_graph_equals_eager_eval(structure):
+    """eval-mode forward (running BatchNorm statistics, no dropout) replayed as a forward-only
+    graph under no_grad must equal the eager eval forward, batch after batch, also after the running statistics
+    moved (a training step in between), and must leave parameters / buffers untouched."""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    w1, w2 = ([9, 7, 5, 5, 6], [12, 8, 6, 6, 8]) if structure == 'Concate' else ([3] * 5, [4] * 5)
+    kw = dict(structure=structure, n_layers=2, molfp_mode='ave', grad_mode='direct')
+    torch.manual_seed(3)
+    a = EAGCN(6, 24, *w1, *w2, 24, 12, 3, 0.3, **kw).cuda()
+    b = EAGCN(6, 24, *w1, *w2, 24, 12, 3, 0.3, graph=True, **kw).cuda()
+    b.load_state_dict(a.state_dict())
+    for step in range(4):
+        mb = make_batch(B=12, n_max=31, n_med=9 + step, rel_channels=(6, 4, 2, 2, 2), seed=50 + step)
+        d = _dev(mb.dense())
+        if step == 2:                          # move the running statistics identically in both models
+            for m in (a, b):
+                m.train()
+                torch.manual_seed(9)
+                out, _, _ = m(*d)
+                out.sum().backward()
+        before = {k: v.clone() for k, v in b.state_dict().items()}
+        outs = []
+        for m in (a, b):
+            m.eval()
+            with torch.no_grad():
+                out, rep, gr = m(*d)
+            outs.append((out.clone(), gr.clone(), rep.packed[0][:int(mb.sizes.sum())].clone()))
+        for x, y in zip(outs[0], outs[1]):
+            assert rel_err(y.cpu(), x.cpu()) < 2e-6, step
+        for k, v in b.state_dict().items():
+            assert torch.equal(v, before[k]), k
