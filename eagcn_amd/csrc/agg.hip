@@ -440,6 +440,11 @@ static int launch_agg_t(const AggArgs& a, int ct, dim3 grid, bool ksplit, hipStr
     return EAGCN_OK;
 }
 
+// column tiles per workgroup: at most 10 (register budget); EAGCN_AGG_MAXCT lowers it (more, lighter workgroups)
+static int agg_max_ct() {
+    static const int v = [] { const char* e = getenv("EAGCN_AGG_MAXCT"); const int x = e ? atoi(e) : 10; return x < 1 ? 1 : (x > 10 ? 10 : x); }();
+    return v;
+}
 // number of workgroups along x (= number of stat partial slabs) used for a batch
 // Small batches (few hundred tiles, duration set by the largest molecule): one workgroup per tile, K split
 // over its waves.  Large batches: one wave per tile.  Measured on MI355X: K-split 115 vs 136 us/step at
@@ -455,7 +460,7 @@ int launch_agg(AggArgs a, bool trans, hipStream_t s) {
     int tmax = 0;
     for (int k = 0; k < a.vc.K; ++k) tmax = std::max(tmax, (a.vc.off[k + 1] - a.vc.off[k]) / 16);
     // balanced chunking: fewest chunks of at most 10 column tiles, then the smallest CT reaching it
-    const int nchunk = cdiv(tmax, 10);
+    const int nchunk = cdiv(tmax, agg_max_ct());
     const int ct = cdiv(tmax, nchunk);
     a.nchunk = nchunk;
     dim3 grid(agg_grid_x(&a.bt), a.vc.K * nchunk);
@@ -629,7 +634,7 @@ int launch_agg_edge(AggArgs a, const EdgeArgs& e, hipStream_t s) {
     if (a.bt.n_tiles == 0 || a.bt.T == 0) return EAGCN_OK;
     int tmax = 0;
     for (int k = 0; k < a.vc.K; ++k) tmax = std::max(tmax, (a.vc.off[k + 1] - a.vc.off[k]) / 16);
-    const int nchunk = cdiv(tmax, 10);
+    const int nchunk = cdiv(tmax, agg_max_ct());
     const int ct = cdiv(tmax, nchunk);
     a.nchunk = nchunk;
     const int agx = agg_grid_x(&a.bt), egx = edge_grid_x(&a.bt);
