@@ -14,6 +14,11 @@
 // sum is accumulated in the same loop and applied once in the epilogue (row scaling commutes with
 // the product), where the per-channel BatchNorm partial sums (sum y, sum y^2 in fp64) are taken as
 // well.  No LDS tile, no barrier in the main loop, any molecule size.
+// Small batches (B <= 512) use the K-split variant instead: one WORKGROUP per tile, the molecule's column
+// groups spread over its four waves.  The CT column tiles are mapped so that a lane's four B-operand values /
+// results form one float4 (256 contiguous bytes per row and 16 lanes).  BatchNorm partial sums live in LDS,
+// the register budget is held at 128 (4 waves per SIMD): the kernels are bound by round trips in flight.
+// In backward the transposed aggregation and the edge gradients of a layer share one grid (agg_edge_kernel).
 // Columns j >= nat[b] hold 1e-9/rowsum weights on rows whose features are zero (Concate) or on a
 // constant vector (Weighted_sum); they enter the row sum exactly and are dropped from the product
 // (relative contribution <= N*1e-9).

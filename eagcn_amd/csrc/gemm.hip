@@ -3,7 +3,12 @@
 //
 // Used for the flat feature transform of the hot path -- reference layers.py:40 (`torch.mm` over
 // all B*N rows) restated over the packed rows only -- and for its two backward products
-// (dX = dP.W^T, dW = X^T.dP, the latter split-K over the rows).
+// (dX = dP.W^T, dW = X^T.dP, the latter split-K over the rows).  Kernels in this file:
+//   gemm_f32_kernel       one product; XCD-aware tile order; row / reduction extents from device memory
+//   gemm_f32_pair_kernel  dX and dW of a layer in ONE grid (fills the partly empty last round of each)
+//   gemm_f32_group_kernel up to three small dW-form products in one grid (the head's weight gradients)
+// Each takes its 64x64 tile from gemm_tile (fp32 MFMA, exact fp32 products) or, opt-in, gemm_tile_x6
+// (gemm_x6.h: exact three-way bf16 split, six bf16 MFMA products, fp32 accumulation).
 //
 // Operand storage is described by (ta, tb): ta = 0 -> A is [M][K] (K contiguous), ta = 1 -> A is
 // stored [K][M]; tb = 0 -> B is [K][N] (N contiguous), tb = 1 -> B is stored [N][K].
