@@ -57,12 +57,12 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
         if (row >= nrows) break;                                   // wave-uniform
         const int b = (int)(row / N), i = (int)(row % N);
         int deg = 0;
+        uint32_t packed[NIT][EAGCN_MAX_VIEWS];
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
             const int j0 = (lane + 64 * t) * 4;
-            uint32_t packed[EAGCN_MAX_VIEWS];
 #pragma unroll
-            for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) packed[k] = 0u;
+            for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) packed[t][k] = 0u;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float av = a[rr][t][u];
@@ -86,19 +86,28 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
                                 other += (v != 0.0f && !one) ? 1 : 0;
                             }
                             if (ones != 1 || other != 0) ++bad_rel;
-                            packed[k] |= (uint32_t)(hot + 1) << (8 * u);
+                            packed[t][k] |= (uint32_t)(hot + 1) << (8 * u);
                         }
                     }
                 }
             }
-            if (j0 < ldc) {
-#pragma unroll
-                for (int k = 0; k < EAGCN_MAX_VIEWS; ++k)
-                    if (k < K)
-                        *reinterpret_cast<uint32_t*>(code + (((size_t)k * B + b) * N + i) * ldc + j0) = packed[k];
-            }
         }
         deg = wave_sum(deg);
+        // A row without bonds keeps whatever its code row held: every consumer weights such a row by
+        // m_i / rowsum_i = 0 (agg.hip: rscale; the edge gradients skip it) and rows beyond nat[b] are never read,
+        // so the 86 % padding rows of a Tox21-shaped batch cost one adjacency read and no K*ldc bytes of zero stores.
+        if (deg > 0) {
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) {
+                const int j0 = (lane + 64 * t) * 4;
+                if (j0 < ldc) {
+#pragma unroll
+                    for (int k = 0; k < EAGCN_MAX_VIEWS; ++k)
+                        if (k < K)
+                            *reinterpret_cast<uint32_t*>(code + (((size_t)k * B + b) * N + i) * ldc + j0) = packed[t][k];
+                }
+            }
+        }
         if (lane == 0) {
             deg_bn[row] = deg;
             if (deg > 0) atomicMax(&nat[b], i + 1);  // (no single-word counters here: 5k same-address atomics cost 60 us)
@@ -289,8 +298,10 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     EAGCN_HIP(hipMemsetAsync(b->meta, 0, EAGCN_META_WORDS * sizeof(int32_t), s));
     EAGCN_HIP(hipMemsetAsync(b->nat, 0, (size_t)b->B * sizeof(int32_t), s));
     const long rows = (long)b->B * b->N;
-    // rows per wavefront: 4 was measured SLOWER (0.18 vs 0.09 ms at B=256, 1.12 vs 0.97 ms at B=4096): the
-    // per-row bond gather then runs back to back inside one wave instead of in parallel waves
+    // rows per wavefront: 4 was measured SLOWER (0.18 vs 0.09 ms at B=256, 1.12 vs 0.97 ms at B=4096), and so was
+    // a streaming degree pass followed by a per-molecule code pass over the bonded rows (0.39-0.71 vs 0.07 ms at
+    // B=256): the gather of one row (~38 single-sector loads from planes N*N floats apart per bond) takes tens of
+    // microseconds however it is issued, so it has to run in as many waves at once as there are rows
     constexpr int RPW = 1;
     const unsigned sgrid = (unsigned)((rows + 4 * RPW - 1) / (4 * RPW));
     const int nit = cdiv(b->ldc, 256);

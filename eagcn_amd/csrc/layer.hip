@@ -508,7 +508,8 @@ __global__ __launch_bounds__(256) void attention_dense_kernel(eagcn_batch bt, Pa
         const int j = (int)(e % bt.N);
         const size_t kbi = e / bt.N;                 // (k*B + b)*N + i
         const int k = (int)(kbi / ((size_t)bt.B * bt.N));
-        const uint32_t c = bt.code[kbi * bt.ldc + j];
+        const size_t bi = kbi - (size_t)k * bt.B * bt.N;      // b*N + i: rows without bonds have no valid code row
+        const uint32_t c = bt.deg_bn[bi] > 0 ? bt.code[kbi * bt.ldc + j] : 0u;
         out[e] = (c >= 1 && (int)c <= pp.channels[k]) ? sigmoidf_(pp.att_w[k][c - 1]) : 0.0f;
     }
 }

@@ -424,8 +424,11 @@ def test_compact_input_equals_dense_collate(graph):
         i_comp = ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, *bonds.checked())
         assert (i_dense.T, i_dense.n_max, i_dense.n_tiles, i_dense.n_edges) == \
                (i_comp.T, i_comp.n_max, i_comp.n_tiles, i_comp.n_edges)
-        for name in ('code', 'deg_bn', 'nat', 'row0', 'tile0', 'row_mol', 'row_loc', 'row_deg', 'row_m', 'tile_mol'):
+        for name in ('deg_bn', 'nat', 'row0', 'tile0', 'row_mol', 'row_loc', 'row_deg', 'row_m', 'tile_mol'):
             assert torch.equal(getattr(i_dense, name), getattr(i_comp, name)), name
+        # code rows of atoms without bonds are not written by the dense scan (no consumer gives them weight)
+        bonded = (i_dense.deg_bn.view(1, bonds.B, bonds.N, 1) > 0)
+        assert torch.equal(i_dense.code * bonded, i_comp.code * bonded)
         res = []
         for m, call in ((a, lambda: a(*d)), (b, lambda: b.forward_compact(bonds, afm, size))):
             torch.manual_seed(200 + step)
