@@ -446,7 +446,7 @@ static int mm_partial(hipStream_t s, int ta, int tb, int M, int N, int K, const 
 }
 // the three weight gradients dW_i = A_i^T . B_i (rows = batch) as one grouped launch + one reduction launch
 struct DwProblem { int M, N; const float* A; const float* B; float* C; float* slab; };
-static int head_dw(hipStream_t s, int K, const DwProblem* pr) {
+static int head_dw(hipStream_t s, int K, const DwProblem* pr, const GemmDesc* lead = nullptr) {
     int tiles = 0;
     bool ok = true;
     for (int i = 0; i < 3; ++i) {
@@ -467,7 +467,7 @@ static int head_dw(hipStream_t s, int K, const DwProblem* pr) {
         r.slab[i] = pr[i].slab; r.out[i] = pr[i].C; r.n[i] = pr[i].M * pr[i].N; r.splits[i] = splits;
         total += r.n[i];
     }
-    int rc = launch_gemm_group(d, 3, s);
+    int rc = launch_gemm_group(d, 3, s, lead);
     if (rc || splits == 1) return rc;
     ProfScope ps(PROF_HEAD, s);
     splitk_reduce3_kernel<<<std::min(cdiv(total, 256), 1024), 256, 0, s>>>(r);
@@ -588,9 +588,19 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
         const DwProblem pr[3] = {{F, n1, sv.gn, sc.dh1, hg->d_den1_w, sc.gw1},
                                  {n1, n2, sv.a1, sc.dh2, hg->d_den2_w, sc.gw2},
                                  {n2, nc, sv.a2, dout, hg->d_den3_w, sc.gw3}};
-        RC(head_dw(side, B, pr));
+        if (forked) {
+            RC(head_dw(side, B, pr));
+            RC(mm_partial(s, 0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, sc.dgn, sc.gsplit2, &pd));
+        } else {
+            // d(Graph_BN output) = dh1 . den1_w^T rides in the same launch as the three weight gradients
+            const int splits = split_ok(0, 1, B, F, n1, n1, n1) ? head_splits(cdiv(B, 64) * cdiv(F, 64), n1) : 1;
+            GemmDesc lead{0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, splits > 1 ? sc.gsplit2 : sc.dgn, F, splits,
+                          (size_t)B * F};
+            lead.prof_tag = PROF_HEAD;
+            pd = Partial{splits > 1 ? sc.gsplit2 : sc.dgn, splits, (size_t)B * F};
+            RC(head_dw(s, B, pr, &lead));
+        }
     }
-    RC(mm_partial(s, 0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, sc.dgn, sc.gsplit2, &pd));
     RC(rowbn_bwd(s, B, F, pd, sv.g, sv.bn_g, nullptr, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training, 0, 0.0f, 0, nullptr));
     // read-out
     const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
