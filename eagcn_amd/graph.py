@@ -349,5 +349,6 @@ def graph_forward(runner, adj, rels, afm, size, seed, overlap=False, bonds=None)
     if plan.trigger is None or plan.trigger.device != afm.device:
         plan.trigger = torch.zeros((), dtype=torch.float32, device=afm.device, requires_grad=True)
     out, graph_rep = _GraphFn.apply(runner, adj, rels, afm, size, seed, overlap, plan.trigger, bonds)
-    out._eagcn_grad_slot = runner.dout    # hint for eagcn_amd.losses: where d(loss)/d(out) is consumed
+    out._eagcn_grad_slot = runner.dout    # hints for eagcn_amd.losses: where d(loss)/d(out) is consumed ...
+    out._eagcn_step = (runner, runner.generation)      # ... and which captured backward belongs to this forward
     return out, graph_rep

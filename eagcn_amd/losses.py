@@ -41,7 +41,12 @@ class _FusedLoss(torch.autograd.Function):
         x = outputs.contiguous()
         y = labels.to(device=x.device, dtype=torch.float32).contiguous()
         loss = torch.empty((), dtype=torch.float32, device=x.device)
-        dx = torch.empty_like(x)
+        # graph mode hands over the buffer its captured backward reads d(loss)/d(out) from (eagcn_amd/graph.py):
+        # the gradient is written straight into it
+        slot = getattr(outputs, '_eagcn_grad_slot', None)
+        if slot is not None and (slot.shape != x.shape or slot.device != x.device or slot.dtype != x.dtype):
+            slot = None
+        dx = slot if slot is not None else torch.empty_like(x)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         if kind == 'bce':
             B, T = x.shape
@@ -56,27 +61,49 @@ class _FusedLoss(torch.autograd.Function):
             L.check(lib.eagcn_mse_loss(x.data_ptr(), y.data_ptr(), x.numel(), loss.data_ptr(), dx.data_ptr(), stream),
                     'eagcn_mse_loss')
         ctx.save_for_backward(dx)
-        # graph mode hands over the buffer its captured backward reads d(loss)/d(out) from: scaling into it
-        # saves the copy (eagcn_amd/graph.py)
-        slot = getattr(outputs, '_eagcn_grad_slot', None)
-        ctx.slot = slot if (slot is not None and slot.shape == x.shape and slot.device == x.device) else None
+        ctx.slot = slot
         return loss
 
     @staticmethod
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
-        if ctx.slot is not None:
-            return None, torch.mul(dx, g, out=ctx.slot), None, None
+        if ctx.slot is not None:                    # dx IS the captured backward's gradient buffer: scale in place
+            return None, dx.mul_(g), None, None
         return None, dx * g, None, None
+
+
+class _StepLoss(torch.Tensor):
+    """Loss of a graph-mode training step.  ``loss.backward()`` with default arguments launches the captured
+    backward directly: d(loss)/d(logits) already sits in the buffer that graph reads (the loss kernel wrote it
+    there), so autograd's ones-tensor and the scaling kernel between the two graphs disappear.  Any other use
+    (an explicit ``gradient``, ``retain_graph``, arithmetic on the loss, ...) goes through autograd as usual."""
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        d = self.__dict__.pop('_eagcn_direct', None)
+        if d is not None and gradient is None and not retain_graph and not create_graph and inputs is None:
+            runner, generation = d
+            if generation == runner.generation and torch.is_grad_enabled():
+                runner.backward(runner.dout, None, generation)
+                return None
+        return super().backward(gradient, retain_graph, create_graph, inputs)
+
+
+def _apply(kind, outputs, labels, weight):
+    loss = _FusedLoss.apply(kind, outputs, labels, weight)
+    step = getattr(outputs, '_eagcn_step', None)     # (runner, generation) of a graph-mode forward (eagcn_amd/graph.py)
+    if step is not None and getattr(outputs, '_eagcn_grad_slot', None) is not None:
+        loss = loss.as_subclass(_StepLoss)
+        loss._eagcn_direct = step
+    return loss
 
 
 def fused_classification_loss(outputs, labels, bce_weight):
     """train.py:326-331 in one kernel; bce_weight: [T,2] tensor (utils.py:681-700 ``set_weight``)."""
     if not isinstance(bce_weight, torch.Tensor):
         bce_weight = torch.tensor(bce_weight, dtype=torch.float32, device=outputs.device)
-    return _FusedLoss.apply('bce', outputs, labels, bce_weight)
+    return _apply('bce', outputs, labels, bce_weight)
 
 
 def fused_regression_loss(outputs, labels):
     """train.py:321-325 (MSELoss on flattened outputs) in one kernel."""
-    return _FusedLoss.apply('mse', outputs, labels, None)
+    return _apply('mse', outputs, labels, None)

@@ -526,3 +526,43 @@ def test_eval_graph_equals_eager_eval(structure):
             assert rel_err(y.cpu(), x.cpu()) < 2e-6, step
         for k, v in b.state_dict().items():
             assert torch.equal(v, before[k]), k
+
+
+def test_step_loss_direct_backward_equals_autograd_path():
+    """A fused loss on the outputs of a graph-mode forward returns a tensor whose plain ``backward()`` launches
+    the captured backward directly (no autograd ones-tensor, no scaling kernel).  It must give the same gradients
+    as the autograd route (explicit ``gradient``), as the eager engine, and fall back when the loss is transformed."""
+    from eagcn_amd import EAGCN, losses
+    from eagcn_amd.synthetic import bce_weights, make_batch
+    kw = dict(structure='Concate', n_layers=2, grad_mode='direct')
+    torch.manual_seed(6)
+    a = EAGCN(6, 24, *[9, 7, 5, 5, 6], *[12, 8, 6, 6, 8], 24, 12, 4, 0.0, **kw).cuda().train()
+    b = EAGCN(6, 24, *[9, 7, 5, 5, 6], *[12, 8, 6, 6, 8], 24, 12, 4, 0.0, graph=True, **kw).cuda().train()
+    b.load_state_dict(a.state_dict())
+    mb = make_batch(B=14, n_max=25, n_med=9, rel_channels=(6, 4, 2, 2, 2), seed=21, n_tasks=4)
+    d = _dev(mb.dense())
+    labels = torch.from_numpy(mb.labels).cuda()
+    w = torch.tensor(bce_weights(4), device='cuda')
+
+    def grads(m, how):
+        for p in m.parameters():
+            p.grad = None
+        out, _, _ = m(*d)
+        loss = losses.fused_classification_loss(out, labels, w)
+        if how == 'plain':
+            loss.backward()
+        elif how == 'explicit':
+            loss.backward(torch.ones_like(loss))
+        else:
+            (2.0 * loss).backward()
+        return float(loss), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    la, ga = grads(a, 'plain')                      # eager engine, autograd
+    for how, factor in (('plain', 1.0), ('explicit', 1.0), ('scaled', 2.0), ('plain', 1.0)):
+        lb, gb = grads(b, how)
+        assert abs(la - lb) < 1e-5 * max(1.0, abs(la))
+        scale = max(v.abs().max().item() for v in ga.values())
+        assert set(ga) == set(gb)
+        for k in ga:
+            assert_grad_close(gb[k], (factor * ga[k]).cpu(), factor * scale, '%s (%s)' % (k, how), rtol=1e-5, floor=1e-5)
+    assert type(losses.fused_classification_loss(b(*d)[0], labels, w)).__name__ == '_StepLoss'
