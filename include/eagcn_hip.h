@@ -77,7 +77,8 @@ typedef struct eagcn_batch {
                                                on the device and every kernel reads them there, so the
                                                caller may pass upper bounds without a host read-back  */
     int32_t channels[EAGCN_MAX_VIEWS];
-    uint8_t* code;                          /* [K][B][N][ldc] 0 = no bond, c+1 = bond type c    */
+    uint8_t* code;                          /* [K][B][N][ldc] 0 = no bond, c+1 = bond type c;
+                                               rows with deg_bn == 0 are undefined (never given weight) */
     int32_t* deg_bn;                        /* [B][N] degree of every padded row                */
     int32_t* nat;                           /* [B]                                              */
     int32_t* row0;                          /* [B+1] exclusive prefix of nat                    */
