@@ -24,17 +24,19 @@ def main(path):
     agg = {}
     for n, s, e in rows:
         d = (e - s) / 1e3
-        a = agg.setdefault(short(n), [0, 0.0, 1e30, 0.0])
+        a = agg.setdefault(short(n), [0, 0.0, 1e30, 0.0, []])
         a[0] += 1
         a[1] += d
         a[2] = min(a[2], d)
         a[3] = max(a[3], d)
+        a[4].append(d)
     total = sum(a[1] for a in agg.values())
     print('# rocprofv3 --kernel-trace summary of %s' % path)
     print('# %d dispatches, %.3f ms total GPU kernel time' % (len(rows), total / 1e3))
-    print('%-112s %7s %12s %10s %10s %10s %6s' % ('kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', '%'))
+    print('%-112s %7s %12s %10s %10s %10s %10s %6s' % ('kernel', 'calls', 'total_us', 'avg_us', 'median_us', 'min_us', 'max_us', '%'))
     for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print('%-112s %7d %12.1f %10.2f %10.2f %10.2f %6.2f' % (n, a[0], a[1], a[1] / a[0], a[2], a[3], 100 * a[1] / total))
+        med = sorted(a[4])[len(a[4]) // 2]
+        print('%-112s %7d %12.1f %10.2f %10.2f %10.2f %10.2f %6.2f' % (n, a[0], a[1], a[1] / a[0], med, a[2], a[3], 100 * a[1] / total))
 
 
 if __name__ == '__main__':
