@@ -5,6 +5,7 @@ bookkeeping only; every computation is a call into libeagcn_hip.so.  There is no
 fallback: tensors that are not fp32 CUDA(HIP) tensors raise.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -46,7 +47,7 @@ def _index_stream(device):
     host keeps running one step ahead of the GPU."""
     key = device.index
     if key not in _index_streams:
-        _index_streams[key] = torch.cuda.Stream(device=device, priority=-1)
+        _index_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get('EAGCN_SIDE_PRIORITY', '-1')))
     return _index_streams[key]
 
 
