@@ -136,7 +136,9 @@ def test_model_golden(name):
 
 
 @pytest.mark.parametrize('structure,n_layers,B,n_max', [('Concate', 2, 24, 132), ('Concate', 3, 16, 60),
-                                                        ('Weighted_sum', 2, 12, 70)])
+                                                        ('Weighted_sum', 2, 12, 70),
+                                                        # B > 512: the wave-per-tile aggregation kernels (large batches)
+                                                        ('Concate', 2, 640, 40), ('Weighted_sum', 2, 576, 36)])
 def test_model_vs_oracle_tox21_shape(structure, n_layers, B, n_max):
     """Tox21-like widths, large padding, against the CPU oracle on identical seeded inputs."""
     from eagcn_amd import EAGCN
@@ -150,19 +152,39 @@ def test_model_vs_oracle_tox21_shape(structure, n_layers, B, n_max):
     hip = EAGCN(28, 24, *w1, *w2, 256, 64, 12, 0.0, structure=structure, n_layers=n_layers).cuda()
     hip.load_state_dict(ref.state_dict(), strict=True)
     cpu = mb.dense()
-    out_r, _, gr_r = ref(*cpu)
+    refs = [(ref, cpu)]
+    if B > 512:
+        # beyond ~20 k padded rows fp32 is not enough to pin the gradients: against the fp64 oracle the fp32 CPU oracle
+        # is off by up to 2e-3 (tests/probe_large_batch.py; BatchNorm sums, relu boundaries), sometimes the HIP path
+        # with it (Concate 640: both 1.9e-3, equal to each other), sometimes not (Weighted_sum 576: HIP 2e-6, fp32
+        # oracle 1.7e-3).  The HIP result has to agree with ONE of the two oracles to the usual tolerance.
+        ref64 = RefEAGCN(28, 24, w1, w2, 256, 64, 12, 0.0, structure=structure, n_layers=n_layers).double()
+        ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+        refs.append((ref64, [t.double() if t.is_floating_point() else t for t in cpu]))
+    gsel = torch.randn(B, 12)
     out_h, _, gr_h = hip(*_dev(cpu))
-    assert rel_err(out_h.detach().cpu(), out_r.detach()) < TOL
-    assert rel_err(gr_h.detach().cpu(), gr_r.detach()) < TOL
-    gsel = torch.randn(out_r.shape)
-    (out_r * gsel).sum().backward()
     (out_h * gsel.cuda()).sum().backward()
-    gr = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
     gh = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
-    assert set(gr) == set(gh)
-    scale = max(v.abs().max().item() for v in gr.values())
-    for k in gr:
-        assert_grad_close(gh[k], gr[k], scale, k, rtol=1e-4, floor=5e-6)
+    cand = []
+    for m, inp in refs:
+        out_r, _, gr_r = m(*inp)
+        (out_r * gsel.to(out_r.dtype)).sum().backward()
+        cand.append((out_r.detach(), gr_r.detach(), {k: p.grad for k, p in m.named_parameters() if p.grad is not None}))
+    assert min(rel_err(out_h.detach().cpu(), c[0]) for c in cand) < TOL
+    assert min(rel_err(gr_h.detach().cpu(), c[1]) for c in cand) < TOL
+    assert set(cand[0][2]) == set(gh)
+    scale = max(v.abs().max().item() for v in cand[0][2].values())
+    for k in gh:
+        errs = []
+        for c in cand:
+            try:
+                assert_grad_close(gh[k], c[2][k], scale, k, rtol=1e-4, floor=5e-6)
+                errs = None
+                break
+            except AssertionError as e:
+                errs.append(e)
+        if errs:
+            raise errs[0]
 
 
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0)])
