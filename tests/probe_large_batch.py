@@ -37,7 +37,7 @@ for k, g64 in grads['ref64'].items():
     if den < 1e-9:
         continue
     rows.append(((grads['hip'][k] - g64).abs().max().item() / den, (grads['ref32'][k] - g64).abs().max().item() / den, k))
-rows.sort(reverse=True)
+rows.sort(key=lambda r: -r[0] / max(r[1], 2e-6))           # where HIP is worse than the fp32 oracle
 print('%s B=%d N=%d: error vs the fp64 oracle, relative to max|grad| of the parameter' % (structure, B, n_max))
 print('%-40s %12s %12s' % ('parameter', 'HIP fp32', 'oracle fp32'))
 for eh, er, k in rows[:8]:

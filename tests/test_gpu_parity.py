@@ -138,14 +138,22 @@ def test_model_golden(name):
 @pytest.mark.parametrize('structure,n_layers,B,n_max', [('Concate', 2, 24, 132), ('Concate', 3, 16, 60),
                                                         ('Weighted_sum', 2, 12, 70),
                                                         # B > 512: the wave-per-tile aggregation kernels (large batches)
-                                                        ('Concate', 2, 640, 40), ('Weighted_sum', 2, 576, 36)])
+                                                        ('Concate', 2, 640, 40), ('Weighted_sum', 2, 576, 36),
+                                                        # > 1024 molecules / > 14 k packed rows: chunked row-BatchNorm,
+                                                        # multi-trip BatchNorm-backward reduction
+                                                        ('Concate', 2, 1300, 12),
+                                                        # N > 256: two column trips in the index scan and the edge kernel
+                                                        ('Concate', 2, 3, 270)])
 def test_model_vs_oracle_tox21_shape(structure, n_layers, B, n_max):
     """Tox21-like widths, large padding, against the CPU oracle on identical seeded inputs."""
     from eagcn_amd import EAGCN
     from eagcn_amd.synthetic import make_batch
     from oracle.eagcn_ref import RefEAGCN, weights_init_
     torch.manual_seed(5)
-    w1, w2 = ([80] * 5, [140] * 5) if structure == 'Concate' else ([12] * 5, [20] * 5)
+    # (narrow views beyond 1024 molecules: with ~10^7 pre-activations one of them sits within fp32 rounding of the
+    #  relu boundary and flips between any two fp32 evaluations -- an O(1/sqrt(rows)) jump in that view's gradients
+    #  that says nothing about the kernels; tests/probe_layer_large.py)
+    w1, w2 = ([80] * 5, [140] * 5) if (structure == 'Concate' and B <= 1024) else ([12] * 5, [20] * 5)
     mb = make_batch(B=B, n_max=n_max, n_med=16, rel_channels=(28, 4, 2, 2, 2), seed=11)
     ref = RefEAGCN(28, 24, w1, w2, 256, 64, 12, 0.0, structure=structure, n_layers=n_layers)
     weights_init_(ref)
@@ -188,7 +196,8 @@ def test_model_vs_oracle_tox21_shape(structure, n_layers, B, n_max):
 
 
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0)])
-@pytest.mark.parametrize('M,N,K', [(100, 64, 24), (1000, 704, 400), (37, 16, 8), (4608, 400, 704)])
+@pytest.mark.parametrize('M,N,K', [(100, 64, 24), (1000, 704, 400), (37, 16, 8), (4608, 400, 704),
+                                   (4096, 2048, 1024)])      # the last one takes the 128x128 tile configuration
 def test_gemm_f32(ta, tb, M, N, K):
     from eagcn_amd import ops
     if ta and M % 4:
