@@ -597,3 +597,28 @@ def test_step_loss_direct_backward_equals_autograd_path():
         for k in ga:
             assert_grad_close(gb[k], (factor * ga[k]).cpu(), factor * scale, '%s (%s)' % (k, how), rtol=1e-5, floor=1e-5)
     assert type(losses.fused_classification_loss(b(*d)[0], labels, w)).__name__ == '_StepLoss'
+
+
+@pytest.mark.parametrize('B,T', [(7, 1), (300, 12), (1024, 12), (2500, 5)])
+def test_fused_losses_against_tensor_ops(B, T):
+    """The fused loss kernels (train.py:321-331 + utils.py:653-679 in one launch) against the tensor-op statement of
+    the same losses, incl. sizes beyond the kernel's register cache (B*T > 4096) and missing labels."""
+    from eagcn_amd import losses
+    from eagcn_amd.synthetic import bce_weights
+    torch.manual_seed(B + T)
+    x = (3.0 * torch.randn(B, T, device='cuda')).requires_grad_(True)
+    y = torch.randint(-1, 2, (B, T), device='cuda').float()          # -1 = missing label
+    w = torch.tensor(bce_weights(T), device='cuda')
+    l1 = losses.classification_loss(x, y, w)
+    g1, = torch.autograd.grad(l1, x)
+    l2 = losses.fused_classification_loss(x, y, w)
+    g2, = torch.autograd.grad(l2, x)
+    assert abs(float(l1) - float(l2)) < 2e-6 * max(1.0, abs(float(l1)))
+    assert rel_err(g2.cpu(), g1.cpu()) < 2e-6
+    t = torch.randn(B, T, device='cuda')
+    m1 = losses.regression_loss(x, t)
+    h1, = torch.autograd.grad(m1, x)
+    m2 = losses.fused_regression_loss(x, t)
+    h2, = torch.autograd.grad(m2, x)
+    assert abs(float(m1) - float(m2)) < 2e-6 * max(1.0, abs(float(m1)))
+    assert rel_err(h2.cpu(), h1.cpu()) < 2e-6
