@@ -622,3 +622,36 @@ def test_fused_losses_against_tensor_ops(B, T):
     h2, = torch.autograd.grad(m2, x)
     assert abs(float(m1) - float(m2)) < 2e-6 * max(1.0, abs(float(m1)))
     assert rel_err(h2.cpu(), h1.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize('K,structure', [(1, 'Concate'), (3, 'Weighted_sum'), (7, 'Concate')])
+def test_view_counts_other_than_five(K, structure):
+    """The reference hard-wires five attention views; the kernels take 1..8 (EAGCN_MAX_VIEWS).  Oracle parity for
+    one, three and seven views (engine and graph replay), incl. widths that are not multiples of 16."""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    from oracle.eagcn_ref import RefEAGCN, weights_init_
+    chans = [6, 4, 2, 3, 2, 5, 2][:K]
+    w1, w2 = [7, 9, 5, 6, 4, 8, 3][:K], [10, 6, 12, 5, 9, 7, 11][:K]
+    torch.manual_seed(K)
+    mb = make_batch(B=9, n_max=26, n_med=9, rel_channels=chans, seed=40 + K, isolated_frac=0.1)
+    ref = RefEAGCN(chans[0], 24, w1, w2, 20, 10, 2, 0.0, structure=structure, n_layers=2, rel_channels=chans)
+    weights_init_(ref)
+    cpu = mb.dense()
+    out_r, _, gr_r = ref(*cpu)
+    gsel = torch.randn(out_r.shape)
+    (out_r * gsel).sum().backward()
+    gr = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    scale = max(v.abs().max().item() for v in gr.values())
+    for graph in (False, True):
+        hip = EAGCN(chans[0], 24, n_den1=20, n_den2=10, nclass=2, dropout=0.0, structure=structure, n_layers=2,
+                    widths1=w1, widths2=w2, rel_channels=chans, grad_mode='direct', graph=graph).cuda().train()
+        hip.load_state_dict(ref.state_dict(), strict=True)
+        out_h, _, gr_h = hip(*_dev(cpu))
+        assert rel_err(out_h.detach().cpu(), out_r.detach()) < TOL
+        assert rel_err(gr_h.detach().cpu(), gr_r.detach()) < TOL
+        (out_h * gsel.cuda()).sum().backward()
+        gh = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+        assert set(gr) == set(gh)
+        for k in gr:
+            assert_grad_close(gh[k], gr[k], scale, '%s (graph=%s)' % (k, graph), rtol=1e-4, floor=5e-6)
