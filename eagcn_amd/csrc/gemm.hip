@@ -25,10 +25,15 @@
 
 namespace eagcn {
 
+// floats of LDS one tile needs (two buffers of an A and a B image)
+constexpr int gemm_lds_floats(int BM, int BN, int BK, bool a_kc, bool b_kc) {
+    return 2 * ((a_kc ? BM * (BK + 2) : BK * (BM + 16)) + (b_kc ? BN * (BK + 2) : BK * (BN + 16)));
+}
+
 // one BM x BN output tile of split z; Mx / Kx are the actual extents (<= g.M / g.K)
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, int D>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int D, bool EXT_LDS = false>
 __device__ __forceinline__ void gemm_tile(const GemmDesc& g, const int Mx, const int Kx, const int tile_x,
-                                          const int tile_y, const int z, const int nsp) {
+                                          const int tile_y, const int z, const int nsp, float* shared = nullptr) {
     constexpr int WM = BM / 2, WN = BN / 2;      // 2x2 waves
     constexpr int MR = WM / 16, NR = WN / 16;
     constexpr int LDA_S = A_KC ? (BK + 2) : (BM + 16);
@@ -44,7 +49,15 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& g, const int Mx, const
     constexpr int B_PASS = (B_KC ? BN : BK) / B_RPP;
     static_assert(A_PASS >= 1 && B_PASS >= 1, "tile too small for 256 threads");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+    // `shared`: gemm_lds_floats(...) floats of 16-byte aligned LDS owned by the calling kernel (kernels that hold
+    // two differently laid out tiles share ONE buffer that way); by default the tile owns its own
+    float* smem;
+    if constexpr (EXT_LDS) {
+        smem = shared;
+    } else {
+        __shared__ __attribute__((aligned(16))) float own_smem[2 * (A_SZ + B_SZ)];
+        smem = own_smem;
+    }
     auto As = [&](int buf) -> float* { return smem + buf * (A_SZ + B_SZ); };
     auto Bs = [&](int buf) -> float* { return smem + buf * (A_SZ + B_SZ) + A_SZ; };
 
@@ -261,7 +274,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
 // 256 CUs); together the second fills the tail of the first.  Workgroups [0, first1) belong to dX.
 template <int BM, int BN, int BK, int D, bool X6 = false>
 __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(GemmDesc g0, GemmDesc g1, int first1) {
-    __shared__ __attribute__((aligned(16))) unsigned char x6_smem[X6 ? X6_LDS_BYTES : 16];   // one buffer for both halves
+    // one LDS buffer for both halves of the grid
+    constexpr int F32_LDS = gemm_lds_floats(BM, BN, BK, true, true) > gemm_lds_floats(BM, BN, BK, false, false)
+                                ? gemm_lds_floats(BM, BN, BK, true, true) : gemm_lds_floats(BM, BN, BK, false, false);
+    __shared__ __attribute__((aligned(16))) unsigned char x6_smem[X6 ? X6_LDS_BYTES : F32_LDS * 4];
+    float* f32_smem = reinterpret_cast<float*>(x6_smem);
     const int b = blockIdx.x;
     if (b < first1) {
         const int Mx = g0.M_dev ? min(*g0.M_dev, g0.M) : g0.M;
@@ -271,7 +288,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(GemmDesc g0, GemmDes
         const int nid = xcd_remap(b, nreal);
         const int ty = nid / gx;
         if constexpr (X6) gemm_tile_x6<true, true>(g0, Mx, g0.K, nid - ty * gx, ty, 0, 1, x6_smem);
-        else gemm_tile<BM, BN, BK, true, true, D>(g0, Mx, g0.K, nid - ty * gx, ty, 0, 1);
+        else gemm_tile<BM, BN, BK, true, true, D, true>(g0, Mx, g0.K, nid - ty * gx, ty, 0, 1, f32_smem);
     } else {
         const int lin = b - first1;                                 // first1 is a multiple of 8
         const int Kx = g1.K_dev ? min(*g1.K_dev, g1.K) : g1.K;
@@ -284,7 +301,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(GemmDesc g0, GemmDes
         const int z = nid / per_z, rem = nid - z * per_z;
         const int ty = rem / gx;
         if constexpr (X6) gemm_tile_x6<false, false>(g1, g1.M, Kx, rem - ty * gx, ty, z, nsp, x6_smem);
-        else gemm_tile<BM, BN, BK, false, false, D>(g1, g1.M, Kx, rem - ty * gx, ty, z, nsp);
+        else gemm_tile<BM, BN, BK, false, false, D, true>(g1, g1.M, Kx, rem - ty * gx, ty, z, nsp, f32_smem);
     }
 }
 
