@@ -58,6 +58,17 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& g, const int Mx, const
         __shared__ __attribute__((aligned(16))) float own_smem[2 * (A_SZ + B_SZ)];
         smem = own_smem;
     }
+    // K-contiguous images, BK = 16: the 16-lane groups a ds_write_b64 is served in (4 rows x 4 k-quads) take rows
+    // {r, r+1, r+8, r+9} instead of {r .. r+3}: with the 18-word row stride rows r and r+2 share banks, rows r and
+    // r+8 do not (SQ_LDS_BANK_CONFLICT was 14 % of the LDS cycles of these kernels, all of it from these stores)
+    auto kc_row = [](int x) -> int {
+        if constexpr (BK == 16) {
+            const int g = x >> 2, rs = x & 3;
+            return ((g >> 2) << 4) + ((g & 3) << 1) + (rs & 1) + ((rs >> 1) << 3);
+        } else {
+            return x;
+        }
+    };
     auto As = [&](int buf) -> float* { return smem + buf * (A_SZ + B_SZ); };
     auto Bs = [&](int buf) -> float* { return smem + buf * (A_SZ + B_SZ) + A_SZ; };
 
@@ -80,7 +91,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& g, const int Mx, const
         for (int p = 0; p < A_PASS; ++p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (A_KC) {
-                int row = p * A_RPP + tid / A_TPR, kq = (tid % A_TPR) * 4;
+                int row = p * A_RPP + kc_row(tid / A_TPR), kq = (tid % A_TPR) * 4;
                 if (m0 + row < Mx && k0 + kq < kend) {
                     const float* src = g.A + (size_t)(m0 + row) * g.lda + k0 + kq;
                     if (g.vecA) v = *reinterpret_cast<const float4*>(src);
@@ -110,7 +121,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& g, const int Mx, const
         for (int p = 0; p < B_PASS; ++p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (B_KC) {
-                int row = p * B_RPP + tid / B_TPR, kq = (tid % B_TPR) * 4;
+                int row = p * B_RPP + kc_row(tid / B_TPR), kq = (tid % B_TPR) * 4;
                 if (n0 + row < g.N && k0 + kq < kend) {
                     const float* src = g.B + (size_t)(n0 + row) * g.ldb + k0 + kq;
                     if (g.vecB) v = *reinterpret_cast<const float4*>(src);
@@ -141,7 +152,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& g, const int Mx, const
 #pragma unroll
         for (int p = 0; p < A_PASS; ++p) {
             if constexpr (A_KC) {
-                int row = p * A_RPP + tid / A_TPR, kq = (tid % A_TPR) * 4;
+                int row = p * A_RPP + kc_row(tid / A_TPR), kq = (tid % A_TPR) * 4;
                 float2* d = reinterpret_cast<float2*>(As(buf) + row * LDA_S + kq);   // 8-byte aligned: LDA_S even
                 d[0] = make_float2(ra[p].x, ra[p].y);
                 d[1] = make_float2(ra[p].z, ra[p].w);
@@ -153,7 +164,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& g, const int Mx, const
 #pragma unroll
         for (int p = 0; p < B_PASS; ++p) {
             if constexpr (B_KC) {
-                int row = p * B_RPP + tid / B_TPR, kq = (tid % B_TPR) * 4;
+                int row = p * B_RPP + kc_row(tid / B_TPR), kq = (tid % B_TPR) * 4;
                 float2* d = reinterpret_cast<float2*>(Bs(buf) + row * LDB_S + kq);
                 d[0] = make_float2(rb[p].x, rb[p].y);
                 d[1] = make_float2(rb[p].z, rb[p].w);
