@@ -35,15 +35,25 @@ WORKLOADS = {
     # configs[3]: Lipophilicity regression, 3-layer Concate, batch 4096 over 8 GPUs (512 / GPU)
     'lipo_c4': dict(structure='Concate', n_layers=3, widths1=[60] * 5, widths2=[100] * 5, dens=(128, 64),
                     nclass=1, n_bfeat=18, batch=512, n_max=115, n_med=27, task='reg'),
+    # configs[4]: synthetic roofline stress, N = 256 atoms in every molecule, K = 8 views (channels
+    # [32,4,2,2,2,2,2,2], widths 64 / 128: SURVEY.md section 8 config table), batch 8192 over 8 GPUs (1024 / GPU)
+    'c5_synth': dict(structure='Concate', n_layers=2, widths1=[64] * 8, widths2=[128] * 8, dens=(256, 64),
+                     nclass=1, n_bfeat=32, rel_channels=[32, 4, 2, 2, 2, 2, 2, 2], batch=1024, n_max=256, n_med=None,
+                     all_full=True, task='reg'),
 }
+
+
+def rel_channels(cfg):
+    return list(cfg.get('rel_channels') or [cfg['n_bfeat'], 4, 2, 2, 2])
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 
 
 def build_model(cfg, dropout, device, graph=False):
     from eagcn_amd import EAGCN, weights_init
-    m = EAGCN(cfg['n_bfeat'], 24, *cfg['widths1'], *cfg['widths2'], cfg['dens'][0], cfg['dens'][1], cfg['nclass'],
-              dropout, structure=cfg['structure'], n_layers=cfg['n_layers'], atom_rep='lazy', grad_mode='direct', overlap_index=True, graph=graph)
+    m = EAGCN(cfg['n_bfeat'], 24, n_den1=cfg['dens'][0], n_den2=cfg['dens'][1], nclass=cfg['nclass'], dropout=dropout,
+              widths1=cfg['widths1'], widths2=cfg['widths2'], rel_channels=rel_channels(cfg), structure=cfg['structure'],
+              n_layers=cfg['n_layers'], atom_rep='lazy', grad_mode='direct', overlap_index=True, graph=graph)
     m.apply(weights_init)
     return m.to(device)
 
@@ -94,7 +104,8 @@ def cpu_baseline(cfg, mb, dropout, bce_w, steps=5, warmup=2):
     except Exception:
         pass
     model = RefEAGCN(cfg['n_bfeat'], 24, cfg['widths1'], cfg['widths2'], cfg['dens'][0], cfg['dens'][1],
-                     cfg['nclass'], dropout, structure=cfg['structure'], n_layers=cfg['n_layers'])
+                     cfg['nclass'], dropout, structure=cfg['structure'], n_layers=cfg['n_layers'],
+                     rel_channels=rel_channels(cfg))
     weights_init_(model)
     dense = mb.dense('cpu')
     labels = torch.from_numpy(mb.labels)
@@ -176,8 +187,8 @@ def main():
     cfg = dict(WORKLOADS[args.workload])
     B = args.batch or cfg['batch']
     torch.manual_seed(1234 + rank)
-    mb = make_batch(B=B, n_max=cfg['n_max'], n_med=cfg['n_med'], rel_channels=(cfg['n_bfeat'], 4, 2, 2, 2),
-                    seed=1234 + rank, n_tasks=cfg['nclass'], task=cfg['task'])
+    mb = make_batch(B=B, n_max=cfg['n_max'], n_med=cfg['n_med'], rel_channels=rel_channels(cfg),
+                    seed=1234 + rank, n_tasks=cfg['nclass'], task=cfg['task'], all_full=cfg.get('all_full', False))
     dense = mb.dense(dev) if args.input == 'dense' else None
     compact = mb.compact(dev) if args.input == 'compact' else None
     labels = torch.from_numpy(mb.labels).to(dev)

@@ -15,3 +15,46 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+def _report_lines():
+    """One line per test: largest achieved forward/output error (max|d|/max|ref|), largest gradient error relative to
+    the tensor's OWN largest entry (tensors that are not analytic zeros) and relative to the largest gradient of the
+    case, each with the label it occurred at."""
+    try:
+        from helpers import REPORT
+    except Exception:
+        return []
+    per = {}
+    for test, kind, label, err, bound, own in REPORT:
+        d = per.setdefault(test, {'rel': (0.0, ''), 'grad': (0.0, ''), 'own': (0.0, ''), 'n': 0})
+        d['n'] += 1
+        if kind == 'rel' and err >= d['rel'][0]:
+            d['rel'] = (err, label)
+        if kind == 'grad' and err >= d['grad'][0]:
+            d['grad'] = (err, label)
+        if kind == 'grad' and own is not None and own >= d['own'][0]:
+            d['own'] = (own, label)
+    lines = []
+    for test in sorted(per):
+        d = per[test]
+        lines.append('%-86s n=%-4d out: %.1e (%s) | grad/own max: %.1e (%s) | grad/case scale: %.1e (%s)'
+                     % (test.replace('tests/', ''), d['n'], d['rel'][0], d['rel'][1], d['own'][0], d['own'][1],
+                        d['grad'][0], d['grad'][1]))
+    return lines
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    lines = _report_lines()
+    if not lines:
+        return
+    terminalreporter.write_sep('-', 'achieved parity errors (HIP vs oracle / golden vectors)')
+    for ln in lines:
+        terminalreporter.write_line(ln)
+    out = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity_report.txt'), 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+    except OSError:
+        pass

@@ -2,6 +2,7 @@
 import glob
 import json
 import os
+import sys
 
 import numpy as np
 import torch
@@ -38,7 +39,19 @@ class Golden:
         return {k: torch.from_numpy(v.copy()) for k, v in self.group('sd/').items()}
 
 
-def rel_err(a, b):
+# ---- achieved-error report ---------------------------------------------------------------------
+# Every comparison made through rel_err / assert_grad_close is recorded (test id, label, achieved
+# error, bound); tests/conftest.py prints the table in the terminal summary and writes it to
+# gpurun_out/parity_report.txt, so a green run also shows HOW close the HIP path is to the oracle.
+REPORT = []
+
+
+def _note(kind, label, err, bound, own=None):
+    test = os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]
+    REPORT.append((test, kind, str(label), float(err), None if bound is None else float(bound), own))
+
+
+def rel_err(a, b, name=None):
     """max|a-b| / max|b|  (SURVEY.md 8(d) parity metric); b is the reference."""
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)
@@ -47,7 +60,9 @@ def rel_err(a, b):
         return 0.0
     den = b.abs().max().item()
     num = (a - b).abs().max().item()
-    return num / den if den > 0 else num
+    e = num / den if den > 0 else num
+    _note('rel', name if name is not None else 'line %d' % sys._getframe(1).f_lineno, e, None)
+    return e
 
 
 def build_oracle_model(meta, n_layers=4):
@@ -73,4 +88,9 @@ def assert_grad_close(got, ref, scale, name='', rtol=2e-5, floor=1e-6):
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     err = (got - ref).abs().max().item() if ref.numel() else 0.0
     bound = rtol * ref.abs().max().item() + floor * float(scale)
+    # reported relative to the largest gradient of the case (the scale the floor refers to)
+    # ... and relative to the tensor's own largest entry where that is not an analytic zero (>= 1e-3 of the scale)
+    rmax = ref.abs().max().item() if ref.numel() else 0.0
+    own = err / rmax if rmax >= 1e-3 * float(scale) and rmax > 0 else None
+    _note('grad', name, err / max(float(scale), 1e-300), bound / max(float(scale), 1e-300), own)
     assert err <= bound, (name, err, bound)

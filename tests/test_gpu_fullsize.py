@@ -12,12 +12,16 @@ CONFIGS = {
     # BASELINE configs[1]: Tox21 12-task, 2-layer 5-view Concate, batch 256, N_pad 132
     'tox21_c2': dict(structure='Concate', n_layers=2, w1=[80] * 5, w2=[140] * 5, dens=(256, 64), nclass=12,
                      n_bfeat=28, B=256, n_max=132, n_med=16),
-    # configs[2] shape: HIV 2-layer Weighted_sum, N_pad 222 (batch 256 of the 1024 to bound test time)
+    # configs[2]: HIV 2-layer Weighted_sum (every view 500 / 1250 wide), N_pad 222, batch 1024
     'hiv_c3': dict(structure='Weighted_sum', n_layers=2, w1=[100] * 5, w2=[250] * 5, dens=(512, 128), nclass=1,
-                   n_bfeat=28, B=256, n_max=222, n_med=23),
+                   n_bfeat=28, B=1024, n_max=222, n_med=23),
     # configs[3] shape: Lipophilicity 3-layer Concate, N_pad 115, the 512-molecule shard of one GPU
     'lipo_c4': dict(structure='Concate', n_layers=3, w1=[60] * 5, w2=[100] * 5, dens=(128, 64), nclass=1,
                     n_bfeat=18, B=512, n_max=115, n_med=27),
+    # configs[4]: synthetic roofline stress, K = 8 views, channels [32,4,2,2,2,2,2,2], 64 / 128 per view, every molecule
+    # has all N = 256 atoms, the 1024-molecule shard of one GPU
+    'c5_synth': dict(structure='Concate', n_layers=2, w1=[64] * 8, w2=[128] * 8, dens=(256, 64), nclass=1,
+                     n_bfeat=32, chans=[32, 4, 2, 2, 2, 2, 2, 2], B=1024, n_max=256, n_med=None, all_full=True),
 }
 
 
@@ -26,9 +30,12 @@ def _setup(name, **kw):
     from eagcn_amd.synthetic import make_batch
     c = CONFIGS[name]
     torch.manual_seed(0)
-    mb = make_batch(B=c['B'], n_max=c['n_max'], n_med=c['n_med'], rel_channels=(c['n_bfeat'], 4, 2, 2, 2), seed=77)
-    model = EAGCN(c['n_bfeat'], 24, *c['w1'], *c['w2'], c['dens'][0], c['dens'][1], c['nclass'], 0.0,
-                  structure=c['structure'], n_layers=c['n_layers'], **kw)
+    chans = c.get('chans', [c['n_bfeat'], 4, 2, 2, 2])
+    mb = make_batch(B=c['B'], n_max=c['n_max'], n_med=c['n_med'], rel_channels=chans, seed=77,
+                    all_full=c.get('all_full', False))
+    model = EAGCN(c['n_bfeat'], 24, n_den1=c['dens'][0], n_den2=c['dens'][1], nclass=c['nclass'], dropout=0.0,
+                  widths1=c['w1'], widths2=c['w2'], rel_channels=chans, structure=c['structure'],
+                  n_layers=c['n_layers'], **kw)
     model.apply(weights_init)
     return c, mb, model.cuda().train()
 
@@ -40,7 +47,7 @@ def _grads(model):
 @pytest.mark.parametrize('name', sorted(CONFIGS))
 def test_permutation_equivariance_and_backward_linearity(name):
     c, mb, model = _setup(name)
-    dense = [t.cuda() for t in mb.dense()]
+    dense = list(mb.dense('cuda'))              # built on the device (HIV / C5: 8 - 13 GB of dense collate tensors)
     B = c['B']
     g1 = torch.randn(B, c['nclass'], device='cuda')
     g2 = torch.randn(B, c['nclass'], device='cuda')
@@ -56,7 +63,7 @@ def test_permutation_equivariance_and_backward_linearity(name):
     #     permutation invariant; packing order changes, so sums are re-associated: fp32 tolerance)
     perm = torch.randperm(B, device='cuda')
     out_p, gp = run([t[perm] for t in dense], g1[perm])
-    assert rel_err(out_p.cpu(), out_a[perm].cpu()) < 2e-5
+    assert rel_err(out_p.cpu(), out_a[perm].cpu(), name + ' permuted') < 2e-5
     scale = max(v.abs().max().item() for v in ga.values())
     for k in ga:
         assert_grad_close(gp[k], ga[k].cpu(), scale, k, rtol=2e-4, floor=2e-5)
@@ -68,12 +75,12 @@ def test_permutation_equivariance_and_backward_linearity(name):
         assert_grad_close(gc[k], want.cpu(), 5.0 * scale, k, rtol=2e-4, floor=2e-5)
 
 
-@pytest.mark.parametrize('name', ['tox21_c2', 'hiv_c3'])
+@pytest.mark.parametrize('name', ['tox21_c2', 'hiv_c3', 'c5_synth'])
 def test_engine_composition_and_graph_agree_at_full_size(name):
     c, mb, a = _setup(name, grad_mode='direct')
     _, _, b = _setup(name, grad_mode='direct', graph=True)
     b.load_state_dict(a.state_dict())
-    dense = [t.cuda() for t in mb.dense()]
+    dense = list(mb.dense('cuda'))
     cot = torch.randn(c['B'], c['nclass'], device='cuda')
     res = []
     for model, fn in ((a, a.forward), (a, a.forward_composed), (b, b.forward), (b, b.forward)):
@@ -87,6 +94,6 @@ def test_engine_composition_and_graph_agree_at_full_size(name):
     ref_out, ref_g = res[0]
     scale = max(v.abs().max().item() for v in ref_g.values())
     for i, (out, g) in enumerate(res[1:], 1):
-        assert rel_err(out.cpu(), ref_out.cpu()) < 1e-5, i
+        assert rel_err(out.cpu(), ref_out.cpu(), '%s run %d' % (name, i)) < 1e-5, i
         for k in ref_g:
             assert_grad_close(g[k], ref_g[k].cpu(), scale, '%s (run %d)' % (k, i), rtol=1e-4, floor=2e-5)

@@ -655,3 +655,173 @@ def test_view_counts_other_than_five(K, structure):
         assert set(gr) == set(gh)
         for k in gr:
             assert_grad_close(gh[k], gr[k], scale, '%s (graph=%s)' % (k, graph), rtol=1e-4, floor=5e-6)
+
+
+# ---- BASELINE.json configs at their stated widths / padding, against the CPU oracle ---------------------------------
+FULL_WIDTH_CASES = {
+    # configs[2] HIV: 2-layer Weighted_sum, every view 500 / 1250 wide (train.py:70-71 + models.py:33-47), N_pad 222
+    'hiv_c3': dict(structure='Weighted_sum', n_layers=2, w1=[100] * 5, w2=[250] * 5, dens=(512, 128), nclass=1,
+                   chans=[28, 4, 2, 2, 2], B=6, n_max=222, n_med=23, all_full=False),
+    # configs[3] Lipophilicity: 3-layer Concate 60 / 100 / 200 per view, N_pad 115
+    'lipo_c4': dict(structure='Concate', n_layers=3, w1=[60] * 5, w2=[100] * 5, dens=(128, 64), nclass=1,
+                    chans=[18, 4, 2, 2, 2], B=12, n_max=115, n_med=27, all_full=False),
+    # configs[4] synthetic roofline stress: K = 8 views, channels [32,4,2,2,2,2,2,2], 64 / 128 per view, every
+    # molecule has all N = 256 atoms
+    'c5_synth': dict(structure='Concate', n_layers=2, w1=[64] * 8, w2=[128] * 8, dens=(256, 64), nclass=1,
+                     chans=[32, 4, 2, 2, 2, 2, 2, 2], B=8, n_max=256, n_med=None, all_full=True),
+    # configs[1] Tox21 widths with the reference's 4-layer stack (parity mode P of SURVEY 8: 80/140/280/280)
+    'tox21_p4': dict(structure='Concate', n_layers=4, w1=[80] * 5, w2=[140] * 5, dens=(256, 64), nclass=12,
+                     chans=[28, 4, 2, 2, 2], B=10, n_max=60, n_med=16, all_full=False),
+}
+
+
+@pytest.mark.parametrize('graph', [False, True])
+@pytest.mark.parametrize('name', sorted(FULL_WIDTH_CASES))
+def test_model_vs_oracle_baseline_widths(name, graph):
+    """Every BASELINE.json config at its own widths, view count and padding (small B so the CPU oracle takes
+    seconds), eager engine and graph replay.  Outputs to 1e-5; every parameter gradient either within 1e-5 of the
+    fp32 oracle (relative to the tensor's own largest entry) or -- where fp32 itself is not that reproducible -- at
+    most 2x as far from the fp64 oracle as the fp32 oracle is."""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    from oracle.eagcn_ref import RefEAGCN, weights_init_
+    c = FULL_WIDTH_CASES[name]
+    torch.manual_seed(17)
+    mb = make_batch(B=c['B'], n_max=c['n_max'], n_med=c['n_med'], rel_channels=c['chans'], seed=23,
+                    all_full=c['all_full'])
+    kw = dict(structure=c['structure'], n_layers=c['n_layers'], rel_channels=c['chans'])
+    ref = RefEAGCN(c['chans'][0], 24, c['w1'], c['w2'], c['dens'][0], c['dens'][1], c['nclass'], 0.0, **kw)
+    weights_init_(ref)
+    ref64 = RefEAGCN(c['chans'][0], 24, c['w1'], c['w2'], c['dens'][0], c['dens'][1], c['nclass'], 0.0, **kw).double()
+    ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+    hip = EAGCN(c['chans'][0], 24, n_den1=c['dens'][0], n_den2=c['dens'][1], nclass=c['nclass'], dropout=0.0,
+                widths1=c['w1'], widths2=c['w2'], grad_mode='direct', graph=graph, **kw).cuda().train()
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    cpu = mb.dense()
+    gsel = torch.randn(c['B'], c['nclass'])
+    res = []
+    for m, inp in ((ref, cpu), (ref64, [t.double() if t.is_floating_point() else t for t in cpu])):
+        out, _, gr = m(*inp)
+        ((out * gsel.to(out.dtype)).sum() + 0.1 * gr.sum()).backward()
+        res.append((out.detach(), gr.detach(), {k: p.grad for k, p in m.named_parameters() if p.grad is not None},
+                    {k: v for k, v in m.state_dict().items() if 'running' in k}))
+    (o32, g32, p32, b32), (o64, g64, p64, b64) = res
+    reps = 3 if graph else 1                      # graph mode: the first use of each of the two slots runs eagerly + captures
+    for rep in range(reps):
+        if rep:
+            hip.load_state_dict(ref.state_dict(), strict=True)      # undo the running-statistics update
+        for p in hip.parameters():
+            p.grad = None
+        out_h, _, gr_h = hip(*_dev(cpu))
+        ((out_h * gsel.cuda()).sum() + 0.1 * gr_h.sum()).backward()
+        tag = '%s/%s%d' % (name, 'graph' if graph else 'eager', rep)
+        assert rel_err(out_h.detach().cpu(), o32, tag + ' out') < TOL
+        assert rel_err(gr_h.detach().cpu(), g32, tag + ' graph_rep') < TOL
+        gh = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+        assert set(gh) == set(p32)
+        scale = max(v.abs().max().item() for v in p32.values())
+        for k in gh:
+            try:
+                assert_grad_close(gh[k], p32[k], scale, '%s %s' % (tag, k), rtol=1e-5, floor=1e-6)
+            except AssertionError:
+                e_ref = (p32[k].double() - p64[k]).abs().max().item()
+                e_hip = (gh[k].double().cpu() - p64[k]).abs().max().item()
+                assert e_hip <= 2.0 * e_ref + 1e-6 * scale, (k, e_hip, e_ref, scale)
+        sd = hip.state_dict()
+        for k, v in b32.items():
+            assert rel_err(sd[k].cpu(), v, tag + ' ' + k) < TOL, k
+
+
+# ---- SURVEY 8(f) rows against the reference's golden vectors (not against the package itself) ------------------------
+@pytest.mark.parametrize('graph', [False, True])
+@pytest.mark.parametrize('name', ['model_concate_bce_train', 'model_concate_mse_train'])
+def test_fused_losses_golden(name, graph):
+    """f-2: the fused loss kernels (loss value + d/dlogits in one launch, train.py:321-331 incl. the class-weight
+    tensor of utils.py:653-679) inside a full training step, against the loss and every parameter gradient the
+    unmodified reference produced; in graph mode the loss's plain backward() launches the captured backward."""
+    from eagcn_amd import losses
+    g = Golden(name)
+    model = _hip_model(g.meta)
+    model.grad_mode, model.graph = 'direct', graph
+    model.load_state_dict(g.state_dict(), strict=True)
+    model.cuda().train(True)
+    dense = _dev(g.batch.dense())
+    labels = torch.from_numpy(g.z['labels']).cuda()
+    grads = g.group('grad/')
+    scale = max(np.abs(v).max() for v in grads.values())
+    for rep in range(3 if graph else 1):          # graph: eager+capture, replay slot 1 (eager+capture), replay slot 0
+        model.load_state_dict(g.state_dict(), strict=True)
+        for p in model.parameters():
+            p.grad = None
+        out, _, _ = model(*dense)
+        if g.meta['loss'] == 'bce':
+            loss = losses.fused_classification_loss(out, labels, torch.tensor(g.z['bce_weight'], device='cuda'))
+        else:
+            loss = losses.fused_regression_loss(out, labels)
+        want = float(g.z['out/loss'])
+        assert abs(float(loss.detach()) - want) <= 1e-5 * max(1.0, abs(want))
+        loss.backward()
+        got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        assert set(got) == set(grads)
+        for k, ref in grads.items():
+            assert_grad_close(got[k], ref, scale, '%s rep%d' % (k, rep), rtol=2e-5, floor=2e-6)
+
+
+@pytest.mark.parametrize('graph', [False, True])
+@pytest.mark.parametrize('name', golden_cases('model'))
+def test_compact_input_golden(name, graph):
+    """f-1: forward_compact (bond list -> batch index on the device, no dense adjacency / relation tensors) on the
+    molecules of every golden case, against the outputs and gradients the reference computed from its dense
+    collate tensors."""
+    g = Golden(name)
+    if g.meta['loss'] != 'proj':
+        pytest.skip('loss fixtures are covered by test_fused_losses_golden')
+    model = _hip_model(g.meta)
+    model.grad_mode, model.graph = 'direct', graph
+    model.load_state_dict(g.state_dict(), strict=True)
+    model.cuda().train(g.meta['training'])
+    bonds, afm, size = g.batch.compact('cuda')
+    grads = g.group('grad/')
+    scale = max(np.abs(v).max() for v in grads.values())
+    with torch.set_grad_enabled(g.meta['training'] or not graph):
+        out, atom_rep, graph_rep = model.forward_compact(bonds, afm, size)
+    assert rel_err(out.detach().cpu(), g.z['out/out'], 'out') < TOL
+    assert rel_err(graph_rep.detach().cpu(), g.z['out/graph_rep'], 'graph_rep') < TOL
+    assert rel_err(atom_rep.cpu(), g.z['out/atom_rep'], 'atom_rep') < TOL
+    if not out.requires_grad:
+        return
+    ((out * torch.from_numpy(g.z['gout']).cuda()).sum() +
+     (graph_rep * torch.from_numpy(g.z['gout_graph_rep']).cuda()).sum()).backward()
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(grads)
+    f64 = None
+    for k, ref in grads.items():
+        try:
+            assert_grad_close(got[k], ref, scale, k, rtol=2e-5, floor=2e-6)
+        except AssertionError:
+            if f64 is None:
+                f64 = _f64_grads(g)
+            e_ref = (torch.from_numpy(ref).double() - f64[k]).abs().max().item()
+            e_hip = (got[k].double().cpu() - f64[k]).abs().max().item()
+            assert e_hip <= 4.0 * e_ref + 2e-6 * scale, (k, e_hip, e_ref)
+
+
+@pytest.mark.parametrize('name', ['model_concate_eval', 'model_weighted_eval'])
+def test_eval_graph_golden(name):
+    """f-3: the forward-only graph of the eval-mode model (running BatchNorm statistics, no dropout) under no_grad,
+    replayed, against the reference's eval-mode outputs."""
+    g = Golden(name)
+    model = _hip_model(g.meta)
+    model.graph = True
+    model.load_state_dict(g.state_dict(), strict=True)
+    model.cuda().eval()
+    dense = _dev(g.batch.dense())
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    for rep in range(3):
+        with torch.no_grad():
+            out, atom_rep, graph_rep = model(*dense)
+        assert rel_err(out.cpu(), g.z['out/out'], 'out rep%d' % rep) < TOL
+        assert rel_err(graph_rep.cpu(), g.z['out/graph_rep'], 'graph_rep rep%d' % rep) < TOL
+        assert rel_err(atom_rep.cpu(), g.z['out/atom_rep'], 'atom_rep rep%d' % rep) < TOL
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
