@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libeagcn_hip.so')
 MAX_VIEWS = 8
 MAX_SEGS = 8
 META_WORDS = 8
-META_T, META_NMAX, META_NTILES, META_BAD_ADJ, META_BAD_REL, META_NEDGE = range(6)
+META_T, META_NMAX, META_NTILES, META_BAD_ADJ, META_BAD_REL, META_NEDGE, META_OVERFLOW = range(7)
 STRUCT_CONCATE, STRUCT_WEIGHTED = 0, 1
 
 _fp = C.c_void_p   # device pointers travel as integers
@@ -101,6 +101,13 @@ SIGNATURES = {
                                          _fp, _fp, _fp]),
     'eagcn_gemm_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int,
                                  _fp, C.c_int, _fp]),
+    'eagcn_gemm_sk_workspace_bytes': (C.c_size_t, []),
+    'eagcn_gemm_f32_sk': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int,
+                                    _fp, C.c_int, _fp, C.c_size_t, _fp]),
+    'eagcn_gemm_pair_sk': (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
+                                     _fp, C.c_size_t, _fp]),
+    'eagcn_gemm_sk_timeouts': (C.c_int, []),
     'eagcn_model_saved_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(Model)]),
     'eagcn_model_scratch_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(Model)]),
     'eagcn_model_atom_rep': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), C.POINTER(C.c_size_t),

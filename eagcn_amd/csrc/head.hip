@@ -518,6 +518,7 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "eagcn_model_forward: saved block too small");
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_forward: scratch too small");
     const eagcn_head_params* h = &m->head;
+    RC(gemm3_clear_flags(sc.layer, sc.layer_bytes, s));          // one clear for every layer product of this call
     if (!m->input_packed)
         RC(eagcn_pack_rows(b, afm, layout_width(&m->layer[0].in), &m->layer[0].in, sv.x0, stream));
     const float* x = sv.x0;
@@ -572,6 +573,7 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_backward: scratch too small");
     const eagcn_head_params* h = &m->head;
     const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
+    RC(gemm3_clear_flags(sc.layer, sc.layer_bytes, s));          // one clear for every layer product of this call
     hipStream_t side = m->aux_stream ? (hipStream_t)m->aux_stream : s;
     const bool forked = side != s;
     Partial pd;

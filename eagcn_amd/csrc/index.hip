@@ -151,7 +151,7 @@ __global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __re
                                                               const int32_t* __restrict__ deg_bn, int BN,
                                                               int32_t* __restrict__ row0,
                                                               int32_t* __restrict__ tile0,
-                                                              int32_t* __restrict__ meta) {
+                                                              int32_t* __restrict__ meta, int cap_rows) {
     __shared__ int s_rows[1024], s_tiles[1024];
     __shared__ int carry_r, carry_t, s_max;
     const int t = threadIdx.x;
@@ -199,8 +199,12 @@ __global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __re
     if (t == 0) {
         row0[B] = carry_r;
         tile0[B] = carry_t;
-        meta[EAGCN_META_T] = carry_r;
-        meta[EAGCN_META_NTILES] = carry_t;
+        // a batch that does not fit the caller's row capacity is indexed as empty (and reported): every consumer
+        // takes its extents from meta[], so nothing is read or written beyond the capacity-sized buffers
+        const bool over = cap_rows > 0 && carry_r > cap_rows;
+        meta[EAGCN_META_T] = over ? 0 : carry_r;
+        meta[EAGCN_META_NTILES] = over ? 0 : carry_t;
+        meta[EAGCN_META_OVERFLOW] = over ? carry_r : 0;
         meta[EAGCN_META_NMAX] = s_max;
     }
 }
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __re
 __global__ __launch_bounds__(256) void index_rows_kernel(eagcn_batch bt) {
     const int b = blockIdx.x;
     const int n = bt.nat[b], r0 = bt.row0[b], t0 = bt.tile0[b];
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int i = threadIdx.x; i < n && r0 + i < bt.T; i += blockDim.x) {       // (never beyond the row capacity)
         int d = bt.deg_bn[(size_t)b * bt.N + i];
         bt.row_mol[r0 + i] = b;
         bt.row_loc[r0 + i] = i;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void index_rows_kernel(eagcn_batch bt) {
         bt.row_m[r0 + i] = d > 0 ? 1.0f : 0.0f;
         reinterpret_cast<int4*>(bt.row_info)[r0 + i] = make_int4(b, i, n, r0);
     }
-    for (int t = threadIdx.x; t < (n + 15) / 16; t += blockDim.x) {
+    for (int t = threadIdx.x; t < (n + 15) / 16 && t0 + t < bt.n_tiles; t += blockDim.x) {
         bt.tile_mol[t0 + t] = b;
         reinterpret_cast<int4*>(bt.tile_info)[t0 + t] = make_int4(b, t, n, r0);
     }
@@ -315,7 +319,7 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     }
 #undef EAGCN_SCAN
     EAGCN_LAUNCH_CHECK();
-    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta);
+    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta, b->T);
     EAGCN_LAUNCH_CHECK();
     EAGCN_HIP(hipMemcpyAsync(host_meta, b->meta, EAGCN_META_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     return EAGCN_OK;
@@ -344,7 +348,7 @@ extern "C" int eagcn_index_from_bonds(const int32_t* bond_mol, const int32_t* bo
                                                 b->code, b->deg_bn, b->nat, b->meta);
         EAGCN_LAUNCH_CHECK();
     }
-    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta);
+    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta, b->T);
     EAGCN_LAUNCH_CHECK();
     EAGCN_HIP(hipMemcpyAsync(host_meta, b->meta, EAGCN_META_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     return EAGCN_OK;

@@ -53,6 +53,27 @@ struct ReadoutGrad {
     const int64_t* size; int mode;
     ColMapD map;                 // layout of the layer output (packed column -> exact column)
 };
+// ---- wave-autonomous balanced GEMM (gemm3.hip): NT (ta=0,tb=1) and TN (ta=1,tb=0) forms --------------------------------
+struct G2Prob {                  // one product C[M,N] = op(A).op(B) in one of the three operand forms of a layer
+    const float* A; const float* B; float* C;
+    int lda, ldb, ldc;
+    int M, N, K;                 // static extents (capacities where a device-side count exists)
+    const int* M_dev;            // actual M (rows of A and C), read on the device
+    const int* K_dev;            // actual K
+};
+struct DwScatter {               // epilogue of a layer's dW product: packed (input column, output column) -> blockK.graph_conv.weight.grad
+    float* dW[EAGCN_MAX_VIEWS];
+    ViewCols vc;
+    ColMapD in;
+};
+size_t gemm3_workspace_bytes();
+// the hand-off flags must be zero when a launch starts; every launch leaves them zero again, so ONE clear at the start of
+// an API call (a memset node under capture) covers all its launches on the same workspace
+int gemm3_clear_flags(void* workspace, size_t bytes, hipStream_t s);
+bool gemm3_ok(const GemmDesc& g);
+int launch_gemm3(const GemmDesc& g, const DwScatter* sc, void* workspace, size_t bytes, hipStream_t s);
+int launch_gemm3_pair(const GemmDesc& dx, const GemmDesc& dw, const DwScatter* sc, void* workspace, size_t bytes, hipStream_t s);
+
 int layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                         const float* dxout, const ReadoutGrad* rg, const float* dpad_row, float* dx,
                         const eagcn_layer_grads* g, void* stream);

@@ -63,8 +63,8 @@ __device__ __forceinline__ int packed_to_exact(const ColMapD& m, int cp) {
 
 // ---- parameter packing -------------------------------------------------------------------------
 __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const ViewCols& vc, const ColMapD& in, int ld_in,
-                                                 int fp, float* __restrict__ Wcat, float* __restrict__ colp,
-                                                 float* __restrict__ sig, float* __restrict__ rsig) {
+                                                 int fp, float* __restrict__ Wcat, float* __restrict__ WcatT,
+                                                 float* __restrict__ colp, float* __restrict__ sig, float* __restrict__ rsig) {
     const int total = ld_in * fp;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int ip = e / fp, cp = e % fp;
@@ -73,6 +73,7 @@ __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const View
         float v = 0.0f;
         if (fi >= 0 && f < vc.width[k]) v = pp.W[k][(size_t)fi * vc.width[k] + f];
         Wcat[e] = v;
+        WcatT[(size_t)cp * ld_in + ip] = v;      // [Fp][ld_in]: the K-contiguous B operand of the forward product (NT form)
     }
     for (int cp = blockIdx.x * blockDim.x + threadIdx.x; cp < fp; cp += gridDim.x * blockDim.x) {
         const int k = col_view(vc, cp), f = cp - vc.off[k];
@@ -91,23 +92,24 @@ __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const View
     if (blockIdx.x == 0 && threadIdx.x < vc.K) rsig[threadIdx.x] = sigmoidf_(pp.self_r[threadIdx.x][0]);
 }
 __global__ __launch_bounds__(256) void pack_params_kernel(ParamPtrs pp, ViewCols vc, ColMapD in, int ld_in, int fp,
-                                                           float* __restrict__ Wcat, float* __restrict__ colp,
-                                                           float* __restrict__ sig, float* __restrict__ rsig) {
-    pack_params_body(pp, vc, in, ld_in, fp, Wcat, colp, sig, rsig);
+                                                           float* __restrict__ Wcat, float* __restrict__ WcatT,
+                                                           float* __restrict__ colp, float* __restrict__ sig,
+                                                           float* __restrict__ rsig) {
+    pack_params_body(pp, vc, in, ld_in, fp, Wcat, WcatT, colp, sig, rsig);
 }
 // every layer of a model in one launch (blockIdx.y = layer): the parameters of all layers are known before the
 // first layer runs, and each packing launch is a few microseconds of fixed cost on the critical path
 struct PackJob {
     ParamPtrs pp; ViewCols vc; ColMapD in; int ld_in, fp;
-    float *Wcat, *colp, *sig, *rsig;
+    float *Wcat, *WcatT, *colp, *sig, *rsig;
 };
 struct PackJobs { PackJob j0, j1, j2, j3; };
 __global__ __launch_bounds__(256) void pack_params_multi_kernel(PackJobs jobs) {
     // (an if-chain, not an indexed array: indexing the by-value argument block dynamically would move it to scratch)
-    if (blockIdx.y == 0) pack_params_body(jobs.j0.pp, jobs.j0.vc, jobs.j0.in, jobs.j0.ld_in, jobs.j0.fp, jobs.j0.Wcat, jobs.j0.colp, jobs.j0.sig, jobs.j0.rsig);
-    else if (blockIdx.y == 1) pack_params_body(jobs.j1.pp, jobs.j1.vc, jobs.j1.in, jobs.j1.ld_in, jobs.j1.fp, jobs.j1.Wcat, jobs.j1.colp, jobs.j1.sig, jobs.j1.rsig);
-    else if (blockIdx.y == 2) pack_params_body(jobs.j2.pp, jobs.j2.vc, jobs.j2.in, jobs.j2.ld_in, jobs.j2.fp, jobs.j2.Wcat, jobs.j2.colp, jobs.j2.sig, jobs.j2.rsig);
-    else pack_params_body(jobs.j3.pp, jobs.j3.vc, jobs.j3.in, jobs.j3.ld_in, jobs.j3.fp, jobs.j3.Wcat, jobs.j3.colp, jobs.j3.sig, jobs.j3.rsig);
+    if (blockIdx.y == 0) pack_params_body(jobs.j0.pp, jobs.j0.vc, jobs.j0.in, jobs.j0.ld_in, jobs.j0.fp, jobs.j0.Wcat, jobs.j0.WcatT, jobs.j0.colp, jobs.j0.sig, jobs.j0.rsig);
+    else if (blockIdx.y == 1) pack_params_body(jobs.j1.pp, jobs.j1.vc, jobs.j1.in, jobs.j1.ld_in, jobs.j1.fp, jobs.j1.Wcat, jobs.j1.WcatT, jobs.j1.colp, jobs.j1.sig, jobs.j1.rsig);
+    else if (blockIdx.y == 2) pack_params_body(jobs.j2.pp, jobs.j2.vc, jobs.j2.in, jobs.j2.ld_in, jobs.j2.fp, jobs.j2.Wcat, jobs.j2.WcatT, jobs.j2.colp, jobs.j2.sig, jobs.j2.rsig);
+    else pack_params_body(jobs.j3.pp, jobs.j3.vc, jobs.j3.in, jobs.j3.ld_in, jobs.j3.fp, jobs.j3.Wcat, jobs.j3.WcatT, jobs.j3.colp, jobs.j3.sig, jobs.j3.rsig);
 }
 
 // sum of per-workgroup partial pairs slab[s][cp][0..1] over s, L (16 or 64) lanes per column: with hundreds of
@@ -553,12 +555,22 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     return d;
 }
 
-struct Packed { float *Wcat, *colp, *sig, *rsig; };
-struct FwdScratch { float *Wcat, *colp, *sig, *rsig; double* stats; };
+// Which layers run their products on the wave-autonomous balanced kernel (gemm3.hip): the hidden layers.  The first
+// layer (24 atom features) is a different animal: its forward product has two k-steps per tile and its weight gradient
+// seven 64x64 tiles with thousands of k-steps each -- a balanced cut would make every wave hand a partial tile to a
+// single owner per tile (measured: 0.2 ms instead of 0.02 ms) -- it stays on the workgroup-tiled kernels (gemm.hip).
+static bool gemm3_layer(int ld_in) {
+    static const bool on = [] { const char* v = getenv("EAGCN_NO_GEMM3"); return !(v && v[0] == '1'); }();
+    return on && ld_in >= 128;
+}
+
+struct Packed { float *Wcat, *WcatT, *colp, *sig, *rsig; };
+struct FwdScratch { void* gws; float *Wcat, *WcatT, *colp, *sig, *rsig; double* stats; };
 static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
     Carver c(base);
     Packed t;
     t.Wcat = c.take<float>(d.wslab);
+    t.WcatT = c.take<float>(d.wslab);
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
     t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
@@ -566,13 +578,17 @@ static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
     return c.off;
 }
 struct BwdScratch {
-    float *Wcat, *colp, *sig, *rsig, *dY, *dP, *cc, *dWcat;
+    void* gws;                   // GEMM hand-off workspace: FIRST in both carvings, so that every layer of a model and both
+                                 // directions share one region (one flag clear per API call, kernels.h gemm3_clear_flags)
+    float *Wcat, *WcatT, *colp, *sig, *rsig, *dY, *dP, *cc, *dWcat;
     double *slab, *slab_da, *datt;
 };
 static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, FwdScratch* s) {
     Carver c(base);
     FwdScratch t;
+    t.gws = c.take<char>(gemm3_workspace_bytes());
     t.Wcat = c.take<float>(d.wslab);
+    t.WcatT = c.take<float>(d.wslab);
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
     t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
@@ -583,7 +599,9 @@ static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, Fw
 static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, BwdScratch* s) {
     Carver c(base);
     BwdScratch t;
+    t.gws = c.take<char>(gemm3_workspace_bytes());
     t.Wcat = c.take<float>(d.wslab);
+    t.WcatT = c.take<float>(d.wslab);
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
     t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
@@ -659,6 +677,10 @@ extern "C" size_t eagcn_layer_bwd_scratch_bytes(const eagcn_batch* b, const eagc
 
 extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                                    void* stream) {
+    if (w && w->scratch && w->scratch_bytes >= gemm3_workspace_bytes()) {
+        int rc = gemm3_clear_flags(w->scratch, w->scratch_bytes, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     return layer_forward_impl(b, p, w, stream, false);
 }
 
@@ -682,7 +704,7 @@ int eagcn::pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const
         }
         jobs[l].pp = param_ptrs(b, ps[ll]); jobs[l].vc = d.vc; jobs[l].in = make_colmap(&ps[ll]->in);
         jobs[l].ld_in = d.ld_in; jobs[l].fp = d.fp;
-        jobs[l].Wcat = pk.Wcat; jobs[l].colp = pk.colp; jobs[l].sig = pk.sig; jobs[l].rsig = pk.rsig;
+        jobs[l].Wcat = pk.Wcat; jobs[l].WcatT = pk.WcatT; jobs[l].colp = pk.colp; jobs[l].sig = pk.sig; jobs[l].rsig = pk.rsig;
         if (l < n) wmax = std::max(wmax, d.wslab);
     }
     PackJobs pj{jobs[0], jobs[1], jobs[2], jobs[3]};
@@ -715,12 +737,12 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
             set_error("eagcn_layer_forward: packed buffer too small (%zu < %zu)", w->packed_bytes, pneed);
             return EAGCN_ERR_SCRATCH;
         }
-        sc.Wcat = pk.Wcat; sc.colp = pk.colp; sc.sig = pk.sig; sc.rsig = pk.rsig;
+        sc.Wcat = pk.Wcat; sc.WcatT = pk.WcatT; sc.colp = pk.colp; sc.sig = pk.sig; sc.rsig = pk.rsig;
     }
     EAGCN_CHECK_ARG(!prepacked || w->packed, "eagcn_layer_forward: prepacked parameters need the packed block");
     if (!prepacked) {
         ProfScope ps(PROF_PACK, s);
-        pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.colp, sc.sig, sc.rsig);
+        pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.WcatT, sc.colp, sc.sig, sc.rsig);
     }
     EAGCN_LAUNCH_CHECK();
     // algorithmic flops of the flat transform: exact widths, packed rows
@@ -729,9 +751,17 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
     const double gemm_work = 2.0 * (double)b->T * (double)d.fin * fsum;
     int nslab = 0;
     if (b->T > 0) {
-        GemmDesc g{0, 0, b->T, d.fp, d.ld_in, w->x, d.ld_in, sc.Wcat, d.fp, w->P, d.fp, 1, 0, gemm_work};
-        g.M_dev = b->meta + EAGCN_META_T;
-        rc = launch_gemm(g, s);
+        // P = X.[W_1|..|W_K]: NT form on the pre-transposed weight (wave-autonomous balanced kernel, gemm3.hip); operands
+        // that are not 16-byte aligned fall back to the workgroup-tiled kernel
+        GemmDesc g3{0, 1, b->T, d.fp, d.ld_in, w->x, d.ld_in, sc.WcatT, d.ld_in, w->P, d.fp, 1, 0, gemm_work};
+        g3.M_dev = b->meta + EAGCN_META_T;
+        if (gemm3_layer(d.ld_in) && gemm3_ok(g3)) {
+            rc = launch_gemm3(g3, nullptr, sc.gws, gemm3_workspace_bytes(), s);
+        } else {
+            GemmDesc g{0, 0, b->T, d.fp, d.ld_in, w->x, d.ld_in, sc.Wcat, d.fp, w->P, d.fp, 1, 0, gemm_work};
+            g.M_dev = b->meta + EAGCN_META_T;
+            rc = launch_gemm(g, s);
+        }
         if (rc) return rc;
         AggArgs a;
         a.bt = *b; a.vc = d.vc; a.src = w->P; a.lds = d.fp; a.dst = w->Y; a.ldd = d.fp;
@@ -765,6 +795,10 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
 extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                                     const float* dxout, const float* dpad_row, float* dx,
                                     const eagcn_layer_grads* g, void* stream) {
+    if (w && w->scratch && w->scratch_bytes >= gemm3_workspace_bytes()) {
+        int rc = gemm3_clear_flags(w->scratch, w->scratch_bytes, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     return layer_backward_impl(b, p, w, dxout, nullptr, dpad_row, dx, g, stream);
 }
 
@@ -802,10 +836,10 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             set_error("eagcn_layer_backward: packed buffer too small (%zu < %zu)", w->packed_bytes, pneed);
             return EAGCN_ERR_SCRATCH;
         }
-        sc.Wcat = pk.Wcat; sc.colp = pk.colp; sc.sig = pk.sig; sc.rsig = pk.rsig;
+        sc.Wcat = pk.Wcat; sc.WcatT = pk.WcatT; sc.colp = pk.colp; sc.sig = pk.sig; sc.rsig = pk.rsig;
     } else {
         ProfScope ps(PROF_PACK, s);
-        pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.colp, sc.sig, sc.rsig);
+        pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.WcatT, sc.colp, sc.sig, sc.rsig);
     }
     EAGCN_LAUNCH_CHECK();
     double fsum = 0.0;
@@ -873,7 +907,17 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         GemmDesc gx{0, 1, b->T, d.ld_in, d.fp, sc.dP, d.fp, sc.Wcat, d.fp, dx, d.ld_in, 1, 0, gemm_work};
         gx.M_dev = b->meta + EAGCN_META_T;
         static const bool pair = [] { const char* v = getenv("EAGCN_NO_PAIR"); return !(v && v[0] == '1'); }();
-        if (dx && !forked && colaunch && pair) {
+        static const bool use3 = [] { const char* v = getenv("EAGCN_NO_GEMM3"); return !(v && v[0] == '1'); }();
+        DwScatter dsc;
+        for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) dsc.dW[k] = gp.dW[k];
+        dsc.vc = d.vc;
+        dsc.in = in;
+        if (use3 && !forked && dx && gemm3_layer(d.ld_in) && gemm3_ok(gw) && gemm3_ok(gx)) {
+            // wave-autonomous balanced kernel: dX and dW in one launch, dW written straight into the per-view gradients
+            rc = launch_gemm3_pair(gx, gw, &dsc, sc.gws, gemm3_workspace_bytes(), s);
+            if (rc) return rc;
+            nsplit = 0;                                   // no partial slabs: unpack_grads only reduces the edge partials
+        } else if (dx && !forked && colaunch && pair) {
             rc = launch_gemm_pair(gx, gw, s);                                    // dX and dW share one grid
             if (rc) return rc;
         } else {
@@ -883,7 +927,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         }
     }
     {
-        const int wblocks = cdiv((int)d.wslab, 256);
+        const int wblocks = nsplit > 0 ? cdiv((int)d.wslab, 256) : 0;
         ProfScope psu(PROF_PACK, side);
         unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, side>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
                                                                                     nsplit, d.wslab, sc.datt, nedge, sc.rsig,

@@ -71,10 +71,13 @@ class GraphRunner:
     """One captured (forward, backward) pair for a fixed (model plan, B, N, channels); with ``training=False``
     a forward-only graph of the eval-mode model (running BatchNorm statistics, no dropout, no backward)."""
 
-    def __init__(self, plan, B, N, channels, device, dropout, row_cap=None, training=True):
+    def __init__(self, plan, B, N, channels, device, dropout, row_cap=None, training=True, static_outputs=False,
+                 validate='sync'):
         lib = L.load()
         self.plan, self.device = plan, device
         self.training = bool(training)
+        self.static_outputs = bool(static_outputs)
+        self.validate = validate
         self.key = (B, N, tuple(channels))
         self.slots = [StaticIndex(B, N, channels, device, row_cap if row_cap else B * N) for _ in range(2)]
         self.index = self.slots[0]
@@ -118,6 +121,20 @@ class GraphRunner:
         self._xout_views = [sv[xo.value:xo.value + 4 * T * ld.value].view(torch.float32).view(T, ld.value) for sv in self.saved]
         self._pad_views = [sv[po.value:po.value + 4 * ld.value].view(torch.float32) for sv in self.saved]
         self.ptrs = [t.data_ptr() for t in plan._ptr_tensors]
+
+    def nbytes(self):
+        """Device memory this runner holds (two index slots, two saved-activation blocks, scratch, gradients)."""
+        n = sum(sv.numel() for sv in self.saved) + self.scratch.numel() + 4 * self.flat_acc.numel()
+        for sl in self.slots:
+            n += sl.code.numel() + 4 * (sl._blob.numel() + sl._rows.numel())
+        return n
+
+    def release(self):
+        """Drop the captured graphs and every static buffer (eviction from EAGCN._runners)."""
+        torch.cuda.synchronize(self.device)
+        self.graphs = [[None, None], [None, None]]
+        self.saved, self.scratch, self.slots, self.index = [], None, [], None
+        self._xout_views, self._pad_views = [], []
 
     @property
     def xout_view(self):
@@ -210,9 +227,9 @@ class GraphRunner:
             if meta[L.META_BAD_REL]:
                 raise L.EagcnHipError('a previous batch held %d bonds whose relation channels are not one-hot'
                                       % meta[L.META_BAD_REL])
-            if meta[L.META_T] > self.index.T:
-                raise L.EagcnHipError('a previous batch packed %d rows, more than row_cap=%d'
-                                      % (meta[L.META_T], self.index.T))
+            if meta[L.META_OVERFLOW]:
+                raise L.EagcnHipError('a previous batch packed %d rows, more than row_cap=%d (it was processed as an '
+                                      'empty batch; no memory was overwritten)' % (meta[L.META_OVERFLOW], self.slots[0].T))
 
     def forward(self, adj, rels, afm, size, seed, overlap=False, bonds=None):
         lib = L.load()
@@ -270,6 +287,24 @@ class GraphRunner:
         ev = torch.cuda.Event()           # meta_host[slot] is valid and seeds_host[slot] is free again after this point
         ev.record(side)
         self.meta_event[slot] = ev
+        if self.validate == 'sync':
+            # wait for THIS batch's index kernels (they only depend on the slot's previous user, not on the main
+            # stream's backlog) and raise on invalid input / row_cap overflow before anything consumes the index
+            ev.synchronize()
+            meta = self.meta_host[slot].tolist()
+            self.meta_event[slot] = None
+            bad = None
+            if meta[L.META_BAD_ADJ]:
+                bad = ('%d bonds are out of range or self-loops' if bonds is not None else
+                       'adjs holds %d entries outside {0,1}') % meta[L.META_BAD_ADJ]
+            elif meta[L.META_BAD_REL]:
+                bad = '%d bonded (i,j,view) positions are not one-hot over the relation channels' % meta[L.META_BAD_REL]
+            elif meta[L.META_OVERFLOW]:
+                bad = 'the batch packs %d rows, more than row_cap=%d' % (meta[L.META_OVERFLOW], idx.T)
+            if bad:
+                if overlap:
+                    main.wait_stream(side)
+                raise L.EagcnHipError(bad)
         if overlap:
             done = torch.cuda.Event()
             done.record(side)
@@ -287,6 +322,14 @@ class GraphRunner:
             self.fwd_done = torch.cuda.Event()
             self.fwd_done.record(main)
         return self.generation
+
+    def outputs(self):
+        """(out, graph_representation) of the last forward.  By default fresh tensors, as the reference returns
+        (code that collects predictions / embeddings over several batches, train.py:279-285, keeps working);
+        with static_outputs=True views of the static buffers that the next forward of this shape overwrites."""
+        if self.static_outputs:
+            return self.out.detach(), self.graph_rep.detach()
+        return self.out.clone(), self.graph_rep.clone()
 
     def backward(self, dout, dgr, generation):
         if generation != self.generation:
@@ -329,9 +372,11 @@ class _GraphFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, adj, rels, afm, size, seed, overlap, trigger, bonds=None):
         ctx.set_materialize_grads(False)
+        if ctx.needs_input_grad[3]:
+            raise L.EagcnHipError('graph mode does not produce d/d(afms); use EAGCN.forward_composed for input gradients')
         ctx.runner = runner
         ctx.generation = runner.forward(adj, rels, afm, size, seed, overlap, bonds)
-        return runner.out.detach(), runner.graph_rep.detach()
+        return runner.outputs()
 
     @staticmethod
     def backward(ctx, dout, dgr):
@@ -344,7 +389,7 @@ class _GraphFn(torch.autograd.Function):
 def graph_forward(runner, adj, rels, afm, size, seed, overlap=False, bonds=None):
     if not runner.training:               # eval: forward-only graph, nothing to differentiate
         runner.forward(adj, rels, afm, size, seed, overlap, bonds)
-        return runner.out.detach(), runner.graph_rep.detach()
+        return runner.outputs()
     plan = runner.plan
     if plan.trigger is None or plan.trigger.device != afm.device:
         plan.trigger = torch.zeros((), dtype=torch.float32, device=afm.device, requires_grad=True)

@@ -129,6 +129,12 @@ class GraphConv_Layer(nn.Module):
         self.self_r = Parameter(torch.empty(1).uniform_(-0.01, 0.01))
         self._specs = {}
 
+    def __getstate__(self):                 # cached LayerSpec objects hold ctypes structs: rebuilt on demand
+        state = super().__getstate__() if hasattr(nn.Module, '__getstate__') else self.__dict__.copy()
+        state = dict(state)
+        state['_specs'] = {}
+        return state
+
     # -- packed (internal) path ------------------------------------------------------------------
     def blocks(self):
         return [getattr(self, 'block%d' % (k + 1)) for k in range(self.K)]

@@ -17,7 +17,16 @@ that fix ``structure``.  Keyword-only extensions (defaults = reference behaviour
                 per captured pair (a new pair is captured for every new shape), delivers gradients
                 as in grad_mode='direct', keeps ONE training forward in flight, and the lazy atom
                 representations are valid until the next forward.  ``row_cap`` bounds the packed rows
-                the static buffers are sized for (default B*N).
+                the static buffers are sized for (default B*N).  Every distinct (B, N, training) shape owns a
+                runner (two index slots, two saved-activation blocks, scratch: see GraphRunner.nbytes());
+                at most ``max_runners`` (default 8) are kept, least recently used evicted first.
+  graph_outputs 'copy' (default): graph mode returns fresh tensors like the reference does; 'static': it
+                returns views of the runner's static output buffers, which the NEXT forward of the same shape
+                overwrites (saves two small copies per step; for loops that consume the outputs at once).
+  validate      'sync' (default): graph mode waits for the batch-index kernels of the batch it was given and
+                raises on a non-binary adjacency / non-one-hot relation tensor / row_cap overflow BEFORE
+                the forward runs; 'deferred': no host wait at all, the same errors are raised when a later
+                batch is submitted (one or two steps late) -- for input pipelines that are known to be valid.
   overlap_index False (default) | True: declare that the batch tensors are already resident in HBM when
                 forward is called (prefetched batches); the batch index then runs on a side stream
                 without waiting for the previous step's queued work (see ops.BatchIndex).
@@ -68,7 +77,8 @@ class EAGCN(nn.Module):
                  n_sgc1_5=None, n_sgc2_1=None, n_sgc2_2=None, n_sgc2_3=None, n_sgc2_4=None, n_sgc2_5=None,
                  n_den1=128, n_den2=64, nclass=1, dropout=0.0, structure='Concate', molfp_mode='sum',
                  pool_num=5, *, n_layers=4, widths1=None, widths2=None, rel_channels=None, atom_rep='lazy',
-                 grad_mode='autograd', overlap_index=False, graph=False, row_cap=None):
+                 grad_mode='autograd', overlap_index=False, graph=False, row_cap=None, graph_outputs='copy',
+                 validate='sync', max_runners=8):
         super().__init__()
         if widths1 is None:
             widths1 = [n_sgc1_1, n_sgc1_2, n_sgc1_3, n_sgc1_4, n_sgc1_5]
@@ -110,6 +120,11 @@ class EAGCN(nn.Module):
         self.grad_mode = grad_mode
         self.overlap_index = bool(overlap_index)
         self.graph, self.row_cap = bool(graph), row_cap
+        if graph_outputs not in ('copy', 'static'):
+            raise ValueError("graph_outputs must be 'copy' or 'static'")
+        if validate not in ('sync', 'deferred'):
+            raise ValueError("validate must be 'sync' or 'deferred'")
+        self.graph_outputs, self.validate, self.max_runners = graph_outputs, validate, int(max_runners)
         self._runners = {}
         self.den1 = Dense(f_last, n_den1)
         self.den2 = Dense(n_den1, n_den2)
@@ -137,6 +152,26 @@ class EAGCN(nn.Module):
             head = {n: getattr(self, n) for n in ('den1', 'den2', 'den3', 'Graph_BN', 'bn_den1', 'bn_den2')}
             self._plan = ops.ModelPlan(self.graph_layers(), head, self.n_afeat, self.molfp_mode, self.dropout)
         return self._plan
+
+    # The plan and the graph runners hold ctypes structs with device pointers, captured HIP graphs and static
+    # buffers: none of that can (or should) travel with a pickled / deep-copied module -- the reference pickles
+    # the whole model at every best-validation checkpoint (train.py:440, torch.save(model, ...)).  They are
+    # dropped here and rebuilt lazily by the first forward of the copy.
+    def __getstate__(self):
+        if self._plan is not None:
+            self._plan.flush_nbt()
+        state = super().__getstate__() if hasattr(nn.Module, '__getstate__') else self.__dict__.copy()
+        state = dict(state)
+        state['_plan'] = None
+        state['_runners'] = {}
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._plan = None
+        self._runners = {}
+        for name, default in (('graph_outputs', 'copy'), ('validate', 'sync'), ('max_runners', 8)):
+            self.__dict__.setdefault(name, default)
 
     def state_dict(self, *a, **kw):
         if self._plan is not None:
@@ -178,10 +213,14 @@ class EAGCN(nn.Module):
             btuple = bonds.checked()
         plan = self.plan()
         key = (B, N, channels, float(self.dropout), self.training)
-        runner = self._runners.get(key)
+        runner = self._runners.pop(key, None)
         if runner is None or runner.stale():
-            runner = G.GraphRunner(plan, B, N, channels, afms.device, self.dropout, self.row_cap, training=self.training)
-            self._runners[key] = runner
+            while len(self._runners) >= max(1, self.max_runners):       # least recently used first (dict order)
+                old = self._runners.pop(next(iter(self._runners)))
+                old.release()
+            runner = G.GraphRunner(plan, B, N, channels, afms.device, self.dropout, self.row_cap, training=self.training,
+                                   static_outputs=(self.graph_outputs == 'static'), validate=self.validate)
+        self._runners[key] = runner                                      # (re-)inserted last = most recently used
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (self.dropout > 0 and self.training) else 0
         if self.molfp_mode == 'ave':
             size = size.to(device=afms.device, dtype=torch.int64)

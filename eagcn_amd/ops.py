@@ -627,6 +627,9 @@ class _ModelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, index, holder, training, seed, dropout, size, afm, trigger, *params):
         lib = L.load()
+        if ctx.needs_input_grad[7]:
+            raise L.EagcnHipError('the model-level engine does not produce d/d(afms) (the reference training loop never '
+                                  'asks for it); use EAGCN.forward_composed, whose layer-level ops return it')
         afm = _need_cuda_f32(afm, 'afms')
         ctx.direct = trigger is not None
         if ctx.direct:

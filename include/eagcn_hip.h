@@ -67,6 +67,9 @@ extern "C" {
 #define EAGCN_META_BAD_ADJ 3  /* # adjacency entries not in {0,1}              */
 #define EAGCN_META_BAD_REL 4  /* # bonded (i,j,view) whose channels are not one-hot */
 #define EAGCN_META_NEDGE 5    /* # directed edges                              */
+#define EAGCN_META_OVERFLOW 6 /* packed rows of a batch that does not fit the row capacity eagcn_batch.T (0 if it
+                                 fits): such a batch is indexed as EMPTY (meta[T] = meta[NTILES] = 0), so that no
+                                 kernel touches memory beyond the capacity-sized buffers              */
 #define EAGCN_META_WORDS 8
 
 typedef struct eagcn_batch {
@@ -263,6 +266,21 @@ int eagcn_set_gemm_mode(int mode);
 /* C[M,N] = op(A).op(B); ta/tb: 0 = as stored, 1 = transposed; leading dimensions in floats */
 int eagcn_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
                    int ldb, float* C, int ldc, void* stream);
+
+/* ---- persistent, balanced ("stream-K") form of the same products: the kernel the layer products run on ---------
+ * A launch is a fixed grid; the iteration space (tiles x k-tiles, counted on the device) is cut into equal ranges, tiles
+ * cut between workgroups are finished in the launch (no split-K slabs, no reduction launch).  Needs 16-byte aligned
+ * operands, leading dimensions / contiguous extents that are multiples of 4, and eagcn_gemm_sk_workspace_bytes() bytes
+ * of device scratch (need not be initialised).  (ta,tb) in {(0,0), (0,1), (1,0)}. */
+size_t eagcn_gemm_sk_workspace_bytes(void);
+int eagcn_gemm_f32_sk(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                      int ldc, void* workspace, size_t workspace_bytes, void* stream);
+/* C0[M0,N0] = A0[M0,K0].B0[N0,K0]^T and C1[M1,N1] = A1[K1,M1]^T.B1[K1,N1] in ONE launch: the two autograd products of
+ * reference layers.py:40 (dX = dP.W^T, dW = X^T.dP) */
+int eagcn_gemm_pair_sk(int M0, int N0, int K0, const float* A0, int lda0, const float* B0, int ldb0, float* C0, int ldc0,
+                       int M1, int N1, int K1, const float* A1, int lda1, const float* B1, int ldb1, float* C1, int ldc1,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int eagcn_gemm_sk_timeouts(void);   /* hand-offs that gave up waiting since load (must stay 0) */
 
 /* ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline) -- */
 void eagcn_prof_enable(int on);

@@ -675,61 +675,94 @@ FULL_WIDTH_CASES = {
 }
 
 
+def _relu_flips(hip, ref64, cpu):
+    """Number of activations that are zero on one side and positive on the other (HIP forward vs the fp64 oracle).
+    relu is not differentiable at 0: a pre-activation that sits within fp32 rounding of the boundary (|h| ~ 1e-7 of
+    the layer's scale) may land on either side in ANY fp32 evaluation, and the gradients of that view then differ by
+    the whole contribution of that element (O(1/rows), observed 1e-3 relative at 330 rows) -- such an instance says
+    nothing about the kernels' gradients."""
+    import copy
+    from eagcn_amd import ops
+    probe = copy.deepcopy(hip)
+    dev = _dev(cpu)
+    with torch.no_grad():
+        index = ops.BatchIndex(dev[0], dev[2:-1])
+        pad_struct = hip.structure == 'Weighted_sum'
+        outs_h = [ops.unpack_rows(index, lay, x, pad if pad_struct else None).cpu()
+                  for x, pad, lay in probe.forward_layers(index, dev[1])]
+        inp = [t.double() if t.is_floating_point() else t for t in cpu]
+        outs_r = ref64.layer_outputs(inp[0], inp[1], *inp[2:-1])
+    return sum(int(((h > 0) != (r > 0)).sum()) for h, r in zip(outs_h, outs_r))
+
+
 @pytest.mark.parametrize('graph', [False, True])
 @pytest.mark.parametrize('name', sorted(FULL_WIDTH_CASES))
 def test_model_vs_oracle_baseline_widths(name, graph):
     """Every BASELINE.json config at its own widths, view count and padding (small B so the CPU oracle takes
-    seconds), eager engine and graph replay.  Outputs to 1e-5; every parameter gradient either within 1e-5 of the
-    fp32 oracle (relative to the tensor's own largest entry) or -- where fp32 itself is not that reproducible -- at
-    most 2x as far from the fp64 oracle as the fp32 oracle is."""
+    seconds), eager engine and graph replay.  Outputs and BatchNorm buffers to 1e-5; every parameter gradient either
+    within 1e-5 of the fp32 oracle (relative to the tensor's own largest entry) or -- where fp32 itself is not that
+    reproducible -- at most 2x as far from the fp64 oracle as the fp32 oracle is.  Instances with an activation on the
+    relu boundary (see _relu_flips) are compared in their outputs only and the next seed is taken for the gradients."""
     from eagcn_amd import EAGCN
     from eagcn_amd.synthetic import make_batch
     from oracle.eagcn_ref import RefEAGCN, weights_init_
     c = FULL_WIDTH_CASES[name]
-    torch.manual_seed(17)
-    mb = make_batch(B=c['B'], n_max=c['n_max'], n_med=c['n_med'], rel_channels=c['chans'], seed=23,
-                    all_full=c['all_full'])
     kw = dict(structure=c['structure'], n_layers=c['n_layers'], rel_channels=c['chans'])
-    ref = RefEAGCN(c['chans'][0], 24, c['w1'], c['w2'], c['dens'][0], c['dens'][1], c['nclass'], 0.0, **kw)
-    weights_init_(ref)
-    ref64 = RefEAGCN(c['chans'][0], 24, c['w1'], c['w2'], c['dens'][0], c['dens'][1], c['nclass'], 0.0, **kw).double()
-    ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
-    hip = EAGCN(c['chans'][0], 24, n_den1=c['dens'][0], n_den2=c['dens'][1], nclass=c['nclass'], dropout=0.0,
-                widths1=c['w1'], widths2=c['w2'], grad_mode='direct', graph=graph, **kw).cuda().train()
-    hip.load_state_dict(ref.state_dict(), strict=True)
-    cpu = mb.dense()
-    gsel = torch.randn(c['B'], c['nclass'])
-    res = []
-    for m, inp in ((ref, cpu), (ref64, [t.double() if t.is_floating_point() else t for t in cpu])):
-        out, _, gr = m(*inp)
-        ((out * gsel.to(out.dtype)).sum() + 0.1 * gr.sum()).backward()
-        res.append((out.detach(), gr.detach(), {k: p.grad for k, p in m.named_parameters() if p.grad is not None},
-                    {k: v for k, v in m.state_dict().items() if 'running' in k}))
-    (o32, g32, p32, b32), (o64, g64, p64, b64) = res
-    reps = 3 if graph else 1                      # graph mode: the first use of each of the two slots runs eagerly + captures
-    for rep in range(reps):
-        if rep:
-            hip.load_state_dict(ref.state_dict(), strict=True)      # undo the running-statistics update
-        for p in hip.parameters():
-            p.grad = None
-        out_h, _, gr_h = hip(*_dev(cpu))
-        ((out_h * gsel.cuda()).sum() + 0.1 * gr_h.sum()).backward()
-        tag = '%s/%s%d' % (name, 'graph' if graph else 'eager', rep)
-        assert rel_err(out_h.detach().cpu(), o32, tag + ' out') < TOL
-        assert rel_err(gr_h.detach().cpu(), g32, tag + ' graph_rep') < TOL
-        gh = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
-        assert set(gh) == set(p32)
-        scale = max(v.abs().max().item() for v in p32.values())
-        for k in gh:
-            try:
-                assert_grad_close(gh[k], p32[k], scale, '%s %s' % (tag, k), rtol=1e-5, floor=1e-6)
-            except AssertionError:
-                e_ref = (p32[k].double() - p64[k]).abs().max().item()
-                e_hip = (gh[k].double().cpu() - p64[k]).abs().max().item()
-                assert e_hip <= 2.0 * e_ref + 1e-6 * scale, (k, e_hip, e_ref, scale)
-        sd = hip.state_dict()
-        for k, v in b32.items():
-            assert rel_err(sd[k].cpu(), v, tag + ' ' + k) < TOL, k
+    tried = []
+    for seed in (23, 24, 25, 26):
+        torch.manual_seed(seed)
+        mb = make_batch(B=c['B'], n_max=c['n_max'], n_med=c['n_med'], rel_channels=c['chans'], seed=seed,
+                        all_full=c['all_full'])
+        ref = RefEAGCN(c['chans'][0], 24, c['w1'], c['w2'], c['dens'][0], c['dens'][1], c['nclass'], 0.0, **kw)
+        weights_init_(ref)
+        ref64 = RefEAGCN(c['chans'][0], 24, c['w1'], c['w2'], c['dens'][0], c['dens'][1], c['nclass'], 0.0, **kw).double()
+        ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+        hip = EAGCN(c['chans'][0], 24, n_den1=c['dens'][0], n_den2=c['dens'][1], nclass=c['nclass'], dropout=0.0,
+                    widths1=c['w1'], widths2=c['w2'], grad_mode='direct', graph=graph, **kw).cuda().train()
+        hip.load_state_dict(ref.state_dict(), strict=True)
+        cpu = mb.dense()
+        flips = _relu_flips(hip, ref64, cpu)
+        tried.append((seed, flips))
+        gsel = torch.randn(c['B'], c['nclass'])
+        res = []
+        for m, inp in ((ref, cpu), (ref64, [t.double() if t.is_floating_point() else t for t in cpu])):
+            out, _, gr = m(*inp)
+            ((out * gsel.to(out.dtype)).sum() + 0.1 * gr.sum()).backward()
+            res.append((out.detach(), gr.detach(), {k: p.grad for k, p in m.named_parameters() if p.grad is not None},
+                        {k: v for k, v in m.state_dict().items() if 'running' in k}))
+        (o32, g32, p32, b32), (o64, g64, p64, b64) = res
+        reps = 3 if graph else 1                  # graph mode: the first use of each of the two slots runs eagerly + captures
+        for rep in range(reps):
+            if rep:
+                hip.load_state_dict(ref.state_dict(), strict=True)      # undo the running-statistics update
+            for p in hip.parameters():
+                p.grad = None
+            out_h, _, gr_h = hip(*_dev(cpu))
+            ((out_h * gsel.cuda()).sum() + 0.1 * gr_h.sum()).backward()
+            tag = '%s/%s%d' % (name, 'graph' if graph else 'eager', rep)
+            assert rel_err(out_h.detach().cpu(), o32, tag + ' out') < TOL
+            assert rel_err(gr_h.detach().cpu(), g32, tag + ' graph_rep') < TOL
+            sd = hip.state_dict()
+            for k, v in b32.items():
+                # absolute floor: bn_den1.running_mean is analytically zero (its input is a BatchNorm output times W)
+                dd = (sd[k].double().cpu() - v.double()).abs().max().item()
+                _ = rel_err(sd[k].cpu(), v, tag + ' ' + k) if v.abs().max() > 1e-3 else 0.0
+                assert dd <= TOL * max(v.abs().max().item(), 1.0), (k, dd)
+            if flips:
+                continue
+            gh = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+            assert set(gh) == set(p32)
+            scale = max(v.abs().max().item() for v in p32.values())
+            for k in gh:
+                try:
+                    assert_grad_close(gh[k], p32[k], scale, '%s %s' % (tag, k), rtol=1e-5, floor=1e-6)
+                except AssertionError:
+                    e_ref = (p32[k].double() - p64[k]).abs().max().item()
+                    e_hip = (gh[k].double().cpu() - p64[k]).abs().max().item()
+                    assert e_hip <= 2.0 * e_ref + 1e-6 * scale, (k, e_hip, e_ref, scale)
+        if not flips:
+            return
+    raise AssertionError('every instance tried sits on a relu boundary: %s' % (tried,))
 
 
 # ---- SURVEY 8(f) rows against the reference's golden vectors (not against the package itself) ------------------------
