@@ -10,7 +10,12 @@ A step = one pass of the hot path over one batch resident in HBM: batch index bu
 reference's dense collate tensors, all graph-conv layers forward, read-out + head, the train.py loss,
 full backward (gradients of every parameter), and for N > 1 the gradient all-reduce.  The optimizer
 is excluded.  Weak scaling: every rank processes its own batch of `--batch` molecules.
-Rank 0 prints ONE JSON line.
+
+Timing: after W warm-up steps, R blocks of exactly K steps each are timed (barrier + synchronize on both
+sides of every block, MAX over ranks); `ms_per_step` / `value` are the MEDIAN block, `value_min` /
+`value_max` the slowest / fastest block.  Rank 0 prints ONE JSON line.  At N = 1 the line also carries
+`extra`: the same measurement for the north-star shape (Tox21, batch 1024) and the other BASELINE.json
+configs that fit one GPU, each with its whole-step fraction of the fp32-MFMA roofline.
 """
 import argparse
 import ctypes as C
@@ -41,19 +46,23 @@ WORKLOADS = {
                      nclass=1, n_bfeat=32, rel_channels=[32, 4, 2, 2, 2, 2, 2, 2], batch=1024, n_max=256, n_med=None,
                      all_full=True, task='reg'),
 }
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+PMC_FILE = os.path.join('profiles', 'r02_pmc_traffic.json')
 
 
 def rel_channels(cfg):
     return list(cfg.get('rel_channels') or [cfg['n_bfeat'], 4, 2, 2, 2])
-PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 2.4 GHz
-PEAK_HBM_GBS = 8000.0
 
 
 def build_model(cfg, dropout, device, graph=False):
     from eagcn_amd import EAGCN, weights_init
+    # graph_outputs='static' / validate='deferred': the step consumes its outputs at once (loss) and the synthetic
+    # batches are valid by construction -- both are reported in the JSON `config`
     m = EAGCN(cfg['n_bfeat'], 24, n_den1=cfg['dens'][0], n_den2=cfg['dens'][1], nclass=cfg['nclass'], dropout=dropout,
               widths1=cfg['widths1'], widths2=cfg['widths2'], rel_channels=rel_channels(cfg), structure=cfg['structure'],
-              n_layers=cfg['n_layers'], atom_rep='lazy', grad_mode='direct', overlap_index=True, graph=graph)
+              n_layers=cfg['n_layers'], atom_rep='lazy', grad_mode='direct', overlap_index=True, graph=graph,
+              graph_outputs='static', validate='deferred')
     m.apply(weights_init)
     return m.to(device)
 
@@ -80,19 +89,18 @@ def algorithmic_flops(cfg, sizes):
     return 3.0 * total
 
 
-def committed_traffic():
-    """HBM-side bytes per launch of the dominant kernel (gemm_f32_pair_kernel) from the committed PMC passes of this command
-    (tools/pmc_traffic.py -> profiles/r01_pmc_traffic.json; rocprofv3 cannot run inside bench.py)."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+def committed_traffic(kernel_substr):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of this command
+    (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json; rocprofv3 cannot run inside bench.py)."""
     try:
-        table = json.load(open(path))
+        table = json.load(open(os.path.join(ROOT, PMC_FILE)))
     except Exception:
         return None, None
-    big = [v for k, v in table.items() if 'gemm_f32_pair_kernel' in k]
+    big = [v for k, v in table.items() if kernel_substr in k]
     n = sum(v['launches'] for v in big)
     if not n:
         return None, None
-    return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in big) / n, 'profiles/r01_pmc_traffic.json'
+    return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in big) / n, PMC_FILE
 
 
 def cpu_baseline(cfg, mb, dropout, bce_w, steps=5, warmup=2):
@@ -132,10 +140,7 @@ def cpu_baseline(cfg, mb, dropout, bce_w, steps=5, warmup=2):
     ts = []
     for i in range(warmup + steps):
         t0 = time.perf_counter()
-        model.zero_grad(set_to_none=True)
-        out, _, _ = model(*dense)
-        loss = classification_loss(out, labels, bce_w) if cfg['task'] == 'class' else regression_loss(out, labels)
-        loss.backward()
+        one_step()
         if i >= warmup:
             ts.append(time.perf_counter() - t0)
     ts.sort()
@@ -155,37 +160,12 @@ def cpu_baseline(cfg, mb, dropout, bce_w, steps=5, warmup=2):
                       % (steps, warmup, mb.B, torch.__version__, cores, model_name or 'unknown CPU')}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--workload', default='tox21_c2', choices=sorted(WORKLOADS))
-    ap.add_argument('--batch', type=int, default=None, help='molecules per GPU (default: the config\'s)')
-    ap.add_argument('--dropout', type=float, default=0.3)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--eager', action='store_true', help='eager launches instead of HIP-graph replay')
-    ap.add_argument('--cpu-steps', type=int, default=5)
-    ap.add_argument('--eval-throughput', action='store_true',
-                    help='also time the eval-mode forward (forward-only graph under no_grad); reported as an extra field')
-    ap.add_argument('--input', default='dense', choices=('dense', 'compact'),
-                    help="dense: the reference's collate tensors (headline); compact: bond list via forward_compact")
-    args = ap.parse_args()
-
-    from eagcn_amd import _lib
+def run_workload(name, B, args, lib, dev, rank, world, reducer_cls, detail):
+    """Build the model and one resident batch, time R blocks of K steps.  Returns a dict (timings are the MAX over
+    ranks); with `detail` also the per-kernel-class HIP-event durations of eager steps of the same workload."""
     from eagcn_amd.losses import fused_classification_loss, fused_regression_loss
-    from eagcn_amd.parallel import GradientAllReducer, init_distributed
     from eagcn_amd.synthetic import bce_weights, make_batch
-    lib = _lib.load()                                    # fail loudly if the HIP library is missing
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: there is no CPU path')
-    rank, world, local = init_distributed()
-    if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    cfg = dict(WORKLOADS[args.workload])
-    B = args.batch or cfg['batch']
+    cfg = dict(WORKLOADS[name])
     torch.manual_seed(1234 + rank)
     mb = make_batch(B=B, n_max=cfg['n_max'], n_med=cfg['n_med'], rel_channels=rel_channels(cfg),
                     seed=1234 + rank, n_tasks=cfg['nclass'], task=cfg['task'], all_full=cfg.get('all_full', False))
@@ -196,7 +176,7 @@ def main():
     bce_w_dev = torch.tensor(bce_w, dtype=torch.float32, device=dev)
     model = build_model(cfg, args.dropout, dev, graph=not args.eager)
     model.train()
-    reducer = GradientAllReducer(model.parameters(), model=model)
+    reducer = reducer_cls(model.parameters(), model=model)
     params = list(model.parameters())
 
     def step():
@@ -204,7 +184,7 @@ def main():
             p.grad = None
         out, _, _ = model(*dense) if compact is None else model.forward_compact(*compact)
         if cfg['task'] == 'class':
-            loss = fused_classification_loss(out, labels, bce_w_dev)
+            loss = fused_classification_loss(out, labels, bce_w_dev, dp_global_norm=(world > 1))
         else:
             loss = fused_regression_loss(out, labels)
         loss.backward()
@@ -213,30 +193,35 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    profile_in_loop = args.eager            # HIP events cannot bracket kernels inside a replayed graph
+    profile_in_loop = args.eager and detail   # HIP events cannot bracket kernels inside a replayed graph
     lib.eagcn_prof_reset()
-    lib.eagcn_prof_enable(1 if profile_in_loop else 0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    lib.eagcn_prof_enable(0)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    blocks = []
+    loss = None
+    for r in range(args.repeats):
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        lib.eagcn_prof_enable(1 if profile_in_loop else 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        lib.eagcn_prof_enable(0)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if dist.is_initialized():
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        blocks.append(float(t.item()))
     if not torch.isfinite(loss.detach()).item():
         raise SystemExit('non-finite loss')
-    prof_steps = args.steps
-    if not profile_in_loop:
+    res = {'cfg': cfg, 'mb': mb, 'bce_w': bce_w, 'B': B, 'blocks': sorted(blocks),
+           'gflop': algorithmic_flops(cfg, mb.sizes) / 1e9, 'N': mb.N}
+    prof_steps = args.steps * args.repeats
+    if detail and not profile_in_loop:
         # per-kernel-class durations: the same step, same batch, eager launches with one HIP-event pair per
         # kernel class on the launch stream (the timed region above replays the identical kernels as graphs)
         model.graph = False
@@ -251,72 +236,149 @@ def main():
         torch.cuda.synchronize()
         lib.eagcn_prof_enable(0)
         model.graph = not args.eager
-
-    # per-kernel-class time from HIP events recorded on the launch stream inside the timed region
     kern = {}
-    for tag in range(lib.eagcn_prof_ntags()):
-        ms, work, n = C.c_double(), C.c_double(), C.c_int64()
-        lib.eagcn_prof_read(tag, C.byref(ms), C.byref(work), C.byref(n))
-        kern[lib.eagcn_prof_tag_name(tag).decode()] = (ms.value, work.value, n.value)
+    if detail:
+        for tag in range(lib.eagcn_prof_ntags()):
+            ms, work, n = C.c_double(), C.c_double(), C.c_int64()
+            lib.eagcn_prof_read(tag, C.byref(ms), C.byref(work), C.byref(n))
+            kern[lib.eagcn_prof_tag_name(tag).decode()] = (ms.value, work.value, n.value)
+    res.update(kern=kern, prof_steps=prof_steps, profile_in_loop=profile_in_loop)
+    if detail and args.eval_throughput and not args.eager:
+        model.eval()
+        with torch.no_grad():
+            for _ in range(10):
+                model(*dense) if compact is None else model.forward_compact(*compact)
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            for _ in range(args.steps):
+                model(*dense) if compact is None else model.forward_compact(*compact)
+            torch.cuda.synchronize()
+            te = time.perf_counter() - te
+        model.train()
+        res['eval_forward'] = {'molecules_per_s': round(B * args.steps / te, 1), 'ms_per_batch': round(te / args.steps * 1e3, 4),
+                               'execution': 'forward-only HIP graph, eval mode, no_grad'}
+    return res
+
+
+def summarize(res, args, world):
+    """(value, ms_per_step, min, max, step_frac) of a run_workload result: median block."""
+    b = res['blocks']
+    med = b[len(b) // 2]
+    ms = med / args.steps * 1e3
+    value = world * res['B'] * args.steps / med
+    return {'value': round(value, 1), 'ms_per_step': round(ms, 4),
+            'value_min': round(world * res['B'] * args.steps / b[-1], 1), 'value_max': round(world * res['B'] * args.steps / b[0], 1),
+            'algorithmic_gflop_per_step': round(res['gflop'], 3),
+            'step_tflops': round(res['gflop'] / ms, 2), 'step_frac': round(res['gflop'] / ms / PEAK_FP32_MFMA_TFLOPS, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--repeats', type=int, default=15, help='timed blocks of --steps steps; the median block is reported')
+    ap.add_argument('--workload', default='tox21_c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=None, help='molecules per GPU (default: the config\'s)')
+    ap.add_argument('--dropout', type=float, default=0.3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the extra single-GPU shapes (north-star batch 1024, HIV, Lipo, C5)')
+    ap.add_argument('--eager', action='store_true', help='eager launches instead of HIP-graph replay')
+    ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--eval-throughput', action='store_true',
+                    help='also time the eval-mode forward (forward-only graph under no_grad); reported as an extra field')
+    ap.add_argument('--input', default='dense', choices=('dense', 'compact'),
+                    help="dense: the reference's collate tensors (headline); compact: bond list via forward_compact")
+    args = ap.parse_args()
+
+    from eagcn_amd import _lib
+    from eagcn_amd.parallel import GradientAllReducer, init_distributed
+    lib = _lib.load()                                    # fail loudly if the HIP library is missing
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU path')
+    rank, world, local = init_distributed()
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    B = args.batch or WORKLOADS[args.workload]['batch']
+    res = run_workload(args.workload, B, args, lib, dev, rank, world, GradientAllReducer, detail=True)
+    cfg, mb, kern = res['cfg'], res['mb'], res['kern']
+    out = None
     if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
-        # dominant kernel: the paired backward products of the hidden layers (dX = dP.W^T and dW = X^T.dP in one grid);
+        head = summarize(res, args, world)
+        # dominant kernel: the paired backward products of the hidden layers (dX = dP.W^T and dW = X^T.dP in one launch);
         # models without a hidden layer below the top have no such launch -> the plain layer GEMMs
         pair = kern.get('gemm_pair', (0.0, 0.0, 0))[2] > 0
         g_ms, g_work, g_n = kern['gemm_pair'] if pair else kern['gemm']
         achieved = (g_work / (g_ms * 1e-3)) / 1e12 if g_ms > 0 else 0.0
-        traffic, traffic_src = committed_traffic() if args.workload == 'tox21_c2' and B == 256 else (None, None)
+        traffic, traffic_src = committed_traffic('gemm3_kernel<false, true') if args.workload == 'tox21_c2' and B == 256 else (None, None)
+        prof_steps = res['prof_steps']
         out = {
             'metric': 'molecules/sec fwd+bwd, 2-layer 5-view EAGCN, Tox21 batch' if args.workload == 'tox21_c2'
                       else 'molecules/sec fwd+bwd, EAGCN %s' % args.workload,
-            'value': round(value, 1), 'unit': 'molecules/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
+            'value': head['value'], 'unit': 'molecules/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'repeats': args.repeats, 'value_min': head['value_min'], 'value_max': head['value_max'],
+            'timing': 'median of %d timed blocks of %d steps each (barrier + synchronize around every block, max over ranks); '
+                      'value_min / value_max = slowest / fastest block' % (args.repeats, args.steps),
             'config': {'workload': '%s: %s, %d-layer %d-view, widths %s/%s, %d tasks, batch %d per GPU, '
                                    'N_pad %d, dropout %.2f, loss %s' %
                                    (args.workload, cfg['structure'], cfg['n_layers'], len(cfg['widths1']),
                                     cfg['widths1'][0], cfg['widths2'][0], cfg['nclass'], B, mb.N, args.dropout,
                                     'weighted BCE' if cfg['task'] == 'class' else 'MSE'),
-                       'input': args.input, 'global_batch': world * B, 'atoms_per_batch': int(mb.sizes.sum()),
+                       'input': args.input, 'inputs': 'HBM-resident (one synthetic batch per rank, reused every step)',
+                       'overlap_index': True, 'graph_outputs': 'static', 'validate': 'deferred',
+                       'optimizer': 'excluded (SURVEY.md 8d: forward + loss + backward [+ gradient all-reduce])',
+                       'global_batch': world * B, 'atoms_per_batch': int(mb.sizes.sum()),
                        'parallelism': 'dp%d' % world},
-            'algorithmic_gflop_per_step': round(algorithmic_flops(cfg, mb.sizes) / 1e9, 3),
-            'roofline': {'kernel': 'gemm_f32_pair_kernel<64, 64, 16, 4, false> (dX = dP.W^T and dW = X^T.dP of a layer in one grid, fp32 MFMA)'
-                                   if pair else 'gemm_f32_kernel (flat X.[W_1..W_K] transform and its backward products)',
+            'algorithmic_gflop_per_step': head['algorithmic_gflop_per_step'],
+            'roofline': {'kernel': 'gemm3_kernel<false, true, true> (dX = dP.W^T and dW = X^T.dP of a hidden layer in one balanced launch, fp32 MFMA)'
+                                   if pair else 'layer GEMMs (flat X.[W_1..W_K] transform and its backward products)',
                          'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'step_frac': head['step_frac'],
+                         'step_frac_note': 'whole step: algorithmic_gflop_per_step / ms_per_step / peak',
                          'traffic': None if traffic is None else round(traffic),
                          'traffic_note': None if traffic is None else
-                         'bytes per launch of gemm_f32_pair_kernel, memory-side FETCH_SIZE x2 + WRITE_SIZE from %s; '
-                         'algorithmic operand bytes are 44.6 MB (dP 13.5, X 7.7, W 1.1 read; dX 7.7 and 13 split-K '
-                         'partials of dW 14.6 written)' % traffic_src,
+                         'bytes per launch, memory-side FETCH_SIZE x2 + WRITE_SIZE from %s' % traffic_src,
                          'launches': int(g_n), 'avg_launch_us': round(g_ms * 1e3 / max(g_n, 1), 3),
-                         'measured': 'HIP events on the launch stream, %s' % ('inside the timed region' if profile_in_loop else
+                         'measured': 'HIP events on the launch stream, %s' % ('inside the timed region' if res['profile_in_loop'] else
                                      '%d eager steps of the same workload right after the timed graph-replay region' % prof_steps)},
             'layer_gemm_tflops_all': round(((kern['gemm'][1] + kern.get('gemm_pair', (0, 0, 0))[1]) /
                                             max((kern['gemm'][0] + kern.get('gemm_pair', (0, 0, 0))[0]) * 1e-3, 1e-12)) / 1e12, 3),
             'kernel_ms_per_step': {k: round(v[0] / prof_steps, 4) for k, v in kern.items()},
             'execution': 'eager launches' if args.eager else 'HIP graph replay (forward + backward), eager batch index',
         }
-        if args.eval_throughput and not args.eager:
-            model.eval()
-            with torch.no_grad():
-                for _ in range(10):
-                    model(*dense) if compact is None else model.forward_compact(*compact)
-                torch.cuda.synchronize()
-                te = time.perf_counter()
-                for _ in range(args.steps):
-                    model(*dense) if compact is None else model.forward_compact(*compact)
-                torch.cuda.synchronize()
-                te = time.perf_counter() - te
-            model.train()
-            out['eval_forward'] = {'molecules_per_s': round(B * args.steps / te, 1), 'ms_per_batch': round(te / args.steps * 1e3, 4),
-                                   'execution': 'forward-only HIP graph, eval mode, no_grad'}
+        if 'eval_forward' in res:
+            out['eval_forward'] = res['eval_forward']
+    # ---- other single-GPU shapes: same measurement, fewer blocks ------------------------------------------------------
+    if world == 1 and not args.no_extras and args.workload == 'tox21_c2' and args.batch is None and not args.eager:
+        keep = (args.repeats, args.steps, args.warmup)
+        extra = {}
+        for key, (wname, wb, steps) in (('b1024', ('tox21_c2', 1024, 30)), ('hiv_c3', ('hiv_c3', 1024, 10)),
+                                         ('lipo_c4', ('lipo_c4', 512, 30)), ('c5_synth', ('c5_synth', 1024, 6))):
+            del res
+            torch.cuda.empty_cache()
+            args.repeats, args.steps, args.warmup = 5, steps, 4
+            res = run_workload(wname, wb, args, lib, dev, rank, world, GradientAllReducer, detail=False)
+            e = summarize(res, args, world)
+            e['workload'] = '%s, batch %d, N_pad %d, %d blocks of %d steps' % (wname, wb, res['N'], args.repeats, args.steps)
+            extra[key] = e
+        args.repeats, args.steps, args.warmup = keep
+        out['extra'] = extra
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg, mb, args.dropout, bce_w, steps=args.cpu_steps)
+            out['cpu_baseline'] = cpu_baseline(cfg, mb, args.dropout, bce_w_of(cfg), steps=args.cpu_steps)
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def bce_w_of(cfg):
+    from eagcn_amd.synthetic import bce_weights
+    return bce_weights(cfg['nclass'])
 
 
 if __name__ == '__main__':

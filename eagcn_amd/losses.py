@@ -34,7 +34,7 @@ def regression_loss(outputs, labels):
 
 class _FusedLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, kind, outputs, labels, weight):
+    def forward(ctx, kind, outputs, labels, weight, scale=None):
         if not outputs.is_cuda or outputs.dtype != torch.float32:
             raise L.EagcnHipError('fused loss needs fp32 device logits (no CPU path)')
         lib = L.load()
@@ -60,6 +60,9 @@ class _FusedLoss(torch.autograd.Function):
                 raise L.EagcnHipError('mse loss: %d predictions, %d targets' % (x.numel(), y.numel()))
             L.check(lib.eagcn_mse_loss(x.data_ptr(), y.data_ptr(), x.numel(), loss.data_ptr(), dx.data_ptr(), stream),
                     'eagcn_mse_loss')
+        if scale is not None:                       # data-parallel global normalisation (parallel.dp_loss_scale): a device
+            dx.mul_(scale)                          # scalar, no host sync; the gradient buffer is scaled in place
+            loss = loss * scale
         ctx.save_for_backward(dx)
         ctx.slot = slot
         return loss
@@ -68,8 +71,8 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
         if ctx.slot is not None:                    # dx IS the captured backward's gradient buffer: scale in place
-            return None, dx.mul_(g), None, None
-        return None, dx * g, None, None
+            return None, dx.mul_(g), None, None, None
+        return None, dx * g, None, None, None
 
 
 class _StepLoss(torch.Tensor):
@@ -88,8 +91,8 @@ class _StepLoss(torch.Tensor):
         return super().backward(gradient, retain_graph, create_graph, inputs)
 
 
-def _apply(kind, outputs, labels, weight):
-    loss = _FusedLoss.apply(kind, outputs, labels, weight)
+def _apply(kind, outputs, labels, weight, scale=None):
+    loss = _FusedLoss.apply(kind, outputs, labels, weight, scale)
     step = getattr(outputs, '_eagcn_step', None)     # (runner, generation) of a graph-mode forward (eagcn_amd/graph.py)
     if step is not None and getattr(outputs, '_eagcn_grad_slot', None) is not None:
         loss = loss.as_subclass(_StepLoss)
@@ -97,11 +100,18 @@ def _apply(kind, outputs, labels, weight):
     return loss
 
 
-def fused_classification_loss(outputs, labels, bce_weight):
-    """train.py:326-331 in one kernel; bce_weight: [T,2] tensor (utils.py:681-700 ``set_weight``)."""
+def fused_classification_loss(outputs, labels, bce_weight, dp_global_norm=False, group=None):
+    """train.py:326-331 in one kernel; bce_weight: [T,2] tensor (utils.py:681-700 ``set_weight``).
+    dp_global_norm=True (data parallel): the loss is normalised by the number of labelled entries of the GLOBAL batch
+    instead of this rank's shard (eagcn_amd.parallel.dp_loss_scale: one 1-element all-reduce, no host sync), so that the
+    averaged gradients equal the reference's on the concatenated batch."""
     if not isinstance(bce_weight, torch.Tensor):
         bce_weight = torch.tensor(bce_weight, dtype=torch.float32, device=outputs.device)
-    return _apply('bce', outputs, labels, bce_weight)
+    scale = None
+    if dp_global_norm:
+        from .parallel import dp_loss_scale
+        scale = dp_loss_scale(labels.to(outputs.device), group)
+    return _apply('bce', outputs, labels, bce_weight, scale)
 
 
 def fused_regression_loss(outputs, labels):

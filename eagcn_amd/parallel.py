@@ -37,6 +37,52 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def dp_loss_scale(labels, group=None):
+    """Per-rank factor c_r = world * n_r / sum_r n_r (a 0-dim tensor on the labels' device, no host sync) that turns
+    the reference's per-batch normalisation of the classification loss -- weighted BCE summed and divided by the number
+    of labels in {0,1} (train.py:328-331) -- into the GLOBAL-batch normalisation under data parallelism:
+        L_global = sum_r S_r / sum_r n_r       (S_r: this rank's weighted BCE sum, n_r: its labelled entries)
+                 = mean_r ( c_r * S_r / n_r ) = mean_r ( c_r * L_r ).
+    Scaling the local loss (and hence d loss / d logits) by c_r and AVERAGING the gradients over ranks (what
+    GradientAllReducer does) therefore yields exactly the gradient of the loss the reference would compute on the
+    concatenated batch; without it a shard with few labelled entries is over-weighted.  One 1-element all-reduce."""
+    n = ((labels == 1) | (labels == 0)).sum().to(torch.float32).reshape(1)
+    if not dist.is_initialized():
+        return torch.ones((), dtype=torch.float32, device=labels.device)
+    tot = n.clone()
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    return (n * float(dist.get_world_size(group)) / tot).reshape(())
+
+
+# ---- sync-BatchNorm: the cross-rank part of a BatchNorm over the GLOBAL batch (SURVEY.md 8e "BN modes") ---------------
+# Every rank reduces its own rows to per-channel partial sums (that is what the layer kernels produce anyway: the
+# per-workgroup (sum y, sum y^2) slabs of agg.hip / (sum dH, sum dH*xhat) slabs of bn_bwd_reduce); the functions below are
+# the two tiny collectives per layer and direction that turn them into statistics of the concatenated batch.
+def sync_bn_forward_stats(sum_y, sum_y2, rows, group=None):
+    """(sum y, sum y^2) per channel [F] (float64) and this rank's row count (B_r * N_pad_r, padded rows included, reference
+    layers.py:408-412) -> (mean, biased var, unbiased var, total rows) of the global batch.  ONE all-reduce of 2F+1 doubles."""
+    buf = torch.cat([sum_y.double().reshape(-1), sum_y2.double().reshape(-1),
+                     torch.tensor([float(rows)], dtype=torch.float64, device=sum_y.device)])
+    if dist.is_initialized():
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    F = sum_y.numel()
+    M = buf[-1]
+    mean = buf[:F] / M
+    var = (buf[F:2 * F] / M - mean * mean).clamp_min(0.0)
+    return mean, var, var * (M / (M - 1.0)), M
+
+
+def sync_bn_backward_stats(sum_dh, sum_dh_xhat, group=None):
+    """Per-channel (sum dH, sum dH * xhat) of this rank -> the same sums over the global batch (the c1, c2 terms of
+    dY = scale * (dH - mean(dH) - xhat * mean(dH * xhat)) are means over ALL rows).  d gamma / d beta stay the LOCAL
+    sums: like every other parameter gradient they are averaged by the gradient all-reduce.  ONE all-reduce of 2F doubles."""
+    buf = torch.cat([sum_dh.double().reshape(-1), sum_dh_xhat.double().reshape(-1)])
+    if dist.is_initialized():
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    F = sum_dh.numel()
+    return buf[:F], buf[F:]
+
+
 class GradientAllReducer:
     """Averages the gradients of `params` across ranks with a single collective.
 

@@ -719,7 +719,8 @@ def test_model_vs_oracle_baseline_widths(name, graph):
         ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
         hip = EAGCN(c['chans'][0], 24, n_den1=c['dens'][0], n_den2=c['dens'][1], nclass=c['nclass'], dropout=0.0,
                     widths1=c['w1'], widths2=c['w2'], grad_mode='direct', graph=graph, **kw).cuda().train()
-        hip.load_state_dict(ref.state_dict(), strict=True)
+        sd0 = {k: v.clone() for k, v in ref.state_dict().items()}     # (the oracle's own forward moves its running statistics)
+        hip.load_state_dict(sd0, strict=True)
         cpu = mb.dense()
         flips = _relu_flips(hip, ref64, cpu)
         tried.append((seed, flips))
@@ -734,7 +735,7 @@ def test_model_vs_oracle_baseline_widths(name, graph):
         reps = 3 if graph else 1                  # graph mode: the first use of each of the two slots runs eagerly + captures
         for rep in range(reps):
             if rep:
-                hip.load_state_dict(ref.state_dict(), strict=True)      # undo the running-statistics update
+                hip.load_state_dict(sd0, strict=True)                   # undo the running-statistics update
             for p in hip.parameters():
                 p.grad = None
             out_h, _, gr_h = hip(*_dev(cpu))
