@@ -200,6 +200,11 @@ class GraphRunner:
         eagerly, which also serves as the warm-up HIP needs before a capture."""
         lib = L.load()
         lib.eagcn_prof_enable(0)
+        if self.training and os.environ.get('EAGCN_NO_WARM_BWD', '0') != '1':
+            # the backward sequence has never run when the first slot is captured: launch it once eagerly (it only
+            # overwrites the gradient buffer and scratch), so that no kernel is launched for the first time inside a
+            # capture
+            self._call_backward()
         torch.cuda.synchronize(self.device)
         fwd = torch.cuda.CUDAGraph()
         # thread_local: other threads (e.g. the RCCL watchdog of torch.distributed) may touch the HIP API during capture
