@@ -68,7 +68,7 @@ struct DwScatter {               // epilogue of a layer's dW product: packed (in
 };
 size_t gemm3_workspace_bytes();
 // the hand-off flags must be zero when a launch starts; every launch leaves them zero again, so ONE clear at the start of
-// an API call (a memset node under capture) covers all its launches on the same workspace
+// an API call (a tiny kernel, also under capture) covers all its launches on the same workspace
 int gemm3_clear_flags(void* workspace, size_t bytes, hipStream_t s);
 bool gemm3_ok(const GemmDesc& g);
 int launch_gemm3(const GemmDesc& g, const DwScatter* sc, void* workspace, size_t bytes, hipStream_t s);

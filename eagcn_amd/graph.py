@@ -204,7 +204,9 @@ class GraphRunner:
             # the backward sequence has never run when the first slot is captured: launch it once eagerly (it only
             # overwrites the gradient buffer and scratch), so that no kernel is launched for the first time inside a
             # capture
+            keep = self.flat_acc.clone()              # (gradients of earlier backward passes may be attached to it)
             self._call_backward()
+            self.flat_acc.copy_(keep)
         torch.cuda.synchronize(self.device)
         fwd = torch.cuda.CUDAGraph()
         # thread_local: other threads (e.g. the RCCL watchdog of torch.distributed) may touch the HIP API during capture
