@@ -356,18 +356,19 @@ static int g3_prepare(void* workspace, size_t bytes, float** ws, unsigned** flag
     *flags = (unsigned*)((char*)workspace + align256(ranges * G3_SLOT * sizeof(float)));
     return EAGCN_OK;
 }
-__global__ void g3_zero_kernel(unsigned* __restrict__ p, int n) {
+__global__ void g3_zero_kernel(unsigned* __restrict__ p, int n, double* __restrict__ z, int nz) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0u;
+    if (i < nz) z[i] = 0.0;
 }
-int gemm3_clear_flags(void* workspace, size_t bytes, hipStream_t s) {
+int gemm3_clear_flags(void* workspace, size_t bytes, hipStream_t s, double* zero, int nzero) {
     float* ws; unsigned* flags;
     int rc = g3_prepare(workspace, bytes, &ws, &flags);
     if (rc) return rc;
     // a KERNEL, not hipMemsetAsync: as a memset node of a captured graph the clear was not ordered with the kernel nodes
     // around it on replay (ROCm 7.2: owners then read parked tiles of an earlier launch; tests/probe_graph_replay.py)
     const int n = gemm3_grid() * 4;
-    g3_zero_kernel<<<cdiv(n, 256), 256, 0, s>>>(flags, n);
+    g3_zero_kernel<<<cdiv(std::max(n, nzero), 256), 256, 0, s>>>(flags, n, zero, zero ? nzero : 0);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

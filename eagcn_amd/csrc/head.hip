@@ -294,6 +294,7 @@ static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m
 
 struct ModelScratch {
     float *da2, *dh2, *da1, *dh1, *dgn, *dg, *dxa, *dxb, *dpad, *gsplit, *gsplit2, *gw1, *gw2, *gw3;
+    double* hst; int n_hst;      // BatchNorm sums of the head: [f_in + n_den1 + n_den2][2], cleared at the start of each call
     void* layer; size_t layer_bytes;
 };
 static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model* m, ModelScratch* out) {
@@ -301,6 +302,8 @@ static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model*
     ModelScratch s;
     const eagcn_head_params* h = &m->head;
     const size_t B = (size_t)b->B, T = (size_t)b->T;
+    s.n_hst = 2 * (h->f_in + h->n_den1 + h->n_den2);
+    s.hst = c.take<double>((size_t)s.n_hst);
     s.da2 = c.take<float>(B * h->n_den2);
     s.dh2 = c.take<float>(B * h->n_den2);
     s.da1 = c.take<float>(B * h->n_den1);
@@ -518,7 +521,7 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "eagcn_model_forward: saved block too small");
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_forward: scratch too small");
     const eagcn_head_params* h = &m->head;
-    RC(gemm3_clear_flags(sc.layer, sc.layer_bytes, s));          // one clear for every layer product of this call
+    RC(gemm3_clear_flags(sc.layer, sc.layer_bytes, s, sc.hst, sc.n_hst));   // one clear for the whole call
     if (!m->input_packed)
         RC(eagcn_pack_rows(b, afm, layout_width(&m->layer[0].in), &m->layer[0].in, sv.x0, stream));
     const float* x = sv.x0;
@@ -544,17 +547,25 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
     RC(eagcn_readout_forward(b, LL.xout, &lay, last->structure == EAGCN_STRUCT_WEIGHTED ? LL.pad_row : nullptr,
                              size, m->molfp_mode, sv.g, F, stream));
-    Partial ph;
-    RC(rowbn_fwd(s, B, F, Partial{sv.g, 1, 0}, nullptr, nullptr, sv.gn, h->gbn_w, h->gbn_b, h->gbn_rm, h->gbn_rv, sv.bn_g,
-                 m->training, 0, 0.0f, 0, nullptr, h->bn_eps, h->bn_momentum));
-    RC(mm_partial(s, 0, 0, B, n1, F, sv.gn, F, h->den1_w, n1, sv.h1, sc.gsplit, &ph));
-    RC(rowbn_fwd(s, B, n1, ph, sv.h1, nullptr, sv.a1, h->bn1_w, h->bn1_b, h->bn1_rm, h->bn1_rv, sv.bn_1, m->training, 1,
-                 h->dropout, m->head_seed, m->head_seed_dev, h->bn_eps, h->bn_momentum));
-    RC(mm_partial(s, 0, 0, B, n2, n1, sv.a1, n1, h->den2_w, n2, sv.h2, sc.gsplit, &ph));
-    // bn_den2 also sums the partials of den2 into h2 and writes the graph_representation copy
-    RC(rowbn_fwd(s, B, n2, ph, sv.h2, graph_rep, sv.a2, h->bn2_w, h->bn2_b, h->bn2_rm, h->bn2_rv, sv.bn_2, m->training, 1,
-                 0.0f, 0, nullptr, h->bn_eps, h->bn_momentum));
-    RC(mm(s, 0, 0, B, nc, n2, sv.a2, n2, h->den3_w, nc, out, nc));
+    // head (head2.hip): every BatchNorm's sums come from the kernel that produces its input, its normalisation is
+    // applied by the product that consumes it
+    double *st_g = sc.hst, *st_1 = sc.hst + 2 * F, *st_2 = sc.hst + 2 * (F + n1);
+    RC(head_colstats(sv.g, B, F, st_g, s));
+    HeadDrop nodrop{0, 0u, 1.0f, 0, nullptr}, drop1 = nodrop;
+    {
+        int on; uint32_t thr; float inv_keep;
+        fill_drop(h->dropout, m->training, &on, &thr, &inv_keep);
+        drop1 = HeadDrop{on, thr, inv_keep, m->head_seed, m->head_seed_dev};
+    }
+    HeadFwd f1{B, F, n1, sv.g, st_g, h->gbn_w, h->gbn_b, h->gbn_rm, h->gbn_rv, sv.bn_g, h->den1_w, sv.h1, nullptr, st_1,
+               m->training, 0, h->bn_eps, h->bn_momentum, nodrop};
+    RC(head_fwd(f1, s));
+    HeadFwd f2{B, n1, n2, sv.h1, st_1, h->bn1_w, h->bn1_b, h->bn1_rm, h->bn1_rv, sv.bn_1, h->den2_w, sv.h2, graph_rep, st_2,
+               m->training, 1, h->bn_eps, h->bn_momentum, drop1};
+    RC(head_fwd(f2, s));
+    HeadFwd f3{B, n2, nc, sv.h2, st_2, h->bn2_w, h->bn2_b, h->bn2_rm, h->bn2_rv, sv.bn_2, h->den3_w, out, nullptr, nullptr,
+               m->training, 1, h->bn_eps, h->bn_momentum, nodrop};
+    RC(head_fwd(f3, s));
     return EAGCN_OK;
 }
 
@@ -573,37 +584,32 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_backward: scratch too small");
     const eagcn_head_params* h = &m->head;
     const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
-    RC(gemm3_clear_flags(sc.layer, sc.layer_bytes, s));          // one clear for every layer product of this call
+    RC(gemm3_clear_flags(sc.layer, sc.layer_bytes, s, sc.hst, sc.n_hst));   // one clear for the whole call
     hipStream_t side = m->aux_stream ? (hipStream_t)m->aux_stream : s;
     const bool forked = side != s;
-    Partial pd;
-    // den3 -> bn_den2 -> den2 -> bn_den1 -> den1 -> Graph_BN: the dX chain
-    RC(mm(s, 0, 1, B, n2, nc, dout, nc, h->den3_w, nc, sc.da2, n2));
-    RC(rowbn_bwd(s, B, n2, Partial{sc.da2, 1, 0}, sv.h2, sv.bn_2, dgraph_rep, sc.dh2, hg->d_bn2_w, hg->d_bn2_b, m->training,
-                 1, 0.0f, 0, nullptr));
-    RC(mm_partial(s, 0, 1, B, n1, n2, sc.dh2, n2, h->den2_w, n2, sc.da1, sc.gsplit2, &pd));
-    RC(rowbn_bwd(s, B, n1, pd, sv.h1, sv.bn_1, nullptr, sc.dh1, hg->d_bn1_w, hg->d_bn1_b, m->training, 1, h->dropout,
-                 m->head_seed, m->head_seed_dev));
-    // the three weight gradients need dout, dh2, dh1: one grouped launch, off the dX critical path
-    if (forked) RC(stream_after(side, s));
+    // head backward (head2.hip): den3 -> bn_den2 -> den2 -> bn_den1 -> den1 -> Graph_BN, one launch per dense layer
+    // (d input + d weight), each BatchNorm's backward sums taken by the launch in front of it
+    double *sb_g = sc.hst, *sb_1 = sc.hst + 2 * F, *sb_2 = sc.hst + 2 * (F + n1);
+    HeadDrop nodrop{0, 0u, 1.0f, 0, nullptr}, drop1 = nodrop;
     {
-        const DwProblem pr[3] = {{F, n1, sv.gn, sc.dh1, hg->d_den1_w, sc.gw1},
-                                 {n1, n2, sv.a1, sc.dh2, hg->d_den2_w, sc.gw2},
-                                 {n2, nc, sv.a2, dout, hg->d_den3_w, sc.gw3}};
-        if (forked) {
-            RC(head_dw(side, B, pr));
-            RC(mm_partial(s, 0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, sc.dgn, sc.gsplit2, &pd));
-        } else {
-            // d(Graph_BN output) = dh1 . den1_w^T rides in the same launch as the three weight gradients
-            const int splits = split_ok(0, 1, B, F, n1, n1, n1) ? head_splits(cdiv(B, 64) * cdiv(F, 64), n1) : 1;
-            GemmDesc lead{0, 1, B, F, n1, sc.dh1, n1, h->den1_w, n1, splits > 1 ? sc.gsplit2 : sc.dgn, F, splits,
-                          (size_t)B * F};
-            lead.prof_tag = PROF_HEAD;
-            pd = Partial{splits > 1 ? sc.gsplit2 : sc.dgn, splits, (size_t)B * F};
-            RC(head_dw(s, B, pr, &lead));
-        }
+        int on; uint32_t thr; float inv_keep;
+        fill_drop(h->dropout, m->training, &on, &thr, &inv_keep);
+        drop1 = HeadDrop{on, thr, inv_keep, m->head_seed, m->head_seed_dev};
     }
-    RC(rowbn_bwd(s, B, F, pd, sv.g, sv.bn_g, nullptr, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training, 0, 0.0f, 0, nullptr));
+    // dense 3: y = out (no BatchNorm behind it), input a2 = relu(bn_den2(h2))
+    HeadBwd b3{B, n2, nc, sv.h2, sv.bn_2, 1, nodrop, h->den3_w, dout, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+               sc.da2, sb_2, hg->d_den3_w, m->training};
+    RC(head_bwd(b3, s));
+    // dense 2: y = h2 followed by bn_den2 (+ the gradient that reaches graph_representation directly), input a1
+    HeadBwd b2{B, n1, n2, sv.h1, sv.bn_1, 1, drop1, h->den2_w, sc.da2, sv.h2, sv.bn_2, sb_2, dgraph_rep, hg->d_bn2_w, hg->d_bn2_b,
+               sc.da1, sb_1, hg->d_den2_w, m->training};
+    RC(head_bwd(b2, s));
+    // dense 1: y = h1 followed by bn_den1, input gn = Graph_BN(g)
+    HeadBwd b1{B, F, n1, sv.g, sv.bn_g, 0, nodrop, h->den1_w, sc.da1, sv.h1, sv.bn_1, sb_1, nullptr, hg->d_bn1_w, hg->d_bn1_b,
+               sc.dgn, sb_g, hg->d_den1_w, m->training};
+    RC(head_bwd(b1, s));
+    HeadGbn bg{B, F, sc.dgn, sv.g, sv.bn_g, sb_g, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training};
+    RC(head_gbn_bwd(bg, s));
     // read-out
     const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
     const eagcn_layout lay = out_layout(last);

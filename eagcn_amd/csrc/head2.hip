@@ -1,0 +1,440 @@
+// The model head (reference models.py:112-120): Graph_BN -> den1 -> bn_den1 -> relu -> dropout -> den2
+// (= graph_representation) -> bn_den2 -> relu -> den3, and its backward, as FOUR launches per direction.
+//
+// A BatchNorm1d over a [B, F] matrix needs column statistics over the whole batch before a single output can be
+// formed, so a chain  BN -> Dense -> BN -> Dense ...  looks like one launch per BatchNorm plus one per product (round 1:
+// 13 launches of 5-15 us for 0.4 % of the step's flops).  Here every BatchNorm is split in two halves that ride in the
+// neighbouring products:
+//   * its STATISTICS (sum x, sum x^2 per column; backward: sum dy, sum dy*xhat) are accumulated in fp64 atomics by the
+//     epilogue of the kernel that PRODUCES x (read-out, den1, den2; backward: the kernel that produces dy);
+//   * its NORMALISATION (+ relu, dropout; backward: the affine dx = a*dy + b*x + c) is applied by the kernel that
+//     CONSUMES it, while it loads its operands (per-column tables in LDS, built from the statistics by every workgroup).
+// The products themselves are tiny (B x 700 x 256 ...): one WAVE per 16x16 output tile, operands straight from global
+// memory into the MFMA operand registers (v_mfma_f32_16x16x4_f32, exact fp32); one WORKGROUP per 16x64 output tile, its
+// four waves split K and keep two k-steps (ten vector loads) in flight each (the products are latency chains, not flops).
+// Every backward launch carries two products: d(input) of a dense layer (NT form) and its weight gradient (TN form).
+#include <algorithm>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace eagcn {
+
+enum { HT_SC = 0, HT_SH, HT_MU, HT_INV };    // rows of a saved BatchNorm table [4][F]
+
+__device__ __forceinline__ uint64_t head_seed(const HeadDrop& d) { return d.seed_dev ? *d.seed_dev : d.seed; }
+
+// ---- 16x64 output tile of one WORKGROUP: acc[j] = sum_k A(row, k) B_j(k, col) ----------------------------------------------
+// MFMA step s of a 16-wide k-step multiplies the actual k = k0 + 4q + s in slot q for both operands.  The operands are
+// given as functors with a LOAD half (raw registers, clamped addresses, no predicate) and a TRANSFORM half (BatchNorm
+// affine / relu / dropout / zero beyond the extents): the products are chains of dependent memory round trips, not of
+// MFMAs, so all loads of STEPS k-steps are issued back to back before the first value is touched (a conditional or a
+// select right behind a load makes the compiler wait -- or branch -- per load).  Two forms of the B side:
+//   QUAD: fb.load(k) = B[k][n0 + 4 li .. + 3], one k, four adjacent columns: component j feeds column tile j (tile j
+//         holds the columns 4c + j; 16 lanes read 256 contiguous bytes of a [K][N] operand);
+//   NT:   fb.load(j, kq) = the four values k = kq .. kq+3 of column 16 j + li (an operand stored [N][K]).
+// The four waves split the k-steps; the partial tiles are summed through LDS and returned to wave 0.
+__device__ __forceinline__ void keep(f32x4& v) { asm volatile("" : "+v"(v)); }   // the load feeding v is not sunk / predicated
+
+template <bool QUAD, int STEPS, class FA, class FB>
+__device__ __forceinline__ void head_tile(int K, const FA& fa, const FB& fb, f32x4* red, f32x4 (&acc)[4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4;
+    const int nsteps = (K + 15) >> 4;
+    const int per = (((nsteps + 3) >> 2) + STEPS - 1) / STEPS * STEPS;      // k-steps per wave, a multiple of STEPS
+    const int sb = wave * per, se = min(nsteps, sb + per);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int st = sb; st < se; st += STEPS) {
+        typename FA::Raw ra[STEPS];
+        typename FB::Raw rb[STEPS][4];
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+            const int kq = (st + u) * 16 + 4 * q;
+            ra[u] = fa.load(kq);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (QUAD) rb[u][t] = fb.load(kq + t);   // t = MFMA step s
+                else rb[u][t] = fb.load(t, kq);                   // t = column tile j
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+            const int kq = (st + u) * 16 + 4 * q;
+            const f32x4 a = fa.xf(ra[u], kq);
+            f32x4 b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (QUAD) b[t] = fb.xf(rb[u][t], kq + t);
+                else b[t] = fb.xf(rb[u][t], t, kq);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], QUAD ? b[s][j] : b[j][s], acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(j * 4 + wave) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[j] = (red[(j * 4) * 64 + lane] + red[(j * 4 + 1) * 64 + lane]) + (red[(j * 4 + 2) * 64 + lane] + red[(j * 4 + 3) * 64 + lane]);
+    }
+}
+
+// raw load of p[i .. i+3] at a clamped (always valid) index; VEC: i and n multiples of 4, row 16-byte aligned
+template <bool VEC>
+__device__ __forceinline__ f32x4 ld4raw(const float* __restrict__ p, int i, int n) {
+    f32x4 v;
+    if constexpr (VEC) {
+        v = *reinterpret_cast<const f32x4*>(p + max(min(i, n - 4), 0));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = p[max(min(i + e, n - 1), 0)];
+    }
+
+    return v;
+}
+__device__ __forceinline__ f32x4 zero_beyond(f32x4 v, int i, int n) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = i + e < n ? v[e] : 0.0f;
+    return v;
+}
+
+// ---- forward stage: y = act(bn(x)) . W, statistics of y (HeadFwd, kernels.h) ------------------------------------------------
+template <bool VEC, bool DROP>
+struct HfA {                     // A side: x row, BatchNorm affine from the LDS table, relu, dropout
+    typedef f32x4 Raw;
+    const float* xr; const float* tab; int K, Kp, row; float lo; uint64_t seed; uint32_t thr; float inv_keep;
+    __device__ __forceinline__ Raw load(int kq) const { return ld4raw<VEC>(xr, kq, K); }
+    __device__ __forceinline__ f32x4 xf(Raw v, int kq) const {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = min(kq + e, K - 1);
+            float h = fmaxf(v[e] * tab[k] + tab[Kp + k], lo);
+            if constexpr (DROP) h *= drop_scale(seed, (uint64_t)row * K + k, thr, inv_keep);
+            v[e] = kq + e < K ? h : 0.0f;
+        }
+        return v;
+    }
+};
+template <bool VEC>
+struct HfB {                     // B side (QUAD): W[k][col0 .. col0+3]
+    typedef f32x4 Raw;
+    const float* W; int K, N, col0;
+    __device__ __forceinline__ Raw load(int k) const { return ld4raw<VEC>(W + (size_t)min(k, K - 1) * N, col0, N); }
+    __device__ __forceinline__ f32x4 xf(Raw v, int k) const { return k < K ? zero_beyond(v, col0, N) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+};
+
+template <bool VEC, bool DROP>
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwd a) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];          // [2][Kp]: scale, shift
+    const int Kp = (a.K + 3) & ~3;
+    for (int k = threadIdx.x; k < a.K; k += 256) {
+        float mu, inv;
+        if (a.training) {
+            const double mean = a.st_in[2 * k] / a.B;
+            double var = a.st_in[2 * k + 1] / a.B - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            mu = (float)mean;
+            inv = (float)(1.0 / sqrt(var + (double)a.eps));
+            if (blockIdx.x == 0) {
+                const double unbiased = var * ((double)a.B / ((double)a.B - 1.0));
+                a.run_mean[k] = (float)((1.0 - a.momentum) * (double)a.run_mean[k] + a.momentum * mean);
+                a.run_var[k] = (float)((1.0 - a.momentum) * (double)a.run_var[k] + a.momentum * unbiased);
+            }
+        } else {
+            mu = a.run_mean[k];
+            inv = 1.0f / sqrtf(a.run_var[k] + a.eps);
+        }
+        const float sc = a.gamma[k] * inv, sh = a.beta[k] - mu * sc;
+        tab[k] = sc;
+        tab[Kp + k] = sh;
+        if (blockIdx.x == 0) {
+            a.bn[HT_SC * a.K + k] = sc; a.bn[HT_SH * a.K + k] = sh; a.bn[HT_MU * a.K + k] = mu; a.bn[HT_INV * a.K + k] = inv;
+        }
+    }
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(tab + 2 * Kp);
+    const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
+    const int ncb = (a.N + 63) >> 6;
+    const int tile = blockIdx.x;                         // one 16 x 64 tile per workgroup
+    const int rb = tile / ncb, cb = tile - rb * ncb;
+    const int row = min(rb * 16 + li, a.B - 1), col0 = cb * 64 + 4 * li;
+    const HfA<VEC, DROP> fa{a.x + (size_t)row * a.K, tab, a.K, Kp, row, a.relu ? 0.0f : -INFINITY,
+                            DROP ? head_seed(a.drop) : 0, a.drop.thr, a.drop.inv_keep};
+    const HfB<VEC> fb{a.W, a.K, a.N, col0};
+    f32x4 acc[4];
+    head_tile<true, 4>(a.K, fa, fb, red, acc);
+    if (threadIdx.x >= 64) return;
+    // D layout of tile j: column 4 li + j, rows 4q + r
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int orow = rb * 16 + 4 * q + r;
+        if (orow < a.B) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (col0 + j < a.N) {
+                    const float v = acc[j][r];
+                    a.y[(size_t)orow * a.N + col0 + j] = v;
+                    if (a.y2) a.y2[(size_t)orow * a.N + col0 + j] = v;
+                    s1[j] += (double)v;
+                    s2[j] += (double)v * (double)v;
+                }
+        }
+    }
+    if (a.st_out) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double t1 = s1[j], t2 = s2[j];
+            t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+            if (q == 0 && col0 + j < a.N) {
+                atomicAdd(&a.st_out[2 * (col0 + j)], t1);
+                atomicAdd(&a.st_out[2 * (col0 + j) + 1], t2);
+            }
+        }
+    }
+}
+
+// ---- backward stage of the dense layer  y = a . W,  a = act(bn_p(x)) -----------------------------------------------------
+//   dy_eff = the gradient that reaches y: either given plainly (dense 3: d out) or through the BatchNorm that follows y:
+//            dy_eff = al * dy + be * y + ga (+ extra), coefficients from that BatchNorm's backward sums (this kernel's
+//            prologue; it also writes that BatchNorm's d gamma / d beta)
+//   (a) da = dy_eff . W^T ;  dyp = da * dropmask * [bn_p(x) > 0]  -> written, with sum dyp, sum dyp * xhat_p (atomics)
+//   (b) dW = a^T . dy_eff
+struct Raw3 { f32x4 d, y, e; };
+template <bool VEC>
+struct HbDy {                    // dy_eff[b][n4 .. n4+3]: the plain case reads dy in place of y with the coefficients
+    typedef Raw3 Raw;            // (1, 0, 0), a missing `extra` reads dy with weight 0 -- no branch between the loads
+    const float *dy, *yp, *ep; const float* tab; int B, N, Np; float ew;
+    __device__ __forceinline__ Raw ld(int b, int n4) const {
+        const size_t ro = (size_t)min(b, B - 1) * N;
+        Raw r;
+        r.d = ld4raw<VEC>(dy + ro, n4, N); r.y = ld4raw<VEC>(yp + ro, n4, N); r.e = ld4raw<VEC>(ep + ro, n4, N);
+        return r;
+    }
+    __device__ __forceinline__ f32x4 tr(const Raw& r, int b, int n4) const {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = min(n4 + e, N - 1);
+            const float v = tab[n] * r.d[e] + tab[Np + n] * r.y[e] + tab[2 * Np + n] + ew * r.e[e];
+            o[e] = (n4 + e < N && b < B) ? v : 0.0f;
+        }
+        return o;
+    }
+};
+template <bool VEC>
+struct HbA_a {                   // (a) A side: dy_eff[row][nq .. nq+3]
+    typedef Raw3 Raw;
+    HbDy<VEC> g; int row;
+    __device__ __forceinline__ Raw load(int nq) const { return g.ld(row, nq); }
+    __device__ __forceinline__ f32x4 xf(const Raw& r, int nq) const { return g.tr(r, row, nq); }
+};
+template <bool VEC>
+struct HbB_a {                   // (a) B side (NT): W[k_j][nq .. nq+3], k_j = kb*64 + 16 j + li
+    typedef f32x4 Raw;
+    const float* W; int K, N, k0;
+    __device__ __forceinline__ Raw load(int j, int nq) const { return ld4raw<VEC>(W + (size_t)min(k0 + 16 * j, K - 1) * N, nq, N); }
+    __device__ __forceinline__ f32x4 xf(Raw v, int j, int nq) const { return zero_beyond(v, nq, N); }
+};
+template <bool DROP>
+struct HbA_b {                   // (b) A side: a[b][k] = drop(relu(bn_p(x[b][k]))) for b = bq .. bq+3
+    typedef f32x4 Raw;
+    const float* x; int B, K, k; float sc, sh, lo; uint64_t seed; uint32_t thr; float inv_keep;
+    __device__ __forceinline__ Raw load(int bq) const {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = x[(size_t)min(bq + e, B - 1) * K + k];
+        keep(v);
+        return v;
+    }
+    __device__ __forceinline__ f32x4 xf(Raw v, int bq) const {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float h = fmaxf(v[e] * sc + sh, lo);
+            if constexpr (DROP) h *= drop_scale(seed, (uint64_t)(bq + e) * K + k, thr, inv_keep);
+            v[e] = bq + e < B ? h : 0.0f;
+        }
+        return v;
+    }
+};
+template <bool VEC>
+struct HbB_b {                   // (b) B side (QUAD): dy_eff[b][n0 .. n0+3]
+    typedef Raw3 Raw;
+    HbDy<VEC> g; int n0;
+    __device__ __forceinline__ Raw load(int b) const { return g.ld(b, n0); }
+    __device__ __forceinline__ f32x4 xf(const Raw& r, int b) const { return g.tr(r, b, n0); }
+};
+
+template <bool VEC, bool DROP>
+__global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwd a) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];          // [3][Np]: al, be, ga of dy_eff
+    const int Np = (a.N + 3) & ~3;
+    for (int n = threadIdx.x; n < a.N; n += 256) {
+        float al = 1.0f, be = 0.0f, ga = 0.0f;
+        if (a.bny) {
+            const float sc = a.bny[HT_SC * a.N + n], mu = a.bny[HT_MU * a.N + n], inv = a.bny[HT_INV * a.N + n];
+            const double s1 = a.sb_y[2 * n], s2 = a.sb_y[2 * n + 1];
+            const float c1 = a.training ? (float)(s1 / a.B) : 0.0f, c2 = a.training ? (float)(s2 / a.B) : 0.0f;
+            // sc * (dy - c1 - (y - mu) * inv * c2)
+            al = sc;
+            be = -sc * inv * c2;
+            ga = sc * (inv * c2 * mu - c1);
+            if (blockIdx.x == 0) { a.dgamma_y[n] = (float)s2; a.dbeta_y[n] = (float)s1; }
+        }
+        tab[n] = al; tab[Np + n] = be; tab[2 * Np + n] = ga;
+    }
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(tab + 3 * Np);
+    const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
+    const int nkb64 = (a.K + 63) >> 6, nnb64 = (a.N + 63) >> 6, nrb = (a.B + 15) >> 4;
+    const int tiles_a = nrb * nkb64;
+    const int tile = blockIdx.x;                         // one 16 x 64 tile per workgroup
+    const uint64_t seed = DROP ? head_seed(a.drop) : 0;
+    const HbDy<VEC> dyf{a.dy, a.bny ? a.y : a.dy, a.extra ? a.extra : a.dy, tab, a.B, a.N, Np, a.extra ? 1.0f : 0.0f};
+    f32x4 acc[4];
+    if (tile < tiles_a) {
+        // (a) da[b][k] = sum_n dy_eff[b][n] W[k][n]   (both operands contiguous along the reduction index n: NT form)
+        const int rb = tile / nkb64, kb = tile - rb * nkb64;
+        const HbA_a<VEC> fa{dyf, min(rb * 16 + li, a.B - 1)};
+        const HbB_a<VEC> fb{a.W, a.K, a.N, kb * 64 + li};
+        head_tile<false, 2>(a.N, fa, fb, red, acc);
+        if (threadIdx.x >= 64) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kb * 64 + 16 * j + li;             // tile j: column li <-> input feature k
+            double s1 = 0.0, s2 = 0.0;
+            if (k < a.K) {
+                const float sc = a.bnp[HT_SC * a.K + k], sh = a.bnp[HT_SH * a.K + k];
+                const float mu = a.bnp[HT_MU * a.K + k], inv = a.bnp[HT_INV * a.K + k];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = rb * 16 + 4 * q + r;
+                    if (b < a.B) {
+                        const float xv = a.x[(size_t)b * a.K + k];
+                        float d = acc[j][r];
+                        if constexpr (DROP) d *= drop_scale(seed, (uint64_t)b * a.K + k, a.drop.thr, a.drop.inv_keep);
+                        if (a.relu_p && !(xv * sc + sh > 0.0f)) d = 0.0f;
+                        a.dyp[(size_t)b * a.K + k] = d;
+                        s1 += (double)d;
+                        s2 += (double)(d * ((xv - mu) * inv));
+                    }
+                }
+            }
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (q == 0 && k < a.K) {
+                atomicAdd(&a.sb_p[2 * k], s1);
+                atomicAdd(&a.sb_p[2 * k + 1], s2);
+            }
+        }
+    } else {
+        // (b) dW[k][n] = sum_b a[b][k] dy_eff[b][n],  a = drop(relu(bn_p(x)));  tile: 16 input features x 64 output features
+        const int t = tile - tiles_a;
+        const int kb = t / nnb64, nb = t - kb * nnb64;
+        const int k = min(kb * 16 + li, a.K - 1), n0 = nb * 64 + 4 * li;
+        const HbA_b<DROP> fa{a.x, a.B, a.K, k, a.bnp[HT_SC * a.K + k], a.bnp[HT_SH * a.K + k], a.relu_p ? 0.0f : -INFINITY,
+                             seed, a.drop.thr, a.drop.inv_keep};
+        const HbB_b<VEC> fb{dyf, n0};
+        head_tile<true, 2>(a.B, fa, fb, red, acc);
+        if (threadIdx.x >= 64) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ok = kb * 16 + 4 * q + r;
+            if (ok < a.K) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n0 + j < a.N) a.dW[(size_t)ok * a.N + n0 + j] = acc[j][r];
+            }
+        }
+    }
+}
+
+// Graph_BN backward (no product in front of it): dg = al * dgn + be * g + ga, d gamma / d beta
+__global__ __launch_bounds__(256) void head_gbn_bwd_kernel(HeadGbn a) {
+    const size_t total = (size_t)a.B * a.F;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(e % a.F);
+        const float sc = a.bn[HT_SC * a.F + f], mu = a.bn[HT_MU * a.F + f], inv = a.bn[HT_INV * a.F + f];
+        const double s1 = a.sb[2 * f], s2 = a.sb[2 * f + 1];
+        const float c1 = a.training ? (float)(s1 / a.B) : 0.0f, c2 = a.training ? (float)(s2 / a.B) : 0.0f;
+        a.dg[e] = sc * (a.dgn[e] - c1 - (a.g[e] - mu) * inv * c2);
+        if (e < (size_t)a.F) { a.dgamma[f] = (float)s2; a.dbeta[f] = (float)s1; }
+    }
+}
+
+// column sums (sum g, sum g^2) of the read-out: 16 molecules per workgroup pre-reduced, then fp64 atomics
+__global__ __launch_bounds__(256) void head_colstats_kernel(const float* __restrict__ g, int B, int F, double* __restrict__ st) {
+    // grid (ceil(F/64), ceil(B/64)): lane = column, the four waves take rows r0 + wave, +4, ...
+    __shared__ double part[4][64][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * 64;
+    double s1 = 0.0, s2 = 0.0;
+    if (f < F)
+        for (int r = r0 + wave; r < min(r0 + 64, B); r += 4) {
+            const float v = g[(size_t)r * F + f];
+            s1 += (double)v;
+            s2 += (double)v * (double)v;
+        }
+    part[wave][lane][0] = s1;
+    part[wave][lane][1] = s2;
+    __syncthreads();
+    if (wave == 0 && f < F) {
+        s1 = (part[0][lane][0] + part[1][lane][0]) + (part[2][lane][0] + part[3][lane][0]);
+        s2 = (part[0][lane][1] + part[1][lane][1]) + (part[2][lane][1] + part[3][lane][1]);
+        atomicAdd(&st[2 * f], s1);
+        atomicAdd(&st[2 * f + 1], s2);
+    }
+}
+
+// ---- launchers --------------------------------------------------------------------------------------------------------
+int head_colstats(const float* g, int B, int F, double* st, hipStream_t s) {
+    ProfScope ps(PROF_HEAD, s);
+    head_colstats_kernel<<<dim3(cdiv(F, 64), cdiv(B, 64)), 256, 0, s>>>(g, B, F, st);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+int head_fwd(const HeadFwd& a, hipStream_t s) {
+    const int tiles = cdiv(a.B, 16) * cdiv(a.N, 64);
+    const size_t lds = (size_t)2 * ((a.K + 3) & ~3) * sizeof(float) + 16384;
+    EAGCN_CHECK_ARG(lds <= 64 * 1024, "head: %d input features exceed the table size", a.K);
+    ProfScope ps(PROF_HEAD, s, 2.0 * a.B * a.K * a.N);
+    const bool vec = (a.K & 3) == 0 && (a.N & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.W)) & 15) == 0;
+    if (vec && a.drop.on) head_fwd_kernel<true, true><<<tiles, 256, lds, s>>>(a);
+    else if (vec) head_fwd_kernel<true, false><<<tiles, 256, lds, s>>>(a);
+    else if (a.drop.on) head_fwd_kernel<false, true><<<tiles, 256, lds, s>>>(a);
+    else head_fwd_kernel<false, false><<<tiles, 256, lds, s>>>(a);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+int head_bwd(const HeadBwd& a, hipStream_t s) {
+    const int tiles = cdiv(a.B, 16) * cdiv(a.K, 64) + cdiv(a.K, 16) * cdiv(a.N, 64);
+    const size_t lds = (size_t)3 * ((a.N + 3) & ~3) * sizeof(float) + 16384;
+    EAGCN_CHECK_ARG(lds <= 64 * 1024, "head: %d output features exceed the table size", a.N);
+    ProfScope ps(PROF_HEAD, s, 4.0 * a.B * a.K * a.N);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(a.dy) | reinterpret_cast<uintptr_t>(a.W) | reinterpret_cast<uintptr_t>(a.y) |
+                         reinterpret_cast<uintptr_t>(a.extra);
+    const bool vec = (a.N & 3) == 0 && (al & 15) == 0;
+    if (vec && a.drop.on) head_bwd_kernel<true, true><<<tiles, 256, lds, s>>>(a);
+    else if (vec) head_bwd_kernel<true, false><<<tiles, 256, lds, s>>>(a);
+    else if (a.drop.on) head_bwd_kernel<false, true><<<tiles, 256, lds, s>>>(a);
+    else head_bwd_kernel<false, false><<<tiles, 256, lds, s>>>(a);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+int head_gbn_bwd(const HeadGbn& a, hipStream_t s) {
+    const size_t total = (size_t)a.B * a.F;
+    ProfScope ps(PROF_HEAD, s);
+    head_gbn_bwd_kernel<<<(int)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 1024)), 256, 0, s>>>(a);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+}  // namespace eagcn

@@ -69,10 +69,31 @@ struct DwScatter {               // epilogue of a layer's dW product: packed (in
 size_t gemm3_workspace_bytes();
 // the hand-off flags must be zero when a launch starts; every launch leaves them zero again, so ONE clear at the start of
 // an API call (a tiny kernel, also under capture) covers all its launches on the same workspace
-int gemm3_clear_flags(void* workspace, size_t bytes, hipStream_t s);
+// (`zero`: optionally `nzero` doubles cleared by the same launch -- the head's BatchNorm sums)
+int gemm3_clear_flags(void* workspace, size_t bytes, hipStream_t s, double* zero = nullptr, int nzero = 0);
 bool gemm3_ok(const GemmDesc& g);
 int launch_gemm3(const GemmDesc& g, const DwScatter* sc, void* workspace, size_t bytes, hipStream_t s);
 int launch_gemm3_pair(const GemmDesc& dx, const GemmDesc& dw, const DwScatter* sc, void* workspace, size_t bytes, hipStream_t s);
+
+// ---- model head (head2.hip) -----------------------------------------------------------------------------------------------
+struct HeadDrop { int on; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev; };
+struct HeadFwd {                 // y = act(bn(x)) . W  (+ column sums of y)
+    int B, K, N;
+    const float* x; const double* st_in; const float *gamma, *beta; float *run_mean, *run_var; float* bn;
+    const float* W; float* y; float* y2; double* st_out;
+    int training, relu; float eps, momentum; HeadDrop drop;
+};
+struct HeadBwd {                 // backward of  y = act(bn_p(x)) . W : d(bn_p output) with its sums, and dW
+    int B, K, N;
+    const float* x; const float* bnp; int relu_p; HeadDrop drop; const float* W;
+    const float* dy; const float* y; const float* bny; const double* sb_y; const float* extra;
+    float *dgamma_y, *dbeta_y; float* dyp; double* sb_p; float* dW; int training;
+};
+struct HeadGbn { int B, F; const float *dgn, *g, *bn; const double* sb; float *dg, *dgamma, *dbeta; int training; };
+int head_colstats(const float* g, int B, int F, double* st, hipStream_t s);
+int head_fwd(const HeadFwd& a, hipStream_t s);
+int head_bwd(const HeadBwd& a, hipStream_t s);
+int head_gbn_bwd(const HeadGbn& a, hipStream_t s);
 
 int layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                         const float* dxout, const ReadoutGrad* rg, const float* dpad_row, float* dx,
