@@ -120,6 +120,18 @@ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
     z ^= z >> 32;
     return (uint32_t)z;
 }
+// 64 mixed bits per (seed, index): four 16-bit draws at once (dropout of the NON-STORED rows of a Weighted_sum layer, where
+// only the NUMBER of kept rows per (molecule, view, column) matters: readout.hip)
+__device__ __forceinline__ uint64_t rng_u64(uint64_t seed, uint64_t idx) {
+    uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+    z ^= z >> 32;
+    z *= 0xD6E8FEB86659FD93ull;
+    z ^= z >> 32;
+    z *= 0xD6E8FEB86659FD93ull;
+    z ^= z >> 32;
+    return z;
+}
+constexpr uint64_t PAD_STREAM_BASE = 1ull << 40;     // index space of the non-stored rows' draws (rows beyond any packed row)
 // keep-scale of an element: 0 (dropped) or 1/(1-p); thr = p * 2^32
 __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
     return rng_u32(seed, idx) >= thr ? inv_keep : 0.0f;

@@ -252,8 +252,15 @@ struct ModelSaved {
     float* x0;
     LayerSaved L[4];
     float *g, *gn, *h1, *a1, *h2, *a2, *bn_g, *bn_1, *bn_2;
+    uint16_t* pad_cnt;           // [B][K][ldo]: kept non-stored rows per (molecule, view, column) (readout.hip), or unused
+    float* padc;                 // [B][ldo]
     size_t xout_last_off, pad_last_off;
 };
+// the last layer's non-stored rows go through a SAMPLED dropout when they reach the read-out unmasked
+static bool pad_sampled(const eagcn_model* m) {
+    const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
+    return last->structure == EAGCN_STRUCT_WEIGHTED && m->training && last->dropout > 0.0f;
+}
 
 static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m, ModelSaved* out) {
     Carver2 c(base);
@@ -288,6 +295,13 @@ static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m
     s.bn_g = c.take<float>((size_t)4 * h->f_in);
     s.bn_1 = c.take<float>((size_t)4 * h->n_den1);
     s.bn_2 = c.take<float>((size_t)4 * h->n_den2);
+    {
+        const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
+        const size_t ldo = (size_t)eagcn_layer_out_ld(last);
+        const bool need = last->structure == EAGCN_STRUCT_WEIGHTED;
+        s.pad_cnt = c.take<uint16_t>(need ? B * last->K * ldo : 1);
+        s.padc = c.take<float>(need ? B * ldo : 1);
+    }
     if (out) *out = s;
     return c.off;
 }
@@ -330,7 +344,7 @@ static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model*
     }
     s.dxa = c.take<float>(T * ldmax);
     s.dxb = c.take<float>(T * ldmax);
-    s.dpad = c.take<float>(ldmax);
+    s.dpad = c.take<float>((size_t)EAGCN_MAX_VIEWS * ldmax);
     s.layer_bytes = lbytes;
     s.layer = c.take<char>(lbytes);
     if (out) *out = s;
@@ -545,8 +559,12 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     const LayerSaved& LL = sv.L[m->n_layers - 1];
     const eagcn_layout lay = out_layout(last);
     const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
-    RC(eagcn_readout_forward(b, LL.xout, &lay, last->structure == EAGCN_STRUCT_WEIGHTED ? LL.pad_row : nullptr,
-                             size, m->molfp_mode, sv.g, F, stream));
+    if (pad_sampled(m))
+        RC(readout_forward_sampled(b, LL.xout, &lay, last, LL.bn + (size_t)LL.fp /* shift row of the BatchNorm table */, size,
+                                   m->molfp_mode, sv.g, F, sv.pad_cnt, sv.padc, stream));
+    else
+        RC(eagcn_readout_forward(b, LL.xout, &lay, last->structure == EAGCN_STRUCT_WEIGHTED ? LL.pad_row : nullptr,
+                                 size, m->molfp_mode, sv.g, F, stream));
     // head (head2.hip): every BatchNorm's sums come from the kernel that produces its input, its normalisation is
     // applied by the product that consumes it
     double *st_g = sc.hst, *st_1 = sc.hst + 2 * F, *st_2 = sc.hst + 2 * (F + n1);
@@ -620,7 +638,9 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
     // gradient of the common non-stored row of Weighted_sum needs a (tiny) launch of its own
     ReadoutGrad rgd;
     rgd.dg = sc.dg; rgd.F = F; rgd.size = size; rgd.mode = m->molfp_mode; rgd.map = make_colmap(&lay);
-    if (weighted) RC(readout_backward_pad(b, sc.dg, &lay, size, m->molfp_mode, F, sc.dpad, stream));
+    const bool sampled = pad_sampled(m);
+    if (sampled) RC(readout_backward_pad_views(b, sc.dg, &lay, size, m->molfp_mode, F, last->K, sv.pad_cnt, last->dropout, sc.dpad, stream));
+    else if (weighted) RC(readout_backward_pad(b, sc.dg, &lay, size, m->molfp_mode, F, sc.dpad, stream));
     for (int l = m->n_layers - 1; l >= 0; --l) {
         LayerSaved& L = sv.L[l];
         eagcn_layer_bufs w;
@@ -632,7 +652,7 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
         const bool top = l == m->n_layers - 1;
         const float* dpad = (weighted && top) ? sc.dpad : nullptr;
         RC(layer_backward_impl(b, &m->layer[l], &w, top ? nullptr : cur, top ? &rgd : nullptr, dpad,
-                               l > 0 ? other : nullptr, &lg[l], stream));
+                               l > 0 ? other : nullptr, &lg[l], stream, top && sampled));
         std::swap(cur, other);
     }
     if (forked) RC(stream_after(s, side));                       // join: every gradient is complete on s

@@ -95,13 +95,19 @@ int head_fwd(const HeadFwd& a, hipStream_t s);
 int head_bwd(const HeadBwd& a, hipStream_t s);
 int head_gbn_bwd(const HeadGbn& a, hipStream_t s);
 
+// dpad_views: dpad_row holds one gradient row per VIEW ([K][ld_out]: sampled dropout of the non-stored rows) instead of one
 int layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                         const float* dxout, const ReadoutGrad* rg, const float* dpad_row, float* dx,
-                        const eagcn_layer_grads* g, void* stream);
+                        const eagcn_layer_grads* g, void* stream, bool dpad_views = false);
 int layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, void* stream,
                        bool prepacked);
 int pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const* ps, void* const* packed,
                     const size_t* packed_bytes, int n, void* stream);
+int readout_forward_sampled(const eagcn_batch* b, const float* x, const eagcn_layout* lay, const eagcn_layer_params* p,
+                            const float* bn_sh, const int64_t* size, int mode, float* g, int F, uint16_t* cnt, float* padc,
+                            void* stream);
+int readout_backward_pad_views(const eagcn_batch* b, const float* dg, const eagcn_layout* lay, const int64_t* size, int mode,
+                               int F, int K, const uint16_t* cnt, float dropout, float* dpad, void* stream);
 int readout_backward_pad(const eagcn_batch* b, const float* dg, const eagcn_layout* lay, const int64_t* size,
                          int mode, int F, float* dpad_row, void* stream);
 

@@ -252,6 +252,7 @@ struct BwdArgs {
     const float* dxout; int ldo;
     ReadoutGrad rg;              // rg.dg != null: the upstream gradient is dg[row_mol[r]] (dxout unused)
     const float* dpad;           // [ldo] gradient of the common non-stored row, or null
+    int dpad_views;              // dpad is [K][ldo]: one row per view (sampled dropout of the non-stored rows)
     const float* Y; int ldy;
     const float* bn;
     const float* colp;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
                         upv[u].x *= m; upv[u].y *= m; upv[u].z *= m; upv[u].w *= m;
                     }
                 } else if (r < rows) {                 // the one virtual row standing for all non-stored rows
-                    upv[u] = *reinterpret_cast<const float4*>(a.dpad + (size_t)(r - T) * a.ldo + cu);
+                    upv[u] = *reinterpret_cast<const float4*>(a.dpad + (size_t)(a.dpad_views ? k : (r - T)) * a.ldo + cu);
                 }
             }
 #pragma unroll
@@ -804,7 +805,7 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
 
 int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                                const float* dxout, const ReadoutGrad* rg, const float* dpad_row, float* dx,
-                               const eagcn_layer_grads* g, void* stream) {
+                               const eagcn_layer_grads* g, void* stream, bool dpad_views) {
     hipStream_t s = (hipStream_t)stream;
     int rc = check_layer(b, p, "eagcn_layer_backward");
     if (rc) return rc;
@@ -849,7 +850,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     BwdArgs ba;
     ba.bt = *b; ba.vc = d.vc; ba.structure = p->structure; ba.fp = d.fp;
     ba.nvirt = (dpad_row && p->structure == EAGCN_STRUCT_WEIGHTED) ? 1 : 0;
-    ba.dxout = dxout; ba.ldo = d.ldo; ba.dpad = dpad_row;
+    ba.dxout = dxout; ba.ldo = d.ldo; ba.dpad = dpad_row; ba.dpad_views = dpad_views ? 1 : 0;
     if (rg) ba.rg = *rg; else memset(&ba.rg, 0, sizeof(ba.rg)); ba.Y = w->Y; ba.ldy = d.fp; ba.bn = w->bn;
     ba.colp = sc.colp; ba.dH = sc.dY; ba.slab = sc.slab; ba.slab_da = sc.slab_da;
     ba.do_drop = (p->training && p->dropout > 0.0f) ? 1 : 0;

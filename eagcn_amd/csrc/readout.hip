@@ -20,9 +20,76 @@ __device__ __forceinline__ int exact_to_packed(const ColMapD& m, int ce) {
     return -1;
 }
 
-// grid (B, ceil(F/64)); 4 wavefronts split the molecule's rows, 64 lanes own 64 exact columns
+// ---- dropout of the rows that are not stored (Weighted_sum has no row mask: reference layers.py:94 drops every element
+// of the padded [B,N,F] tensor independently, layers.py:315-316 sums the views, models.py:108 sums all N rows) ------------
+// A non-stored row of view k holds relu(shift_k[c]) in column c before dropout, so the read-out only needs HOW MANY of the
+// N - nat[b] non-stored rows keep (molecule b, view k, column c): cnt[b][k][c], drawn from the layer's dropout seed (16-bit
+// draws, four rows per 64-bit hash) and kept for the backward pass.  padc[b][c] = sum_k a_k relu(shift_k[c]) cnt / (1-p).
+struct PadSample {
+    int K, ld, fp;                           // views, output columns (one view's padded width), BatchNorm table stride
+    int off[EAGCN_MAX_VIEWS];                // column offset of view k inside the [fp] tables
+    const float* bn_sh;                      // [fp] BatchNorm shift (beta - mean * scale)
+    const float* ave_w;                      // [K]
+    uint64_t seed; const uint64_t* seed_dev;
+    uint32_t thr16; float inv_keep;
+    uint16_t* cnt;                           // [B][K][ld]
+    float* padc;                             // [B][ld]
+};
+__device__ __forceinline__ int pad_keep_count(uint64_t seed, int b, int N, int n, uint64_t col, uint64_t ncol, uint32_t thr16) {
+    const int g4 = (N + 3) >> 2;
+    int cnt = 0;
+    for (int i4 = n >> 2; i4 < g4; ++i4) {
+        const uint64_t z = rng_u64(seed, (PAD_STREAM_BASE + (uint64_t)b * g4 + i4) * ncol + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * i4 + e;
+            cnt += (i >= n && i < N && ((uint32_t)(z >> (16 * e)) & 0xFFFFu) >= thr16) ? 1 : 0;
+        }
+    }
+    return cnt;
+}
+__global__ __launch_bounds__(256) void readout_pad_sample_kernel(eagcn_batch bt, PadSample a) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.ld) return;
+    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
+    const int n = bt.nat[b];
+    float acc = 0.0f;
+    for (int k = 0; k < a.K; ++k) {
+        const int cp = a.off[k] + c;
+        const int cnt = pad_keep_count(seed, b, bt.N, n, (uint64_t)cp, (uint64_t)a.fp, a.thr16);
+        a.cnt[((size_t)b * a.K + k) * a.ld + c] = (uint16_t)cnt;
+        acc += a.ave_w[k] * fmaxf(a.bn_sh[cp], 0.0f) * ((float)cnt * a.inv_keep);
+    }
+    a.padc[(size_t)b * a.ld + c] = acc;
+}
+// d(value of the non-stored rows of view k, column c) = sum_b cnt[b][k][c] / (1-p) * dg[b][c] / size[b]
+__global__ __launch_bounds__(256) void readout_bwd_pad_views_kernel(eagcn_batch bt, const float* __restrict__ dg, ColMapD m,
+                                                                     int ld, const int64_t* __restrict__ size, int mode, int F,
+                                                                     int K, const uint16_t* __restrict__ cnt, float inv_keep,
+                                                                     float* __restrict__ dpad) {
+    const int cp = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (cp >= ld) return;
+    int eo = 0, po = 0, ce = -1;
+    for (int s = 0; s < m.nseg; ++s) {
+        if (cp < po + m.p[s]) { ce = (cp - po < m.w[s]) ? eo + (cp - po) : -1; break; }
+        eo += m.w[s];
+        po += m.p[s];
+    }
+    double acc = 0.0;
+    if (ce >= 0)
+        for (int b = 0; b < bt.B; ++b) {
+            const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
+            acc += (double)((float)cnt[((size_t)b * K + k) * ld + cp] * inv_keep * dg[(size_t)b * F + ce] * inv);
+        }
+    dpad[(size_t)k * ld + cp] = (float)acc;
+}
+
+// grid (B, ceil(F/64)); 4 wavefronts split the molecule's rows, 64 lanes own 64 exact columns.
+// padc (optional): per-molecule contribution of the non-stored rows (sampled dropout), replaces (N - nat) * pad_row
 __global__ __launch_bounds__(256) void readout_fwd_kernel(eagcn_batch bt, const float* __restrict__ x, ColMapD m,
                                                            int ld, const float* __restrict__ pad_row,
+                                                           const float* __restrict__ padc,
                                                            const int64_t* __restrict__ size, int mode,
                                                            float* __restrict__ g, int F) {
     __shared__ float part[4][64];
@@ -46,7 +113,8 @@ __global__ __launch_bounds__(256) void readout_fwd_kernel(eagcn_batch bt, const 
     __syncthreads();
     if (wave == 0 && f < F) {
         s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-        if (pad_row) s += (float)(bt.N - n) * pad_row[cp];
+        if (padc) s += padc[(size_t)b * ld + cp];
+        else if (pad_row) s += (float)(bt.N - n) * pad_row[cp];
         const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
         g[(size_t)b * F + f] = s * inv;
     }
@@ -92,6 +160,37 @@ __global__ __launch_bounds__(256) void readout_bwd_pad_kernel(eagcn_batch bt, co
     dpad[cp] = (float)acc;
 }
 
+// forward read-out with the non-stored rows' dropout SAMPLED (Weighted_sum, training, p > 0): fills cnt / padc, then sums
+int readout_forward_sampled(const eagcn_batch* b, const float* x, const eagcn_layout* lay, const eagcn_layer_params* p,
+                            const float* bn_sh, const int64_t* size, int mode, float* g, int F, uint16_t* cnt, float* padc,
+                            void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int ld = layout_ld(lay);
+    PadSample a;
+    a.K = p->K; a.ld = ld; a.fp = p->K * ld;
+    for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) a.off[k] = k * ld;
+    a.bn_sh = bn_sh; a.ave_w = p->ave_w; a.seed = p->seed; a.seed_dev = p->seed_dev;
+    a.thr16 = (uint32_t)std::min(65535.0, (double)p->dropout * 65536.0);
+    a.inv_keep = 1.0f / (1.0f - p->dropout);
+    a.cnt = cnt; a.padc = padc;
+    ProfScope ps(PROF_READOUT, s);
+    readout_pad_sample_kernel<<<dim3(cdiv(ld, 256), b->B), 256, 0, s>>>(*b, a);
+    EAGCN_LAUNCH_CHECK();
+    readout_fwd_kernel<<<dim3(b->B, cdiv(F, 64)), 256, 0, s>>>(*b, x, make_colmap(lay), ld, nullptr, padc, size, mode, g, F);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+// its backward half: dpad [K][ld], one gradient row per view
+int readout_backward_pad_views(const eagcn_batch* b, const float* dg, const eagcn_layout* lay, const int64_t* size, int mode,
+                               int F, int K, const uint16_t* cnt, float dropout, float* dpad, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_READOUT, s);
+    readout_bwd_pad_views_kernel<<<dim3(cdiv(layout_ld(lay), 256), K), 256, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size,
+                                                                                mode, F, K, cnt, 1.0f / (1.0f - dropout), dpad);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
 int readout_backward_pad(const eagcn_batch* b, const float* dg, const eagcn_layout* lay, const int64_t* size,
                          int mode, int F, float* dpad_row, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -115,7 +214,7 @@ extern "C" int eagcn_readout_forward(const eagcn_batch* b, const float* x, const
     EAGCN_CHECK_ARG(layout_width(lay) == F, "eagcn_readout_forward: layout width %d != F %d", layout_width(lay), F);
     EAGCN_CHECK_ARG(mode == 0 || (mode == 1 && size), "eagcn_readout_forward: mode 1 ('ave') needs size");
     ProfScope ps(PROF_READOUT, s);
-    readout_fwd_kernel<<<dim3(b->B, cdiv(F, 64)), 256, 0, s>>>(*b, x, make_colmap(lay), layout_ld(lay), pad_row, size, mode, g, F);
+    readout_fwd_kernel<<<dim3(b->B, cdiv(F, 64)), 256, 0, s>>>(*b, x, make_colmap(lay), layout_ld(lay), pad_row, nullptr, size, mode, g, F);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

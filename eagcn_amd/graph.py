@@ -27,7 +27,10 @@ from . import _lib as L
 from .ops import _index_stream, _ptr, _stream
 
 _RING = 4
-_SIDE_AFTER_FWD = os.environ.get('EAGCN_SIDE_AFTER_FWD', '0') == '1'   # measured: no difference (0.553 ms either way)
+# hold the side-stream batch work until the previous step's FORWARD graph has finished: it then runs beside the loss and
+# the head / BatchNorm backward (latency chains on a few CUs) instead of beside the layer products (measured round 2:
+# 0.5228 -> 0.5175 ms/step at B=256, 1.2386 -> 1.2162 at B=1024; the wave-per-SIMD GEMM is sensitive to co-runners)
+_SIDE_AFTER_FWD = os.environ.get('EAGCN_SIDE_AFTER_FWD', '1') == '1'
 
 
 class StaticIndex:

@@ -859,3 +859,140 @@ def test_eval_graph_golden(name):
         assert rel_err(atom_rep.cpu(), g.z['out/atom_rep'], 'atom_rep rep%d' % rep) < TOL
     for k, v in model.state_dict().items():
         assert torch.equal(v, before[k]), k
+
+
+# ---- training-mode dropout: the kernels' counter-based masks injected into the oracle -----------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix64(seed, idx):
+    """csrc/common.h rng_u64 on numpy uint64 arrays (wrap-around arithmetic)."""
+    with np.errstate(over='ignore'):
+        z = idx.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)
+        z ^= z >> np.uint64(32)
+        z *= np.uint64(0xD6E8FEB86659FD93)
+        z ^= z >> np.uint64(32)
+        z *= np.uint64(0xD6E8FEB86659FD93)
+        z ^= z >> np.uint64(32)
+    return z
+
+
+def _hip_dropout_masks(mb, widths_per_layer, structure, n_den1, p, seed):
+    """The keep-scales (0 or 1/(1-p)) the HIP kernels apply, in the order the oracle calls F.dropout: every block of every
+    layer ([B,N,F_k]), then the head ([B,n_den1]).  Stored rows: drop_scale(seed_l, r*Fp + cp) with r the PACKED row;
+    non-stored rows of the last Weighted_sum layer: the 16-bit draws of csrc/readout.hip; elsewhere they do not matter
+    (masked to zero / never consumed) and are left at 1."""
+    p32 = np.float32(p)
+    thr = np.uint64(min(4294967295.0, float(p32) * 4294967296.0))
+    thr16 = np.uint64(min(65535.0, float(p32) * 65536.0))
+    inv_keep = np.float32(1.0) / (np.float32(1.0) - p32)
+    B, N = mb.B, mb.N
+    adj = np.zeros((B, N, N), dtype=bool)
+    adj[mb.edges[:, 0], mb.edges[:, 1], mb.edges[:, 2]] = True
+    has = adj.any(axis=2)
+    nat = np.array([(np.nonzero(has[b])[0].max() + 1) if has[b].any() else 0 for b in range(B)])
+    row0 = np.concatenate([[0], np.cumsum(nat)[:-1]])
+    masks = []
+    L = len(widths_per_layer)
+    for l, widths in enumerate(widths_per_layer):
+        seed_l = (seed + 7919 * (l + 1)) & (2 ** 63 - 1)
+        pads = [(w + 15) // 16 * 16 for w in widths]
+        fp = sum(pads)
+        off = np.concatenate([[0], np.cumsum(pads)[:-1]])
+        for k, w in enumerate(widths):
+            m = np.ones((B, N, w), dtype=np.float32)
+            for b in range(B):
+                n = int(nat[b])
+                if n:
+                    r = (row0[b] + np.arange(n)).astype(np.uint64)[:, None]
+                    cp = (off[k] + np.arange(w)).astype(np.uint64)[None, :]
+                    z = _mix64(seed_l, r * np.uint64(fp) + cp) & np.uint64(0xFFFFFFFF)
+                    m[b, :n, :] = np.where(z >= thr, inv_keep, np.float32(0.0))
+                if structure == 'Weighted_sum' and l == L - 1 and n < N:
+                    i = np.arange(n, N)
+                    g4 = (N + 3) // 4
+                    grp = (np.uint64(1 << 40) + np.uint64(b * g4) + (i // 4).astype(np.uint64))[:, None]
+                    cp = (off[k] + np.arange(w)).astype(np.uint64)[None, :]
+                    z = _mix64(seed_l, grp * np.uint64(fp) + cp)
+                    draw = (z >> (np.uint64(16) * (i % 4).astype(np.uint64))[:, None]) & np.uint64(0xFFFF)
+                    m[b, n:, :] = np.where(draw >= thr16, inv_keep, np.float32(0.0))
+            masks.append(torch.from_numpy(m))
+    seed_h = (seed + 0x51ED27) & (2 ** 63 - 1)
+    idx = (np.arange(B, dtype=np.uint64)[:, None] * np.uint64(n_den1) + np.arange(n_den1, dtype=np.uint64)[None, :])
+    z = _mix64(seed_h, idx) & np.uint64(0xFFFFFFFF)
+    masks.append(torch.from_numpy(np.where(z >= thr, inv_keep, np.float32(0.0)).astype(np.float32)))
+    return masks
+
+
+@pytest.mark.parametrize('graph', [False, True])
+@pytest.mark.parametrize('structure', ['Concate', 'Weighted_sum'])
+def test_training_dropout_masks_injected_into_oracle(structure, graph):
+    """a-6: relu -> dropout (layers.py:93-94) and the head's dropout (models.py:116) in TRAINING mode at p = 0.3.  The CPU
+    generator cannot be matched, but the kernels' masks are a pure function of (seed, element): they are rebuilt here in
+    numpy and multiplied into the oracle in place of its F.dropout calls, which pins every dropped / kept element, the
+    1/(1-p) scaling, the mask reuse in backward and -- for Weighted_sum, which has no row mask (layers.py:315-316) -- the
+    dropout of the rows that are not stored (their per-(molecule, view, column) kept counts)."""
+    import oracle.eagcn_ref as R
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    p = 0.3
+    w1, w2 = ([9, 7, 5, 5, 6], [12, 8, 6, 6, 8]) if structure == 'Concate' else ([3, 2, 2, 2, 3], [4, 3, 2, 2, 3])
+    for seed in (31, 32, 33, 34):
+        torch.manual_seed(seed)
+        mb = make_batch(B=9, n_max=26, n_med=9, rel_channels=(6, 4, 2, 2, 2), seed=seed, isolated_frac=0.1)
+        ref = R.RefEAGCN(6, 24, w1, w2, 20, 10, 3, p, structure=structure, n_layers=2)
+        R.weights_init_(ref)
+        ref64 = R.RefEAGCN(6, 24, w1, w2, 20, 10, 3, p, structure=structure, n_layers=2).double()
+        ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+        hip = EAGCN(6, 24, *w1, *w2, 20, 10, 3, p, structure=structure, n_layers=2, grad_mode='direct', graph=graph).cuda().train()
+        hip.load_state_dict(ref.state_dict(), strict=True)
+        cpu = mb.dense()
+        gsel = torch.randn(9, 3)
+        widths = [[sum(w1)] * 5, [sum(w2)] * 5] if structure == 'Weighted_sum' else [w1, w2]
+        ok = True
+        for rep in range(3 if graph else 1):
+            torch.manual_seed(1000 + seed + rep)
+            hseed = int(torch.randint(0, 2 ** 62, (1,)).item())       # what EAGCN.forward is about to draw
+            torch.manual_seed(1000 + seed + rep)
+            for q in hip.parameters():
+                q.grad = None
+            out_h, _, gr_h = hip(*_dev(cpu))
+            ((out_h * gsel.cuda()).sum() + 0.1 * gr_h.sum()).backward()
+            masks = _hip_dropout_masks(mb, widths, structure, 20, p, hseed)
+            res = []
+            for m in (ref, ref64):
+                queue = [t.to(next(m.parameters()).dtype) for t in masks]
+                orig = R.F.dropout
+                R.F.dropout = lambda x, p=0.5, training=True, inplace=False: x * queue.pop(0) if training else x
+                try:
+                    m.zero_grad(set_to_none=True)
+                    m.train()
+                    inp = cpu if m is ref else [t.double() if t.is_floating_point() else t for t in cpu]
+                    out, _, gr = m(*inp)
+                    ((out * gsel.to(out.dtype)).sum() + 0.1 * gr.sum()).backward()
+                    assert not queue
+                finally:
+                    R.F.dropout = orig
+                res.append((out.detach(), gr.detach(), {k: q.grad.clone() for k, q in m.named_parameters() if q.grad is not None}))
+            (o32, g32, p32), (o64, g64, p64) = res
+            tag = '%s/%s%d' % (structure, 'graph' if graph else 'eager', rep)
+            assert rel_err(out_h.detach().cpu(), o32, tag + ' out') < TOL
+            assert rel_err(gr_h.detach().cpu(), g32, tag + ' graph_rep') < TOL
+            gh = {k: q.grad for k, q in hip.named_parameters() if q.grad is not None}
+            assert set(gh) == set(p32)
+            scale = max(v.abs().max().item() for v in p32.values())
+            for k in gh:
+                try:
+                    assert_grad_close(gh[k], p32[k], scale, '%s %s' % (tag, k), rtol=2e-5, floor=2e-6)
+                except AssertionError:
+                    e_ref = (p32[k].double() - p64[k]).abs().max().item()
+                    e_hip = (gh[k].double().cpu() - p64[k]).abs().max().item()
+                    if e_hip > 4.0 * e_ref + 2e-6 * scale:
+                        ok = False                      # an activation on the relu boundary: next seed
+                        break
+            if not ok:
+                break
+            # (running statistics move every rep; they are compared against the golden vectors elsewhere)
+        if ok:
+            return
+    raise AssertionError('no seed without an ill-conditioned (relu boundary) instance')
