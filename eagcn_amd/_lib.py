@@ -119,6 +119,7 @@ SIGNATURES = {
                                        _fp, _fp, C.POINTER(LayerGrads), C.POINTER(HeadGrads), _fp]),
     'eagcn_bce_loss': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     'eagcn_mse_loss': (C.c_int, [_fp, _fp, C.c_int, _fp, _fp, _fp]),
+    'eagcn_eval_append': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int64, _fp]),
     'eagcn_prof_enable': (None, [C.c_int]),
     'eagcn_prof_reset': (None, []),
     'eagcn_prof_ntags': (C.c_int, []),

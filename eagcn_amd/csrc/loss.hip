@@ -88,9 +88,35 @@ __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict_
     }
 }
 
+// Evaluation outputs (train.py:130-211): the reference moves every batch's logits to the host, applies sigmoid there and
+// walks B x T Python lists to drop the missing labels.  Here a batch is APPENDED to device-resident [cap, T] buffers:
+// score = sigmoid(logit) (classification) or the prediction itself (regression), valid = label in {0, 1} (classification) or
+// always 1; the metrics (AUC per task, RMSE) are then computed once over the buffers (eagcn_amd/training.py).
+__global__ __launch_bounds__(256) void eval_append_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                           int n, int classification, float* __restrict__ scores,
+                                                           float* __restrict__ targets, uint8_t* __restrict__ valid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = logits[i], y = labels[i];
+    scores[i] = classification ? 1.0f / (1.0f + expf(-x)) : x;
+    targets[i] = y;
+    valid[i] = classification ? ((y == 0.0f || y == 1.0f) ? 1 : 0) : 1;
+}
+
 }  // namespace eagcn
 
 using namespace eagcn;
+
+extern "C" int eagcn_eval_append(const float* logits, const float* labels, int B, int T, int classification, float* scores,
+                                 float* targets, uint8_t* valid, int64_t row_offset, void* stream) {
+    EAGCN_CHECK_ARG(logits && labels && scores && targets && valid, "eagcn_eval_append: null argument");
+    EAGCN_CHECK_ARG(B > 0 && T > 0 && row_offset >= 0, "eagcn_eval_append: bad sizes");
+    const int n = B * T;
+    const size_t o = (size_t)row_offset * T;
+    eval_append_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(logits, labels, n, classification, scores + o, targets + o, valid + o);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
 
 extern "C" int eagcn_bce_loss(const float* logits, const float* labels, const float* class_weight, int B, int T,
                               float* loss, float* dlogits, void* stream) {

@@ -257,6 +257,11 @@ int eagcn_bce_loss(const float* logits, const float* labels, const float* class_
                    float* loss, float* dlogits, void* stream);
 int eagcn_mse_loss(const float* pred, const float* target, int n, float* loss, float* dpred, void* stream);
 
+/* ---- evaluation outputs (train.py:130-211): append one batch to device-resident [cap][T] buffers at row `row_offset`:
+ * scores = sigmoid(logits) (classification = 1) or the predictions (0), targets = labels, valid = label in {0,1} / 1 ---- */
+int eagcn_eval_append(const float* logits, const float* labels, int B, int T, int classification, float* scores,
+                      float* targets, uint8_t* valid, int64_t row_offset, void* stream);
+
 /* Matrix-core path of the layer products: 0 = fp32 MFMA (default: exact fp32 products, the reference's torch.mm
  * semantics, layers.py:40), 1 = every fp32 operand split exactly into three bf16 pieces and six bf16 MFMA
  * products accumulated in fp32 (same accuracy, see csrc/gemm_x6.h).  Returns the previous mode. */

@@ -154,3 +154,54 @@ def test_compat_modules_expose_reference_names():
         sys.path.remove(os.path.join(ROOT, 'compat'))
         sys.modules.pop('models', None)
         sys.modules.pop('layers', None)
+
+
+def test_eval_metrics_match_sklearn():
+    """train.py:156-186 (roc_curve + auc per task over the labelled entries) and train.py:188-211 (RMSE) as tensor ops."""
+    from sklearn import metrics
+    from eagcn_amd.training import auc_per_task, rmse, set_weight
+    g = torch.Generator().manual_seed(3)
+    n, T = 500, 4
+    scores = torch.rand(n, T, generator=g)
+    scores[:, 1] = (scores[:, 1] * 5).round() / 5                   # heavy ties
+    labels = torch.randint(-1, 2, (n, T), generator=g).float()      # -1 = missing
+    labels[:, 3] = torch.where(labels[:, 3] == 1, torch.zeros(()), labels[:, 3])   # a task without positives
+    valid = (labels == 0) | (labels == 1)
+    aucs, mean = auc_per_task(scores, labels, valid)
+    want = []
+    for j in range(T):
+        m = valid[:, j].numpy()
+        y, s = labels[:, j].numpy()[m], scores[:, j].numpy()[m]
+        if y.min() == y.max():
+            want.append(float('nan'))
+            continue
+        fpr, tpr, _ = metrics.roc_curve(y.astype(int), s, pos_label=1)
+        want.append(metrics.auc(fpr, tpr))
+    for a, w in zip(aucs, want):
+        assert (np.isnan(a) and np.isnan(w)) or abs(a - w) < 1e-12, (aucs, want)
+    assert abs(mean - np.nanmean(want)) < 1e-12
+    pred, tgt = torch.randn(300, 1, generator=g), torch.randn(300, 1, generator=g)
+    assert abs(rmse(pred, tgt) - np.sqrt(metrics.mean_squared_error(pred.numpy().ravel(), tgt.numpy().ravel()))) < 1e-6
+    w = set_weight(labels, T)
+    assert abs(w[0][0] - (int(valid[:, 0].sum()) / max(int((labels[:, 0] == 1).sum()), 1))) < 1e-12
+
+
+def test_model_pickles_and_deepcopies_after_planning():
+    """The reference checkpoints with torch.save(model, ...) (train.py:440): the cached ctypes descriptors / graph runners
+    must not travel with the module."""
+    import copy
+    import io
+    from eagcn_amd import EAGCN
+    m = EAGCN(7, 24, *[8, 6, 4, 4, 5], *[10, 7, 5, 6, 4], 16, 8, 3, 0.2, n_layers=2, graph=True)
+    plan = m.plan()
+    plan.cmodel(True, 1, 0.2)                       # populates the ctypes cache (no GPU needed)
+    m._runners['fake'] = object()
+    c = copy.deepcopy(m)
+    assert c._plan is None and c._runners == {} and m._plan is plan
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    r = torch.load(buf, weights_only=False)
+    assert r._plan is None and r._runners == {}
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), r.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
