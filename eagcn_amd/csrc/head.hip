@@ -7,9 +7,9 @@
 //             -> den3                                                      (models.py:112-120)
 //   backward: the exact reverse, producing every parameter gradient.
 //
-// The head's BatchNorm1d layers work on [B, F] matrices.  BatchNorm over rows is independent per
-// column, so one workgroup that owns 16 columns does statistics AND normalisation for them in a
-// single kernel (no grid-wide reduction): rowbn_fwd_kernel / rowbn_bwd_kernel.
+// The head's dense layers and BatchNorm1d layers live in head2.hip: the producer of a matrix takes its
+// column sums in the epilogue, the consumer normalises on the operand load, so no BatchNorm has a
+// kernel of its own (except Graph_BN's backward, which has no dense layer in front of it).
 #include <stdlib.h>
 
 #include <algorithm>
@@ -20,219 +20,6 @@
 namespace eagcn {
 
 enum { RB_SC = 0, RB_SH, RB_MU, RB_INV };
-constexpr int HEAD_MAX_SPLITS = 16;   // split-K factor bound of the head's weight-gradient products
-
-struct RowBnFwd {
-    int R, F;
-    const float* x; float* y;            // [R][F]
-    int splits; size_t stride;           // x is the sum of `splits` partial matrices `stride` floats apart (split-K)
-    float* xs;                           // splits > 1: the summed x is stored here (kept for backward)
-    float* x2;                           // optional second copy of x (graph_representation)
-    const float* gamma; const float* beta;
-    float* run_mean; float* run_var;
-    float* bn;                           // [4][F]
-    int training, relu, do_drop;
-    float eps, momentum;
-    uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
-};
-
-// Row BatchNorm: a workgroup owns 16 columns and RL "row lanes" per column (thread = 16*row_lane + column,
-// so 16 adjacent lanes read 64 contiguous bytes of one row).  Every lane keeps RB_CACHE of its rows in
-// registers: the statistics pass and the normalisation pass share ONE batch of loads when R <= RL*RB_CACHE.
-// RL = 16 (256 threads) up to 64 rows, 64 (1024 threads) beyond; 4 cached rows per lane up to 256 rows, 16 beyond.
-
-template <int RL, int RB_CACHE>
-__global__ __launch_bounds__(16 * RL) void rowbn_fwd_kernel(RowBnFwd a) {
-    __shared__ double red[RL / 4][16][2];
-    __shared__ float par[16][2];
-    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
-    const int col_l = threadIdx.x & 15, rl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
-    const int cr = blockIdx.x * 16 + col_l;
-    const int c = min(cr, a.F - 1);
-    constexpr int CH = RL * RB_CACHE;                 // rows per chunk (one batch of loads per lane)
-    float v[RB_CACHE];
-    auto load_chunk = [&](int base) {
-#pragma unroll
-        for (int t = 0; t < RB_CACHE; ++t) {
-            const int r = base + rl + RL * t;
-            v[t] = r < a.R ? a.x[(size_t)r * a.F + c] : 0.0f;
-        }
-        for (int z = 1; z < a.splits; ++z) {           // fixed order: deterministic sum of the split-K partials
-#pragma unroll
-            for (int t = 0; t < RB_CACHE; ++t) {
-                const int r = base + rl + RL * t;
-                if (r < a.R) v[t] += a.x[(size_t)z * a.stride + (size_t)r * a.F + c];
-            }
-        }
-    };
-    // per-column parameters are requested before the statistics pass: together with the first chunk of rows
-    // they are ONE round trip (they used to be a second and a third one after the reduction)
-    const float gam = a.gamma[c], bet = a.beta[c];
-    const float rm0 = a.run_mean[c], rv0 = a.run_var[c];
-    float mu, inv;
-    if (a.training) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int base = 0; base < a.R; base += CH) {
-            load_chunk(base);
-#pragma unroll
-            for (int t = 0; t < RB_CACHE; ++t) {
-                s1 += (double)v[t];
-                s2 += (double)v[t] * (double)v[t];
-            }
-        }
-        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-        if ((threadIdx.x & 63) < 16) { red[wave][col_l][0] = s1; red[wave][col_l][1] = s2; }
-        __syncthreads();
-        if (threadIdx.x < 16) {
-            double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-            for (int w = 0; w < RL / 4; ++w) { t1 += red[w][col_l][0]; t2 += red[w][col_l][1]; }
-            const double mean = t1 / a.R;
-            double var = t2 / a.R - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            par[col_l][0] = (float)mean;
-            par[col_l][1] = (float)(1.0 / sqrt(var + (double)a.eps));
-            if (cr < a.F) {
-                const double unbiased = var * ((double)a.R / ((double)a.R - 1.0));
-                a.run_mean[c] = (float)((1.0 - a.momentum) * (double)rm0 + a.momentum * mean);
-                a.run_var[c] = (float)((1.0 - a.momentum) * (double)rv0 + a.momentum * unbiased);
-            }
-        }
-        __syncthreads();
-        mu = par[col_l][0];
-        inv = par[col_l][1];
-    } else {
-        mu = rm0;
-        inv = 1.0f / sqrtf(rv0 + a.eps);
-    }
-    const float sc = gam * inv, sh = bet - mu * sc;
-    if (cr >= a.F) return;
-    if (rl == 0) {
-        a.bn[RB_SC * a.F + c] = sc;
-        a.bn[RB_SH * a.F + c] = sh;
-        a.bn[RB_MU * a.F + c] = mu;
-        a.bn[RB_INV * a.F + c] = inv;
-    }
-    for (int base = 0; base < a.R; base += CH) {
-        if (a.R > CH || !a.training) load_chunk(base);    // a single chunk is still in registers
-#pragma unroll
-        for (int t = 0; t < RB_CACHE; ++t) {
-            const int r = base + rl + RL * t;
-            if (r < a.R) {
-                if (a.splits > 1) a.xs[(size_t)r * a.F + c] = v[t];
-                if (a.x2) a.x2[(size_t)r * a.F + c] = v[t];
-                float h = v[t] * sc + sh;
-                if (a.relu) h = fmaxf(h, 0.0f);
-                if (a.do_drop) h *= drop_scale(seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
-                a.y[(size_t)r * a.F + c] = h;
-            }
-        }
-    }
-}
-
-struct RowBnBwd {
-    int R, F;
-    const float* dy; const float* x; const float* bn;
-    int splits; size_t stride;           // dy is the sum of `splits` split-K partials `stride` floats apart
-    const float* extra;                  // added to dx (gradient that reaches x directly), or null
-    float* dx; float* dgamma; float* dbeta;
-    int training, relu, do_drop;
-    uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
-};
-
-template <int RL, int RB_CACHE>
-__global__ __launch_bounds__(16 * RL) void rowbn_bwd_kernel(RowBnBwd a) {
-    __shared__ double red[RL / 4][16][2];
-    __shared__ double tot[16][2];
-    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
-    const int col_l = threadIdx.x & 15, rl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
-    const int cr = blockIdx.x * 16 + col_l;
-    const int c = min(cr, a.F - 1);
-    const float sc = a.bn[RB_SC * a.F + c], sh = a.bn[RB_SH * a.F + c];
-    const float mu = a.bn[RB_MU * a.F + c], inv = a.bn[RB_INV * a.F + c];
-    constexpr int CH = RL * RB_CACHE;
-    float xv[RB_CACHE], dh[RB_CACHE];
-    auto load_chunk = [&](int base) {                  // x and the gradient that reaches the BatchNorm output
-#pragma unroll
-        for (int t = 0; t < RB_CACHE; ++t) {
-            const int r = base + rl + RL * t;
-            xv[t] = r < a.R ? a.x[(size_t)r * a.F + c] : 0.0f;
-            dh[t] = r < a.R ? a.dy[(size_t)r * a.F + c] : 0.0f;
-        }
-        for (int z = 1; z < a.splits; ++z) {
-#pragma unroll
-            for (int t = 0; t < RB_CACHE; ++t) {
-                const int r = base + rl + RL * t;
-                if (r < a.R) dh[t] += a.dy[(size_t)z * a.stride + (size_t)r * a.F + c];
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < RB_CACHE; ++t) {
-            const int r = base + rl + RL * t;
-            if (a.do_drop && r < a.R) dh[t] *= drop_scale(seed, (uint64_t)r * a.F + c, a.thr, a.inv_keep);
-            if (a.relu && !(xv[t] * sc + sh > 0.0f)) dh[t] = 0.0f;
-        }
-    };
-    double s1 = 0.0, s2 = 0.0;
-    for (int base = 0; base < a.R; base += CH) {
-        load_chunk(base);
-#pragma unroll
-        for (int t = 0; t < RB_CACHE; ++t) {
-            s1 += (double)dh[t];
-            s2 += (double)(dh[t] * ((xv[t] - mu) * inv));
-        }
-    }
-    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-    if ((threadIdx.x & 63) < 16) { red[wave][col_l][0] = s1; red[wave][col_l][1] = s2; }
-    __syncthreads();
-    if (threadIdx.x < 16) {
-        double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-        for (int w = 0; w < RL / 4; ++w) { t1 += red[w][col_l][0]; t2 += red[w][col_l][1]; }
-        tot[col_l][0] = t1;
-        tot[col_l][1] = t2;
-        if (cr < a.F) {
-            a.dgamma[c] = (float)t2;
-            a.dbeta[c] = (float)t1;
-        }
-    }
-    __syncthreads();
-    if (cr >= a.F) return;
-    const float c1 = a.training ? (float)(tot[col_l][0] / a.R) : 0.0f;
-    const float c2 = a.training ? (float)(tot[col_l][1] / a.R) : 0.0f;
-    for (int base = 0; base < a.R; base += CH) {
-        if (a.R > CH) load_chunk(base);                    // a single chunk is still in registers
-#pragma unroll
-        for (int t = 0; t < RB_CACHE; ++t) {
-            const int r = base + rl + RL * t;
-            if (r < a.R) {
-                float o = sc * (dh[t] - c1 - (xv[t] - mu) * inv * c2);
-                if (a.extra) o += a.extra[(size_t)r * a.F + c];
-                a.dx[(size_t)r * a.F + c] = o;
-            }
-        }
-    }
-}
-
-// C[i] = sum_z slab[z][i] for up to three result matrices in one launch (split-K partials of the head's three
-// weight-gradient products)
-struct Reduce3 { const float* slab[3]; float* out[3]; int n[3]; int splits[3]; };
-__global__ __launch_bounds__(256) void splitk_reduce3_kernel(Reduce3 a) {
-    const int n0 = a.n[0], n1 = a.n[1], n2 = a.n[2];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1 + n2; i += gridDim.x * blockDim.x) {
-        const int w = i < n0 ? 0 : (i < n0 + n1 ? 1 : 2);
-        const int e = i - (w == 0 ? 0 : (w == 1 ? n0 : n0 + n1));
-        const float* slab = w == 0 ? a.slab[0] : (w == 1 ? a.slab[1] : a.slab[2]);
-        float* out = w == 0 ? a.out[0] : (w == 1 ? a.out[1] : a.out[2]);
-        const int n = w == 0 ? n0 : (w == 1 ? n1 : n2);
-        const int splits = w == 0 ? a.splits[0] : (w == 1 ? a.splits[1] : a.splits[2]);
-        float s0 = 0.0f;
-        for (int z = 0; z < splits; ++z) s0 += slab[(size_t)z * n + e];
-        out[e] = s0;
-    }
-}
 
 // ---- carving of the saved-for-backward block and of the transient scratch ---------------------------
 struct Carver2 {
@@ -251,7 +38,7 @@ struct LayerSaved { float *P, *Y, *rscale, *bn, *xout, *pad_row; void* packed; s
 struct ModelSaved {
     float* x0;
     LayerSaved L[4];
-    float *g, *gn, *h1, *a1, *h2, *a2, *bn_g, *bn_1, *bn_2;
+    float *g, *h1, *h2, *bn_g, *bn_1, *bn_2;     // pre-BatchNorm matrices + [4][F] BN coefficient tables (the consumers re-normalise)
     uint16_t* pad_cnt;           // [B][K][ldo]: kept non-stored rows per (molecule, view, column) (readout.hip), or unused
     float* padc;                 // [B][ldo]
     size_t xout_last_off, pad_last_off;
@@ -287,11 +74,8 @@ static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m
     const eagcn_head_params* h = &m->head;
     const size_t B = (size_t)b->B;
     s.g = c.take<float>(B * h->f_in);
-    s.gn = c.take<float>(B * h->f_in);
     s.h1 = c.take<float>(B * h->n_den1);
-    s.a1 = c.take<float>(B * h->n_den1);
     s.h2 = c.take<float>(B * h->n_den2);
-    s.a2 = c.take<float>(B * h->n_den2);
     s.bn_g = c.take<float>((size_t)4 * h->f_in);
     s.bn_1 = c.take<float>((size_t)4 * h->n_den1);
     s.bn_2 = c.take<float>((size_t)4 * h->n_den2);
@@ -307,7 +91,7 @@ static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m
 }
 
 struct ModelScratch {
-    float *da2, *dh2, *da1, *dh1, *dgn, *dg, *dxa, *dxb, *dpad, *gsplit, *gsplit2, *gw1, *gw2, *gw3;
+    float *da2, *da1, *dgn, *dg, *dxa, *dxb, *dpad;
     double* hst; int n_hst;      // BatchNorm sums of the head: [f_in + n_den1 + n_den2][2], cleared at the start of each call
     void* layer; size_t layer_bytes;
 };
@@ -319,22 +103,9 @@ static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model*
     s.n_hst = 2 * (h->f_in + h->n_den1 + h->n_den2);
     s.hst = c.take<double>((size_t)s.n_hst);
     s.da2 = c.take<float>(B * h->n_den2);
-    s.dh2 = c.take<float>(B * h->n_den2);
     s.da1 = c.take<float>(B * h->n_den1);
-    s.dh1 = c.take<float>(B * h->n_den1);
     s.dgn = c.take<float>(B * h->f_in);
     s.dg = c.take<float>(B * h->f_in);
-    {
-        const size_t Bn = (size_t)b->B;
-        size_t mx = std::max((size_t)h->f_in * h->n_den1, (size_t)h->n_den1 * h->n_den2);
-        mx = std::max(mx, Bn * (size_t)std::max(h->f_in, std::max(h->n_den1, h->n_den2)));
-        s.gsplit = c.take<float>((size_t)HEAD_MAX_SPLITS * mx);
-        s.gsplit2 = c.take<float>((size_t)HEAD_MAX_SPLITS * mx);
-        // split-K partials of the three weight gradients (alive together: one grouped launch)
-        s.gw1 = c.take<float>((size_t)HEAD_MAX_SPLITS * h->f_in * h->n_den1);
-        s.gw2 = c.take<float>((size_t)HEAD_MAX_SPLITS * h->n_den1 * h->n_den2);
-        s.gw3 = c.take<float>((size_t)HEAD_MAX_SPLITS * h->n_den2 * h->nclass);
-    }
     int ldmax = 0;
     size_t lbytes = 0;
     for (int l = 0; l < m->n_layers; ++l) {
@@ -385,111 +156,6 @@ static void fill_drop(float p, int training, int* do_drop, uint32_t* thr, float*
     *do_drop = (training && p > 0.0f) ? 1 : 0;
     *thr = (uint32_t)std::min(4294967295.0, (double)p * 4294967296.0);
     *inv_keep = 1.0f / (1.0f - p);
-}
-
-static int rowbn_wide_rows() {
-    static const int v = [] { const char* e = getenv("EAGCN_ROWBN_WIDE"); return e ? atoi(e) : 64; }();
-    return v;
-}
-// a matrix that may still be `splits` split-K partials `stride` floats apart (summed by its consumer)
-struct Partial { const float* p; int splits; size_t stride; };
-
-static int rowbn_fwd(hipStream_t s, int R, int F, Partial x, float* xs, float* x2, float* y, const float* g,
-                     const float* be, float* rm, float* rv, float* bn, int training, int relu, float dropout,
-                     uint64_t seed, const uint64_t* seed_dev, float eps, float mom) {
-    RowBnFwd a;
-    a.R = R; a.F = F; a.x = x.p; a.splits = x.splits; a.stride = x.stride; a.xs = xs; a.x2 = x2; a.y = y;
-    a.gamma = g; a.beta = be; a.run_mean = rm; a.run_var = rv; a.bn = bn;
-    a.training = training; a.relu = relu; a.eps = eps; a.momentum = mom; a.seed = seed; a.seed_dev = seed_dev;
-    fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
-    ProfScope ps(PROF_HEAD, s);
-    // row lanes x rows cached per lane: one batch of loads covers all R rows whenever R <= RL * cache
-    if (R <= rowbn_wide_rows()) rowbn_fwd_kernel<16, 4><<<cdiv(F, 16), 256, 0, s>>>(a);
-    else if (R <= 256) rowbn_fwd_kernel<64, 4><<<cdiv(F, 16), 1024, 0, s>>>(a);
-    else rowbn_fwd_kernel<64, 16><<<cdiv(F, 16), 1024, 0, s>>>(a);
-    EAGCN_LAUNCH_CHECK();
-    return EAGCN_OK;
-}
-static int rowbn_bwd(hipStream_t s, int R, int F, Partial dy, const float* x, const float* bn,
-                     const float* extra, float* dx, float* dgamma, float* dbeta, int training, int relu,
-                     float dropout, uint64_t seed, const uint64_t* seed_dev) {
-    RowBnBwd a;
-    a.R = R; a.F = F; a.dy = dy.p; a.splits = dy.splits; a.stride = dy.stride; a.x = x; a.bn = bn; a.extra = extra;
-    a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta;
-    a.training = training; a.relu = relu; a.seed = seed; a.seed_dev = seed_dev;
-    fill_drop(dropout, training, &a.do_drop, &a.thr, &a.inv_keep);
-    ProfScope ps(PROF_HEAD, s);
-    if (R <= rowbn_wide_rows()) rowbn_bwd_kernel<16, 4><<<cdiv(F, 16), 256, 0, s>>>(a);
-    else if (R <= 256) rowbn_bwd_kernel<64, 4><<<cdiv(F, 16), 1024, 0, s>>>(a);
-    else rowbn_bwd_kernel<64, 16><<<cdiv(F, 16), 1024, 0, s>>>(a);
-    EAGCN_LAUNCH_CHECK();
-    return EAGCN_OK;
-}
-static int mm(hipStream_t s, int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
-              int ldb, float* C, int ldc) {
-    GemmDesc g{ta, tb, M, N, K, A, lda, B, ldb, C, ldc, 1, 0};
-    g.prof_tag = PROF_HEAD;
-    return launch_gemm(g, s);
-}
-
-// The head's products have few output tiles (B x 256, 700 x 256, ...) and a comparatively long K: with one
-// workgroup per tile they occupy a few percent of the chip and are a serial chain of k-tiles (256x256x700:
-// 16 workgroups, 28 us).  Split K over more workgroups; the partial slabs are summed by the CONSUMER of the
-// product (the row-BatchNorm kernels read `splits` partials), so no separate reduction launch exists on the
-// activation path.
-static int head_splits(int tiles, int K) {
-    static const int div = [] { const char* e = getenv("EAGCN_HEAD_KDIV"); return e ? atoi(e) : 128; }();
-    if (tiles >= 96 || K < 2 * div) return 1;
-    const int by_k = K / div;                                 // at least div/16 k-tiles per split
-    const int by_fill = cdiv(256, std::max(tiles, 1));        // aim at ~one workgroup per CU
-    return std::max(1, std::min(std::min(HEAD_MAX_SPLITS, by_k), by_fill));
-}
-static bool split_ok(int ta, int tb, int M, int N, int K, int lda, int ldb) {
-    // split-K needs float4-aligned operands and a dense [M][N] result
-    return (lda % 4) == 0 && (ldb % 4) == 0 && ((ta ? M : K) % 4) == 0 && ((tb ? K : N) % 4) == 0;
-}
-// C = A.B, or its split-K partials in `slab` (then *out describes them and C is NOT written)
-static int mm_partial(hipStream_t s, int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
-                      int ldb, float* C, float* slab, Partial* out) {
-    const int splits = split_ok(ta, tb, M, N, K, lda, ldb) ? head_splits(cdiv(M, 64) * cdiv(N, 64), K) : 1;
-    if (splits == 1) {
-        *out = Partial{C, 1, 0};
-        return mm(s, ta, tb, M, N, K, A, lda, B, ldb, C, N);
-    }
-    GemmDesc g{ta, tb, M, N, K, A, lda, B, ldb, slab, N, splits, (size_t)M * N};
-    g.prof_tag = PROF_HEAD;
-    *out = Partial{slab, splits, (size_t)M * N};
-    return launch_gemm(g, s);
-}
-// the three weight gradients dW_i = A_i^T . B_i (rows = batch) as one grouped launch + one reduction launch
-struct DwProblem { int M, N; const float* A; const float* B; float* C; float* slab; };
-static int head_dw(hipStream_t s, int K, const DwProblem* pr, const GemmDesc* lead = nullptr) {
-    int tiles = 0;
-    bool ok = true;
-    for (int i = 0; i < 3; ++i) {
-        tiles += cdiv(pr[i].M, 64) * cdiv(pr[i].N, 64);
-        ok = ok && split_ok(1, 0, pr[i].M, pr[i].N, K, pr[i].M, pr[i].N);
-    }
-    // one grouped launch already fills ~50 workgroups; splitting K only pays once the chain of k-tiles is long
-    // (K = batch size: 256 -> 16 k-tiles, shorter than a reduction launch)
-    const int splits = (ok && K >= 1024) ? head_splits(tiles, K) : 1;
-    GemmDesc d[3];
-    Reduce3 r;
-    int total = 0;
-    for (int i = 0; i < 3; ++i) {
-        float* dst = splits > 1 ? pr[i].slab : pr[i].C;
-        d[i] = GemmDesc{1, 0, pr[i].M, pr[i].N, K, pr[i].A, pr[i].M, pr[i].B, pr[i].N, dst, pr[i].N, splits,
-                        (size_t)pr[i].M * pr[i].N};
-        d[i].prof_tag = PROF_HEAD;
-        r.slab[i] = pr[i].slab; r.out[i] = pr[i].C; r.n[i] = pr[i].M * pr[i].N; r.splits[i] = splits;
-        total += r.n[i];
-    }
-    int rc = launch_gemm_group(d, 3, s, lead);
-    if (rc || splits == 1) return rc;
-    ProfScope ps(PROF_HEAD, s);
-    splitk_reduce3_kernel<<<std::min(cdiv(total, 256), 1024), 256, 0, s>>>(r);
-    EAGCN_LAUNCH_CHECK();
-    return EAGCN_OK;
 }
 
 }  // namespace eagcn
