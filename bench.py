@@ -61,7 +61,8 @@ def build_model(cfg, dropout, device, graph=False):
     # batches are valid by construction -- both are reported in the JSON `config`
     m = EAGCN(cfg['n_bfeat'], 24, n_den1=cfg['dens'][0], n_den2=cfg['dens'][1], nclass=cfg['nclass'], dropout=dropout,
               widths1=cfg['widths1'], widths2=cfg['widths2'], rel_channels=rel_channels(cfg), structure=cfg['structure'],
-              n_layers=cfg['n_layers'], atom_rep='lazy', grad_mode='direct', overlap_index=True, graph=graph,
+              n_layers=cfg['n_layers'], atom_rep='lazy', grad_mode='direct',
+              overlap_index=os.environ.get('EAGCN_BENCH_OVERLAP', '1') == '1', graph=graph,
               graph_outputs='static', validate='deferred')
     m.apply(weights_init)
     return m.to(device)
@@ -179,9 +180,21 @@ def run_workload(name, B, args, lib, dev, rank, world, reducer_cls, detail):
     reducer = reducer_cls(model.parameters(), model=model)
     params = list(model.parameters())
 
+    fused = (not args.eager) and not args.separate_graphs
+
     def step():
         for p in params:            # optimizer.zero_grad(set_to_none=True) of the reference loop (train.py:317)
             p.grad = None
+        if fused and model.graph:
+            # forward + loss + backward as ONE captured graph (EAGCN.fused_step, what eagcn_amd.training.train_step runs)
+            scale = None
+            if world > 1 and cfg['task'] == 'class':
+                from eagcn_amd.parallel import dp_loss_scale
+                scale = dp_loss_scale(labels)
+            batch = dense if compact is None else (compact[1], compact[2])
+            loss, _ = model.fused_step(batch, labels, cfg['task'], bce_w_dev, scale, bonds=None if compact is None else compact[0])
+            reducer()
+            return loss
         out, _, _ = model(*dense) if compact is None else model.forward_compact(*compact)
         if cfg['task'] == 'class':
             loss = fused_classification_loss(out, labels, bce_w_dev, dp_global_norm=(world > 1))
@@ -284,6 +297,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the extra single-GPU shapes (north-star batch 1024, HIV, Lipo, C5)')
     ap.add_argument('--eager', action='store_true', help='eager launches instead of HIP-graph replay')
+    ap.add_argument('--separate-graphs', action='store_true', help='graph mode with separate forward / backward graphs and an eager loss kernel '
+                    '(the nn.Module call sequence) instead of the single whole-step graph')
     ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--eval-throughput', action='store_true',
                     help='also time the eval-mode forward (forward-only graph under no_grad); reported as an extra field')
@@ -349,7 +364,7 @@ def main():
             'layer_gemm_tflops_all': round(((kern['gemm'][1] + kern.get('gemm_pair', (0, 0, 0))[1]) /
                                             max((kern['gemm'][0] + kern.get('gemm_pair', (0, 0, 0))[0]) * 1e-3, 1e-12)) / 1e12, 3),
             'kernel_ms_per_step': {k: round(v[0] / prof_steps, 4) for k, v in kern.items()},
-            'execution': 'eager launches' if args.eager else 'HIP graph replay (forward + backward), eager batch index',
+            'execution': 'eager launches' if args.eager else ('HIP graph replay (forward graph, eager loss kernel, backward graph), eager batch index' if args.separate_graphs else 'one HIP graph per step (forward + fused loss + backward; EAGCN.fused_step), eager batch index'),
         }
         if 'eval_forward' in res:
             out['eval_forward'] = res['eval_forward']

@@ -84,7 +84,8 @@ class GraphRunner:
         self.key = (B, N, tuple(channels))
         self.slots = [StaticIndex(B, N, channels, device, row_cap if row_cap else B * N) for _ in range(2)]
         self.index = self.slots[0]
-        self.graphs = [[None, None], [None, None]]            # per slot: [forward graph, backward graph]
+        self.graphs = [[None, None, None], [None, None, None]]   # per slot: [forward, backward, whole step (fused loss)]
+        self.step_kind = [None, None]
         self.entry_events = [None, None]                      # main-stream position at the last two forward entries
         self.fwd_done = None                                  # main-stream position after the last forward graph
         self.dropout = float(dropout)
@@ -113,6 +114,12 @@ class GraphRunner:
         self.dout = torch.zeros((B, m.head.nclass), **f32)
         self.dgr = torch.zeros((B, m.head.n_den2), **f32)
         self.dgr_is_zero = True
+        self._weight_src = None
+        # fused training step (forward + loss + backward in ONE graph): labels per slot, class weights, loss value, DP scale
+        self.labels_static = [torch.zeros((B, m.head.nclass), **f32) for _ in range(2)]
+        self.weight_static = torch.zeros((m.head.nclass, 2), **f32)
+        self.loss_static = [torch.zeros((), **f32) for _ in range(2)]
+        self.scale_static = torch.ones((), **f32)
         n = plan.offsets[-1]
         self.flat_acc = torch.zeros(n, **f32)               # the captured backward writes here; p.grad are views of it
         pieces = self.flat_acc.split(plan.sizes)
@@ -135,7 +142,7 @@ class GraphRunner:
     def release(self):
         """Drop the captured graphs and every static buffer (eviction from EAGCN._runners)."""
         torch.cuda.synchronize(self.device)
-        self.graphs = [[None, None], [None, None]]
+        self.graphs = [[None, None, None], [None, None, None]]
         self.saved, self.scratch, self.slots, self.index = [], None, [], None
         self._xout_views, self._pad_views = [], []
 
@@ -220,7 +227,7 @@ class GraphRunner:
             bwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(bwd, capture_error_mode='thread_local'):
                 self._call_backward()
-        self.graphs[self.cur] = [fwd, bwd]
+        self.graphs[self.cur][0], self.graphs[self.cur][1] = fwd, bwd
 
     # -- per-step entry points -----------------------------------------------------------------------
     def _check_old_batches(self, force=False):
@@ -241,7 +248,9 @@ class GraphRunner:
                 raise L.EagcnHipError('a previous batch packed %d rows, more than row_cap=%d (it was processed as an '
                                       'empty batch; no memory was overwritten)' % (meta[L.META_OVERFLOW], self.slots[0].T))
 
-    def forward(self, adj, rels, afm, size, seed, overlap=False, bonds=None):
+    def _prepare(self, adj, rels, afm, size, seed, overlap=False, bonds=None, labels=None):
+        """Everything of a step that reads the caller's tensors (index build, packed input, seeds, sizes, labels of a fused
+        step), on the side stream when `overlap`; afterwards the main stream is ordered behind it."""
         lib = L.load()
         self._check_old_batches()
         self.cur = cur = self.step % 2
@@ -266,7 +275,7 @@ class GraphRunner:
             # layer GEMMs and aggregations)
             if self.fwd_done is not None and _SIDE_AFTER_FWD:
                 side.wait_event(self.fwd_done)
-            for t in (afm, adj, size) + tuple(rels or ()) + tuple(bonds or ()):
+            for t in (afm, adj, size, labels) + tuple(rels or ()) + tuple(bonds or ()):
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(side)                     # read on the side stream after this call returns
         else:
@@ -294,6 +303,8 @@ class GraphRunner:
             self.seeds_dev[cur].copy_(sh, non_blocking=True)
             if self.plan.molfp:
                 self.size_static[cur].copy_(size, non_blocking=True)
+            if labels is not None:
+                self.labels_static[cur].copy_(labels.reshape(self.labels_static[cur].shape), non_blocking=True)
         ev = torch.cuda.Event()           # meta_host[slot] is valid and seeds_host[slot] is free again after this point
         ev.record(side)
         self.meta_event[slot] = ev
@@ -323,6 +334,11 @@ class GraphRunner:
         self.generation += 1
         if self.training:
             self.plan.nbt_pending += 1    # num_batches_tracked: counted on the host, written by ModelPlan.flush_nbt()
+        return main
+
+    def forward(self, adj, rels, afm, size, seed, overlap=False, bonds=None):
+        main = self._prepare(adj, rels, afm, size, seed, overlap, bonds)
+        cur = self.cur
         if self.graphs[cur][0] is None:
             self._call_forward()                              # first use of a slot: eager (and the capture warm-up)
             self._capture()
@@ -353,17 +369,24 @@ class GraphRunner:
         elif not self.dgr_is_zero:
             self.dgr.zero_()
             self.dgr_is_zero = True
-        params, views = self.plan.params, self.acc_views
-        grads = [p.grad for p in params]
-        # the captured backward OVERWRITES flat_acc (the storage p.grad are views of); if gradients of an earlier
-        # backward are still attached (accumulation across backward calls) keep them and add afterwards
-        keep = None
-        if any(g is v for g, v in zip(grads, views)):
-            keep = self.flat_acc.clone()
+        keep, grads = self._before_grads()
         if self.graphs[self.cur][1] is None:
             self._call_backward()
         else:
             self.graphs[self.cur][1].replay()
+        self._attach_grads(keep, grads)
+
+    def _before_grads(self):
+        grads = [p.grad for p in self.plan.params]
+        # the captured backward OVERWRITES flat_acc (the storage p.grad are views of); if gradients of an earlier
+        # backward are still attached (accumulation across backward calls) keep them and add afterwards
+        keep = None
+        if any(g is v for g, v in zip(grads, self.acc_views)):
+            keep = self.flat_acc.clone()
+        return keep, grads
+
+    def _attach_grads(self, keep, grads):
+        params, views = self.plan.params, self.acc_views
         if keep is None and all(g is None for g in grads):
             for p, v in zip(params, views):
                 p.grad = v
@@ -376,6 +399,65 @@ class GraphRunner:
                 v.add_(kept[i] if v.dim() == 1 else kept[i].view(v.shape))
             else:
                 g.add_(v)                                     # a gradient tensor of the caller's: accumulate into it
+
+    # -- fused training step: forward + loss + backward as ONE graph launch -----------------------------
+    def _call_loss(self, kind, scaled):
+        lib = L.load()
+        x, y, cur = self.out, self.labels_static[self.cur], self.cur
+        if kind == 'bce':
+            L.check(lib.eagcn_bce_loss(x.data_ptr(), y.data_ptr(), self.weight_static.data_ptr(), x.shape[0], x.shape[1],
+                                       self.loss_static[cur].data_ptr(), self.dout.data_ptr(), _stream()), 'eagcn_bce_loss')
+        else:
+            L.check(lib.eagcn_mse_loss(x.data_ptr(), y.data_ptr(), x.numel(), self.loss_static[cur].data_ptr(),
+                                       self.dout.data_ptr(), _stream()), 'eagcn_mse_loss')
+        if scaled:                                            # data-parallel global normalisation (parallel.dp_loss_scale)
+            self.dout.mul_(self.scale_static)
+            self.loss_static[cur].mul_(self.scale_static)
+
+    def train_step(self, adj, rels, afm, size, seed, labels, kind, weight=None, scale=None, overlap=False, bonds=None):
+        """forward -> fused loss (csrc/loss.hip) -> backward of one batch as a single captured graph: no launch boundary
+        between the three, one host call per step.  Returns the loss (device scalar); out / graph_representation are read
+        with outputs(), the parameter gradients are attached exactly as backward() does."""
+        if not self.training:
+            raise L.EagcnHipError('train_step needs a training-mode runner')
+        labels = labels.to(device=self.device, dtype=torch.float32)
+        if labels.numel() != self.labels_static[0].numel():
+            raise L.EagcnHipError('train_step: %d labels for logits %s' % (labels.numel(), tuple(self.out.shape)))
+        if kind == 'bce':
+            w = weight.to(device=self.device, dtype=torch.float32)
+            if tuple(w.shape) != tuple(self.weight_static.shape):
+                raise L.EagcnHipError('bce loss: weight %s for %d tasks' % (tuple(w.shape), self.weight_static.shape[0]))
+            tag = (id(w), w._version)
+            if self._weight_src != tag:                       # (class weights change once per run, not per step)
+                self.weight_static.copy_(w)
+                self._weight_src = tag
+        if scale is not None:
+            self.scale_static.copy_(scale)
+        if not self.dgr_is_zero:
+            self.dgr.zero_()
+            self.dgr_is_zero = True
+        keep, grads = self._before_grads()
+        self._prepare(adj, rels, afm, size, seed, overlap, bonds, labels=labels)
+        cur = self.cur
+        key = (kind, scale is not None)
+        if self.graphs[cur][2] is None or self.step_kind[cur] != key:
+            self._call_forward()                              # eager (first use of the slot / of this loss): the warm-up
+            self._call_loss(*key)
+            self._call_backward()
+            torch.cuda.synchronize(self.device)
+            L.load().eagcn_prof_enable(0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                self._call_forward()
+                self._call_loss(*key)
+                self._call_backward()
+            self.graphs[cur][2], self.step_kind[cur] = g, key
+        else:
+            self.graphs[cur][2].replay()
+        self.fwd_done = None            # (no launch boundary after the forward any more: the next index build only waits
+                                        #  for its slot and runs under this step's kernels)
+        self._attach_grads(keep, grads)
+        return self.loss_static[cur].detach() if self.static_outputs else self.loss_static[cur].clone()
 
 
 class _GraphFn(torch.autograd.Function):

@@ -190,7 +190,8 @@ class EAGCN(nn.Module):
         self._runners = {}
         return super()._apply(fn, *a, **kw)
 
-    def _graph_forward(self, adjs, afms, rels, size, bonds=None):
+    def _graph_runner(self, adjs, afms, rels, size, bonds=None):
+        """Validated inputs and the (cached, least-recently-used) GraphRunner of this batch shape."""
         from . import graph as G
         afms = ops._need_cuda_f32(afms, 'afms')
         if bonds is None:
@@ -224,14 +225,43 @@ class EAGCN(nn.Module):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (self.dropout > 0 and self.training) else 0
         if self.molfp_mode == 'ave':
             size = size.to(device=afms.device, dtype=torch.int64)
+        return runner, adjs, rels, afms, size, seed, btuple
+
+    def _atom_rep(self, runner):
+        if self.atom_rep == 'none':
+            return None
+        pad = runner.pad_view if self.structure == 'Weighted_sum' else None
+        rep = LazyAtomRep(runner.index, self.plan().last_layout, runner.xout_view, pad)
+        return rep.cpu() if self.atom_rep == 'eager' else rep
+
+    def _graph_forward(self, adjs, afms, rels, size, bonds=None):
+        from . import graph as G
+        runner, adjs, rels, afms, size, seed, btuple = self._graph_runner(adjs, afms, rels, size, bonds)
         out, graph_representation = G.graph_forward(runner, adjs, rels, afms, size, seed, self.overlap_index, btuple)
-        atom_representations = None
-        if self.atom_rep != 'none':
-            pad = runner.pad_view if self.structure == 'Weighted_sum' else None
-            atom_representations = LazyAtomRep(runner.index, plan.last_layout, runner.xout_view, pad)
-            if self.atom_rep == 'eager':
-                atom_representations = atom_representations.cpu()
-        return out, atom_representations, graph_representation
+        return out, self._atom_rep(runner), graph_representation
+
+    def fused_step(self, batch, labels, task, bce_weight=None, scale=None, bonds=None):
+        """forward -> loss -> backward of one training batch as ONE captured graph launch (graph mode only): the inner
+        loop of train.py:310-334 without the launch boundaries between the three phases.  `batch` is the reference's
+        forward argument tuple (adjs, afms, TypeAtt, ..., size) -- or (afms, size) together with `bonds` for a compact
+        batch; task 'reg' = MSE (train.py:321-325), anything else = weighted masked BCE-with-logits (train.py:326-331)
+        with `bce_weight` [T,2]; `scale` an optional device scalar multiplied into loss and gradient (data-parallel
+        global normalisation, parallel.dp_loss_scale).  Returns (loss, (out, atom_representations,
+        graph_representation)); the parameter gradients are attached to ``p.grad`` as ``loss.backward()`` would."""
+        if not (self.graph and self.training and torch.is_grad_enabled()):
+            raise ops.L.EagcnHipError('fused_step needs graph=True, training mode and grad enabled')
+        if bonds is None:
+            adjs, afms, *rels_and_size = batch
+            *rels, size = rels_and_size
+        else:
+            adjs, rels, (afms, size) = None, None, batch
+        runner, adjs, rels, afms, size, seed, btuple = self._graph_runner(adjs, afms, rels, size, bonds)
+        kind = 'mse' if task == 'reg' else 'bce'
+        if kind == 'bce' and not isinstance(bce_weight, torch.Tensor):
+            raise ops.L.EagcnHipError('fused_step: bce_weight must be a [T,2] device tensor (make it once per run)')
+        loss = runner.train_step(adjs, rels, afms, size, seed, labels, kind, bce_weight, scale, self.overlap_index, btuple)
+        out, graph_representation = runner.outputs()
+        return loss, (out, self._atom_rep(runner), graph_representation)
 
     def forward(self, adjs, afms, *rels_and_size):
         """Reference signature (models.py:96): (adjs, afms, TypeAtt, OrderAtt, AromAtt, ConjAtt, RingAtt,

@@ -93,16 +93,26 @@ def set_weight(labels, n_tasks):
     return out
 
 
-def train_step(model, optimizer, batch, labels, task, bce_weight=None, dp_global_norm=False):
+def train_step(model, optimizer, batch, labels, task, bce_weight=None, dp_global_norm=False, fused=None):
     """One iteration of train.py:310-334.  `batch` = (adjs, afms, TypeAtt, OrderAtt, AromAtt, ConjAtt, RingAtt, size) device
-    tensors; returns the loss tensor (device; no host sync)."""
+    tensors; returns the loss tensor (device; no host sync).  With a graph-mode model the three phases run as ONE captured
+    graph (EAGCN.fused_step) unless fused=False."""
     optimizer.zero_grad(set_to_none=True)
-    out, _, _ = model(*batch)
-    if task == 'reg':
-        loss = fused_regression_loss(out, labels)
+    if fused is None:
+        fused = bool(getattr(model, 'graph', False)) and model.training and hasattr(model, 'fused_step')
+    if fused:
+        scale = None
+        if dp_global_norm:
+            from .parallel import dp_loss_scale
+            scale = dp_loss_scale(labels, None)
+        loss, _ = model.fused_step(batch, labels, task, bce_weight, scale)
     else:
-        loss = fused_classification_loss(out, labels, bce_weight, dp_global_norm=dp_global_norm)
-    loss.backward()
+        out, _, _ = model(*batch)
+        if task == 'reg':
+            loss = fused_regression_loss(out, labels)
+        else:
+            loss = fused_classification_loss(out, labels, bce_weight, dp_global_norm=dp_global_norm)
+        loss.backward()
     optimizer.step()
     return loss
 

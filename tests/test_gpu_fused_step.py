@@ -1,0 +1,69 @@
+"""EAGCN.fused_step (forward + loss + backward as one captured graph) against the separate calls of the same model."""
+import copy
+
+import pytest
+import torch
+
+from eagcn_amd.losses import fused_classification_loss, fused_regression_loss
+from eagcn_amd.models import EAGCN
+from eagcn_amd.synthetic import bce_weights, make_batch
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('task,structure', [('class', 'Concate'), ('reg', 'Weighted_sum')])
+def test_fused_step_matches_forward_loss_backward(task, structure):
+    dev = torch.device('cuda', 0)
+    T = 5 if task == 'class' else 1
+    torch.manual_seed(5)
+    a = EAGCN(28, 24, dropout=0.0, structure=structure, n_layers=2, widths1=[16] * 5, widths2=[32] * 5, n_den1=64, n_den2=32,
+              nclass=T, graph=True, validate='deferred').to(dev).train()
+    b = copy.deepcopy(a)
+    bw = torch.tensor(bce_weights(T), dtype=torch.float32, device=dev)
+    for step in range(5):                      # both slots, eager first use and replays; changing labels and batches
+        mb = make_batch(B=24, n_max=30, n_med=11, rel_channels=(28, 4, 2, 2, 2), seed=40 + step, n_tasks=T, task=task)
+        dense = mb.dense(dev)
+        labels = torch.from_numpy(mb.labels).to(dev)
+        for m in (a, b):
+            for p in m.parameters():
+                p.grad = None
+        out, _, gr = a(*dense)
+        loss = (fused_regression_loss(out, labels) if task == 'reg' else fused_classification_loss(out, labels, bw))
+        loss.backward()
+        loss_f, (out_f, _, gr_f) = b.fused_step(dense, labels, task, bw)
+        rel_err(loss_f, loss, 'loss, step %d' % step)
+        rel_err(out_f, out, 'out')
+        rel_err(gr_f, gr, 'graph_representation')
+        assert torch.equal(loss_f, loss) and torch.equal(out_f, out)
+        for (n, p), q in zip(a.named_parameters(), b.parameters()):
+            if p.grad is None:
+                assert q.grad is None, n
+                continue
+            assert torch.equal(p.grad, q.grad), (step, n, (p.grad - q.grad).abs().max().item())
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
+def test_fused_step_scale_and_accumulation():
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(6)
+    a = EAGCN(28, 24, dropout=0.0, structure='Concate', n_layers=2, widths1=[16] * 5, widths2=[32] * 5, n_den1=64, n_den2=32,
+              nclass=3, graph=True).to(dev).train()
+    b = copy.deepcopy(a)
+    bw = torch.tensor(bce_weights(3), dtype=torch.float32, device=dev)
+    mb = make_batch(B=16, n_max=24, n_med=10, rel_channels=(28, 4, 2, 2, 2), seed=77, n_tasks=3)
+    dense = mb.dense(dev)
+    labels = torch.from_numpy(mb.labels).to(dev)
+    scale = torch.tensor(0.625, device=dev)
+    for rep in range(3):                       # gradients stay attached: the second and third step ACCUMULATE
+        out, _, _ = a(*dense)
+        l1 = fused_classification_loss(out, labels, bw) * scale
+        l1.backward()
+        l2, _ = b.fused_step(dense, labels, 'class', bw, scale)
+        assert abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l1))
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        if p.grad is not None:
+            d = (p.grad - q.grad).abs().max().item()
+            assert d <= 2e-6 * max(p.grad.abs().max().item(), 1e-6), (n, d)
