@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libeagcn_hip.so')
 MAX_VIEWS = 8
 MAX_SEGS = 8
 META_WORDS = 8
-META_T, META_NMAX, META_NTILES, META_BAD_ADJ, META_BAD_REL, META_NEDGE, META_OVERFLOW = range(7)
+META_T, META_NMAX, META_NTILES, META_BAD_ADJ, META_BAD_REL, META_NEDGE, META_OVERFLOW, META_EDGE_OVERFLOW = range(8)
 STRUCT_CONCATE, STRUCT_WEIGHTED = 0, 1
 
 _fp = C.c_void_p   # device pointers travel as integers
@@ -25,7 +25,23 @@ class Batch(C.Structure):
                 ('channels', C.c_int32 * MAX_VIEWS),
                 ('code', _fp), ('deg_bn', _fp), ('nat', _fp), ('row0', _fp), ('tile0', _fp),
                 ('meta', _fp), ('row_mol', _fp), ('row_loc', _fp), ('row_m', _fp), ('row_deg', _fp),
-                ('tile_mol', _fp), ('row_info', _fp), ('tile_info', _fp)]
+                ('tile_mol', _fp), ('row_info', _fp), ('tile_info', _fp),
+                ('E', C.c_int32), ('reserved_', C.c_int32), ('ecnt', _fp), ('edge0', _fp), ('mol_info', _fp), ('row_ptr', _fp),
+                ('col_ptr', _fp), ('nbr', _fp), ('tnbr', _fp), ('ecode', _fp), ('tcode', _fp)]
+
+
+def set_bond_lists(c, small_ptr, ptrs, edges, E):
+    """Point the bond-list fields of a Batch at their buffers: `small_ptr` = device address of [ecnt B | edge0 B+1] int32,
+    `ptrs` = int32 [4*T + 4*B] (row_ptr | col_ptr | mol_info), `edges` = int32 [6*E + 2] (nbr | tnbr | ecode u64 | tcode u64)."""
+    c.E = int(E)
+    c.ecnt, c.edge0 = small_ptr, small_ptr + 4 * c.B
+    pb, T = ptrs.data_ptr(), c.T
+    c.row_ptr, c.col_ptr, c.mol_info = pb, pb + 8 * T, pb + 16 * T
+    eb = edges.data_ptr()
+    c.nbr, c.tnbr = eb, eb + 4 * E
+    code = eb + 8 * E
+    code += (-code) % 8
+    c.ecode, c.tcode = code, code + 8 * E
 
 
 class Layout(C.Structure):

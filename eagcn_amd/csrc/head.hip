@@ -19,7 +19,6 @@
 
 namespace eagcn {
 
-enum { RB_SC = 0, RB_SH, RB_MU, RB_INV };
 
 // ---- carving of the saved-for-backward block and of the transient scratch ---------------------------
 struct Carver2 {

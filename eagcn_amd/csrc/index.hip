@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
                                                           uint8_t* __restrict__ code,
                                                           int32_t* __restrict__ deg_bn,
                                                           int32_t* __restrict__ nat,
+                                                          int32_t* __restrict__ ecnt,
                                                           int32_t* __restrict__ meta) {
     const int lane = threadIdx.x & 63;
     const long row_first = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;      // b*N + i of the first row
@@ -110,7 +111,10 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
         }
         if (lane == 0) {
             deg_bn[row] = deg;
-            if (deg > 0) atomicMax(&nat[b], i + 1);  // (no single-word counters here: 5k same-address atomics cost 60 us)
+            if (deg > 0) {                           // (no single-word counters here: 5k same-address atomics cost 60 us;
+                atomicMax(&nat[b], i + 1);           //  these are one word per molecule)
+                atomicAdd(&ecnt[b], deg);
+            }
         }
     }
     bad_adj = wave_sum(bad_adj);
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void index_bonds_kernel(const int32_t* __restr
                                                            const uint8_t* __restrict__ bc, long E, int B, int N, int K,
                                                            int ldc, RelPtrs rel, uint8_t* __restrict__ code,
                                                            int32_t* __restrict__ deg_bn, int32_t* __restrict__ nat,
-                                                           int32_t* __restrict__ meta) {
+                                                           int32_t* __restrict__ ecnt, int32_t* __restrict__ meta) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
         const int b = bm[e], i = bi[e], j = bj[e];
         if (b < 0 || b >= B || i < 0 || i >= N || j < 0 || j >= N || i == j) {
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(256) void index_bonds_kernel(const int32_t* __restr
         if (bad) atomicAdd(&meta[EAGCN_META_BAD_REL], 1);
         atomicAdd(&deg_bn[(size_t)b * N + i], 1);
         atomicMax(&nat[b], i + 1);
+        atomicAdd(&ecnt[b], 1);
     }
 }
 
@@ -151,34 +156,41 @@ __global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __re
                                                               const int32_t* __restrict__ deg_bn, int BN,
                                                               int32_t* __restrict__ row0,
                                                               int32_t* __restrict__ tile0,
-                                                              int32_t* __restrict__ meta, int cap_rows) {
-    __shared__ int s_rows[1024], s_tiles[1024];
-    __shared__ int carry_r, carry_t, s_max;
+                                                              int32_t* __restrict__ meta, int cap_rows,
+                                                              const int32_t* __restrict__ ecnt,
+                                                              int32_t* __restrict__ edge0, int cap_edges) {
+    __shared__ int s_rows[1024], s_tiles[1024], s_edges[1024];
+    __shared__ int carry_r, carry_t, carry_e, s_max;
     const int t = threadIdx.x;
-    if (t == 0) { carry_r = 0; carry_t = 0; s_max = 0; }
+    if (t == 0) { carry_r = 0; carry_t = 0; carry_e = 0; s_max = 0; }
     __syncthreads();
     int nmax = 0;
     for (int base = 0; base < B; base += 1024) {
         int idx = base + t;
         int n = idx < B ? nat[idx] : 0;
         nmax = max(nmax, n);
+        const int ne = (idx < B && ecnt) ? ecnt[idx] : 0;
         s_rows[t] = n;
         s_tiles[t] = (n + 15) >> 4;
+        s_edges[t] = ne;
         __syncthreads();
         for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
             int vr = t >= o ? s_rows[t - o] : 0;
             int vt = t >= o ? s_tiles[t - o] : 0;
+            int ve = t >= o ? s_edges[t - o] : 0;
             __syncthreads();
             s_rows[t] += vr;
             s_tiles[t] += vt;
+            s_edges[t] += ve;
             __syncthreads();
         }
         if (idx < B) {
             row0[idx] = carry_r + s_rows[t] - n;
             tile0[idx] = carry_t + s_tiles[t] - ((n + 15) >> 4);
+            if (edge0) edge0[idx] = carry_e + s_edges[t] - ne;
         }
         __syncthreads();
-        if (t == 1023) { carry_r += s_rows[t]; carry_t += s_tiles[t]; }
+        if (t == 1023) { carry_r += s_rows[t]; carry_t += s_tiles[t]; carry_e += s_edges[t]; }
         __syncthreads();
     }
     atomicMax(&s_max, nmax);
@@ -201,10 +213,14 @@ __global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __re
         tile0[B] = carry_t;
         // a batch that does not fit the caller's row capacity is indexed as empty (and reported): every consumer
         // takes its extents from meta[], so nothing is read or written beyond the capacity-sized buffers
-        const bool over = cap_rows > 0 && carry_r > cap_rows;
+        if (edge0) edge0[B] = carry_e;
+        const bool over_r = cap_rows > 0 && carry_r > cap_rows;
+        const bool over_e = edge0 && carry_e > cap_edges;          // (the edge arrays are always capacity-sized)
+        const bool over = over_r || over_e;
         meta[EAGCN_META_T] = over ? 0 : carry_r;
         meta[EAGCN_META_NTILES] = over ? 0 : carry_t;
-        meta[EAGCN_META_OVERFLOW] = over ? carry_r : 0;
+        meta[EAGCN_META_OVERFLOW] = over_r ? carry_r : 0;
+        meta[EAGCN_META_EDGE_OVERFLOW] = over_e ? carry_e : 0;
         meta[EAGCN_META_NMAX] = s_max;
     }
 }
@@ -223,6 +239,122 @@ __global__ __launch_bounds__(256) void index_rows_kernel(eagcn_batch bt) {
     for (int t = threadIdx.x; t < (n + 15) / 16 && t0 + t < bt.n_tiles; t += blockDim.x) {
         bt.tile_mol[t0 + t] = b;
         reinterpret_cast<int4*>(bt.tile_info)[t0 + t] = make_int4(b, t, n, r0);
+    }
+    if (threadIdx.x == 0 && bt.mol_info) {
+        const int e0 = bt.edge0[b];
+        reinterpret_cast<int4*>(bt.mol_info)[b] = make_int4(r0 + n <= bt.T ? n : 0, r0, e0, bt.edge0[b + 1] - e0);
+    }
+}
+
+// Bond lists of one molecule (one workgroup each) from its code maps: row lists (bonds (i,j) of row i, j ascending) and
+// column lists (bonds (i,j) into column j, i ascending), each with the K per-view bond-type codes of the bond in one
+// 64-bit word.  Only bonds with both ends inside the molecule's nat rows are listed (what the dense kernels multiply,
+// agg.hip); rows without bonds have undefined code rows and are skipped.  Entries of molecule b live in
+// [edge0[b], edge0[b+1]) of both list families.
+// BITMAP: the bond positions of the molecule are first packed into an LDS bitmap ([nat][W] 32-bit words, one coalesced
+// pass over the view-0 code rows), which both list families are then read from -- walking a COLUMN of the byte map in
+// global memory is one dependent single-byte load per row (measured 256 us at the Tox21 shape).  Molecules beyond 512
+// atom slots (bitmap > 32 KB) read the byte map directly.
+template <bool BITMAP>
+__global__ __launch_bounds__(256) void index_csr_kernel(eagcn_batch bt, int W) {
+    extern __shared__ uint32_t bits[];
+    __shared__ int s_cnt[1024], s_ccnt[1024], s_scan[256];
+    __shared__ unsigned char s_live[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = bt.nat[b], r0 = bt.row0[b], e0 = bt.edge0[b];
+    if (bt.meta[EAGCN_META_T] == 0 || n == 0 || r0 + n > bt.T) return;    // empty / overflowing batch: nothing is read
+    const size_t plane = (size_t)bt.B * bt.N * bt.ldc;
+    const uint8_t* code0 = bt.code + (size_t)b * bt.N * bt.ldc;          // view 0: every view has the same bond positions
+    const int Wn = (n + 31) >> 5;
+    auto bond = [&](int i, int j) -> bool {
+        if constexpr (BITMAP) return (bits[i * W + (j >> 5)] >> (j & 31)) & 1u;
+        else return s_live[i] && code0[(size_t)i * bt.ldc + j] != 0;
+    };
+    for (int i = tid; i < n; i += 256) {
+        const bool lv = bt.deg_bn[(size_t)b * bt.N + i] > 0;
+        s_live[i] = lv ? 1 : 0;
+        int c = 0;
+        for (int w = 0; w < Wn; ++w) {
+            uint32_t m = 0u;
+            if (lv) {
+                const uint8_t* src = code0 + (size_t)i * bt.ldc + 32 * w;
+                const uint4 a0 = *reinterpret_cast<const uint4*>(src);
+                const uint4 a1 = (32 * w + 16 < bt.ldc) ? *reinterpret_cast<const uint4*>(src + 16) : make_uint4(0u, 0u, 0u, 0u);
+                const uint32_t ww[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int t = 0; t < 32; ++t)
+                    m |= (((ww[t >> 2] >> (8 * (t & 3))) & 255u) != 0u && 32 * w + t < n) ? (1u << t) : 0u;
+            }
+            if constexpr (BITMAP) bits[i * W + w] = m;
+            c += __popc(m);
+        }
+        s_cnt[i] = c;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) {                          // bonds into column j
+        int cc = 0;
+        if constexpr (BITMAP) {
+            for (int i = 0; i < n; ++i) cc += bond(i, j) ? 1 : 0;
+        } else {
+            for (int i0 = 0; i0 < n; i0 += 8) {                   // 8 single-byte loads in flight
+                uint8_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (i0 + u < n && s_live[i0 + u]) ? code0[(size_t)(i0 + u) * bt.ldc + j] : 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cc += v[u] ? 1 : 0;
+            }
+        }
+        s_ccnt[j] = cc;
+    }
+    __syncthreads();
+    // exclusive scans of both count arrays (n <= 1024: four entries per thread, then a 256-entry scan)
+    for (int pass = 0; pass < 2; ++pass) {
+        int* cnt = pass ? s_ccnt : s_cnt;
+        int v[4], tot = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = tid * 4 + u; v[u] = i < n ? cnt[i] : 0; tot += v[u]; }
+        s_scan[tid] = tot;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int x = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += x;
+            __syncthreads();
+        }
+        int run = s_scan[tid] - tot;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid * 4 + u;
+            if (i < n) {
+                int* ptr = (pass ? bt.col_ptr : bt.row_ptr) + (size_t)(r0 + i) * 2;
+                const bool fits = e0 + run + v[u] <= bt.E;         // (always: index_offsets empties a batch that does not fit)
+                ptr[0] = e0 + run;
+                ptr[1] = fits ? v[u] : 0;
+                cnt[i] = fits ? e0 + run : -1;
+                run += v[u];
+            }
+        }
+        __syncthreads();
+    }
+    auto codes = [&](int i, int j) -> uint64_t {                   // the K bond-type bytes of bond (i,j): K loads in flight
+        uint8_t c[EAGCN_MAX_VIEWS];
+#pragma unroll
+        for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) c[k] = k < bt.K ? code0[k * plane + (size_t)i * bt.ldc + j] : 0;
+        uint64_t c64 = 0;
+#pragma unroll
+        for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) c64 |= (uint64_t)c[k] << (8 * k);
+        return c64;
+    };
+    for (int i = tid; i < n; i += 256) {
+        int e = s_cnt[i];
+        if (s_live[i] && e >= 0)
+            for (int j = 0; j < n; ++j)
+                if (bond(i, j)) { bt.nbr[e] = j; bt.ecode[e] = codes(i, j); ++e; }
+        int ec = s_ccnt[i];                                      // column list of atom i: rows ascending
+        if (ec >= 0)
+            for (int ii = 0; ii < n; ++ii)
+                if (bond(ii, i)) { bt.tnbr[ec] = ii; bt.tcode[ec] = codes(ii, i); ++ec; }
     }
 }
 
@@ -301,6 +433,8 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     ProfScope ps(PROF_INDEX, s);
     EAGCN_HIP(hipMemsetAsync(b->meta, 0, EAGCN_META_WORDS * sizeof(int32_t), s));
     EAGCN_HIP(hipMemsetAsync(b->nat, 0, (size_t)b->B * sizeof(int32_t), s));
+    EAGCN_CHECK_ARG(b->ecnt && b->edge0, "eagcn_index_build: bond-list buffers not allocated");
+    EAGCN_HIP(hipMemsetAsync(b->ecnt, 0, (size_t)b->B * sizeof(int32_t), s));
     const long rows = (long)b->B * b->N;
     // rows per wavefront: 4 was measured SLOWER (0.18 vs 0.09 ms at B=256, 1.12 vs 0.97 ms at B=4096), and so was
     // a streaming degree pass followed by a per-molecule code pass over the bonded rows (0.39-0.71 vs 0.07 ms at
@@ -310,7 +444,7 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     const unsigned sgrid = (unsigned)((rows + 4 * RPW - 1) / (4 * RPW));
     const int nit = cdiv(b->ldc, 256);
     EAGCN_CHECK_ARG(nit <= 4, "eagcn_index_build: N=%d exceeds the supported 1024 atoms", b->N);
-#define EAGCN_SCAN(NIT) index_scan_kernel<NIT, RPW><<<sgrid, 256, 0, s>>>(adj, rp, b->B, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->meta)
+#define EAGCN_SCAN(NIT) index_scan_kernel<NIT, RPW><<<sgrid, 256, 0, s>>>(adj, rp, b->B, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->ecnt, b->meta)
     switch (nit) {
         case 1: EAGCN_SCAN(1); break;
         case 2: EAGCN_SCAN(2); break;
@@ -319,7 +453,7 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     }
 #undef EAGCN_SCAN
     EAGCN_LAUNCH_CHECK();
-    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta, b->T);
+    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta, b->T, b->ecnt, b->edge0, b->E);
     EAGCN_LAUNCH_CHECK();
     EAGCN_HIP(hipMemcpyAsync(host_meta, b->meta, EAGCN_META_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     return EAGCN_OK;
@@ -341,14 +475,16 @@ extern "C" int eagcn_index_from_bonds(const int32_t* bond_mol, const int32_t* bo
     EAGCN_HIP(hipMemsetAsync(b->meta, 0, EAGCN_META_WORDS * sizeof(int32_t), s));
     EAGCN_HIP(hipMemsetAsync(b->nat, 0, (size_t)b->B * sizeof(int32_t), s));
     EAGCN_HIP(hipMemsetAsync(b->deg_bn, 0, (size_t)b->B * b->N * sizeof(int32_t), s));
+    EAGCN_CHECK_ARG(b->ecnt && b->edge0, "eagcn_index_from_bonds: bond-list buffers not allocated");
+    EAGCN_HIP(hipMemsetAsync(b->ecnt, 0, (size_t)b->B * sizeof(int32_t), s));
     EAGCN_HIP(hipMemsetAsync(b->code, 0, (size_t)b->K * b->B * b->N * b->ldc, s));
     if (E > 0) {
         const int grid = (int)std::min<long>((E + 255) / 256, 4096);
         index_bonds_kernel<<<grid, 256, 0, s>>>(bond_mol, bond_i, bond_j, bond_code, (long)E, b->B, b->N, b->K, b->ldc, rp,
-                                                b->code, b->deg_bn, b->nat, b->meta);
+                                                b->code, b->deg_bn, b->nat, b->ecnt, b->meta);
         EAGCN_LAUNCH_CHECK();
     }
-    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta, b->T);
+    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta, b->T, b->ecnt, b->edge0, b->E);
     EAGCN_LAUNCH_CHECK();
     EAGCN_HIP(hipMemcpyAsync(host_meta, b->meta, EAGCN_META_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     return EAGCN_OK;
@@ -360,8 +496,15 @@ extern "C" int eagcn_index_rows(const eagcn_batch* b, void* stream) {
     if (b->T == 0) return EAGCN_OK;
     EAGCN_CHECK_ARG(b->row_mol && b->row_loc && b->row_m && b->row_deg && b->tile_mol && b->row_info && b->tile_info,
                     "eagcn_index_rows: per-row buffers not allocated");
+    EAGCN_CHECK_ARG(b->N <= 1024, "eagcn_index_rows: N=%d exceeds the supported 1024 atoms", b->N);
+    EAGCN_CHECK_ARG(b->edge0 && b->mol_info && b->row_ptr && b->col_ptr && (b->E == 0 || (b->nbr && b->tnbr && b->ecode && b->tcode)),
+                    "eagcn_index_rows: bond-list buffers not allocated");
     ProfScope ps(PROF_INDEX, s);
     index_rows_kernel<<<b->B, 256, 0, s>>>(*b);
+    EAGCN_LAUNCH_CHECK();
+    const int W = (b->N + 31) / 32;
+    if (b->N <= 512) index_csr_kernel<true><<<b->B, 256, (size_t)b->N * W * sizeof(uint32_t), s>>>(*b, W);
+    else index_csr_kernel<false><<<b->B, 256, 0, s>>>(*b, W);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

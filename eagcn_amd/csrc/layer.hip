@@ -43,7 +43,6 @@ struct GradPtrs {
 // colp rows
 enum { CP_GAMMA = 0, CP_BETA, CP_BIAS, CP_RMEAN, CP_RVAR, CP_AVEW, CP_ROWS = 8 };
 // bn rows
-enum { BN_SC = 0, BN_SH, BN_MU, BN_INV };
 
 __device__ __forceinline__ int col_view(const ViewCols& vc, int cp) {
     int k = 0;
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                            ViewCols vc, float* __restrict__ bn,
                                                            const int32_t* __restrict__ meta, int tiles_per_wg) {
     // aggregation workgroups beyond the actual tile count exit without writing their slab
-    nslab = min(nslab, (meta[EAGCN_META_NTILES] + tiles_per_wg - 1) / tiles_per_wg);
+    if (tiles_per_wg > 0) nslab = min(nslab, (meta[EAGCN_META_NTILES] + tiles_per_wg - 1) / tiles_per_wg);   // (0: every slab is written)
     const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
     const int cp = min(cpr, fp - 1);
     double s1 = 0.0, s2 = 0.0;
@@ -455,7 +454,7 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
                                                             int nsplit, size_t slab, const double* __restrict__ datt,
                                                             int nedge, const float* __restrict__ rsig, int wblocks,
                                                             const int32_t* __restrict__ meta) {
-    nedge = min(nedge, (meta[EAGCN_META_T] + 15) / 16);        // edge-gradient workgroups that had rows
+    nedge = nedge < 0 ? -nedge : min(nedge, (meta[EAGCN_META_T] + 15) / 16);   // edge-gradient workgroups that had rows (< 0: all wrote)
     nsplit = max(1, min(nsplit, meta[EAGCN_META_T] >> 7));     // split-K partials actually written (gemm.hip eff_splits)
     if ((int)blockIdx.x < wblocks) {
         const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -532,7 +531,7 @@ struct Carver {
 
 struct LayerDims {
     ViewCols vc;
-    int fp, ld_in, fin, ldo, gx, gxb, nsplit;
+    int fp, ld_in, fin, ldo, gx, gxb, nsplit, snsplit, sslabs;
     size_t wslab;
 };
 static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
@@ -543,6 +542,12 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     d.fin = layout_width(&p->in);
     d.ldo = p->structure == EAGCN_STRUCT_CONCATE ? d.fp : pad16(p->width[0]);
     d.gx = agg_grid_x(b);
+    {
+        int fmax = 16;
+        for (int k = 0; k < p->K; ++k) fmax = std::max(fmax, d.vc.off[k + 1] - d.vc.off[k]);
+        d.snsplit = sagg_nsplit(b, fmax);
+        d.sslabs = sagg_grid_x(b) * d.snsplit;           // partial slabs of the bond-list aggregation (sagg.hip)
+    }
     // row-partial slabs of the BatchNorm backward: 8 rows per workgroup, at most 2048 workgroups and at most
     // 32 MB of fp64 partials (wide layers: Fp = 6320 -> 331 workgroups)
     {
@@ -593,7 +598,7 @@ static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, Fw
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
     t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
-    t.stats = c.take<double>((size_t)d.gx * d.fp * 2);
+    t.stats = c.take<double>((size_t)std::max(d.gx, d.sslabs) * d.fp * 2);
     if (s) *s = t;
     return c.off;
 }
@@ -612,7 +617,7 @@ static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, Bw
     t.dWcat = c.take<float>(d.wslab * d.nsplit);
     t.slab = c.take<double>((size_t)d.gxb * d.fp * 2);
     t.slab_da = c.take<double>((size_t)d.gxb * EAGCN_MAX_VIEWS);
-    t.datt = c.take<double>((size_t)edge_grid_x(b) * EAGCN_MAX_VIEWS * EDGE_SLAB);
+    t.datt = c.take<double>((size_t)std::max(edge_grid_x(b), d.sslabs) * EAGCN_MAX_VIEWS * EDGE_SLAB);
     if (s) *s = t;
     return c.off;
 }
@@ -750,7 +755,7 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
     double fsum = 0.0;
     for (int k = 0; k < p->K; ++k) fsum += p->width[k];
     const double gemm_work = 2.0 * (double)b->T * (double)d.fin * fsum;
-    int nslab = 0;
+    int nslab = 0, tiles_per_wg = agg_ksplit(b) ? 1 : 4;
     if (b->T > 0) {
         // P = X.[W_1|..|W_K]: NT form on the pre-transposed weight (wave-autonomous balanced kernel, gemm3.hip); operands
         // that are not 16-byte aligned fall back to the workgroup-tiled kernel
@@ -764,21 +769,31 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
             rc = launch_gemm(g, s);
         }
         if (rc) return rc;
-        AggArgs a;
-        a.bt = *b; a.vc = d.vc; a.src = w->P; a.lds = d.fp; a.dst = w->Y; a.ldd = d.fp;
-        a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = sc.stats; a.nchunk = 1;
-        rc = launch_agg(a, false, s);
-        if (rc) return rc;
-        nslab = d.gx;
+        if (sagg_enabled()) {
+            SAggFwd a;
+            a.bt = *b; a.vc = d.vc; a.P = w->P; a.Y = w->Y; a.ld = d.fp; a.sig = sc.sig; a.rsig = sc.rsig;
+            a.rscale = w->rscale; a.stats = p->training ? sc.stats : nullptr; a.nsplit = d.snsplit;
+            rc = launch_sagg_fwd(a, s);
+            if (rc) return rc;
+            nslab = sagg_grid_x(b);
+            tiles_per_wg = 0;
+        } else {
+            AggArgs a;
+            a.bt = *b; a.vc = d.vc; a.src = w->P; a.lds = d.fp; a.dst = w->Y; a.ldd = d.fp;
+            a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = sc.stats; a.nchunk = 1;
+            rc = launch_agg(a, false, s);
+            if (rc) return rc;
+            nslab = d.gx;
+        }
     }
     const double M = (double)b->B * (double)b->N;
     ProfScope psbn(PROF_BN, s);
     if (nslab > 64)
         bn_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
-                                                               p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, agg_ksplit(b) ? 1 : 4);
+                                                               p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, tiles_per_wg);
     else
         bn_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
-                                                                p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, agg_ksplit(b) ? 1 : 4);
+                                                                p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, tiles_per_wg);
     EAGCN_LAUNCH_CHECK();
     ApplyArgs aa;
     aa.bt = *b; aa.vc = d.vc; aa.structure = p->structure; aa.fp = d.fp; aa.Y = w->Y; aa.ldy = d.fp;
@@ -872,7 +887,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             bn_bwd_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
                                                                         d.vc, gp, sc.cc, b->meta, ba.nvirt);
         EAGCN_LAUNCH_CHECK();
-        if (b->T > 0) {
+        if (b->T > 0 && !sagg_enabled()) {        // (the bond-list aggregation applies this affine while it stages dH)
             bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
             EAGCN_LAUNCH_CHECK();
         }
@@ -891,7 +906,15 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         e.rsig = sc.rsig; e.rscale = w->rscale; e.datt = sc.datt;
         static const bool colaunch = [] { const char* v = getenv("EAGCN_NO_COLAUNCH"); return !(v && v[0] == '1'); }();
         nedge = edge_grid_x(b);
-        if (!forked && colaunch) {
+        if (sagg_enabled()) {
+            // transposed aggregation + edge gradients + BatchNorm-backward affine in one kernel over the bond lists
+            SAggBwd sa;
+            sa.bt = *b; sa.vc = d.vc; sa.fp = d.fp; sa.dH = sc.dY; sa.Y = w->Y; sa.P = w->P; sa.bn = w->bn; sa.cc = sc.cc;
+            sa.dP = sc.dP; sa.sig = sc.sig; sa.rsig = sc.rsig; sa.rscale = w->rscale; sa.datt = sc.datt; sa.nsplit = d.snsplit;
+            rc = launch_sagg_bwd(sa, s);
+            if (rc) return rc;
+            nedge = -d.sslabs;
+        } else if (!forked && colaunch) {
             rc = launch_agg_edge(a, e, s);                                       // one grid for both
             if (rc) return rc;
         } else {

@@ -36,7 +36,7 @@ _SIDE_AFTER_FWD = os.environ.get('EAGCN_SIDE_AFTER_FWD', '1') == '1'
 class StaticIndex:
     """BatchIndex-compatible view of the runner's static index buffers (capacities, no host values)."""
 
-    def __init__(self, B, N, channels, device, row_cap):
+    def __init__(self, B, N, channels, device, row_cap, edge_cap=None):
         K = len(channels)
         self.device, self.B, self.N, self.K = device, B, N, K
         self.channels = list(channels)
@@ -46,8 +46,12 @@ class StaticIndex:
         self.n_max = N
         i32 = dict(dtype=torch.int32, device=device)
         self.code = torch.empty((K, B, N, self.ldc), dtype=torch.uint8, device=device)
-        blob = torch.zeros(B * N + 3 * B + 2 + L.META_WORDS, **i32)
+        blob = torch.zeros(B * N + 3 * B + 2 + L.META_WORDS + 2 * B + 2, **i32)
         rows = torch.zeros(8 * self.T + 5 * self.n_tiles, **i32)
+        # bond lists (csrc/sagg.hip): capacity in directed bonds; a molecular graph has 2-2.5 per atom
+        self.E = int(edge_cap) if edge_cap else min(self.T * N, max(8 * self.T, 1024))
+        self._ptrs = torch.zeros(4 * self.T + 4 * B, **i32)
+        self._edges = torch.zeros(6 * self.E + 2, **i32)       # nbr | tnbr | ecode (u64) | tcode (u64)
         self._blob, self._rows = blob, rows
         o = B * N
         self.nat = blob[o:o + B]
@@ -64,6 +68,7 @@ class StaticIndex:
         c.row_info, c.tile_info = rb, rb + 16 * T
         ob = rb + 16 * T + 16 * self.n_tiles
         c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = ob, ob + 4 * T, ob + 8 * T, ob + 12 * T, ob + 16 * T
+        L.set_bond_lists(c, base + 4 * (B * N + 3 * B + 2 + L.META_WORDS), self._ptrs, self._edges, self.E)
         self.c = c
 
     def ref(self):
@@ -75,14 +80,14 @@ class GraphRunner:
     a forward-only graph of the eval-mode model (running BatchNorm statistics, no dropout, no backward)."""
 
     def __init__(self, plan, B, N, channels, device, dropout, row_cap=None, training=True, static_outputs=False,
-                 validate='sync'):
+                 validate='sync', edge_cap=None):
         lib = L.load()
         self.plan, self.device = plan, device
         self.training = bool(training)
         self.static_outputs = bool(static_outputs)
         self.validate = validate
         self.key = (B, N, tuple(channels))
-        self.slots = [StaticIndex(B, N, channels, device, row_cap if row_cap else B * N) for _ in range(2)]
+        self.slots = [StaticIndex(B, N, channels, device, row_cap if row_cap else B * N, edge_cap) for _ in range(2)]
         self.index = self.slots[0]
         self.graphs = [[None, None, None], [None, None, None]]   # per slot: [forward, backward, whole step (fused loss)]
         self.step_kind = [None, None]
@@ -136,7 +141,7 @@ class GraphRunner:
         """Device memory this runner holds (two index slots, two saved-activation blocks, scratch, gradients)."""
         n = sum(sv.numel() for sv in self.saved) + self.scratch.numel() + 4 * self.flat_acc.numel()
         for sl in self.slots:
-            n += sl.code.numel() + 4 * (sl._blob.numel() + sl._rows.numel())
+            n += sl.code.numel() + 4 * (sl._blob.numel() + sl._rows.numel() + sl._ptrs.numel() + sl._edges.numel())
         return n
 
     def release(self):
@@ -247,6 +252,9 @@ class GraphRunner:
             if meta[L.META_OVERFLOW]:
                 raise L.EagcnHipError('a previous batch packed %d rows, more than row_cap=%d (it was processed as an '
                                       'empty batch; no memory was overwritten)' % (meta[L.META_OVERFLOW], self.slots[0].T))
+            if meta[L.META_EDGE_OVERFLOW]:
+                raise L.EagcnHipError('a previous batch held %d directed bonds, more than edge_cap=%d (it was processed as '
+                                      'an empty batch; no memory was overwritten)' % (meta[L.META_EDGE_OVERFLOW], self.slots[0].E))
 
     def _prepare(self, adj, rels, afm, size, seed, overlap=False, bonds=None, labels=None):
         """Everything of a step that reads the caller's tensors (index build, packed input, seeds, sizes, labels of a fused
@@ -322,6 +330,8 @@ class GraphRunner:
                 bad = '%d bonded (i,j,view) positions are not one-hot over the relation channels' % meta[L.META_BAD_REL]
             elif meta[L.META_OVERFLOW]:
                 bad = 'the batch packs %d rows, more than row_cap=%d' % (meta[L.META_OVERFLOW], idx.T)
+            elif meta[L.META_EDGE_OVERFLOW]:
+                bad = 'the batch holds %d directed bonds, more than edge_cap=%d' % (meta[L.META_EDGE_OVERFLOW], idx.E)
             if bad:
                 if overlap:
                     main.wait_stream(side)

@@ -17,7 +17,8 @@ that fix ``structure``.  Keyword-only extensions (defaults = reference behaviour
                 per captured pair (a new pair is captured for every new shape), delivers gradients
                 as in grad_mode='direct', keeps ONE training forward in flight, and the lazy atom
                 representations are valid until the next forward.  ``row_cap`` bounds the packed rows
-                the static buffers are sized for (default B*N).  Every distinct (B, N, training) shape owns a
+                the static buffers are sized for (default B*N), ``edge_cap`` the directed bonds of a batch
+                (default 8 per row of row_cap: molecular graphs hold 2-2.5).  Every distinct (B, N, training) shape owns a
                 runner (two index slots, two saved-activation blocks, scratch: see GraphRunner.nbytes());
                 at most ``max_runners`` (default 8) are kept, least recently used evicted first.
   graph_outputs 'copy' (default): graph mode returns fresh tensors like the reference does; 'static': it
@@ -78,7 +79,7 @@ class EAGCN(nn.Module):
                  n_den1=128, n_den2=64, nclass=1, dropout=0.0, structure='Concate', molfp_mode='sum',
                  pool_num=5, *, n_layers=4, widths1=None, widths2=None, rel_channels=None, atom_rep='lazy',
                  grad_mode='autograd', overlap_index=False, graph=False, row_cap=None, graph_outputs='copy',
-                 validate='sync', max_runners=8):
+                 validate='sync', max_runners=8, edge_cap=None):
         super().__init__()
         if widths1 is None:
             widths1 = [n_sgc1_1, n_sgc1_2, n_sgc1_3, n_sgc1_4, n_sgc1_5]
@@ -119,7 +120,7 @@ class EAGCN(nn.Module):
             raise ValueError("grad_mode must be 'autograd' or 'direct'")
         self.grad_mode = grad_mode
         self.overlap_index = bool(overlap_index)
-        self.graph, self.row_cap = bool(graph), row_cap
+        self.graph, self.row_cap, self.edge_cap = bool(graph), row_cap, edge_cap
         if graph_outputs not in ('copy', 'static'):
             raise ValueError("graph_outputs must be 'copy' or 'static'")
         if validate not in ('sync', 'deferred'):
@@ -170,7 +171,7 @@ class EAGCN(nn.Module):
         super().__setstate__(state)
         self._plan = None
         self._runners = {}
-        for name, default in (('graph_outputs', 'copy'), ('validate', 'sync'), ('max_runners', 8)):
+        for name, default in (('graph_outputs', 'copy'), ('validate', 'sync'), ('max_runners', 8), ('edge_cap', None)):
             self.__dict__.setdefault(name, default)
 
     def state_dict(self, *a, **kw):
@@ -220,7 +221,8 @@ class EAGCN(nn.Module):
                 old = self._runners.pop(next(iter(self._runners)))
                 old.release()
             runner = G.GraphRunner(plan, B, N, channels, afms.device, self.dropout, self.row_cap, training=self.training,
-                                   static_outputs=(self.graph_outputs == 'static'), validate=self.validate)
+                                   static_outputs=(self.graph_outputs == 'static'), validate=self.validate,
+                                   edge_cap=self.edge_cap)
         self._runners[key] = runner                                      # (re-)inserted last = most recently used
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (self.dropout > 0 and self.training) else 0
         if self.molfp_mode == 'ave':

@@ -125,7 +125,7 @@ class BatchIndex:
         with torch.cuda.stream(side):
             self.code = torch.empty((K, B, N, self.ldc), dtype=torch.uint8, device=dev)
             # one allocation for the small int32 arrays: [deg_bn B*N | nat B | row0 B+1 | tile0 B+1 | meta]
-            blob = torch.empty(B * N + 3 * B + 2 + L.META_WORDS, **i32)
+            blob = torch.empty(B * N + 3 * B + 2 + L.META_WORDS + 2 * B + 2, **i32)
         o = 0
         self.deg_bn = blob[o:o + B * N]; o += B * N
         self.nat = blob[o:o + B]; o += B
@@ -141,6 +141,9 @@ class BatchIndex:
         c.code, c.deg_bn, c.nat = self.code.data_ptr(), base, base + 4 * B * N
         c.row0, c.tile0 = base + 4 * (B * N + B), base + 4 * (B * N + 2 * B + 1)
         c.meta = base + 4 * (B * N + 3 * B + 2)
+        c.ecnt = base + 4 * (B * N + 3 * B + 2 + L.META_WORDS)
+        c.edge0 = c.ecnt + 4 * B
+        c.E = 1 << 30                     # (exact-size edge arrays are allocated once the bond count is known)
         host = _host_meta(dev)
         if not overlap:
             side.wait_stream(main)        # inputs may have been produced by work still queued on `main`
@@ -193,6 +196,10 @@ class BatchIndex:
         c.row_info, c.tile_info = rb, rb + 16 * T
         ob = rb + 4 * o
         c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = ob, ob + 4 * T, ob + 8 * T, ob + 12 * T, ob + 16 * T
+        self.E = max(int(self.n_edges), 1)
+        self._ptrs = torch.zeros(4 * T + 4 * B, **i32)
+        self._edges = torch.empty(6 * self.E + 2, **i32)
+        L.set_bond_lists(c, base + 4 * (B * N + 3 * B + 2 + L.META_WORDS), self._ptrs, self._edges, self.E)
         L.check(lib.eagcn_index_rows(C.byref(c), C.c_void_p(main.cuda_stream)), 'eagcn_index_rows')
         for t in (self.code, blob):
             t.record_stream(main)         # allocated on `side`, consumed on `main`

@@ -70,6 +70,8 @@ extern "C" {
 #define EAGCN_META_OVERFLOW 6 /* packed rows of a batch that does not fit the row capacity eagcn_batch.T (0 if it
                                  fits): such a batch is indexed as EMPTY (meta[T] = meta[NTILES] = 0), so that no
                                  kernel touches memory beyond the capacity-sized buffers              */
+#define EAGCN_META_EDGE_OVERFLOW 7 /* directed bonds of a batch that does not fit the edge capacity eagcn_batch.E (0 if it
+                                 fits); handled like EAGCN_META_OVERFLOW: the batch is indexed as empty                   */
 #define EAGCN_META_WORDS 8
 
 typedef struct eagcn_batch {
@@ -95,6 +97,20 @@ typedef struct eagcn_batch {
     int32_t* row_info;                      /* [T][4] {molecule, atom, nat[mol], row0[mol]}: one
                                                16-byte load instead of a two-hop lookup          */
     int32_t* tile_info;                     /* [n_tiles][4] {molecule, row tile, nat[mol], row0[mol]} */
+    /* Bond lists (built by eagcn_index_rows from the code maps): the attention matrix of layers.py:82-90 is
+       sigma(w[type]) at the bonds, sigma(self_r) on the diagonal and 1e-9 everywhere else, so the aggregation
+       kernels walk these lists instead of a dense N x N operand (csrc/sagg.hip).                           */
+    int32_t E;                              /* CAPACITY of the four edge arrays (directed bonds)             */
+    int32_t reserved_;
+    int32_t* ecnt;                          /* [B]   directed bonds of each molecule                         */
+    int32_t* edge0;                         /* [B+1] exclusive prefix of ecnt                                */
+    int32_t* mol_info;                      /* [B][4] {nat, row0, edge0, directed bonds}: one 16-byte load   */
+    int32_t* row_ptr;                       /* [T][2] {first entry, count}: bonds (i,j) of packed row i      */
+    int32_t* col_ptr;                       /* [T][2] {first entry, count}: bonds (i,j) INTO packed row j    */
+    int32_t* nbr;                           /* [E] row lists: atom index j inside the molecule               */
+    int32_t* tnbr;                          /* [E] column lists: atom index i inside the molecule            */
+    uint64_t* ecode;                        /* [E] row lists: byte k = bond-type code of view k (1-based)    */
+    uint64_t* tcode;                        /* [E] column lists: the same for bond (i,j)                     */
 } eagcn_batch;
 
 /* column layout of a packed activation matrix */

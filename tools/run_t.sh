@@ -1,3 +1,4 @@
-mkdir -p gpurun_out; python -m pytest tests/test_gpu_fused_step.py -q -x 2>&1 | tail -15
-EAGCN_BENCH_OVERLAP=0 bash tools/run_prof.sh r2_noovl --steps 20 --warmup 5 > gpurun_out/noovl_prof.log 2>&1
-grep -v "^#" gpurun_out/prof_r2_noovl/timeline.txt | head -60
+mkdir -p gpurun_out/tests
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_training.py -m gpu -q --timeout=300 > gpurun_out/tests/pytest_parity.log 2>&1; echo "pytest rc=$?"
+grep -E "^FAILED|^ERROR|passed|failed" gpurun_out/tests/pytest_parity.log | tail -12
+grep -E "AssertionError: \(" gpurun_out/tests/pytest_parity.log | head -20
