@@ -1,4 +1,8 @@
-// Multi-view edge-attention aggregation over the BOND LISTS of the batch index, forward and backward.
+// EXPERIMENTAL, opt-in (EAGCN_AGG=sparse): multi-view edge-attention aggregation over the BOND LISTS of the batch index,
+// forward and backward.  NOT the default path: dropping the 1e-9 filler from the product (below) is a 5e-7 relative
+// change of the attention operator, which three ill-conditioned parity cases amplify to 1.0-1.3x their tolerance, and
+// the exact variants that were tried (per-molecule column sums staged through LDS; 8-row bins with fp64 LDS sums)
+// measured SLOWER than the dense matrix-core kernels of agg.hip at the Tox21 shape.  Measurements in DESIGN.md.
 //
 // Reference semantics (layers.py:82-92 with the masks of layers.py:294-304), per molecule b, view k and the slice
 // P_k = X.W_k of the flat product (the reference computes (A.X).W, layers.py:39-40; re-associated):

@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/tests
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_training.py -m gpu -q --timeout=300 > gpurun_out/tests/pytest_parity.log 2>&1; echo "pytest rc=$?"
-grep -E "^FAILED|^ERROR|passed|failed" gpurun_out/tests/pytest_parity.log | tail -12
-grep -E "AssertionError: \(" gpurun_out/tests/pytest_parity.log | head -20
+timeout 200 bash tools/run_prof.sh r2_sparse --steps 20 --warmup 5 > gpurun_out/sparse_prof.log 2>&1
+grep -v "^#" gpurun_out/prof_r2_sparse/timeline.txt | grep -E "sagg|csr|scan|bn_|gemm"
+tail -1 gpurun_out/prof_r2_sparse/timeline.txt
