@@ -373,6 +373,14 @@ int gemm3_clear_flags(void* workspace, size_t bytes, hipStream_t s, double* zero
     return EAGCN_OK;
 }
 
+int gemm3_zero_job(void* workspace, size_t bytes, double* zero, int nzero, ZeroJob* out) {
+    float* ws; unsigned* flags;
+    int rc = g3_prepare(workspace, bytes, &ws, &flags);
+    if (rc) return rc;
+    out->u = flags; out->nu = gemm3_grid() * 4; out->d = zero; out->nd = zero ? nzero : 0;
+    return EAGCN_OK;
+}
+
 // one product; with `sc0` (TN only) the result goes to the per-view weight gradients instead of g.C
 int launch_gemm3(const GemmDesc& g, const DwScatter* sc0, void* workspace, size_t bytes, hipStream_t s) {
     EAGCN_CHECK_ARG(gemm3_ok(g), "gemm: operands not 16-byte aligned / extents not multiples of 4 / unsupported form");

@@ -91,7 +91,9 @@ static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m
 
 struct ModelScratch {
     float *da2, *da1, *dgn, *dg, *dxa, *dxb, *dpad;
-    double* hst; int n_hst;      // BatchNorm sums of the head: [f_in + n_den1 + n_den2][2], cleared at the start of each call
+    double* hst; int n_hst;      // BatchNorm sums of the head: [f_in + n_den1 + n_den2][2], forward ...
+    double* hsb;                 // ... and backward.  Both are cleared by the forward's parameter-packing launch; the backward clears
+                                 // its own again on the way out (bn_bwd_reduce of the top layer), for a second backward call
     void* layer; size_t layer_bytes;
 };
 static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model* m, ModelScratch* out) {
@@ -100,7 +102,8 @@ static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model*
     const eagcn_head_params* h = &m->head;
     const size_t B = (size_t)b->B, T = (size_t)b->T;
     s.n_hst = 2 * (h->f_in + h->n_den1 + h->n_den2);
-    s.hst = c.take<double>((size_t)s.n_hst);
+    s.hst = c.take<double>((size_t)2 * s.n_hst);
+    s.hsb = s.hst + s.n_hst;
     s.da2 = c.take<float>(B * h->n_den2);
     s.da1 = c.take<float>(B * h->n_den1);
     s.dgn = c.take<float>(B * h->f_in);
@@ -200,7 +203,8 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "eagcn_model_forward: saved block too small");
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_forward: scratch too small");
     const eagcn_head_params* h = &m->head;
-    RC(gemm3_clear_flags(sc.layer, sc.layer_bytes, s, sc.hst, sc.n_hst));   // one clear for the whole call
+    ZeroJob zj;                                   // hand-off flags + the head's sums: cleared by the packing launch below
+    RC(gemm3_zero_job(sc.layer, sc.layer_bytes, sc.hst, 2 * sc.n_hst, &zj));
     if (!m->input_packed)
         RC(eagcn_pack_rows(b, afm, layout_width(&m->layer[0].in), &m->layer[0].in, sv.x0, stream));
     const float* x = sv.x0;
@@ -209,7 +213,7 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
         void* pk[4];
         size_t pkb[4];
         for (int l = 0; l < m->n_layers; ++l) { ps[l] = &m->layer[l]; pk[l] = sv.L[l].packed; pkb[l] = sv.L[l].packed_bytes; }
-        RC(pack_params_all(b, ps, pk, pkb, m->n_layers, stream));
+        RC(pack_params_all(b, ps, pk, pkb, m->n_layers, stream, &zj));
     }
     for (int l = 0; l < m->n_layers; ++l) {
         LayerSaved& L = sv.L[l];
@@ -267,12 +271,13 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_backward: scratch too small");
     const eagcn_head_params* h = &m->head;
     const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
-    RC(gemm3_clear_flags(sc.layer, sc.layer_bytes, s, sc.hst, sc.n_hst));   // one clear for the whole call
+    // (no clearing launch: the forward call left the hand-off flags and the backward sums zero; owners reset their flags)
+    const ZeroJob zb{nullptr, 0, sc.hsb, sc.n_hst};
     hipStream_t side = m->aux_stream ? (hipStream_t)m->aux_stream : s;
     const bool forked = side != s;
     // head backward (head2.hip): den3 -> bn_den2 -> den2 -> bn_den1 -> den1 -> Graph_BN, one launch per dense layer
     // (d input + d weight), each BatchNorm's backward sums taken by the launch in front of it
-    double *sb_g = sc.hst, *sb_1 = sc.hst + 2 * F, *sb_2 = sc.hst + 2 * (F + n1);
+    double *sb_g = sc.hsb, *sb_1 = sc.hsb + 2 * F, *sb_2 = sc.hsb + 2 * (F + n1);
     HeadDrop nodrop{0, 0u, 1.0f, 0, nullptr}, drop1 = nodrop;
     {
         int on; uint32_t thr; float inv_keep;
@@ -317,7 +322,7 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
         const bool top = l == m->n_layers - 1;
         const float* dpad = (weighted && top) ? sc.dpad : nullptr;
         RC(layer_backward_impl(b, &m->layer[l], &w, top ? nullptr : cur, top ? &rgd : nullptr, dpad,
-                               l > 0 ? other : nullptr, &lg[l], stream, top && sampled));
+                               l > 0 ? other : nullptr, &lg[l], stream, top && sampled, top ? &zb : nullptr));
         std::swap(cur, other);
     }
     if (forked) RC(stream_after(s, side));                       // join: every gradient is complete on s

@@ -99,6 +99,9 @@ size_t gemm3_workspace_bytes();
 // an API call (a tiny kernel, also under capture) covers all its launches on the same workspace
 // (`zero`: optionally `nzero` doubles cleared by the same launch -- the head's BatchNorm sums)
 int gemm3_clear_flags(void* workspace, size_t bytes, hipStream_t s, double* zero = nullptr, int nzero = 0);
+// words another kernel clears on the way (instead of a launch of its own): the hand-off flags of gemm3.hip and fp64 sums
+struct ZeroJob { unsigned* u; int nu; double* d; int nd; };
+int gemm3_zero_job(void* workspace, size_t bytes, double* zero, int nzero, ZeroJob* out);
 bool gemm3_ok(const GemmDesc& g);
 int launch_gemm3(const GemmDesc& g, const DwScatter* sc, void* workspace, size_t bytes, hipStream_t s);
 int launch_gemm3_pair(const GemmDesc& dx, const GemmDesc& dw, const DwScatter* sc, void* workspace, size_t bytes, hipStream_t s);
@@ -126,11 +129,12 @@ int head_gbn_bwd(const HeadGbn& a, hipStream_t s);
 // dpad_views: dpad_row holds one gradient row per VIEW ([K][ld_out]: sampled dropout of the non-stored rows) instead of one
 int layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                         const float* dxout, const ReadoutGrad* rg, const float* dpad_row, float* dx,
-                        const eagcn_layer_grads* g, void* stream, bool dpad_views = false);
+                        const eagcn_layer_grads* g, void* stream, bool dpad_views = false,
+                        const ZeroJob* zero_after = nullptr);
 int layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, void* stream,
                        bool prepacked);
 int pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const* ps, void* const* packed,
-                    const size_t* packed_bytes, int n, void* stream);
+                    const size_t* packed_bytes, int n, void* stream, const ZeroJob* zj = nullptr);
 int readout_forward_sampled(const eagcn_batch* b, const float* x, const eagcn_layout* lay, const eagcn_layer_params* p,
                             const float* bn_sh, const int64_t* size, int mode, float* g, int F, uint16_t* cnt, float* padc,
                             void* stream);

@@ -103,7 +103,14 @@ struct PackJob {
     float *Wcat, *WcatT, *colp, *sig, *rsig;
 };
 struct PackJobs { PackJob j0, j1, j2, j3; };
-__global__ __launch_bounds__(256) void pack_params_multi_kernel(PackJobs jobs) {
+__global__ __launch_bounds__(256) void pack_params_multi_kernel(PackJobs jobs, ZeroJob zj) {
+    // the call prologue of the model engine rides along: hand-off flags of gemm3.hip and the head's fp64 BatchNorm sums
+    if (blockIdx.y == 0) {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < max(zj.nu, zj.nd); i += gridDim.x * blockDim.x) {
+            if (i < zj.nu) zj.u[i] = 0u;
+            if (i < zj.nd) zj.d[i] = 0.0;
+        }
+    }
     // (an if-chain, not an indexed array: indexing the by-value argument block dynamically would move it to scratch)
     if (blockIdx.y == 0) pack_params_body(jobs.j0.pp, jobs.j0.vc, jobs.j0.in, jobs.j0.ld_in, jobs.j0.fp, jobs.j0.Wcat, jobs.j0.WcatT, jobs.j0.colp, jobs.j0.sig, jobs.j0.rsig);
     else if (blockIdx.y == 1) pack_params_body(jobs.j1.pp, jobs.j1.vc, jobs.j1.in, jobs.j1.ld_in, jobs.j1.fp, jobs.j1.Wcat, jobs.j1.WcatT, jobs.j1.colp, jobs.j1.sig, jobs.j1.rsig);
@@ -259,6 +266,7 @@ struct BwdArgs {
     double* slab;                // [grid][fp][2]
     double* slab_da;             // [grid][MAX_VIEWS]
     int do_drop; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
+    double* zero; int nzero;     // fp64 words cleared on the way (the head's backward sums, for the next backward call)
 };
 
 // One workgroup owns BWD_ROWS consecutive-strided rows; a thread owns FOUR adjacent columns (one float4 per row
@@ -274,6 +282,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     // the grid is sized for the row CAPACITY: only the first ceil(rows / BWD_ROWS) workgroups work (and write a
     // slab); bn_bwd_finalize derives the same count from the device-side row count
     const int nwg = max(1, min((int)gridDim.x, (rows + BWD_ROWS - 1) / BWD_ROWS));
+    if (blockIdx.x == 0 && a.zero)
+        for (int i = threadIdx.x; i < a.nzero; i += blockDim.x) a.zero[i] = 0.0;
     if ((int)blockIdx.x >= nwg) return;
     if (threadIdx.x < EAGCN_MAX_VIEWS) da_s[threadIdx.x] = 0.0;
     __syncthreads();
@@ -692,7 +702,7 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
 
 // parameters of up to four layers re-laid into their `packed` blocks by ONE launch (model engine)
 int eagcn::pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const* ps, void* const* packed,
-                           const size_t* packed_bytes, int n, void* stream) {
+                           const size_t* packed_bytes, int n, void* stream, const ZeroJob* zj) {
     hipStream_t s = (hipStream_t)stream;
     EAGCN_CHECK_ARG(n >= 1 && n <= 4, "pack_params_all: 1..4 layers");
     PackJob jobs[4];
@@ -715,7 +725,8 @@ int eagcn::pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const
     }
     PackJobs pj{jobs[0], jobs[1], jobs[2], jobs[3]};
     ProfScope ps_(PROF_PACK, s);
-    pack_params_multi_kernel<<<dim3(ew_grid(wmax), n), 256, 0, s>>>(pj);
+    const ZeroJob none{nullptr, 0, nullptr, 0};
+    pack_params_multi_kernel<<<dim3(ew_grid(wmax), n), 256, 0, s>>>(pj, zj ? *zj : none);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
@@ -820,7 +831,7 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
 
 int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                                const float* dxout, const ReadoutGrad* rg, const float* dpad_row, float* dx,
-                               const eagcn_layer_grads* g, void* stream, bool dpad_views) {
+                               const eagcn_layer_grads* g, void* stream, bool dpad_views, const ZeroJob* zero_after) {
     hipStream_t s = (hipStream_t)stream;
     int rc = check_layer(b, p, "eagcn_layer_backward");
     if (rc) return rc;
@@ -873,6 +884,8 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     ba.inv_keep = 1.0f / (1.0f - p->dropout);
     ba.seed = p->seed;
     ba.seed_dev = p->seed_dev;
+    ba.zero = zero_after ? zero_after->d : nullptr;
+    ba.nzero = zero_after ? zero_after->nd : 0;
     const int rows = b->T + ba.nvirt;
     const int gxb = std::max(1, std::min(rows, d.gxb));
     const double M = (double)b->B * (double)b->N;
