@@ -194,6 +194,90 @@ class GraphConv_Layer(nn.Module):
         return (u / u.sum(dim=2, keepdim=True)) * m
 
 
+class _Frozen:
+    """Stand-in for a parameter container whose `weight` is a constant buffer (Vanilla_GCN)."""
+
+    def __init__(self, weight):
+        self.weight = weight
+
+
+class Vanilla_GCN(nn.Module):
+    """The Kipf-GCN baseline layer of the reference (layers.py:205-258, used by models.py:63-67 for structure='GCN'):
+    A = adj + mask*I + 1e-9*(1-adj), row-normalised and row-masked, then (A.X).W + b -> BatchNorm -> relu -> dropout.
+    That is one view of the edge-attention layer with every bond weight and the self weight equal to ONE and no row
+    mask on the output, so it runs on the same kernels: a single-view 'Weighted_sum' layer whose attention logits are
+    frozen at +40 (sigmoid(40) == 1.0f exactly) and whose mixing weight is frozen at 1.  Parameter tree as the reference:
+    graph_conv.{weight,bias}, batch_norm.{weight,bias,bn.*}; the frozen constants are non-persistent buffers.
+    forward(adjs, afms, TypeAtt, ...) -> (x, A) as the reference; only the first relation tensor's bond POSITIONS are
+    used (= adj)."""
+
+    structure = 'Weighted_sum'
+    K = 1
+    last = False
+
+    def __init__(self, node_feature_in, node_feature_out, dropout, *, bond_channels=1):
+        super().__init__()
+        self.node_feature_in, self.node_feature_out = node_feature_in, node_feature_out
+        self.graph_conv = GraphConv_base(node_feature_in, node_feature_out, bias=True)
+        self.batch_norm = AFM_BatchNorm(node_feature_out)
+        self.dropout = dropout
+        self.widths, self.rel_channels = [int(node_feature_out)], [int(bond_channels)]
+        self.total_output = int(node_feature_out)
+        self.register_buffer('_att_w', torch.full((1, int(bond_channels), 1, 1), 40.0), persistent=False)
+        self.register_buffer('_self_r', torch.full((1,), 40.0), persistent=False)
+        self.register_buffer('_ave_w', torch.ones(1), persistent=False)
+        self._specs = {}
+
+    def __getstate__(self):
+        state = super().__getstate__() if hasattr(nn.Module, '__getstate__') else self.__dict__.copy()
+        state = dict(state)
+        state['_specs'] = {}
+        return state
+
+    # the interface ModelPlan / forward_packed expect from a layer and from a view
+    @property
+    def att(self):
+        return _Frozen(self._att_w)
+
+    @property
+    def self_r(self):
+        return self._self_r
+
+    @property
+    def ave(self):
+        return _Frozen(self._ave_w)
+
+    def blocks(self):
+        return [self]
+
+    def hot_params(self):
+        return (self._att_w, self._self_r, self.graph_conv.weight, self.graph_conv.bias,
+                self.batch_norm.bn.weight, self.batch_norm.bn.bias)
+
+    spec_for = GraphConv_Layer.spec_for
+    forward_packed = GraphConv_Layer.forward_packed
+
+    @property
+    def block1(self):
+        return self
+
+    def forward(self, adjs, afms, *rels, index=None):
+        if index is None:
+            if not rels:
+                raise EagcnHipError('Vanilla_GCN needs the first relation tensor (bond positions)')
+            index = ops.BatchIndex(adjs, rels[:1])
+        in_layout = ops.ColLayout.single(self.node_feature_in)
+        x = ops.pack_rows(index, in_layout, afms)
+        xout, pad_row, out_layout = self.forward_packed(index, x, in_layout)
+        dense = ops.unpack_rows(index, out_layout, xout, pad_row)
+        with torch.no_grad():                       # A of layers.py:250-253 (dense tensor algebra; not on the hot path)
+            B, N, _ = adjs.shape
+            m = adjs.max(dim=2, keepdim=True)[0]
+            a = adjs + m * torch.eye(N, device=adjs.device, dtype=adjs.dtype) + (1.0 - adjs) * 1e-9
+            a = (a / a.sum(dim=2, keepdim=True)) * m
+        return dense, a
+
+
 class Dense(nn.Module):
     """x @ W without bias by default (reference layers.py:360-392); W is U(-1/sqrt(fout), ..)."""
 

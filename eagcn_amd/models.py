@@ -41,7 +41,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import Dense, GraphConv_Layer
+from .layers import Dense, GraphConv_Layer, Vanilla_GCN
 
 
 class LazyAtomRep:
@@ -91,14 +91,22 @@ class EAGCN(nn.Module):
             raise ValueError('widths1 and widths2 need one entry per view')
         if rel_channels is None:
             rel_channels = [n_bfeat, 4, 2, 2, 2][:K]
-        if structure not in ('Concate', 'Weighted_sum'):
-            raise ValueError("the HIP hot path implements structure 'Concate' and 'Weighted_sum' "
-                             "(the GCN / GAT baselines of models.py:63-73 are outside its scope)")
+        if structure not in ('Concate', 'Weighted_sum', 'GCN'):
+            raise ValueError("the HIP hot path implements structure 'Concate', 'Weighted_sum' and the Kipf-GCN baseline "
+                             "'GCN' (the GAT baseline of models.py:69-73 is outside its scope)")
         if molfp_mode not in ('sum', 'ave'):
             raise ValueError("molfp_mode 'sum' and 'ave' are implemented ('pool' = Diff_Pooling is "
                              "outside the hot path, SURVEY.md 8f)")
         if not 1 <= n_layers <= 4:
             raise ValueError('n_layers must be 1..4')
+        if structure == 'GCN':                                            # models.py:63-67: four Vanilla_GCN layers
+            self.ngc1, self.ngc2 = sum(widths1), sum(widths2)
+            gplan = [(n_afeat, self.ngc1), (self.ngc1, self.ngc2), (self.ngc2, self.ngc2), (self.ngc2, 2 * self.ngc2)][:n_layers]
+            for i, (fin, fout) in enumerate(gplan):
+                setattr(self, 'layer%d' % (i + 1), Vanilla_GCN(fin, fout, dropout, bond_channels=rel_channels[0]))
+            self._finish_init(n_layers, n_afeat, 1, structure, molfp_mode, dropout, atom_rep, grad_mode, overlap_index, graph,
+                              row_cap, edge_cap, graph_outputs, validate, max_runners, gplan[-1][1], n_den1, n_den2, nclass)
+            return
         if structure == 'Weighted_sum':                                   # models.py:33-47
             widths1 = [sum(widths1)] * K
             widths2 = [sum(widths2)] * K
@@ -112,7 +120,11 @@ class EAGCN(nn.Module):
             setattr(self, 'layer%d' % (i + 1),
                     GraphConv_Layer(fin, n_bfeat, None, dropout=dropout, structure=structure, last=(i == 3),
                                     widths=ws, rel_channels=rel_channels))
-        f_last = plan[-1][2]
+        self._finish_init(n_layers, n_afeat, K, structure, molfp_mode, dropout, atom_rep, grad_mode, overlap_index, graph,
+                          row_cap, edge_cap, graph_outputs, validate, max_runners, plan[-1][2], n_den1, n_den2, nclass)
+
+    def _finish_init(self, n_layers, n_afeat, K, structure, molfp_mode, dropout, atom_rep, grad_mode, overlap_index, graph,
+                     row_cap, edge_cap, graph_outputs, validate, max_runners, f_last, n_den1, n_den2, nclass):
         self.n_layers, self.n_afeat, self.K = n_layers, n_afeat, K
         self.structure, self.molfp_mode, self.dropout = structure, molfp_mode, dropout
         self.atom_rep = atom_rep
@@ -232,7 +244,7 @@ class EAGCN(nn.Module):
     def _atom_rep(self, runner):
         if self.atom_rep == 'none':
             return None
-        pad = runner.pad_view if self.structure == 'Weighted_sum' else None
+        pad = runner.pad_view if self.structure in ('Weighted_sum', 'GCN') else None
         rep = LazyAtomRep(runner.index, self.plan().last_layout, runner.xout_view, pad)
         return rep.cpu() if self.atom_rep == 'eager' else rep
 
@@ -255,8 +267,12 @@ class EAGCN(nn.Module):
         if bonds is None:
             adjs, afms, *rels_and_size = batch
             *rels, size = rels_and_size
+            if self.structure == 'GCN':
+                rels = rels[:1]
         else:
             adjs, rels, (afms, size) = None, None, batch
+            if self.structure == 'GCN':
+                bonds = bonds.first_view()
         runner, adjs, rels, afms, size, seed, btuple = self._graph_runner(adjs, afms, rels, size, bonds)
         kind = 'mse' if task == 'reg' else 'bce'
         if kind == 'bce' and not isinstance(bce_weight, torch.Tensor):
@@ -270,6 +286,8 @@ class EAGCN(nn.Module):
         size) -> (x, atom_representations, graph_representation).  The whole forward is one call into
         eagcn_model_forward (layers, read-out and head); backward is one call into eagcn_model_backward."""
         *rels, size = rels_and_size
+        if self.structure == 'GCN':
+            rels = rels[:1]                                          # Vanilla_GCN only needs the bond positions (= adj)
         if self.graph and (self.training and torch.is_grad_enabled() or not self.training and not torch.is_grad_enabled()):
             return self._graph_forward(adjs, afms, rels, size)       # training step, or eval under no_grad (train.py:130-211)
         index = ops.BatchIndex(adjs, rels, overlap=self.overlap_index)   # once per batch, shared by all layers
@@ -280,6 +298,8 @@ class EAGCN(nn.Module):
         (directed bond list + per-view bond type), ``afms`` the padded [B,N,n_afeat] atom features.  Results are
         identical to ``forward`` on the dense tensors the reference's collate (utils.py:575-640) would build for
         the same molecules; the adjacency / relation tensors are never materialised."""
+        if self.structure == 'GCN':
+            bonds = bonds.first_view()
         if self.graph and (self.training and torch.is_grad_enabled() or not self.training and not torch.is_grad_enabled()):
             return self._graph_forward(None, afms, None, size, bonds)
         index = ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, *bonds.checked())
@@ -297,7 +317,7 @@ class EAGCN(nn.Module):
             torch._foreach_add_(plan.nbt, 1)
         atom_representations = None
         if holder is not None:
-            pad = holder['pad_row'] if self.structure == 'Weighted_sum' else None
+            pad = holder['pad_row'] if self.structure in ('Weighted_sum', 'GCN') else None
             atom_representations = LazyAtomRep(index, plan.last_layout, holder['xout'], pad)
             if self.atom_rep == 'eager':
                 atom_representations = atom_representations.cpu()
@@ -320,9 +340,11 @@ class EAGCN(nn.Module):
         """Same computation composed from the layer-level entry points (one autograd node per layer,
         head as separate ops); kept for tests that cross-check the model-level engine."""
         *rels, size = rels_and_size
+        if self.structure == 'GCN':
+            rels = rels[:1]
         index = ops.BatchIndex(adjs, rels)
         x, pad_row, layout = self.forward_layers(index, afms)[-1]
-        pad = pad_row if self.structure == 'Weighted_sum' else None
+        pad = pad_row if self.structure in ('Weighted_sum', 'GCN') else None
         g = ops.readout(index, layout, x, pad, self.molfp_mode, size)      # models.py:108-111
         g = self.Graph_BN(g)
         h = F.relu(self.bn_den1(self.den1(g)))

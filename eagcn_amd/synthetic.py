@@ -84,6 +84,13 @@ class CompactBonds:
     bond_j: torch.Tensor
     bond_code: torch.Tensor
 
+    def first_view(self):
+        """The same bonds with the first attention view only (structure='GCN' needs the bond positions, no types)."""
+        if len(self.channels) == 1:
+            return self
+        return CompactBonds(self.B, self.N, list(self.channels[:1]), self.bond_mol, self.bond_i, self.bond_j,
+                            self.bond_code[:, :1].contiguous())
+
     def checked(self):
         E = self.bond_mol.numel()
         for t, dt, name in ((self.bond_mol, torch.int32, 'bond_mol'), (self.bond_i, torch.int32, 'bond_i'),

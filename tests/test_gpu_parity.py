@@ -89,9 +89,9 @@ def test_model_golden(name):
     import copy
     probe = copy.deepcopy(model)
     with torch.no_grad():
-        index = ops.BatchIndex(adj, rels)
+        index = ops.BatchIndex(adj, rels[:1] if g.meta['structure'] == 'GCN' else rels)
         for i, (x, pad_row, layout) in enumerate(probe.forward_layers(index, afm)):
-            pad = pad_row if g.meta['structure'] == 'Weighted_sum' else None
+            pad = pad_row if g.meta['structure'] in ('Weighted_sum', 'GCN') else None
             dense_x = ops.unpack_rows(index, layout, x, pad)
             assert rel_err(dense_x.cpu(), g.z['out/layer%d' % (i + 1)]) < TOL, 'layer%d' % (i + 1)
     out, atom_rep, graph_rep = model(adj, afm, *rels, size)
@@ -996,3 +996,50 @@ def test_training_dropout_masks_injected_into_oracle(structure, graph):
         if ok:
             return
     raise AssertionError('no seed without an ill-conditioned (relu boundary) instance')
+
+
+@pytest.mark.gpu
+def test_gcn_baseline_graph_mode_and_training_vs_oracle():
+    """structure='GCN' (Vanilla_GCN layers, reference layers.py:205-258 / models.py:63-67): eager engine, captured graphs
+    and the oracle agree on outputs, gradients and running statistics over two steps with dropout 0."""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    from oracle.eagcn_ref import RefEAGCN, regression_loss
+    torch.manual_seed(11)
+    w1, w2 = [12, 8, 4, 4, 4], [16, 8, 8, 8, 8]
+    ref = RefEAGCN(28, 24, w1, w2, 32, 16, 1, 0.0, structure='GCN', n_layers=4)
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    models = {}
+    for graph in (False, True):
+        m = EAGCN(28, 24, widths1=w1, widths2=w2, n_den1=32, n_den2=16, nclass=1, dropout=0.0, structure='GCN', graph=graph)
+        m.load_state_dict(sd0, strict=True)
+        models[graph] = m.cuda().train()
+    ref.train()
+    for step in range(2):
+        mb = make_batch(B=10, n_max=26, n_med=9, rel_channels=(28, 4, 2, 2, 2), seed=60 + step, n_tasks=1, task='reg',
+                        isolated_frac=0.1)
+        dense = mb.dense()
+        labels = torch.from_numpy(mb.labels)
+        ref.zero_grad()
+        out_r, _, gr_r = ref(*dense)
+        regression_loss(out_r, labels).backward()
+        for graph, m in models.items():
+            for p in m.parameters():
+                p.grad = None
+            out, _, gr = m(*_dev(dense))
+            torch.nn.functional.mse_loss(out.view(-1), labels.cuda().view(-1)).backward()
+            assert rel_err(out.detach().cpu(), out_r.detach(), 'gcn out (graph=%s, step %d)' % (graph, step)) < 1e-5
+            assert rel_err(gr.detach().cpu(), gr_r.detach(), 'gcn graph_rep') < 1e-5
+            got = dict(m.named_parameters())
+            scale = max(p.grad.abs().max().item() for p in ref.parameters() if p.grad is not None)
+            for k, p in ref.named_parameters():
+                if p.grad is None:
+                    continue
+                assert_grad_close(got[k].grad.cpu(), p.grad.numpy(), scale, k + ' (graph=%s)' % graph, rtol=1e-4, floor=5e-6)
+    sd_r = ref.state_dict()
+    for graph, m in models.items():
+        for k, v in m.state_dict().items():
+            if 'running' in k:
+                assert (v.cpu() - sd_r[k]).abs().max().item() <= 1e-5 * max(sd_r[k].abs().max().item(), 1.0), k
+            if 'num_batches' in k:
+                assert int(v) == int(sd_r[k]) == 2, k

@@ -178,6 +178,12 @@ def layer_case(name, structure, training, batch_kw, fin, widths, n_bfeat, seed=0
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]          # optional: names of the cases to (re)generate; default all
+    global model_case, layer_case
+    if only:
+        mc, lc = model_case, layer_case
+        model_case = lambda name, *a, **k: mc(name, *a, **k) if name in only else None
+        layer_case = lambda name, *a, **k: lc(name, *a, **k) if name in only else None
     small = dict(B=6, n_max=12, n_med=6)
     w1 = (8, 6, 4, 4, 5)
     w2 = (10, 7, 5, 6, 4)
@@ -205,6 +211,12 @@ def main():
                dict(B=4, n_max=7, sizes=np.array([1, 7, 3, 1]), force_max=True), w1, w2, (16, 8), 2, 7, seed=11)
     model_case('model_concate_bigN', 'Concate', 'sum', True, dict(B=3, n_max=33, n_med=12),
                (6, 5, 4, 3, 2), (7, 6, 5, 4, 3), (12, 6), 2, 3, seed=12)
+    # --- the Kipf-GCN baseline of models.py:63-67 (Vanilla_GCN layers, layers.py:205-258): SURVEY 8 row f-4 ---
+    model_case('model_gcn_train', 'GCN', 'sum', True, dict(B=6, n_max=12, n_med=6, isolated_frac=0.15), w1, w2, (16, 8), 3, 7,
+               seed=13)
+    model_case('model_gcn_eval', 'GCN', 'sum', False, small, w1, w2, (16, 8), 2, 7, seed=14)
+    model_case('model_gcn_ave_bce_train', 'GCN', 'ave', True, dict(B=8, n_max=10, n_med=5), w1, w2, (16, 8), 4, 7, loss='bce',
+               seed=15)
     # --- single layers (used for the 2-/3-layer parity of the n_layers extension) ---
     layer_case('layer_concate_train', 'Concate', True, small, 24, (8, 6, 4, 4, 5), 7, seed=21)
     layer_case('layer_concate_eval', 'Concate', False, small, 24, (8, 6, 4, 4, 5), 7, seed=22)
