@@ -107,6 +107,7 @@ SIGNATURES = {
     'eagcn_set_gemm_mode': (C.c_int, [C.c_int]),
     'eagcn_pack_rows': (C.c_int, [C.POINTER(Batch), _fp, C.c_int, C.POINTER(Layout), _fp, _fp]),
     'eagcn_unpack_rows': (C.c_int, [C.POINTER(Batch), _fp, C.POINTER(Layout), _fp, _fp, C.c_int, _fp]),
+    'eagcn_pad_rows': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     'eagcn_layer_forward': (C.c_int, [C.POINTER(Batch), C.POINTER(LayerParams), C.POINTER(LayerBufs), _fp]),
     'eagcn_layer_backward': (C.c_int, [C.POINTER(Batch), C.POINTER(LayerParams), C.POINTER(LayerBufs),
                                        _fp, _fp, _fp, C.POINTER(LayerGrads), _fp]),

@@ -383,6 +383,20 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(eagcn_batch bt, const fl
     }
 }
 
+// unpadded per-molecule rows [sum n_b][F] (molecule b = rows off[b] .. off[b+1]) -> padded [B][N][F], zero beyond n_b:
+// the device half of the reference's collate padding (utils.py:586-590 / 534-538)
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ rows, const int32_t* __restrict__ off,
+                                                        int B, int N, int F, float* __restrict__ out) {
+    const size_t total = (size_t)B * N * F;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(e % F);
+        const size_t bi = e / F;
+        const int i = (int)(bi % N), b = (int)(bi / N);
+        const int o = off[b], n = off[b + 1] - o;
+        out[e] = i < n ? rows[(size_t)(o + i) * F + f] : 0.0f;
+    }
+}
+
 __global__ __launch_bounds__(256) void unpack_rows_kernel(eagcn_batch bt, const float* __restrict__ packed,
                                                            ColMap m, int ld, const float* __restrict__ pad_row,
                                                            float* __restrict__ dense, int F) {
@@ -521,6 +535,16 @@ extern "C" int eagcn_pack_rows(const eagcn_batch* b, const float* dense, int F, 
     int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
     ProfScope ps(PROF_PACK, s);
     pack_rows_kernel<<<grid, 256, 0, s>>>(*b, dense, F, make_colmap(lay), ld, packed);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_pad_rows(const float* rows, const int32_t* mol_offset, int B, int N, int F, float* out, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    EAGCN_CHECK_ARG(rows && mol_offset && out && B > 0 && N > 0 && F > 0, "eagcn_pad_rows: bad argument");
+    const size_t total = (size_t)B * N * F;
+    ProfScope ps(PROF_PACK, s);
+    pad_rows_kernel<<<(int)std::min<size_t>((total + 255) / 256, 4096), 256, 0, s>>>(rows, mol_offset, B, N, F, out);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

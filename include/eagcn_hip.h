@@ -198,6 +198,12 @@ int eagcn_index_rows(const eagcn_batch* b, void* stream);
 /* ---- layout conversion ----------------------------------------------------------------------- */
 int eagcn_pack_rows(const eagcn_batch* b, const float* dense, int F, const eagcn_layout* lay,
                     float* packed, void* stream);
+/* Device half of the reference's collate (utils.py:504-640: every molecule zero-padded to the batch maximum): per-molecule
+   atom-feature rows, concatenated [sum n_b][F] with molecule b = rows mol_offset[b] .. mol_offset[b+1], -> padded [B][N][F].
+   Together with eagcn_index_from_bonds a batch reaches the device as O(atoms + bonds) bytes instead of
+   4 (1 + sum C_k) B N^2.                                                                     */
+int eagcn_pad_rows(const float* rows, const int32_t* mol_offset, int B, int N, int F, float* out, void* stream);
+
 int eagcn_unpack_rows(const eagcn_batch* b, const float* packed, const eagcn_layout* lay,
                       const float* pad_row, float* dense, int F, void* stream);
 

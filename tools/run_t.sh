@@ -1,4 +1,3 @@
 mkdir -p gpurun_out/tests
-timeout 400 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout=300 -k "gcn" > gpurun_out/tests/pytest_gcn.log 2>&1; echo "pytest rc=$?"
-grep -E "^FAILED|^ERROR|passed|failed|Error" gpurun_out/tests/pytest_gcn.log | tail -8
-grep -E "gcn" gpurun_out/tests/pytest_gcn.log | tail -8 | cut -c1-260
+timeout 300 python -m pytest tests/test_gpu_collate.py -m gpu -q --timeout=200 > gpurun_out/tests/pytest_col.log 2>&1; echo "pytest rc=$?"
+grep -E "^FAILED|^ERROR|passed|failed|^E  " gpurun_out/tests/pytest_col.log | tail -12
