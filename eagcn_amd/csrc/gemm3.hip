@@ -43,6 +43,8 @@ constexpr int G3_MAX_RANGES = 8192;
 #define G3_WAVES_PER_SIMD 1
 #endif
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 struct G3Sched {
     int total, R, per, rem;                // R ranges; range l = [l*per + min(l,rem), ...)
     __device__ __forceinline__ int start(int l) const { return l * per + min(l, rem); }
@@ -160,47 +162,62 @@ __device__ __forceinline__ void g3_segment(const G2Prob& p, const DwScatter& sc,
     }
 #undef EAGCN_G3_STEP
 
-    // ---- hand-off of partial tiles (per wave; write-through stores / sc1 loads, no fences) -------------------------------
+    // ---- hand-off of partial tiles (per wave; 16-byte write-through (sc1) stores and sc1 loads through a buffer
+    //      descriptor -- no fences: sc1 stores leave the XCD's L2, sc1 loads bypass the CU's L1; 8-byte agent-scope
+    //      atomics, the only other fence-free form, move the same bytes at about half the rate) ------------------------------
     if (mode == 1) {
-        gu64* slot = (gu64*)(ws + (size_t)l * G3_SLOT);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(ws + (size_t)l * G3_SLOT), 0, G3_SLOT * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int o = ((i * 4 + j) * 64 + lane) * 2;
-                __hip_atomic_store(slot + o, ((unsigned long long)__float_as_uint(acc[i][j][1]) << 32) | __float_as_uint(acc[i][j][0]), EAGCN_RLX_AGENT);
-                __hip_atomic_store(slot + o + 1, ((unsigned long long)__float_as_uint(acc[i][j][3]) << 32) | __float_as_uint(acc[i][j][2]), EAGCN_RLX_AGENT);
-            }
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, ((i * 4 + j) * 64 + lane) * 16, 0, 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's stores have left
         if (lane == 0) __hip_atomic_store((gu32*)(flags + l), 1u, EAGCN_RLX_AGENT);
         return;
     }
     if (mode == 2) {
-        // contributors: the ranges l+1, l+2, ... that start inside this tile (empty ranges export nothing)
+        // contributors: the ranges l+1, l+2, ... that start inside this tile (empty ranges export nothing); taken two at a
+        // time so that the loads of two parked tiles are in flight together (the ring registers are free by now); the
+        // additions stay in range order
         int last = l;
         while (last + 1 < sched.R && sched.start(last + 1) < tile_end_global) ++last;
-        for (int c = l + 1; c <= last; ++c) {
-            if (sched.start(c + 1) <= sched.start(c)) continue;
+        auto wait_flag = [&](int c) __attribute__((always_inline)) {
             unsigned spins = 0;
             while (__hip_atomic_load((gu32*)(flags + c), EAGCN_RLX_AGENT) == 0u) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1u << 22)) { if (lane == 0) atomicAdd(&g_gemm3_timeouts, 1); break; }
             }
-            const gu64* slot = (const gu64*)(ws + (size_t)c * G3_SLOT);
+        };
+        int c = l + 1;
+        while (c <= last) {
+            while (c <= last && sched.start(c + 1) <= sched.start(c)) ++c;
+            if (c > last) break;
+            const int c1 = c++;
+            while (c <= last && sched.start(c + 1) <= sched.start(c)) ++c;
+            const int c2 = c <= last ? c++ : -1;
+            wait_flag(c1);
+            if (c2 >= 0) wait_flag(c2);
+            const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(ws + (size_t)c1 * G3_SLOT), 0, G3_SLOT * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(ws + (size_t)(c2 >= 0 ? c2 : c1) * G3_SLOT), 0, G3_SLOT * 4, 0x00020000);
+            u32x4 t1[16], t2[16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int e = 0; e < 16; ++e) t1[e] = __builtin_amdgcn_raw_buffer_load_b128(r1, (e * 64 + lane) * 16, 0, 16);
+            if (c2 >= 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int o = ((i * 4 + j) * 64 + lane) * 2;
-                    const unsigned long long v0 = __hip_atomic_load(slot + o, EAGCN_RLX_AGENT);
-                    const unsigned long long v1 = __hip_atomic_load(slot + o + 1, EAGCN_RLX_AGENT);
-                    acc[i][j][0] += __uint_as_float((unsigned)v0);
-                    acc[i][j][1] += __uint_as_float((unsigned)(v0 >> 32));
-                    acc[i][j][2] += __uint_as_float((unsigned)v1);
-                    acc[i][j][3] += __uint_as_float((unsigned)(v1 >> 32));
-                }
+                for (int e = 0; e < 16; ++e) t2[e] = __builtin_amdgcn_raw_buffer_load_b128(r2, (e * 64 + lane) * 16, 0, 16);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e >> 2][e & 3] += __builtin_bit_cast(f32x4, t1[e]);
+            if (c2 >= 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e >> 2][e & 3] += __builtin_bit_cast(f32x4, t2[e]);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store((gu32*)(flags + c), 0u, EAGCN_RLX_AGENT);
+            if (lane == 0) {
+                __hip_atomic_store((gu32*)(flags + c1), 0u, EAGCN_RLX_AGENT);
+                if (c2 >= 0) __hip_atomic_store((gu32*)(flags + c2), 0u, EAGCN_RLX_AGENT);
+            }
         }
     }
 
