@@ -372,14 +372,23 @@ def main():
     if world == 1 and not args.no_extras and args.workload == 'tox21_c2' and args.batch is None and not args.eager:
         keep = (args.repeats, args.steps, args.warmup)
         extra = {}
-        for key, (wname, wb, steps) in (('b1024', ('tox21_c2', 1024, 30)), ('hiv_c3', ('hiv_c3', 1024, 10)),
-                                         ('lipo_c4', ('lipo_c4', 512, 30)), ('c5_synth', ('c5_synth', 1024, 6))):
+        for key, (wname, wb, steps, mode) in (('b1024', ('tox21_c2', 1024, 30, 0)), ('hiv_c3', ('hiv_c3', 1024, 10, 0)),
+                                               ('lipo_c4', ('lipo_c4', 512, 30, 0)), ('c5_synth', ('c5_synth', 1024, 6, 0)),
+                                               ('c2_bf16_products', ('tox21_c2', 256, 50, 2))):
             del res
             torch.cuda.empty_cache()
             args.repeats, args.steps, args.warmup = 5, steps, 4
-            res = run_workload(wname, wb, args, lib, dev, rank, world, GradientAllReducer, detail=False)
+            old_mode = lib.eagcn_set_gemm_mode(mode)         # fresh model + fresh graphs per workload: captured with this mode
+            try:
+                res = run_workload(wname, wb, args, lib, dev, rank, world, GradientAllReducer, detail=False)
+            finally:
+                lib.eagcn_set_gemm_mode(old_mode)
             e = summarize(res, args, world)
             e['workload'] = '%s, batch %d, N_pad %d, %d blocks of %d steps' % (wname, wb, res['N'], args.repeats, args.steps)
+            if mode == 2:
+                e['dtype'] = ('BASELINE configs[1] as written: hidden-layer products X.W, dP.W^T, X^T.dP with bf16 operands '
+                              '(round to nearest even, one bf16 MFMA product, fp32 accumulate); aggregation, BatchNorm, head and '
+                              'first layer fp32.  NOT the parity path: error vs the fp32 oracle in tests/test_gpu_bf16.py')
             extra[key] = e
         args.repeats, args.steps, args.warmup = keep
         out['extra'] = extra

@@ -18,8 +18,23 @@ namespace eagcn {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-constexpr int x6_lds_bytes(int bm, int bn) { return 2 * 3 * (bm + bn) * 64; }   // two buffers x three pieces x rows x 64 B
+constexpr int x6_lds_bytes(int bm, int bn, int np = 3) { return 2 * np * (bm + bn) * 64; }   // two buffers x pieces x rows x 64 B
 constexpr int X6_LDS_BYTES = x6_lds_bytes(64, 64);
+
+// eight fp32 values (consecutive k) -> eight bf16 values, round to nearest even (the plain bf16 mode: ONE piece, ONE product;
+// operands rounded to 8 significand bits, fp32 accumulation -- BASELINE.json configs[1] as written, NOT the parity path)
+__device__ __forceinline__ void bf16_round8(const float (&v)[8], u32x4_t& pl) {
+    uint32_t h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t b = __float_as_uint(v[e]);
+        h[e] = (b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u;
+    }
+    pl[0] = (h[0] >> 16) | h[1];
+    pl[1] = (h[2] >> 16) | h[3];
+    pl[2] = (h[4] >> 16) | h[5];
+    pl[3] = (h[6] >> 16) | h[7];
+}
 
 // eight fp32 values (consecutive k) -> three vectors of eight bf16 pieces
 __device__ __forceinline__ void x6_split8(const float (&v)[8], u32x4_t (&pl)[3]) {
@@ -43,18 +58,19 @@ __device__ __forceinline__ void x6_split8(const float (&v)[8], u32x4_t (&pl)[3])
     }
 }
 
-template <bool A_KC, bool B_KC, int BM = 64, int BN = 64>
+// NP = 3: the exact split (six products); NP = 1: plain bf16 operands (one product)
+template <bool A_KC, bool B_KC, int BM = 64, int BN = 64, int NP = 3>
 __device__ __forceinline__ void gemm_tile_x6(const GemmDesc& g, const int Mx, const int Kx, const int tile_x,
                                              const int tile_y, const int z, const int nsp, unsigned char* smem) {
     constexpr int BK = 32;
     constexpr int WM = BM / 2, WN = BN / 2;                          // 2 x 2 waves
     constexpr int MR = WM / 16, NR = WN / 16;                        // MFMA tiles per wave
     constexpr int APL = BM * 64, BPL = BN * 64;                      // bytes of one piece plane: rows x 32 bf16
-    constexpr int BUF = 3 * (APL + BPL);
+    constexpr int BUF = NP * (APL + BPL);
     constexpr int ABLK = BM / 64, BBLK = BN / 64;                    // 8-element blocks a thread stages per operand
     // smem: x6_lds_bytes(BM, BN) of 16-byte aligned LDS owned by the calling kernel: [buffer][A pieces | B pieces]
     auto aplane = [&](int buf, int p) -> unsigned char* { return smem + buf * BUF + p * APL; };
-    auto bplane = [&](int buf, int p) -> unsigned char* { return smem + buf * BUF + 3 * APL + p * BPL; };
+    auto bplane = [&](int buf, int p) -> unsigned char* { return smem + buf * BUF + NP * APL + p * BPL; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
@@ -108,19 +124,19 @@ __device__ __forceinline__ void gemm_tile_x6(const GemmDesc& g, const int Mx, co
         u32x4_t pl[3];
 #pragma unroll
         for (int u = 0; u < ABLK; ++u) {
-            x6_split8(ra[u], pl);
+            if constexpr (NP == 1) bf16_round8(ra[u], pl[0]); else x6_split8(ra[u], pl);
             const int r = a_row + 64 * u;
             const int o = r * 64 + ((a_kb ^ ((r >> 1) & 3)) << 4);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4_t*>(aplane(buf, p) + o) = pl[p];
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4_t*>(aplane(buf, p) + o) = pl[p];
         }
 #pragma unroll
         for (int u = 0; u < BBLK; ++u) {
-            x6_split8(rb[u], pl);
+            if constexpr (NP == 1) bf16_round8(rb[u], pl[0]); else x6_split8(rb[u], pl);
             const int r = b_row + 64 * u;
             const int o = r * 64 + ((b_kb ^ ((r >> 1) & 3)) << 4);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4_t*>(bplane(buf, p) + o) = pl[p];
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4_t*>(bplane(buf, p) + o) = pl[p];
         }
     };
 
@@ -141,9 +157,9 @@ __device__ __forceinline__ void gemm_tile_x6(const GemmDesc& g, const int Mx, co
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);          // lands while this tile is multiplied
-        u32x4_t af[MR][3], bf[NR][3];
+        u32x4_t af[MR][NP], bf[NR][NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int i = 0; i < MR; ++i) af[i][p] = *reinterpret_cast<const u32x4_t*>(aplane(cur, p) + (wm + i * 16 + li) * 64 + fo);
 #pragma unroll
@@ -154,11 +170,13 @@ __device__ __forceinline__ void gemm_tile_x6(const GemmDesc& g, const int Mx, co
     _Pragma("unroll") for (int i = 0; i < MR; ++i) _Pragma("unroll") for (int j = 0; j < NR; ++j)                   \
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i][PA]),                 \
                                                             __builtin_bit_cast(bf16x8_t, bf[j][PB]), acc[i][j], 0, 0, 0);
-        EAGCN_X6_PROD(2, 0)
-        EAGCN_X6_PROD(1, 1)
-        EAGCN_X6_PROD(0, 2)
-        EAGCN_X6_PROD(1, 0)
-        EAGCN_X6_PROD(0, 1)
+        if constexpr (NP == 3) {
+            EAGCN_X6_PROD(2, 0)
+            EAGCN_X6_PROD(1, 1)
+            EAGCN_X6_PROD(0, 2)
+            EAGCN_X6_PROD(1, 0)
+            EAGCN_X6_PROD(0, 1)
+        }
         EAGCN_X6_PROD(0, 0)
 #undef EAGCN_X6_PROD
         if (kt + 1 < nk) store_tiles(cur ^ 1);

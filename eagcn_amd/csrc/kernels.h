@@ -100,6 +100,7 @@ size_t gemm3_workspace_bytes();
 // (`zero`: optionally `nzero` doubles cleared by the same launch -- the head's BatchNorm sums)
 int gemm3_clear_flags(void* workspace, size_t bytes, hipStream_t s, double* zero = nullptr, int nzero = 0);
 // words another kernel clears on the way (instead of a launch of its own): the hand-off flags of gemm3.hip and fp64 sums
+int gemm_mode();             // 0 fp32 MFMA (default, parity path) | 1 exact bf16 x 6 | 2 plain bf16 operands (gemm.hip)
 struct ZeroJob { unsigned* u; int nu; double* d; int nd; };
 int gemm3_zero_job(void* workspace, size_t bytes, double* zero, int nzero, ZeroJob* out);
 bool gemm3_ok(const GemmDesc& g);

@@ -577,7 +577,7 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
 // single owner per tile (measured: 0.2 ms instead of 0.02 ms) -- it stays on the workgroup-tiled kernels (gemm.hip).
 static bool gemm3_layer(int ld_in) {
     static const bool on = [] { const char* v = getenv("EAGCN_NO_GEMM3"); return !(v && v[0] == '1'); }();
-    return on && ld_in >= 128;
+    return on && ld_in >= 128 && gemm_mode() != 2;       // (the bf16 mode runs on the LDS-tiled kernels of gemm.hip)
 }
 
 struct Packed { float *Wcat, *WcatT, *colp, *sig, *rsig; };
