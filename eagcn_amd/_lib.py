@@ -26,6 +26,7 @@ class Batch(C.Structure):
                 ('code', _fp), ('deg_bn', _fp), ('nat', _fp), ('row0', _fp), ('tile0', _fp),
                 ('meta', _fp), ('row_mol', _fp), ('row_loc', _fp), ('row_m', _fp), ('row_deg', _fp),
                 ('tile_mol', _fp), ('row_info', _fp), ('tile_info', _fp),
+                ('rel_vec', _fp * MAX_VIEWS), ('rel_c', C.c_int32 * MAX_VIEWS),
                 ('E', C.c_int32), ('reserved_', C.c_int32), ('ecnt', _fp), ('edge0', _fp), ('mol_info', _fp), ('row_ptr', _fp),
                 ('col_ptr', _fp), ('nbr', _fp), ('tnbr', _fp), ('ecode', _fp), ('tcode', _fp)]
 

@@ -17,11 +17,14 @@ from . import _lib as L
 from .synthetic import CompactBonds
 
 
-def compact_host(batch):
+def compact_host(batch, general=False):
     """Host half: list of per-molecule tuples -> dict of numpy arrays (no padding).
     bonds (mol, i, j) int32 [E] in row-major order of each adjacency, codes uint8 [E,K], rows float32 [sum n, F],
-    offsets int32 [B+1], sizes int64 [B], labels float32 [B, ...]."""
-    bm, bi, bj, codes, rows, sizes, labels = [], [], [], [], [], [], []
+    offsets int32 [B+1], sizes int64 [B], labels float32 [B, ...].
+    general=False: the relation tensors must be one-hot at the bonds (what neural_fp.py:111-120 produces); code = channel.
+    general=True: ANY channel values (layers.py:82 is a plain 1x1 convolution): the distinct channel vectors found at the bonds
+    of the batch become the code book of each view (`rel_vectors[k]`, lexicographically sorted, at most 255 per view)."""
+    bm, bi, bj, vecs, rows, sizes, labels = [], [], [], [], [], [], []
     K = 5
     for b, datum in enumerate(batch):
         adj, afm, rels = np.asarray(datum[0]), np.asarray(datum[1], dtype=np.float32), [np.asarray(r) for r in datum[2:7]]
@@ -30,22 +33,33 @@ def compact_host(batch):
         bm.append(np.full(i.shape, b, dtype=np.int32))
         bi.append(i.astype(np.int32))
         bj.append(j.astype(np.int32))
-        c = np.zeros((len(i), K), dtype=np.uint8)
-        for k, r in enumerate(rels):
-            hot = r[:, i, j]                                   # [C_k, E_b]
-            if len(i) and not ((hot == 1).sum(0) == 1).all():
-                raise ValueError('molecule %d, view %d: relation channels are not one-hot at the bonds' % (b, k))
-            c[:, k] = hot.argmax(0).astype(np.uint8) if len(i) else 0
-        codes.append(c)
+        vecs.append([np.ascontiguousarray(r[:, i, j].T, dtype=np.float32) for r in rels])     # per view [E_b, C_k]
         rows.append(afm.reshape(n, -1))
         sizes.append(n)
         labels.append(np.asarray(datum[7], dtype=np.float32))
+    E = int(sum(len(x) for x in bm))
+    codes = np.zeros((E, K), dtype=np.uint8)
+    channels, rel_vectors = [], []
+    for k in range(K):
+        v = np.concatenate([m[k] for m in vecs]) if E else np.zeros((0, np.asarray(batch[0][2 + k]).shape[0]), np.float32)
+        if not general:
+            if E and not (((v == 1).sum(1) == 1) & ((v != 0).sum(1) == 1)).all():
+                raise ValueError('view %d: relation channels are not one-hot at the bonds (use general=True)' % k)
+            codes[:, k] = v.argmax(1).astype(np.uint8) if E else 0
+            channels.append(int(v.shape[1]))
+        else:
+            table, inv = np.unique(v, axis=0, return_inverse=True) if E else (np.zeros((1, v.shape[1]), np.float32), np.zeros(0, int))
+            if len(table) > 255:
+                raise ValueError('view %d: %d distinct relation vectors at the bonds of this batch (at most 255)' % (k, len(table)))
+            codes[:, k] = np.asarray(inv).reshape(-1).astype(np.uint8)
+            channels.append(int(len(table)))
+            rel_vectors.append(np.ascontiguousarray(table, dtype=np.float32))
     off = np.zeros(len(batch) + 1, dtype=np.int32)
     off[1:] = np.cumsum(sizes)
     return {'bond_mol': np.concatenate(bm), 'bond_i': np.concatenate(bi), 'bond_j': np.concatenate(bj),
-            'bond_code': np.concatenate(codes), 'rows': np.concatenate(rows), 'offsets': off,
+            'bond_code': codes, 'rows': np.concatenate(rows), 'offsets': off,
             'sizes': np.asarray(sizes, dtype=np.int64), 'labels': np.stack(labels),
-            'channels': [int(np.asarray(r).shape[0]) for r in batch[0][2:7]]}
+            'channels': channels, 'rel_vectors': rel_vectors if general else None}
 
 
 def pad_rows(rows, offsets, B, N):
@@ -59,11 +73,11 @@ def pad_rows(rows, offsets, B, N):
     return out
 
 
-def collate_compact(batch, device, n_pad=None):
+def collate_compact(batch, device, n_pad=None, general=False):
     """-> (CompactBonds, afms [B,N,F] padded on the device, size [B], labels): the arguments of EAGCN.forward_compact /
     fused_step(bonds=...).  N = the batch maximum as in the reference (utils.py:583), or ``n_pad`` if given (a fixed N keeps
     one captured graph per model, utils.py:584's commented-out max_molsize)."""
-    h = compact_host(batch)
+    h = compact_host(batch, general)
     B = len(batch)
     N = int(n_pad) if n_pad else int(h['sizes'].max())
     if N < int(h['sizes'].max()):
@@ -71,6 +85,7 @@ def collate_compact(batch, device, n_pad=None):
 
     def dev(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(device)
-    bonds = CompactBonds(B, N, list(h['channels']), dev(h['bond_mol']), dev(h['bond_i']), dev(h['bond_j']), dev(h['bond_code']))
+    bonds = CompactBonds(B, N, list(h['channels']), dev(h['bond_mol']), dev(h['bond_i']), dev(h['bond_j']), dev(h['bond_code']),
+                         None if h['rel_vectors'] is None else [dev(v) for v in h['rel_vectors']])
     afms = pad_rows(dev(h['rows']), dev(h['offsets']), B, N)
     return bonds, afms, dev(h['sizes']), dev(h['labels'])

@@ -28,8 +28,18 @@ struct ParamPtrs {
     float* run_mean[EAGCN_MAX_VIEWS];
     float* run_var[EAGCN_MAX_VIEWS];
     const float* ave_w;
-    int channels[EAGCN_MAX_VIEWS];
+    int channels[EAGCN_MAX_VIEWS];          // bond-type codes of view k (1..channels[k])
+    const float* rel_vec[EAGCN_MAX_VIEWS];  // general relations: code c+1 -> channel vector rel_vec[k][c][0..rel_c[k]); null: one-hot
+    int rel_c[EAGCN_MAX_VIEWS];
 };
+// attention logit of bond code c (1-based) in view k: w[c-1] for one-hot relation tensors, <w, vec[c-1]> in general (layers.py:82)
+__device__ __forceinline__ float att_logit(const ParamPtrs& pp, int k, int c) {
+    if (!pp.rel_vec[k]) return pp.att_w[k][c - 1];
+    const float* v = pp.rel_vec[k] + (size_t)(c - 1) * pp.rel_c[k];
+    float s = 0.0f;
+    for (int ch = 0; ch < pp.rel_c[k]; ++ch) s = fmaf(pp.att_w[k][ch], v[ch], s);
+    return s;
+}
 struct GradPtrs {
     float* dW[EAGCN_MAX_VIEWS];
     float* dbias[EAGCN_MAX_VIEWS];
@@ -86,7 +96,7 @@ __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const View
     }
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < vc.K * 256; e += gridDim.x * blockDim.x) {
         const int k = e >> 8, c = e & 255;
-        sig[e] = (c >= 1 && c <= pp.channels[k]) ? sigmoidf_(pp.att_w[k][c - 1]) : 0.0f;
+        sig[e] = (c >= 1 && c <= pp.channels[k]) ? sigmoidf_(att_logit(pp, k, c)) : 0.0f;
     }
     if (blockIdx.x == 0 && threadIdx.x < vc.K) rsig[threadIdx.x] = sigmoidf_(pp.self_r[threadIdx.x][0]);
 }
@@ -485,29 +495,41 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
         gp.dW[k][(size_t)fi * vc.width[k] + f] = (s0 + s1) + (s2 + s3);
         return;
     }
-    // edge-gradient partials [nedge][K][EDGE_SLAB]: entry c in 1..C_k -> d att_w[c-1]; entry 256 -> self term
+    // edge-gradient partials [nedge][K][EDGE_SLAB]: entry c in 1..C_k -> d att_w[c-1]; entry 256 -> self term.
+    // General relation vectors (pp.rel_vec[k]): the histogram is per bond CODE, the gradient per CHANNEL:
+    //   d att_w[ch] = sum_codes h[code] * vec[code][ch]  -- entry ch of view k sums over all codes (rare path, not tuned)
     const int er = ((int)blockIdx.x - wblocks) * 16 + (threadIdx.x >> 4), sl = threadIdx.x & 15;
     const int tot = vc.K * EDGE_SLAB;
     const int e = min(er, tot - 1);
+    const int k = e / EDGE_SLAB, c = e % EDGE_SLAB;
+    const bool general = pp.rel_vec[k] != nullptr && c != 256;
     double t = 0.0;
-    for (int z0 = sl; z0 < nedge; z0 += 16 * 8) {
-        double v[8];
+    if (!general) {
+        for (int z0 = sl; z0 < nedge; z0 += 16 * 8) {
+            double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int z = z0 + 16 * u;
-            v[u] = z < nedge ? datt[(size_t)z * tot + e] : 0.0;
+            for (int u = 0; u < 8; ++u) {
+                const int z = z0 + 16 * u;
+                v[u] = z < nedge ? datt[(size_t)z * tot + e] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t += v[u];
+    } else if (c >= 1 && c <= pp.rel_c[k]) {
+        const float* vec = pp.rel_vec[k];
+        const int C = pp.rel_c[k], D = pp.channels[k];
+        for (int z = sl; z < nedge; z += 16)
+            for (int code = 1; code <= D; ++code)
+                t += datt[(size_t)z * tot + k * EDGE_SLAB + code] * (double)vec[(size_t)(code - 1) * C + (c - 1)];
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);
     if (er >= tot || sl != 0) return;
-    const int k = e / EDGE_SLAB, c = e % EDGE_SLAB;
-    if (c >= 1 && c <= pp.channels[k]) gp.datt_w[k][c - 1] = (float)t;
-    else if (c == 256) {
+    if (c == 256) {
         const double r = (double)rsig[k];
         gp.dself_r[k][0] = (float)(t * r * (1.0 - r));
+    } else if (c >= 1 && c <= (pp.rel_vec[k] ? pp.rel_c[k] : pp.channels[k])) {
+        gp.datt_w[k][c - 1] = (float)t;
     }
 }
 
@@ -522,7 +544,7 @@ __global__ __launch_bounds__(256) void attention_dense_kernel(eagcn_batch bt, Pa
         const int k = (int)(kbi / ((size_t)bt.B * bt.N));
         const size_t bi = kbi - (size_t)k * bt.B * bt.N;      // b*N + i: rows without bonds have no valid code row
         const uint32_t c = bt.deg_bn[bi] > 0 ? bt.code[kbi * bt.ldc + j] : 0u;
-        out[e] = (c >= 1 && (int)c <= pp.channels[k]) ? sigmoidf_(pp.att_w[k][c - 1]) : 0.0f;
+        out[e] = (c >= 1 && (int)c <= pp.channels[k]) ? sigmoidf_(att_logit(pp, k, (int)c)) : 0.0f;
     }
 }
 
@@ -662,6 +684,7 @@ static ParamPtrs param_ptrs(const eagcn_batch* b, const eagcn_layer_params* p) {
         pp.att_w[k] = p->att_w[k]; pp.self_r[k] = p->self_r[k]; pp.W[k] = p->W[k]; pp.bias[k] = p->bias[k];
         pp.gamma[k] = p->gamma[k]; pp.beta[k] = p->beta[k]; pp.run_mean[k] = p->run_mean[k];
         pp.run_var[k] = p->run_var[k]; pp.channels[k] = b->channels[k];
+        pp.rel_vec[k] = b->rel_vec[k]; pp.rel_c[k] = b->rel_c[k];
     }
     pp.ave_w = p->structure == EAGCN_STRUCT_WEIGHTED ? p->ave_w : nullptr;
     return pp;
@@ -987,6 +1010,7 @@ extern "C" int eagcn_attention_dense(const eagcn_batch* b, const eagcn_layer_par
         EAGCN_CHECK_ARG(p->att_w[k], "eagcn_attention_dense: view %d has no attention weight", k);
         pp.att_w[k] = p->att_w[k];
         pp.channels[k] = b->channels[k];
+        pp.rel_vec[k] = b->rel_vec[k]; pp.rel_c[k] = b->rel_c[k];
     }
     const size_t total = (size_t)b->K * b->B * b->N * b->N;
     attention_dense_kernel<<<ew_grid(total), 256, 0, s>>>(*b, pp, out);

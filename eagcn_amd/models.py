@@ -224,6 +224,10 @@ class EAGCN(nn.Module):
             if afms.shape != (B, N, self.n_afeat) or len(channels) != self.K:
                 raise ops.L.EagcnHipError('inconsistent compact batch: afms %s for B=%d N=%d, %d views'
                                           % (tuple(afms.shape), B, N, len(channels)))
+            if bonds.rel_vectors is not None:
+                raise ops.L.EagcnHipError('general relation vectors are served by the eager engine: build the model with '
+                                          'graph=False (the captured graphs hold the one-hot lookup)')
+            self._check_channels(channels)
             btuple = bonds.checked()
         plan = self.plan()
         key = (B, N, channels, float(self.dropout), self.training)
@@ -290,6 +294,7 @@ class EAGCN(nn.Module):
             rels = rels[:1]                                          # Vanilla_GCN only needs the bond positions (= adj)
         if self.graph and (self.training and torch.is_grad_enabled() or not self.training and not torch.is_grad_enabled()):
             return self._graph_forward(adjs, afms, rels, size)       # training step, or eval under no_grad (train.py:130-211)
+        self._check_channels([int(r.shape[1]) for r in rels])
         index = ops.BatchIndex(adjs, rels, overlap=self.overlap_index)   # once per batch, shared by all layers
         return self._forward_index(index, afms, size)
 
@@ -302,8 +307,23 @@ class EAGCN(nn.Module):
             bonds = bonds.first_view()
         if self.graph and (self.training and torch.is_grad_enabled() or not self.training and not torch.is_grad_enabled()):
             return self._graph_forward(None, afms, None, size, bonds)
-        index = ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, *bonds.checked())
+        self._check_channels(bonds.channels, bonds.rel_vectors)
+        index = ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, *bonds.checked(), rel_vectors=bonds.rel_vectors)
         return self._forward_index(index, afms, size)
+
+    def _check_channels(self, channels, rel_vectors=None):
+        """The attention weight of view k has rel_channels[k] entries (layers.py:64): a one-hot batch may use that many bond
+        types, a general batch (rel_vectors) must bring channel vectors of exactly that length."""
+        want = self.graph_layers()[0].rel_channels
+        if len(channels) != len(want):
+            raise ops.L.EagcnHipError('batch has %d relation views, the model %d' % (len(channels), len(want)))
+        for k, (c, w) in enumerate(zip(channels, want)):
+            if rel_vectors is not None:
+                if int(rel_vectors[k].shape[1]) != int(w):
+                    raise ops.L.EagcnHipError('view %d: relation vectors have %d channels, the attention weight %d'
+                                              % (k, int(rel_vectors[k].shape[1]), w))
+            elif int(c) > int(w):
+                raise ops.L.EagcnHipError('view %d: %d bond types but the attention weight has %d channels' % (k, c, w))
 
     def _forward_index(self, index, afms, size):
         plan = self.plan()

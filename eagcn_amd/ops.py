@@ -79,12 +79,22 @@ class BatchIndex:
     """
 
     @classmethod
-    def from_bonds(cls, B, N, channels, bond_mol, bond_i, bond_j, bond_code, row_cap=None):
+    def from_bonds(cls, B, N, channels, bond_mol, bond_i, bond_j, bond_code, row_cap=None, rel_vectors=None):
         """Index of a COMPACT batch: directed bonds as int32 device vectors bond_mol / bond_i /
         bond_j [E] plus their type per view bond_code [E,K] (uint8).  Equivalent to BatchIndex(adj, rels) on
         the dense tensors the reference's collate would build from the same molecules, without ever
         materialising them (O(E) input bytes instead of 4*(1+sum C_k)*B*N*N)."""
         self = cls.__new__(cls)
+        self.rel_vectors = None
+        if rel_vectors is not None:                   # general relation tensors: a code stands for a channel vector
+            if len(rel_vectors) != len(channels):
+                raise L.EagcnHipError('rel_vectors needs one table per view')
+            self.rel_vectors = []
+            for k, v in enumerate(rel_vectors):
+                v = _need_cuda_f32(v, 'rel_vectors[%d]' % k).contiguous()
+                if v.dim() != 2 or v.shape[0] != channels[k] or not 1 <= v.shape[0] <= 255:
+                    raise L.EagcnHipError('rel_vectors[%d] must be [%d codes <= 255, C], got %s' % (k, channels[k], tuple(v.shape)))
+                self.rel_vectors.append(v)
         self._build(None, None, B, N, list(channels), bond_mol.device, False, row_cap,
                     bonds=(bond_mol, bond_i, bond_j, bond_code))
         return self
@@ -141,6 +151,8 @@ class BatchIndex:
         c.code, c.deg_bn, c.nat = self.code.data_ptr(), base, base + 4 * B * N
         c.row0, c.tile0 = base + 4 * (B * N + B), base + 4 * (B * N + 2 * B + 1)
         c.meta = base + 4 * (B * N + 3 * B + 2)
+        for k, v in enumerate(getattr(self, 'rel_vectors', None) or ()):
+            c.rel_vec[k], c.rel_c[k] = v.data_ptr(), int(v.shape[1])
         c.ecnt = base + 4 * (B * N + 3 * B + 2 + L.META_WORDS)
         c.edge0 = c.ecnt + 4 * B
         c.E = 1 << 30                     # (exact-size edge arrays are allocated once the bond count is known)

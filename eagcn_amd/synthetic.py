@@ -83,13 +83,16 @@ class CompactBonds:
     bond_i: torch.Tensor
     bond_j: torch.Tensor
     bond_code: torch.Tensor
+    # general (non one-hot) relation tensors, layers.py:82: code c of view k stands for the channel vector rel_vectors[k][c]
+    # (float32 device tensor [channels[k], C_k]); None = one-hot, code c stands for channel c
+    rel_vectors: Optional[List[torch.Tensor]] = None
 
     def first_view(self):
         """The same bonds with the first attention view only (structure='GCN' needs the bond positions, no types)."""
         if len(self.channels) == 1:
             return self
         return CompactBonds(self.B, self.N, list(self.channels[:1]), self.bond_mol, self.bond_i, self.bond_j,
-                            self.bond_code[:, :1].contiguous())
+                            self.bond_code[:, :1].contiguous(), None if self.rel_vectors is None else self.rel_vectors[:1])
 
     def checked(self):
         E = self.bond_mol.numel()

@@ -97,6 +97,12 @@ typedef struct eagcn_batch {
     int32_t* row_info;                      /* [T][4] {molecule, atom, nat[mol], row0[mol]}: one
                                                16-byte load instead of a two-hop lookup          */
     int32_t* tile_info;                     /* [n_tiles][4] {molecule, row tile, nat[mol], row0[mol]} */
+    /* General (non one-hot) relation tensors, layers.py:82: at a bond the reference evaluates sigmoid(sum_c w[c] R[c,i,j]) for
+       ANY channel values.  The index keeps bond-type CODES; a code's meaning is a channel VECTOR: rel_vec[k] = [channels[k]]
+       [rel_c[k]] floats (code c+1 -> row c), built per batch from the distinct vectors at the bonds (eagcn_amd/collate.py; at
+       most 255 per view).  NULL (the default): code c+1 means the one-hot vector e_c, i.e. sigma(w[c]).                 */
+    const float* rel_vec[EAGCN_MAX_VIEWS];
+    int32_t rel_c[EAGCN_MAX_VIEWS];         /* channels of view k's attention weight when rel_vec[k] is set           */
     /* Bond lists (built by eagcn_index_rows from the code maps): the attention matrix of layers.py:82-90 is
        sigma(w[type]) at the bonds, sigma(self_r) on the diagonal and 1e-9 everywhere else, so the aggregation
        kernels walk these lists instead of a dense N x N operand (csrc/sagg.hip).                           */
