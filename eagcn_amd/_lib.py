@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libeagcn_hip.so')
 
 MAX_VIEWS = 8
 MAX_SEGS = 8
-META_WORDS = 8
+META_WORDS = 16
+META_NLOG = 8
 META_T, META_NMAX, META_NTILES, META_BAD_ADJ, META_BAD_REL, META_NEDGE, META_OVERFLOW, META_EDGE_OVERFLOW = range(8)
 STRUCT_CONCATE, STRUCT_WEIGHTED = 0, 1
 
@@ -27,7 +28,7 @@ class Batch(C.Structure):
                 ('meta', _fp), ('row_mol', _fp), ('row_loc', _fp), ('row_m', _fp), ('row_deg', _fp),
                 ('tile_mol', _fp), ('row_info', _fp), ('tile_info', _fp),
                 ('rel_vec', _fp * MAX_VIEWS), ('rel_c', C.c_int32 * MAX_VIEWS),
-                ('E', C.c_int32), ('reserved_', C.c_int32), ('ecnt', _fp), ('edge0', _fp), ('mol_info', _fp), ('row_ptr', _fp),
+                ('E', C.c_int32), ('n_logical', C.c_int32), ('ecnt', _fp), ('edge0', _fp), ('mol_info', _fp), ('row_ptr', _fp),
                 ('col_ptr', _fp), ('nbr', _fp), ('tnbr', _fp), ('ecode', _fp), ('tcode', _fp)]
 
 

@@ -42,6 +42,7 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
     const int ct0 = cc * CT;
     if (ct0 >= ntile_k) return;                       // uniform for the whole workgroup
     const int ntiles = dev_tiles(a.bt);
+    const int nlog = dev_n(a.bt);
     if (bx * 4 >= ntiles) return;        // capacity-sized grid: no tile for this workgroup (its
                                                       // stats slab is not read either: bn_finalize counts live slabs)
     const int nct = min(CT, ntile_k - ct0);
@@ -102,7 +103,7 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
             }
             dsum += __shfl_xor(dsum, 16);
             dsum += __shfl_xor(dsum, 32);
-            const float d = dsum + TINY * (float)(bt.N - n);
+            const float d = dsum + TINY * (float)(nlog - n);
             const float sc = (mi > 0.0f && ia < n) ? 1.0f / d : 0.0f;
             if (cc == 0 && q == 0 && ia < n) a.rscale[(size_t)k * bt.T + r0 + ia] = sc;
             float scr[4];
@@ -208,6 +209,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
 #pragma unroll
     for (int i = 0; i < 4 / NW; ++i) sig_v[i] = a.sig[k * 256 + tid + i * NW * 64];
     const int ntiles = dev_tiles(a.bt);
+    const int nlog = dev_n(a.bt);
     if (bx >= ntiles) return;            // capacity-sized grid: no tile for this workgroup (its
                                                       // stats slab is not read either: bn_finalize counts live slabs)
     const int nct = min(CT, ntile_k - ct0);
@@ -349,7 +351,7 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
         if (wave == 0) {
             if (!TRANS) {
                 const float mi = (ia < n) ? bt.row_m[r0 + ia] : 0.0f;
-                const float d = dsum + TINY * (float)(bt.N - n);
+                const float d = dsum + TINY * (float)(nlog - n);
                 const float sc = (mi > 0.0f && ia < n) ? 1.0f / d : 0.0f;
                 if (cc == 0 && q == 0 && ia < n) a.rscale[(size_t)k * bt.T + r0 + ia] = sc;
                 float scr[4];

@@ -141,6 +141,8 @@ __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_
 // eagcn_batch.T / .n_tiles are CAPACITIES (buffer strides, grid sizing); the actual packed row count
 // and tile count are read from meta[] on the device, so no launch depends on a host read-back.
 __device__ __forceinline__ int dev_rows(const eagcn_batch& bt) { return min(bt.meta[EAGCN_META_T], bt.T); }
+// padded molecule size of the batch as the reference sees it (<= the capacity bt.N): BatchNorm row counts, filler weights
+__device__ __forceinline__ int dev_n(const eagcn_batch& bt) { const int v = bt.meta[EAGCN_META_NLOG]; return v > 0 ? min(v, bt.N) : bt.N; }
 __device__ __forceinline__ int dev_tiles(const eagcn_batch& bt) { return min(bt.meta[EAGCN_META_NTILES], bt.n_tiles); }
 
 // ---- column map of a layer's Fp-wide buffers -----------------------------------------------------

@@ -27,7 +27,7 @@ struct RelPtrs {
 // leave as one coalesced 32-bit store per lane (ldc is a multiple of 16).
 template <int NIT, int RPW>
 __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict__ adj, RelPtrs rel,
-                                                          int B, int N, int K, int ldc,
+                                                          int B, int N, int Ncap, int K, int ldc,
                                                           uint8_t* __restrict__ code,
                                                           int32_t* __restrict__ deg_bn,
                                                           int32_t* __restrict__ nat,
@@ -105,12 +105,12 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
 #pragma unroll
                     for (int k = 0; k < EAGCN_MAX_VIEWS; ++k)
                         if (k < K)
-                            *reinterpret_cast<uint32_t*>(code + (((size_t)k * B + b) * N + i) * ldc + j0) = packed[t][k];
+                            *reinterpret_cast<uint32_t*>(code + (((size_t)k * B + b) * Ncap + i) * ldc + j0) = packed[t][k];
                 }
             }
         }
         if (lane == 0) {
-            deg_bn[row] = deg;
+            deg_bn[(size_t)b * Ncap + i] = deg;       // (N = padded size of the caller's tensors, Ncap = capacity of the index)
             if (deg > 0) {                           // (no single-word counters here: 5k same-address atomics cost 60 us;
                 atomicMax(&nat[b], i + 1);           //  these are one word per molecule)
                 atomicAdd(&ecnt[b], deg);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __re
                                                               int32_t* __restrict__ tile0,
                                                               int32_t* __restrict__ meta, int cap_rows,
                                                               const int32_t* __restrict__ ecnt,
-                                                              int32_t* __restrict__ edge0, int cap_edges) {
+                                                              int32_t* __restrict__ edge0, int cap_edges, int n_logical) {
     __shared__ int s_rows[1024], s_tiles[1024], s_edges[1024];
     __shared__ int carry_r, carry_t, carry_e, s_max;
     const int t = threadIdx.x;
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __re
         meta[EAGCN_META_OVERFLOW] = over_r ? carry_r : 0;
         meta[EAGCN_META_EDGE_OVERFLOW] = over_e ? carry_e : 0;
         meta[EAGCN_META_NMAX] = s_max;
+        meta[EAGCN_META_NLOG] = n_logical;
     }
 }
 
@@ -371,14 +372,14 @@ __device__ __forceinline__ int packed_to_exact(const ColMap& m, int cp) {
 }
 
 __global__ __launch_bounds__(256) void pack_rows_kernel(eagcn_batch bt, const float* __restrict__ dense,
-                                                         int F, ColMap m, int ld, float* __restrict__ packed) {
+                                                         int F, ColMap m, int ld, float* __restrict__ packed, int Nin) {
     const size_t total = (size_t)dev_rows(bt) * ld;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (size_t)gridDim.x * blockDim.x) {
         int r = (int)(e / ld), cp = (int)(e % ld);
         int ce = packed_to_exact(m, cp);
         float v = 0.0f;
-        if (ce >= 0) v = dense[((size_t)bt.row_mol[r] * bt.N + bt.row_loc[r]) * F + ce];
+        if (ce >= 0) v = dense[((size_t)bt.row_mol[r] * Nin + bt.row_loc[r]) * F + ce];      // Nin: padded size of the caller's tensor
         packed[e] = v;
     }
 }
@@ -444,21 +445,24 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
                             EAGCN_MAX_CHANNELS);
         }
     }
+    const int Nin = b->n_logical > 0 ? b->n_logical : b->N;      // padded size (and row stride) of the caller's tensors
+    EAGCN_CHECK_ARG(Nin <= b->N, "eagcn_index_build: n_logical %d exceeds the capacity N=%d", Nin, b->N);
     ProfScope ps(PROF_INDEX, s);
     EAGCN_HIP(hipMemsetAsync(b->meta, 0, EAGCN_META_WORDS * sizeof(int32_t), s));
     EAGCN_HIP(hipMemsetAsync(b->nat, 0, (size_t)b->B * sizeof(int32_t), s));
     EAGCN_CHECK_ARG(b->ecnt && b->edge0, "eagcn_index_build: bond-list buffers not allocated");
     EAGCN_HIP(hipMemsetAsync(b->ecnt, 0, (size_t)b->B * sizeof(int32_t), s));
-    const long rows = (long)b->B * b->N;
+    if (Nin < b->N) EAGCN_HIP(hipMemsetAsync(b->deg_bn, 0, (size_t)b->B * b->N * sizeof(int32_t), s));   // rows the scan does not visit
+    const long rows = (long)b->B * Nin;
     // rows per wavefront: 4 was measured SLOWER (0.18 vs 0.09 ms at B=256, 1.12 vs 0.97 ms at B=4096), and so was
     // a streaming degree pass followed by a per-molecule code pass over the bonded rows (0.39-0.71 vs 0.07 ms at
     // B=256): the gather of one row (~38 single-sector loads from planes N*N floats apart per bond) takes tens of
     // microseconds however it is issued, so it has to run in as many waves at once as there are rows
     constexpr int RPW = 1;
     const unsigned sgrid = (unsigned)((rows + 4 * RPW - 1) / (4 * RPW));
-    const int nit = cdiv(b->ldc, 256);
+    const int nit = cdiv((Nin + 15) / 16 * 16, 256);
     EAGCN_CHECK_ARG(nit <= 4, "eagcn_index_build: N=%d exceeds the supported 1024 atoms", b->N);
-#define EAGCN_SCAN(NIT) index_scan_kernel<NIT, RPW><<<sgrid, 256, 0, s>>>(adj, rp, b->B, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->ecnt, b->meta)
+#define EAGCN_SCAN(NIT) index_scan_kernel<NIT, RPW><<<sgrid, 256, 0, s>>>(adj, rp, b->B, Nin, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->ecnt, b->meta)
     switch (nit) {
         case 1: EAGCN_SCAN(1); break;
         case 2: EAGCN_SCAN(2); break;
@@ -467,7 +471,7 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     }
 #undef EAGCN_SCAN
     EAGCN_LAUNCH_CHECK();
-    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta, b->T, b->ecnt, b->edge0, b->E);
+    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta, b->T, b->ecnt, b->edge0, b->E, b->n_logical > 0 ? b->n_logical : 0);
     EAGCN_LAUNCH_CHECK();
     EAGCN_HIP(hipMemcpyAsync(host_meta, b->meta, EAGCN_META_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     return EAGCN_OK;
@@ -498,7 +502,7 @@ extern "C" int eagcn_index_from_bonds(const int32_t* bond_mol, const int32_t* bo
                                                 b->code, b->deg_bn, b->nat, b->ecnt, b->meta);
         EAGCN_LAUNCH_CHECK();
     }
-    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta, b->T, b->ecnt, b->edge0, b->E);
+    index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta, b->T, b->ecnt, b->edge0, b->E, b->n_logical > 0 ? b->n_logical : 0);
     EAGCN_LAUNCH_CHECK();
     EAGCN_HIP(hipMemcpyAsync(host_meta, b->meta, EAGCN_META_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     return EAGCN_OK;
@@ -534,7 +538,7 @@ extern "C" int eagcn_pack_rows(const eagcn_batch* b, const float* dense, int F, 
     size_t total = (size_t)b->T * ld;
     int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
     ProfScope ps(PROF_PACK, s);
-    pack_rows_kernel<<<grid, 256, 0, s>>>(*b, dense, F, make_colmap(lay), ld, packed);
+    pack_rows_kernel<<<grid, 256, 0, s>>>(*b, dense, F, make_colmap(lay), ld, packed, b->n_logical > 0 ? b->n_logical : b->N);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

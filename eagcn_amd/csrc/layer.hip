@@ -159,8 +159,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                            double M, int training, float eps, float momentum,
                                                            const float* __restrict__ colp, ParamPtrs pp,
                                                            ViewCols vc, float* __restrict__ bn,
-                                                           const int32_t* __restrict__ meta, int tiles_per_wg) {
+                                                           const int32_t* __restrict__ meta, int tiles_per_wg, int batch_B) {
     // aggregation workgroups beyond the actual tile count exit without writing their slab
+    if (meta[EAGCN_META_NLOG] > 0) M = (double)batch_B * (double)meta[EAGCN_META_NLOG];    // (M was computed from the capacity N)
     if (tiles_per_wg > 0) nslab = min(nslab, (meta[EAGCN_META_NTILES] + tiles_per_wg - 1) / tiles_per_wg);   // (0: every slab is written)
     const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
     const int cp = min(cpr, fp - 1);
@@ -418,7 +419,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
                                                                const double* __restrict__ slab_da, int nslab,
                                                                int fp, double M, int training,
                                                                const float* __restrict__ bn, ViewCols vc,
-                                                               GradPtrs gp, float* __restrict__ cc, const int32_t* __restrict__ meta, int nvirt) {
+                                                               GradPtrs gp, float* __restrict__ cc, const int32_t* __restrict__ meta, int nvirt,
+                                                               int batch_B) {
+    if (meta[EAGCN_META_NLOG] > 0) M = (double)batch_B * (double)meta[EAGCN_META_NLOG];
     nslab = max(1, min(nslab, (meta[EAGCN_META_T] + nvirt + BWD_ROWS - 1) / BWD_ROWS));   // slabs actually written
     const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
     const int cp = min(cpr, fp - 1);
@@ -824,10 +827,10 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
     ProfScope psbn(PROF_BN, s);
     if (nslab > 64)
         bn_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
-                                                               p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, tiles_per_wg);
+                                                               p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, tiles_per_wg, b->B);
     else
         bn_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
-                                                                p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, tiles_per_wg);
+                                                                p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, tiles_per_wg, b->B);
     EAGCN_LAUNCH_CHECK();
     ApplyArgs aa;
     aa.bt = *b; aa.vc = d.vc; aa.structure = p->structure; aa.fp = d.fp; aa.Y = w->Y; aa.ldy = d.fp;
@@ -918,10 +921,10 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         EAGCN_LAUNCH_CHECK();
         if (gxb > 64)
             bn_bwd_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
-                                                                       d.vc, gp, sc.cc, b->meta, ba.nvirt);
+                                                                       d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B);
         else
             bn_bwd_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
-                                                                        d.vc, gp, sc.cc, b->meta, ba.nvirt);
+                                                                        d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B);
         EAGCN_LAUNCH_CHECK();
         if (b->T > 0 && !sagg_enabled()) {        // (the bond-list aggregation applies this affine while it stages dH)
             bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);

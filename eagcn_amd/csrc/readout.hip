@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void readout_pad_sample_kernel(eagcn_batch bt,
     float acc = 0.0f;
     for (int k = 0; k < a.K; ++k) {
         const int cp = a.off[k] + c;
-        const int cnt = pad_keep_count(seed, b, bt.N, n, (uint64_t)cp, (uint64_t)a.fp, a.thr16);
+        const int cnt = pad_keep_count(seed, b, dev_n(bt), n, (uint64_t)cp, (uint64_t)a.fp, a.thr16);
         a.cnt[((size_t)b * a.K + k) * a.ld + c] = (uint16_t)cnt;
         acc += a.ave_w[k] * fmaxf(a.bn_sh[cp], 0.0f) * ((float)cnt * a.inv_keep);
     }
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void readout_fwd_kernel(eagcn_batch bt, const 
     if (wave == 0 && f < F) {
         s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
         if (padc) s += padc[(size_t)b * ld + cp];
-        else if (pad_row) s += (float)(bt.N - n) * pad_row[cp];
+        else if (pad_row) s += (float)(dev_n(bt) - n) * pad_row[cp];
         const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
         g[(size_t)b * F + f] = s * inv;
     }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void readout_bwd_pad_kernel(eagcn_batch bt, co
     if (ce >= 0)
         for (int b = 0; b < bt.B; ++b) {
             const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
-            acc += (double)((float)(bt.N - bt.nat[b]) * dg[(size_t)b * F + ce] * inv);
+            acc += (double)((float)(dev_n(bt) - bt.nat[b]) * dg[(size_t)b * F + ce] * inv);
         }
     dpad[cp] = (float)acc;
 }

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void sagg_fwd_kernel(SAggFwd a) {
     for (int c = tid; c < SA_NCG * 8; c += 256) st_c[c] = 0.0;
     const float rself = a.rsig[k];
     const int T = dev_rows(bt);
+    const int nlog = dev_n(bt);
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
     __syncthreads();
     if (rl < RL) {
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void sagg_fwd_kernel(SAggFwd a) {
                         f4fma(acc, w, v[t]);
                     }
             }
-            const float d = sum + rm + TINY * (float)(bt.N - rp.y);
+            const float d = sum + rm + TINY * (float)(nlog - rp.y);
             const float sc = rm > 0.0f ? 1.0f / d : 0.0f;           // (sigmoid(self_r) > 0: rm > 0 <=> m_i = 1)
             const float4 y = make_float4(acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc);
             *reinterpret_cast<float4*>(Y + (size_t)r * a.ld) = y;

@@ -100,6 +100,7 @@ class GraphRunner:
         self.meta_event = [None] * _RING
         self.step = 0
         self.cur = 0
+        self.n_in = N                  # padded size of the current batch's tensors (EAGCN(n_bucket=...): may be < N)
         self.generation = 0
         self.size_static = [torch.ones(B, dtype=torch.int64, device=device) for _ in range(2)]
         self.aux = None
@@ -289,6 +290,7 @@ class GraphRunner:
         else:
             side = main
         istream = C.c_void_p(side.cuda_stream)
+        idx.c.n_logical = int(self.n_in) if self.n_in != idx.N else 0     # row stride of the caller's tensors / logical N
         # ---- everything that reads the caller's tensors: index, packed input, seeds, sizes -----------------
         if bonds is None:
             rel_ptrs = (C.c_void_p * idx.K)(*[r.data_ptr() for r in rels])

@@ -17,7 +17,10 @@ that fix ``structure``.  Keyword-only extensions (defaults = reference behaviour
                 per captured pair (a new pair is captured for every new shape), delivers gradients
                 as in grad_mode='direct', keeps ONE training forward in flight, and the lazy atom
                 representations are valid until the next forward.  ``row_cap`` bounds the packed rows
-                the static buffers are sized for (default B*N), ``edge_cap`` the directed bonds of a batch
+                the static buffers are sized for (default B*N); ``n_bucket`` (e.g. 16) rounds the padded size N up
+                to a multiple so that the batches of a real loader -- the reference pads each batch to ITS maximum,
+                utils.py:583 -- share one runner per bucket instead of one per distinct N (the kernels still see the
+                batch's own N: BatchNorm row counts and filler weights come from a device word); ``edge_cap`` the directed bonds of a batch
                 (default 8 per row of row_cap: molecular graphs hold 2-2.5).  Every distinct (B, N, training) shape owns a
                 runner (two index slots, two saved-activation blocks, scratch: see GraphRunner.nbytes());
                 at most ``max_runners`` (default 8) are kept, least recently used evicted first.
@@ -48,9 +51,10 @@ class LazyAtomRep:
     """Deferred ``x2.data.cpu()`` (models.py:102): materialises the padded [B,N,F] host tensor on
     first use.  Supports what train.py:213-266 does with it (.view / indexing / .numpy / .shape)."""
 
-    def __init__(self, index, layout, packed, pad_row):
+    def __init__(self, index, layout, packed, pad_row, n_out=None):
         self._args = (index, layout, packed.detach(), None if pad_row is None else pad_row.detach())
         self._cpu = None
+        self._n_out = n_out            # N of the caller's batch when the index was built for a larger (bucketed) N
 
     @property
     def packed(self):
@@ -62,7 +66,8 @@ class LazyAtomRep:
         if self._cpu is None:
             index, layout, packed, pad_row = self._args
             with torch.no_grad():
-                self._cpu = ops.unpack_rows(index, layout, packed, pad_row).cpu()
+                dense = ops.unpack_rows(index, layout, packed, pad_row)
+                self._cpu = (dense if self._n_out is None else dense[:, :self._n_out]).cpu()
             self._args = None
         return self._cpu
 
@@ -79,8 +84,9 @@ class EAGCN(nn.Module):
                  n_den1=128, n_den2=64, nclass=1, dropout=0.0, structure='Concate', molfp_mode='sum',
                  pool_num=5, *, n_layers=4, widths1=None, widths2=None, rel_channels=None, atom_rep='lazy',
                  grad_mode='autograd', overlap_index=False, graph=False, row_cap=None, graph_outputs='copy',
-                 validate='sync', max_runners=8, edge_cap=None):
+                 validate='sync', max_runners=8, edge_cap=None, n_bucket=0):
         super().__init__()
+        self.n_bucket = int(n_bucket)
         if widths1 is None:
             widths1 = [n_sgc1_1, n_sgc1_2, n_sgc1_3, n_sgc1_4, n_sgc1_5]
         if widths2 is None:
@@ -183,7 +189,7 @@ class EAGCN(nn.Module):
         super().__setstate__(state)
         self._plan = None
         self._runners = {}
-        for name, default in (('graph_outputs', 'copy'), ('validate', 'sync'), ('max_runners', 8), ('edge_cap', None)):
+        for name, default in (('graph_outputs', 'copy'), ('validate', 'sync'), ('max_runners', 8), ('edge_cap', None), ('n_bucket', 0)):
             self.__dict__.setdefault(name, default)
 
     def state_dict(self, *a, **kw):
@@ -230,6 +236,9 @@ class EAGCN(nn.Module):
             self._check_channels(channels)
             btuple = bonds.checked()
         plan = self.plan()
+        n_in = N
+        if self.n_bucket > 1:                       # one runner (one pair of captured graphs) per BUCKET of padded sizes
+            N = -(-N // self.n_bucket) * self.n_bucket
         key = (B, N, channels, float(self.dropout), self.training)
         runner = self._runners.pop(key, None)
         if runner is None or runner.stale():
@@ -243,13 +252,15 @@ class EAGCN(nn.Module):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (self.dropout > 0 and self.training) else 0
         if self.molfp_mode == 'ave':
             size = size.to(device=afms.device, dtype=torch.int64)
+        runner.n_in = n_in                           # padded size of THIS batch's tensors (<= the runner's capacity N)
         return runner, adjs, rels, afms, size, seed, btuple
 
     def _atom_rep(self, runner):
         if self.atom_rep == 'none':
             return None
         pad = runner.pad_view if self.structure in ('Weighted_sum', 'GCN') else None
-        rep = LazyAtomRep(runner.index, self.plan().last_layout, runner.xout_view, pad)
+        rep = LazyAtomRep(runner.index, self.plan().last_layout, runner.xout_view, pad,
+                          runner.n_in if runner.n_in != runner.key[1] else None)
         return rep.cpu() if self.atom_rep == 'eager' else rep
 
     def _graph_forward(self, adjs, afms, rels, size, bonds=None):

@@ -72,7 +72,11 @@ extern "C" {
                                  kernel touches memory beyond the capacity-sized buffers              */
 #define EAGCN_META_EDGE_OVERFLOW 7 /* directed bonds of a batch that does not fit the edge capacity eagcn_batch.E (0 if it
                                  fits); handled like EAGCN_META_OVERFLOW: the batch is indexed as empty                   */
-#define EAGCN_META_WORDS 8
+#define EAGCN_META_NLOG 8     /* logical padded molecule size of THIS batch when it is smaller than the capacity eagcn_batch.N
+                                 (eagcn_batch.n_logical): the reference pads every batch to its own maximum (utils.py:583) and
+                                 counts the padding rows in its BatchNorm statistics and filler weights, so kernels take
+                                 B * N_logical, N_logical - nat[b] from here; 0 = eagcn_batch.N                           */
+#define EAGCN_META_WORDS 16
 
 typedef struct eagcn_batch {
     int32_t B, N, K;
@@ -107,7 +111,8 @@ typedef struct eagcn_batch {
        sigma(w[type]) at the bonds, sigma(self_r) on the diagonal and 1e-9 everywhere else, so the aggregation
        kernels walk these lists instead of a dense N x N operand (csrc/sagg.hip).                           */
     int32_t E;                              /* CAPACITY of the four edge arrays (directed bonds)             */
-    int32_t reserved_;
+    int32_t n_logical;                      /* HOST input of the index entry points: padded size N_in <= N of the caller's
+                                               tensors for this batch (their row stride), 0 = N; mirrored to meta[NLOG] */
     int32_t* ecnt;                          /* [B]   directed bonds of each molecule                         */
     int32_t* edge0;                         /* [B+1] exclusive prefix of ecnt                                */
     int32_t* mol_info;                      /* [B][4] {nat, row0, edge0, directed bonds}: one 16-byte load   */
