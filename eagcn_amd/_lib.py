@@ -29,7 +29,8 @@ class Batch(C.Structure):
                 ('tile_mol', _fp), ('row_info', _fp), ('tile_info', _fp),
                 ('rel_vec', _fp * MAX_VIEWS), ('rel_c', C.c_int32 * MAX_VIEWS),
                 ('E', C.c_int32), ('n_logical', C.c_int32), ('ecnt', _fp), ('edge0', _fp), ('mol_info', _fp), ('row_ptr', _fp),
-                ('col_ptr', _fp), ('nbr', _fp), ('tnbr', _fp), ('ecode', _fp), ('tcode', _fp)]
+                ('col_ptr', _fp), ('nbr', _fp), ('tnbr', _fp), ('ecode', _fp), ('tcode', _fp),
+                ('build_lists', C.c_int32), ('reserved_', C.c_int32)]
 
 
 def set_bond_lists(c, small_ptr, ptrs, edges, E):
@@ -44,6 +45,12 @@ def set_bond_lists(c, small_ptr, ptrs, edges, E):
     code = eb + 8 * E
     code += (-code) % 8
     c.ecode, c.tcode = code, code + 8 * E
+
+
+class GatParams(C.Structure):
+    _fields_ = [('fin', C.c_int32), ('ld_in', C.c_int32), ('F', C.c_int32), ('training', C.c_int32),
+                ('alpha', C.c_float), ('att_dropout', C.c_float), ('dropout', C.c_float), ('reserved_', C.c_float),
+                ('seed', C.c_uint64), ('W', _fp), ('a', _fp)]
 
 
 class Layout(C.Structure):
@@ -110,6 +117,10 @@ SIGNATURES = {
     'eagcn_pack_rows': (C.c_int, [C.POINTER(Batch), _fp, C.c_int, C.POINTER(Layout), _fp, _fp]),
     'eagcn_unpack_rows': (C.c_int, [C.POINTER(Batch), _fp, C.POINTER(Layout), _fp, _fp, C.c_int, _fp]),
     'eagcn_pad_rows': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    'eagcn_gat_scratch_bytes': (C.c_size_t, [C.POINTER(Batch), C.c_int]),
+    'eagcn_gat_forward': (C.c_int, [C.POINTER(Batch), C.POINTER(GatParams), _fp, _fp, _fp, _fp, _fp]),
+    'eagcn_gat_backward': (C.c_int, [C.POINTER(Batch), C.POINTER(GatParams), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
+                                     C.c_size_t, _fp]),
     'eagcn_layer_forward': (C.c_int, [C.POINTER(Batch), C.POINTER(LayerParams), C.POINTER(LayerBufs), _fp]),
     'eagcn_layer_backward': (C.c_int, [C.POINTER(Batch), C.POINTER(LayerParams), C.POINTER(LayerBufs),
                                        _fp, _fp, _fp, C.POINTER(LayerGrads), _fp]),

@@ -278,6 +278,66 @@ class Vanilla_GCN(nn.Module):
         return dense, a
 
 
+class GraphAttentionLayer(nn.Module):
+    """Parameter container of the reference's GAT attention (layers.py:99-143): W [fin,fout], a [2*fout,1], both
+    xavier_uniform(gain=1.414); attention dropout 0.5 and leaky-relu slope 0.2 are the reference's defaults (the GAT module
+    of layers.py:160 does not override them)."""
+
+    def __init__(self, in_features, out_features, dropout=0.5, alpha=0.2, concat=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.dropout, self.alpha, self.concat = dropout, alpha, concat
+        self.W = Parameter(torch.zeros(in_features, out_features))
+        nn.init.xavier_uniform_(self.W.data, gain=1.414)
+        self.a = Parameter(torch.zeros(2 * out_features, 1))
+        nn.init.xavier_uniform_(self.a.data, gain=1.414)
+
+
+class GAT(nn.Module):
+    """The GAT baseline layer (reference layers.py:145-203, models.py:69-73): per molecule h = X.W, attention
+    softmax_j leakyrelu(a1.h_i + a2.h_j) over the bonds of atom i and i itself, attention dropout, h' = att.h, then
+    dropout and relu.  The reference materialises an N x N x 2F pair tensor per molecule; csrc/gat.hip walks the bond lists
+    of the batch index.  forward(adjs, afms, TypeAtt, ...) -> (x, A) as the reference (A = adjs + mask*I); the BatchNorm
+    container exists in the reference's module (and state_dict) but its forward never calls it."""
+
+    structure = 'GAT'
+    K = 1
+    last = False
+
+    def __init__(self, node_feature_in, node_feature_out, dropout):
+        super().__init__()
+        self.node_feature_in, self.node_feature_out = node_feature_in, node_feature_out
+        self.graph_conv = GraphAttentionLayer(node_feature_in, node_feature_out)
+        self.batch_norm = AFM_BatchNorm(node_feature_out)
+        self.dropout = dropout
+        self.total_output = int(node_feature_out)
+
+    def forward_packed(self, index, x, in_layout, seed=None):
+        if len(in_layout.widths) != 1:
+            raise EagcnHipError('the GAT layer takes a single-segment input layout')
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.training else 0
+        gc = self.graph_conv
+        xout = ops.gat_layer(index, self.node_feature_in, in_layout.ld, self.node_feature_out, self.training, seed,
+                             self.dropout, gc.dropout, gc.alpha, x, gc.W, gc.a.view(-1))
+        return xout, None, ops.ColLayout.single(self.node_feature_out, 16)
+
+    def forward(self, adjs, afms, *rels, index=None):
+        if index is None:
+            if not rels:
+                raise EagcnHipError('GAT needs the first relation tensor (bond positions)')
+            index = ops.BatchIndex(adjs, rels[:1], bond_lists=True)
+        in_layout = ops.ColLayout.single(self.node_feature_in)
+        x = ops.pack_rows(index, in_layout, afms)
+        xout, _, out_layout = self.forward_packed(index, x, in_layout)
+        dense = ops.unpack_rows(index, out_layout, xout, None)
+        with torch.no_grad():
+            N = adjs.shape[1]
+            m = adjs.max(dim=2, keepdim=True)[0]
+            a = adjs + m * torch.eye(N, device=adjs.device, dtype=adjs.dtype)       # layers.py:189
+        return dense, a
+
+
 class Dense(nn.Module):
     """x @ W without bias by default (reference layers.py:360-392); W is U(-1/sqrt(fout), ..)."""
 

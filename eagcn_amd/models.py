@@ -44,7 +44,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import Dense, GraphConv_Layer, Vanilla_GCN
+from .layers import GAT, Dense, GraphConv_Layer, Vanilla_GCN
 
 
 class LazyAtomRep:
@@ -97,14 +97,23 @@ class EAGCN(nn.Module):
             raise ValueError('widths1 and widths2 need one entry per view')
         if rel_channels is None:
             rel_channels = [n_bfeat, 4, 2, 2, 2][:K]
-        if structure not in ('Concate', 'Weighted_sum', 'GCN'):
-            raise ValueError("the HIP hot path implements structure 'Concate', 'Weighted_sum' and the Kipf-GCN baseline "
-                             "'GCN' (the GAT baseline of models.py:69-73 is outside its scope)")
+        if structure not in ('Concate', 'Weighted_sum', 'GCN', 'GAT'):
+            raise ValueError("structure must be 'Concate', 'Weighted_sum' or one of the baselines 'GCN' / 'GAT' (models.py:50-73)")
+        if structure == 'GAT' and graph:
+            raise ValueError("structure='GAT' runs layer by layer on the eager engine (graph=False)")
         if molfp_mode not in ('sum', 'ave'):
             raise ValueError("molfp_mode 'sum' and 'ave' are implemented ('pool' = Diff_Pooling is "
                              "outside the hot path, SURVEY.md 8f)")
         if not 1 <= n_layers <= 4:
             raise ValueError('n_layers must be 1..4')
+        if structure == 'GAT':                                            # models.py:69-73: four GAT layers
+            self.ngc1, self.ngc2 = sum(widths1), sum(widths2)
+            gplan = [(n_afeat, self.ngc1), (self.ngc1, self.ngc2), (self.ngc2, self.ngc2), (self.ngc2, 2 * self.ngc2)][:n_layers]
+            for i, (fin, fout) in enumerate(gplan):
+                setattr(self, 'layer%d' % (i + 1), GAT(fin, fout, dropout))
+            self._finish_init(n_layers, n_afeat, 1, structure, molfp_mode, dropout, atom_rep, grad_mode, overlap_index, graph,
+                              row_cap, edge_cap, graph_outputs, validate, max_runners, gplan[-1][1], n_den1, n_den2, nclass)
+            return
         if structure == 'GCN':                                            # models.py:63-67: four Vanilla_GCN layers
             self.ngc1, self.ngc2 = sum(widths1), sum(widths2)
             gplan = [(n_afeat, self.ngc1), (self.ngc1, self.ngc2), (self.ngc2, self.ngc2), (self.ngc2, 2 * self.ngc2)][:n_layers]
@@ -301,6 +310,8 @@ class EAGCN(nn.Module):
         size) -> (x, atom_representations, graph_representation).  The whole forward is one call into
         eagcn_model_forward (layers, read-out and head); backward is one call into eagcn_model_backward."""
         *rels, size = rels_and_size
+        if self.structure == 'GAT':                                  # baseline: layer-level entry points + composed head
+            return self.forward_composed(adjs, afms, *rels, size)
         if self.structure == 'GCN':
             rels = rels[:1]                                          # Vanilla_GCN only needs the bond positions (= adj)
         if self.graph and (self.training and torch.is_grad_enabled() or not self.training and not torch.is_grad_enabled()):
@@ -314,8 +325,11 @@ class EAGCN(nn.Module):
         (directed bond list + per-view bond type), ``afms`` the padded [B,N,n_afeat] atom features.  Results are
         identical to ``forward`` on the dense tensors the reference's collate (utils.py:575-640) would build for
         the same molecules; the adjacency / relation tensors are never materialised."""
-        if self.structure == 'GCN':
+        if self.structure in ('GCN', 'GAT'):
             bonds = bonds.first_view()
+        if self.structure == 'GAT':
+            index = ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, *bonds.checked(), bond_lists=True)
+            return self._forward_composed_index(index, ops._need_cuda_f32(afms, 'afms'), size)
         if self.graph and (self.training and torch.is_grad_enabled() or not self.training and not torch.is_grad_enabled()):
             return self._graph_forward(None, afms, None, size, bonds)
         self._check_channels(bonds.channels, bonds.rel_vectors)
@@ -371,9 +385,12 @@ class EAGCN(nn.Module):
         """Same computation composed from the layer-level entry points (one autograd node per layer,
         head as separate ops); kept for tests that cross-check the model-level engine."""
         *rels, size = rels_and_size
-        if self.structure == 'GCN':
+        if self.structure in ('GCN', 'GAT'):
             rels = rels[:1]
-        index = ops.BatchIndex(adjs, rels)
+        index = ops.BatchIndex(adjs, rels, bond_lists=(self.structure == 'GAT'))
+        return self._forward_composed_index(index, afms, size)
+
+    def _forward_composed_index(self, index, afms, size):
         x, pad_row, layout = self.forward_layers(index, afms)[-1]
         pad = pad_row if self.structure in ('Weighted_sum', 'GCN') else None
         g = ops.readout(index, layout, x, pad, self.molfp_mode, size)      # models.py:108-111

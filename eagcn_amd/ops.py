@@ -79,13 +79,14 @@ class BatchIndex:
     """
 
     @classmethod
-    def from_bonds(cls, B, N, channels, bond_mol, bond_i, bond_j, bond_code, row_cap=None, rel_vectors=None):
+    def from_bonds(cls, B, N, channels, bond_mol, bond_i, bond_j, bond_code, row_cap=None, rel_vectors=None, bond_lists=False):
         """Index of a COMPACT batch: directed bonds as int32 device vectors bond_mol / bond_i /
         bond_j [E] plus their type per view bond_code [E,K] (uint8).  Equivalent to BatchIndex(adj, rels) on
         the dense tensors the reference's collate would build from the same molecules, without ever
         materialising them (O(E) input bytes instead of 4*(1+sum C_k)*B*N*N)."""
         self = cls.__new__(cls)
         self.rel_vectors = None
+        self.bond_lists = bool(bond_lists)
         if rel_vectors is not None:                   # general relation tensors: a code stands for a channel vector
             if len(rel_vectors) != len(channels):
                 raise L.EagcnHipError('rel_vectors needs one table per view')
@@ -99,7 +100,7 @@ class BatchIndex:
                     bonds=(bond_mol, bond_i, bond_j, bond_code))
         return self
 
-    def __init__(self, adj, rels, overlap=False, row_cap=None):
+    def __init__(self, adj, rels, overlap=False, row_cap=None, bond_lists=False):
         """row_cap: size every packed buffer / grid for `row_cap` rows instead of the exact packed row
         count (kernels read the exact count from device memory); used by tests and by graph mode.
         overlap=True: the inputs are already materialised in HBM (prefetched batches), so the index
@@ -119,6 +120,8 @@ class BatchIndex:
             if r.dim() != 4 or r.shape[0] != B or r.shape[2] != N or r.shape[3] != N:
                 raise L.EagcnHipError('relation tensor %d must be [B,C,N,N] = [%d,C,%d,%d], got %s'
                                       % (i, B, N, N, tuple(r.shape)))
+        self.rel_vectors = None
+        self.bond_lists = bool(bond_lists)
         self._build(adj, rels, B, N, [int(r.shape[1]) for r in rels], adj.device, overlap, row_cap)
 
     def _build(self, adj, rels, B, N, channels, dev, overlap, row_cap, bonds=None):
@@ -212,6 +215,7 @@ class BatchIndex:
         self._ptrs = torch.zeros(4 * T + 4 * B, **i32)
         self._edges = torch.empty(6 * self.E + 2, **i32)
         L.set_bond_lists(c, base + 4 * (B * N + 3 * B + 2 + L.META_WORDS), self._ptrs, self._edges, self.E)
+        c.build_lists = 1 if getattr(self, 'bond_lists', False) else 0
         L.check(lib.eagcn_index_rows(C.byref(c), C.c_void_p(main.cuda_stream)), 'eagcn_index_rows')
         for t in (self.code, blob):
             t.record_stream(main)         # allocated on `side`, consumed on `main`
@@ -415,6 +419,57 @@ class _LayerFn(torch.autograd.Function):
 
 def layer_forward(index, spec, training, seed, buffers, x, ave_w, flat_params):
     return _LayerFn.apply(index, spec, training, seed, buffers, x, ave_w, *flat_params)
+
+
+class _GatFn(torch.autograd.Function):
+    """The GAT baseline layer (reference layers.py:99-203) on packed rows: (x, W, a) -> xout.  One C call each way."""
+
+    @staticmethod
+    def forward(ctx, index, fin, ld_in, F, training, seed, dropout, att_dropout, alpha, x, W, a):
+        lib = L.load()
+        if not getattr(index, 'bond_lists', False):
+            raise L.EagcnHipError('the GAT layer needs a batch index with bond lists: BatchIndex(..., bond_lists=True)')
+        x, W, a = x.contiguous(), W.contiguous(), a.contiguous()
+        if x.shape != (index.T, ld_in) or tuple(W.shape) != (fin, F) or a.numel() != 2 * F:
+            raise L.EagcnHipError('GAT layer: x %s W %s a %s for fin=%d ld=%d F=%d' % (tuple(x.shape), tuple(W.shape), tuple(a.shape), fin, ld_in, F))
+        p = L.GatParams()
+        p.fin, p.ld_in, p.F, p.training = fin, ld_in, F, int(bool(training))
+        p.alpha, p.att_dropout, p.dropout, p.seed = float(alpha), float(att_dropout), float(dropout), int(seed) & (2 ** 63 - 1)
+        p.W, p.a = W.data_ptr(), a.data_ptr()
+        Fp = (F + 15) // 16 * 16
+        f32 = dict(dtype=torch.float32, device=x.device)
+        h = torch.empty((index.T, Fp), **f32)
+        s12 = torch.empty((2, index.T), **f32)
+        xout = torch.empty((index.T, Fp), **f32)
+        L.check(lib.eagcn_gat_forward(index.ref(), C.byref(p), x.data_ptr(), h.data_ptr(), s12.data_ptr(), xout.data_ptr(),
+                                      _stream()), 'eagcn_gat_forward')
+        ctx.index, ctx.p_args = index, (fin, ld_in, F, training, seed, dropout, att_dropout, alpha)
+        ctx.save_for_backward(x, W, a, h, s12, xout)
+        return xout
+
+    @staticmethod
+    def backward(ctx, dxout):
+        lib = L.load()
+        x, W, a, h, s12, xout = ctx.saved_tensors
+        fin, ld_in, F, training, seed, dropout, att_dropout, alpha = ctx.p_args
+        index = ctx.index
+        p = L.GatParams()
+        p.fin, p.ld_in, p.F, p.training = fin, ld_in, F, int(bool(training))
+        p.alpha, p.att_dropout, p.dropout, p.seed = float(alpha), float(att_dropout), float(dropout), int(seed) & (2 ** 63 - 1)
+        p.W, p.a = W.data_ptr(), a.data_ptr()
+        dxout = dxout.contiguous()
+        dW, da = torch.empty_like(W), torch.empty_like(a)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[9] else None
+        nbytes = lib.eagcn_gat_scratch_bytes(index.ref(), F)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        L.check(lib.eagcn_gat_backward(index.ref(), C.byref(p), x.data_ptr(), h.data_ptr(), s12.data_ptr(), xout.data_ptr(),
+                                       dxout.data_ptr(), _ptr(dx) if dx is not None else C.c_void_p(0), dW.data_ptr(),
+                                       da.data_ptr(), scratch.data_ptr(), nbytes, _stream()), 'eagcn_gat_backward')
+        return (None,) * 9 + (dx, dW, da)
+
+
+def gat_layer(index, fin, ld_in, F, training, seed, dropout, att_dropout, alpha, x, W, a):
+    return _GatFn.apply(index, fin, ld_in, F, training, seed, dropout, att_dropout, alpha, x, W, a)
 
 
 def attention_dense(index, att_weights):

@@ -122,6 +122,9 @@ typedef struct eagcn_batch {
     int32_t* tnbr;                          /* [E] column lists: atom index i inside the molecule            */
     uint64_t* ecode;                        /* [E] row lists: byte k = bond-type code of view k (1-based)    */
     uint64_t* tcode;                        /* [E] column lists: the same for bond (i,j)                     */
+    int32_t build_lists;                    /* HOST input of eagcn_index_rows: build the bond lists (GAT layers; the
+                                               opt-in sparse aggregation builds them regardless)               */
+    int32_t reserved_;
 } eagcn_batch;
 
 /* column layout of a packed activation matrix */
@@ -209,6 +212,25 @@ int eagcn_index_rows(const eagcn_batch* b, void* stream);
 /* ---- layout conversion ----------------------------------------------------------------------- */
 int eagcn_pack_rows(const eagcn_batch* b, const float* dense, int F, const eagcn_layout* lay,
                     float* packed, void* stream);
+/* The GAT baseline layer (reference layers.py:99-203, models.py:69-73): x [T][ld_in] packed rows with a
+   single-segment layout -> xout [T][pad16(F)].  h [T][pad16(F)] and s12 [2][T] are saved for the backward.  Needs a batch
+   index with bond lists (eagcn_batch.build_lists).  Attention dropout 0.5 (layers.py:104) and the layer dropout are applied in
+   training mode from the counter-based stream `seed`.                                                                      */
+typedef struct eagcn_gat_params {
+    int32_t fin, ld_in, F, training;
+    float alpha, att_dropout, dropout;      /* leaky-relu slope (0.2), attention dropout (0.5), layer dropout          */
+    float reserved_;
+    uint64_t seed;
+    const float* W;                         /* [fin][F]  graph_conv.W                                                   */
+    const float* a;                         /* [2F]      graph_conv.a                                                   */
+} eagcn_gat_params;
+size_t eagcn_gat_scratch_bytes(const eagcn_batch* b, int F);
+int eagcn_gat_forward(const eagcn_batch* b, const eagcn_gat_params* p, const float* x, float* h, float* s12, float* xout,
+                      void* stream);
+int eagcn_gat_backward(const eagcn_batch* b, const eagcn_gat_params* p, const float* x, const float* h, const float* s12,
+                       const float* xout, const float* dxout, float* dx, float* dW, float* da, void* scratch,
+                       size_t scratch_bytes, void* stream);
+
 /* Device half of the reference's collate (utils.py:504-640: every molecule zero-padded to the batch maximum): per-molecule
    atom-feature rows, concatenated [sum n_b][F] with molecule b = rows mol_offset[b] .. mol_offset[b+1], -> padded [B][N][F].
    Together with eagcn_index_from_bonds a batch reaches the device as O(atoms + bonds) bytes instead of

@@ -89,7 +89,8 @@ def test_model_golden(name):
     import copy
     probe = copy.deepcopy(model)
     with torch.no_grad():
-        index = ops.BatchIndex(adj, rels[:1] if g.meta['structure'] == 'GCN' else rels)
+        index = ops.BatchIndex(adj, rels[:1] if g.meta['structure'] in ('GCN', 'GAT') else rels,
+                               bond_lists=(g.meta['structure'] == 'GAT'))
         for i, (x, pad_row, layout) in enumerate(probe.forward_layers(index, afm)):
             pad = pad_row if g.meta['structure'] in ('Weighted_sum', 'GCN') else None
             dense_x = ops.unpack_rows(index, layout, x, pad)
@@ -1043,3 +1044,63 @@ def test_gcn_baseline_graph_mode_and_training_vs_oracle():
                 assert (v.cpu() - sd_r[k]).abs().max().item() <= 1e-5 * max(sd_r[k].abs().max().item(), 1.0), k
             if 'num_batches' in k:
                 assert int(v) == int(sd_r[k]) == 2, k
+
+
+@pytest.mark.gpu
+def test_gat_layer_training_mode_with_injected_dropout_masks():
+    """The GAT baseline layer in TRAINING mode (attention dropout 0.5, layers.py:104,133, + layer dropout): the kernels'
+    counter-based keep-scales are regenerated here and applied to the oracle's attention matrix and output by hand."""
+    from eagcn_amd import ops
+    from eagcn_amd.layers import GAT
+    from eagcn_amd.synthetic import make_batch
+    import torch.nn.functional as F
+    torch.manual_seed(31)
+    fin, fout, p_layer, seed = 24, 20, 0.3, 123456789
+    mb = make_batch(B=7, n_max=17, n_med=8, rel_channels=(28, 4, 2, 2, 2), seed=44, isolated_frac=0.15)
+    dense = mb.dense()
+    adj, afm = dense[0], dense[1]
+    layer = GAT(fin, fout, p_layer).cuda().train()
+    W, a = layer.graph_conv.W.detach().cpu(), layer.graph_conv.a.detach().cpu()
+    index = ops.BatchIndex(adj.cuda(), [dense[2].cuda()], bond_lists=True)
+    lay = ops.ColLayout.single(fin)
+    x = ops.pack_rows(index, lay, afm.cuda())
+    xout, _, out_layout = layer.forward_packed(index, x, lay, seed=seed)
+    got = ops.unpack_rows(index, out_layout, xout, None)
+    gout = torch.randn(got.shape, generator=torch.Generator().manual_seed(5))
+    (got * gout.cuda()).sum().backward()
+
+    # ---- the same computation in plain torch with the regenerated masks ----
+    B, N = mb.B, mb.N
+    has = (adj > 0).any(dim=2).numpy()
+    nat = np.array([(np.nonzero(has[b])[0].max() + 1) if has[b].any() else 0 for b in range(B)])
+    row0 = np.concatenate([[0], np.cumsum(nat)[:-1]])
+    Fp = (fout + 15) // 16 * 16
+    att_seed = seed ^ 0xA77E17105EED
+    att_scale = torch.ones(B, N, N)
+    out_scale = torch.ones(B, N, fout)
+    for b in range(B):
+        n = int(nat[b])
+        if not n:
+            continue
+        r = (row0[b] + np.arange(n)).astype(np.uint64)[:, None]
+        z = _mix64(att_seed, r * np.uint64(1024) + np.arange(N).astype(np.uint64)[None, :]) & np.uint64(0xFFFFFFFF)
+        att_scale[b, :n, :] = torch.from_numpy(np.where(z >= np.uint64(2 ** 31), np.float32(2.0), np.float32(0.0)))
+        thr = np.uint64(min(4294967295.0, float(np.float32(p_layer)) * 4294967296.0))
+        z = _mix64(seed, r * np.uint64(Fp) + np.arange(fout).astype(np.uint64)[None, :]) & np.uint64(0xFFFFFFFF)
+        out_scale[b, :n, :] = torch.from_numpy(np.where(z >= thr, np.float32(1.0) / (np.float32(1.0) - np.float32(p_layer)), np.float32(0.0)))
+    Wr, ar = W.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    m = adj.max(dim=2, keepdim=True)[0]
+    A = adj + m * torch.eye(N)
+    outs = []
+    for b in range(B):
+        h = afm[b] @ Wr
+        e = F.leaky_relu((h @ ar[:fout]) + (h @ ar[fout:]).t(), 0.2)
+        att = torch.where(A[b] > 0, e, torch.full_like(e, -9e15))
+        att = torch.where(A[b] > 0, F.softmax(att, dim=1), torch.zeros_like(e)) * att_scale[b]
+        outs.append(F.relu((att @ h) * out_scale[b]))
+    ref = torch.stack(outs)
+    (ref * gout).sum().backward()
+    assert rel_err(got.detach().cpu(), ref.detach(), 'GAT layer, training mode, injected masks') < 1e-5
+    scale = max(Wr.grad.abs().max().item(), ar.grad.abs().max().item())
+    assert_grad_close(layer.graph_conv.W.grad.cpu(), Wr.grad.numpy(), scale, 'graph_conv.W', rtol=2e-5, floor=2e-6)
+    assert_grad_close(layer.graph_conv.a.grad.cpu(), ar.grad.numpy(), scale, 'graph_conv.a', rtol=2e-5, floor=2e-6)

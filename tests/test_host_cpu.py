@@ -78,8 +78,12 @@ def test_aliases_and_layer_count_extension():
     m3 = Weighted_GCN(28, 24, *[10] * 5, *[20] * 5, 32, 16, 1, 0.0, n_layers=3)
     assert m3.structure == 'Weighted_sum' and m3.den1.in_features == 200 and m3.layer3.widths == [200] * 5
     from eagcn_amd import EAGCN
+    gat = EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, structure='GAT')     # baselines of models.py:63-73
+    assert gat.layer4.graph_conv.W.shape == (40, 80) and gat.layer1.graph_conv.a.shape == (80, 1) and gat.den1.in_features == 80
     with pytest.raises(ValueError):
-        EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, structure='GAT')       # baseline archs are out of scope
+        EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, structure='GAT', graph=True)   # GAT runs on the eager engine
+    with pytest.raises(ValueError):
+        EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, structure='Pool')
 
 
 def test_no_cpu_fallback():

@@ -43,8 +43,10 @@ def init_like_train(model, gen):
     for name, p in model.named_parameters():
         if name.endswith('batch_norm.weight') or name.endswith('batch_norm.bias'):
             p.data.zero_()                      # unused, uninitialised in the reference
-        elif name.endswith('graph_conv.weight'):
+        elif name.endswith('graph_conv.weight') or name.endswith('graph_conv.W'):
             p.data.normal_(0.0, 0.3, generator=gen)
+        elif name.endswith('graph_conv.a'):               # GAT attention vector (layers.py:114)
+            p.data.normal_(0.0, 0.5, generator=gen)
         elif '.bn.weight' in name or name.startswith('Graph_BN.weight') or 'bn_den' in name and name.endswith('weight'):
             p.data.normal_(1.0, 0.2, generator=gen)
         elif '.bn.bias' in name or name.startswith('Graph_BN.bias') or 'bn_den' in name and name.endswith('bias'):
@@ -217,6 +219,11 @@ def main():
     model_case('model_gcn_eval', 'GCN', 'sum', False, small, w1, w2, (16, 8), 2, 7, seed=14)
     model_case('model_gcn_ave_bce_train', 'GCN', 'ave', True, dict(B=8, n_max=10, n_med=5), w1, w2, (16, 8), 4, 7, loss='bce',
                seed=15)
+    # --- the GAT baseline of models.py:69-73 (layers.py:99-203), eval mode only: its attention dropout (0.5, not
+    #     configurable) makes training-mode outputs a function of torch's RNG stream ---
+    model_case('model_gat_eval', 'GAT', 'sum', False, dict(B=6, n_max=12, n_med=6, isolated_frac=0.15), w1, w2, (16, 8), 3, 7,
+               seed=16)
+    model_case('model_gat_ave_eval', 'GAT', 'ave', False, small, (4, 3, 3, 2, 2), (5, 4, 3, 2, 2), (16, 8), 2, 7, loss='mse', seed=17)
     # --- single layers (used for the 2-/3-layer parity of the n_layers extension) ---
     layer_case('layer_concate_train', 'Concate', True, small, 24, (8, 6, 4, 4, 5), 7, seed=21)
     layer_case('layer_concate_eval', 'Concate', False, small, 24, (8, 6, 4, 4, 5), 7, seed=22)
