@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     // the grid is sized for the row CAPACITY: only the first ceil(rows / BWD_ROWS) workgroups work (and write a
     // slab); bn_bwd_finalize derives the same count from the device-side row count
     const int nwg = max(1, min((int)gridDim.x, (rows + BWD_ROWS - 1) / BWD_ROWS));
-    if (blockIdx.x == 0 && a.zero)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && a.zero)
         for (int i = threadIdx.x; i < a.nzero; i += blockDim.x) a.zero[i] = 0.0;
     if ((int)blockIdx.x >= nwg) return;
     if (threadIdx.x < EAGCN_MAX_VIEWS) da_s[threadIdx.x] = 0.0;
@@ -302,7 +302,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     double da[EAGCN_MAX_VIEWS];
 #pragma unroll
     for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) da[k] = 0.0;
-    for (int cp = threadIdx.x * 4; cp < fp; cp += blockDim.x * 4) {
+    // grid.y cuts the columns into chunks of 1024 (one pass of the workgroup): a wide layer (Fp = 6320 at the HIV widths) is
+    // limited to a few hundred row blocks by the size of its partial slabs -- too few waves to stream at HBM rate
+    const int c_lo = blockIdx.y * (int)blockDim.x * 4;
+    for (int cp = c_lo + threadIdx.x * 4; cp < min(fp, c_lo + (int)blockDim.x * 4); cp += blockDim.x * 4) {
         const int k = col_view(a.vc, cp), f = cp - a.vc.off[k];
         const float4 sc = *reinterpret_cast<const float4*>(a.bn + BN_SC * fp + cp);
         const float4 sh = *reinterpret_cast<const float4*>(a.bn + BN_SH * fp + cp);
@@ -410,7 +413,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
             if ((threadIdx.x & 63) == 0 && t != 0.0) atomicAdd(&da_s[v], t);
         }
         __syncthreads();
-        if (threadIdx.x < EAGCN_MAX_VIEWS) a.slab_da[(size_t)blockIdx.x * EAGCN_MAX_VIEWS + threadIdx.x] = da_s[threadIdx.x];
+        if (threadIdx.x < EAGCN_MAX_VIEWS)
+            a.slab_da[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * EAGCN_MAX_VIEWS + threadIdx.x] = da_s[threadIdx.x];
     }
 }
 
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
                                                                int fp, double M, int training,
                                                                const float* __restrict__ bn, ViewCols vc,
                                                                GradPtrs gp, float* __restrict__ cc, const int32_t* __restrict__ meta, int nvirt,
-                                                               int batch_B) {
+                                                               int batch_B, int da_chunks, int da_stride) {
     if (meta[EAGCN_META_NLOG] > 0) M = (double)batch_B * (double)meta[EAGCN_META_NLOG];
     nslab = max(1, min(nslab, (meta[EAGCN_META_T] + nvirt + BWD_ROWS - 1) / BWD_ROWS));   // slabs actually written
     const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
@@ -429,7 +433,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
         const int v = threadIdx.x >> 5, l = threadIdx.x & 31;
         double t = 0.0;
         if (v < vc.K)
-            for (int s = l; s < nslab; s += 32) t += slab_da[(size_t)s * EAGCN_MAX_VIEWS + v];
+            for (int y = 0; y < da_chunks; ++y)             // (column chunk y of the reduce grid, row block s)
+                for (int s = l; s < nslab; s += 32) t += slab_da[((size_t)y * da_stride + s) * EAGCN_MAX_VIEWS + v];
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o);
         if (v < vc.K && l == 0) gp.dave_w[v] = (float)t;
@@ -651,7 +656,7 @@ static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, Bw
     t.cc = c.take<float>((size_t)2 * d.fp);
     t.dWcat = c.take<float>(d.wslab * d.nsplit);
     t.slab = c.take<double>((size_t)d.gxb * d.fp * 2);
-    t.slab_da = c.take<double>((size_t)d.gxb * EAGCN_MAX_VIEWS);
+    t.slab_da = c.take<double>((size_t)d.gxb * cdiv(d.fp, 1024) * EAGCN_MAX_VIEWS);
     t.datt = c.take<double>((size_t)std::max(edge_grid_x(b), d.sslabs) * EAGCN_MAX_VIEWS * EDGE_SLAB);
     if (s) *s = t;
     return c.off;
@@ -917,14 +922,15 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     const double M = (double)b->B * (double)b->N;
     {
         ProfScope ps(PROF_BN, s);
-        bn_bwd_reduce_kernel<<<gxb, 256, 0, s>>>(ba);
+        const int ny = cdiv(d.fp, 1024);
+        bn_bwd_reduce_kernel<<<dim3(gxb, ny), 256, 0, s>>>(ba);
         EAGCN_LAUNCH_CHECK();
         if (gxb > 64)
             bn_bwd_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
-                                                                       d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B);
+                                                                       d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb);
         else
             bn_bwd_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
-                                                                        d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B);
+                                                                        d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb);
         EAGCN_LAUNCH_CHECK();
         if (b->T > 0 && !sagg_enabled()) {        // (the bond-list aggregation applies this affine while it stages dH)
             bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
