@@ -36,7 +36,7 @@ _SIDE_AFTER_FWD = os.environ.get('EAGCN_SIDE_AFTER_FWD', '1') == '1'
 class StaticIndex:
     """BatchIndex-compatible view of the runner's static index buffers (capacities, no host values)."""
 
-    def __init__(self, B, N, channels, device, row_cap, edge_cap=None):
+    def __init__(self, B, N, channels, device, row_cap, edge_cap=None, rel_c=None):
         K = len(channels)
         self.device, self.B, self.N, self.K = device, B, N, K
         self.channels = list(channels)
@@ -69,6 +69,12 @@ class StaticIndex:
         ob = rb + 16 * T + 16 * self.n_tiles
         c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = ob, ob + 4 * T, ob + 8 * T, ob + 12 * T, ob + 16 * T
         L.set_bond_lists(c, base + 4 * (B * N + 3 * B + 2 + L.META_WORDS), self._ptrs, self._edges, self.E)
+        # general relation vectors (layers.py:82 with arbitrary channel values): a static 255-row code book per view
+        self.relvec = None
+        if rel_c is not None:
+            self.relvec = [torch.zeros((255, int(cw)), dtype=torch.float32, device=device) for cw in rel_c]
+            for k, t in enumerate(self.relvec):
+                c.rel_vec[k], c.rel_c[k] = t.data_ptr(), int(t.shape[1])
         self.c = c
 
     def ref(self):
@@ -80,14 +86,15 @@ class GraphRunner:
     a forward-only graph of the eval-mode model (running BatchNorm statistics, no dropout, no backward)."""
 
     def __init__(self, plan, B, N, channels, device, dropout, row_cap=None, training=True, static_outputs=False,
-                 validate='sync', edge_cap=None):
+                 validate='sync', edge_cap=None, rel_c=None):
         lib = L.load()
         self.plan, self.device = plan, device
         self.training = bool(training)
         self.static_outputs = bool(static_outputs)
         self.validate = validate
         self.key = (B, N, tuple(channels))
-        self.slots = [StaticIndex(B, N, channels, device, row_cap if row_cap else B * N, edge_cap) for _ in range(2)]
+        self.slots = [StaticIndex(B, N, channels, device, row_cap if row_cap else B * N, edge_cap, rel_c) for _ in range(2)]
+        self.rel_vectors = None        # per batch: the code books of a general batch (set by EAGCN._graph_runner)
         self.index = self.slots[0]
         self.graphs = [[None, None, None], [None, None, None]]   # per slot: [forward, backward, whole step (fused loss)]
         self.step_kind = [None, None]
@@ -315,6 +322,9 @@ class GraphRunner:
                 self.size_static[cur].copy_(size, non_blocking=True)
             if labels is not None:
                 self.labels_static[cur].copy_(labels.reshape(self.labels_static[cur].shape), non_blocking=True)
+            if idx.relvec is not None:                       # code books of this batch (rows beyond them are never referenced)
+                for t, v in zip(idx.relvec, self.rel_vectors):
+                    t[:v.shape[0]].copy_(v, non_blocking=True)
         ev = torch.cuda.Event()           # meta_host[slot] is valid and seeds_host[slot] is free again after this point
         ev.record(side)
         self.meta_event[slot] = ev

@@ -239,16 +239,20 @@ class EAGCN(nn.Module):
             if afms.shape != (B, N, self.n_afeat) or len(channels) != self.K:
                 raise ops.L.EagcnHipError('inconsistent compact batch: afms %s for B=%d N=%d, %d views'
                                           % (tuple(afms.shape), B, N, len(channels)))
-            if bonds.rel_vectors is not None:
-                raise ops.L.EagcnHipError('general relation vectors are served by the eager engine: build the model with '
-                                          'graph=False (the captured graphs hold the one-hot lookup)')
-            self._check_channels(channels)
+            self._check_channels(channels, bonds.rel_vectors)
             btuple = bonds.checked()
+            if bonds.rel_vectors is not None:
+                # general relation vectors: the runner's index holds a 255-row code book per view (static buffers, refilled per
+                # batch), so one pair of graphs serves batches with different numbers of distinct vectors
+                general = tuple(int(v.shape[1]) for v in bonds.rel_vectors)
+                channels = tuple(255 for _ in general)
         plan = self.plan()
+        if bonds is None or bonds.rel_vectors is None:
+            general = None
         n_in = N
         if self.n_bucket > 1:                       # one runner (one pair of captured graphs) per BUCKET of padded sizes
             N = -(-N // self.n_bucket) * self.n_bucket
-        key = (B, N, channels, float(self.dropout), self.training)
+        key = (B, N, channels, float(self.dropout), self.training, general)
         runner = self._runners.pop(key, None)
         if runner is None or runner.stale():
             while len(self._runners) >= max(1, self.max_runners):       # least recently used first (dict order)
@@ -256,12 +260,13 @@ class EAGCN(nn.Module):
                 old.release()
             runner = G.GraphRunner(plan, B, N, channels, afms.device, self.dropout, self.row_cap, training=self.training,
                                    static_outputs=(self.graph_outputs == 'static'), validate=self.validate,
-                                   edge_cap=self.edge_cap)
+                                   edge_cap=self.edge_cap, rel_c=general)
         self._runners[key] = runner                                      # (re-)inserted last = most recently used
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (self.dropout > 0 and self.training) else 0
         if self.molfp_mode == 'ave':
             size = size.to(device=afms.device, dtype=torch.int64)
         runner.n_in = n_in                           # padded size of THIS batch's tensors (<= the runner's capacity N)
+        runner.rel_vectors = None if general is None else bonds.rel_vectors
         return runner, adjs, rels, afms, size, seed, btuple
 
     def _atom_rep(self, runner):

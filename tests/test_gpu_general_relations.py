@@ -39,8 +39,9 @@ def _general_molecules(seed, B, channels):
     return mb, [torch.from_numpy(t) for t in [adj, afm] + rels], mols
 
 
+@pytest.mark.parametrize('graph', [False, True])
 @pytest.mark.parametrize('structure', ['Concate', 'Weighted_sum'])
-def test_general_relation_tensors_vs_oracle(structure):
+def test_general_relation_tensors_vs_oracle(structure, graph):
     from oracle.eagcn_ref import RefEAGCN, regression_loss
     channels = (6, 4, 3, 2, 2)
     mb, dense, mols = _general_molecules(17, 9, channels)
@@ -59,12 +60,22 @@ def test_general_relation_tensors_vs_oracle(structure):
 
     dev = torch.device('cuda', 0)
     m = EAGCN(6, 24, widths1=w1, widths2=w2, n_den1=16, n_den2=8, nclass=2, dropout=0.0, structure=structure, n_layers=2,
-              rel_channels=list(channels))
+              rel_channels=list(channels), graph=graph)
     m.load_state_dict(sd0, strict=True)
     m = m.to(dev).train()
-    bonds, afms, size_c, labels_c = collate_compact(mols, dev, general=True)
+    if graph:                                           # another general batch first: same runner, other code books
+        _, _, mols0 = _general_molecules(18, 9, channels)
+        b0, a0, s0, _ = collate_compact(mols0, dev, general=True, n_pad=21)
+        m.forward_compact(b0, a0, s0)[0].sum().backward()
+        sd = {k: v.to(dev) for k, v in sd0.items()}
+        m.load_state_dict(sd, strict=True)             # (undo the running-statistics update of that step)
+        for p in m.parameters():
+            p.grad = None
+    bonds, afms, size_c, labels_c = collate_compact(mols, dev, general=True, n_pad=21 if graph else None)
     assert bonds.rel_vectors is not None and all(5 <= v.shape[0] <= 10 for v in bonds.rel_vectors)
     out, _, gr = m.forward_compact(bonds, afms, size_c)
+    if graph:
+        assert len(m._runners) == 1
     torch.nn.functional.mse_loss(out.view(-1), labels_c.view(-1)).backward()
     assert rel_err(out.detach().cpu(), out_r.detach(), 'out (%s)' % structure) < 1e-5
     assert rel_err(gr.detach().cpu(), gr_r.detach(), 'graph_rep') < 1e-5
