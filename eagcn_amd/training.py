@@ -93,10 +93,11 @@ def set_weight(labels, n_tasks):
     return out
 
 
-def train_step(model, optimizer, batch, labels, task, bce_weight=None, dp_global_norm=False, fused=None):
+def train_step(model, optimizer, batch, labels, task, bce_weight=None, dp_global_norm=False, fused=None, bonds=None):
     """One iteration of train.py:310-334.  `batch` = (adjs, afms, TypeAtt, OrderAtt, AromAtt, ConjAtt, RingAtt, size) device
-    tensors; returns the loss tensor (device; no host sync).  With a graph-mode model the three phases run as ONE captured
-    graph (EAGCN.fused_step) unless fused=False."""
+    tensors -- or (afms, size) together with `bonds` (a CompactBonds: eagcn_amd.collate.collate_compact) for a compact batch;
+    returns the loss tensor (device; no host sync).  With a graph-mode model the three phases run as ONE captured graph
+    (EAGCN.fused_step) unless fused=False."""
     optimizer.zero_grad(set_to_none=True)
     if fused is None:
         fused = bool(getattr(model, 'graph', False)) and model.training and hasattr(model, 'fused_step')
@@ -105,9 +106,9 @@ def train_step(model, optimizer, batch, labels, task, bce_weight=None, dp_global
         if dp_global_norm:
             from .parallel import dp_loss_scale
             scale = dp_loss_scale(labels, None)
-        loss, _ = model.fused_step(batch, labels, task, bce_weight, scale)
+        loss, _ = model.fused_step(batch, labels, task, bce_weight, scale, bonds=bonds)
     else:
-        out, _, _ = model(*batch)
+        out, _, _ = model(*batch) if bonds is None else model.forward_compact(bonds, *batch)
         if task == 'reg':
             loss = fused_regression_loss(out, labels)
         else:
@@ -119,14 +120,15 @@ def train_step(model, optimizer, batch, labels, task, bce_weight=None, dp_global
 
 @torch.no_grad()
 def evaluate(model, batches, task, n_tasks):
-    """train.py:130-211: eval-mode forward over `batches` (iterable of (batch tuple, labels)); classification returns
-    (per-task AUCs, mean AUC), regression the RMSE.  The model is put back into training mode afterwards, as the reference
-    does (train.py:171, 210)."""
+    """train.py:130-211: eval-mode forward over `batches` (iterable of (batch tuple, labels); a batch tuple that starts with a
+    CompactBonds is (bonds, afms, size)); classification returns (per-task AUCs, mean AUC), regression the RMSE.  The model
+    is put back into training mode afterwards, as the reference does (train.py:171, 210)."""
     was_training = model.training
     model.eval()
     buf = None
     for batch, labels in batches:
-        out, _, _ = model(*batch)
+        compact = hasattr(batch[0], 'bond_mol')
+        out, _, _ = model.forward_compact(*batch) if compact else model(*batch)
         if buf is None:
             buf = EvalBuffers(n_tasks, task != 'reg', out.device)
         buf.append(out, labels)

@@ -3,6 +3,8 @@
 HIP-graph replay of the step, periodic evaluation (per-task ROC-AUC / RMSE on device-resident buffers).
 
     python examples/train_synth.py --dataset tox21 --steps 200 --batch 256
+    python examples/train_synth.py --dataset tox21 --loader compact      # per-molecule data -> compact collate, every batch
+                                                                        # padded to ITS maximum (utils.py:583), n_bucket=16
 """
 import argparse
 import os
@@ -13,6 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from eagcn_amd import EAGCN, training, weights_init  # noqa: E402
+from eagcn_amd.collate import collate_compact  # noqa: E402
 from eagcn_amd.synthetic import make_batch  # noqa: E402
 
 # train.py:61-114: widths, head sizes, learning rate, weight decay, task kind, tasks, (median atoms, N_max)
@@ -32,35 +35,51 @@ def main():
     ap.add_argument('--dr', type=float, default=0.3)
     ap.add_argument('--print-freq', type=int, default=50)
     ap.add_argument('--n-train', type=int, default=8, help='distinct synthetic training batches (cycled)')
+    ap.add_argument('--loader', default='dense', choices=('dense', 'compact'),
+                    help="dense: the reference's collate tensors; compact: bond list + unpadded rows (collate_compact)")
     args = ap.parse_args()
     w1, w2, d1, d2, lr, wd, task, T, n_bfeat, (n_med, n_max) = DATASETS[args.dataset]
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
 
     def batch(seed):
+        compact = args.loader == 'compact'
         mb = make_batch(B=args.batch, n_max=n_max, n_med=n_med, rel_channels=(n_bfeat, 4, 2, 2, 2), seed=seed, n_tasks=T,
-                        task=task)
-        return tuple(mb.dense(dev)), torch.from_numpy(mb.labels).to(dev)
+                        task=task, force_max=not compact)
+        if not compact:
+            return tuple(mb.dense(dev)), torch.from_numpy(mb.labels).to(dev)
+        # what a Dataset.__getitem__ of the reference yields (utils.py:470-502), one tuple per molecule
+        dense = [t.numpy() for t in mb.dense()]
+        mols = []
+        for b in range(mb.B):
+            n = int(mb.sizes[b])
+            mols.append((dense[0][b, :n, :n], dense[1][b, :n]) + tuple(r[b, :, :n, :n] for r in dense[2:7]) +
+                        (mb.labels[b], 'mol%d' % b, None, b))
+        bonds, afms, size, labels = collate_compact(mols, dev)
+        return (bonds, afms, size), labels
     train_set = [batch(100 + i) for i in range(args.n_train)]
     val_set = [batch(900 + i) for i in range(2)]
     bce_w = None
     if task == 'class':
         bce_w = torch.tensor(training.set_weight(torch.cat([l.cpu() for _, l in train_set]), T), device=dev)
     model = EAGCN(n_bfeat, 24, *w1, *w2, d1, d2, T, args.dr, structure=args.arch, n_layers=args.layers, graph=True,
-                  overlap_index=True, validate='deferred').to(dev)
+                  overlap_index=True, validate='deferred', n_bucket=16 if args.loader == 'compact' else 0).to(dev)
     model.apply(weights_init)
     opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
     t0 = time.perf_counter()
     for step in range(args.steps):
         b, labels = train_set[step % len(train_set)]
-        loss = training.train_step(model, opt, b, labels, task, bce_w)
+        if args.loader == 'compact':
+            loss = training.train_step(model, opt, b[1:], labels, task, bce_w, bonds=b[0])
+        else:
+            loss = training.train_step(model, opt, b, labels, task, bce_w)
         if step % args.print_freq == 0 or step == args.steps - 1:
             metric = training.evaluate(model, val_set, task, T)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             shown = 'val mean AUC %.4f' % metric[1] if task == 'class' else 'val RMSE %.4f' % metric
-            print('step %4d  loss %.5f  %s  (%.1f molecules/s incl. evaluation)' % (step, float(loss), shown,
-                                                                                    (step + 1) * args.batch / dt))
+            print('step %4d  loss %.5f  %s  (%.1f molecules/s incl. evaluation; %d captured runner(s))'
+                  % (step, float(loss), shown, (step + 1) * args.batch / dt, len(model._runners)))
 
 
 if __name__ == '__main__':
