@@ -49,3 +49,36 @@ def test_compact_collate_rejects_non_one_hot_relations():
     bad[2] = r
     with pytest.raises(ValueError, match='one-hot'):
         compact_host([tuple(bad)] + mols[1:])
+
+
+def test_general_collate_code_book_reconstructs_the_relation_tensors():
+    """general=True: any channel values at the bonds (layers.py:82 is a plain 1x1 convolution); the per-view code book of the
+    batch + the codes reproduce the dense relation tensors exactly."""
+    z, mols = _load('collate_class')
+    rng = np.random.default_rng(3)
+    gen = []
+    for m in mols:
+        adj = m[0]
+        i, j = np.nonzero(np.triu(adj))
+        rels = []
+        for r in m[2:7]:
+            pal = np.round(rng.normal(size=(4, r.shape[0])), 1).astype(np.float32)
+            g = np.zeros_like(r)
+            pick = pal[rng.integers(0, 4, size=len(i))]
+            g[:, i, j] = pick.T
+            g[:, j, i] = pick.T
+            rels.append(g)
+        gen.append((adj, m[1]) + tuple(rels) + m[7:])
+    h = compact_host(gen, general=True)
+    assert h['rel_vectors'] is not None and all(1 <= len(t) <= 255 for t in h['rel_vectors'])
+    assert h['channels'] == [len(t) for t in h['rel_vectors']]
+    B, N = len(gen), int(h['sizes'].max())
+    for k, table in enumerate(h['rel_vectors']):
+        assert np.array_equal(table, np.unique(table, axis=0))              # sorted, distinct: a deterministic code book
+        dense = np.zeros((B, table.shape[1], N, N), dtype=np.float32)
+        dense[h['bond_mol'], :, h['bond_i'], h['bond_j']] = table[h['bond_code'][:, k]]
+        for b, m in enumerate(gen):
+            n = m[0].shape[0]
+            assert np.array_equal(dense[b, :, :n, :n], m[2 + k]), (b, k)
+    with pytest.raises(ValueError, match='general=True'):
+        compact_host(gen)
