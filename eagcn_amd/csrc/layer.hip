@@ -995,6 +995,12 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             if (dx) { rc = launch_gemm(gx, s); if (rc) return rc; }
         }
     }
+    if (b->T == 0) {
+        // a batch without a single bond has no packed row: no product ran, the weight gradients are exactly zero (the edge
+        // partials below are summed over zero workgroups; the BatchNorm gradients came from the row-less reduction above)
+        for (int k = 0; k < p->K; ++k)
+            EAGCN_HIP(hipMemsetAsync(gp.dW[k], 0, (size_t)d.fin * p->width[k] * sizeof(float), side));
+    }
     {
         const int wblocks = nsplit > 0 ? cdiv((int)d.wslab, 256) : 0;
         ProfScope psu(PROF_PACK, side);
