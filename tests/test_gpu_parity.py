@@ -1160,3 +1160,34 @@ def test_batch_without_any_bond(structure):
         for k, v in m.state_dict().items():
             if 'running' in k:
                 assert (v.cpu() - sd_r[k]).abs().max().item() <= 1e-5 * max(sd_r[k].abs().max().item(), 1.0), (k, graph)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_max,channels', [(1024, (28, 4, 2, 2, 2)), (600, (28, 4, 2, 2, 2)), (40, (255, 4, 2, 2, 2))])
+def test_maximum_sizes(n_max, channels):
+    """The stated limits of the index: N up to 1024 atom slots (four column trips of the adjacency scan, row tables of the
+    aggregation for a 1024-atom molecule) and up to 255 bond types in a view, against the oracle (2 layers, narrow)."""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    from oracle.eagcn_ref import RefEAGCN
+    torch.manual_seed(12)
+    w1, w2 = [8, 4, 4, 4, 4], [8, 8, 4, 4, 4]
+    mb = make_batch(B=3, n_max=n_max, n_med=max(n_max // 3, 8), rel_channels=channels, seed=5, n_tasks=1, task='reg')
+    assert mb.N == n_max
+    ref = RefEAGCN(channels[0], 24, w1, w2, 16, 8, 1, 0.0, n_layers=2, rel_channels=list(channels)).train()
+    m = EAGCN(channels[0], 24, widths1=w1, widths2=w2, n_den1=16, n_den2=8, nclass=1, dropout=0.0, n_layers=2,
+              rel_channels=list(channels))
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.cuda().train()
+    dense = mb.dense()
+    out_r, atom_r, gr_r = ref(*dense)
+    (out_r.sum() + gr_r.sum()).backward()
+    out, atom_rep, gr = m(*_dev(dense))
+    (out.sum() + gr.sum()).backward()
+    assert rel_err(out.detach().cpu(), out_r.detach(), 'out N=%d C=%d' % (n_max, channels[0])) < 1e-5
+    assert rel_err(atom_rep.cpu(), atom_r, 'atom_rep') < 1e-5
+    got = dict(m.named_parameters())
+    scale = max(p.grad.abs().max().item() for p in ref.parameters() if p.grad is not None)
+    for k, p in ref.named_parameters():
+        if p.grad is not None:
+            assert_grad_close(got[k].grad.cpu(), p.grad.numpy(), scale, k, rtol=1e-4, floor=5e-6)
