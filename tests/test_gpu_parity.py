@@ -1191,3 +1191,51 @@ def test_maximum_sizes(n_max, channels):
     for k, p in ref.named_parameters():
         if p.grad is not None:
             assert_grad_close(got[k].grad.cpu(), p.grad.numpy(), scale, k, rtol=1e-4, floor=5e-6)
+
+
+@pytest.mark.gpu
+def test_self_loops_and_directed_bonds_dense_signature():
+    """The dense signature takes ANY 0/1 adjacency (layers.py:82-90 never assumes symmetry or an empty diagonal): bonds on the
+    diagonal (the attention weight adds to sigmoid(self_r)) and one-directional bonds, against the oracle.  (Every atom below
+    nat keeps at least one outgoing bond: an atom that is only pointed AT lies beyond the packed rows)"""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    from oracle.eagcn_ref import RefEAGCN
+    torch.manual_seed(14)
+    channels = (9, 4, 2, 2, 2)
+    mb = make_batch(B=6, n_max=15, n_med=8, rel_channels=channels, seed=91, n_tasks=1, task='reg')
+    dense = [t.clone() for t in mb.dense()]
+    adj, rels = dense[0], dense[2:7]
+    rng = np.random.default_rng(7)
+    for b in range(mb.B):
+        n = int(mb.sizes[b])
+        for i in rng.choice(n, size=max(1, n // 4), replace=False):          # self loops with a random bond type per view
+            adj[b, i, i] = 1.0
+            for k, c in enumerate(channels):
+                rels[k][b, :, i, i] = 0.0
+                rels[k][b, rng.integers(0, c), i, i] = 1.0
+        for _ in range(n // 3):                                              # delete one direction of a few bonds
+            i = int(rng.integers(0, n))
+            js = torch.nonzero(adj[b, i, :n]).flatten().tolist()
+            js = [j for j in js if j != i]
+            if len(js) >= 2:                                                 # (row i keeps another outgoing bond)
+                j = js[int(rng.integers(0, len(js)))]
+                adj[b, i, j] = 0.0
+                for k in range(5):
+                    rels[k][b, :, i, j] = 0.0
+    w1, w2 = [8, 6, 4, 4, 6], [10, 8, 6, 6, 6]
+    ref = RefEAGCN(9, 24, w1, w2, 16, 8, 1, 0.0, n_layers=2, rel_channels=list(channels)).train()
+    m = EAGCN(9, 24, widths1=w1, widths2=w2, n_den1=16, n_den2=8, nclass=1, dropout=0.0, n_layers=2, rel_channels=list(channels))
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.cuda().train()
+    out_r, atom_r, gr_r = ref(*dense)
+    (out_r.sum() + gr_r.sum()).backward()
+    out, atom_rep, gr = m(*_dev(dense))
+    (out.sum() + gr.sum()).backward()
+    assert rel_err(out.detach().cpu(), out_r.detach(), 'out (self loops, directed bonds)') < 1e-5
+    assert rel_err(atom_rep.cpu(), atom_r, 'atom_rep') < 1e-5
+    got = dict(m.named_parameters())
+    scale = max(p.grad.abs().max().item() for p in ref.parameters() if p.grad is not None)
+    for k, p in ref.named_parameters():
+        if p.grad is not None:
+            assert_grad_close(got[k].grad.cpu(), p.grad.numpy(), scale, k, rtol=1e-4, floor=5e-6)
