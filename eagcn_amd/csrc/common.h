@@ -216,8 +216,5 @@ struct GemmDesc {
 int launch_gemm(const GemmDesc& g, hipStream_t s);
 // dX (ta=0,tb=1) and dW (ta=1,tb=0) of one layer in one launch (falls back to two launches otherwise)
 int launch_gemm_pair(const GemmDesc& dx, const GemmDesc& dw, hipStream_t s);
-// up to three products with ta = 1, tb = 0 in one launch (falls back to one launch each otherwise)
-// `lead`: optionally one product of the dX form (ta=0, tb=1) computed by the first workgroups of the same launch
-int launch_gemm_group(const GemmDesc* descs, int n, hipStream_t s, const GemmDesc* lead = nullptr);
 
 }  // namespace eagcn

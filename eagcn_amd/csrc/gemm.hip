@@ -6,7 +6,6 @@
 // (dX = dP.W^T, dW = X^T.dP, the latter split-K over the rows).  Kernels in this file:
 //   gemm_f32_kernel       one product; XCD-aware tile order; row / reduction extents from device memory
 //   gemm_f32_pair_kernel  dX and dW of a layer in ONE grid (fills the partly empty last round of each)
-//   gemm_f32_group_kernel up to three small dW-form products in one grid (the head's weight gradients)
 // Each takes its 64x64 tile from gemm_tile (fp32 MFMA, exact fp32 products) or, opt-in, gemm_tile_x6
 // (gemm_x6.h: exact three-way bf16 split, six bf16 MFMA products, fp32 accumulation).
 //
@@ -318,39 +317,6 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(GemmDesc g0, GemmDes
     }
 }
 
-// Up to three independent products of the dW form (A stored [K][M], B stored [K][N]) in ONE launch: the head's
-// three weight-gradient products are each a handful of tiles, so one grid covers them all.
-struct GemmGroup {
-    GemmDesc d0, d1, d2;
-    int first1, first2;     // first workgroup of problem 1 / 2 (problem 0 starts at 0)
-};
-// LEAD: the first `lead_wgs` workgroups compute one more product of the dX form (A stored [M][K], B stored
-// [N][K], optionally split-K) -- the head's d(input) product shares the launch with its three weight gradients
-template <int BM, int BN, int BK, int D, bool LEAD = false>
-__global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroup gg, GemmDesc lead, int lead_wgs) {
-    auto run = [&](const GemmDesc& g, int lin) {
-        const int gx = (g.N + BN - 1) / BN;
-        const int per_z = gx * ((g.M + BM - 1) / BM);
-        const int z = lin / per_z, rem = lin - z * per_z;
-        const int ty = rem / gx;
-        gemm_tile<BM, BN, BK, false, false, D>(g, g.M, g.K, rem - ty * gx, ty, z, g.splits);
-    };
-    int b = blockIdx.x;
-    if constexpr (LEAD) {
-        if (b < lead_wgs) {
-            const int gx = (lead.N + BN - 1) / BN;
-            const int per_z = gx * ((lead.M + BM - 1) / BM);
-            const int z = b / per_z, rem = b - z * per_z;
-            const int ty = rem / gx;
-            gemm_tile<BM, BN, BK, true, true, D>(lead, lead.M, lead.K, rem - ty * gx, ty, z, lead.splits);
-            return;
-        }
-        b -= lead_wgs;
-    }
-    if (b < gg.first1) run(gg.d0, b);
-    else if (b < gg.first2) run(gg.d1, b - gg.first1);
-    else run(gg.d2, b - gg.first2);
-}
 
 template <int BM, int BN, int BK, int D>
 static int launch_cfg(const GemmDesc& g, hipStream_t s) {
@@ -443,48 +409,6 @@ int launch_gemm_pair(const GemmDesc& dx, const GemmDesc& dw, hipStream_t s) {
     if (use_x6(g0) == 2 && use_x6(g1) == 2) gemm_f32_pair_kernel<64, 64, 16, 4, 2><<<first1 + n1, 256, 0, s>>>(g0, g1, first1);
     else if (use_x6(g0) && use_x6(g1)) gemm_f32_pair_kernel<64, 64, 16, 4, 1><<<first1 + n1, 256, 0, s>>>(g0, g1, first1);
     else gemm_f32_pair_kernel<64, 64, 16, 4><<<first1 + n1, 256, 0, s>>>(g0, g1, first1);
-    EAGCN_LAUNCH_CHECK();
-    return EAGCN_OK;
-}
-
-int launch_gemm_group(const GemmDesc* descs, int n, hipStream_t s, const GemmDesc* lead0) {
-    EAGCN_CHECK_ARG(n >= 1 && n <= 3, "gemm group: 1..3 products");
-    GemmGroup gg;
-    GemmDesc d[3];
-    int wgs[3] = {0, 0, 0};
-    bool ok = true;
-    for (int i = 0; i < 3; ++i) {
-        d[i] = descs[i < n ? i : n - 1];
-        GemmDesc& g = d[i];
-        g.vecA = (g.lda % 4) == 0 && (g.M % 4) == 0 && (reinterpret_cast<uintptr_t>(g.A) % 16) == 0;
-        g.vecB = (g.ldb % 4) == 0 && (g.N % 4) == 0 && (reinterpret_cast<uintptr_t>(g.B) % 16) == 0;
-        ok = ok && g.ta == 1 && g.tb == 0 && !g.M_dev && !g.K_dev && g.M > 0 && g.N > 0 && (g.splits == 1 || (g.vecA && g.vecB));
-        if (i < n) wgs[i] = cdiv(g.M, 64) * cdiv(g.N, 64) * g.splits;
-    }
-    GemmDesc lead;
-    int lead_wgs = 0;
-    if (lead0) {
-        lead = *lead0;
-        lead.vecA = (lead.lda % 4) == 0 && (lead.K % 4) == 0 && (reinterpret_cast<uintptr_t>(lead.A) % 16) == 0;
-        lead.vecB = (lead.ldb % 4) == 0 && (lead.K % 4) == 0 && (reinterpret_cast<uintptr_t>(lead.B) % 16) == 0;
-        ok = ok && lead.ta == 0 && lead.tb == 1 && !lead.M_dev && !lead.K_dev && lead.M > 0 && lead.N > 0 &&
-             (lead.splits == 1 || (lead.vecA && lead.vecB));
-        lead_wgs = cdiv(lead.M, 64) * cdiv(lead.N, 64) * lead.splits;
-    }
-    if (!ok) {                     // not the grouped form: one launch per product
-        if (lead0) { int rc = launch_gemm(*lead0, s); if (rc) return rc; }
-        for (int i = 0; i < n; ++i) { int rc = launch_gemm(descs[i], s); if (rc) return rc; }
-        return EAGCN_OK;
-    }
-    gg.d0 = d[0]; gg.d1 = d[1]; gg.d2 = d[2];
-    gg.first1 = wgs[0];
-    gg.first2 = wgs[0] + wgs[1];
-    double work = 0.0;
-    for (int i = 0; i < n; ++i) work += d[i].work > 0.0 ? d[i].work : 2.0 * d[i].M * d[i].N * d[i].K;
-    if (lead0) work += lead.work > 0.0 ? lead.work : 2.0 * lead.M * lead.N * lead.K;
-    ProfScope ps(d[0].prof_tag, s, work);
-    if (lead0) gemm_f32_group_kernel<64, 64, 16, 4, true><<<lead_wgs + wgs[0] + wgs[1] + wgs[2], 256, 0, s>>>(gg, lead, lead_wgs);
-    else gemm_f32_group_kernel<64, 64, 16, 4, false><<<wgs[0] + wgs[1] + wgs[2], 256, 0, s>>>(gg, d[0], 0);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
