@@ -3,6 +3,8 @@
 //   w[t][1] if label == 0, else 0 (missing label); loss = sum_i weight_i * bce_with_logits(x_i, y_i)
 //   / #labels in {0,1}.   regression (train.py:321-325): mean squared error.
 // The reference builds the weight tensor with a B x T Python double loop (10 ms per 64x12 batch).
+#include <algorithm>
+
 #include "common.h"
 
 namespace eagcn {
@@ -68,6 +70,59 @@ __global__ __launch_bounds__(1024) void bce_loss_kernel(const float* __restrict_
     }
 }
 
+// Large batches (B*T beyond a few thousand): several workgroups.  d loss / d logit of an element needs the GLOBAL count of
+// labelled entries, which every workgroup recounts for itself (labels are B*T floats, L2-resident); the loss value is the
+// sum of the workgroups' partials (fp64 atomics on a device word that the last workgroup reads, publishes and re-arms).
+// One call at a time per device (the accumulator is a module-level word): the training loop's single stream.
+__device__ double g_bce_acc;
+__device__ unsigned g_bce_ticket;
+__global__ __launch_bounds__(1024) void bce_loss_multi_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                               const float* __restrict__ w, int B, int T,
+                                                               float* __restrict__ loss, float* __restrict__ dx) {
+    __shared__ double s_sum[16];
+    __shared__ int s_cnt[16];
+    const int n = B * T, nthr = blockDim.x;
+    int cnt = 0;
+    for (int i0 = threadIdx.x; i0 < n; i0 += nthr * 8) {               // 8 label loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i0 + u * nthr < n ? y[i0 + u * nthr] : -1.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cnt += (v[u] == 1.0f || v[u] == 0.0f) ? 1 : 0;
+    }
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    int c = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) c += s_cnt[k];
+    const float inv = 1.0f / (float)c;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += nthr) {
+        const int t = i % T;
+        const float xi = x[i], yi = y[i];
+        const float wi = yi == 1.0f ? w[t * 2 + 0] : (yi == 0.0f ? w[t * 2 + 1] : 0.0f);
+        acc += (double)(wi * (fmaxf(xi, 0.0f) - xi * yi + log1pf(expf(-fabsf(xi)))));
+        dx[i] = wi * (1.0f / (1.0f + expf(-xi)) - yi) * inv;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) tot += s_sum[k];
+        atomicAdd(&g_bce_acc, tot);
+        __threadfence();
+        if (atomicAdd(&g_bce_ticket, 1u) == gridDim.x - 1) {           // the last workgroup: every partial has been added
+            const double total = atomicAdd(&g_bce_acc, 0.0);
+            loss[0] = (float)(total / (double)c);
+            atomicExch((unsigned long long*)&g_bce_acc, 0ull);
+            atomicExch(&g_bce_ticket, 0u);
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          int n, float* __restrict__ loss, float* __restrict__ dx) {
     __shared__ double s_sum[16];
@@ -122,7 +177,9 @@ extern "C" int eagcn_bce_loss(const float* logits, const float* labels, const fl
                               float* loss, float* dlogits, void* stream) {
     EAGCN_CHECK_ARG(logits && labels && class_weight && loss && dlogits, "eagcn_bce_loss: null argument");
     EAGCN_CHECK_ARG(B > 0 && T > 0, "eagcn_bce_loss: empty batch");
-    bce_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, labels, class_weight, B, T, loss, dlogits);
+    const int n = B * T;
+    if (n <= 4096) bce_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, labels, class_weight, B, T, loss, dlogits);
+    else bce_loss_multi_kernel<<<std::min(16, cdiv(n, 1024)), 1024, 0, (hipStream_t)stream>>>(logits, labels, class_weight, B, T, loss, dlogits);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

@@ -67,3 +67,24 @@ def test_fused_step_scale_and_accumulation():
         if p.grad is not None:
             d = (p.grad - q.grad).abs().max().item()
             assert d <= 2e-6 * max(p.grad.abs().max().item(), 1e-6), (n, d)
+
+
+def test_bce_loss_large_batch_multi_workgroup_kernel():
+    """B*T beyond 4096 takes the multi-workgroup loss kernel: value and gradient against the tensor-op restatement of
+    train.py:326-331 (eagcn_amd.losses.classification_loss), twice in a row (the accumulator re-arms itself)."""
+    from eagcn_amd.losses import classification_loss
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(3)
+    B, T = 1024, 12
+    x = (torch.randn(B, T, generator=g) * 3).to(dev)
+    y = torch.randint(-1, 2, (B, T), generator=g).float().to(dev)
+    w = torch.tensor(bce_weights(T), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        xa = x.clone().requires_grad_(True)
+        la = fused_classification_loss(xa, y, w)
+        la.backward()
+        xb = x.clone().requires_grad_(True)
+        lb = classification_loss(xb, y, w)
+        lb.backward()
+        assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb)), (float(la), float(lb))
+        assert (xa.grad - xb.grad).abs().max().item() <= 2e-6 * xb.grad.abs().max().item()
