@@ -45,6 +45,8 @@ def init_like_train(model, gen):
             p.data.zero_()                      # unused, uninitialised in the reference
         elif name.endswith('graph_conv.weight') or name.endswith('graph_conv.W'):
             p.data.normal_(0.0, 0.3, generator=gen)
+        elif name.endswith('feature_layer.weight') or name.endswith('adjacent_layer.weight'):   # Diff_Pooling (layers.py:495-496)
+            p.data.normal_(0.0, 0.3, generator=gen)
         elif name.endswith('graph_conv.a'):               # GAT attention vector (layers.py:114)
             p.data.normal_(0.0, 0.5, generator=gen)
         elif '.bn.weight' in name or name.startswith('Graph_BN.weight') or 'bn_den' in name and name.endswith('weight'):
@@ -224,6 +226,15 @@ def main():
     model_case('model_gat_eval', 'GAT', 'sum', False, dict(B=6, n_max=12, n_med=6, isolated_frac=0.15), w1, w2, (16, 8), 3, 7,
                seed=16)
     model_case('model_gat_ave_eval', 'GAT', 'ave', False, small, (4, 3, 3, 2, 2), (5, 4, 3, 2, 2), (16, 8), 2, 7, loss='mse', seed=17)
+    # --- molfp_mode='pool' (Diff_Pooling read-out, layers.py:492-506, models.py:90-92, 104-106) over every layer family ---
+    iso = dict(B=6, n_max=12, n_med=6, isolated_frac=0.15)
+    model_case('model_concate_pool_train', 'Concate', 'pool', True, iso, w1, w2, (16, 8), 3, 7, seed=31)
+    model_case('model_weighted_pool_train', 'Weighted_sum', 'pool', True, iso, (3, 2, 2, 2, 3), (4, 3, 2, 2, 3), (16, 8), 2, 5,
+               seed=32)
+    model_case('model_weighted_pool_eval', 'Weighted_sum', 'pool', False, small, (3, 2, 2, 2, 3), (4, 3, 2, 2, 3), (16, 8), 2, 5,
+               seed=33)
+    model_case('model_gcn_pool_train', 'GCN', 'pool', True, iso, w1, w2, (16, 8), 3, 7, loss='mse', seed=34)
+    model_case('model_gat_pool_eval', 'GAT', 'pool', False, iso, w1, w2, (16, 8), 2, 7, seed=35)
     # --- single layers (used for the 2-/3-layer parity of the n_layers extension) ---
     layer_case('layer_concate_train', 'Concate', True, small, 24, (8, 6, 4, 4, 5), 7, seed=21)
     layer_case('layer_concate_eval', 'Concate', False, small, 24, (8, 6, 4, 4, 5), 7, seed=22)
