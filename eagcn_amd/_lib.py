@@ -53,6 +53,14 @@ class GatParams(C.Structure):
                 ('seed', C.c_uint64), ('W', _fp), ('a', _fp)]
 
 
+POOL_MAX = 8
+
+
+class PoolAtt(C.Structure):
+    _fields_ = [('K', C.c_int32), ('mode', C.c_int32), ('att_c', C.c_int32 * MAX_VIEWS), ('att_w', _fp * MAX_VIEWS),
+                ('ave_a', _fp), ('self_r', _fp), ('datt_w', _fp * MAX_VIEWS), ('dave_a', _fp), ('dself_r', _fp)]
+
+
 class Layout(C.Structure):
     _fields_ = [('nseg', C.c_int32), ('width', C.c_int32 * MAX_SEGS), ('pad', C.c_int32 * MAX_SEGS)]
 
@@ -121,6 +129,15 @@ SIGNATURES = {
     'eagcn_gat_forward': (C.c_int, [C.POINTER(Batch), C.POINTER(GatParams), _fp, _fp, _fp, _fp, _fp]),
     'eagcn_gat_backward': (C.c_int, [C.POINTER(Batch), C.POINTER(GatParams), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
                                      C.c_size_t, _fp]),
+    'eagcn_pool_scratch_bytes': (C.c_size_t, []),
+    'eagcn_pool_attention_forward': (C.c_int, [C.POINTER(Batch), C.POINTER(PoolAtt), _fp, C.c_int, _fp, _fp, _fp]),
+    'eagcn_pool_attention_backward': (C.c_int, [C.POINTER(Batch), C.POINTER(PoolAtt), _fp, C.c_int, _fp, _fp, _fp, C.c_size_t,
+                                                _fp]),
+    'eagcn_pool_mix_forward': (C.c_int, [C.POINTER(Batch), C.POINTER(Layout), _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp]),
+    'eagcn_pool_mix_backward': (C.c_int, [C.POINTER(Batch), C.POINTER(Layout), _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp,
+                                          _fp, _fp, _fp]),
+    'eagcn_pool_reduce_forward': (C.c_int, [C.POINTER(Batch), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
+    'eagcn_pool_reduce_backward': (C.c_int, [C.POINTER(Batch), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]),
     'eagcn_layer_forward': (C.c_int, [C.POINTER(Batch), C.POINTER(LayerParams), C.POINTER(LayerBufs), _fp]),
     'eagcn_layer_backward': (C.c_int, [C.POINTER(Batch), C.POINTER(LayerParams), C.POINTER(LayerBufs),
                                        _fp, _fp, _fp, C.POINTER(LayerGrads), _fp]),

@@ -100,6 +100,8 @@ extern "C" size_t eagcn_struct_size(int which) {
         case 5: return sizeof(eagcn_head_params);
         case 6: return sizeof(eagcn_head_grads);
         case 7: return sizeof(eagcn_model);
+        case 8: return sizeof(eagcn_gat_params);
+        case 9: return sizeof(eagcn_pool_att);
         default: return 0;
     }
 }

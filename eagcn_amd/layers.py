@@ -338,6 +338,35 @@ class GAT(nn.Module):
         return dense, a
 
 
+class Diff_Pooling(nn.Module):
+    """Soft cluster assignment read-out (reference layers.py:492-506; models.py:90-92 builds ``pool1`` with pool_num clusters
+    and an unused ``pool3``).  Parameter tree as the reference: feature_layer.weight [fin,fout], adjacent_layer.weight
+    [fin,out_size], both bias-free GraphConv_base.  The computation runs on csrc/pool.hip + the flat fp32 GEMM through
+    ``ops.pool_readout``; ``pooled_sum`` returns sum over clusters of relu(S^T . relu((A.X).Wf)) -- the only thing
+    models.py:104-106 consumes (the pooled adjacency of layers.py:504-505 is never read and not computed)."""
+
+    def __init__(self, in_feature, out_feature, out_size):
+        super().__init__()
+        if not 1 <= int(out_size) <= ops.L.POOL_MAX:
+            raise ValueError('Diff_Pooling: out_size must be 1..%d' % ops.L.POOL_MAX)
+        self.feature_layer = GraphConv_base(in_feature, out_feature)
+        self.adjacent_layer = GraphConv_base(in_feature, out_size)
+
+    def pooled_sum(self, index, layout, x, pad_row, last_layer):
+        """x: packed output [T, ld] of ``last_layer`` (whose attention matrix A is rebuilt on the device) -> [B, fout]."""
+        if isinstance(last_layer, GAT):
+            kw = dict(mode='gat')
+        elif isinstance(last_layer, Vanilla_GCN):
+            kw = dict(mode='gcn')
+        else:
+            if not last_layer.last:
+                raise EagcnHipError("molfp_mode='pool' needs the attention matrix of a layer built with last=True "
+                                    "(layers.py:319-324)")
+            kw = dict(mode='attention', att_w=[b.att.weight for b in last_layer.blocks()],
+                      ave_a=last_layer.ave_A.weight, self_r=last_layer.self_r)
+        return ops.pool_readout(index, layout, x, pad_row, self.feature_layer.weight, self.adjacent_layer.weight, **kw)
+
+
 class Dense(nn.Module):
     """x @ W without bias by default (reference layers.py:360-392); W is U(-1/sqrt(fout), ..)."""
 

@@ -44,7 +44,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import GAT, Dense, GraphConv_Layer, Vanilla_GCN
+from .layers import GAT, Dense, Diff_Pooling, GraphConv_Layer, Vanilla_GCN
 
 
 class LazyAtomRep:
@@ -101,9 +101,14 @@ class EAGCN(nn.Module):
             raise ValueError("structure must be 'Concate', 'Weighted_sum' or one of the baselines 'GCN' / 'GAT' (models.py:50-73)")
         if structure == 'GAT' and graph:
             raise ValueError("structure='GAT' runs layer by layer on the eager engine (graph=False)")
-        if molfp_mode not in ('sum', 'ave'):
-            raise ValueError("molfp_mode 'sum' and 'ave' are implemented ('pool' = Diff_Pooling is "
-                             "outside the hot path, SURVEY.md 8f)")
+        if molfp_mode not in ('sum', 'ave', 'pool'):
+            raise ValueError("molfp_mode must be 'sum', 'ave' or 'pool' (models.py:104-111)")
+        if molfp_mode == 'pool':
+            if graph:
+                raise ValueError("molfp_mode='pool' (Diff_Pooling) runs on the eager engine (graph=False)")
+            if structure in ('Concate', 'Weighted_sum') and n_layers != 4:
+                raise ValueError("molfp_mode='pool' reads the attention matrix of layer 4 (last=True, layers.py:319-324)")
+        self.pool_num = int(pool_num)
         if not 1 <= n_layers <= 4:
             raise ValueError('n_layers must be 1..4')
         if structure == 'GAT':                                            # models.py:69-73: four GAT layers
@@ -160,6 +165,9 @@ class EAGCN(nn.Module):
         self.Graph_BN = nn.BatchNorm1d(f_last)
         self.bn_den1 = nn.BatchNorm1d(n_den1)
         self.bn_den2 = nn.BatchNorm1d(n_den2)
+        if molfp_mode == 'pool':                                          # models.py:90-92 (pool3 is built, never called)
+            self.pool1 = Diff_Pooling(f_last, f_last, self.pool_num)
+            self.pool3 = Diff_Pooling(f_last, f_last, 1)
         self._plan = None
 
     def graph_layers(self):
@@ -176,6 +184,8 @@ class EAGCN(nn.Module):
         return outs
 
     def plan(self):
+        if self.molfp_mode == 'pool':
+            raise ops.L.EagcnHipError("molfp_mode='pool' has no model-level plan: it runs layer by layer (forward_composed)")
         if self._plan is None:
             head = {n: getattr(self, n) for n in ('den1', 'den2', 'den3', 'Graph_BN', 'bn_den1', 'bn_den2')}
             self._plan = ops.ModelPlan(self.graph_layers(), head, self.n_afeat, self.molfp_mode, self.dropout)
@@ -315,7 +325,7 @@ class EAGCN(nn.Module):
         size) -> (x, atom_representations, graph_representation).  The whole forward is one call into
         eagcn_model_forward (layers, read-out and head); backward is one call into eagcn_model_backward."""
         *rels, size = rels_and_size
-        if self.structure == 'GAT':                                  # baseline: layer-level entry points + composed head
+        if self.structure == 'GAT' or self.molfp_mode == 'pool':     # layer-level entry points + composed head
             return self.forward_composed(adjs, afms, *rels, size)
         if self.structure == 'GCN':
             rels = rels[:1]                                          # Vanilla_GCN only needs the bond positions (= adj)
@@ -334,6 +344,10 @@ class EAGCN(nn.Module):
             bonds = bonds.first_view()
         if self.structure == 'GAT':
             index = ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, *bonds.checked(), bond_lists=True)
+            return self._forward_composed_index(index, ops._need_cuda_f32(afms, 'afms'), size)
+        if self.molfp_mode == 'pool':
+            self._check_channels(bonds.channels, bonds.rel_vectors)
+            index = ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, *bonds.checked(), rel_vectors=bonds.rel_vectors)
             return self._forward_composed_index(index, ops._need_cuda_f32(afms, 'afms'), size)
         if self.graph and (self.training and torch.is_grad_enabled() or not self.training and not torch.is_grad_enabled()):
             return self._graph_forward(None, afms, None, size, bonds)
@@ -398,7 +412,10 @@ class EAGCN(nn.Module):
     def _forward_composed_index(self, index, afms, size):
         x, pad_row, layout = self.forward_layers(index, afms)[-1]
         pad = pad_row if self.structure in ('Weighted_sum', 'GCN') else None
-        g = ops.readout(index, layout, x, pad, self.molfp_mode, size)      # models.py:108-111
+        if self.molfp_mode == 'pool':                                      # models.py:104-106
+            g = self.pool1.pooled_sum(index, layout, x, pad, self.graph_layers()[-1])
+        else:
+            g = ops.readout(index, layout, x, pad, self.molfp_mode, size)  # models.py:108-111
         g = self.Graph_BN(g)
         h = F.relu(self.bn_den1(self.den1(g)))
         h = F.dropout(h, p=self.dropout, training=self.training)

@@ -516,6 +516,133 @@ class _Readout(torch.autograd.Function):
         return None, None, None, None, dx, dpad
 
 
+# ------------------------------------------------------------------------------------------------
+# Diff_Pooling read-out (molfp_mode='pool'): csrc/pool.hip + the flat fp32 GEMM
+# ------------------------------------------------------------------------------------------------
+POOL_MODES = {'attention': 0, 'gcn': 1, 'gat': 2}
+
+
+class _PoolAttention(torch.autograd.Function):
+    """The attention matrix the last layer returns (layers.py:319-324 / 250-253 / 189) as packed rows [T][lda], with its
+    backward into ave_A.weight, the layer's self_r and the views' att.weight."""
+
+    @staticmethod
+    def forward(ctx, index, mode, ave_a, self_r, *att_w):
+        T, lda = max(index.T, 1), L.pad4(index.N)
+        dev = index.device
+        A = torch.empty((T, lda), dtype=torch.float32, device=dev)
+        rinv = torch.empty(T, dtype=torch.float32, device=dev)
+        padsum = torch.empty(T, dtype=torch.float32, device=dev)
+        p = L.PoolAtt()
+        p.mode = mode
+        p.K = len(att_w) if mode == 0 else index.K
+        if mode == 0:
+            ave_a, self_r = _need_cuda_f32(ave_a, 'ave_A.weight').contiguous(), _need_cuda_f32(self_r, 'self_r').contiguous()
+            att_w = [_need_cuda_f32(a, 'att.weight').contiguous() for a in att_w]
+            p.ave_a, p.self_r = ave_a.data_ptr(), self_r.data_ptr()
+            for k, a in enumerate(att_w):
+                p.att_w[k], p.att_c[k] = a.data_ptr(), a.numel()
+        L.check(L.load().eagcn_pool_attention_forward(index.ref(), C.byref(p), _ptr(A), lda, _ptr(rinv), _ptr(padsum),
+                                                      _stream()), 'eagcn_pool_attention_forward')
+        ctx.index, ctx.mode = index, mode
+        if mode == 0:
+            ctx.save_for_backward(A, rinv, ave_a, self_r, *att_w)
+        ctx.mark_non_differentiable(rinv, padsum)
+        return A, rinv, padsum
+
+    @staticmethod
+    def backward(ctx, dA, _drinv, _dpadsum):
+        if ctx.mode != 0:
+            return (None,) * 4
+        A, rinv, ave_a, self_r, *att_w = ctx.saved_tensors
+        index = ctx.index
+        lib = L.load()
+        p = L.PoolAtt()
+        p.mode, p.K = 0, len(att_w)
+        p.ave_a, p.self_r = ave_a.data_ptr(), self_r.data_ptr()
+        dave, dself = torch.empty_like(ave_a), torch.empty_like(self_r)
+        datt = [torch.empty_like(a) for a in att_w]
+        p.dave_a, p.dself_r = dave.data_ptr(), dself.data_ptr()
+        for k, a in enumerate(att_w):
+            p.att_w[k], p.att_c[k], p.datt_w[k] = a.data_ptr(), a.numel(), datt[k].data_ptr()
+        nbytes = lib.eagcn_pool_scratch_bytes()
+        scratch = _scratch(index.device, nbytes)
+        L.check(lib.eagcn_pool_attention_backward(index.ref(), C.byref(p), _ptr(A), A.shape[1], _ptr(rinv),
+                                                  _ptr(dA.contiguous()), scratch.data_ptr(), nbytes, _stream()),
+                'eagcn_pool_attention_backward')
+        return (None, None, dave, dself, *datt)
+
+
+class _PoolMix(torch.autograd.Function):
+    """AX = A . x over the stored rows (layers.py:39): [T][F] exact columns."""
+
+    @staticmethod
+    def forward(ctx, index, layout, A, padsum, x, pad_row):
+        F = layout.width
+        AX = torch.empty((max(index.T, 1), F), dtype=torch.float32, device=x.device)
+        L.check(L.load().eagcn_pool_mix_forward(index.ref(), C.byref(layout.c), _ptr(A), A.shape[1], _ptr(padsum), _ptr(x),
+                                                _ptr(pad_row), _ptr(AX), F, _stream()), 'eagcn_pool_mix_forward')
+        ctx.index, ctx.layout = index, layout
+        ctx.has_pad = pad_row is not None
+        ctx.save_for_backward(A, padsum, x, pad_row)
+        return AX
+
+    @staticmethod
+    def backward(ctx, dAX):
+        A, padsum, x, pad_row = ctx.saved_tensors
+        index, layout = ctx.index, ctx.layout
+        dAX = dAX.contiguous()
+        dA = torch.empty_like(A) if ctx.needs_input_grad[2] else None
+        dx = torch.zeros_like(x) if ctx.needs_input_grad[4] else None
+        dpad = torch.empty_like(pad_row) if ctx.has_pad and ctx.needs_input_grad[5] else None
+        L.check(L.load().eagcn_pool_mix_backward(index.ref(), C.byref(layout.c), _ptr(A), A.shape[1], _ptr(padsum), _ptr(x),
+                                                 _ptr(pad_row), _ptr(dAX), layout.width, _ptr(dA), _ptr(dx), _ptr(dpad),
+                                                 _stream()), 'eagcn_pool_mix_backward')
+        return None, None, dA, None, dx, dpad
+
+
+class _PoolReduce(torch.autograd.Function):
+    """Z [T][F+P] = (A.x).[Wf | Ws]  ->  g [B][F] = sum_p relu(S^T relu(Z[:, :F])), S = softmax(Z[:, F:])
+    (layers.py:499-503 and the sum over clusters of models.py:106)."""
+
+    @staticmethod
+    def forward(ctx, index, F, P, Z):
+        dev = Z.device
+        S = torch.empty((max(index.T, 1), P), dtype=torch.float32, device=dev)
+        Pm = torch.empty((index.B, P, F), dtype=torch.float32, device=dev)
+        g = torch.empty((index.B, F), dtype=torch.float32, device=dev)
+        L.check(L.load().eagcn_pool_reduce_forward(index.ref(), _ptr(Z), Z.shape[1], F, P, _ptr(S), _ptr(Pm), _ptr(g),
+                                                   _stream()), 'eagcn_pool_reduce_forward')
+        ctx.index, ctx.F, ctx.P = index, F, P
+        ctx.save_for_backward(Z, S, Pm)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        Z, S, Pm = ctx.saved_tensors
+        dZ = torch.empty_like(Z)
+        L.check(L.load().eagcn_pool_reduce_backward(ctx.index.ref(), _ptr(Z), Z.shape[1], ctx.F, ctx.P, _ptr(S), _ptr(Pm),
+                                                    _ptr(dg.contiguous()), _ptr(dZ), _stream()), 'eagcn_pool_reduce_backward')
+        return None, None, None, dZ
+
+
+def pool_readout(index, layout, x, pad_row, w_feature, w_assign, mode='attention', att_w=(), ave_a=None, self_r=None):
+    """models.py:104-106 for molfp_mode='pool': sum over the clusters of Diff_Pooling's pooled features.  `mode` names the
+    family of the last layer (its attention matrix is rebuilt from the batch index and the layer's parameters)."""
+    if layout.width != w_feature.shape[0] or w_assign.shape[0] != w_feature.shape[0]:
+        raise L.EagcnHipError('pool_readout: %d feature columns, weights [%d,..] / [%d,..]'
+                              % (layout.width, w_feature.shape[0], w_assign.shape[0]))
+    F, P = int(w_feature.shape[1]), int(w_assign.shape[1])
+    if not 1 <= P <= L.POOL_MAX:
+        raise L.EagcnHipError('pool_readout: %d clusters (1..%d)' % (P, L.POOL_MAX))
+    if index.T == 0:                                   # no atom in the whole batch: every pooled feature is relu(0)
+        return torch.zeros((index.B, F), dtype=torch.float32, device=x.device)
+    A, _rinv, padsum = _PoolAttention.apply(index, POOL_MODES[mode], ave_a, self_r, *att_w)
+    AX = _PoolMix.apply(index, layout, A, padsum, x, pad_row)
+    Z = dense_mm(AX, torch.cat([w_feature, w_assign], dim=1))          # one flat GEMM for both bases (layers.py:40)
+    return _PoolReduce.apply(index, F, P, Z)
+
+
 def readout(index, layout, x, pad_row, mode='sum', size=None):
     return _Readout.apply(index, layout, 1 if mode == 'ave' else 0, size, x, pad_row)
 

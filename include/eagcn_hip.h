@@ -20,6 +20,8 @@
  *   eagcn_layer_backward <- autograd of the above (the reference has no hand-written backward)
  *   eagcn_attention_dense<- the A_weight return value, layers.py:318 (stack of A1, layers.py:83)
  *   eagcn_readout_*      <- models.py:108-111 (sum / ave over atoms)
+ *   eagcn_pool_*         <- Diff_Pooling.forward layers.py:498-506 as used by models.py:104-106 (molfp_mode='pool'), with
+ *                           the last layer's A_weight of layers.py:319-324 (and its autograd backward)
  *   eagcn_gemm_f32       <- Dense.forward layers.py:382-387 (x @ W), used by models.py:114-120
  *   eagcn_bce_loss / eagcn_mse_loss
  *                        <- the loss of train.py:321-331 incl. weight_tensor utils.py:653-679
@@ -187,7 +189,7 @@ typedef struct eagcn_layer_grads {
 /* ---- library ------------------------------------------------------------------------------- */
 int eagcn_abi_version(void);
 size_t eagcn_struct_size(int which);   /* 0 batch, 1 layout, 2 layer_params, 3 layer_bufs, 4 layer_grads,
-                                          5 head_params, 6 head_grads, 7 model */
+                                          5 head_params, 6 head_grads, 7 model, 8 gat_params, 9 pool_att */
 const char* eagcn_last_error(void);
 int eagcn_pad16(int width);
 int eagcn_layer_out_ld(const eagcn_layer_params* p);   /* ld of xout                            */
@@ -230,6 +232,43 @@ int eagcn_gat_forward(const eagcn_batch* b, const eagcn_gat_params* p, const flo
 int eagcn_gat_backward(const eagcn_batch* b, const eagcn_gat_params* p, const float* x, const float* h, const float* s12,
                        const float* xout, const float* dxout, float* dx, float* dW, float* da, void* scratch,
                        size_t scratch_bytes, void* stream);
+
+/* ---- Diff_Pooling read-out, molfp_mode='pool' (layers.py:492-506, models.py:90-92, 104-106) ------------------------------------
+   g[b] = sum_p relu(S^T . relu((A.x).Wf)),  S = softmax((A.x).Ws), A = the attention matrix the LAST layer returns.
+   The call sequence of one forward: eagcn_pool_attention_forward (A as packed rows [T][lda], lda >= N; rinv [T] = 1 / row sum;
+   padsum [T] = total weight of the non-stored columns) -> eagcn_pool_mix_forward (AX [T][F] = A.x, exact columns) ->
+   eagcn_gemm_f32 (Z [T][ldz] = AX . [Wf | Ws], F + P columns) -> eagcn_pool_reduce_forward (S [T][P], Pm [B][P][F], g [B][F]).
+   Backward: the same entry points mirrored (reduce -> two GEMMs -> mix -> attention).  The pooled adjacency S^T.A.S that
+   layers.py:504 also returns is never read by models.py and is not computed.                                             */
+#define EAGCN_POOL_MAX 8                    /* clusters P (pool_num, models.py:25: 5)                                        */
+typedef struct eagcn_pool_att {
+    int32_t K;                              /* views of the layer that produced A (1 for the baselines)                      */
+    int32_t mode;                           /* 0: edge-attention layer with last=True (layers.py:319-324)
+                                               1: Vanilla_GCN (layers.py:250-253)   2: GAT (layers.py:189: adj + mask*I)     */
+    int32_t att_c[EAGCN_MAX_VIEWS];         /* entries of att_w[k] / datt_w[k]                                               */
+    const float* att_w[EAGCN_MAX_VIEWS];    /* mode 0: blockK.att.weight                                                     */
+    const float* ave_a;                     /* mode 0: [K] ave_A.weight                                                      */
+    const float* self_r;                    /* mode 0: [1] the LAYER's self_r (layers.py:287)                                */
+    float* datt_w[EAGCN_MAX_VIEWS];         /* backward outputs (mode 0); NULL entries are skipped                           */
+    float* dave_a;
+    float* dself_r;
+} eagcn_pool_att;
+size_t eagcn_pool_scratch_bytes(void);
+int eagcn_pool_attention_forward(const eagcn_batch* b, const eagcn_pool_att* p, float* A, int lda, float* rinv, float* padsum,
+                                 void* stream);
+int eagcn_pool_attention_backward(const eagcn_batch* b, const eagcn_pool_att* p, const float* A, int lda, const float* rinv,
+                                  const float* dA, void* scratch, size_t scratch_bytes, void* stream);
+/* x: packed activations [T][ld(lay)] of the last layer, pad_row [ld] (or NULL = 0): the value of every non-stored row */
+int eagcn_pool_mix_forward(const eagcn_batch* b, const eagcn_layout* lay, const float* A, int lda, const float* padsum,
+                           const float* x, const float* pad_row, float* AX, int F, void* stream);
+/* dA [T][lda], dx [T][ld] (ZERO-FILLED by the caller: only exact columns are written), dpad_row [ld]; each may be NULL */
+int eagcn_pool_mix_backward(const eagcn_batch* b, const eagcn_layout* lay, const float* A, int lda, const float* padsum,
+                            const float* x, const float* pad_row, const float* dAX, int F, float* dA, float* dx,
+                            float* dpad_row, void* stream);
+int eagcn_pool_reduce_forward(const eagcn_batch* b, const float* Z, int ldz, int F, int P, float* S, float* Pm, float* g,
+                              void* stream);
+int eagcn_pool_reduce_backward(const eagcn_batch* b, const float* Z, int ldz, int F, int P, const float* S, const float* Pm,
+                               const float* dg, float* dZ, void* stream);
 
 /* Device half of the reference's collate (utils.py:504-640: every molecule zero-padded to the batch maximum): per-molecule
    atom-feature rows, concatenated [sum n_b][F] with molecule b = rows mol_offset[b] .. mol_offset[b+1], -> padded [B][N][F].

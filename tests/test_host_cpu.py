@@ -39,7 +39,7 @@ def test_ctypes_structs_match_c_layout():
     from eagcn_amd import _lib
     lib = _lib.load()
     for which, cls in enumerate((_lib.Batch, _lib.Layout, _lib.LayerParams, _lib.LayerBufs, _lib.LayerGrads,
-                                 _lib.HeadParams, _lib.HeadGrads, _lib.Model)):
+                                 _lib.HeadParams, _lib.HeadGrads, _lib.Model, _lib.GatParams, _lib.PoolAtt)):
         assert lib.eagcn_struct_size(which) == C.sizeof(cls), cls.__name__
 
 
@@ -55,7 +55,7 @@ def test_argument_errors_are_reported_not_crashed():
         _lib.check(rc, 'eagcn_index_build')
 
 
-@pytest.mark.parametrize('name', [n for n in golden_cases('model') if n in ('model_concate_train', 'model_weighted_train')])
+@pytest.mark.parametrize('name', [n for n in golden_cases('model') if n in ('model_concate_train', 'model_weighted_train', 'model_concate_pool_train')])
 def test_module_tree_equals_reference_state_dict(name):
     from eagcn_amd import EAGCN
     g = Golden(name)
@@ -65,7 +65,7 @@ def test_module_tree_equals_reference_state_dict(name):
     sd = g.state_dict()
     model.load_state_dict(sd, strict=True)
     assert list(model.state_dict().keys()) == list(sd.keys())        # same keys, same order
-    assert len(sd) == 246 if m['structure'] == 'Concate' else len(sd) > 246
+    assert len(sd) == 246 + (4 if m['molfp'] == 'pool' else 0) if m['structure'] == 'Concate' else len(sd) > 246
     # attribute walk of check_model.py:48-58
     assert model.layer1.block1.att.weight.shape == (1, m['n_bfeat'], 1, 1)
     assert model.layer4.block5.batch_norm.bn.running_mean.shape[0] == model.layer4.widths[4]
