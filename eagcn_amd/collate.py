@@ -62,6 +62,44 @@ def compact_host(batch, general=False):
             'channels': channels, 'rel_vectors': rel_vectors if general else None}
 
 
+def bonds_from_dense(adjs, rels, general=True):
+    """The reference's padded DEVICE tensors (adjs [B,N,N] in {0,1}, rels[k] [B,C_k,N,N]) -> CompactBonds, for relation tensors
+    with arbitrary channel values (layers.py:82): the distinct channel vectors at the bonds become the code book of each view
+    (lexicographically sorted, at most 255), exactly as ``compact_host(general=True)`` builds them from per-molecule tuples.
+    Input canonicalisation with tensor ops (nonzero / gather / unique; one host sync for the sizes); the compute stays on the
+    kernels behind ``EAGCN.forward_compact``.  general=False: one-hot channels, code = channel index."""
+    if not bool(((adjs == 0) | (adjs == 1)).all()):
+        raise L.EagcnHipError('adjacency entries must be 0 or 1')
+    B, N, _ = adjs.shape
+    nz = (adjs != 0).nonzero()                                        # [E,3], row-major: the order of np.nonzero per molecule
+    bm, bi, bj = nz[:, 0], nz[:, 1], nz[:, 2]
+    E = int(nz.shape[0])
+    codes = torch.zeros((E, len(rels)), dtype=torch.uint8, device=adjs.device)
+    channels, tables = [], []
+    for k, r in enumerate(rels):
+        v = r.to(torch.float32)[bm, :, bi, bj]                        # [E, C_k]
+        if general:
+            if E:
+                table, inv = torch.unique(v, dim=0, return_inverse=True)
+            else:
+                table, inv = torch.zeros((1, r.shape[1]), dtype=torch.float32, device=adjs.device), None
+            if table.shape[0] > 255:
+                raise ValueError('view %d: %d distinct relation vectors at the bonds of this batch (at most 255)'
+                                 % (k, table.shape[0]))
+            if E:
+                codes[:, k] = inv.reshape(-1).to(torch.uint8)
+            channels.append(int(table.shape[0]))
+            tables.append(table.contiguous())
+        else:
+            if E and not bool((((v == 1).sum(1) == 1) & ((v != 0).sum(1) == 1)).all()):
+                raise ValueError('view %d: relation channels are not one-hot at the bonds (use general=True)' % k)
+            if E:
+                codes[:, k] = v.argmax(1).to(torch.uint8)
+            channels.append(int(r.shape[1]))
+    return CompactBonds(B, N, channels, bm.to(torch.int32).contiguous(), bi.to(torch.int32).contiguous(),
+                        bj.to(torch.int32).contiguous(), codes, tables if general else None)
+
+
 def pad_rows(rows, offsets, B, N):
     """Device half of the padding: rows [sum n, F] + offsets [B+1] (device tensors) -> [B, N, F]."""
     if not rows.is_cuda:

@@ -84,9 +84,12 @@ class EAGCN(nn.Module):
                  n_den1=128, n_den2=64, nclass=1, dropout=0.0, structure='Concate', molfp_mode='sum',
                  pool_num=5, *, n_layers=4, widths1=None, widths2=None, rel_channels=None, atom_rep='lazy',
                  grad_mode='autograd', overlap_index=False, graph=False, row_cap=None, graph_outputs='copy',
-                 validate='sync', max_runners=8, edge_cap=None, n_bucket=0):
+                 validate='sync', max_runners=8, edge_cap=None, n_bucket=0, relations='onehot'):
         super().__init__()
         self.n_bucket = int(n_bucket)
+        if relations not in ('onehot', 'general'):
+            raise ValueError("relations must be 'onehot' (neural_fp.py:111-120) or 'general' (any channel values, layers.py:82)")
+        self.relations = relations
         if widths1 is None:
             widths1 = [n_sgc1_1, n_sgc1_2, n_sgc1_3, n_sgc1_4, n_sgc1_5]
         if widths2 is None:
@@ -325,6 +328,12 @@ class EAGCN(nn.Module):
         size) -> (x, atom_representations, graph_representation).  The whole forward is one call into
         eagcn_model_forward (layers, read-out and head); backward is one call into eagcn_model_backward."""
         *rels, size = rels_and_size
+        if self.relations == 'general' and self.structure in ('Concate', 'Weighted_sum'):
+            # relation tensors with arbitrary channel values (layers.py:82): code books from the distinct channel vectors at
+            # the bonds, then the compact path (the dense tensors are read once, by the canonicalisation)
+            from .collate import bonds_from_dense
+            adjs = ops._need_cuda_f32(adjs, 'adjs')
+            return self.forward_compact(bonds_from_dense(adjs, rels), afms, size)
         if self.structure == 'GAT' or self.molfp_mode == 'pool':     # layer-level entry points + composed head
             return self.forward_composed(adjs, afms, *rels, size)
         if self.structure == 'GCN':

@@ -187,7 +187,8 @@ class BatchIndex:
                                   'adjacency (reference neural_fp.py:85,109-110)' % meta[L.META_BAD_ADJ])
         if meta[L.META_BAD_REL]:
             raise L.EagcnHipError('%d bonded (i,j,view) positions are not one-hot over the relation channels '
-                                  '(reference neural_fp.py:111-120)' % meta[L.META_BAD_REL])
+                                  '(reference neural_fp.py:111-120); build the model with relations=\'general\' for relation '
+                                  'tensors with arbitrary channel values (layers.py:82)' % meta[L.META_BAD_REL])
         self.T, self.n_max, self.n_tiles = meta[L.META_T], meta[L.META_NMAX], meta[L.META_NTILES]
         self.n_edges = meta[L.META_NEDGE]
         self.rows = self.T                                   # exact packed row count

@@ -82,3 +82,26 @@ def test_general_collate_code_book_reconstructs_the_relation_tensors():
             assert np.array_equal(dense[b, :, :n, :n], m[2 + k]), (b, k)
     with pytest.raises(ValueError, match='general=True'):
         compact_host(gen)
+
+
+def test_bonds_from_dense_equals_compact_host_for_general_relations():
+    """The dense-signature canonicalisation (EAGCN(relations='general').forward) builds the same bond list, codes and code
+    books from the reference's padded tensors as compact_host(general=True) builds from the per-molecule tuples."""
+    import torch
+    from eagcn_amd.collate import bonds_from_dense, compact_host
+    from test_gpu_general_relations import _general_molecules
+    channels = (6, 4, 3, 2, 2)
+    mb, dense, mols = _general_molecules(17, 9, channels)
+    h = compact_host(mols, general=True)
+    b = bonds_from_dense(dense[0], dense[2:], general=True)
+    assert (b.bond_mol.numpy() == h['bond_mol']).all() and (b.bond_i.numpy() == h['bond_i']).all()
+    assert (b.bond_j.numpy() == h['bond_j']).all()
+    assert b.channels == h['channels']
+    assert (b.bond_code.numpy() == h['bond_code']).all()
+    for t, ref in zip(b.rel_vectors, h['rel_vectors']):
+        assert (t.numpy() == ref).all()
+    onehot = mb.dense()
+    c = bonds_from_dense(onehot[0], onehot[2:-1], general=False)
+    assert c.rel_vectors is None and c.channels == list(channels)
+    with pytest.raises(ValueError, match='general=True'):
+        bonds_from_dense(dense[0], dense[2:], general=False)

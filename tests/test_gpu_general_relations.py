@@ -84,7 +84,20 @@ def test_general_relation_tensors_vs_oracle(structure, graph):
     for k, p in ref.named_parameters():
         if p.grad is not None:
             assert_grad_close(got[k].grad.cpu(), p.grad.numpy(), scale, k, rtol=2e-5, floor=2e-6)
-    # one-hot batches through the dense signature are refused loudly, with the way out
+    # the same batch through the reference's DENSE signature: relations='general' builds the code books from the padded tensors
+    mg = EAGCN(6, 24, widths1=w1, widths2=w2, n_den1=16, n_den2=8, nclass=2, dropout=0.0, structure=structure, n_layers=2,
+               rel_channels=list(channels), graph=graph, relations='general')
+    mg.load_state_dict(sd0, strict=True)
+    mg = mg.to(dev).train()
+    out2, _, gr2 = mg(*[t.to(dev) for t in dense], size.to(dev))
+    torch.nn.functional.mse_loss(out2.view(-1), labels_c.view(-1)).backward()
+    assert rel_err(out2.detach().cpu(), out_r.detach(), 'out, dense signature (%s)' % structure) < 1e-5
+    assert rel_err(gr2.detach().cpu(), gr_r.detach(), 'graph_rep, dense signature') < 1e-5
+    got2 = dict(mg.named_parameters())
+    for k, p in ref.named_parameters():
+        if p.grad is not None:
+            assert_grad_close(got2[k].grad.cpu(), p.grad.numpy(), scale, k + ' (dense signature)', rtol=2e-5, floor=2e-6)
+    # non one-hot batches through the dense signature of a default model are refused loudly, with the way out
     with pytest.raises(Exception, match='one-hot'):
         m(*[t.to(dev) for t in dense], size.to(dev))
     with pytest.raises(ValueError, match='general=True'):
