@@ -241,40 +241,56 @@ __device__ __forceinline__ void g3_segment(const G2Prob& p, const DwScatter& sc,
                 }
             }
     } else {
+        const int col = n0 + 4 * li;                                   // tile j holds the columns 4 c + j: one float4
+        // dW of a layer (SCATTER): row = packed input column, col = packed output column -> blockK.graph_conv.weight.grad.
+        // This runs at the very end of a tile's serial import chain, so it is kept short: the column side (view, width,
+        // target) is resolved once per lane, the row side is the identity whenever the input layout has no padded
+        // columns (DwScatter::in_identity: widths that are multiples of 16, every hidden layer of the stated configs),
+        // and a lane's four results leave as ONE 16-byte store when the view's width allows it.
+        int off_k = 0, wk = 0, f = 0;
+        float* dwk = nullptr;
+        bool vec = false;
+        if constexpr (SCATTER) {
+            int k = 0;
+#pragma unroll
+            for (int vv = 1; vv < EAGCN_MAX_VIEWS; ++vv) k += (vv < sc.vc.K && col >= sc.vc.off[vv]) ? 1 : 0;
+#pragma unroll
+            for (int vv = 0; vv < EAGCN_MAX_VIEWS; ++vv)
+                if (vv == k) { off_k = sc.vc.off[vv]; wk = sc.vc.width[vv]; dwk = sc.dW[vv]; }
+            f = col - off_k;
+            vec = (wk & 3) == 0 && f + 3 < wk && (reinterpret_cast<uintptr_t>(dwk) & 15) == 0;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + 4 * (4 * q + r) + i;              // tile i holds the rows 4 rho + i
-                const int col = n0 + 4 * li;                           // tile j holds the columns 4 c + j: one float4
                 if (row >= Mx || col >= p.N) continue;                 // (N is a multiple of 4)
                 const f32x4 v = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
                 if constexpr (SCATTER) {
-                    // dW of a layer: row = packed input column, col = packed output column -> blockK.graph_conv.weight.grad
-                    int k = 0;
+                    int fi = row;
+                    if (!sc.in_identity) {
+                        int eo = 0, po = 0;
+                        bool done = false;
+                        fi = -1;
 #pragma unroll
-                    for (int vv = 1; vv < EAGCN_MAX_VIEWS; ++vv) k += (vv < sc.vc.K && col >= sc.vc.off[vv]) ? 1 : 0;
-                    int off_k = 0, wk = 0;
-                    float* dwk = nullptr;
-#pragma unroll
-                    for (int vv = 0; vv < EAGCN_MAX_VIEWS; ++vv)
-                        if (vv == k) { off_k = sc.vc.off[vv]; wk = sc.vc.width[vv]; dwk = sc.dW[vv]; }
-                    const int f = col - off_k;
-                    int eo = 0, po = 0, fi = -1;
-                    bool done = false;
-#pragma unroll
-                    for (int sg = 0; sg < EAGCN_MAX_SEGS; ++sg) {
-                        if (sg < sc.in.nseg && !done) {
-                            if (row < po + sc.in.p[sg]) { fi = (row - po < sc.in.w[sg]) ? eo + (row - po) : -1; done = true; }
-                            eo += sc.in.w[sg];
-                            po += sc.in.p[sg];
+                        for (int sg = 0; sg < EAGCN_MAX_SEGS; ++sg) {
+                            if (sg < sc.in.nseg && !done) {
+                                if (row < po + sc.in.p[sg]) { fi = (row - po < sc.in.w[sg]) ? eo + (row - po) : -1; done = true; }
+                                eo += sc.in.w[sg];
+                                po += sc.in.p[sg];
+                            }
                         }
                     }
-                    if (fi >= 0) {
+                    if (fi >= 0 && f < wk) {
                         float* d = dwk + (size_t)fi * wk + f;
+                        if (vec) {
+                            *reinterpret_cast<f32x4*>(d) = v;
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (f + e < wk) d[e] = v[e];
+                            for (int e = 0; e < 4; ++e)
+                                if (f + e < wk) d[e] = v[e];
+                        }
                     }
                 } else {
                     *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
@@ -407,6 +423,8 @@ int launch_gemm3(const GemmDesc& g, const DwScatter* sc0, void* workspace, size_
     if (rc) return rc;
     DwScatter sc;
     if (sc0) sc = *sc0; else memset(&sc, 0, sizeof(sc));
+    sc.in_identity = 1;
+    for (int i = 0; i < sc.in.nseg; ++i) sc.in_identity &= sc.in.w[i] == sc.in.p[i] ? 1 : 0;
     const G2Prob p = g3_prob(g);
     const int G = gemm3_grid();
     ProfScope ps(g.prof_tag, s, g.work > 0.0 ? g.work : 2.0 * g.M * g.N * g.K);
@@ -425,6 +443,8 @@ int launch_gemm3_pair(const GemmDesc& dx, const GemmDesc& dw, const DwScatter* s
     if (rc) return rc;
     DwScatter sc;
     if (sc0) sc = *sc0; else memset(&sc, 0, sizeof(sc));
+    sc.in_identity = 1;
+    for (int i = 0; i < sc.in.nseg; ++i) sc.in_identity &= sc.in.w[i] == sc.in.p[i] ? 1 : 0;
     const int G = gemm3_grid();
     const double w0 = dx.work > 0.0 ? dx.work : 2.0 * dx.M * dx.N * dx.K;
     const double w1 = dw.work > 0.0 ? dw.work : 2.0 * dw.M * dw.N * dw.K;

@@ -93,6 +93,7 @@ struct DwScatter {               // epilogue of a layer's dW product: packed (in
     float* dW[EAGCN_MAX_VIEWS];
     ViewCols vc;
     ColMapD in;
+    int in_identity;             // the input layout has no padded columns: packed row == exact row (set by the launchers)
 };
 size_t gemm3_workspace_bytes();
 // the hand-off flags must be zero when a launch starts; every launch leaves them zero again, so ONE clear at the start of

@@ -135,8 +135,7 @@ class GraphRunner:
         self.scale_static = torch.ones((), **f32)
         n = plan.offsets[-1]
         self.flat_acc = torch.zeros(n, **f32)               # the captured backward writes here; p.grad are views of it
-        pieces = self.flat_acc.split(plan.sizes)
-        self.acc_views = [p if len(sh) == 1 else p.view(sh) for p, sh in zip(pieces, plan.shapes)]
+        self.acc_views = plan.grad_views(self.flat_acc)
         self._grads_struct()
         xo, po, ld = C.c_size_t(), C.c_size_t(), C.c_int()
         lib.eagcn_model_atom_rep(self.index.ref(), C.byref(m), C.byref(xo), C.byref(po), C.byref(ld))
@@ -413,12 +412,12 @@ class GraphRunner:
             for p, v in zip(params, views):
                 p.grad = v
             return
-        kept = keep.split(self.plan.sizes) if keep is not None else None
+        kept = self.plan.grad_views(keep) if keep is not None else None
         for i, (p, g, v) in enumerate(zip(params, grads, views)):
             if g is None:
                 p.grad = v
             elif g is v:
-                v.add_(kept[i] if v.dim() == 1 else kept[i].view(v.shape))
+                v.add_(kept[i])
             else:
                 g.add_(v)                                     # a gradient tensor of the caller's: accumulate into it
 

@@ -751,9 +751,12 @@ class ModelPlan:
                             h['bn_den2'].weight, h['bn_den2'].bias])
         self.sizes = [p.numel() for p in self.params]
         self.shapes = [tuple(p.shape) for p in self.params]
+        # every parameter's gradient starts on a 16-byte boundary of the flat buffer (a 1-element self_r in front of a weight
+        # matrix would otherwise leave the matrix 4-byte aligned: the GEMM epilogue that writes blockK.graph_conv.weight.grad
+        # uses 16-byte stores).  The few padding words stay zero.
         self.offsets = [0]
         for n in self.sizes:
-            self.offsets.append(self.offsets[-1] + n)
+            self.offsets.append(self.offsets[-1] + L.pad4(n))
         self.trigger = None
         self.flat_grad = None
         self._cm_cache = {}
@@ -767,6 +770,11 @@ class ModelPlan:
                    [h['Graph_BN'].num_batches_tracked, h['bn_den1'].num_batches_tracked,
                     h['bn_den2'].num_batches_tracked]
         self.nbt_pending = 0          # graph mode counts batches on the host (see flush_nbt)
+
+    def grad_views(self, flat):
+        """Per-parameter views (parameter shapes) of a flat gradient buffer laid out by `offsets`."""
+        return [flat[o:o + n] if len(sh) == 1 else flat[o:o + n].view(sh)
+                for o, n, sh in zip(self.offsets, self.sizes, self.shapes)]
 
     def flush_nbt(self):
         """Write the batches counted on the host by graph mode into the num_batches_tracked buffers (they are not
@@ -875,7 +883,7 @@ class _ModelFn(torch.autograd.Function):
         dev = saved.device
         dout = dout.contiguous()
         dgr = dgraph_rep.contiguous() if dgraph_rep is not None else None
-        flat = torch.empty(plan.offsets[-1], dtype=torch.float32, device=dev)
+        flat = torch.zeros(plan.offsets[-1], dtype=torch.float32, device=dev)
         base = flat.data_ptr()
 
         def gptr(i):
@@ -898,8 +906,7 @@ class _ModelFn(torch.autograd.Function):
                                          _ptr(saved), saved.numel(), _ptr(scratch), scratch.numel(), _ptr(dout),
                                          _ptr(dgr), lg, C.byref(hg), _stream()), 'eagcn_model_backward')
         ctx.saved_blob = None
-        pieces = flat.split(plan.sizes)
-        grads = [p if len(sh) == 1 else p.view(sh) for p, sh in zip(pieces, plan.shapes)]
+        grads = plan.grad_views(flat)
         if ctx.direct:
             # gradients are delivered straight into .grad as views of ONE flat buffer (accumulating if a
             # gradient is already there), bypassing ~70 AccumulateGrad nodes

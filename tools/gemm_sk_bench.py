@@ -85,6 +85,23 @@ if CHECK:
     e2 = err(dw, x.double().t() @ dp.double())
 us = timeit(pair)
 res.append('pair err %.1e/%.1e %7.1f us %6.1f TF' % (e1, e2, us, 4.0 * T * FIN * FP / us / 1e6))
+# the same launch with COLD caches (a 768 MB read-modify-write between the calls evicts L2 and the 256 MB MALL), and with
+# a small kernel stream in front of it as in a training step (launch right behind other work instead of back to back)
+big = torch.zeros(192 << 20, device='cuda')
+small = torch.zeros(1 << 16, device='cuda')
+for label, pre in (('cold', lambda: big.add_(1.0)), ('behind small kernels', lambda: [small.add_(1.0) for _ in range(4)])):
+    ts = []
+    for it in range(12):
+        pre()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        pair()
+        eb.record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            ts.append(ea.elapsed_time(eb) * 1e3)
+    ts.sort()
+    res.append('pair %s: median %.1f us (min %.1f)' % (label, ts[len(ts) // 2], ts[0]))
 # ragged / tiny shapes (correctness only): K tail of 8, M not a multiple of 64, N = 400, fewer iterations than workgroups
 if CHECK:
     bad = []
