@@ -137,6 +137,22 @@ __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_
     return rng_u32(seed, idx) >= thr ? inv_keep : 0.0f;
 }
 
+// Dropout of the STORED rows of a graph-conv layer (element index r * Fp + column): one 64-bit hash serves two adjacent
+// elements -- the even index takes its low 32 bits, the odd one the high 32 bits -- so that the backward pass, which
+// regenerates the mask instead of reading it, pays two hashes per float4 (it was bound by the integer multiplies of four).
+__device__ __forceinline__ float drop_scale_el(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
+    const uint64_t z = rng_u64(seed, idx >> 1);
+    return ((idx & 1) ? (uint32_t)(z >> 32) : (uint32_t)z) >= thr ? inv_keep : 0.0f;
+}
+// four adjacent elements starting at an index that is a multiple of 4
+__device__ __forceinline__ void drop_scale4(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep, float (&out)[4]) {
+    const uint64_t z0 = rng_u64(seed, idx >> 1), z1 = rng_u64(seed, (idx >> 1) + 1);
+    out[0] = (uint32_t)z0 >= thr ? inv_keep : 0.0f;
+    out[1] = (uint32_t)(z0 >> 32) >= thr ? inv_keep : 0.0f;
+    out[2] = (uint32_t)z1 >= thr ? inv_keep : 0.0f;
+    out[3] = (uint32_t)(z1 >> 32) >= thr ? inv_keep : 0.0f;
+}
+
 // ---- actual extents live in device memory ----------------------------------------------------------
 // eagcn_batch.T / .n_tiles are CAPACITIES (buffer strides, grid sizing); the actual packed row count
 // and tile count are read from meta[] on the device, so no launch depends on a host read-back.

@@ -237,11 +237,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
             o.z = fmaxf(y.z * sc.z + sh.z, 0.0f) * m;
             o.w = fmaxf(y.w * sc.w + sh.w, 0.0f) * m;
             if (a.do_drop) {
-                const uint64_t idx = (uint64_t)r * fp + c;
-                o.x *= drop_scale(seed, idx + 0, a.thr, a.inv_keep);
-                o.y *= drop_scale(seed, idx + 1, a.thr, a.inv_keep);
-                o.z *= drop_scale(seed, idx + 2, a.thr, a.inv_keep);
-                o.w *= drop_scale(seed, idx + 3, a.thr, a.inv_keep);
+                float ds[4];
+                drop_scale4(seed, (uint64_t)r * fp + c, a.thr, a.inv_keep, ds);
+                o.x *= ds[0]; o.y *= ds[1]; o.z *= ds[2]; o.w *= ds[3];
             }
             *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + c) = o;
         }
@@ -253,7 +251,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
             for (int k = 0; k < a.vc.K; ++k) {
                 const int cp = a.vc.off[k] + f;
                 float p = fmaxf(a.Y[(size_t)r * a.ldy + cp] * a.bn[BN_SC * fp + cp] + a.bn[BN_SH * fp + cp], 0.0f);
-                if (a.do_drop) p *= drop_scale(seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
+                if (a.do_drop) p *= drop_scale_el(seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
                 acc += a.colp[CP_AVEW * fp + cp] * p;
             }
             a.out[e] = acc;
@@ -263,7 +261,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
 
 // ---- BatchNorm backward ----------------------------------------------------------------------------
 struct BwdArgs {
-    eagcn_batch bt;
+    const int32_t* meta; int Tcap;       // (only what the kernel reads of the batch index: the argument block stays in SGPRs)
+    const int32_t* row_mol;
+    const float* row_m;
     ViewCols vc;
     int structure, fp, nvirt;
     const float* dxout; int ldo;
@@ -284,11 +284,15 @@ struct BwdArgs {
 // and operand) and has all BWD_ROWS rows in flight at once: a single batch of independent 16-byte loads
 // instead of a column loop of scalar ones.  View column ranges are multiples of 16, so the four columns share
 // their view.
+// Compile-time variants (structure, per-molecule upstream gradient, dropout): the general kernel carried every path at once
+// -- 7.7 k instructions, scalar registers spilled to vector lanes, a few hundred exec-mask branches -- and was bound by
+// that, not by memory.
 constexpr int BWD_ROWS = 7;
+template <bool WEIGHTED, bool DG, bool DROP>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     __shared__ double da_s[EAGCN_MAX_VIEWS];
-    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
-    const int fp = a.fp, T = dev_rows(a.bt);
+    const uint64_t seed = DROP ? (a.seed_dev ? *a.seed_dev : a.seed) : 0ull;
+    const int fp = a.fp, T = min(a.meta[EAGCN_META_T], a.Tcap);
     const int rows = T + a.nvirt;
     // the grid is sized for the row CAPACITY: only the first ceil(rows / BWD_ROWS) workgroups work (and write a
     // slab); bn_bwd_finalize derives the same count from the device-side row count
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     if ((int)blockIdx.x >= nwg) return;
     if (threadIdx.x < EAGCN_MAX_VIEWS) da_s[threadIdx.x] = 0.0;
     __syncthreads();
-    const bool weighted = a.structure == EAGCN_STRUCT_WEIGHTED;
+    constexpr bool weighted = WEIGHTED;
     double da[EAGCN_MAX_VIEWS];
 #pragma unroll
     for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) da[k] = 0.0;
@@ -328,11 +332,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
             }
             return res;
         };
-        int ce0 = -1;
+        int ce0 = -1, ce1 = -1, ce2 = -1, ce3 = -1;                // exact columns of the four packed columns: once per thread
         bool ce4 = false;
-        if (a.rg.dg) {
-            ce0 = exact(cu);
-            ce4 = ce0 >= 0 && exact(cu + 3) == ce0 + 3 && (ce0 & 3) == 0 && (a.rg.F & 3) == 0 &&
+        if constexpr (DG) {
+            ce0 = exact(cu); ce1 = exact(cu + 1); ce2 = exact(cu + 2); ce3 = exact(cu + 3);
+            ce4 = ce0 >= 0 && ce3 == ce0 + 3 && (ce0 & 3) == 0 && (a.rg.F & 3) == 0 &&
                   (reinterpret_cast<uintptr_t>(a.rg.dg) & 15) == 0;
         }
         double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, dak = 0.0;
@@ -345,18 +349,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
                 upv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < T) {
                     yv[u] = *reinterpret_cast<const float4*>(a.Y + (size_t)r * a.ldy + cp);
-                    if (a.rg.dg) {
-                        const int mol = a.bt.row_mol[r];
+                    if constexpr (DG) {
+                        const int mol = a.row_mol[r];
                         const float* g = a.rg.dg + (size_t)mol * a.rg.F;
                         float4 v;
                         if (ce4) {
                             v = *reinterpret_cast<const float4*>(g + ce0);
                         } else {
-                            const int e1 = exact(cu + 1), e2 = exact(cu + 2), e3 = exact(cu + 3);
                             v.x = ce0 >= 0 ? g[ce0] : 0.0f;
-                            v.y = e1 >= 0 ? g[e1] : 0.0f;
-                            v.z = e2 >= 0 ? g[e2] : 0.0f;
-                            v.w = e3 >= 0 ? g[e3] : 0.0f;
+                            v.y = ce1 >= 0 ? g[ce1] : 0.0f;
+                            v.z = ce2 >= 0 ? g[ce2] : 0.0f;
+                            v.w = ce3 >= 0 ? g[ce3] : 0.0f;
                         }
                         if (a.rg.mode == 1) {
                             const float is = 1.0f / (float)a.rg.size[mol];
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
                         upv[u] = *reinterpret_cast<const float4*>(a.dxout + (size_t)r * a.ldo + cu);
                     }
                     if (!weighted) {
-                        const float m = a.bt.row_m[r];
+                        const float m = a.row_m[r];
                         upv[u].x *= m; upv[u].y *= m; upv[u].z *= m; upv[u].w *= m;
                     }
                 } else if (r < rows) {                 // the one virtual row standing for all non-stored rows
@@ -383,11 +386,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
                 const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
                 const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, ivv[4] = {iv.x, iv.y, iv.z, iv.w};
                 const float awv[4] = {aw.x, aw.y, aw.z, aw.w};
-                float dh[4];
+                float dh[4], dsv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+                if (DROP && r < T) drop_scale4(seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep, dsv);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float up = uu[j];
-                    const float ds = (a.do_drop && r < T) ? drop_scale(seed, (uint64_t)r * fp + cp + j, a.thr, a.inv_keep) : 1.0f;
+                    const float ds = dsv[j];
                     const float h = yy[j] * scv[j] + shv[j];
                     if (weighted) { dak += (double)(up * ds * fmaxf(h, 0.0f)); up *= awv[j]; }
                     dh[j] = h > 0.0f ? up * ds : 0.0f;
@@ -588,8 +592,10 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
         d.snsplit = sagg_nsplit(b, fmax);
         d.sslabs = sagg_grid_x(b) * d.snsplit;           // partial slabs of the bond-list aggregation (sagg.hip)
     }
-    // row-partial slabs of the BatchNorm backward: 8 rows per workgroup, at most 2048 workgroups and at most
-    // 32 MB of fp64 partials (wide layers: Fp = 6320 -> 331 workgroups)
+    // row-partial slabs of the BatchNorm backward: 7 rows per workgroup, at most 2048 workgroups and at most
+    // 32 MB of fp64 partials (wide layers: Fp = 6320 -> 331 workgroups).  Fewer, longer workgroups were measured
+    // slower (the kernel is bound by its instruction stream and one memory round trip per 7-row batch, not by the
+    // partial slabs: cap 512 -> +4 us, 192 -> +22 us at the Tox21 shape)
     {
         const long by_rows = cdiv(b->T + 1, BWD_ROWS);
         const long by_bytes = std::max<long>(64, (32L << 20) / ((long)d.fp * 16));
@@ -905,7 +911,8 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     const double gemm_work = 2.0 * (double)b->T * (double)d.fin * fsum;
 
     BwdArgs ba;
-    ba.bt = *b; ba.vc = d.vc; ba.structure = p->structure; ba.fp = d.fp;
+    ba.meta = b->meta; ba.Tcap = b->T; ba.row_mol = b->row_mol; ba.row_m = b->row_m;
+    ba.vc = d.vc; ba.structure = p->structure; ba.fp = d.fp;
     ba.nvirt = (dpad_row && p->structure == EAGCN_STRUCT_WEIGHTED) ? 1 : 0;
     ba.dxout = dxout; ba.ldo = d.ldo; ba.dpad = dpad_row; ba.dpad_views = dpad_views ? 1 : 0;
     if (rg) ba.rg = *rg; else memset(&ba.rg, 0, sizeof(ba.rg)); ba.Y = w->Y; ba.ldy = d.fp; ba.bn = w->bn;
@@ -923,7 +930,16 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     {
         ProfScope ps(PROF_BN, s);
         const int ny = cdiv(d.fp, 1024);
-        bn_bwd_reduce_kernel<<<dim3(gxb, ny), 256, 0, s>>>(ba);
+        {
+            const bool wt = p->structure == EAGCN_STRUCT_WEIGHTED, dg = ba.rg.dg != nullptr, dr = ba.do_drop != 0;
+            const dim3 grid(gxb, ny);
+#define EAGCN_BWD(W, G, D) bn_bwd_reduce_kernel<W, G, D><<<grid, 256, 0, s>>>(ba)
+            if (wt) { if (dg) { if (dr) EAGCN_BWD(true, true, true); else EAGCN_BWD(true, true, false); }
+                      else    { if (dr) EAGCN_BWD(true, false, true); else EAGCN_BWD(true, false, false); } }
+            else    { if (dg) { if (dr) EAGCN_BWD(false, true, true); else EAGCN_BWD(false, true, false); }
+                      else    { if (dr) EAGCN_BWD(false, false, true); else EAGCN_BWD(false, false, false); } }
+#undef EAGCN_BWD
+        }
         EAGCN_LAUNCH_CHECK();
         if (gxb > 64)
             bn_bwd_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,

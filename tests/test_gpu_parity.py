@@ -882,7 +882,7 @@ def _mix64(seed, idx):
 
 def _hip_dropout_masks(mb, widths_per_layer, structure, n_den1, p, seed):
     """The keep-scales (0 or 1/(1-p)) the HIP kernels apply, in the order the oracle calls F.dropout: every block of every
-    layer ([B,N,F_k]), then the head ([B,n_den1]).  Stored rows: drop_scale(seed_l, r*Fp + cp) with r the PACKED row;
+    layer ([B,N,F_k]), then the head ([B,n_den1]).  Stored rows: drop_scale_el(seed_l, r*Fp + cp) with r the PACKED row;
     non-stored rows of the last Weighted_sum layer: the 16-bit draws of csrc/readout.hip; elsewhere they do not matter
     (masked to zero / never consumed) and are left at 1."""
     p32 = np.float32(p)
@@ -909,7 +909,9 @@ def _hip_dropout_masks(mb, widths_per_layer, structure, n_den1, p, seed):
                 if n:
                     r = (row0[b] + np.arange(n)).astype(np.uint64)[:, None]
                     cp = (off[k] + np.arange(w)).astype(np.uint64)[None, :]
-                    z = _mix64(seed_l, r * np.uint64(fp) + cp) & np.uint64(0xFFFFFFFF)
+                    idx = r * np.uint64(fp) + cp                      # csrc/common.h drop_scale4 / drop_scale_el: one hash
+                    z = _mix64(seed_l, idx >> np.uint64(1))           # per PAIR of elements, low half even, high half odd
+                    z = np.where((idx & np.uint64(1)) == np.uint64(1), z >> np.uint64(32), z & np.uint64(0xFFFFFFFF))
                     m[b, :n, :] = np.where(z >= thr, inv_keep, np.float32(0.0))
                 if structure == 'Weighted_sum' and l == L - 1 and n < N:
                     i = np.arange(n, N)
