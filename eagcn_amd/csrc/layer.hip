@@ -74,15 +74,37 @@ __device__ __forceinline__ int packed_to_exact(const ColMapD& m, int cp) {
 __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const ViewCols& vc, const ColMapD& in, int ld_in,
                                                  int fp, float* __restrict__ Wcat, float* __restrict__ WcatT,
                                                  float* __restrict__ colp, float* __restrict__ sig, float* __restrict__ rsig) {
-    const int total = ld_in * fp;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int ip = e / fp, cp = e % fp;
-        const int k = col_view(vc, cp), f = cp - vc.off[k];
-        const int fi = packed_to_exact(in, ip);
-        float v = 0.0f;
-        if (fi >= 0 && f < vc.width[k]) v = pp.W[k][(size_t)fi * vc.width[k] + f];
-        Wcat[e] = v;
-        WcatT[(size_t)cp * ld_in + ip] = v;      // [Fp][ld_in]: the K-contiguous B operand of the forward product (NT form)
+    // 32 x 32 tiles through LDS: Wcat rows AND the rows of its transpose are written as contiguous 128-byte runs (the
+    // transpose used to leave as 4-byte stores ld_in floats apart: one cache line per lane)
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 columns x 8 rows per pass
+    const int ntx = (fp + 31) >> 5, nty = (ld_in + 31) >> 5;
+    for (int t = blockIdx.x; t < ntx * nty; t += gridDim.x) {
+        const int ip0 = (t / ntx) << 5, cp0 = (t % ntx) << 5;
+        {
+            const int cp = cp0 + tx;
+            const int k = cp < fp ? col_view(vc, cp) : 0;
+            const int f = cp - vc.off[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ip = ip0 + ty + 8 * j;
+                float v = 0.0f;
+                if (ip < ld_in && cp < fp) {
+                    const int fi = packed_to_exact(in, ip);
+                    if (fi >= 0 && f < vc.width[k]) v = pp.W[k][(size_t)fi * vc.width[k] + f];
+                    Wcat[(size_t)ip * fp + cp] = v;
+                }
+                tile[ty + 8 * j][tx] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cp = cp0 + ty + 8 * j, ip = ip0 + tx;
+            // [Fp][ld_in]: the K-contiguous B operand of the forward product (NT form)
+            if (cp < fp && ip < ld_in) WcatT[(size_t)cp * ld_in + ip] = tile[tx][ty + 8 * j];
+        }
+        __syncthreads();
     }
     for (int cp = blockIdx.x * blockDim.x + threadIdx.x; cp < fp; cp += gridDim.x * blockDim.x) {
         const int k = col_view(vc, cp), f = cp - vc.off[k];
