@@ -199,15 +199,3 @@ def test_pool_model_vs_oracle_wide(structure, pool_num, compact):
             if 'running' in k or 'num_batches' in k:                    # (bn_den1 follows a BatchNorm: its mean is summation noise)
                 d = (sd_h[k].double().cpu() - sd_r[k].double()).abs().max().item()
                 assert d <= TOL * sd_r[k].double().abs().max().item() + 1e-6, (k, d)
-
-
-def test_pool_constructor_contract():
-    from eagcn_amd import EAGCN
-    with pytest.raises(ValueError):
-        EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, molfp_mode='pool', graph=True)
-    with pytest.raises(ValueError):
-        EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, molfp_mode='pool', n_layers=2)       # A of layers.py:319-324 needs layer 4
-    with pytest.raises(ValueError):
-        EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, molfp_mode='pool', pool_num=9)
-    m = EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, structure='GCN', molfp_mode='pool', n_layers=2)
-    assert m.pool1.adjacent_layer.weight.shape == (40, 5) and m.pool3.adjacent_layer.weight.shape == (40, 1)

@@ -209,3 +209,15 @@ def test_model_pickles_and_deepcopies_after_planning():
     assert r._plan is None and r._runners == {}
     for (k1, v1), (k2, v2) in zip(m.state_dict().items(), r.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_pool_constructor_contract():
+    from eagcn_amd import EAGCN
+    with pytest.raises(ValueError):
+        EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, molfp_mode='pool', graph=True)
+    with pytest.raises(ValueError):
+        EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, molfp_mode='pool', n_layers=2)       # A of layers.py:319-324 needs layer 4
+    with pytest.raises(ValueError):
+        EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, molfp_mode='pool', pool_num=9)
+    m = EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, structure='GCN', molfp_mode='pool', n_layers=2)
+    assert m.pool1.adjacent_layer.weight.shape == (40, 5) and m.pool3.adjacent_layer.weight.shape == (40, 1)
