@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void pool_att_bwd_final_kernel(eagcn_batch bt,
         }
         g.datt_w[k][ch] = (float)t;
     }
-    if (threadIdx.x < K && g.dave_a) g.dave_a[threadIdx.x] = (float)acc[K * 256 + threadIdx.x];
+    if ((int)threadIdx.x < K && g.dave_a) g.dave_a[threadIdx.x] = (float)acc[K * 256 + threadIdx.x];
     if (threadIdx.x == 0 && g.dself_r) g.dself_r[0] = (float)acc[K * 256 + K];
 }
 
