@@ -28,7 +28,9 @@ DATASETS = {'tox21': ([80] * 5, [140] * 5, 256, 64, 5e-4, 1e-4, 'class', 12, 28,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--dataset', default='tox21', choices=sorted(DATASETS))
-    ap.add_argument('--arch', default='Concate', choices=('Concate', 'Weighted_sum'))
+    ap.add_argument('--arch', default='Concate', choices=('Concate', 'Weighted_sum', 'GCN', 'GAT'),
+                    help="models.py:33-73; 'GCN' / 'GAT' are the reference's baselines")
+    ap.add_argument('--molfp', default='sum', choices=('sum', 'ave', 'pool'), help='read-out, models.py:104-111')
     ap.add_argument('--layers', type=int, default=2)
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--steps', type=int, default=200)
@@ -62,8 +64,12 @@ def main():
     bce_w = None
     if task == 'class':
         bce_w = torch.tensor(training.set_weight(torch.cat([l.cpu() for _, l in train_set]), T), device=dev)
-    model = EAGCN(n_bfeat, 24, *w1, *w2, d1, d2, T, args.dr, structure=args.arch, n_layers=args.layers, graph=True,
-                  overlap_index=True, validate='deferred', n_bucket=16 if args.loader == 'compact' else 0).to(dev)
+    graph = args.arch != 'GAT' and args.molfp != 'pool'       # (those two run layer by layer on the eager engine)
+    if args.molfp == 'pool' and args.arch in ('Concate', 'Weighted_sum'):
+        args.layers = 4                                        # the pool read-out needs layer 4's attention matrix
+    model = EAGCN(n_bfeat, 24, *w1, *w2, d1, d2, T, args.dr, structure=args.arch, molfp_mode=args.molfp, n_layers=args.layers,
+                  graph=graph, overlap_index=graph, validate='deferred' if graph else 'sync',
+                  n_bucket=16 if (args.loader == 'compact' and graph) else 0).to(dev)
     model.apply(weights_init)
     opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
     t0 = time.perf_counter()
