@@ -221,3 +221,23 @@ def test_pool_constructor_contract():
         EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, molfp_mode='pool', pool_num=9)
     m = EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, structure='GCN', molfp_mode='pool', n_layers=2)
     assert m.pool1.adjacent_layer.weight.shape == (40, 5) and m.pool3.adjacent_layer.weight.shape == (40, 1)
+
+
+def test_flat_gradient_layout_is_16_byte_aligned_per_parameter():
+    """Every parameter's slot of the flat gradient buffer starts on a 16-byte boundary (the GEMM epilogue that writes
+    blockK.graph_conv.weight.grad uses 16-byte stores; a 1-element self_r sits right in front of that matrix) and the views
+    have the parameters' shapes, in parameter order."""
+    from eagcn_amd import EAGCN
+    m = EAGCN(28, 24, *[8] * 5, *[12] * 5, 16, 8, 3, 0.0, n_layers=2)
+    p = m.plan()
+    assert all(o % 4 == 0 for o in p.offsets)
+    assert p.offsets[-1] >= sum(p.sizes) and p.offsets[-1] - sum(p.sizes) < 4 * len(p.sizes)
+    flat = torch.arange(p.offsets[-1], dtype=torch.float32)
+    views = p.grad_views(flat)
+    assert [tuple(v.shape) for v in views] == [tuple(q.shape) for q in p.params]
+    for o, v in zip(p.offsets, views):
+        assert v.data_ptr() == flat.data_ptr() + 4 * o
+    seen = torch.zeros(p.offsets[-1], dtype=torch.bool)
+    for o, n in zip(p.offsets, p.sizes):
+        assert not seen[o:o + n].any()
+        seen[o:o + n] = True
