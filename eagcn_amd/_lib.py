@@ -155,6 +155,9 @@ SIGNATURES = {
                                      C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
                                      _fp, C.c_size_t, _fp]),
     'eagcn_gemm_sk_timeouts': (C.c_int, []),
+    'eagcn_gemm_sk_failed': (C.c_int, []),
+    'eagcn_gemm_sk_reset_failed': (None, []),
+    'eagcn_gemm_sk_inject_failure': (None, []),
     'eagcn_model_saved_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(Model)]),
     'eagcn_model_scratch_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(Model)]),
     'eagcn_model_atom_rep': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), C.POINTER(C.c_size_t),

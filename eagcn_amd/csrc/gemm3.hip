@@ -33,7 +33,24 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 #define EAGCN_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-__device__ int g_gemm3_timeouts = 0;       // hand-offs that gave up waiting (must stay 0)
+__device__ int g_gemm3_timeouts = 0;       // hand-offs that gave up waiting (must stay 0; diagnostics: eagcn_gemm_sk_timeouts)
+// The STICKY error word lives in host memory mapped into the device's address space: a kernel whose owner wave gave up
+// waiting stores 1 there (system scope) and poisons its tile with NaN, and every later API call -- and the graph-replay
+// host loop, which makes no API call per step -- reads the word without any synchronisation and fails loudly.
+static int* g_g3_err_host = nullptr;       // host view
+static int* g_g3_err_dev = nullptr;        // device view of the same word
+static int* g3_err_word() {
+    if (!g_g3_err_dev) {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+        memset(h, 0, 64);
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) return nullptr;
+        g_g3_err_host = (int*)h;
+        g_g3_err_dev = (int*)d;
+    }
+    return g_g3_err_dev;
+}
 
 constexpr int G3_T = 64;                   // wave tile (both dimensions)
 constexpr int G3_BK = 16;
@@ -56,7 +73,8 @@ __device__ __forceinline__ f32x4 g3_sel(bool ok, f32x4 v) { return ok ? v : (f32
 template <bool TN, bool SCATTER>
 __device__ __forceinline__ void g3_segment(const G2Prob& p, const DwScatter& sc, const int Mx, const int Kx, const int tile,
                                            const int kb, const int ke, const int mode, const int l, const int tile_end_global,
-                                           const G3Sched& sched, float* __restrict__ ws, unsigned* __restrict__ flags) {
+                                           const G3Sched& sched, float* __restrict__ ws, unsigned* __restrict__ flags,
+                                           int* __restrict__ err) {
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, q = lane >> 4;
     const int gx = (p.N + G3_T - 1) / G3_T;
@@ -182,11 +200,22 @@ __device__ __forceinline__ void g3_segment(const G2Prob& p, const DwScatter& sc,
         // additions stay in range order
         int last = l;
         while (last + 1 < sched.R && sched.start(last + 1) < tile_end_global) ++last;
+        // A contributor that never shows up (the scheme needs every wave of the grid co-resident with its owner) must
+        // not yield a silently wrong tile: the owner gives up after 2^22 polls, raises the sticky host-visible error word
+        // and poisons its tile with NaN -- it never continues with a partial sum.
+        bool timed_out = false;
         auto wait_flag = [&](int c) __attribute__((always_inline)) {
             unsigned spins = 0;
             while (__hip_atomic_load((gu32*)(flags + c), EAGCN_RLX_AGENT) == 0u) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22)) { if (lane == 0) atomicAdd(&g_gemm3_timeouts, 1); break; }
+                if (++spins > (1u << 22)) {
+                    if (lane == 0) {
+                        atomicAdd(&g_gemm3_timeouts, 1);
+                        if (err) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    timed_out = true;
+                    break;
+                }
             }
         };
         int c = l + 1;
@@ -218,6 +247,11 @@ __device__ __forceinline__ void g3_segment(const G2Prob& p, const DwScatter& sc,
                 __hip_atomic_store((gu32*)(flags + c1), 0u, EAGCN_RLX_AGENT);
                 if (c2 >= 0) __hip_atomic_store((gu32*)(flags + c2), 0u, EAGCN_RLX_AGENT);
             }
+        }
+        if (timed_out) {
+            const float qnan = __builtin_nanf("");
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e >> 2][e & 3] = (f32x4){qnan, qnan, qnan, qnan};
         }
     }
 
@@ -308,7 +342,7 @@ __device__ __forceinline__ int g3_logical(int b, int G) {
 // problem 0: NT or TN (TN0); optional problem 1 is always TN (the dW that rides with a dX), optionally scattered
 template <bool TN0, bool HAS1, bool SCAT>
 __global__ __launch_bounds__(256, G3_WAVES_PER_SIMD) void gemm3_kernel(G2Prob p0, G2Prob p1, DwScatter sc, float* __restrict__ ws,
-                                                    unsigned* __restrict__ flags) {
+                                                    unsigned* __restrict__ flags, int* __restrict__ err) {
     const int G = gridDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l = g3_logical(blockIdx.x, G) * 4 + wave;
@@ -341,8 +375,8 @@ __global__ __launch_bounds__(256, G3_WAVES_PER_SIMD) void gemm3_kernel(G2Prob p0
         const int seg_end = min(end, tile_end);
         const int ke = kb + (seg_end - it);
         const int mode = kb > 0 ? 1 : (seg_end < tile_end ? 2 : 0);
-        if (!second) g3_segment<TN0, SCAT && !HAS1>(p0, sc, M0, K0, tile, kb, ke, mode, l, tile_end, sched, ws, flags);
-        else if constexpr (HAS1) g3_segment<true, SCAT>(p1, sc, M1, K1, tile, kb, ke, mode, l, tile_end, sched, ws, flags);
+        if (!second) g3_segment<TN0, SCAT && !HAS1>(p0, sc, M0, K0, tile, kb, ke, mode, l, tile_end, sched, ws, flags, err);
+        else if constexpr (HAS1) g3_segment<true, SCAT>(p1, sc, M1, K1, tile, kb, ke, mode, l, tile_end, sched, ws, flags, err);
         it = seg_end;
     }
 }
@@ -354,7 +388,16 @@ static int g3_env(const char* name, int dflt) {
 }
 int gemm3_grid() {           // workgroups of four autonomous waves: one wave per SIMD (two measured 40 % slower: the fragment
                              // streams of eight waves no longer fit the CU's 32 KB vector cache)
-    static const int g = [] { int v = g3_env("EAGCN_GEMM3_WGS", 256); return std::max(8, std::min(v, G3_MAX_RANGES / 4)); }();
+    // default: one workgroup per CU of THIS device (the hand-off needs the whole grid co-resident; 256 on an MI355X)
+    static const int g = [] {
+        int cus = 256, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        (void)hipGetLastError();               // (no device in the build container: keep the nominal 256)
+        int v = g3_env("EAGCN_GEMM3_WGS", cus);
+        return std::max(8, std::min(v, G3_MAX_RANGES / 4));
+    }();
     return g;
 }
 size_t gemm3_workspace_bytes() {       // one parked tile + one flag per wave of the grid
@@ -428,9 +471,9 @@ int launch_gemm3(const GemmDesc& g, const DwScatter* sc0, void* workspace, size_
     const G2Prob p = g3_prob(g);
     const int G = gemm3_grid();
     ProfScope ps(g.prof_tag, s, g.work > 0.0 ? g.work : 2.0 * g.M * g.N * g.K);
-    if (g.ta == 0) gemm3_kernel<false, false, false><<<G, 256, 0, s>>>(p, p, sc, ws, flags);
-    else if (sc0) gemm3_kernel<true, false, true><<<G, 256, 0, s>>>(p, p, sc, ws, flags);
-    else gemm3_kernel<true, false, false><<<G, 256, 0, s>>>(p, p, sc, ws, flags);
+    if (g.ta == 0) gemm3_kernel<false, false, false><<<G, 256, 0, s>>>(p, p, sc, ws, flags, g3_err_word());
+    else if (sc0) gemm3_kernel<true, false, true><<<G, 256, 0, s>>>(p, p, sc, ws, flags, g3_err_word());
+    else gemm3_kernel<true, false, false><<<G, 256, 0, s>>>(p, p, sc, ws, flags, g3_err_word());
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
@@ -449,8 +492,8 @@ int launch_gemm3_pair(const GemmDesc& dx, const GemmDesc& dw, const DwScatter* s
     const double w0 = dx.work > 0.0 ? dx.work : 2.0 * dx.M * dx.N * dx.K;
     const double w1 = dw.work > 0.0 ? dw.work : 2.0 * dw.M * dw.N * dw.K;
     ProfScope ps(PROF_GEMM_PAIR, s, w0 + w1);
-    if (sc0) gemm3_kernel<false, true, true><<<G, 256, 0, s>>>(g3_prob(dx), g3_prob(dw), sc, ws, flags);
-    else gemm3_kernel<false, true, false><<<G, 256, 0, s>>>(g3_prob(dx), g3_prob(dw), sc, ws, flags);
+    if (sc0) gemm3_kernel<false, true, true><<<G, 256, 0, s>>>(g3_prob(dx), g3_prob(dw), sc, ws, flags, g3_err_word());
+    else gemm3_kernel<false, true, false><<<G, 256, 0, s>>>(g3_prob(dx), g3_prob(dw), sc, ws, flags, g3_err_word());
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
@@ -461,10 +504,24 @@ using namespace eagcn;
 
 extern "C" size_t eagcn_gemm_sk_workspace_bytes(void) { return gemm3_workspace_bytes(); }
 
+int eagcn::gemm3_failed() { return g_g3_err_host ? __atomic_load_n(g_g3_err_host, __ATOMIC_RELAXED) : 0; }
+
+/* number of hand-offs that gave up waiting since load (synchronising read of the device counter; must stay 0) */
 extern "C" int eagcn_gemm_sk_timeouts(void) {
     int v = -1;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_gemm3_timeouts), sizeof(int)) != hipSuccess) return -1;
     return v;
+}
+/* sticky error word (host-mapped, no synchronisation): non-zero once any hand-off of any launch timed out -- the tile it
+ * belonged to was poisoned with NaN.  Every model / layer entry point refuses to run while it is set. */
+extern "C" int eagcn_gemm_sk_failed(void) { return gemm3_failed(); }
+extern "C" void eagcn_gemm_sk_inject_failure(void) {     /* test hook: what a timed-out owner wave does to the sticky word */
+    if (g3_err_word()) __atomic_store_n(g_g3_err_host, 1, __ATOMIC_RELAXED);
+}
+extern "C" void eagcn_gemm_sk_reset_failed(void) {
+    if (g_g3_err_host) __atomic_store_n(g_g3_err_host, 0, __ATOMIC_RELAXED);
+    int z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm3_timeouts), &z, sizeof(int));
 }
 
 extern "C" int eagcn_gemm_f32_sk(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,

@@ -196,6 +196,7 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
                                    size_t scratch_bytes, float* out, float* graph_rep, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     RC(check_model(b, m, "eagcn_model_forward"));
+    EAGCN_CHECK_GEMM3("eagcn_model_forward");
     EAGCN_CHECK_ARG((afm || m->input_packed) && saved && scratch && out && graph_rep, "eagcn_model_forward: null buffer");
     EAGCN_CHECK_ARG(m->molfp_mode == 0 || size, "eagcn_model_forward: 'ave' read-out needs size");
     ModelSaved sv;
@@ -262,6 +263,7 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
                                     const eagcn_head_grads* hg, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     RC(check_model(b, m, "eagcn_model_backward"));
+    EAGCN_CHECK_GEMM3("eagcn_model_backward");
     EAGCN_CHECK_ARG(saved && scratch && dout && lg && hg, "eagcn_model_backward: null buffer");
     EAGCN_CHECK_ARG(hg->d_den1_w && hg->d_den2_w && hg->d_den3_w && hg->d_gbn_w && hg->d_gbn_b && hg->d_bn1_w &&
                         hg->d_bn1_b && hg->d_bn2_w && hg->d_bn2_b, "eagcn_model_backward: null head gradient");

@@ -125,21 +125,35 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
     }
 }
 
-// compact input: one thread per directed bond writes its K codes and bumps the row degree
+// compact input: one thread per directed bond writes its K codes and bumps the row degree.  Same contract as the dense
+// scan: atoms inside the batch's padded size Nlog (<= the capacity N), a bond on the diagonal is a bond like any other (the
+// dense signature accepts adj[i,i] = 1 too), and a directed bond may be listed only ONCE -- a repeated (b,i,j) would count
+// its degree twice where the dense adjacency holds a single 1: the view-0 code byte is claimed with an atomic OR on its
+// 32-bit word (the map is cleared before this kernel) and a second claim is reported in meta[BAD_ADJ].
 __global__ __launch_bounds__(256) void index_bonds_kernel(const int32_t* __restrict__ bm, const int32_t* __restrict__ bi,
                                                            const int32_t* __restrict__ bj,
-                                                           const uint8_t* __restrict__ bc, long E, int B, int N, int K,
+                                                           const uint8_t* __restrict__ bc, long E, int B, int N, int Nlog, int K,
                                                            int ldc, RelPtrs rel, uint8_t* __restrict__ code,
                                                            int32_t* __restrict__ deg_bn, int32_t* __restrict__ nat,
                                                            int32_t* __restrict__ ecnt, int32_t* __restrict__ meta) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
         const int b = bm[e], i = bi[e], j = bj[e];
-        if (b < 0 || b >= B || i < 0 || i >= N || j < 0 || j >= N || i == j) {
+        if (b < 0 || b >= B || i < 0 || i >= Nlog || j < 0 || j >= Nlog) {
             atomicAdd(&meta[EAGCN_META_BAD_ADJ], 1);
             continue;
         }
-        bool bad = false;
-        for (int k = 0; k < K; ++k) {
+        {
+            const size_t at = (((size_t)b) * N + i) * ldc + j;             // view 0 (ldc is a multiple of 16: words never straddle rows)
+            const unsigned sh = 8u * (unsigned)(at & 3);
+            const unsigned c0 = (unsigned)min((int)bc[e * K], 254) + 1u;
+            const unsigned old = atomicOr(reinterpret_cast<unsigned*>(code + (at & ~(size_t)3)), c0 << sh);
+            if ((old >> sh) & 255u) {                                      // this (b,i,j) was listed before
+                atomicAdd(&meta[EAGCN_META_BAD_ADJ], 1);
+                continue;
+            }
+        }
+        bool bad = bc[e * K] >= rel.c[0];
+        for (int k = 1; k < K; ++k) {
             const int c = bc[e * K + k];
             if (c >= rel.c[k]) bad = true;
             code[(((size_t)k * B + b) * N + i) * ldc + j] = (uint8_t)(c + 1);
@@ -498,7 +512,8 @@ extern "C" int eagcn_index_from_bonds(const int32_t* bond_mol, const int32_t* bo
     EAGCN_HIP(hipMemsetAsync(b->code, 0, (size_t)b->K * b->B * b->N * b->ldc, s));
     if (E > 0) {
         const int grid = (int)std::min<long>((E + 255) / 256, 4096);
-        index_bonds_kernel<<<grid, 256, 0, s>>>(bond_mol, bond_i, bond_j, bond_code, (long)E, b->B, b->N, b->K, b->ldc, rp,
+        index_bonds_kernel<<<grid, 256, 0, s>>>(bond_mol, bond_i, bond_j, bond_code, (long)E, b->B, b->N,
+                                                b->n_logical > 0 ? std::min(b->n_logical, b->N) : b->N, b->K, b->ldc, rp,
                                                 b->code, b->deg_bn, b->nat, b->ecnt, b->meta);
         EAGCN_LAUNCH_CHECK();
     }

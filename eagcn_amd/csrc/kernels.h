@@ -100,6 +100,16 @@ size_t gemm3_workspace_bytes();
 // an API call (a tiny kernel, also under capture) covers all its launches on the same workspace
 // (`zero`: optionally `nzero` doubles cleared by the same launch -- the head's BatchNorm sums)
 int gemm3_clear_flags(void* workspace, size_t bytes, hipStream_t s, double* zero = nullptr, int nzero = 0);
+int gemm3_failed();              // sticky, host-visible: a hand-off of some earlier launch timed out (its tile is NaN)
+#define EAGCN_CHECK_GEMM3(who)                                                                                         \
+    do {                                                                                                               \
+        if (::eagcn::gemm3_failed()) {                                                                                 \
+            ::eagcn::set_error("%s: a stream-K hand-off of an earlier GEMM launch timed out (a contributor wave was not " \
+                               "co-resident with its owner): that launch's results are NaN-poisoned; call "           \
+                               "eagcn_gemm_sk_reset_failed() after fixing the cause (EAGCN_GEMM3_WGS, concurrent work)", who); \
+            return EAGCN_ERR_HIP;                                                                                      \
+        }                                                                                                              \
+    } while (0)
 // words another kernel clears on the way (instead of a launch of its own): the hand-off flags of gemm3.hip and fp64 sums
 int gemm_mode();             // 0 fp32 MFMA (default, parity path) | 1 exact bf16 x 6 | 2 plain bf16 operands (gemm.hip)
 struct ZeroJob { unsigned* u; int nu; double* d; int nd; };

@@ -752,6 +752,7 @@ extern "C" size_t eagcn_layer_bwd_scratch_bytes(const eagcn_batch* b, const eagc
 
 extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                                    void* stream) {
+    EAGCN_CHECK_GEMM3("eagcn_layer_forward");
     if (w && w->scratch && w->scratch_bytes >= gemm3_workspace_bytes()) {
         int rc = gemm3_clear_flags(w->scratch, w->scratch_bytes, (hipStream_t)stream);
         if (rc) return rc;
@@ -881,6 +882,7 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
 extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                                     const float* dxout, const float* dpad_row, float* dx,
                                     const eagcn_layer_grads* g, void* stream) {
+    EAGCN_CHECK_GEMM3("eagcn_layer_backward");
     if (w && w->scratch && w->scratch_bytes >= gemm3_workspace_bytes()) {
         int rc = gemm3_clear_flags(w->scratch, w->scratch_bytes, (hipStream_t)stream);
         if (rc) return rc;

@@ -243,6 +243,12 @@ class GraphRunner:
 
     # -- per-step entry points -----------------------------------------------------------------------
     def _check_old_batches(self, force=False):
+        # a timed-out stream-K hand-off (csrc/gemm3.hip) poisons its tile and raises a sticky host-mapped word: the replay
+        # loop makes no C call per step, so it is polled here (a plain host read, no synchronisation)
+        if L.load().eagcn_gemm_sk_failed():
+            raise L.EagcnHipError('a stream-K GEMM hand-off timed out in an earlier step (a contributor wave was not '
+                                  'co-resident with its owner): the gradients of that step are NaN-poisoned; '
+                                  'eagcn_gemm_sk_reset_failed() clears the flag')
         for slot in range(_RING):
             ev = self.meta_event[slot]
             if ev is None or not (force or ev.query()):
@@ -335,7 +341,7 @@ class GraphRunner:
             self.meta_event[slot] = None
             bad = None
             if meta[L.META_BAD_ADJ]:
-                bad = ('%d bonds are out of range or self-loops' if bonds is not None else
+                bad = ('%d bonds are out of range or listed twice' if bonds is not None else
                        'adjs holds %d entries outside {0,1}') % meta[L.META_BAD_ADJ]
             elif meta[L.META_BAD_REL]:
                 bad = '%d bonded (i,j,view) positions are not one-hot over the relation channels' % meta[L.META_BAD_REL]
@@ -398,7 +404,9 @@ class GraphRunner:
         self._attach_grads(keep, grads)
 
     def _before_grads(self):
-        grads = [p.grad for p in self.plan.params]
+        # (frozen buffers that ride in plan.params -- the constant attention weights of Vanilla_GCN.hot_params -- never get a
+        #  .grad: optimizer.zero_grad would not clear it and every later step would take the accumulate path below)
+        grads = [p.grad if p.requires_grad else None for p in self.plan.params]
         # the captured backward OVERWRITES flat_acc (the storage p.grad are views of); if gradients of an earlier
         # backward are still attached (accumulation across backward calls) keep them and add afterwards
         keep = None
@@ -410,10 +418,13 @@ class GraphRunner:
         params, views = self.plan.params, self.acc_views
         if keep is None and all(g is None for g in grads):
             for p, v in zip(params, views):
-                p.grad = v
+                if p.requires_grad:
+                    p.grad = v
             return
         kept = self.plan.grad_views(keep) if keep is not None else None
         for i, (p, g, v) in enumerate(zip(params, grads, views)):
+            if not p.requires_grad:
+                continue
             if g is None:
                 p.grad = v
             elif g is v:

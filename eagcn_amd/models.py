@@ -205,13 +205,15 @@ class EAGCN(nn.Module):
         state = dict(state)
         state['_plan'] = None
         state['_runners'] = {}
+        state.pop('_bce_weight_cache', None)
         return state
 
     def __setstate__(self, state):
         super().__setstate__(state)
         self._plan = None
         self._runners = {}
-        for name, default in (('graph_outputs', 'copy'), ('validate', 'sync'), ('max_runners', 8), ('edge_cap', None), ('n_bucket', 0)):
+        for name, default in (('graph_outputs', 'copy'), ('validate', 'sync'), ('max_runners', 8), ('edge_cap', None), ('n_bucket', 0),
+                              ('relations', 'onehot'), ('pool_num', 5)):
             self.__dict__.setdefault(name, default)
 
     def state_dict(self, *a, **kw):
@@ -318,7 +320,13 @@ class EAGCN(nn.Module):
         runner, adjs, rels, afms, size, seed, btuple = self._graph_runner(adjs, afms, rels, size, bonds)
         kind = 'mse' if task == 'reg' else 'bce'
         if kind == 'bce' and not isinstance(bce_weight, torch.Tensor):
-            raise ops.L.EagcnHipError('fused_step: bce_weight must be a [T,2] device tensor (make it once per run)')
+            if bce_weight is None:
+                raise ops.L.EagcnHipError('fused_step: the classification loss needs bce_weight ([T,2]; training.set_weight)')
+            # the list set_weight returns (utils.py:681-700), as the eager losses accept it; converted once per list object
+            key = id(bce_weight)
+            if getattr(self, '_bce_weight_cache', (None, None))[0] != key:
+                self._bce_weight_cache = (key, torch.tensor(bce_weight, dtype=torch.float32, device=afms.device))
+            bce_weight = self._bce_weight_cache[1]
         loss = runner.train_step(adjs, rels, afms, size, seed, labels, kind, bce_weight, scale, self.overlap_index, btuple)
         out, graph_representation = runner.outputs()
         return loss, (out, self._atom_rep(runner), graph_representation)
@@ -399,13 +407,18 @@ class EAGCN(nn.Module):
     def flat_grad_buffer(self):
         """The single fp32 buffer that holds every hot-path parameter gradient after a backward in
         grad_mode='direct' or graph mode (``p.grad`` are views of it); None otherwise."""
+        def first_live(plan):            # (frozen buffers in plan.params never carry a .grad)
+            return next((i for i, p in enumerate(plan.params) if p.requires_grad), None)
         if self.graph and self._runners:
             for r in self._runners.values():
-                if r.plan.params and r.plan.params[0].grad is r.acc_views[0]:
+                i = first_live(r.plan)
+                if i is not None and r.plan.params[i].grad is r.acc_views[i]:
                     return r.flat_acc
         if self._plan is not None and self._plan.flat_grad is not None:
-            g0 = self._plan.params[0].grad
-            if g0 is not None and g0.data_ptr() == self._plan.flat_grad.data_ptr():
+            i = first_live(self._plan)
+            g0 = self._plan.params[i].grad if i is not None else None
+            if g0 is not None and self._plan.flat_grad.data_ptr() <= g0.data_ptr() < \
+                    self._plan.flat_grad.data_ptr() + 4 * self._plan.flat_grad.numel():
                 return self._plan.flat_grad
         return None
 

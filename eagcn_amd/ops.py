@@ -181,7 +181,7 @@ class BatchIndex:
         side.synchronize()                # waits for the index kernels only, not for the main stream's backlog
         meta = host.tolist()
         if meta[L.META_BAD_ADJ] and bonds is not None:
-            raise L.EagcnHipError('%d bonds are out of range or self-loops' % meta[L.META_BAD_ADJ])
+            raise L.EagcnHipError('%d bonds are out of range or listed twice' % meta[L.META_BAD_ADJ])
         if meta[L.META_BAD_ADJ]:
             raise L.EagcnHipError('adjs holds %d entries outside {0,1}: the hot path requires a 0/1 '
                                   'adjacency (reference neural_fp.py:85,109-110)' % meta[L.META_BAD_ADJ])
@@ -911,6 +911,8 @@ class _ModelFn(torch.autograd.Function):
             # gradients are delivered straight into .grad as views of ONE flat buffer (accumulating if a
             # gradient is already there), bypassing ~70 AccumulateGrad nodes
             for p, g in zip(plan.params, grads):
+                if not p.requires_grad:          # frozen buffers riding in plan.params (Vanilla_GCN's constant weights)
+                    continue
                 if p.grad is None:
                     p.grad = g
                 else:

@@ -81,23 +81,44 @@ def rmse(scores, targets):
     return math.sqrt(float((d * d).mean()))
 
 
-def set_weight(labels, n_tasks):
-    """Class weights of the weighted BCE (utils.py:681-700): [w_pos, w_neg] per task from the label counts of the training
-    set, w = total / count (labels: array-like [n, T] with -1 = missing)."""
+def set_weight(labels, n_tasks=None):
+    """Class weights of the weighted BCE, exactly utils.py:681-700: per task [5000 / #positives, 5000 / #negatives] over the
+    labels of the training set (array-like [n, T]; anything other than 0 / 1 is a missing label).  Returned as a list
+    indexed by task, what train.py hands to ``weight_tensor`` (utils.py:653-679) as ``weights[j][0]`` / ``weights[j][1]``.
+    A task without a positive label has no entry in the reference's dictionary and its training loop dies with a KeyError
+    as soon as a label of that task shows up (a task with positives but no negatives already in set_weight itself); the
+    same error is raised here, at once, naming the task."""
     y = torch.as_tensor(labels)
+    if y.dim() != 2:
+        raise ValueError('set_weight: labels must be [n, tasks], got %s' % (tuple(y.shape),))
+    T = y.shape[1] if n_tasks is None else int(n_tasks)
     out = []
-    for j in range(n_tasks):
+    for j in range(T):
         pos, neg = int((y[:, j] == 1).sum()), int((y[:, j] == 0).sum())
-        tot = pos + neg
-        out.append([tot / max(pos, 1), tot / max(neg, 1)])
+        if pos == 0 or neg == 0:
+            raise KeyError('set_weight: task %d has %d positive and %d negative labels (utils.py:697-699 has no weight '
+                           'for it)' % (j, pos, neg))
+        out.append([5000 / pos, 5000 / neg])
     return out
 
 
-def train_step(model, optimizer, batch, labels, task, bce_weight=None, dp_global_norm=False, fused=None, bonds=None):
+def train_step(model, optimizer, batch, labels, task, bce_weight=None, dp_global_norm=False, fused=None, bonds=None,
+               reducer=None):
     """One iteration of train.py:310-334.  `batch` = (adjs, afms, TypeAtt, OrderAtt, AromAtt, ConjAtt, RingAtt, size) device
     tensors -- or (afms, size) together with `bonds` (a CompactBonds: eagcn_amd.collate.collate_compact) for a compact batch;
     returns the loss tensor (device; no host sync).  With a graph-mode model the three phases run as ONE captured graph
-    (EAGCN.fused_step) unless fused=False."""
+    (EAGCN.fused_step) unless fused=False.
+
+    Data parallel: `reducer` (an eagcn_amd.parallel.GradientAllReducer over the model's parameters) averages the gradients
+    across ranks between backward and ``optimizer.step()``.  ``dp_global_norm=True`` rescales this rank's loss by
+    world * n_r / sum n_r (parallel.dp_loss_scale), which is only meaningful when the gradients are averaged afterwards: with
+    torch.distributed initialised it therefore REQUIRES a reducer (replicas that never synchronise and step on mis-scaled
+    gradients would be the silent alternative)."""
+    if dp_global_norm and reducer is None:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise ValueError('train_step(dp_global_norm=True) under torch.distributed needs reducer=GradientAllReducer(...): '
+                             'the global loss normalisation assumes the gradients are averaged across ranks')
     optimizer.zero_grad(set_to_none=True)
     if fused is None:
         fused = bool(getattr(model, 'graph', False)) and model.training and hasattr(model, 'fused_step')
@@ -105,15 +126,18 @@ def train_step(model, optimizer, batch, labels, task, bce_weight=None, dp_global
         scale = None
         if dp_global_norm:
             from .parallel import dp_loss_scale
-            scale = dp_loss_scale(labels, None)
+            scale = dp_loss_scale(labels, reducer.group if reducer is not None else None)
         loss, _ = model.fused_step(batch, labels, task, bce_weight, scale, bonds=bonds)
     else:
         out, _, _ = model(*batch) if bonds is None else model.forward_compact(bonds, *batch)
         if task == 'reg':
             loss = fused_regression_loss(out, labels)
         else:
-            loss = fused_classification_loss(out, labels, bce_weight, dp_global_norm=dp_global_norm)
+            loss = fused_classification_loss(out, labels, bce_weight, dp_global_norm=dp_global_norm,
+                                             group=reducer.group if reducer is not None else None)
         loss.backward()
+    if reducer is not None:
+        reducer()
     optimizer.step()
     return loss
 

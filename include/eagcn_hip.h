@@ -379,7 +379,14 @@ int eagcn_gemm_f32_sk(int ta, int tb, int M, int N, int K, const float* A, int l
 int eagcn_gemm_pair_sk(int M0, int N0, int K0, const float* A0, int lda0, const float* B0, int ldb0, float* C0, int ldc0,
                        int M1, int N1, int K1, const float* A1, int lda1, const float* B1, int ldb1, float* C1, int ldc1,
                        void* workspace, size_t workspace_bytes, void* stream);
-int eagcn_gemm_sk_timeouts(void);   /* hand-offs that gave up waiting since load (must stay 0) */
+int eagcn_gemm_sk_timeouts(void);   /* hand-offs that gave up waiting since load (must stay 0); synchronising device read */
+/* A hand-off that times out is FATAL, never silent: the owner wave poisons its output tile with NaN and stores 1 into a
+ * sticky word in host-mapped memory.  eagcn_gemm_sk_failed() reads that word without synchronising (the graph-replay host
+ * loop polls it every step, eagcn_amd/graph.py); every eagcn_model_* / eagcn_layer_* entry point returns EAGCN_ERR_HIP while
+ * it is set.  eagcn_gemm_sk_reset_failed() clears it; eagcn_gemm_sk_inject_failure() sets it (test hook). */
+int eagcn_gemm_sk_failed(void);
+void eagcn_gemm_sk_reset_failed(void);
+void eagcn_gemm_sk_inject_failure(void);
 
 /* ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline) -- */
 void eagcn_prof_enable(int on);

@@ -12,6 +12,24 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+@pytest.fixture(scope='session', autouse=True)
+def _no_gemm_handoff_timeouts():
+    """The stream-K hand-off of csrc/gemm3.hip must never time out: asserted once after the WHOLE session (the sticky
+    host-visible word and the device counter), so a time-out in any test is a failure of the run."""
+    yield
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return
+        from eagcn_amd import _lib
+        lib = _lib.load()
+    except Exception:
+        return
+    torch.cuda.synchronize()
+    assert lib.eagcn_gemm_sk_failed() == 0, 'a stream-K hand-off timed out during the session'
+    assert lib.eagcn_gemm_sk_timeouts() == 0, '%d stream-K hand-offs timed out during the session' % lib.eagcn_gemm_sk_timeouts()
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')

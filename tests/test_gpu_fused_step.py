@@ -88,3 +88,34 @@ def test_bce_loss_large_batch_multi_workgroup_kernel():
         lb.backward()
         assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb)), (float(la), float(lb))
         assert (xa.grad - xb.grad).abs().max().item() <= 2e-6 * xb.grad.abs().max().item()
+
+
+def test_gemm_handoff_failure_is_loud():
+    """A timed-out stream-K hand-off (csrc/gemm3.hip) sets a sticky host-visible word: the eager engine's next C call and the
+    graph-replay loop (which makes no C call per step) both raise instead of continuing with a poisoned step."""
+    from eagcn_amd import _lib as L
+    lib = L.load()
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(1)
+    mb = make_batch(B=8, n_max=20, n_med=9, rel_channels=(28, 4, 2, 2, 2), seed=3, n_tasks=1, task='reg')
+    dense = mb.dense(dev)
+    labels = torch.from_numpy(mb.labels).to(dev)
+    kw = dict(dropout=0.0, n_layers=2, widths1=[32] * 5, widths2=[16] * 5, n_den1=32, n_den2=16, nclass=1)
+    g = EAGCN(28, 24, graph=True, validate='deferred', **kw).to(dev).train()
+    e = EAGCN(28, 24, **kw).to(dev).train()
+    for _ in range(3):
+        g.fused_step(dense, labels, 'reg')
+    e(*dense)
+    torch.cuda.synchronize()
+    assert lib.eagcn_gemm_sk_failed() == 0
+    lib.eagcn_gemm_sk_inject_failure()
+    try:
+        with pytest.raises(L.EagcnHipError, match='hand-off'):
+            g.fused_step(dense, labels, 'reg')
+        with pytest.raises(L.EagcnHipError, match='hand-off'):
+            e(*dense)
+    finally:
+        lib.eagcn_gemm_sk_reset_failed()
+    g.fused_step(dense, labels, 'reg')            # usable again after the reset
+    torch.cuda.synchronize()
+    assert lib.eagcn_gemm_sk_failed() == 0

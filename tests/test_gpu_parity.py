@@ -475,7 +475,7 @@ def test_compact_input_equals_dense_collate(graph):
         for k in pa:
             if pa[k].grad is not None:      # float atomics reorder sums between runs: tolerance, not equality
                 assert_grad_close(pb[k].grad, pa[k].grad.cpu(), scale, '%s step %d' % (k, step), rtol=1e-5, floor=1e-5)
-    # malformed bond lists are rejected: out-of-range atom, self-loop, type beyond the view's channels
+    # malformed bond lists are rejected: out-of-range atom, a bond listed twice, type beyond the view's channels
     bm, bi, bj, bc = bonds.checked()
     for field, val in (('bond_i', 33), ('bond_j', -1), ('bond_code', 6)):
         t = {'bond_i': bi.clone(), 'bond_j': bj.clone(), 'bond_code': bc.clone()}
@@ -485,9 +485,23 @@ def test_compact_input_equals_dense_collate(graph):
             t[field][0] = val
         with pytest.raises(EagcnHipError):
             ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, bm, t['bond_i'], t['bond_j'], t['bond_code'])
-    loop = bi.clone(); loop[0] = int(bj[0])
+    dup = [torch.cat([t, t[:1]]) for t in (bm, bi, bj, bc)]           # the dense adjacency holds ONE 1 for a repeated bond
     with pytest.raises(EagcnHipError):
-        ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, bm, loop, bj, bc)
+        ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, *dup)
+    # a bond on the diagonal is accepted, exactly as adj[i,i] = 1 is by the dense signature
+    loop = [torch.cat([t, t[:1]]) for t in (bm, bi, bj, bc)]
+    loop[2][-1] = int(loop[1][-1])
+    i_loop = ops.BatchIndex.from_bonds(bonds.B, bonds.N, bonds.channels, *loop)
+    d2 = [t.clone() for t in d]
+    b0, a0 = int(bm[0]), int(bi[0])
+    d2[0][b0, a0, a0] = 1.0
+    for k, r in enumerate(d2[2:-1]):
+        r[b0, int(bc[0, k]), a0, a0] = 1.0
+    i_dense2 = ops.BatchIndex(d2[0], d2[2:-1])
+    for name in ('deg_bn', 'nat', 'row0', 'tile0', 'row_deg', 'row_m'):
+        assert torch.equal(getattr(i_dense2, name), getattr(i_loop, name)), name
+    bonded = (i_dense2.deg_bn.view(1, bonds.B, bonds.N, 1) > 0)
+    assert torch.equal(i_dense2.code * bonded, i_loop.code * bonded)
 
 
 def test_graph_mode_gradient_accumulation_and_foreign_grads():

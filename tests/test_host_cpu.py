@@ -186,8 +186,20 @@ def test_eval_metrics_match_sklearn():
     assert abs(mean - np.nanmean(want)) < 1e-12
     pred, tgt = torch.randn(300, 1, generator=g), torch.randn(300, 1, generator=g)
     assert abs(rmse(pred, tgt) - np.sqrt(metrics.mean_squared_error(pred.numpy().ravel(), tgt.numpy().ravel()))) < 1e-6
-    w = set_weight(labels, T)
-    assert abs(w[0][0] - (int(valid[:, 0].sum()) / max(int((labels[:, 0] == 1).sum()), 1))) < 1e-12
+    with pytest.raises(KeyError):                  # task 3 has no positives: the reference has no weight for it either
+        set_weight(labels, T)
+
+
+def test_set_weight_and_weight_tensor_match_the_reference(golden_dir):
+    """utils.py:681-700 / 653-679, lifted out of the reference by tools/make_collate_golden.py (inputs + outputs only)."""
+    from eagcn_amd.losses import class_weight_tensor
+    from eagcn_amd.training import set_weight
+    z = np.load(os.path.join(golden_dir, 'class_weights.npz'))
+    w = set_weight(z['y_all'])
+    assert np.array_equal(np.array(w, dtype=np.float64), z['weights'])          # 5000 / count, bit for bit
+    assert w == set_weight(torch.from_numpy(z['y_all']), z['y_all'].shape[1])
+    wt = class_weight_tensor(w, torch.from_numpy(z['batch']))
+    assert np.array_equal(wt.numpy(), z['weight_tensor'])
 
 
 def test_model_pickles_and_deepcopies_after_planning():

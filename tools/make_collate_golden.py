@@ -56,7 +56,29 @@ def case(name, fn, mb):
     print('wrote', name, [tuple(t.shape) for t in got[:3]])
 
 
+def class_weight_case():
+    """utils.py:681-700 ``set_weight`` and utils.py:653-679 ``weight_tensor`` lifted the same way: labels of a synthetic
+    training set -> the reference's weight dictionary (stored as [T,2]) and the per-entry weight vector of one batch."""
+    tree = ast.parse(open(REF).read())
+    wanted = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('set_weight', 'weight_tensor')]
+    assert len(wanted) == 2
+    ns = {'np': np, 'torch': torch, 'use_cuda': False, 'IntTensor': torch.IntTensor}
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), REF, 'exec'), ns)
+    rng = np.random.default_rng(77)
+    T = 6
+    y_all = rng.choice([1.0, 0.0, -1.0], size=(400, T), p=[0.08, 0.85, 0.07]).astype(np.float32)
+    y_all[:, 4] = rng.choice([1.0, 0.0, -1.0], size=400, p=[0.45, 0.45, 0.10])      # a balanced task
+    wd = ns['set_weight'](y_all.tolist())
+    assert sorted(wd.keys()) == list(range(T))
+    w = np.array([wd[j] for j in range(T)], dtype=np.float64)
+    batch = y_all[:37]
+    wt = ns['weight_tensor'](wd, torch.from_numpy(batch)).numpy()
+    np.savez_compressed(os.path.join(OUT, 'class_weights.npz'), y_all=y_all, weights=w, batch=batch, weight_tensor=wt)
+    print('wrote class_weights', w[:2].tolist())
+
+
 def main():
+    class_weight_case()
     cls, reg = reference_collates()
     case('collate_class', cls, make_batch(B=7, n_max=19, n_med=8, rel_channels=(9, 4, 2, 2, 2), seed=31, n_tasks=3,
                                           isolated_frac=0.1, force_max=False))
