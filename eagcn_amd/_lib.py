@@ -154,6 +154,10 @@ SIGNATURES = {
     'eagcn_gemm_pair_sk': (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
                                      C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
                                      _fp, C.c_size_t, _fp]),
+    'eagcn_gemm_pair_sk_slabs': (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
+                                           C.c_size_t, _fp, C.c_size_t, _fp]),
+    'eagcn_gemm_sk_plan': (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'eagcn_gemm_sk_timeouts': (C.c_int, []),
     'eagcn_gemm_sk_failed': (C.c_int, []),
     'eagcn_gemm_sk_reset_failed': (None, []),

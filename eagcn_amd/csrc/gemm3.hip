@@ -339,10 +339,11 @@ __device__ __forceinline__ int g3_logical(int b, int G) {
     return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
 }
 
-// problem 0: NT or TN (TN0); optional problem 1 is always TN (the dW that rides with a dX), optionally scattered
-template <bool TN0, bool HAS1, bool SCAT>
+// problem 0: NT or TN (TN0); optional problem 1 is always TN (the dW that rides with a dX), optionally scattered.
+// XK (pairs only): XCD-local schedule (kernels.h g3_plan): dW leaves as one partial slab per segment at p1.C + x * xk_slab.
+template <bool TN0, bool HAS1, bool SCAT, bool XK>
 __global__ __launch_bounds__(256, G3_WAVES_PER_SIMD) void gemm3_kernel(G2Prob p0, G2Prob p1, DwScatter sc, float* __restrict__ ws,
-                                                    unsigned* __restrict__ flags, int* __restrict__ err) {
+                                                    unsigned* __restrict__ flags, int* __restrict__ err, size_t xk_slab) {
     const int G = gridDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l = g3_logical(blockIdx.x, G) * 4 + wave;
@@ -364,6 +365,46 @@ __global__ __launch_bounds__(256, G3_WAVES_PER_SIMD) void gemm3_kernel(G2Prob p0
     sched.rem = sched.total - sched.per * sched.R;
     int it = sched.start(l);
     const int end = sched.start(l + 1);
+    if constexpr (XK && HAS1 && !TN0) {
+        const int RB = (M0 + G3_T - 1) / G3_T, CT0 = (p0.N + G3_T - 1) / G3_T;
+        const int T1 = ((M1 + G3_T - 1) / G3_T) * ((p1.N + G3_T - 1) / G3_T);
+        G3Plan pl;
+        g3_plan(RB, CT0, ipt0, T1, ipt1, G, pl);
+        const int rowit = CT0 * ipt0;                                   // iterations of one dX row block
+        while (it < end) {
+            // segment of `it`: the last x with base_x <= it (empty segments share their base with the next one)
+            int ax = 0, ax1 = pl.a[1], cx = 0, cx1 = pl.c[1], x = 0;
+#pragma unroll
+            for (int y = 1; y < G3_XSEG; ++y) {
+                const bool in = it >= pl.a[y] * rowit + T1 * pl.c[y];
+                ax = in ? pl.a[y] : ax; ax1 = in ? pl.a[y + 1] : ax1;
+                cx = in ? pl.c[y] : cx; cx1 = in ? pl.c[y + 1] : cx1;
+                x = in ? y : x;
+            }
+            const int base = ax * rowit + T1 * cx;
+            const int nA = (ax1 - ax) * rowit;
+            const int local = it - base;
+            if (local < nA) {                                           // dX tile of this segment's row blocks
+                const int tl = local / ipt0, kb = local - tl * ipt0;
+                const int run_end = base + (tl + 1) * ipt0;
+                const int seg_end = min(end, run_end);
+                const int mode = kb > 0 ? 1 : (seg_end < run_end ? 2 : 0);
+                g3_segment<false, false>(p0, sc, M0, K0, ax * CT0 + tl, kb, kb + (seg_end - it), mode, l, run_end, sched, ws, flags, err);
+                it = seg_end;
+            } else {                                                    // k-steps [cx, cx1) of a dW tile -> partial slab x
+                const int kw = cx1 - cx, l2 = local - nA;
+                const int tile = l2 / kw, kk = l2 - tile * kw;
+                const int run_end = base + nA + (tile + 1) * kw;
+                const int seg_end = min(end, run_end);
+                const int mode = kk > 0 ? 1 : (seg_end < run_end ? 2 : 0);
+                G2Prob px = p1;
+                px.C = p1.C + (size_t)x * xk_slab;
+                g3_segment<true, false>(px, sc, M1, K1, tile, cx + kk, cx + kk + (seg_end - it), mode, l, run_end, sched, ws, flags, err);
+                it = seg_end;
+            }
+        }
+        return;
+    }
     while (it < end) {
         const bool second = HAS1 && it >= it0;
         const int base = second ? it0 : 0;
@@ -471,16 +512,23 @@ int launch_gemm3(const GemmDesc& g, const DwScatter* sc0, void* workspace, size_
     const G2Prob p = g3_prob(g);
     const int G = gemm3_grid();
     ProfScope ps(g.prof_tag, s, g.work > 0.0 ? g.work : 2.0 * g.M * g.N * g.K);
-    if (g.ta == 0) gemm3_kernel<false, false, false><<<G, 256, 0, s>>>(p, p, sc, ws, flags, g3_err_word());
-    else if (sc0) gemm3_kernel<true, false, true><<<G, 256, 0, s>>>(p, p, sc, ws, flags, g3_err_word());
-    else gemm3_kernel<true, false, false><<<G, 256, 0, s>>>(p, p, sc, ws, flags, g3_err_word());
+    if (g.ta == 0) gemm3_kernel<false, false, false, false><<<G, 256, 0, s>>>(p, p, sc, ws, flags, g3_err_word(), 0);
+    else if (sc0) gemm3_kernel<true, false, true, false><<<G, 256, 0, s>>>(p, p, sc, ws, flags, g3_err_word(), 0);
+    else gemm3_kernel<true, false, false, false><<<G, 256, 0, s>>>(p, p, sc, ws, flags, g3_err_word(), 0);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
 
 // dX = dP.W^T (NT) and dW = X^T.dP (TN) of a layer in one balanced launch
-int launch_gemm3_pair(const GemmDesc& dx, const GemmDesc& dw, const DwScatter* sc0, void* workspace, size_t bytes, hipStream_t s) {
+bool gemm3_xk_enabled() {
+    static const bool on = g3_env("EAGCN_GEMM3_XK", 1) != 0;
+    return on;
+}
+
+int launch_gemm3_pair(const GemmDesc& dx, const GemmDesc& dw, const DwScatter* sc0, void* workspace, size_t bytes, hipStream_t s,
+                      size_t xk_slab) {
     EAGCN_CHECK_ARG(gemm3_ok(dx) && gemm3_ok(dw) && dx.ta == 0 && dw.ta == 1, "gemm pair: unsupported operands");
+    EAGCN_CHECK_ARG(xk_slab == 0 || !sc0, "gemm pair: the XCD-local schedule writes partial slabs, not scattered gradients");
     float* ws; unsigned* flags;
     int rc = g3_prepare(workspace, bytes, &ws, &flags);
     if (rc) return rc;
@@ -492,8 +540,9 @@ int launch_gemm3_pair(const GemmDesc& dx, const GemmDesc& dw, const DwScatter* s
     const double w0 = dx.work > 0.0 ? dx.work : 2.0 * dx.M * dx.N * dx.K;
     const double w1 = dw.work > 0.0 ? dw.work : 2.0 * dw.M * dw.N * dw.K;
     ProfScope ps(PROF_GEMM_PAIR, s, w0 + w1);
-    if (sc0) gemm3_kernel<false, true, true><<<G, 256, 0, s>>>(g3_prob(dx), g3_prob(dw), sc, ws, flags, g3_err_word());
-    else gemm3_kernel<false, true, false><<<G, 256, 0, s>>>(g3_prob(dx), g3_prob(dw), sc, ws, flags, g3_err_word());
+    if (xk_slab) gemm3_kernel<false, true, false, true><<<G, 256, 0, s>>>(g3_prob(dx), g3_prob(dw), sc, ws, flags, g3_err_word(), xk_slab);
+    else if (sc0) gemm3_kernel<false, true, true, false><<<G, 256, 0, s>>>(g3_prob(dx), g3_prob(dw), sc, ws, flags, g3_err_word(), 0);
+    else gemm3_kernel<false, true, false, false><<<G, 256, 0, s>>>(g3_prob(dx), g3_prob(dw), sc, ws, flags, g3_err_word(), 0);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
@@ -503,6 +552,18 @@ int launch_gemm3_pair(const GemmDesc& dx, const GemmDesc& dw, const DwScatter* s
 using namespace eagcn;
 
 extern "C" size_t eagcn_gemm_sk_workspace_bytes(void) { return gemm3_workspace_bytes(); }
+
+/* segment boundaries of the XCD-local paired schedule for (M0,N0,K0) x (M1,N1,K1) on a grid of `wgs` workgroups (0: the
+ * library's grid): a[9] row-block boundaries of the first product, c[9] k-step boundaries of the second (host-side mirror of
+ * what the kernel computes from the device-side extents; lets the CPU tests check the partition) */
+extern "C" int eagcn_gemm_sk_plan(int M0, int N0, int K0, int M1, int N1, int K1, int wgs, int* a, int* c) {
+    EAGCN_CHECK_ARG(a && c, "eagcn_gemm_sk_plan: null output");
+    G3Plan pl;
+    g3_plan(cdiv(M0, G3_T), cdiv(N0, G3_T), std::max(1, cdiv(K0, G3_BK)), cdiv(M1, G3_T) * cdiv(N1, G3_T), std::max(1, cdiv(K1, G3_BK)),
+            wgs > 0 ? wgs : gemm3_grid(), pl);
+    for (int x = 0; x <= G3_XSEG; ++x) { a[x] = pl.a[x]; c[x] = pl.c[x]; }
+    return EAGCN_OK;
+}
 
 int eagcn::gemm3_failed() { return g_g3_err_host ? __atomic_load_n(g_g3_err_host, __ATOMIC_RELAXED) : 0; }
 
@@ -530,6 +591,21 @@ extern "C" int eagcn_gemm_f32_sk(int ta, int tb, int M, int N, int K, const floa
     GemmDesc g{ta, tb, M, N, K, A, lda, B, ldb, C, ldc, 1, 0};
     int rc = gemm3_clear_flags(workspace, workspace_bytes, (hipStream_t)stream);
     return rc ? rc : launch_gemm3(g, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+/* The same pair on the XCD-local schedule (kernels.h g3_plan): C1 receives G3_XSEG = 8 partial slabs of M1 x ldc1 floats,
+ * `slab` floats apart (cleared first: a segment without k-steps of the second product writes nothing); their sum in slab
+ * order is the product (test / benchmark entry). */
+extern "C" int eagcn_gemm_pair_sk_slabs(int M0, int N0, int K0, const float* A0, int lda0, const float* B0, int ldb0, float* C0, int ldc0,
+                                        int M1, int N1, int K1, const float* A1, int lda1, const float* B1, int ldb1, float* C1, int ldc1,
+                                        size_t slab, void* workspace, size_t workspace_bytes, void* stream) {
+    EAGCN_CHECK_ARG(A0 && B0 && C0 && A1 && B1 && C1, "eagcn_gemm_pair_sk_slabs: null operand");
+    EAGCN_CHECK_ARG(slab >= (size_t)M1 * ldc1, "eagcn_gemm_pair_sk_slabs: slab stride smaller than one matrix");
+    GemmDesc g0{0, 1, M0, N0, K0, A0, lda0, B0, ldb0, C0, ldc0, 1, 0};
+    GemmDesc g1{1, 0, M1, N1, K1, A1, lda1, B1, ldb1, C1, ldc1, 1, 0};
+    EAGCN_HIP(hipMemsetAsync(C1, 0, slab * G3_XSEG * sizeof(float), (hipStream_t)stream));
+    int rc = gemm3_clear_flags(workspace, workspace_bytes, (hipStream_t)stream);
+    return rc ? rc : launch_gemm3_pair(g0, g1, nullptr, workspace, workspace_bytes, (hipStream_t)stream, slab);
 }
 
 /* dX[M0,N0] = A0[M0,K0] . B0[N0,K0]^T  and  dW[M1,N1] = A1[K1,M1]^T . B1[K1,N1] in ONE launch (test / benchmark entry of the

@@ -95,7 +95,44 @@ struct DwScatter {               // epilogue of a layer's dW product: packed (in
     ColMapD in;
     int in_identity;             // the input layout has no padded columns: packed row == exact row (set by the launchers)
 };
+// ---- XCD-local schedule of a paired launch (dX = dP.W^T with dW = X^T.dP) -------------------------------------------------
+// The linear iteration space of the pair is laid out as eight SEGMENTS, one per XCD (dispatch slot b runs on XCD b % 8 and
+// the kernel hands every XCD a contiguous run of wave ranges): segment x = the dX tiles of the row blocks [a_x, a_x+1) followed
+// by, for EVERY dW tile, the k-steps [c_x, c_x+1) -- i.e. the long reduction of dW (K = packed rows) is split ACROSS the XCDs
+// and each XCD only ever touches the rows [~x T/8, ~(x+1) T/8) of dP and X (both products!): they cross the fabric once
+// and stay in that XCD's 4 MB L2, instead of every XCD streaming full-K column strips for "its" dW tiles.  The price is one
+// partial dW slab per XCD (plain tile stores), summed by the gradient-unpacking launch that follows anyway.  The boundaries
+// are a pure function of the device-side extents, shared by the kernel and that reduction.
+constexpr int G3_XSEG = 8;
+struct G3Plan {
+    int a[G3_XSEG + 1];          // dX row-block boundaries
+    int c[G3_XSEG + 1];          // dW k-step boundaries
+};
+__host__ __device__ inline void g3_plan(int RB, int CT0, int ipt0, int T1, int ipt1, int G, G3Plan& pl) {
+    const long total = (long)RB * CT0 * ipt0 + (long)T1 * ipt1;
+    const int R = 4 * G;
+    const long per = total / R, rem = total - per * R;
+    const int qn = G >> 3, rn = G & 7;
+    pl.a[0] = 0;
+    pl.c[0] = 0;
+    for (int x = 1; x < G3_XSEG; ++x) {
+        const long L = 4L * (x * qn + (x < rn ? x : rn));            // first wave range of XCD x
+        const long tgt = L * per + (L < rem ? L : rem);              // iteration where that range starts
+        int a = (int)(((long)RB * L + R / 2) / R);                   // row blocks in proportion to the waves in front
+        a = a < pl.a[x - 1] ? pl.a[x - 1] : (a > RB ? RB : a);
+        long cc = T1 > 0 ? (tgt - (long)a * CT0 * ipt0 + T1 / 2) / T1 : 0;
+        if (tgt - (long)a * CT0 * ipt0 < 0) cc = 0;
+        int c = (int)(cc > ipt1 ? ipt1 : cc);
+        c = c < pl.c[x - 1] ? pl.c[x - 1] : c;
+        pl.a[x] = a;
+        pl.c[x] = c;
+    }
+    pl.a[G3_XSEG] = RB;
+    pl.c[G3_XSEG] = ipt1;
+}
 size_t gemm3_workspace_bytes();
+bool gemm3_xk_enabled();          // the schedule above is used for the paired backward products (EAGCN_GEMM3_XK=0 turns it off)
+int gemm3_grid();
 // the hand-off flags must be zero when a launch starts; every launch leaves them zero again, so ONE clear at the start of
 // an API call (a tiny kernel, also under capture) covers all its launches on the same workspace
 // (`zero`: optionally `nzero` doubles cleared by the same launch -- the head's BatchNorm sums)
@@ -116,7 +153,9 @@ struct ZeroJob { unsigned* u; int nu; double* d; int nd; };
 int gemm3_zero_job(void* workspace, size_t bytes, double* zero, int nzero, ZeroJob* out);
 bool gemm3_ok(const GemmDesc& g);
 int launch_gemm3(const GemmDesc& g, const DwScatter* sc, void* workspace, size_t bytes, hipStream_t s);
-int launch_gemm3_pair(const GemmDesc& dx, const GemmDesc& dw, const DwScatter* sc, void* workspace, size_t bytes, hipStream_t s);
+// xk_slab > 0: XCD-local schedule, dW leaves as G3_XSEG partial slabs dw.C + x * xk_slab (sc must be null)
+int launch_gemm3_pair(const GemmDesc& dx, const GemmDesc& dw, const DwScatter* sc, void* workspace, size_t bytes, hipStream_t s,
+                      size_t xk_slab = 0);
 
 // ---- model head (head2.hip) -----------------------------------------------------------------------------------------------
 struct HeadDrop { int on; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev; };

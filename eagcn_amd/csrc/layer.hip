@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
                                                             int ld_in, int fp, const float* __restrict__ dWcat,
                                                             int nsplit, size_t slab, const double* __restrict__ datt,
                                                             int nedge, const float* __restrict__ rsig, int wblocks,
-                                                            const int32_t* __restrict__ meta) {
+                                                            const int32_t* __restrict__ meta, int xk_G) {
     nedge = nedge < 0 ? -nedge : min(nedge, (meta[EAGCN_META_T] + 15) / 16);   // edge-gradient workgroups that had rows (< 0: all wrote)
     nsplit = max(1, min(nsplit, meta[EAGCN_META_T] >> 7));     // split-K partials actually written (gemm.hip eff_splits)
     if ((int)blockIdx.x < wblocks) {
@@ -517,6 +517,22 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
         const int k = col_view(vc, cp), f = cp - vc.off[k];
         const int fi = packed_to_exact(in, ip);
         if (fi < 0 || f >= vc.width[k]) return;
+        if (xk_G > 0) {
+            // partial slabs of the XCD-local paired GEMM (gemm3.hip, kernels.h g3_plan): slab x exists iff segment x holds
+            // k-steps of the dW product; summed in segment order (deterministic)
+            const int T = meta[EAGCN_META_T];
+            G3Plan pl;
+            g3_plan((T + 63) / 64, (ld_in + 63) / 64, max(1, (fp + 15) / 16), ((ld_in + 63) / 64) * ((fp + 63) / 64),
+                    max(1, (T + 15) / 16), xk_G, pl);
+            float v[G3_XSEG];
+#pragma unroll
+            for (int x = 0; x < G3_XSEG; ++x) v[x] = pl.c[x + 1] > pl.c[x] ? dWcat[(size_t)x * slab + e] : 0.0f;
+            float t = 0.0f;
+#pragma unroll
+            for (int x = 0; x < G3_XSEG; ++x) t += v[x];
+            gp.dW[k][(size_t)fi * vc.width[k] + f] = T > 0 ? t : 0.0f;
+            return;
+        }
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
         int z = 0;
         for (; z + 4 <= nsplit; z += 4) {
@@ -682,7 +698,7 @@ static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, Bw
     t.dY = c.take<float>((size_t)std::max(b->T, 1) * d.fp);
     t.dP = c.take<float>((size_t)std::max(b->T, 1) * d.fp);
     t.cc = c.take<float>((size_t)2 * d.fp);
-    t.dWcat = c.take<float>(d.wslab * d.nsplit);
+    t.dWcat = c.take<float>(d.wslab * std::max(d.nsplit, G3_XSEG));
     t.slab = c.take<double>((size_t)d.gxb * d.fp * 2);
     t.slab_da = c.take<double>((size_t)d.gxb * cdiv(d.fp, 1024) * EAGCN_MAX_VIEWS);
     t.datt = c.take<double>((size_t)std::max(edge_grid_x(b), d.sslabs) * EAGCN_MAX_VIEWS * EDGE_SLAB);
@@ -977,7 +993,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             EAGCN_LAUNCH_CHECK();
         }
     }
-    int nsplit = 0, nedge = 0;
+    int nsplit = 0, nedge = 0, xk_G = 0;
     // side = stream for work that is off the dX critical path (edge gradients, dW product, gradient
     // unpacking); with no auxiliary stream everything stays in order on s
     hipStream_t side = w->aux_stream ? (hipStream_t)w->aux_stream : s;
@@ -1021,8 +1037,15 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) dsc.dW[k] = gp.dW[k];
         dsc.vc = d.vc;
         dsc.in = in;
-        if (use3 && !forked && dx && gemm3_layer(d.ld_in) && gemm3_ok(gw) && gemm3_ok(gx)) {
-            // wave-autonomous balanced kernel: dX and dW in one launch, dW written straight into the per-view gradients
+        if (use3 && !forked && dx && gemm3_layer(d.ld_in) && gemm3_ok(gw) && gemm3_ok(gx) && gemm3_xk_enabled()) {
+            // wave-autonomous balanced kernel, XCD-local schedule: dX and dW in one launch, every XCD works on its own eighth of
+            // the packed rows for BOTH products; dW leaves as one partial slab per XCD, summed by unpack_grads below
+            rc = launch_gemm3_pair(gx, gw, nullptr, sc.gws, gemm3_workspace_bytes(), s, d.wslab);
+            if (rc) return rc;
+            nsplit = 1;
+            xk_G = gemm3_grid();
+        } else if (use3 && !forked && dx && gemm3_layer(d.ld_in) && gemm3_ok(gw) && gemm3_ok(gx)) {
+            // ... tile-contiguous schedule: dW written straight into the per-view gradients
             rc = launch_gemm3_pair(gx, gw, &dsc, sc.gws, gemm3_workspace_bytes(), s);
             if (rc) return rc;
             nsplit = 0;                                   // no partial slabs: unpack_grads only reduces the edge partials
@@ -1046,7 +1069,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         ProfScope psu(PROF_PACK, side);
         unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, side>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
                                                                                     nsplit, d.wslab, sc.datt, nedge, sc.rsig,
-                                                                                    wblocks, b->meta);
+                                                                                    wblocks, b->meta, xk_G);
         EAGCN_LAUNCH_CHECK();
     }
     // join: the caller reuses the scratch block (dY', dP, partial slabs) for the next layer

@@ -379,6 +379,15 @@ int eagcn_gemm_f32_sk(int ta, int tb, int M, int N, int K, const float* A, int l
 int eagcn_gemm_pair_sk(int M0, int N0, int K0, const float* A0, int lda0, const float* B0, int ldb0, float* C0, int ldc0,
                        int M1, int N1, int K1, const float* A1, int lda1, const float* B1, int ldb1, float* C1, int ldc1,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* The same pair on the XCD-local schedule used by the layer backward: the long reduction of the second product is split across
+ * the eight XCDs (each XCD reads only its own eighth of the K rows, for both products); C1 receives 8 partial slabs, `slab`
+ * floats apart, whose sum (in slab order) is the product. */
+int eagcn_gemm_pair_sk_slabs(int M0, int N0, int K0, const float* A0, int lda0, const float* B0, int ldb0, float* C0, int ldc0,
+                             int M1, int N1, int K1, const float* A1, int lda1, const float* B1, int ldb1, float* C1, int ldc1,
+                             size_t slab, void* workspace, size_t workspace_bytes, void* stream);
+/* host-side mirror of that schedule's partition: a[9] = row-block (64 rows) boundaries of the first product per XCD segment,
+ * c[9] = k-step (16 rows) boundaries of the second; wgs = 0: the library's grid */
+int eagcn_gemm_sk_plan(int M0, int N0, int K0, int M1, int N1, int K1, int wgs, int* a, int* c);
 int eagcn_gemm_sk_timeouts(void);   /* hand-offs that gave up waiting since load (must stay 0); synchronising device read */
 /* A hand-off that times out is FATAL, never silent: the owner wave poisons its output tile with NaN and stores 1 into a
  * sticky word in host-mapped memory.  eagcn_gemm_sk_failed() reads that word without synchronising (the graph-replay host

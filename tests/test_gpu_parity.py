@@ -211,6 +211,36 @@ def test_gemm_f32(ta, tb, M, N, K):
     assert rel_err(c.double().cpu(), ref.cpu()) < 2e-6
 
 
+@pytest.mark.parametrize('T,FIN,FP', [(4809, 400, 704), (64, 400, 704), (37, 128, 144), (1000, 256, 80), (20003, 400, 704),
+                                      (5, 128, 16), (2500, 1264, 320)])
+def test_gemm_pair_xcd_local_schedule(T, FIN, FP):
+    """The paired backward products of a layer (dX = dP.W^T, dW = X^T.dP; reference layers.py:40 under autograd) on the
+    XCD-local schedule of csrc/gemm3.hip: dX complete, dW as eight partial slabs whose sum is the product -- against fp64,
+    incl. row counts that are not multiples of 16 / 64, fewer rows than segments, and the stand-alone pair entry."""
+    import ctypes as C
+    from eagcn_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(3)
+    x, w, dp = torch.randn(T, FIN, device='cuda'), torch.randn(FIN, FP, device='cuda'), torch.randn(T, FP, device='cuda')
+    ws = torch.empty(lib.eagcn_gemm_sk_workspace_bytes(), dtype=torch.uint8, device='cuda')
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dx = torch.full((T, FIN), float('nan'), device='cuda')
+    slabs = torch.full((8, FIN, FP), float('nan'), device='cuda')
+    dx_ref, dw_ref = dp.double() @ w.double().t(), x.double().t() @ dp.double()
+    for rep in range(3):                                   # flags left clean by every launch
+        _lib.check(lib.eagcn_gemm_pair_sk_slabs(T, FIN, FP, dp.data_ptr(), FP, w.data_ptr(), FP, dx.data_ptr(), FIN,
+                                                FIN, FP, T, x.data_ptr(), FIN, dp.data_ptr(), FP, slabs.data_ptr(), FP,
+                                                FIN * FP, ws.data_ptr(), ws.numel(), s), 'pair_sk_slabs')
+        assert rel_err(dx.double().cpu(), dx_ref.cpu()) < 2e-6
+        assert rel_err(slabs.double().sum(0).cpu(), dw_ref.cpu()) < 2e-6
+    dw = torch.full((FIN, FP), float('nan'), device='cuda')
+    _lib.check(lib.eagcn_gemm_pair_sk(T, FIN, FP, dp.data_ptr(), FP, w.data_ptr(), FP, dx.data_ptr(), FIN,
+                                      FIN, FP, T, x.data_ptr(), FIN, dp.data_ptr(), FP, dw.data_ptr(), FP,
+                                      ws.data_ptr(), ws.numel(), s), 'pair_sk')
+    assert rel_err(dx.double().cpu(), dx_ref.cpu()) < 2e-6 and rel_err(dw.double().cpu(), dw_ref.cpu()) < 2e-6
+    assert lib.eagcn_gemm_sk_timeouts() == 0
+
+
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize('M,N,K', [(1000, 704, 400), (4608, 400, 704), (133, 72, 100)])
 def test_gemm_bf16x6_mode(ta, tb, M, N, K):

@@ -253,3 +253,29 @@ def test_flat_gradient_layout_is_16_byte_aligned_per_parameter():
     for o, n in zip(p.offsets, p.sizes):
         assert not seen[o:o + n].any()
         seen[o:o + n] = True
+
+
+def test_xcd_local_gemm_schedule_partitions_the_iteration_space():
+    """csrc/kernels.h g3_plan (the XCD-local schedule of the paired backward products): the eight segments tile the row blocks
+    of dX and the k-steps of dW exactly once, in order, and each segment's share of the work follows its share of the waves."""
+    import ctypes as C
+    from eagcn_amd import _lib
+    lib = _lib.load()
+    cases = [(4809, 400, 704, 400, 704, 4809, 256), (19200, 400, 704, 400, 704, 19200, 256), (25000, 2500, 6320, 2500, 6320, 25000, 256),
+             (100, 128, 128, 128, 128, 100, 256), (64, 400, 704, 400, 704, 64, 256), (4809, 400, 704, 400, 704, 4809, 100),
+             (4809, 400, 704, 400, 704, 4809, 8), (1, 128, 16, 128, 16, 1, 256), (70000, 128, 144, 128, 144, 70000, 304)]
+    for M0, N0, K0, M1, N1, K1, G in cases:
+        a, c = (C.c_int * 9)(), (C.c_int * 9)()
+        assert lib.eagcn_gemm_sk_plan(M0, N0, K0, M1, N1, K1, G, a, c) == 0
+        a, c = list(a), list(c)
+        RB, CT0, ipt0 = -(-M0 // 64), -(-N0 // 64), max(1, -(-K0 // 16))
+        T1, ipt1 = -(-M1 // 64) * -(-N1 // 64), max(1, -(-K1 // 16))
+        assert a[0] == 0 and a[8] == RB and c[0] == 0 and c[8] == ipt1, (a, c)
+        assert all(a[i] <= a[i + 1] for i in range(8)) and all(c[i] <= c[i + 1] for i in range(8)), (a, c)
+        total = RB * CT0 * ipt0 + T1 * ipt1
+        if total > 64 * G:       # a segment starts within half a row of k-steps (T1 / 2 iterations) of its XCD's first wave range
+            R, qn, rn = 4 * G, G // 8, G % 8
+            per, rem = divmod(total, R)
+            for x in range(9):
+                L = 4 * (x * qn + min(x, rn))
+                assert abs(a[x] * CT0 * ipt0 + T1 * c[x] - (L * per + min(L, rem))) <= T1 // 2 + 1, (x, a, c)

@@ -85,6 +85,24 @@ if CHECK:
     e2 = err(dw, x.double().t() @ dp.double())
 us = timeit(pair)
 res.append('pair err %.1e/%.1e %7.1f us %6.1f TF' % (e1, e2, us, 4.0 * T * FIN * FP / us / 1e6))
+# the pair on the XCD-local schedule (8 partial dW slabs + their sum, which the step's unpack_grads launch performs)
+slabs = torch.empty(8, FIN, FP, device='cuda')
+
+
+def pair_xk():
+    _lib.check(lib.eagcn_gemm_pair_sk_slabs(T, FIN, FP, dp.data_ptr(), FP, w.data_ptr(), FP, dx.data_ptr(), FIN,
+                                            FIN, FP, T, x.data_ptr(), FIN, dp.data_ptr(), FP, slabs.data_ptr(), FP,
+                                            FIN * FP, ws.data_ptr(), ws.numel(), s), 'pair_xk')
+
+
+dx.zero_()
+pair_xk()
+if CHECK:
+    e1 = err(dx, dp.double() @ w.double().t())
+    e2 = err(slabs.sum(0), x.double().t() @ dp.double())
+us = timeit(pair_xk)
+us_sum = timeit(lambda: slabs.sum(0))
+res.append('pair XCD-local err %.1e/%.1e %7.1f us incl. slab memset (%6.1f TF), slab sum %.1f us' % (e1, e2, us, 4.0 * T * FIN * FP / us / 1e6, us_sum))
 # the same launch with COLD caches (a 768 MB read-modify-write between the calls evicts L2 and the 256 MB MALL), and with
 # a small kernel stream in front of it as in a training step (launch right behind other work instead of back to back)
 big = torch.zeros(192 << 20, device='cuda')
