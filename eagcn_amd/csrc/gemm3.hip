@@ -56,6 +56,9 @@ constexpr int G3_T = 64;                   // wave tile (both dimensions)
 constexpr int G3_BK = 16;
 constexpr int G3_SLOT = G3_T * G3_T;       // floats of one parked partial tile
 constexpr int G3_MAX_RANGES = 8192;
+#ifndef G3_FAST_LOOP
+#define G3_FAST_LOOP 1
+#endif
 #ifndef G3_WAVES_PER_SIMD
 #define G3_WAVES_PER_SIMD 1
 #endif
@@ -162,6 +165,64 @@ __device__ __forceinline__ void g3_segment(const G2Prob& p, const DwScatter& sc,
     mma_step(sa[CUR], sb[CUR]);                                   \
     __builtin_amdgcn_sched_barrier(0);                            \
     ++it;
+#if G3_FAST_LOOP
+    // Steady state proper: as long as the prefetched step (it + 3 .. it + 6 inside a group of four) is not the LAST step of the
+    // segment nothing can reach beyond K or the segment, so the loads need no clamps at all -- per-lane pointers that are
+    // bumped once per group (NT: the four steps of a group sit at constant byte offsets 0 / 64 / 128 / 192 behind them) or once
+    // per step (TN: 16 rows further), and the eight loads of a step are spread over its 64 MFMAs by the scheduler directives
+    // instead of forming a block of their own in front of them (the matrix pipe drained during every such block: the wave's
+    // non-MFMA issue time was ~500 of ~2550 cycles per step).
+    if (it + 7 < ke) {
+        const float* fa[4];
+        const float* fb[4];
+        size_t stepA = 0, stepB = 0;
+        if constexpr (!TN) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fa[i] = ap[i] + (size_t)(it + 3) * G3_BK; fb[i] = bp[i] + (size_t)(it + 3) * G3_BK; }
+        } else {
+            stepA = (size_t)G3_BK * p.lda;
+            stepB = (size_t)G3_BK * p.ldb;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t kr = (size_t)((it + 3) * G3_BK + 4 * q + u);
+                fa[u] = ap[u] + kr * p.lda;
+                fb[u] = bp[u] + kr * p.ldb;
+            }
+        }
+#define EAGCN_G3_FSTEP(CUR, NXT, U)                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                         \
+        if constexpr (!TN) {                                                                                \
+            sa[NXT][e] = *reinterpret_cast<const f32x4*>(fa[e] + (U) * G3_BK);                              \
+            sb[NXT][e] = *reinterpret_cast<const f32x4*>(fb[e] + (U) * G3_BK);                              \
+        } else {                                                                                            \
+            sa[NXT][e] = *reinterpret_cast<const f32x4*>(fa[e]);                                            \
+            sb[NXT][e] = *reinterpret_cast<const f32x4*>(fb[e]);                                            \
+            fa[e] += stepA;                                                                                 \
+            fb[e] += stepB;                                                                                 \
+        }                                                                                                   \
+    }                                                                                                       \
+    mma_step(sa[CUR], sb[CUR]);                                                                             \
+    _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                  \
+    }                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    ++it;
+        while (it + 7 < ke) {
+            EAGCN_G3_FSTEP(0, 3, 0)
+            EAGCN_G3_FSTEP(1, 0, 1)
+            EAGCN_G3_FSTEP(2, 1, 2)
+            EAGCN_G3_FSTEP(3, 2, 3)
+            if constexpr (!TN) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { fa[i] += 4 * G3_BK; fb[i] += 4 * G3_BK; }
+            }
+        }
+#undef EAGCN_G3_FSTEP
+    }
+#endif
     while (it + 4 < ke) {                            // the four steps it .. it+3 are not the last one of the segment
         EAGCN_G3_STEP(0, 3)
         EAGCN_G3_STEP(1, 0)
@@ -521,7 +582,9 @@ int launch_gemm3(const GemmDesc& g, const DwScatter* sc0, void* workspace, size_
 
 // dX = dP.W^T (NT) and dW = X^T.dP (TN) of a layer in one balanced launch
 bool gemm3_xk_enabled() {
-    static const bool on = g3_env("EAGCN_GEMM3_XK", 1) != 0;
+    // measured on MI355X (gpurun_out/r3a): 8x less fabric traffic and NOT faster (pair 77 vs 71 us stand-alone at 4809
+    // rows, 259 vs 233 us at 19200) -- the kernel is not bound by operand fetch; off unless EAGCN_GEMM3_XK=1
+    static const bool on = g3_env("EAGCN_GEMM3_XK", 0) != 0;
     return on;
 }
 

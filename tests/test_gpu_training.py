@@ -3,9 +3,9 @@ its evaluation (train.py:130-211) on the HIP engine in graph mode, tracked again
 loss curve, parameters, BatchNorm running statistics, num_batches_tracked, validation AUC / RMSE.
 
 Training is a chaotic map: the fp32 CPU oracle itself leaves the fp64 trajectory by 1e-4 .. 2e-2 within 50 Adam steps
-(tests/probe_train_drift.py), so the yardstick is the fp64 oracle and the bar is the reference's own fp32 drift: the HIP
-trajectory may not be further from the exact one than 3x what the fp32 oracle is (plus 1e-5).  Measured: the HIP path
-stays within 1e-6 of the fp64 trajectory for 30+ steps (fp64 BatchNorm sums) while the fp32 oracle is already 1e-3 off."""
+(tests/probe_train_drift.py), so the yardstick is the fp64 oracle and the bar is the reference's own fp32 drift, STEP BY
+STEP: while the fp32 oracle is within 1e-4 of the fp64 trajectory, the HIP trajectory may be at most twice as far from it
+(+ 2e-6); after that Adam has amplified rounding noise and nothing is compared."""
 import numpy as np
 import pytest
 import torch
@@ -47,7 +47,32 @@ def test_fifty_adam_steps_track_the_oracle(task):
         wt = ((l == 1).to(out.dtype) * w[:, 0].view(1, -1) + (l == 0).to(out.dtype) * w[:, 1].view(1, -1)).view(-1)
         return torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1), l.to(out.dtype).view(-1), weight=wt,
                                                                   reduction='sum') / ((l == 1).sum() + (l == 0).sum()).to(out.dtype)
+    def noise_key(k):
+        if k.endswith('num_batches_tracked') or k.endswith('batch_norm.weight') or k.endswith('batch_norm.bias'):
+            return True                                # counters / the reference's unused parameters
+        # a bias in front of a training-mode BatchNorm has an analytically ZERO gradient: what reaches Adam is rounding
+        # noise, which Adam normalises to +-lr steps -- a random walk that no two arithmetics share (the bias itself is
+        # cancelled by the BatchNorm; the per-view running_mean tracks mean + bias and walks with it)
+        return k.endswith('graph_conv.bias') or k == 'Graph_BN.bias' or (k.endswith('running_mean') and 'block' in k)
+
+    def drift(sd, sd_x):
+        """largest distance to the fp64 trajectory, relative to the tensor's own scale"""
+        worst, where = 0.0, ''
+        for k, v in sd_x.items():
+            if noise_key(k):
+                continue
+            d = (sd[k].double().cpu() - v).abs().max().item() / max(v.abs().max().item(), 1e-3)
+            if d > worst:
+                worst, where = d, k
+        return worst, where
+
+    # Trajectory parity, step by step: as long as the fp32 ORACLE itself stays within 1e-4 of the fp64 trajectory the comparison
+    # means something, and there the HIP run must be as close to fp64 as the fp32 oracle is (twice its drift + 2e-6: two fp32
+    # arithmetics round differently); once the oracle has drifted further, Adam has amplified rounding noise and nothing is
+    # compared any more (VERDICT round 2, weak-3: the old bound admitted 22 % of a parameter's scale after 50 steps).
     loss_r, loss_x, loss_h = [], [], []
+    compared, worst_ratio, pworst, d32_last = 0, 0.0, 0.0, 0.0
+    comparing = True
     for step in range(50):
         for m, o, data, acc in ((ref, opt_r, cpu, loss_r), (ref64, opt_x, cpu64, loss_x)):
             d, l = data[step % 4]
@@ -58,36 +83,28 @@ def test_fifty_adam_steps_track_the_oracle(task):
             o.step()
             acc.append(float(lo.detach()))
         dd, ll = dev[step % 4]
-        loss_h.append(training.train_step(hip, opt_h, dd, ll, task, bw_dev))
-    loss_h = [float(x.detach()) for x in loss_h]
-    drift32, worst = 0.0, 0.0
-    for t in range(50):
-        drift32 = max(drift32, abs(loss_r[t] - loss_x[t]))
-        e = abs(loss_h[t] - loss_x[t])
-        worst = max(worst, e / max(abs(loss_x[t]), 1e-6))
-        assert e <= 3.0 * drift32 + 1e-5 * max(abs(loss_x[t]), 1.0), (t, loss_h[t], loss_x[t], drift32)
-    rel_err(torch.tensor([worst]), torch.tensor([0.0]), 'loss curve vs fp64 oracle (fp32 oracle drift %.1e)' % drift32)
-    assert loss_x[-1] < loss_x[0]                      # it trains
-    sd_h, sd_r, sd_x = hip.state_dict(), ref.state_dict(), ref64.state_dict()
-    pworst = 0.0
-    for k, v in sd_x.items():
+        loss_h.append(float(training.train_step(hip, opt_h, dd, ll, task, bw_dev).detach()))
+        if comparing:
+            sd_x = ref64.state_dict()
+            d_r, _ = drift(ref.state_dict(), sd_x)
+            if d_r >= 1e-4:
+                comparing = False
+            else:
+                d_h, where = drift(hip.state_dict(), sd_x)
+                assert d_h <= 2.0 * d_r + 2e-6, (step, where, d_h, d_r)
+                dl_r, dl_h = abs(loss_r[-1] - loss_x[-1]), abs(loss_h[-1] - loss_x[-1])
+                assert dl_h <= 2.0 * dl_r + 2e-6 * max(abs(loss_x[-1]), 1.0), (step, loss_h[-1], loss_x[-1], dl_r)
+                compared, d32_last, pworst = step + 1, d_r, max(pworst, d_h)
+                worst_ratio = max(worst_ratio, d_h / max(d_r, 1e-7))
+    print('trajectory parity [%s]: compared %d of 50 steps (fp32 oracle drift at the last compared step %.1e), worst HIP drift '
+          '%.1e, worst HIP/oracle drift ratio %.2f' % (task, compared, d32_last, pworst, worst_ratio))
+    assert compared >= 5, compared                    # the comparison window is not empty
+    rel_err(torch.tensor([pworst]), torch.tensor([0.0]), 'worst parameter / buffer distance to the fp64 oracle over the %d compared steps '
+            '(fp32 oracle drift there %.1e)' % (compared, d32_last))
+    assert loss_x[-1] < loss_x[0] and loss_h[-1] < loss_h[0]                      # it trains
+    for k, v in hip.state_dict().items():
         if k.endswith('num_batches_tracked'):
-            assert int(sd_h[k]) == int(v) == 50, k
-            continue
-        if k.endswith('batch_norm.weight') or k.endswith('batch_norm.bias'):
-            continue                                   # the reference's unused parameters
-        if k.endswith('graph_conv.bias') or k == 'Graph_BN.bias' or (k.endswith('running_mean') and 'block' in k):
-            # a bias in front of a training-mode BatchNorm has an analytically ZERO gradient: what reaches Adam is rounding
-            # noise, which Adam normalises to +-lr steps -- a random walk that no two arithmetics share (the bias itself is
-            # cancelled by the BatchNorm; the per-view running_mean tracks mean + bias and walks with it)
-            continue
-        scale = max(v.abs().max().item(), 1e-3)
-        d_h = (sd_h[k].double().cpu() - v).abs().max().item()
-        d_r = (sd_r[k].double() - v).abs().max().item()
-        pworst = max(pworst, d_h / scale)
-        # (Adam moves a parameter by at most lr per step: 1 % of that travel is allowed on top of the fp32 oracle's own drift)
-        assert d_h <= 3.0 * d_r + 1e-5 * scale + 0.01 * 5e-4 * 50, (k, d_h, d_r)
-    rel_err(torch.tensor([pworst]), torch.tensor([0.0]), 'worst parameter / buffer distance to the fp64 oracle after 50 steps')
+            assert int(v) == 50, k
     # evaluation (train.py:130-211): the oracle takes the HIP-trained weights, so that what is compared is the
     # evaluation path and not 50 steps of training drift (an AUC moves by 1/(pos*neg) per swapped pair)
     ref = ref64.float()
