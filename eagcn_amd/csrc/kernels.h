@@ -31,6 +31,53 @@ int edge_grid_x(const eagcn_batch* b);
 int launch_edge_grad(const EdgeArgs& a, hipStream_t s);
 int launch_agg_edge(AggArgs a, const EdgeArgs& e, hipStream_t s);   // transposed aggregation + edge gradients, one grid
 
+// ---- molecule-staged backward (mol.hip): BatchNorm-backward affine + transposed aggregation + edge gradients + their final
+//      reduction in one launch -------------------------------------------------------------------------------------------------
+struct MolBwdArgs {
+    eagcn_batch bt;
+    ViewCols vc;
+    const float* dH; const float* Y; const float* P; float* dP; int ld;   // [T][ld], ld = Fp
+    const float* bn;             // [4][Fp] BatchNorm table of the forward (BN_SC ..)
+    const float* cc;             // [2][Fp] mean dH, mean dH * xhat (zeros in eval mode)
+    const float* sig; const float* rsig; const float* rscale;
+    double* eacc;                // [8][K][EDGE_SLAB] fp64 accumulators: zero on entry, left zero
+    unsigned* ticket;            // zero on entry, left zero
+    float* datt_w[EAGCN_MAX_VIEWS];
+    float* dself_r[EAGCN_MAX_VIEWS];
+    const float* rel_vec[EAGCN_MAX_VIEWS]; int rel_c[EAGCN_MAX_VIEWS]; int channels[EAGCN_MAX_VIEWS];
+    int nchunk, CT;              // set by the launcher
+};
+bool mol_bwd_ok(const eagcn_batch* b, const ViewCols& vc);     // the molecule slices fit the LDS budget (and EAGCN_MOLBWD != 0)
+int launch_mol_bwd(MolBwdArgs a, hipStream_t s);
+
+// ---- self-cleaning accumulator block ------------------------------------------------------------------------------------------
+// Kernels that finish a grid-wide reduction themselves (last workgroup by ticket) accumulate into fp64 copies that must be ZERO
+// when they start and that their last workgroup leaves zero again (it drains them with atomic exchanges).  The block sits right
+// behind the GEMM hand-off workspace in every layer scratch carving -- same place for every layer and both directions --, has a
+// fixed size, and is cleared together with the hand-off flags once per API call (the flags are the last words of that workspace).
+constexpr int ACC_TICKETS = 64;               // unsigned words
+constexpr int ACC_COPIES = 8;
+constexpr int ACC_FP_MAX = 8192;              // widest layer (padded columns) the BatchNorm accumulators serve
+struct AccBlock {
+    unsigned* ticket;            // [ACC_TICKETS]
+    double* eacc;                // [ACC_COPIES][EAGCN_MAX_VIEWS][EDGE_SLAB]
+    double* bnacc;               // [ACC_COPIES][ACC_FP_MAX][2]
+};
+inline size_t acc_block_bytes() {
+    return align256(ACC_TICKETS * sizeof(unsigned)) + align256((size_t)ACC_COPIES * EAGCN_MAX_VIEWS * EDGE_SLAB * sizeof(double)) +
+           align256((size_t)ACC_COPIES * ACC_FP_MAX * 2 * sizeof(double));
+}
+inline AccBlock acc_block(void* base) {
+    AccBlock a;
+    char* p = (char*)base;
+    a.ticket = (unsigned*)p;
+    p += align256(ACC_TICKETS * sizeof(unsigned));
+    a.eacc = (double*)p;
+    p += align256((size_t)ACC_COPIES * EAGCN_MAX_VIEWS * EDGE_SLAB * sizeof(double));
+    a.bnacc = (double*)p;
+    return a;
+}
+
 // ---- bond-list aggregation (sagg.hip) -------------------------------------------------------------------------------
 enum { BN_SC = 0, BN_SH, BN_MU, BN_INV };     // rows of a layer's [4][Fp] BatchNorm coefficient table
 struct SAggFwd {

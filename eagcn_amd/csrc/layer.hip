@@ -655,7 +655,7 @@ static bool gemm3_layer(int ld_in) {
 }
 
 struct Packed { float *Wcat, *WcatT, *colp, *sig, *rsig; };
-struct FwdScratch { void* gws; float *Wcat, *WcatT, *colp, *sig, *rsig; double* stats; };
+struct FwdScratch { void* gws; void* acc; float *Wcat, *WcatT, *colp, *sig, *rsig; double* stats; };
 static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
     Carver c(base);
     Packed t;
@@ -670,6 +670,7 @@ static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
 struct BwdScratch {
     void* gws;                   // GEMM hand-off workspace: FIRST in both carvings, so that every layer of a model and both
                                  // directions share one region (one flag clear per API call, kernels.h gemm3_clear_flags)
+    void* acc;                   // self-cleaning accumulator block (kernels.h): right behind it, same place everywhere
     float *Wcat, *WcatT, *colp, *sig, *rsig, *dY, *dP, *cc, *dWcat;
     double *slab, *slab_da, *datt;
 };
@@ -677,6 +678,7 @@ static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, Fw
     Carver c(base);
     FwdScratch t;
     t.gws = c.take<char>(gemm3_workspace_bytes());
+    t.acc = c.take<char>(acc_block_bytes());
     t.Wcat = c.take<float>(d.wslab);
     t.WcatT = c.take<float>(d.wslab);
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
@@ -690,6 +692,7 @@ static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, Bw
     Carver c(base);
     BwdScratch t;
     t.gws = c.take<char>(gemm3_workspace_bytes());
+    t.acc = c.take<char>(acc_block_bytes());
     t.Wcat = c.take<float>(d.wslab);
     t.WcatT = c.take<float>(d.wslab);
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
@@ -967,6 +970,8 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     const int rows = b->T + ba.nvirt;
     const int gxb = std::max(1, std::min(rows, d.gxb));
     const double M = (double)b->B * (double)b->N;
+    bool use_mol = false, edges_done = false;
+    const bool side_is_main = !w->aux_stream || (hipStream_t)w->aux_stream == s;
     {
         ProfScope ps(PROF_BN, s);
         const int ny = cdiv(d.fp, 1024);
@@ -988,7 +993,10 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             bn_bwd_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
                                                                         d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb);
         EAGCN_LAUNCH_CHECK();
-        if (b->T > 0 && !sagg_enabled()) {        // (the bond-list aggregation applies this affine while it stages dH)
+        // molecule-staged backward (mol.hip): the affine below, the transposed aggregation, the edge gradients and their final
+        // reduction in ONE launch
+        use_mol = b->T > 0 && !sagg_enabled() && side_is_main && mol_bwd_ok(b, d.vc);
+        if (b->T > 0 && !sagg_enabled() && !use_mol) {        // (the bond-list aggregation applies this affine while it stages dH)
             bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
             EAGCN_LAUNCH_CHECK();
         }
@@ -1007,7 +1015,21 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         e.rsig = sc.rsig; e.rscale = w->rscale; e.datt = sc.datt;
         static const bool colaunch = [] { const char* v = getenv("EAGCN_NO_COLAUNCH"); return !(v && v[0] == '1'); }();
         nedge = edge_grid_x(b);
-        if (sagg_enabled()) {
+        if (use_mol) {
+            const AccBlock ab = acc_block(sc.acc);
+            MolBwdArgs ma;
+            ma.bt = *b; ma.vc = d.vc; ma.dH = sc.dY; ma.Y = w->Y; ma.P = w->P; ma.dP = sc.dP; ma.ld = d.fp;
+            ma.bn = w->bn; ma.cc = sc.cc; ma.sig = sc.sig; ma.rsig = sc.rsig; ma.rscale = w->rscale;
+            ma.eacc = ab.eacc; ma.ticket = ab.ticket;
+            for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) {
+                ma.datt_w[k] = gp.datt_w[k]; ma.dself_r[k] = gp.dself_r[k];
+                ma.rel_vec[k] = pp.rel_vec[k]; ma.rel_c[k] = pp.rel_c[k]; ma.channels[k] = pp.channels[k];
+            }
+            ma.nchunk = 1; ma.CT = 1;
+            rc = launch_mol_bwd(ma, s);
+            if (rc) return rc;
+            edges_done = true;                            // d att.weight / d self_r are final: nothing left for unpack_grads
+        } else if (sagg_enabled()) {
             // transposed aggregation + edge gradients + BatchNorm-backward affine in one kernel over the bond lists
             SAggBwd sa;
             sa.bt = *b; sa.vc = d.vc; sa.fp = d.fp; sa.dH = sc.dY; sa.Y = w->Y; sa.P = w->P; sa.bn = w->bn; sa.cc = sc.cc;
@@ -1065,12 +1087,17 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             EAGCN_HIP(hipMemsetAsync(gp.dW[k], 0, (size_t)d.fin * p->width[k] * sizeof(float), side));
     }
     {
+        // reduction of the split-K dW slabs and of the edge-gradient partials; with the molecule-staged backward the latter are
+        // final already, and a layer on the balanced GEMM has no dW slabs either: then nothing is launched at all
         const int wblocks = nsplit > 0 ? cdiv((int)d.wslab, 256) : 0;
-        ProfScope psu(PROF_PACK, side);
-        unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, side>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
-                                                                                    nsplit, d.wslab, sc.datt, nedge, sc.rsig,
-                                                                                    wblocks, b->meta, xk_G);
-        EAGCN_LAUNCH_CHECK();
+        const int eblocks = edges_done ? 0 : cdiv(p->K * EDGE_SLAB, 16);
+        if (wblocks + eblocks > 0) {
+            ProfScope psu(PROF_PACK, side);
+            unpack_grads_kernel<<<wblocks + eblocks, 256, 0, side>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
+                                                                     nsplit, d.wslab, sc.datt, nedge, sc.rsig,
+                                                                     wblocks, b->meta, xk_G);
+            EAGCN_LAUNCH_CHECK();
+        }
     }
     // join: the caller reuses the scratch block (dY', dP, partial slabs) for the next layer
     if (forked) { rc = stream_after(s, side); if (rc) return rc; }

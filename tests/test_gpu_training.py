@@ -52,27 +52,24 @@ def test_fifty_adam_steps_track_the_oracle(task):
             return True                                # counters / the reference's unused parameters
         # a bias in front of a training-mode BatchNorm has an analytically ZERO gradient: what reaches Adam is rounding
         # noise, which Adam normalises to +-lr steps -- a random walk that no two arithmetics share (the bias itself is
-        # cancelled by the BatchNorm; the per-view running_mean tracks mean + bias and walks with it)
-        return k.endswith('graph_conv.bias') or k == 'Graph_BN.bias' or (k.endswith('running_mean') and 'block' in k)
+        # cancelled by the BatchNorm; the per-view running_mean tracks mean + bias and walks with it, and bn_den1's running
+        # mean is Graph_BN.bias . den1: the column means of a product of a zero-mean matrix)
+        return k.endswith('graph_conv.bias') or k == 'Graph_BN.bias' or (k.endswith('running_mean') and 'block' in k) or \
+            k == 'bn_den1.running_mean'
 
-    def drift(sd, sd_x):
-        """largest distance to the fp64 trajectory, relative to the tensor's own scale"""
-        worst, where = 0.0, ''
-        for k, v in sd_x.items():
-            if noise_key(k):
-                continue
-            d = (sd[k].double().cpu() - v).abs().max().item() / max(v.abs().max().item(), 1e-3)
-            if d > worst:
-                worst, where = d, k
-        return worst, where
+    def drifts(sd, sd_x):
+        """distance of every compared tensor to the fp64 trajectory, relative to the tensor's own scale"""
+        return {k: (sd[k].double().cpu() - v).abs().max().item() / max(v.abs().max().item(), 1e-3)
+                for k, v in sd_x.items() if not noise_key(k)}
 
-    # Trajectory parity, step by step: as long as the fp32 ORACLE itself stays within 1e-4 of the fp64 trajectory the comparison
-    # means something, and there the HIP run must be as close to fp64 as the fp32 oracle is (twice its drift + 2e-6: two fp32
-    # arithmetics round differently); once the oracle has drifted further, Adam has amplified rounding noise and nothing is
-    # compared any more (VERDICT round 2, weak-3: the old bound admitted 22 % of a parameter's scale after 50 steps).
+    # Trajectory parity, step by step and tensor by tensor: as long as the fp32 ORACLE's copy of a tensor stays within 1e-4 of
+    # the fp64 trajectory the comparison means something, and there the HIP run's copy must be as close to fp64 as the fp32
+    # oracle's is (twice its drift + 2e-6: two fp32 arithmetics round differently).  A tensor the oracle has lost (Adam turns
+    # rounding noise in a near-zero gradient into +-lr steps) is not compared any more from that step on (VERDICT round 2,
+    # weak-3: the old bound admitted 22 % of a parameter's scale after 50 steps).
     loss_r, loss_x, loss_h = [], [], []
-    compared, worst_ratio, pworst, d32_last = 0, 0.0, 0.0, 0.0
-    comparing = True
+    alive, window = None, {}
+    pworst, worst_ratio, n_cmp = 0.0, 0.0, 0
     for step in range(50):
         for m, o, data, acc in ((ref, opt_r, cpu, loss_r), (ref64, opt_x, cpu64, loss_x)):
             d, l = data[step % 4]
@@ -84,23 +81,29 @@ def test_fifty_adam_steps_track_the_oracle(task):
             acc.append(float(lo.detach()))
         dd, ll = dev[step % 4]
         loss_h.append(float(training.train_step(hip, opt_h, dd, ll, task, bw_dev).detach()))
-        if comparing:
+        if alive is None or alive:
             sd_x = ref64.state_dict()
-            d_r, _ = drift(ref.state_dict(), sd_x)
-            if d_r >= 1e-4:
-                comparing = False
-            else:
-                d_h, where = drift(hip.state_dict(), sd_x)
-                assert d_h <= 2.0 * d_r + 2e-6, (step, where, d_h, d_r)
-                dl_r, dl_h = abs(loss_r[-1] - loss_x[-1]), abs(loss_h[-1] - loss_x[-1])
-                assert dl_h <= 2.0 * dl_r + 2e-6 * max(abs(loss_x[-1]), 1.0), (step, loss_h[-1], loss_x[-1], dl_r)
-                compared, d32_last, pworst = step + 1, d_r, max(pworst, d_h)
-                worst_ratio = max(worst_ratio, d_h / max(d_r, 1e-7))
-    print('trajectory parity [%s]: compared %d of 50 steps (fp32 oracle drift at the last compared step %.1e), worst HIP drift '
-          '%.1e, worst HIP/oracle drift ratio %.2f' % (task, compared, d32_last, pworst, worst_ratio))
-    assert compared >= 5, compared                    # the comparison window is not empty
-    rel_err(torch.tensor([pworst]), torch.tensor([0.0]), 'worst parameter / buffer distance to the fp64 oracle over the %d compared steps '
-            '(fp32 oracle drift there %.1e)' % (compared, d32_last))
+            d_r = drifts(ref.state_dict(), sd_x)
+            if alive is None:
+                alive = set(d_r)
+            alive = {k for k in alive if d_r[k] < 1e-4}
+            if alive:
+                d_h = drifts(hip.state_dict(), sd_x)
+                for k in alive:
+                    assert d_h[k] <= 2.0 * d_r[k] + 2e-6, (step, k, d_h[k], d_r[k])
+                    window[k] = step + 1
+                    pworst = max(pworst, d_h[k])
+                    worst_ratio = max(worst_ratio, d_h[k] / max(d_r[k], 1e-6))
+                    n_cmp += 1
+                if len(alive) == len(d_r):             # the loss is compared while the oracle tracks EVERY tensor
+                    dl_r, dl_h = abs(loss_r[-1] - loss_x[-1]), abs(loss_h[-1] - loss_x[-1])
+                    assert dl_h <= 2.0 * dl_r + 2e-6 * max(abs(loss_x[-1]), 1.0), (step, loss_h[-1], loss_x[-1], dl_r)
+    wl = sorted(window.values())
+    print('trajectory parity [%s]: %d tensor-steps compared; per-tensor windows min %d / median %d / max %d of 50 steps; worst HIP '
+          'drift %.1e, worst HIP/oracle drift ratio %.2f' % (task, n_cmp, wl[0], wl[len(wl) // 2], wl[-1], pworst, worst_ratio))
+    assert len(wl) >= 70 and wl[len(wl) // 2] >= 5, wl        # the comparison is not vacuous
+    rel_err(torch.tensor([pworst]), torch.tensor([0.0]), 'worst HIP distance to the fp64 trajectory over %d compared tensor-steps '
+            '(median window %d steps)' % (n_cmp, wl[len(wl) // 2]))
     assert loss_x[-1] < loss_x[0] and loss_h[-1] < loss_h[0]                      # it trains
     for k, v in hip.state_dict().items():
         if k.endswith('num_batches_tracked'):
