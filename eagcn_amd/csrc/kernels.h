@@ -4,6 +4,16 @@
 
 namespace eagcn {
 
+// what the last workgroup of a forward aggregation needs to finish the BatchNorm of the layer itself (fused finalize)
+struct BnFin {
+    const float* colp;           // [CP_ROWS][Fp] packed per-column parameters (layer.hip)
+    float* run_mean[EAGCN_MAX_VIEWS];
+    float* run_var[EAGCN_MAX_VIEWS];
+    float* bn;                   // [4][Fp] table written for bn_apply and the backward
+    double M;                    // rows of the BatchNorm (B * N_pad; device-side override through meta[NLOG])
+    int training, batch_B;
+    float eps, momentum;
+};
 struct AggArgs {
     eagcn_batch bt;
     ViewCols vc;
@@ -14,6 +24,10 @@ struct AggArgs {
     float* rscale;               // [K][T] m_i/rowsum_i: written by forward, read by transposed
     double* stats;               // forward: [grid.x][Fp][2] partial (sum y, sum y^2)
     int nchunk;
+    // fused finalize (forward only; bnacc == nullptr: per-workgroup slabs in `stats` + a bn_finalize launch)
+    double* bnacc;               // [ACC_COPIES][2 * ACC_FP_MAX] self-cleaning accumulators
+    unsigned* ticket;
+    BnFin fin;
 };
 int agg_grid_x(const eagcn_batch* b);
 bool agg_ksplit(const eagcn_batch* b);
@@ -55,7 +69,8 @@ int launch_mol_bwd(MolBwdArgs a, hipStream_t s);
 // when they start and that their last workgroup leaves zero again (it drains them with atomic exchanges).  The block sits right
 // behind the GEMM hand-off workspace in every layer scratch carving -- same place for every layer and both directions --, has a
 // fixed size, and is cleared together with the hand-off flags once per API call (the flags are the last words of that workspace).
-constexpr int ACC_TICKETS = 64;               // unsigned words
+constexpr int ACC_TICKETS = 256;              // unsigned words: one group of TK_SHARDS + 1 counters per kernel family
+constexpr int TK_MOL_BWD = 0, TK_BN_BWD = 64, TK_AGG_FWD = 128;
 constexpr int ACC_COPIES = 8;
 constexpr int ACC_FP_MAX = 8192;              // widest layer (padded columns) the BatchNorm accumulators serve
 struct AccBlock {
@@ -63,6 +78,24 @@ struct AccBlock {
     double* eacc;                // [ACC_COPIES][EAGCN_MAX_VIEWS][EDGE_SLAB]
     double* bnacc;               // [ACC_COPIES][ACC_FP_MAX][2]
 };
+// Sharded arrival ticket: a single counter serialises its arrivals at ~12 ns each (thousands of workgroups -> tens of
+// microseconds), so workgroup x arrives at shard x % 32 and only the last of a shard arrives at the top counter.  Called by ONE
+// thread of every participating workgroup (x < nx; ny workgroups per x) after that workgroup's global atomics have been
+// performed (s_waitcnt vmcnt(0) in every wave + __syncthreads); returns true in exactly one workgroup, the last one, and leaves
+// all counters zero.
+constexpr int TK_SHARDS = 32;
+#ifdef __HIPCC__
+__device__ __forceinline__ bool ticket_arrive(unsigned* tk, int x, int nx, int ny) {
+    const int s = x & (TK_SHARDS - 1);
+    const unsigned members = (unsigned)((nx - s + TK_SHARDS - 1) / TK_SHARDS) * (unsigned)ny;
+    if (atomicAdd(&tk[s], 1u) != members - 1u) return false;
+    atomicExch(&tk[s], 0u);
+    const unsigned nsh = (unsigned)(nx < TK_SHARDS ? nx : TK_SHARDS);
+    if (atomicAdd(&tk[TK_SHARDS], 1u) != nsh - 1u) return false;
+    atomicExch(&tk[TK_SHARDS], 0u);
+    return true;
+}
+#endif
 inline size_t acc_block_bytes() {
     return align256(ACC_TICKETS * sizeof(unsigned)) + align256((size_t)ACC_COPIES * EAGCN_MAX_VIEWS * EDGE_SLAB * sizeof(double)) +
            align256((size_t)ACC_COPIES * ACC_FP_MAX * 2 * sizeof(double));

@@ -296,15 +296,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
         }
     }
-    // ---- ticket: the last workgroup drains the accumulators (atomic exchange: reads AND leaves zero) and writes the gradients --
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's atomics have been performed
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned t = atomicAdd(a.ticket, 1u);
-        last_s = t == gridDim.x * gridDim.y - 1u;
+    // ---- ticket: the last workgroup drains the accumulators (atomic exchange: reads AND leaves zero) and writes the gradients.
+    //      Only workgroups inside the device-side tile count take part (the grid is sized for the tile CAPACITY: tens of
+    //      thousands of arrivals on a counter cost more than the kernel); an empty batch is finished by workgroup (0, 0). ------
+    if ((int)blockIdx.x < ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's atomics have been performed
+        __syncthreads();
+        if (tid == 0) last_s = ticket_arrive(a.ticket, (int)blockIdx.x, ntiles, (int)gridDim.y) ? 1 : 0;
+        __syncthreads();
+        if (!last_s) return;
+    } else if (!(ntiles == 0 && blockIdx.x == 0 && blockIdx.y == 0)) {
+        return;
     }
-    __syncthreads();
-    if (!last_s) return;
     double* tot = reinterpret_cast<double*>(smem);              // [K][EDGE_SLAB] (the launcher sizes the dynamic LDS for it)
     const int K = a.vc.K;
     for (int e = tid; e < K * EDGE_SLAB; e += 256) {
@@ -337,7 +340,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             a.datt_w[kk][c - 1] = (float)t;
         }
     }
-    if (tid == 0) atomicExch(a.ticket, 0u);
 }
 
 // dynamic LDS of the kernel for a batch capacity N and at most `ctl` column tiles per y-chunk: the largest slice any molecule
