@@ -174,20 +174,11 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
     }
 
     if (!TRANS) {
-        // per-workgroup partial BatchNorm sums (accumulated in st_s) -> slab[bx][column][2], or (fused finalize) added to one
-        // of the eight accumulator copies
+        // per-workgroup partial BatchNorm sums (accumulated in st_s) -> slab[bx][column][2]
         __syncthreads();
         const int fp = a.vc.off[a.vc.K];
-        if (a.bnacc) {
-            if (a.fin.training) {
-                double* acc = a.bnacc + (size_t)(bx & (ACC_COPIES - 1)) * 2 * ACC_FP_MAX + (size_t)c0 * 2;
-                for (int i = tid; i < nct * 16 * 2; i += 256)
-                    if (st_s[i] != 0.0) atomicAdd(&acc[i], st_s[i]);
-            }
-        } else {
-            for (int i = tid; i < nct * 16 * 2; i += 256)
-                a.stats[((size_t)bx * fp + c0) * 2 + i] = st_s[i];
-        }
+        for (int i = tid; i < nct * 16 * 2; i += 256)
+            a.stats[((size_t)bx * fp + c0) * 2 + i] = st_s[i];
     }
 }
 
@@ -424,112 +415,21 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
     }
 
     if (!TRANS) {
-        // per-workgroup partial BatchNorm sums (accumulated in st_s by wave 0) -> slab[bx][column][2], or (fused finalize) added
-        // to one of the eight accumulator copies
+        // per-workgroup partial BatchNorm sums (accumulated in st_s by wave 0) -> slab[bx][column][2]
         __syncthreads();
         const int fp = a.vc.off[a.vc.K];
-        if (a.bnacc) {
-            if (a.fin.training) {
-                double* acc = a.bnacc + (size_t)(bx & (ACC_COPIES - 1)) * 2 * ACC_FP_MAX + (size_t)c0 * 2;
-                for (int i = tid; i < nct * 16 * 2; i += NW * 64)
-                    if (st_s[i] != 0.0) atomicAdd(&acc[i], st_s[i]);
-            }
-        } else {
-            for (int i = tid; i < nct * 16 * 2; i += NW * 64)
-                a.stats[((size_t)bx * fp + c0) * 2 + i] = st_s[i];
-        }
-    }
-}
-
-// Fused BatchNorm finalize of the forward aggregation: every workgroup that had tiles arrives at a sharded ticket (kernels.h)
-// once its sums have been added to the accumulator copies; the last one drains the copies (atomic exchange: they are zero
-// again afterwards) and writes the [4][Fp] BatchNorm table and the running statistics -- what bn_finalize_kernel (layer.hip) does
-// in a launch of its own.  TPW = tiles a workgroup takes per trip (1: K-split variant, 4: one tile per wave).
-enum { CPF_GAMMA = 0, CPF_BETA, CPF_BIAS, CPF_RMEAN, CPF_RVAR };     // rows of colp (layer.hip CP_*)
-template <int TPW>
-__device__ __forceinline__ void agg_finish(const AggArgs& a) {
-    if (!a.bnacc) return;
-    __shared__ int last_s;
-    const int ntiles = dev_tiles(a.bt);
-    const int nx = min((int)gridDim.x, (ntiles + TPW - 1) / TPW);          // workgroups (along x) that had a tile
-    const int tid = threadIdx.x;
-    if ((int)blockIdx.x < nx) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's atomics have been performed
-        __syncthreads();
-        if (tid == 0) last_s = ticket_arrive(a.ticket, (int)blockIdx.x, nx, (int)gridDim.y) ? 1 : 0;
-        __syncthreads();
-        if (!last_s) return;
-    } else if (!(nx == 0 && blockIdx.x == 0 && blockIdx.y == 0)) {
-        return;
-    }
-    const BnFin& f = a.fin;
-    const int fp = a.vc.off[a.vc.K];
-    double M = f.M;
-    if (a.bt.meta[EAGCN_META_NLOG] > 0) M = (double)f.batch_B * (double)a.bt.meta[EAGCN_META_NLOG];
-    for (int cp = tid; cp < fp; cp += blockDim.x) {
-        double s1 = 0.0, s2 = 0.0;
-        if (f.training) {
-            unsigned long long v1[ACC_COPIES], v2[ACC_COPIES];
-#pragma unroll
-            for (int c = 0; c < ACC_COPIES; ++c) {
-                double* p = a.bnacc + (size_t)c * 2 * ACC_FP_MAX + (size_t)cp * 2;
-                v1[c] = atomicExch(reinterpret_cast<unsigned long long*>(p), 0ull);
-                v2[c] = atomicExch(reinterpret_cast<unsigned long long*>(p + 1), 0ull);
-            }
-#pragma unroll
-            for (int c = 0; c < ACC_COPIES; ++c) { s1 += __longlong_as_double((long long)v1[c]); s2 += __longlong_as_double((long long)v2[c]); }
-        }
-        int k = 0;
-#pragma unroll
-        for (int v = 1; v < EAGCN_MAX_VIEWS; ++v) k += (v < a.vc.K && cp >= a.vc.off[v]) ? 1 : 0;
-        int off_k = 0, wk = 0;
-        float* rm = nullptr;
-        float* rv = nullptr;
-#pragma unroll
-        for (int v = 0; v < EAGCN_MAX_VIEWS; ++v)
-            if (v == k) { off_k = a.vc.off[v]; wk = a.vc.width[v]; rm = f.run_mean[v]; rv = f.run_var[v]; }
-        const int fcol = cp - off_k;
-        const float gamma = f.colp[CPF_GAMMA * fp + cp], beta = f.colp[CPF_BETA * fp + cp], bias = f.colp[CPF_BIAS * fp + cp];
-        float mu, inv;
-        if (f.training) {
-            const double mean = s1 / M;
-            double var = s2 / M - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            mu = (float)mean;
-            inv = (float)(1.0 / sqrt(var + (double)f.eps));
-            if (fcol < wk) {
-                const double unbiased = var * (M / (M - 1.0));
-                rm[fcol] = (float)((1.0 - f.momentum) * (double)f.colp[CPF_RMEAN * fp + cp] + f.momentum * (mean + (double)bias));
-                rv[fcol] = (float)((1.0 - f.momentum) * (double)f.colp[CPF_RVAR * fp + cp] + f.momentum * unbiased);
-            }
-        } else {
-            mu = f.colp[CPF_RMEAN * fp + cp] - bias;
-            inv = 1.0f / sqrtf(f.colp[CPF_RVAR * fp + cp] + f.eps);
-        }
-        const float sc = gamma * inv;
-        f.bn[BN_SC * fp + cp] = sc;
-        f.bn[BN_SH * fp + cp] = beta - mu * sc;
-        f.bn[BN_MU * fp + cp] = mu;
-        f.bn[BN_INV * fp + cp] = inv;
+        for (int i = tid; i < nct * 16 * 2; i += NW * 64)
+            a.stats[((size_t)bx * fp + c0) * 2 + i] = st_s[i];
     }
 }
 
 template <int CT, bool TRANS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg_wave_kernel(AggArgs a) {
-    agg_wave_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x);
-    if constexpr (!TRANS) agg_finish<4>(a);
-}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg_wave_kernel(AggArgs a) { agg_wave_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 template <int CT, bool TRANS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg_kernel(AggArgs a) {
-    agg_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x);
-    if constexpr (!TRANS) agg_finish<1>(a);
-}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg_kernel(AggArgs a) { agg_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 // two waves per workgroup: most tiles have one or two column groups, so two of four waves would idle
 template <int CT, bool TRANS>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg2_kernel(AggArgs a) {
-    agg_body<CT, TRANS, 2>(a, blockIdx.x, blockIdx.y, gridDim.x);
-    if constexpr (!TRANS) agg_finish<1>(a);
-}
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg2_kernel(AggArgs a) { agg_body<CT, TRANS, 2>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 template <bool TRANS>
 static int launch_agg_t(const AggArgs& a, int ct, dim3 grid, bool ksplit, hipStream_t s) {

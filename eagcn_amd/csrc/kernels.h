@@ -4,16 +4,6 @@
 
 namespace eagcn {
 
-// what the last workgroup of a forward aggregation needs to finish the BatchNorm of the layer itself (fused finalize)
-struct BnFin {
-    const float* colp;           // [CP_ROWS][Fp] packed per-column parameters (layer.hip)
-    float* run_mean[EAGCN_MAX_VIEWS];
-    float* run_var[EAGCN_MAX_VIEWS];
-    float* bn;                   // [4][Fp] table written for bn_apply and the backward
-    double M;                    // rows of the BatchNorm (B * N_pad; device-side override through meta[NLOG])
-    int training, batch_B;
-    float eps, momentum;
-};
 struct AggArgs {
     eagcn_batch bt;
     ViewCols vc;
@@ -24,10 +14,6 @@ struct AggArgs {
     float* rscale;               // [K][T] m_i/rowsum_i: written by forward, read by transposed
     double* stats;               // forward: [grid.x][Fp][2] partial (sum y, sum y^2)
     int nchunk;
-    // fused finalize (forward only; bnacc == nullptr: per-workgroup slabs in `stats` + a bn_finalize launch)
-    double* bnacc;               // [ACC_COPIES][2 * ACC_FP_MAX] self-cleaning accumulators
-    unsigned* ticket;
-    BnFin fin;
 };
 int agg_grid_x(const eagcn_batch* b);
 bool agg_ksplit(const eagcn_batch* b);
@@ -44,72 +30,6 @@ constexpr int EDGE_SLAB = 264;
 int edge_grid_x(const eagcn_batch* b);
 int launch_edge_grad(const EdgeArgs& a, hipStream_t s);
 int launch_agg_edge(AggArgs a, const EdgeArgs& e, hipStream_t s);   // transposed aggregation + edge gradients, one grid
-
-// ---- molecule-staged backward (mol.hip): BatchNorm-backward affine + transposed aggregation + edge gradients + their final
-//      reduction in one launch -------------------------------------------------------------------------------------------------
-struct MolBwdArgs {
-    eagcn_batch bt;
-    ViewCols vc;
-    const float* dH; const float* Y; const float* P; float* dP; int ld;   // [T][ld], ld = Fp
-    const float* bn;             // [4][Fp] BatchNorm table of the forward (BN_SC ..)
-    const float* cc;             // [2][Fp] mean dH, mean dH * xhat (zeros in eval mode)
-    const float* sig; const float* rsig; const float* rscale;
-    double* eacc;                // [8][K][EDGE_SLAB] fp64 accumulators: zero on entry, left zero
-    unsigned* ticket;            // zero on entry, left zero
-    float* datt_w[EAGCN_MAX_VIEWS];
-    float* dself_r[EAGCN_MAX_VIEWS];
-    const float* rel_vec[EAGCN_MAX_VIEWS]; int rel_c[EAGCN_MAX_VIEWS]; int channels[EAGCN_MAX_VIEWS];
-    int nchunk, CT;              // set by the launcher
-};
-bool mol_bwd_ok(const eagcn_batch* b, const ViewCols& vc);     // the molecule slices fit the LDS budget (and EAGCN_MOLBWD != 0)
-int launch_mol_bwd(MolBwdArgs a, hipStream_t s);
-
-// ---- self-cleaning accumulator block ------------------------------------------------------------------------------------------
-// Kernels that finish a grid-wide reduction themselves (last workgroup by ticket) accumulate into fp64 copies that must be ZERO
-// when they start and that their last workgroup leaves zero again (it drains them with atomic exchanges).  The block sits right
-// behind the GEMM hand-off workspace in every layer scratch carving -- same place for every layer and both directions --, has a
-// fixed size, and is cleared together with the hand-off flags once per API call (the flags are the last words of that workspace).
-constexpr int ACC_TICKETS = 256;              // unsigned words: one group of TK_SHARDS + 1 counters per kernel family
-constexpr int TK_MOL_BWD = 0, TK_BN_BWD = 64, TK_AGG_FWD = 128;
-constexpr int ACC_COPIES = 8;
-constexpr int ACC_FP_MAX = 8192;              // widest layer (padded columns) the BatchNorm accumulators serve
-struct AccBlock {
-    unsigned* ticket;            // [ACC_TICKETS]
-    double* eacc;                // [ACC_COPIES][EAGCN_MAX_VIEWS][EDGE_SLAB]
-    double* bnacc;               // [ACC_COPIES][ACC_FP_MAX][2]
-};
-// Sharded arrival ticket: a single counter serialises its arrivals at ~12 ns each (thousands of workgroups -> tens of
-// microseconds), so workgroup x arrives at shard x % 32 and only the last of a shard arrives at the top counter.  Called by ONE
-// thread of every participating workgroup (x < nx; ny workgroups per x) after that workgroup's global atomics have been
-// performed (s_waitcnt vmcnt(0) in every wave + __syncthreads); returns true in exactly one workgroup, the last one, and leaves
-// all counters zero.
-constexpr int TK_SHARDS = 32;
-#ifdef __HIPCC__
-__device__ __forceinline__ bool ticket_arrive(unsigned* tk, int x, int nx, int ny) {
-    const int s = x & (TK_SHARDS - 1);
-    const unsigned members = (unsigned)((nx - s + TK_SHARDS - 1) / TK_SHARDS) * (unsigned)ny;
-    if (atomicAdd(&tk[s], 1u) != members - 1u) return false;
-    atomicExch(&tk[s], 0u);
-    const unsigned nsh = (unsigned)(nx < TK_SHARDS ? nx : TK_SHARDS);
-    if (atomicAdd(&tk[TK_SHARDS], 1u) != nsh - 1u) return false;
-    atomicExch(&tk[TK_SHARDS], 0u);
-    return true;
-}
-#endif
-inline size_t acc_block_bytes() {
-    return align256(ACC_TICKETS * sizeof(unsigned)) + align256((size_t)ACC_COPIES * EAGCN_MAX_VIEWS * EDGE_SLAB * sizeof(double)) +
-           align256((size_t)ACC_COPIES * ACC_FP_MAX * 2 * sizeof(double));
-}
-inline AccBlock acc_block(void* base) {
-    AccBlock a;
-    char* p = (char*)base;
-    a.ticket = (unsigned*)p;
-    p += align256(ACC_TICKETS * sizeof(unsigned));
-    a.eacc = (double*)p;
-    p += align256((size_t)ACC_COPIES * EAGCN_MAX_VIEWS * EDGE_SLAB * sizeof(double));
-    a.bnacc = (double*)p;
-    return a;
-}
 
 // ---- bond-list aggregation (sagg.hip) -------------------------------------------------------------------------------
 enum { BN_SC = 0, BN_SH, BN_MU, BN_INV };     // rows of a layer's [4][Fp] BatchNorm coefficient table

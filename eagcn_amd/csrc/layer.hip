@@ -300,9 +300,6 @@ struct BwdArgs {
     double* slab_da;             // [grid][MAX_VIEWS]
     int do_drop; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
     double* zero; int nzero;     // fp64 words cleared on the way (the head's backward sums, for the next backward call)
-    // fused finalize (RG > 1 variants): the last workgroup turns the accumulated sums into cc / d gamma / d beta / d bias / d ave
-    double* bnacc; unsigned* ticket;   // self-cleaning accumulator block (kernels.h): [ACC_COPIES][2 * ACC_FP_MAX], tickets
-    GradPtrs gp; float* cc; double M; int training, batch_B;
 };
 
 // One workgroup owns BWD_ROWS consecutive-strided rows; a thread owns FOUR adjacent columns (one float4 per row
@@ -313,38 +310,28 @@ struct BwdArgs {
 // -- 7.7 k instructions, scalar registers spilled to vector lanes, a few hundred exec-mask branches -- and was bound by
 // that, not by memory.
 constexpr int BWD_ROWS = 7;
-// RG = 1: one slab of partial sums per workgroup, reduced by bn_bwd_finalize_kernel (a launch of its own).
-// RG = 2 (the default): 512 threads = two row groups of 256 column threads (four groups would cap the kernel at 128 VGPRs: it
-// spilled); the groups' sums meet in LDS, the workgroup adds them to one of eight fp64 accumulator copies in global memory, and
-// the LAST workgroup (sharded ticket, kernels.h) drains the copies and writes what the finalize launch used to write.  The grid
-// is capped at one workgroup per CU (the register budget admits no more): 256 x 2 Fp atomics per launch.
-template <bool WEIGHTED, bool DG, bool DROP, int RG>
-__global__ __launch_bounds__(256 * RG) void bn_bwd_reduce_kernel(BwdArgs a) {
+template <bool WEIGHTED, bool DG, bool DROP>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     __shared__ double da_s[EAGCN_MAX_VIEWS];
-    __shared__ double acc_s[RG > 1 ? 256 * 8 : 1];
-    __shared__ int last_s;
     const uint64_t seed = DROP ? (a.seed_dev ? *a.seed_dev : a.seed) : 0ull;
     const int fp = a.fp, T = min(a.meta[EAGCN_META_T], a.Tcap);
     const int rows = T + a.nvirt;
-    const int ctid = threadIdx.x & 255, rg = threadIdx.x >> 8;
-    // the grid is sized for the row CAPACITY: only the first ceil(rows / (RG * BWD_ROWS)) workgroups work (and write a
-    // slab / take a ticket); bn_bwd_finalize derives the same count from the device-side row count
-    const int nwg = max(1, min((int)gridDim.x, (rows + RG * BWD_ROWS - 1) / (RG * BWD_ROWS)));
+    // the grid is sized for the row CAPACITY: only the first ceil(rows / BWD_ROWS) workgroups work (and write a
+    // slab); bn_bwd_finalize derives the same count from the device-side row count
+    const int nwg = max(1, min((int)gridDim.x, (rows + BWD_ROWS - 1) / BWD_ROWS));
     if (blockIdx.x == 0 && blockIdx.y == 0 && a.zero)
         for (int i = threadIdx.x; i < a.nzero; i += blockDim.x) a.zero[i] = 0.0;
     if ((int)blockIdx.x >= nwg) return;
     if (threadIdx.x < EAGCN_MAX_VIEWS) da_s[threadIdx.x] = 0.0;
-    if constexpr (RG > 1) for (int i = threadIdx.x; i < 256 * 8; i += 256 * RG) acc_s[i] = 0.0;
     __syncthreads();
-    const int vwg = blockIdx.x * RG + rg, nvw = nwg * RG;          // virtual 256-thread workgroup of this row group
     constexpr bool weighted = WEIGHTED;
     double da[EAGCN_MAX_VIEWS];
 #pragma unroll
     for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) da[k] = 0.0;
     // grid.y cuts the columns into chunks of 1024 (one pass of the workgroup): a wide layer (Fp = 6320 at the HIV widths) is
     // limited to a few hundred row blocks by the size of its partial slabs -- too few waves to stream at HBM rate
-    const int c_lo = blockIdx.y * 1024;
-    for (int cp = c_lo + ctid * 4; cp < min(fp, c_lo + 1024); cp += 1024) {
+    const int c_lo = blockIdx.y * (int)blockDim.x * 4;
+    for (int cp = c_lo + threadIdx.x * 4; cp < min(fp, c_lo + (int)blockDim.x * 4); cp += blockDim.x * 4) {
         const int k = col_view(a.vc, cp), f = cp - a.vc.off[k];
         const float4 sc = *reinterpret_cast<const float4*>(a.bn + BN_SC * fp + cp);
         const float4 sh = *reinterpret_cast<const float4*>(a.bn + BN_SH * fp + cp);
@@ -375,11 +362,11 @@ __global__ __launch_bounds__(256 * RG) void bn_bwd_reduce_kernel(BwdArgs a) {
                   (reinterpret_cast<uintptr_t>(a.rg.dg) & 15) == 0;
         }
         double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, dak = 0.0;
-        for (int rb = vwg; rb < rows; rb += BWD_ROWS * nvw) {
+        for (int rb = blockIdx.x; rb < rows; rb += BWD_ROWS * nwg) {
             float4 yv[BWD_ROWS], upv[BWD_ROWS];
 #pragma unroll
             for (int u = 0; u < BWD_ROWS; ++u) {
-                const int r = rb + u * nvw;
+                const int r = rb + u * nwg;
                 yv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 upv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < T) {
@@ -414,7 +401,7 @@ __global__ __launch_bounds__(256 * RG) void bn_bwd_reduce_kernel(BwdArgs a) {
             }
 #pragma unroll
             for (int u = 0; u < BWD_ROWS; ++u) {
-                const int r = rb + u * nvw;
+                const int r = rb + u * nwg;
                 if (r >= rows) continue;
                 const float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
                 const float uu[4] = {upv[u].x, upv[u].y, upv[u].z, upv[u].w};
@@ -437,17 +424,9 @@ __global__ __launch_bounds__(256 * RG) void bn_bwd_reduce_kernel(BwdArgs a) {
                 if (r < T) *reinterpret_cast<float4*>(a.dH + (size_t)r * fp + cp) = make_float4(dh[0], dh[1], dh[2], dh[3]);
             }
         }
-        if constexpr (RG == 1) {
-            double* sl = a.slab + ((size_t)blockIdx.x * fp + cp) * 2;
-            *reinterpret_cast<double4*>(sl) = make_double4(s1[0], s2[0], s1[1], s2[1]);
-            *reinterpret_cast<double4*>(sl + 4) = make_double4(s1[2], s2[2], s1[3], s2[3]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                atomicAdd(&acc_s[ctid * 8 + 2 * j], s1[j]);
-                atomicAdd(&acc_s[ctid * 8 + 2 * j + 1], s2[j]);
-            }
-        }
+        double* sl = a.slab + ((size_t)blockIdx.x * fp + cp) * 2;
+        *reinterpret_cast<double4*>(sl) = make_double4(s1[0], s2[0], s1[1], s2[1]);
+        *reinterpret_cast<double4*>(sl + 4) = make_double4(s1[2], s2[2], s1[3], s2[3]);
         if (weighted) {
 #pragma unroll
             for (int v = 0; v < EAGCN_MAX_VIEWS; ++v) da[v] += (v == k) ? dak : 0.0;
@@ -460,55 +439,8 @@ __global__ __launch_bounds__(256 * RG) void bn_bwd_reduce_kernel(BwdArgs a) {
             if ((threadIdx.x & 63) == 0 && t != 0.0) atomicAdd(&da_s[v], t);
         }
         __syncthreads();
-        if (RG == 1 && threadIdx.x < EAGCN_MAX_VIEWS)
+        if (threadIdx.x < EAGCN_MAX_VIEWS)
             a.slab_da[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * EAGCN_MAX_VIEWS + threadIdx.x] = da_s[threadIdx.x];
-    }
-    if constexpr (RG > 1) {
-        // ---- workgroup sums -> accumulator copy (blockIdx.x % 8); last workgroup: the finalize step -----------------------
-        __syncthreads();
-        double* acc = a.bnacc + (size_t)(blockIdx.x & (ACC_COPIES - 1)) * 2 * ACC_FP_MAX;
-        if (rg == 0) {
-            const int cp = c_lo + ctid * 4;
-            if (cp < fp) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) atomicAdd(&acc[(size_t)cp * 2 + j], acc_s[ctid * 8 + j]);
-            }
-        }
-        if (weighted && threadIdx.x < a.vc.K && da_s[threadIdx.x] != 0.0)
-            atomicAdd(&acc[(size_t)2 * fp + threadIdx.x], da_s[threadIdx.x]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's atomics have been performed
-        __syncthreads();
-        if (threadIdx.x == 0) last_s = ticket_arrive(a.ticket, (int)blockIdx.x, nwg, (int)gridDim.y) ? 1 : 0;
-        __syncthreads();
-        if (!last_s) return;
-        double M = a.M;
-        if (a.meta[EAGCN_META_NLOG] > 0) M = (double)a.batch_B * (double)a.meta[EAGCN_META_NLOG];
-        auto drain = [&](size_t off) {
-            unsigned long long v[ACC_COPIES];
-#pragma unroll
-            for (int c = 0; c < ACC_COPIES; ++c)
-                v[c] = atomicExch(reinterpret_cast<unsigned long long*>(a.bnacc + (size_t)c * 2 * ACC_FP_MAX + off), 0ull);
-            double t = 0.0;
-#pragma unroll
-            for (int c = 0; c < ACC_COPIES; ++c) t += __longlong_as_double((long long)v[c]);
-            return t;
-        };
-        for (int cp = threadIdx.x; cp < fp; cp += 256 * RG) {
-            const double t1 = drain((size_t)cp * 2), t2 = drain((size_t)cp * 2 + 1);
-            a.cc[cp] = a.training ? (float)(t1 / M) : 0.0f;
-            a.cc[fp + cp] = a.training ? (float)(t2 / M) : 0.0f;
-            const int k = col_view(a.vc, cp), f = cp - a.vc.off[k];
-            if (f < a.vc.width[k]) {
-                a.gp.dgamma[k][f] = (float)t2;
-                a.gp.dbeta[k][f] = (float)t1;
-                // training: sum over ALL B*N rows of dY is identically zero (mean removal); eval: sc * sum(dH)
-                a.gp.dbias[k][f] = a.training ? 0.0f : (float)((double)a.bn[BN_SC * fp + cp] * t1);
-            }
-        }
-        if (weighted && threadIdx.x < a.vc.K) {
-            const double t = drain((size_t)2 * fp + threadIdx.x);
-            if (a.gp.dave_w) a.gp.dave_w[threadIdx.x] = (float)t;
-        }
     }
 }
 
@@ -723,7 +655,7 @@ static bool gemm3_layer(int ld_in) {
 }
 
 struct Packed { float *Wcat, *WcatT, *colp, *sig, *rsig; };
-struct FwdScratch { void* gws; void* acc; float *Wcat, *WcatT, *colp, *sig, *rsig; double* stats; };
+struct FwdScratch { void* gws; float *Wcat, *WcatT, *colp, *sig, *rsig; double* stats; };
 static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
     Carver c(base);
     Packed t;
@@ -738,7 +670,6 @@ static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
 struct BwdScratch {
     void* gws;                   // GEMM hand-off workspace: FIRST in both carvings, so that every layer of a model and both
                                  // directions share one region (one flag clear per API call, kernels.h gemm3_clear_flags)
-    void* acc;                   // self-cleaning accumulator block (kernels.h): right behind it, same place everywhere
     float *Wcat, *WcatT, *colp, *sig, *rsig, *dY, *dP, *cc, *dWcat;
     double *slab, *slab_da, *datt;
 };
@@ -746,7 +677,6 @@ static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, Fw
     Carver c(base);
     FwdScratch t;
     t.gws = c.take<char>(gemm3_workspace_bytes());
-    t.acc = c.take<char>(acc_block_bytes());
     t.Wcat = c.take<float>(d.wslab);
     t.WcatT = c.take<float>(d.wslab);
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
@@ -760,7 +690,6 @@ static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, Bw
     Carver c(base);
     BwdScratch t;
     t.gws = c.take<char>(gemm3_workspace_bytes());
-    t.acc = c.take<char>(acc_block_bytes());
     t.Wcat = c.take<float>(d.wslab);
     t.WcatT = c.take<float>(d.wslab);
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
@@ -914,7 +843,6 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
     for (int k = 0; k < p->K; ++k) fsum += p->width[k];
     const double gemm_work = 2.0 * (double)b->T * (double)d.fin * fsum;
     int nslab = 0, tiles_per_wg = agg_ksplit(b) ? 1 : 4;
-    bool fused_fin = false;
     if (b->T > 0) {
         // P = X.[W_1|..|W_K]: NT form on the pre-transposed weight (wave-autonomous balanced kernel, gemm3.hip); operands
         // that are not 16-byte aligned fall back to the workgroup-tiled kernel
@@ -938,19 +866,8 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
             tiles_per_wg = 0;
         } else {
             AggArgs a;
-            memset(&a, 0, sizeof(a));
             a.bt = *b; a.vc = d.vc; a.src = w->P; a.lds = d.fp; a.dst = w->Y; a.ldd = d.fp;
             a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = sc.stats; a.nchunk = 1;
-            // fused finalize: the last aggregation workgroup writes the BatchNorm table + running statistics itself
-            static const bool fuse_env = [] { const char* v = getenv("EAGCN_BN_FUSED"); return !(v && v[0] == '0'); }();
-            if (fuse_env && d.fp <= ACC_FP_MAX) {
-                const AccBlock ab = acc_block(sc.acc);
-                a.bnacc = ab.bnacc; a.ticket = ab.ticket + TK_AGG_FWD;
-                a.fin.colp = sc.colp; a.fin.bn = w->bn; a.fin.M = (double)b->B * (double)b->N;
-                a.fin.training = p->training; a.fin.batch_B = b->B; a.fin.eps = p->bn_eps; a.fin.momentum = p->bn_momentum;
-                for (int k = 0; k < p->K; ++k) { a.fin.run_mean[k] = pp.run_mean[k]; a.fin.run_var[k] = pp.run_var[k]; }
-                fused_fin = true;
-            }
             rc = launch_agg(a, false, s);
             if (rc) return rc;
             nslab = d.gx;
@@ -958,9 +875,7 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
     }
     const double M = (double)b->B * (double)b->N;
     ProfScope psbn(PROF_BN, s);
-    if (fused_fin) {
-        // (table and running statistics were written by the aggregation's last workgroup)
-    } else if (nslab > 64)
+    if (nslab > 64)
         bn_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
                                                                p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, tiles_per_wg, b->B);
     else
@@ -1049,63 +964,31 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     ba.seed_dev = p->seed_dev;
     ba.zero = zero_after ? zero_after->d : nullptr;
     ba.nzero = zero_after ? zero_after->nd : 0;
-    ba.bnacc = nullptr; ba.ticket = nullptr; ba.gp = gp; ba.cc = sc.cc; ba.M = 0.0; ba.training = p->training; ba.batch_B = b->B;
     const int rows = b->T + ba.nvirt;
     const int gxb = std::max(1, std::min(rows, d.gxb));
     const double M = (double)b->B * (double)b->N;
-    bool use_mol = false, edges_done = false;
-    const bool side_is_main = !w->aux_stream || (hipStream_t)w->aux_stream == s;
     {
         ProfScope ps(PROF_BN, s);
         const int ny = cdiv(d.fp, 1024);
-        // fused finalize (the last workgroup of the reduction writes cc / d gamma / d beta / d bias / d ave): one launch less
-        static const bool fuse_env = [] { const char* v = getenv("EAGCN_BN_FUSED"); return !(v && v[0] == '0'); }();
-        const bool fused = fuse_env && 2 * d.fp + 2 * EAGCN_MAX_VIEWS <= 2 * ACC_FP_MAX;
         {
             const bool wt = p->structure == EAGCN_STRUCT_WEIGHTED, dg = ba.rg.dg != nullptr, dr = ba.do_drop != 0;
-            if (fused) {
-                const AccBlock ab = acc_block(sc.acc);
-                ba.bnacc = ab.bnacc; ba.ticket = ab.ticket + TK_BN_BWD;
-                ba.gp = gp; ba.cc = sc.cc; ba.M = M; ba.training = p->training; ba.batch_B = b->B;
-                static const int ncu = [] {
-                    int dev = 0, n = 256;
-                    hipDeviceProp_t prop;
-                    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                        n = prop.multiProcessorCount;
-                    (void)hipGetLastError();
-                    return n;
-                }();
-                const dim3 grid(std::max(1, std::min(cdiv(rows, 2 * BWD_ROWS), ncu)), ny);
-#define EAGCN_BWD(W, G, D) bn_bwd_reduce_kernel<W, G, D, 2><<<grid, 512, 0, s>>>(ba)
-                if (wt) { if (dg) { if (dr) EAGCN_BWD(true, true, true); else EAGCN_BWD(true, true, false); }
-                          else    { if (dr) EAGCN_BWD(true, false, true); else EAGCN_BWD(true, false, false); } }
-                else    { if (dg) { if (dr) EAGCN_BWD(false, true, true); else EAGCN_BWD(false, true, false); }
-                          else    { if (dr) EAGCN_BWD(false, false, true); else EAGCN_BWD(false, false, false); } }
+            const dim3 grid(gxb, ny);
+#define EAGCN_BWD(W, G, D) bn_bwd_reduce_kernel<W, G, D><<<grid, 256, 0, s>>>(ba)
+            if (wt) { if (dg) { if (dr) EAGCN_BWD(true, true, true); else EAGCN_BWD(true, true, false); }
+                      else    { if (dr) EAGCN_BWD(true, false, true); else EAGCN_BWD(true, false, false); } }
+            else    { if (dg) { if (dr) EAGCN_BWD(false, true, true); else EAGCN_BWD(false, true, false); }
+                      else    { if (dr) EAGCN_BWD(false, false, true); else EAGCN_BWD(false, false, false); } }
 #undef EAGCN_BWD
-            } else {
-                const dim3 grid(gxb, ny);
-#define EAGCN_BWD(W, G, D) bn_bwd_reduce_kernel<W, G, D, 1><<<grid, 256, 0, s>>>(ba)
-                if (wt) { if (dg) { if (dr) EAGCN_BWD(true, true, true); else EAGCN_BWD(true, true, false); }
-                          else    { if (dr) EAGCN_BWD(true, false, true); else EAGCN_BWD(true, false, false); } }
-                else    { if (dg) { if (dr) EAGCN_BWD(false, true, true); else EAGCN_BWD(false, true, false); }
-                          else    { if (dr) EAGCN_BWD(false, false, true); else EAGCN_BWD(false, false, false); } }
-#undef EAGCN_BWD
-            }
         }
         EAGCN_LAUNCH_CHECK();
-        if (fused) {
-            // (cc and the BatchNorm parameter gradients were written by the last workgroup of the reduction)
-        } else if (gxb > 64)
+        if (gxb > 64)
             bn_bwd_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
                                                                        d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb);
         else
             bn_bwd_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
                                                                         d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb);
         EAGCN_LAUNCH_CHECK();
-        // molecule-staged backward (mol.hip): the affine below, the transposed aggregation, the edge gradients and their final
-        // reduction in ONE launch
-        use_mol = b->T > 0 && !sagg_enabled() && side_is_main && mol_bwd_ok(b, d.vc);
-        if (b->T > 0 && !sagg_enabled() && !use_mol) {        // (the bond-list aggregation applies this affine while it stages dH)
+        if (b->T > 0 && !sagg_enabled()) {        // (the bond-list aggregation applies this affine while it stages dH)
             bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
             EAGCN_LAUNCH_CHECK();
         }
@@ -1117,7 +1000,6 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     const bool forked = side != s;
     if (b->T > 0) {
         AggArgs a;
-        memset(&a, 0, sizeof(a));
         a.bt = *b; a.vc = d.vc; a.src = sc.dY; a.lds = d.fp; a.dst = sc.dP; a.ldd = d.fp;
         a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = nullptr; a.nchunk = 1;
         EdgeArgs e;
@@ -1125,21 +1007,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         e.rsig = sc.rsig; e.rscale = w->rscale; e.datt = sc.datt;
         static const bool colaunch = [] { const char* v = getenv("EAGCN_NO_COLAUNCH"); return !(v && v[0] == '1'); }();
         nedge = edge_grid_x(b);
-        if (use_mol) {
-            const AccBlock ab = acc_block(sc.acc);
-            MolBwdArgs ma;
-            ma.bt = *b; ma.vc = d.vc; ma.dH = sc.dY; ma.Y = w->Y; ma.P = w->P; ma.dP = sc.dP; ma.ld = d.fp;
-            ma.bn = w->bn; ma.cc = sc.cc; ma.sig = sc.sig; ma.rsig = sc.rsig; ma.rscale = w->rscale;
-            ma.eacc = ab.eacc; ma.ticket = ab.ticket + TK_MOL_BWD;
-            for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) {
-                ma.datt_w[k] = gp.datt_w[k]; ma.dself_r[k] = gp.dself_r[k];
-                ma.rel_vec[k] = pp.rel_vec[k]; ma.rel_c[k] = pp.rel_c[k]; ma.channels[k] = pp.channels[k];
-            }
-            ma.nchunk = 1; ma.CT = 1;
-            rc = launch_mol_bwd(ma, s);
-            if (rc) return rc;
-            edges_done = true;                            // d att.weight / d self_r are final: nothing left for unpack_grads
-        } else if (sagg_enabled()) {
+        if (sagg_enabled()) {
             // transposed aggregation + edge gradients + BatchNorm-backward affine in one kernel over the bond lists
             SAggBwd sa;
             sa.bt = *b; sa.vc = d.vc; sa.fp = d.fp; sa.dH = sc.dY; sa.Y = w->Y; sa.P = w->P; sa.bn = w->bn; sa.cc = sc.cc;
@@ -1197,17 +1065,12 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             EAGCN_HIP(hipMemsetAsync(gp.dW[k], 0, (size_t)d.fin * p->width[k] * sizeof(float), side));
     }
     {
-        // reduction of the split-K dW slabs and of the edge-gradient partials; with the molecule-staged backward the latter are
-        // final already, and a layer on the balanced GEMM has no dW slabs either: then nothing is launched at all
         const int wblocks = nsplit > 0 ? cdiv((int)d.wslab, 256) : 0;
-        const int eblocks = edges_done ? 0 : cdiv(p->K * EDGE_SLAB, 16);
-        if (wblocks + eblocks > 0) {
-            ProfScope psu(PROF_PACK, side);
-            unpack_grads_kernel<<<wblocks + eblocks, 256, 0, side>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
-                                                                     nsplit, d.wslab, sc.datt, nedge, sc.rsig,
-                                                                     wblocks, b->meta, xk_G);
-            EAGCN_LAUNCH_CHECK();
-        }
+        ProfScope psu(PROF_PACK, side);
+        unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, side>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
+                                                                                    nsplit, d.wslab, sc.datt, nedge, sc.rsig,
+                                                                                    wblocks, b->meta, xk_G);
+        EAGCN_LAUNCH_CHECK();
     }
     // join: the caller reuses the scratch block (dY', dP, partial slabs) for the next layer
     if (forked) { rc = stream_after(s, side); if (rc) return rc; }
