@@ -48,7 +48,7 @@ WORKLOADS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = os.path.join('profiles', 'r02_pmc_traffic.json')
+PMC_FILE = os.path.join('profiles', 'r03_pmc_traffic.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')) else 'r02_pmc_traffic.json')
 
 
 def rel_channels(cfg):
@@ -90,6 +90,30 @@ def algorithmic_flops(cfg, sizes):
     return 3.0 * total
 
 
+def algorithmic_bytes(cfg, sizes, n_pad):
+    """SURVEY.md 8(d) "algorithmic bytes per molecule": the dense inputs as the reference signature delivers them, read once
+    (4 (1 + n_bfeat + sum_{k>=2} C_k) N_pad^2), per layer the forward minimum 4 n F_in + 4 n sum F_k + (K+1) n^2 plus the same
+    activations again for the BatchNorm second pass, and twice the forward activations for the backward."""
+    chans = rel_channels(cfg)
+    K = len(cfg['widths1'])
+    w1, w2 = list(cfg['widths1']), list(cfg['widths2'])
+    if cfg['structure'] == 'Weighted_sum':
+        w1, w2 = [sum(w1)] * K, [sum(w2)] * K
+        f1, f2 = w1[0], w2[0]
+    else:
+        f1, f2 = sum(w1), sum(w2)
+    w3 = [2 * w for w in w2]
+    plan = [(24, w1), (f1, w2), (f2, w3), (2 * f2, w3)][:cfg['n_layers']]
+    dense = 4.0 * (1 + sum(chans)) * n_pad * n_pad * len(sizes)
+    act = 0.0
+    for n in sizes:
+        n = float(n)
+        for fin, ws in plan:
+            fwd = 4 * n * fin + 4 * n * sum(ws) + (K + 1) * n * n
+            act += fwd + 4 * n * sum(ws) * 2 + 2 * (4 * n * fin + 4 * n * sum(ws))     # forward, BatchNorm second pass, backward
+    return dense, act
+
+
 def committed_traffic(kernel_substr):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of this command
     (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json; rocprofv3 cannot run inside bench.py)."""
@@ -125,15 +149,18 @@ def cpu_baseline(cfg, mb, dropout, bce_w, steps=5, warmup=2):
         loss = classification_loss(out, labels, bce_w) if cfg['task'] == 'class' else regression_loss(out, labels)
         loss.backward()
 
-    # the many small ATen ops of this path do not scale to hundreds of threads: pick the fastest of
-    # a few thread counts (one step each after one warm-up) and report that count as `cores`
+    # the many small ATen ops of this path do not scale to hundreds of threads: pick the fastest of a few thread counts,
+    # each judged by the median of three steps after a warm-up step at that count, and report it as `cores`
     best = (None, 1e30)
     for nt in [c for c in (8, 16, 32, 64) if c <= avail] or [avail]:
         torch.set_num_threads(nt)
         one_step()
-        t0 = time.perf_counter()
-        one_step()
-        dt = time.perf_counter() - t0
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            one_step()
+            ts.append(time.perf_counter() - t0)
+        dt = sorted(ts)[1]
         if dt < best[1]:
             best = (nt, dt)
     cores = best[0]
@@ -156,9 +183,10 @@ def cpu_baseline(cfg, mb, dropout, bce_w, steps=5, warmup=2):
     except Exception:
         pass
     return {'value': mb.B / med, 'unit': 'molecules/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d timed fwd+bwd steps (median, after %d warm-up) of the same %d-molecule batch, '
-                      'oracle/eagcn_ref.py RefEAGCN on torch %s CPU, %d threads, %s'
-                      % (steps, warmup, mb.B, torch.__version__, cores, model_name or 'unknown CPU')}
+            'sample': '%d timed fwd+bwd steps (median, after %d warm-up) of the same %d-molecule batch (%d tasks, N_pad %d), '
+                      'oracle/eagcn_ref.py RefEAGCN on torch %s CPU, %d threads (fastest of 8/16/32/64 by the median of 3 warmed '
+                      'steps each), %s'
+                      % (steps, warmup, mb.B, cfg['nclass'], mb.N, torch.__version__, cores, model_name or 'unknown CPU')}
 
 
 def run_workload(name, B, args, lib, dev, rank, world, reducer_cls, detail):
@@ -168,11 +196,16 @@ def run_workload(name, B, args, lib, dev, rank, world, reducer_cls, detail):
     from eagcn_amd.synthetic import bce_weights, make_batch
     cfg = dict(WORKLOADS[name])
     torch.manual_seed(1234 + rank)
-    mb = make_batch(B=B, n_max=cfg['n_max'], n_med=cfg['n_med'], rel_channels=rel_channels(cfg),
-                    seed=1234 + rank, n_tasks=cfg['nclass'], task=cfg['task'], all_full=cfg.get('all_full', False))
-    dense = mb.dense(dev) if args.input == 'dense' else None
-    compact = mb.compact(dev) if args.input == 'compact' else None
-    labels = torch.from_numpy(mb.labels).to(dev)
+    nrot = max(1, int(getattr(args, 'rotate', 1)))
+    mbs = [make_batch(B=B, n_max=cfg['n_max'], n_med=cfg['n_med'], rel_channels=rel_channels(cfg),
+                      seed=1234 + rank + 1000 * i, n_tasks=cfg['nclass'], task=cfg['task'], all_full=cfg.get('all_full', False))
+           for i in range(nrot)]
+    mb = mbs[0]
+    denses = [m_.dense(dev) if args.input == 'dense' else None for m_ in mbs]
+    compacts = [m_.compact(dev) if args.input == 'compact' else None for m_ in mbs]
+    labelss = [torch.from_numpy(m_.labels).to(dev) for m_ in mbs]
+    dense, compact, labels = denses[0], compacts[0], labelss[0]
+    counter = [0]
     bce_w = bce_weights(cfg['nclass'])
     bce_w_dev = torch.tensor(bce_w, dtype=torch.float32, device=dev)
     model = build_model(cfg, args.dropout, dev, graph=not args.eager)
@@ -183,17 +216,18 @@ def run_workload(name, B, args, lib, dev, rank, world, reducer_cls, detail):
     fused = (not args.eager) and not args.separate_graphs
 
     def step():
+        i = counter[0] % nrot       # resident batches taken round-robin (--rotate; 1: the same batch every step)
+        counter[0] += 1
+        dense, compact, labels = denses[i], compacts[i], labelss[i]
         for p in params:            # optimizer.zero_grad(set_to_none=True) of the reference loop (train.py:317)
             p.grad = None
         if fused and model.graph:
-            # forward + loss + backward as ONE captured graph (EAGCN.fused_step, what eagcn_amd.training.train_step runs)
-            scale = None
-            if world > 1 and cfg['task'] == 'class':
-                from eagcn_amd.parallel import dp_loss_scale
-                scale = dp_loss_scale(labels)
+            # forward + loss + backward as ONE captured graph (EAGCN.fused_step, what eagcn_amd.training.train_step runs); with
+            # more than one rank the gradient average is captured INTO that graph (upper bucket beside the first layer's
+            # backward) and the global BCE normalisation is a 1-element collective issued with the batch preparation
             batch = dense if compact is None else (compact[1], compact[2])
-            loss, _ = model.fused_step(batch, labels, cfg['task'], bce_w_dev, scale, bonds=None if compact is None else compact[0])
-            reducer()
+            loss, _ = model.fused_step(batch, labels, cfg['task'], bce_w_dev, 'dp' if (world > 1 and cfg['task'] == 'class') else None,
+                                       bonds=None if compact is None else compact[0], reducer=reducer if world > 1 else None)
             return loss
         out, _, _ = model(*dense) if compact is None else model.forward_compact(*compact)
         if cfg['task'] == 'class':
@@ -232,7 +266,18 @@ def run_workload(name, B, args, lib, dev, rank, world, reducer_cls, detail):
     if not torch.isfinite(loss.detach()).item():
         raise SystemExit('non-finite loss')
     res = {'cfg': cfg, 'mb': mb, 'bce_w': bce_w, 'B': B, 'blocks': sorted(blocks),
-           'gflop': algorithmic_flops(cfg, mb.sizes) / 1e9, 'N': mb.N}
+           'gflop': algorithmic_flops(cfg, mb.sizes) / 1e9, 'N': mb.N, 'bytes': algorithmic_bytes(cfg, mb.sizes, mb.N),
+           'rank_ms': None, 'allreduce': None}
+    if dist.is_initialized() and world > 1:
+        mine = torch.tensor([sorted(blocks)[len(blocks) // 2] / args.steps * 1e3], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        res['rank_ms'] = [round(float(t), 4) for t in every]
+        runner = next(iter(model._runners.values()), None) if model.graph else None
+        res['allreduce'] = ('in-place AVG of the flat fp32 gradient buffer over RCCL, captured inside the step graph: bucket [layers >= 2 '
+                            '+ head] started before the first layer\'s backward, bucket [layer 1] after it'
+                            if (runner is not None and runner.comm_in_graph) else
+                            'in-place AVG of the flat fp32 gradient buffer over RCCL, one host-issued collective after the step graph')
     prof_steps = args.steps * args.repeats
     if detail and not profile_in_loop:
         # per-kernel-class durations: the same step, same batch, eager launches with one HIP-event pair per
@@ -279,10 +324,17 @@ def summarize(res, args, world):
     med = b[len(b) // 2]
     ms = med / args.steps * 1e3
     value = world * res['B'] * args.steps / med
+    dense_b, act_b = res['bytes']
+    t_mfma = res['gflop'] / PEAK_FP32_MFMA_TFLOPS                     # ms at the fp32 MFMA peak
+    t_hbm = (dense_b + act_b) / (PEAK_HBM_GBS * 1e6)                   # ms at 8 TB/s
     return {'value': round(value, 1), 'ms_per_step': round(ms, 4),
             'value_min': round(world * res['B'] * args.steps / b[-1], 1), 'value_max': round(world * res['B'] * args.steps / b[0], 1),
             'algorithmic_gflop_per_step': round(res['gflop'], 3),
-            'step_tflops': round(res['gflop'] / ms, 2), 'step_frac': round(res['gflop'] / ms / PEAK_FP32_MFMA_TFLOPS, 4)}
+            'step_tflops': round(res['gflop'] / ms, 2), 'step_frac': round(res['gflop'] / ms / PEAK_FP32_MFMA_TFLOPS, 4),
+            # "report both numbers per config; relevant roofline = max(T_flops, T_bytes)"
+            'algorithmic_mbytes_per_step': {'dense_inputs': round(dense_b / 1e6, 1), 'activations': round(act_b / 1e6, 1)},
+            'hbm_frac': round(t_hbm / ms, 4), 'relevant_roofline': 'hbm' if t_hbm > t_mfma else 'mfma',
+            'relevant_frac': round(max(t_hbm, t_mfma) / ms, 4)}
 
 
 def main():
@@ -295,6 +347,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='molecules per GPU (default: the config\'s)')
     ap.add_argument('--dropout', type=float, default=0.3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rotate', type=int, default=1, help='distinct HBM-resident batches per rank, taken round-robin (1: the same batch every step)')
     ap.add_argument('--no-extras', action='store_true', help='skip the extra single-GPU shapes (north-star batch 1024, HIV, Lipo, C5)')
     ap.add_argument('--eager', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--separate-graphs', action='store_true', help='graph mode with separate forward / backward graphs and an eager loss kernel '
@@ -343,8 +396,8 @@ def main():
                                    (args.workload, cfg['structure'], cfg['n_layers'], len(cfg['widths1']),
                                     cfg['widths1'][0], cfg['widths2'][0], cfg['nclass'], B, mb.N, args.dropout,
                                     'weighted BCE' if cfg['task'] == 'class' else 'MSE'),
-                       'input': args.input, 'inputs': 'HBM-resident (one synthetic batch per rank, reused every step)',
-                       'overlap_index': True, 'graph_outputs': 'static', 'validate': 'deferred',
+                       'input': args.input, 'inputs': 'HBM-resident (%d synthetic batch%s per rank, %s)' % (args.rotate, '' if args.rotate == 1 else 'es', 'reused every step' if args.rotate == 1 else 'round-robin'),
+                       'overlap_index': os.environ.get('EAGCN_BENCH_OVERLAP', '1') == '1', 'graph_outputs': 'static', 'validate': 'deferred',
                        'optimizer': 'excluded (SURVEY.md 8d: forward + loss + backward [+ gradient all-reduce])',
                        'global_batch': world * B, 'atoms_per_batch': int(mb.sizes.sum()),
                        'parallelism': 'dp%d' % world},
@@ -355,6 +408,12 @@ def main():
                          'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          'step_frac': head['step_frac'],
                          'step_frac_note': 'whole step: algorithmic_gflop_per_step / ms_per_step / peak',
+                         'hbm': {'algorithmic_mbytes_per_step': head['algorithmic_mbytes_per_step'], 'peak_gbs': PEAK_HBM_GBS,
+                                 'step_frac': head['hbm_frac'],
+                                 'note': 'whole step against the HBM bound: SURVEY 8(d) algorithmic bytes (dense collate tensors as the '
+                                         'signature delivers them, read once + per-layer activation minimum) / ms_per_step / 8 TB/s; the '
+                                         'implementation streams adj and gathers the relation channels at the bonds only'},
+                         'relevant': head['relevant_roofline'], 'relevant_step_frac': head['relevant_frac'],
                          'traffic': None if traffic is None else round(traffic),
                          'traffic_note': None if traffic is None else
                          'bytes per launch, memory-side FETCH_SIZE x2 + WRITE_SIZE from %s' % traffic_src,
@@ -368,33 +427,49 @@ def main():
         }
         if 'eval_forward' in res:
             out['eval_forward'] = res['eval_forward']
+        if world > 1:
+            out['rccl_world'] = dist.get_world_size()
+            out['ms_per_step_by_rank'] = res['rank_ms']
+            out['gradient_allreduce'] = res['allreduce']
+            out['batchnorm'] = 'local-BN (every shard = a reference run at batch %d)' % B
     # ---- other single-GPU shapes: same measurement, fewer blocks ------------------------------------------------------
     if world == 1 and not args.no_extras and args.workload == 'tox21_c2' and args.batch is None and not args.eager:
         keep = (args.repeats, args.steps, args.warmup)
+        keep_rotate = args.rotate
         extra = {}
         for key, (wname, wb, steps, mode) in (('b1024', ('tox21_c2', 1024, 30, 0)), ('hiv_c3', ('hiv_c3', 1024, 10, 0)),
                                                ('lipo_c4', ('lipo_c4', 512, 30, 0)), ('c5_synth', ('c5_synth', 1024, 6, 0)),
-                                               ('c2_bf16_products', ('tox21_c2', 256, 50, 2))):
+                                               ('c2_bf16_products', ('tox21_c2', 256, 50, 2)),
+                                               ('c2_rotate4', ('tox21_c2', 256, 50, 0)), ('b1024_rotate4', ('tox21_c2', 1024, 30, 0))):
             del res
             torch.cuda.empty_cache()
             args.repeats, args.steps, args.warmup = 5, steps, 4
+            args.rotate = 4 if key.endswith('rotate4') else 1
             old_mode = lib.eagcn_set_gemm_mode(mode)         # fresh model + fresh graphs per workload: captured with this mode
             try:
                 res = run_workload(wname, wb, args, lib, dev, rank, world, GradientAllReducer, detail=False)
             finally:
                 lib.eagcn_set_gemm_mode(old_mode)
             e = summarize(res, args, world)
-            e['workload'] = '%s, batch %d, N_pad %d, %d blocks of %d steps' % (wname, wb, res['N'], args.repeats, args.steps)
+            e['workload'] = '%s, batch %d, N_pad %d, %d blocks of %d steps%s' % (wname, wb, res['N'], args.repeats, args.steps,
+                                                                                 ', 4 distinct resident batches round-robin (the side-stream index build reads fresh data every step)' if args.rotate > 1 else '')
             if mode == 2:
                 e['dtype'] = ('BASELINE configs[1] as written: hidden-layer products X.W, dP.W^T, X^T.dP with bf16 operands '
                               '(round to nearest even, one bf16 MFMA product, fp32 accumulate); aggregation, BatchNorm, head and '
                               'first layer fp32.  NOT the parity path: error vs the fp32 oracle in tests/test_gpu_bf16.py')
             extra[key] = e
         args.repeats, args.steps, args.warmup = keep
+        args.rotate = keep_rotate
         out['extra'] = extra
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, mb, args.dropout, bce_w_of(cfg), steps=args.cpu_steps)
+            if args.workload == 'tox21_c2':
+                # BASELINE.json configs[0] as written: Tox21 single-task, 2-layer 5-view Concate, batch 64, fp32 on the CPU
+                from eagcn_amd.synthetic import make_batch
+                c1 = dict(WORKLOADS['tox21_c2'], nclass=1)
+                mb1 = make_batch(B=64, n_max=c1['n_max'], n_med=c1['n_med'], rel_channels=rel_channels(c1), seed=4321, n_tasks=1, task='class')
+                out['cpu_baseline_configs0'] = cpu_baseline(c1, mb1, args.dropout, bce_w_of(c1), steps=args.cpu_steps)
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

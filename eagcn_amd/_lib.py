@@ -78,7 +78,8 @@ class LayerParams(C.Structure):
 class LayerBufs(C.Structure):
     _fields_ = [('x', _fp), ('P', _fp), ('Y', _fp), ('rscale', _fp), ('bn', _fp), ('xout', _fp),
                 ('pad_row', _fp), ('scratch', _fp), ('scratch_bytes', C.c_size_t),
-                ('aux_stream', _fp), ('packed', _fp), ('packed_bytes', C.c_size_t)]
+                ('aux_stream', _fp), ('packed', _fp), ('packed_bytes', C.c_size_t),
+                ('stats_hook', _fp), ('stats_user', _fp)]
 
 
 class LayerGrads(C.Structure):
@@ -104,7 +105,12 @@ class HeadGrads(C.Structure):
 class Model(C.Structure):
     _fields_ = [('n_layers', C.c_int32), ('molfp_mode', C.c_int32), ('training', C.c_int32),
                 ('head_seed', C.c_uint64), ('head_seed_dev', _fp), ('input_packed', C.c_int32), ('aux_stream', _fp),
-                ('layer', LayerParams * 4), ('head', HeadParams)]
+                ('layer', LayerParams * 4), ('head', HeadParams), ('stats_hook', _fp), ('stats_user', _fp),
+                ('stats_world', C.c_int32), ('reserved_', C.c_int32)]
+
+
+# int hook(double* buf, int n, void* stream, void* user): cross-rank sum in place (sync-BatchNorm, eagcn_hip.h)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
 
 
 # name -> (restype, argtypes); also the list the CPU test checks against include/eagcn_hip.h
@@ -171,6 +177,8 @@ SIGNATURES = {
                                       C.c_size_t, _fp, _fp, _fp]),
     'eagcn_model_backward': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, C.c_size_t, _fp, C.c_size_t,
                                        _fp, _fp, C.POINTER(LayerGrads), C.POINTER(HeadGrads), _fp]),
+    'eagcn_model_backward_range': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, C.c_size_t, _fp, C.c_size_t,
+                                             _fp, _fp, C.POINTER(LayerGrads), C.POINTER(HeadGrads), C.c_int, C.c_int, C.c_int, _fp]),
     'eagcn_bce_loss': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     'eagcn_mse_loss': (C.c_int, [_fp, _fp, C.c_int, _fp, _fp, _fp]),
     'eagcn_eval_append': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int64, _fp]),

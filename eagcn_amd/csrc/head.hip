@@ -101,7 +101,9 @@ static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model*
     ModelScratch s;
     const eagcn_head_params* h = &m->head;
     const size_t B = (size_t)b->B, T = (size_t)b->T;
-    s.n_hst = 2 * (h->f_in + h->n_den1 + h->n_den2);
+    // three segments [2 w sums | row count | pad], one per BatchNorm of the head (the count rides with the sums through the
+    // sync-BatchNorm hook)
+    s.n_hst = 2 * (h->f_in + h->n_den1 + h->n_den2) + 6;
     s.hst = c.take<double>((size_t)2 * s.n_hst);
     s.hsb = s.hst + s.n_hst;
     s.da2 = c.take<float>(B * h->n_den2);
@@ -222,6 +224,7 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
         memset(&w, 0, sizeof(w));
         w.x = x; w.P = L.P; w.Y = L.Y; w.rscale = L.rscale; w.bn = L.bn; w.xout = L.xout; w.pad_row = L.pad_row;
         w.scratch = sc.layer; w.scratch_bytes = sc.layer_bytes; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
+        w.stats_hook = m->stats_hook; w.stats_user = m->stats_user;
         RC(layer_forward_impl(b, &m->layer[l], &w, stream, true));
         x = L.xout;
     }
@@ -237,8 +240,18 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
                                  size, m->molfp_mode, sv.g, F, stream));
     // head (head2.hip): every BatchNorm's sums come from the kernel that produces its input, its normalisation is
     // applied by the product that consumes it
-    double *st_g = sc.hst, *st_1 = sc.hst + 2 * F, *st_2 = sc.hst + 2 * (F + n1);
-    RC(head_colstats(sv.g, B, F, st_g, s));
+    double *st_g = sc.hst, *st_1 = sc.hst + 2 * F + 2, *st_2 = sc.hst + 2 * (F + n1) + 4;
+    const bool sync = m->stats_hook && m->training;
+    auto hook = [&](double* buf, int n) -> int {
+        if (!sync) return EAGCN_OK;
+        if (m->stats_hook(buf, n, stream, m->stats_user)) {
+            set_error("eagcn_model: the sync-BatchNorm all-reduce hook failed");
+            return EAGCN_ERR_HIP;
+        }
+        return EAGCN_OK;
+    };
+    RC(head_colstats(sv.g, B, F, st_g, s, st_g + 2 * F, st_1 + 2 * n1, st_2 + 2 * n2));
+    RC(hook(st_g, 2 * F + 1));
     HeadDrop nodrop{0, 0u, 1.0f, 0, nullptr}, drop1 = nodrop;
     {
         int on; uint32_t thr; float inv_keep;
@@ -247,12 +260,17 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     }
     HeadFwd f1{B, F, n1, sv.g, st_g, h->gbn_w, h->gbn_b, h->gbn_rm, h->gbn_rv, sv.bn_g, h->den1_w, sv.h1, nullptr, st_1,
                m->training, 0, h->bn_eps, h->bn_momentum, nodrop};
+    if (sync) f1.cnt_in = st_g + 2 * F;
     RC(head_fwd(f1, s));
+    RC(hook(st_1, 2 * n1 + 1));
     HeadFwd f2{B, n1, n2, sv.h1, st_1, h->bn1_w, h->bn1_b, h->bn1_rm, h->bn1_rv, sv.bn_1, h->den2_w, sv.h2, graph_rep, st_2,
                m->training, 1, h->bn_eps, h->bn_momentum, drop1};
+    if (sync) f2.cnt_in = st_1 + 2 * n1;
     RC(head_fwd(f2, s));
+    RC(hook(st_2, 2 * n2 + 1));
     HeadFwd f3{B, n2, nc, sv.h2, st_2, h->bn2_w, h->bn2_b, h->bn2_rm, h->bn2_rv, sv.bn_2, h->den3_w, out, nullptr, nullptr,
                m->training, 1, h->bn_eps, h->bn_momentum, nodrop};
+    if (sync) f3.cnt_in = st_2 + 2 * n2;
     RC(head_fwd(f3, s));
     return EAGCN_OK;
 }
@@ -261,12 +279,25 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
                                     size_t saved_bytes, void* scratch, size_t scratch_bytes, const float* dout,
                                     const float* dgraph_rep, const eagcn_layer_grads* lg,
                                     const eagcn_head_grads* hg, void* stream) {
+    EAGCN_CHECK_ARG(m, "eagcn_model_backward: null model");
+    return eagcn_model_backward_range(b, m, size, saved, saved_bytes, scratch, scratch_bytes, dout, dgraph_rep, lg, hg, 1,
+                                      m->n_layers - 1, 0, stream);
+}
+
+extern "C" int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_model* m, const int64_t* size, void* saved,
+                                          size_t saved_bytes, void* scratch, size_t scratch_bytes, const float* dout,
+                                          const float* dgraph_rep, const eagcn_layer_grads* lg,
+                                          const eagcn_head_grads* hg, int with_head, int layer_hi, int layer_lo, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     RC(check_model(b, m, "eagcn_model_backward"));
     EAGCN_CHECK_GEMM3("eagcn_model_backward");
     EAGCN_CHECK_ARG(saved && scratch && dout && lg && hg, "eagcn_model_backward: null buffer");
     EAGCN_CHECK_ARG(hg->d_den1_w && hg->d_den2_w && hg->d_den3_w && hg->d_gbn_w && hg->d_gbn_b && hg->d_bn1_w &&
                         hg->d_bn1_b && hg->d_bn2_w && hg->d_bn2_b, "eagcn_model_backward: null head gradient");
+    EAGCN_CHECK_ARG(layer_hi < m->n_layers && layer_lo >= 0 && layer_lo <= layer_hi + 1,
+                    "eagcn_model_backward_range: layers %d..%d of %d", layer_hi, layer_lo, m->n_layers);
+    EAGCN_CHECK_ARG(!with_head || layer_hi == m->n_layers - 1 || layer_hi < layer_lo,
+                    "eagcn_model_backward_range: the head's backward is followed by the top layer");
     ModelSaved sv;
     ModelScratch sc;
     EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "eagcn_model_backward: saved block too small");
@@ -277,43 +308,67 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
     const ZeroJob zb{nullptr, 0, sc.hsb, sc.n_hst};
     hipStream_t side = m->aux_stream ? (hipStream_t)m->aux_stream : s;
     const bool forked = side != s;
-    // head backward (head2.hip): den3 -> bn_den2 -> den2 -> bn_den1 -> den1 -> Graph_BN, one launch per dense layer
-    // (d input + d weight), each BatchNorm's backward sums taken by the launch in front of it
-    double *sb_g = sc.hsb, *sb_1 = sc.hsb + 2 * F, *sb_2 = sc.hsb + 2 * (F + n1);
-    HeadDrop nodrop{0, 0u, 1.0f, 0, nullptr}, drop1 = nodrop;
-    {
-        int on; uint32_t thr; float inv_keep;
-        fill_drop(h->dropout, m->training, &on, &thr, &inv_keep);
-        drop1 = HeadDrop{on, thr, inv_keep, m->head_seed, m->head_seed_dev};
-    }
-    // dense 3: y = out (no BatchNorm behind it), input a2 = relu(bn_den2(h2))
-    HeadBwd b3{B, n2, nc, sv.h2, sv.bn_2, 1, nodrop, h->den3_w, dout, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-               sc.da2, sb_2, hg->d_den3_w, m->training};
-    RC(head_bwd(b3, s));
-    // dense 2: y = h2 followed by bn_den2 (+ the gradient that reaches graph_representation directly), input a1
-    HeadBwd b2{B, n1, n2, sv.h1, sv.bn_1, 1, drop1, h->den2_w, sc.da2, sv.h2, sv.bn_2, sb_2, dgraph_rep, hg->d_bn2_w, hg->d_bn2_b,
-               sc.da1, sb_1, hg->d_den2_w, m->training};
-    RC(head_bwd(b2, s));
-    // dense 1: y = h1 followed by bn_den1, input gn = Graph_BN(g)
-    HeadBwd b1{B, F, n1, sv.g, sv.bn_g, 0, nodrop, h->den1_w, sc.da1, sv.h1, sv.bn_1, sb_1, nullptr, hg->d_bn1_w, hg->d_bn1_b,
-               sc.dgn, sb_g, hg->d_den1_w, m->training};
-    RC(head_bwd(b1, s));
-    HeadGbn bg{B, F, sc.dgn, sv.g, sv.bn_g, sb_g, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training};
-    RC(head_gbn_bwd(bg, s));
-    // read-out
     const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
     const eagcn_layout lay = out_layout(last);
     const bool weighted = last->structure == EAGCN_STRUCT_WEIGHTED;
-    float* cur = sc.dxa;
-    float* other = sc.dxb;
-    // read-out backward: evaluated inside the last layer's first backward kernel (ReadoutGrad); only the
-    // gradient of the common non-stored row of Weighted_sum needs a (tiny) launch of its own
+    const bool sampled = pad_sampled(m);
+    if (with_head) {
+        // head backward (head2.hip): den3 -> bn_den2 -> den2 -> bn_den1 -> den1 -> Graph_BN, one launch per dense layer
+        // (d input + d weight), each BatchNorm's backward sums taken by the launch in front of it
+        double *sb_g = sc.hsb, *sb_1 = sc.hsb + 2 * F + 2, *sb_2 = sc.hsb + 2 * (F + n1) + 4;
+        // sync-BatchNorm: the backward sums of every head BatchNorm are summed across the ranks before the launch that consumes
+        // them; the global row counts are the ones the forward call left behind its statistics (same scratch block)
+        const bool sync = m->stats_hook && m->training;
+        const double *cn_g = sc.hst + 2 * F, *cn_1 = sc.hst + 2 * F + 2 + 2 * n1, *cn_2 = sc.hst + 2 * (F + n1) + 4 + 2 * n2;
+        const float gscale = sync && m->stats_world > 1 ? 1.0f / (float)m->stats_world : 1.0f;
+        auto hook = [&](double* buf, int n) -> int {
+            if (!sync) return EAGCN_OK;
+            if (m->stats_hook(buf, n, stream, m->stats_user)) {
+                set_error("eagcn_model: the sync-BatchNorm all-reduce hook failed");
+                return EAGCN_ERR_HIP;
+            }
+            return EAGCN_OK;
+        };
+        HeadDrop nodrop{0, 0u, 1.0f, 0, nullptr}, drop1 = nodrop;
+        {
+            int on; uint32_t thr; float inv_keep;
+            fill_drop(h->dropout, m->training, &on, &thr, &inv_keep);
+            drop1 = HeadDrop{on, thr, inv_keep, m->head_seed, m->head_seed_dev};
+        }
+        // dense 3: y = out (no BatchNorm behind it), input a2 = relu(bn_den2(h2))
+        HeadBwd b3{B, n2, nc, sv.h2, sv.bn_2, 1, nodrop, h->den3_w, dout, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                   sc.da2, sb_2, hg->d_den3_w, m->training};
+        RC(head_bwd(b3, s));
+        RC(hook(sb_2, 2 * n2));
+        // dense 2: y = h2 followed by bn_den2 (+ the gradient that reaches graph_representation directly), input a1
+        HeadBwd b2{B, n1, n2, sv.h1, sv.bn_1, 1, drop1, h->den2_w, sc.da2, sv.h2, sv.bn_2, sb_2, dgraph_rep, hg->d_bn2_w, hg->d_bn2_b,
+                   sc.da1, sb_1, hg->d_den2_w, m->training};
+        if (sync) { b2.cnt_y = cn_2; b2.gscale = gscale; }
+        RC(head_bwd(b2, s));
+        RC(hook(sb_1, 2 * n1));
+        // dense 1: y = h1 followed by bn_den1, input gn = Graph_BN(g)
+        HeadBwd b1{B, F, n1, sv.g, sv.bn_g, 0, nodrop, h->den1_w, sc.da1, sv.h1, sv.bn_1, sb_1, nullptr, hg->d_bn1_w, hg->d_bn1_b,
+                   sc.dgn, sb_g, hg->d_den1_w, m->training};
+        if (sync) { b1.cnt_y = cn_1; b1.gscale = gscale; }
+        RC(head_bwd(b1, s));
+        RC(hook(sb_g, 2 * F));
+        HeadGbn bg{B, F, sc.dgn, sv.g, sv.bn_g, sb_g, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training};
+        if (sync) { bg.cnt = cn_g; bg.gscale = gscale; }
+        RC(head_gbn_bwd(bg, s));
+        // read-out backward: evaluated inside the last layer's first backward kernel (ReadoutGrad); only the
+        // gradient of the common non-stored row of Weighted_sum needs a (tiny) launch of its own
+        if (sampled) RC(readout_backward_pad_views(b, sc.dg, &lay, size, m->molfp_mode, F, last->K, sv.pad_cnt, last->dropout, sc.dpad, stream));
+        else if (weighted) RC(readout_backward_pad(b, sc.dg, &lay, size, m->molfp_mode, F, sc.dpad, stream));
+    }
     ReadoutGrad rgd;
     rgd.dg = sc.dg; rgd.F = F; rgd.size = size; rgd.mode = m->molfp_mode; rgd.map = make_colmap(&lay);
-    const bool sampled = pad_sampled(m);
-    if (sampled) RC(readout_backward_pad_views(b, sc.dg, &lay, size, m->molfp_mode, F, last->K, sv.pad_cnt, last->dropout, sc.dpad, stream));
-    else if (weighted) RC(readout_backward_pad(b, sc.dg, &lay, size, m->molfp_mode, F, sc.dpad, stream));
-    for (int l = m->n_layers - 1; l >= 0; --l) {
+    const int top_l = m->n_layers - 1;
+    for (int l = layer_hi; l >= layer_lo; --l) {
+        // d(layer input) ping-pongs between two buffers, top-down: the layer t = top - l below the top reads the buffer the
+        // layer above wrote (t odd: dxb, t even: dxa) and writes the other one
+        const int t = top_l - l;
+        float* cur = (t & 1) ? sc.dxb : sc.dxa;
+        float* other = (t & 1) ? sc.dxa : sc.dxb;
         LayerSaved& L = sv.L[l];
         eagcn_layer_bufs w;
         memset(&w, 0, sizeof(w));
@@ -321,11 +376,11 @@ extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, 
         w.P = L.P; w.Y = L.Y; w.rscale = L.rscale; w.bn = L.bn; w.xout = L.xout; w.pad_row = L.pad_row;
         w.scratch = sc.layer; w.scratch_bytes = sc.layer_bytes; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
         w.aux_stream = m->aux_stream;
-        const bool top = l == m->n_layers - 1;
+        w.stats_hook = m->stats_hook; w.stats_user = m->stats_user;
+        const bool top = l == top_l;
         const float* dpad = (weighted && top) ? sc.dpad : nullptr;
         RC(layer_backward_impl(b, &m->layer[l], &w, top ? nullptr : cur, top ? &rgd : nullptr, dpad,
                                l > 0 ? other : nullptr, &lg[l], stream, top && sampled, top ? &zb : nullptr));
-        std::swap(cur, other);
     }
     if (forked) RC(stream_after(s, side));                       // join: every gradient is complete on s
     return EAGCN_OK;

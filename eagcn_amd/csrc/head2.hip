@@ -133,16 +133,17 @@ template <bool VEC, bool DROP>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwd a) {
     extern __shared__ __attribute__((aligned(16))) float tab[];          // [2][Kp]: scale, shift
     const int Kp = (a.K + 3) & ~3;
+    const double Bn = (a.cnt_in && a.training) ? *a.cnt_in : (double)a.B;      // rows of the BatchNorm (all ranks with sync-BatchNorm)
     for (int k = threadIdx.x; k < a.K; k += 256) {
         float mu, inv;
         if (a.training) {
-            const double mean = a.st_in[2 * k] / a.B;
-            double var = a.st_in[2 * k + 1] / a.B - mean * mean;
+            const double mean = a.st_in[2 * k] / Bn;
+            double var = a.st_in[2 * k + 1] / Bn - mean * mean;
             var = var > 0.0 ? var : 0.0;
             mu = (float)mean;
             inv = (float)(1.0 / sqrt(var + (double)a.eps));
             if (blockIdx.x == 0) {
-                const double unbiased = var * ((double)a.B / ((double)a.B - 1.0));
+                const double unbiased = var * (Bn / (Bn - 1.0));
                 a.run_mean[k] = (float)((1.0 - a.momentum) * (double)a.run_mean[k] + a.momentum * mean);
                 a.run_var[k] = (float)((1.0 - a.momentum) * (double)a.run_var[k] + a.momentum * unbiased);
             }
@@ -276,17 +277,18 @@ template <bool VEC, bool DROP>
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwd a) {
     extern __shared__ __attribute__((aligned(16))) float tab[];          // [3][Np]: al, be, ga of dy_eff
     const int Np = (a.N + 3) & ~3;
+    const double Bn = (a.cnt_y && a.training) ? *a.cnt_y : (double)a.B;
     for (int n = threadIdx.x; n < a.N; n += 256) {
         float al = 1.0f, be = 0.0f, ga = 0.0f;
         if (a.bny) {
             const float sc = a.bny[HT_SC * a.N + n], mu = a.bny[HT_MU * a.N + n], inv = a.bny[HT_INV * a.N + n];
             const double s1 = a.sb_y[2 * n], s2 = a.sb_y[2 * n + 1];
-            const float c1 = a.training ? (float)(s1 / a.B) : 0.0f, c2 = a.training ? (float)(s2 / a.B) : 0.0f;
+            const float c1 = a.training ? (float)(s1 / Bn) : 0.0f, c2 = a.training ? (float)(s2 / Bn) : 0.0f;
             // sc * (dy - c1 - (y - mu) * inv * c2)
             al = sc;
             be = -sc * inv * c2;
             ga = sc * (inv * c2 * mu - c1);
-            if (blockIdx.x == 0) { a.dgamma_y[n] = (float)s2; a.dbeta_y[n] = (float)s1; }
+            if (blockIdx.x == 0) { a.dgamma_y[n] = (float)(s2 * (double)a.gscale); a.dbeta_y[n] = (float)(s1 * (double)a.gscale); }
         }
         tab[n] = al; tab[Np + n] = be; tab[2 * Np + n] = ga;
     }
@@ -359,18 +361,25 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwd a) {
 // Graph_BN backward (no product in front of it): dg = al * dgn + be * g + ga, d gamma / d beta
 __global__ __launch_bounds__(256) void head_gbn_bwd_kernel(HeadGbn a) {
     const size_t total = (size_t)a.B * a.F;
+    const double Bn = (a.cnt && a.training) ? *a.cnt : (double)a.B;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int f = (int)(e % a.F);
         const float sc = a.bn[HT_SC * a.F + f], mu = a.bn[HT_MU * a.F + f], inv = a.bn[HT_INV * a.F + f];
         const double s1 = a.sb[2 * f], s2 = a.sb[2 * f + 1];
-        const float c1 = a.training ? (float)(s1 / a.B) : 0.0f, c2 = a.training ? (float)(s2 / a.B) : 0.0f;
+        const float c1 = a.training ? (float)(s1 / Bn) : 0.0f, c2 = a.training ? (float)(s2 / Bn) : 0.0f;
         a.dg[e] = sc * (a.dgn[e] - c1 - (a.g[e] - mu) * inv * c2);
-        if (e < (size_t)a.F) { a.dgamma[f] = (float)s2; a.dbeta[f] = (float)s1; }
+        if (e < (size_t)a.F) { a.dgamma[f] = (float)(s2 * (double)a.gscale); a.dbeta[f] = (float)(s1 * (double)a.gscale); }
     }
 }
 
 // column sums (sum g, sum g^2) of the read-out: 16 molecules per workgroup pre-reduced, then fp64 atomics
-__global__ __launch_bounds__(256) void head_colstats_kernel(const float* __restrict__ g, int B, int F, double* __restrict__ st) {
+__global__ __launch_bounds__(256) void head_colstats_kernel(const float* __restrict__ g, int B, int F, double* __restrict__ st,
+                                                             double* c0, double* c1, double* c2) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (c0) *c0 = (double)B;
+        if (c1) *c1 = (double)B;
+        if (c2) *c2 = (double)B;
+    }
     // grid (ceil(F/64), ceil(B/64)): lane = column, the four waves take rows r0 + wave, +4, ...
     __shared__ double part[4][64][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -395,9 +404,9 @@ __global__ __launch_bounds__(256) void head_colstats_kernel(const float* __restr
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------------
-int head_colstats(const float* g, int B, int F, double* st, hipStream_t s) {
+int head_colstats(const float* g, int B, int F, double* st, hipStream_t s, double* cnt0, double* cnt1, double* cnt2) {
     ProfScope ps(PROF_HEAD, s);
-    head_colstats_kernel<<<dim3(cdiv(F, 64), cdiv(B, 64)), 256, 0, s>>>(g, B, F, st);
+    head_colstats_kernel<<<dim3(cdiv(F, 64), cdiv(B, 64)), 256, 0, s>>>(g, B, F, st, cnt0, cnt1, cnt2);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

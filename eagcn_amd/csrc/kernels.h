@@ -164,15 +164,21 @@ struct HeadFwd {                 // y = act(bn(x)) . W  (+ column sums of y)
     const float* x; const double* st_in; const float *gamma, *beta; float *run_mean, *run_var; float* bn;
     const float* W; float* y; float* y2; double* st_out;
     int training, relu; float eps, momentum; HeadDrop drop;
+    const double* cnt_in = nullptr;      // sync-BatchNorm: rows of the BatchNorm over ALL ranks (st_in holds their summed sums)
 };
 struct HeadBwd {                 // backward of  y = act(bn_p(x)) . W : d(bn_p output) with its sums, and dW
     int B, K, N;
     const float* x; const float* bnp; int relu_p; HeadDrop drop; const float* W;
     const float* dy; const float* y; const float* bny; const double* sb_y; const float* extra;
     float *dgamma_y, *dbeta_y; float* dyp; double* sb_p; float* dW; int training;
+    const double* cnt_y = nullptr;       // sync-BatchNorm: global row count of the BatchNorm behind y (sb_y: sums of all ranks)
+    float gscale = 1.0f;                 // ... and 1 / world: d gamma / d beta = this rank's share of the summed sums
 };
-struct HeadGbn { int B, F; const float *dgn, *g, *bn; const double* sb; float *dg, *dgamma, *dbeta; int training; };
-int head_colstats(const float* g, int B, int F, double* st, hipStream_t s);
+struct HeadGbn { int B, F; const float *dgn, *g, *bn; const double* sb; float *dg, *dgamma, *dbeta; int training;
+                 const double* cnt = nullptr; float gscale = 1.0f; };
+// cnt (optional): three slots that receive B as a double (row counts of the head's BatchNorms, summed with the statistics)
+int head_colstats(const float* g, int B, int F, double* st, hipStream_t s, double* cnt0 = nullptr, double* cnt1 = nullptr,
+                  double* cnt2 = nullptr);
 int head_fwd(const HeadFwd& a, hipStream_t s);
 int head_bwd(const HeadBwd& a, hipStream_t s);
 int head_gbn_bwd(const HeadGbn& a, hipStream_t s);

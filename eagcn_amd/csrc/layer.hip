@@ -174,6 +174,27 @@ __device__ __forceinline__ void slab_sum(const double* __restrict__ slab, int ns
     }
 }
 
+// ---- sync-BatchNorm (SURVEY.md 8e "BN modes (ii)"): this rank's per-channel sums as ONE vector out[2 Fp + 1] = (sum, sum of
+//      squares / sum dH, sum dH xhat per column; rows of the BatchNorm) that the caller's hook all-reduces across the ranks; the
+//      finalize kernels then read the reduced vector (forward: as a single slab with the global row count; backward: for the
+//      means c1, c2 only -- d gamma / d beta stay this rank's sums, the gradient all-reduce averages them like every gradient).
+//      mode 1: forward slabs (live count from the tile count), mode 2: backward slabs (from the row count)
+constexpr int BWD_ROWS = 7;
+template <int L>
+__global__ __launch_bounds__(256) void bn_stats_sum_kernel(const double* __restrict__ slab, int nslab, int fp, double M,
+                                                            double* __restrict__ out, const int32_t* __restrict__ meta,
+                                                            int mode, int tiles_per_wg, int nvirt, int batch_B) {
+    if (meta[EAGCN_META_NLOG] > 0) M = (double)batch_B * (double)meta[EAGCN_META_NLOG];
+    if (mode == 1 && tiles_per_wg > 0) nslab = min(nslab, (meta[EAGCN_META_NTILES] + tiles_per_wg - 1) / tiles_per_wg);
+    if (mode == 2) nslab = max(1, min(nslab, (meta[EAGCN_META_T] + nvirt + BWD_ROWS - 1) / BWD_ROWS));
+    const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
+    const int cp = min(cpr, fp - 1);
+    double s1, s2;
+    slab_sum<L>(slab, nslab, fp, cp, sl, s1, s2);
+    if (cpr < fp && sl == 0) { out[2 * cp] = s1; out[2 * cp + 1] = s2; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[2 * fp] = M;
+}
+
 // ---- BatchNorm forward ---------------------------------------------------------------------------
 // 256/L columns per workgroup, L lanes per column
 template <int L>
@@ -181,9 +202,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                            double M, int training, float eps, float momentum,
                                                            const float* __restrict__ colp, ParamPtrs pp,
                                                            ViewCols vc, float* __restrict__ bn,
-                                                           const int32_t* __restrict__ meta, int tiles_per_wg, int batch_B) {
+                                                           const int32_t* __restrict__ meta, int tiles_per_wg, int batch_B,
+                                                           const double* __restrict__ M_dev) {
     // aggregation workgroups beyond the actual tile count exit without writing their slab
     if (meta[EAGCN_META_NLOG] > 0) M = (double)batch_B * (double)meta[EAGCN_META_NLOG];    // (M was computed from the capacity N)
+    if (M_dev) M = *M_dev;                             // sync-BatchNorm: rows of ALL ranks (slab = the all-reduced sums)
     if (tiles_per_wg > 0) nslab = min(nslab, (meta[EAGCN_META_NTILES] + tiles_per_wg - 1) / tiles_per_wg);   // (0: every slab is written)
     const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
     const int cp = min(cpr, fp - 1);
@@ -309,7 +332,6 @@ struct BwdArgs {
 // Compile-time variants (structure, per-molecule upstream gradient, dropout): the general kernel carried every path at once
 // -- 7.7 k instructions, scalar registers spilled to vector lanes, a few hundred exec-mask branches -- and was bound by
 // that, not by memory.
-constexpr int BWD_ROWS = 7;
 template <bool WEIGHTED, bool DG, bool DROP>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     __shared__ double da_s[EAGCN_MAX_VIEWS];
@@ -450,7 +472,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
                                                                int fp, double M, int training,
                                                                const float* __restrict__ bn, ViewCols vc,
                                                                GradPtrs gp, float* __restrict__ cc, const int32_t* __restrict__ meta, int nvirt,
-                                                               int batch_B, int da_chunks, int da_stride) {
+                                                               int batch_B, int da_chunks, int da_stride,
+                                                               const double* __restrict__ gsum) {
     if (meta[EAGCN_META_NLOG] > 0) M = (double)batch_B * (double)meta[EAGCN_META_NLOG];
     nslab = max(1, min(nslab, (meta[EAGCN_META_T] + nvirt + BWD_ROWS - 1) / BWD_ROWS));   // slabs actually written
     const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
@@ -468,8 +491,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     double s1, s2;
     slab_sum<L>(slab, nslab, fp, cp, sl, s1, s2);
     if (cpr >= fp || sl != 0) return;
-    cc[cp] = training ? (float)(s1 / M) : 0.0f;
-    cc[fp + cp] = training ? (float)(s2 / M) : 0.0f;
+    {   // the means of dY = sc (dH - c1 - xhat c2) run over ALL rows of the BatchNorm: with sync-BatchNorm those of every rank
+        double g1 = s1, g2 = s2;
+        if (gsum) { g1 = gsum[2 * cp]; g2 = gsum[2 * cp + 1]; M = gsum[2 * fp]; }
+        cc[cp] = training ? (float)(g1 / M) : 0.0f;
+        cc[fp + cp] = training ? (float)(g2 / M) : 0.0f;
+    }
     const int k = col_view(vc, cp), f = cp - vc.off[k];
     if (f < vc.width[k]) {
         gp.dgamma[k][f] = (float)s2;
@@ -655,7 +682,7 @@ static bool gemm3_layer(int ld_in) {
 }
 
 struct Packed { float *Wcat, *WcatT, *colp, *sig, *rsig; };
-struct FwdScratch { void* gws; float *Wcat, *WcatT, *colp, *sig, *rsig; double* stats; };
+struct FwdScratch { void* gws; float *Wcat, *WcatT, *colp, *sig, *rsig; double* stats; double* gsum; };
 static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
     Carver c(base);
     Packed t;
@@ -671,7 +698,7 @@ struct BwdScratch {
     void* gws;                   // GEMM hand-off workspace: FIRST in both carvings, so that every layer of a model and both
                                  // directions share one region (one flag clear per API call, kernels.h gemm3_clear_flags)
     float *Wcat, *WcatT, *colp, *sig, *rsig, *dY, *dP, *cc, *dWcat;
-    double *slab, *slab_da, *datt;
+    double *slab, *slab_da, *datt, *gsum;
 };
 static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, FwdScratch* s) {
     Carver c(base);
@@ -683,6 +710,7 @@ static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, Fw
     t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
     t.stats = c.take<double>((size_t)std::max(d.gx, d.sslabs) * d.fp * 2);
+    t.gsum = c.take<double>((size_t)2 * d.fp + 8);
     if (s) *s = t;
     return c.off;
 }
@@ -702,6 +730,7 @@ static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, Bw
     t.slab = c.take<double>((size_t)d.gxb * d.fp * 2);
     t.slab_da = c.take<double>((size_t)d.gxb * cdiv(d.fp, 1024) * EAGCN_MAX_VIEWS);
     t.datt = c.take<double>((size_t)std::max(edge_grid_x(b), d.sslabs) * EAGCN_MAX_VIEWS * EDGE_SLAB);
+    t.gsum = c.take<double>((size_t)2 * d.fp + 8);
     if (s) *s = t;
     return c.off;
 }
@@ -875,12 +904,23 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
     }
     const double M = (double)b->B * (double)b->N;
     ProfScope psbn(PROF_BN, s);
-    if (nslab > 64)
+    if (w->stats_hook && p->training) {
+        // sync-BatchNorm: this rank's sums -> one vector, summed across the ranks by the caller's hook, finalize from that
+        if (nslab > 64) bn_stats_sum_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.stats, nslab, d.fp, M, sc.gsum, b->meta, 1, tiles_per_wg, 0, b->B);
+        else bn_stats_sum_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.stats, nslab, d.fp, M, sc.gsum, b->meta, 1, tiles_per_wg, 0, b->B);
+        EAGCN_LAUNCH_CHECK();
+        if (w->stats_hook(sc.gsum, 2 * d.fp + 1, stream, w->stats_user)) {
+            set_error("eagcn_layer_forward: the sync-BatchNorm all-reduce hook failed");
+            return EAGCN_ERR_HIP;
+        }
+        bn_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.gsum, 1, d.fp, M, p->training, p->bn_eps, p->bn_momentum, sc.colp,
+                                                                pp, d.vc, w->bn, b->meta, 0, b->B, sc.gsum + 2 * d.fp);
+    } else if (nslab > 64)
         bn_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
-                                                               p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, tiles_per_wg, b->B);
+                                                               p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, tiles_per_wg, b->B, nullptr);
     else
         bn_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
-                                                                p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, tiles_per_wg, b->B);
+                                                                p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, tiles_per_wg, b->B, nullptr);
     EAGCN_LAUNCH_CHECK();
     ApplyArgs aa;
     aa.bt = *b; aa.vc = d.vc; aa.structure = p->structure; aa.fp = d.fp; aa.Y = w->Y; aa.ldy = d.fp;
@@ -981,12 +1021,24 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
 #undef EAGCN_BWD
         }
         EAGCN_LAUNCH_CHECK();
+        const double* gsum = nullptr;
+        if (w->stats_hook && p->training) {
+            // sync-BatchNorm: sum dH, sum dH xhat and the row count of this rank -> summed across the ranks by the caller's hook
+            if (gxb > 64) bn_stats_sum_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.slab, gxb, d.fp, M, sc.gsum, b->meta, 2, 0, ba.nvirt, b->B);
+            else bn_stats_sum_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, gxb, d.fp, M, sc.gsum, b->meta, 2, 0, ba.nvirt, b->B);
+            EAGCN_LAUNCH_CHECK();
+            if (w->stats_hook(sc.gsum, 2 * d.fp + 1, stream, w->stats_user)) {
+                set_error("eagcn_layer_backward: the sync-BatchNorm all-reduce hook failed");
+                return EAGCN_ERR_HIP;
+            }
+            gsum = sc.gsum;
+        }
         if (gxb > 64)
             bn_bwd_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
-                                                                       d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb);
+                                                                       d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb, gsum);
         else
             bn_bwd_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
-                                                                        d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb);
+                                                                        d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb, gsum);
         EAGCN_LAUNCH_CHECK();
         if (b->T > 0 && !sagg_enabled()) {        // (the bond-list aggregation applies this affine while it stages dH)
             bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);

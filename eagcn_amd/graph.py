@@ -111,6 +111,7 @@ class GraphRunner:
         self.generation = 0
         self.size_static = [torch.ones(B, dtype=torch.int64, device=device) for _ in range(2)]
         self.aux = None
+        self.dp_group = None
         # optional fork of off-critical-path backward work onto a second stream (graph branches).
         # Measured on MI355X at the Tox21 shape: replay got SLOWER (0.85 vs 0.77 ms/step), so off by default.
         if os.environ.get('EAGCN_AUX_STREAM', '0') == '1':
@@ -121,6 +122,9 @@ class GraphRunner:
         self.scratch_bytes = lib.eagcn_model_scratch_bytes(self.index.ref(), C.byref(m))
         self.saved = [torch.empty(self.saved_bytes, dtype=torch.uint8, device=device) for _ in range(2)]
         self.scratch = torch.empty(self.scratch_bytes, dtype=torch.uint8, device=device)
+        if plan.stats is not None:
+            from .parallel import register_stats_buffer
+            register_stats_buffer(self.scratch)               # (pieces of it are handed to the sync-BatchNorm hook)
         f32 = dict(dtype=torch.float32, device=device)
         self.out = torch.zeros((B, m.head.nclass), **f32)
         self.graph_rep = torch.zeros((B, m.head.n_den2), **f32)
@@ -132,7 +136,8 @@ class GraphRunner:
         self.labels_static = [torch.zeros((B, m.head.nclass), **f32) for _ in range(2)]
         self.weight_static = torch.zeros((m.head.nclass, 2), **f32)
         self.loss_static = [torch.zeros((), **f32) for _ in range(2)]
-        self.scale_static = torch.ones((), **f32)
+        self.scale_static = [torch.ones((), **f32) for _ in range(2)]      # per slot: written by the NEXT batch's preparation
+        self.comm_in_graph = None      # gradient all-reduce captured inside the step graph (None: not tried yet)
         n = plan.offsets[-1]
         self.flat_acc = torch.zeros(n, **f32)               # the captured backward writes here; p.grad are views of it
         self.acc_views = plan.grad_views(self.flat_acc)
@@ -269,7 +274,7 @@ class GraphRunner:
                 raise L.EagcnHipError('a previous batch held %d directed bonds, more than edge_cap=%d (it was processed as '
                                       'an empty batch; no memory was overwritten)' % (meta[L.META_EDGE_OVERFLOW], self.slots[0].E))
 
-    def _prepare(self, adj, rels, afm, size, seed, overlap=False, bonds=None, labels=None):
+    def _prepare(self, adj, rels, afm, size, seed, overlap=False, bonds=None, labels=None, dp_scale=None):
         """Everything of a step that reads the caller's tensors (index build, packed input, seeds, sizes, labels of a fused
         step), on the side stream when `overlap`; afterwards the main stream is ordered behind it."""
         lib = L.load()
@@ -327,6 +332,13 @@ class GraphRunner:
                 self.size_static[cur].copy_(size, non_blocking=True)
             if labels is not None:
                 self.labels_static[cur].copy_(labels.reshape(self.labels_static[cur].shape), non_blocking=True)
+            if dp_scale is not None:
+                if isinstance(dp_scale, str):
+                    # c_r = world * n_r / sum_r n_r (parallel.dp_loss_scale) from THIS batch's labels: a 1-element collective
+                    # that rides with the batch's preparatory work instead of sitting in front of the step graph
+                    from .parallel import dp_loss_scale
+                    dp_scale = dp_loss_scale(self.labels_static[cur], self.dp_group)
+                self.scale_static[cur].copy_(dp_scale, non_blocking=True)
             if idx.relvec is not None:                       # code books of this batch (rows beyond them are never referenced)
                 for t, v in zip(idx.relvec, self.rel_vectors):
                     t[:v.shape[0]].copy_(v, non_blocking=True)
@@ -443,13 +455,40 @@ class GraphRunner:
             L.check(lib.eagcn_mse_loss(x.data_ptr(), y.data_ptr(), x.numel(), self.loss_static[cur].data_ptr(),
                                        self.dout.data_ptr(), _stream()), 'eagcn_mse_loss')
         if scaled:                                            # data-parallel global normalisation (parallel.dp_loss_scale)
-            self.dout.mul_(self.scale_static)
-            self.loss_static[cur].mul_(self.scale_static)
+            self.dout.mul_(self.scale_static[cur])
+            self.loss_static[cur].mul_(self.scale_static[cur])
 
-    def train_step(self, adj, rels, afm, size, seed, labels, kind, weight=None, scale=None, overlap=False, bonds=None):
+    def _call_backward_comm(self, comm):
+        """The backward with the gradient average inside: head + upper layers, then the all-reduce of their bucket of the flat
+        gradient buffer is STARTED (asynchronously: under capture a branch of the graph), the first layer's backward runs
+        beside it, and its own (small) bucket follows.  One bucket when the model has a single layer."""
+        lib = L.load()
+        nl = len(self.plan.layers)
+        if nl < 2:
+            self._call_backward()
+            comm.start(self.flat_acc).wait()
+            return
+        size_ptr = _ptr(self.size_static[self.cur]) if self.plan.molfp else C.c_void_p(0)
+
+        def part(with_head, hi, lo):
+            L.check(lib.eagcn_model_backward_range(self.index.ref(), C.byref(self.cms[self.cur]), size_ptr, _ptr(self.saved[self.cur]),
+                                                   self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.dout),
+                                                   _ptr(self.dgr), self.lg, C.byref(self.hg), with_head, hi, lo, _stream()),
+                    'eagcn_model_backward_range')
+        part(1, nl - 1, 1)
+        cut = self.plan.offsets[self.plan.layer_slices[1][0]]      # first gradient of the second layer: [0, cut) = layer 1
+        upper = comm.start(self.flat_acc[cut:])
+        part(0, 0, 0)
+        upper.wait()
+        comm.start(self.flat_acc[:cut]).wait()
+
+    def train_step(self, adj, rels, afm, size, seed, labels, kind, weight=None, scale=None, overlap=False, bonds=None,
+                   comm=None):
         """forward -> fused loss (csrc/loss.hip) -> backward of one batch as a single captured graph: no launch boundary
         between the three, one host call per step.  Returns the loss (device scalar); out / graph_representation are read
-        with outputs(), the parameter gradients are attached exactly as backward() does."""
+        with outputs(), the parameter gradients are attached exactly as backward() does.  `comm` (a GradientAllReducer with
+        more than one rank behind it): the gradient average is captured into the same graph (_call_backward_comm); should the
+        capture of the collective fail on this stack, the runner falls back to one host-issued all-reduce after the replay."""
         if not self.training:
             raise L.EagcnHipError('train_step needs a training-mode runner')
         labels = labels.to(device=self.device, dtype=torch.float32)
@@ -463,32 +502,59 @@ class GraphRunner:
             if self._weight_src != tag:                       # (class weights change once per run, not per step)
                 self.weight_static.copy_(w)
                 self._weight_src = tag
-        if scale is not None:
-            self.scale_static.copy_(scale)
+        if comm is not None and not comm.active():
+            comm = None
+        self.dp_group = comm.group if comm is not None else None
         if not self.dgr_is_zero:
             self.dgr.zero_()
             self.dgr_is_zero = True
         keep, grads = self._before_grads()
-        self._prepare(adj, rels, afm, size, seed, overlap, bonds, labels=labels)
+        self._prepare(adj, rels, afm, size, seed, overlap, bonds, labels=labels, dp_scale=scale)
         cur = self.cur
-        key = (kind, scale is not None)
+        in_graph = comm is not None and self.comm_in_graph is not False
+        key = (kind, scale is not None, in_graph)
         if self.graphs[cur][2] is None or self.step_kind[cur] != key:
             self._call_forward()                              # eager (first use of the slot / of this loss): the warm-up
-            self._call_loss(*key)
-            self._call_backward()
+            self._call_loss(key[0], key[1])
+            if in_graph:
+                self._call_backward_comm(comm)
+            else:
+                self._call_backward()
             torch.cuda.synchronize(self.device)
             L.load().eagcn_prof_enable(0)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                self._call_forward()
-                self._call_loss(*key)
-                self._call_backward()
+            try:
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    self._call_forward()
+                    self._call_loss(key[0], key[1])
+                    if in_graph:
+                        self._call_backward_comm(comm)
+                    else:
+                        self._call_backward()
+                if in_graph:
+                    self.comm_in_graph = True
+            except Exception:
+                if not in_graph:
+                    raise
+                # the collective could not be captured: step graph without it, host-issued all-reduce behind every replay
+                torch.cuda.synchronize(self.device)
+                self.comm_in_graph, in_graph = False, False
+                key = (kind, scale is not None, False)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    self._call_forward()
+                    self._call_loss(key[0], key[1])
+                    self._call_backward()
+                # (the eager step above left the AVERAGED gradients in the flat buffer; the host-issued average below is then
+                #  the identity on values that are equal on every rank)
             self.graphs[cur][2], self.step_kind[cur] = g, key
         else:
             self.graphs[cur][2].replay()
         self.fwd_done = None            # (no launch boundary after the forward any more: the next index build only waits
                                         #  for its slot and runs under this step's kernels)
         self._attach_grads(keep, grads)
+        if comm is not None and not in_graph:
+            comm()                                            # one in-place average of the flat buffer, issued by the host
         return self.loss_static[cur].detach() if self.static_outputs else self.loss_static[cur].clone()
 
 

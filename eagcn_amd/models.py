@@ -84,9 +84,10 @@ class EAGCN(nn.Module):
                  n_den1=128, n_den2=64, nclass=1, dropout=0.0, structure='Concate', molfp_mode='sum',
                  pool_num=5, *, n_layers=4, widths1=None, widths2=None, rel_channels=None, atom_rep='lazy',
                  grad_mode='autograd', overlap_index=False, graph=False, row_cap=None, graph_outputs='copy',
-                 validate='sync', max_runners=8, edge_cap=None, n_bucket=0, relations='onehot'):
+                 validate='sync', max_runners=8, edge_cap=None, n_bucket=0, relations='onehot', sync_bn=False):
         super().__init__()
         self.n_bucket = int(n_bucket)
+        self.sync_bn = bool(sync_bn)
         if relations not in ('onehot', 'general'):
             raise ValueError("relations must be 'onehot' (neural_fp.py:111-120) or 'general' (any channel values, layers.py:82)")
         self.relations = relations
@@ -112,6 +113,8 @@ class EAGCN(nn.Module):
             if structure in ('Concate', 'Weighted_sum') and n_layers != 4:
                 raise ValueError("molfp_mode='pool' reads the attention matrix of layer 4 (last=True, layers.py:319-324)")
         self.pool_num = int(pool_num)
+        if sync_bn and (structure == 'GAT' or molfp_mode == 'pool'):
+            raise ValueError("sync_bn is wired into the model engine (structure Concate / Weighted_sum / GCN, molfp_mode sum / ave)")
         if not 1 <= n_layers <= 4:
             raise ValueError('n_layers must be 1..4')
         if structure == 'GAT':                                            # models.py:69-73: four GAT layers
@@ -191,7 +194,11 @@ class EAGCN(nn.Module):
             raise ops.L.EagcnHipError("molfp_mode='pool' has no model-level plan: it runs layer by layer (forward_composed)")
         if self._plan is None:
             head = {n: getattr(self, n) for n in ('den1', 'den2', 'den3', 'Graph_BN', 'bn_den1', 'bn_den2')}
-            self._plan = ops.ModelPlan(self.graph_layers(), head, self.n_afeat, self.molfp_mode, self.dropout)
+            stats = None
+            if getattr(self, 'sync_bn', False):       # every BatchNorm over the GLOBAL batch (SURVEY.md 8e "BN modes (ii)")
+                from .parallel import StatsAllReducer
+                stats = StatsAllReducer()
+            self._plan = ops.ModelPlan(self.graph_layers(), head, self.n_afeat, self.molfp_mode, self.dropout, stats)
         return self._plan
 
     # The plan and the graph runners hold ctypes structs with device pointers, captured HIP graphs and static
@@ -213,7 +220,7 @@ class EAGCN(nn.Module):
         self._plan = None
         self._runners = {}
         for name, default in (('graph_outputs', 'copy'), ('validate', 'sync'), ('max_runners', 8), ('edge_cap', None), ('n_bucket', 0),
-                              ('relations', 'onehot'), ('pool_num', 5)):
+                              ('relations', 'onehot'), ('pool_num', 5), ('sync_bn', False)):
             self.__dict__.setdefault(name, default)
 
     def state_dict(self, *a, **kw):
@@ -298,14 +305,19 @@ class EAGCN(nn.Module):
         out, graph_representation = G.graph_forward(runner, adjs, rels, afms, size, seed, self.overlap_index, btuple)
         return out, self._atom_rep(runner), graph_representation
 
-    def fused_step(self, batch, labels, task, bce_weight=None, scale=None, bonds=None):
+    def fused_step(self, batch, labels, task, bce_weight=None, scale=None, bonds=None, reducer=None):
         """forward -> loss -> backward of one training batch as ONE captured graph launch (graph mode only): the inner
         loop of train.py:310-334 without the launch boundaries between the three phases.  `batch` is the reference's
         forward argument tuple (adjs, afms, TypeAtt, ..., size) -- or (afms, size) together with `bonds` for a compact
         batch; task 'reg' = MSE (train.py:321-325), anything else = weighted masked BCE-with-logits (train.py:326-331)
         with `bce_weight` [T,2]; `scale` an optional device scalar multiplied into loss and gradient (data-parallel
-        global normalisation, parallel.dp_loss_scale).  Returns (loss, (out, atom_representations,
-        graph_representation)); the parameter gradients are attached to ``p.grad`` as ``loss.backward()`` would."""
+        global normalisation, parallel.dp_loss_scale) -- or the string 'dp': the same factor, computed from this batch's
+        labels by a 1-element collective issued with the batch's other preparatory work (on the side stream under the
+        previous step when overlap_index is on).  `reducer` (parallel.GradientAllReducer): the gradient average over
+        the ranks is part of the step -- captured INTO the step graph, the bucket of the upper layers + head starting
+        while the first layer's backward still runs; the caller does not call the reducer again.  Returns (loss, (out,
+        atom_representations, graph_representation)); the parameter gradients are attached to ``p.grad`` as
+        ``loss.backward()`` would."""
         if not (self.graph and self.training and torch.is_grad_enabled()):
             raise ops.L.EagcnHipError('fused_step needs graph=True, training mode and grad enabled')
         if bonds is None:
@@ -327,7 +339,8 @@ class EAGCN(nn.Module):
             if getattr(self, '_bce_weight_cache', (None, None))[0] != key:
                 self._bce_weight_cache = (key, torch.tensor(bce_weight, dtype=torch.float32, device=afms.device))
             bce_weight = self._bce_weight_cache[1]
-        loss = runner.train_step(adjs, rels, afms, size, seed, labels, kind, bce_weight, scale, self.overlap_index, btuple)
+        loss = runner.train_step(adjs, rels, afms, size, seed, labels, kind, bce_weight, scale, self.overlap_index, btuple,
+                                 comm=reducer)
         out, graph_representation = runner.outputs()
         return loss, (out, self._atom_rep(runner), graph_representation)
 

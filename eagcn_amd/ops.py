@@ -714,6 +714,8 @@ def _scratch(device, nbytes):
     if t is None or t.numel() < nbytes:
         t = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
         _scratch_cache[key] = t
+        from .parallel import register_stats_buffer
+        register_stats_buffer(t)                      # (pieces of it are handed to the sync-BatchNorm hook)
     return t
 
 
@@ -721,8 +723,9 @@ class ModelPlan:
     """Static description of an EAGCN module for the model-level entry points: parameter order,
     layer specs with their chained column layouts, gradient-buffer offsets."""
 
-    def __init__(self, layers, head, n_afeat, molfp_mode, dropout):
-        # layers: list of GraphConv_Layer modules; head: dict of modules
+    def __init__(self, layers, head, n_afeat, molfp_mode, dropout, stats=None):
+        # layers: list of GraphConv_Layer modules; head: dict of modules; stats: parallel.StatsAllReducer (sync-BatchNorm) or None
+        self.stats = stats
         self.layers = layers
         self.head = head
         self.molfp = 1 if molfp_mode == 'ave' else 0
@@ -827,6 +830,9 @@ class ModelPlan:
             setattr(hp, pre + '_b', mod.bias.data_ptr())
             setattr(hp, pre + '_rm', mod.running_mean.data_ptr())
             setattr(hp, pre + '_rv', mod.running_var.data_ptr())
+        if self.stats is not None:                    # sync-BatchNorm: cross-rank sums through eagcn_amd.parallel.StatsAllReducer
+            m.stats_hook = C.cast(self.stats.cfn, C.c_void_p)
+            m.stats_world = int(self.stats.world())
         return m
 
 

@@ -83,6 +83,63 @@ def sync_bn_backward_stats(sum_dh, sum_dh_xhat, group=None):
     return buf[:F], buf[F:]
 
 
+# ---- sync-BatchNorm wired into the engine (SURVEY.md 8e "BN modes (ii)") -----------------------------------------------------
+# The C entry points hand the per-channel partial sums of every BatchNorm (graph-conv layers and head) to a callback between
+# the kernel that reduces them and the one that finalizes the statistics -- forward and backward, eager and while a HIP graph is
+# being captured (the collective then becomes a node of that graph).  The callback below sums them across the ranks with
+# torch.distributed; with it the model equals a reference run at the GLOBAL batch (pad all shards to the same N: padding rows
+# enter the per-view BatchNorm through the row count).
+_stats_buffers = []           # weak references to the uint8 device tensors the C side carves its scratch from
+
+
+def register_stats_buffer(t):
+    """Tell the hook about a device tensor the C side may hand pieces of to it (engine scratch blocks)."""
+    import weakref
+    _stats_buffers[:] = [r for r in _stats_buffers if r() is not None]
+    if not any(r() is t for r in _stats_buffers):
+        _stats_buffers.append(weakref.ref(t))
+
+
+class StatsAllReducer:
+    """ctypes callback `int hook(double* buf, int n, void* stream, void* user)` (include/eagcn_hip.h eagcn_allreduce_fn):
+    in-place cross-rank SUM of n doubles that live inside a registered scratch tensor, on the current stream."""
+
+    def __init__(self, group=None):
+        from . import _lib as L
+        self.group = group
+        self.calls = 0
+        self.error = None
+        self.cfn = L.ALLREDUCE_FN(self._call)          # keep the object alive as long as any C struct points at it
+
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _call(self, ptr, n, stream, user):
+        try:
+            self.calls += 1
+            if not dist.is_initialized():
+                return 0
+            if dist.get_world_size(self.group) == 1 and os.environ.get('EAGCN_FORCE_DIST', '0') != '1':
+                return 0
+            view = None
+            for r in _stats_buffers:
+                t = r()
+                if t is None:
+                    continue
+                base = t.data_ptr()
+                if base <= ptr and ptr + 8 * n <= base + t.numel():
+                    off = ptr - base
+                    view = t[off:off + 8 * n].view(torch.float64)
+                    break
+            if view is None:
+                raise RuntimeError('sync-BatchNorm hook: buffer %#x is not inside a registered scratch tensor' % ptr)
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            return 0
+        except Exception as e:                          # never let an exception cross the C boundary
+            self.error = e
+            return 1
+
+
 class GradientAllReducer:
     """Averages the gradients of `params` across ranks with a single collective.
 
@@ -109,6 +166,27 @@ class GradientAllReducer:
             if p.grad is not None and not (lo <= p.grad.data_ptr() < hi):
                 return None                       # some gradient lives elsewhere: use the generic path
         return flat
+
+    def active(self):
+        """True when there is something to reduce over (more than one rank, or EAGCN_FORCE_DIST=1 for single-GPU tests)."""
+        if not dist.is_initialized():
+            return False
+        return dist.get_world_size(self.group) > 1 or os.environ.get('EAGCN_FORCE_DIST', '0') == '1'
+
+    def start(self, t):
+        """Asynchronous in-place average of a contiguous device tensor (a bucket of the flat gradient buffer): returns the
+        work handle; ``.wait()`` orders the current stream behind it.  Capturable: inside a HIP-graph capture the collective
+        becomes a branch of the graph that runs beside whatever is issued before the wait."""
+        if t.is_cuda:
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        world = dist.get_world_size(self.group)
+
+        class _Scaled:
+            def wait(self_inner):
+                w.wait()
+                t.div_(world)
+        return _Scaled()
 
     def __call__(self):
         if not dist.is_initialized():

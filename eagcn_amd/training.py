@@ -123,11 +123,11 @@ def train_step(model, optimizer, batch, labels, task, bce_weight=None, dp_global
     if fused is None:
         fused = bool(getattr(model, 'graph', False)) and model.training and hasattr(model, 'fused_step')
     if fused:
-        scale = None
-        if dp_global_norm:
-            from .parallel import dp_loss_scale
-            scale = dp_loss_scale(labels, reducer.group if reducer is not None else None)
-        loss, _ = model.fused_step(batch, labels, task, bce_weight, scale, bonds=bonds)
+        # the global BCE normalisation ('dp': a 1-element collective issued with the batch's preparatory work) and the gradient
+        # average (captured into the step graph, upper bucket overlapped with the first layer's backward) are part of the step
+        loss, _ = model.fused_step(batch, labels, task, bce_weight, 'dp' if dp_global_norm else None, bonds=bonds, reducer=reducer)
+        optimizer.step()
+        return loss
     else:
         out, _, _ = model(*batch) if bonds is None else model.forward_compact(bonds, *batch)
         if task == 'reg':

@@ -159,6 +159,13 @@ typedef struct eagcn_layer_params {
     const float* ave_w;                     /* [K]      layer.ave.weight (Weighted_sum)         */
 } eagcn_layer_params;
 
+/* Cross-rank sum of `n` doubles in place on `stream` (sync-BatchNorm, SURVEY.md 8e "BN modes (ii)"): the per-channel partial
+ * sums of a layer's BatchNorm (sum y, sum y^2, rows -- backward: sum dH, sum dH xhat, rows) are handed to the caller between
+ * the reduction and the finalize kernel of that BatchNorm, forward and backward; the caller all-reduces them (RCCL through
+ * torch.distributed in eagcn_amd/parallel.py -- also while the call is being captured into a HIP graph, the collective then
+ * becomes a node of that graph).  Returns 0 on success.  NULL hook: BatchNorm over this rank's rows only ("local-BN"). */
+typedef int (*eagcn_allreduce_fn)(double* buf, int n, void* stream, void* user);
+
 typedef struct eagcn_layer_bufs {
     const float* x;                         /* [T][ld_in]                                       */
     float* P;                               /* [T][Fp]  X.[W_1|..|W_K]            (saved)       */
@@ -174,6 +181,8 @@ typedef struct eagcn_layer_bufs {
                                             /* with the dX chain (fork/join by events; capturable)  */
     void* packed;                           /* optional, eagcn_layer_packed_bytes(): forward keeps  */
     size_t packed_bytes;                    /* the re-laid parameters here and backward reuses them */
+    eagcn_allreduce_fn stats_hook;          /* sync-BatchNorm: cross-rank sum of the BatchNorm partial sums (NULL: local-BN) */
+    void* stats_user;
 } eagcn_layer_bufs;
 
 typedef struct eagcn_layer_grads {
@@ -325,6 +334,12 @@ typedef struct eagcn_model {
     void* aux_stream;                       /* optional second stream for off-critical-path backward work */
     eagcn_layer_params layer[4];            /* layer[l].in must equal the output layout of layer l-1   */
     eagcn_head_params head;
+    eagcn_allreduce_fn stats_hook;          /* sync-BatchNorm of EVERY BatchNorm of the model (the per-view ones of the layers and
+                                               Graph_BN / bn_den1 / bn_den2 of the head; see eagcn_layer_bufs); NULL: local-BN   */
+    void* stats_user;
+    int32_t stats_world;                    /* ranks behind the hook (>= 1): the head's d gamma / d beta are formed from the
+                                               summed sums and divided by it, so that the gradient AVERAGE over ranks is exact */
+    int32_t reserved_;
 } eagcn_model;
 
 size_t eagcn_model_saved_bytes(const eagcn_batch* b, const eagcn_model* m);    /* kept forward -> backward */
@@ -344,6 +359,15 @@ int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, const int64
                          size_t saved_bytes, void* scratch, size_t scratch_bytes, const float* dout,
                          const float* dgraph_rep, const eagcn_layer_grads* lg, const eagcn_head_grads* hg,
                          void* stream);
+
+/* The same backward in two pieces, so that a data-parallel caller can start the gradient all-reduce of the upper layers while the
+ * lower ones are still running: with_head != 0 runs the head + read-out backward first; then the layers layer_hi, layer_hi-1,
+ * ..., layer_lo (n_layers-1 >= layer_hi >= layer_lo >= 0).  eagcn_model_backward == (with_head = 1, n_layers-1, 0); a split
+ * must be issued top-down on one stream: (1, n_layers-1, l) then (0, l-1, 0). */
+int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_model* m, const int64_t* size, void* saved,
+                               size_t saved_bytes, void* scratch, size_t scratch_bytes, const float* dout,
+                               const float* dgraph_rep, const eagcn_layer_grads* lg, const eagcn_head_grads* hg,
+                               int with_head, int layer_hi, int layer_lo, void* stream);
 
 /* ---- losses of the training loop (train.py:321-331), value + d/dlogits in one launch --------------- */
 /* labels [B][T] with 1 / 0 / anything else = missing; class_weight [T][2] = {w_pos, w_neg} (utils.py:681-700) */

@@ -1,0 +1,115 @@
+"""Data-parallel step on N ranks (one process per GPU, RCCL), run by tests/test_gpu_dist.py -- under
+``python -m torch.distributed.run --nproc-per-node N`` when the box has N >= 2 GPUs, or stand-alone with EAGCN_FORCE_DIST=1 /
+WORLD_SIZE=1 (same code path, one rank).
+
+What every rank does: its contiguous shard of ONE global synthetic batch (all shards padded to the global N), the graph-mode
+fused training step with the gradient average captured INSIDE the step graph (GraphRunner._call_backward_comm: upper bucket
+started before the first layer's backward) and the global BCE normalisation ('dp' scale, a 1-element collective issued with the
+batch preparation).  What is checked, on every rank, against the CPU oracle (oracle/eagcn_ref.py):
+  * local-BN (default): averaged gradients == sum over shards of the gradient of S_r / n_total, every shard an oracle run of
+    its own (BatchNorm over the shard's rows) -- SURVEY.md 8e "BN modes (i)";
+  * sync_bn=True: averaged gradients, loss and outputs == ONE oracle run on the concatenated batch -- "BN modes (ii)";
+  * all ranks hold bit-identical averaged gradients; the runner reports that the collective really was captured in the graph.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.distributed as dist
+
+from eagcn_amd import EAGCN
+from eagcn_amd.parallel import GradientAllReducer, init_distributed, shard_range
+from eagcn_amd.synthetic import bce_weights, make_batch
+from oracle.eagcn_ref import RefEAGCN, weights_init_      # checker only
+
+rank, world, local = init_distributed()
+assert dist.is_initialized() and dist.get_backend() == 'nccl'
+dev = torch.device('cuda', local)
+T, BS = 3, 12
+W1, W2 = [12, 8, 8, 8, 8], [20, 12, 12, 12, 12]
+torch.manual_seed(0)
+ref = RefEAGCN(9, 24, W1, W2, 32, 16, T, 0.0, n_layers=2)
+weights_init_(ref)
+mb = make_batch(B=BS * world, n_max=30, n_med=10, rel_channels=(9, 4, 2, 2, 2), seed=11, n_tasks=T)
+dense_all = mb.dense()
+labels_all = torch.from_numpy(mb.labels)
+bw = bce_weights(T)
+lo, hi = shard_range(BS * world, rank, world)
+shard = [t[lo:hi].to(dev) for t in dense_all]
+labels = labels_all[lo:hi].to(dev)
+bw_dev = torch.tensor(bw, dtype=torch.float32, device=dev)
+
+
+def bce_sum(out, l):
+    w = torch.tensor(bw, dtype=out.dtype)
+    wt = ((l == 1).to(out.dtype) * w[:, 0].view(1, -1) + (l == 0).to(out.dtype) * w[:, 1].view(1, -1)).view(-1)
+    return torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1), l.to(out.dtype).view(-1), weight=wt, reduction='sum')
+
+
+n_tot = float(((labels_all == 1) | (labels_all == 0)).sum())
+
+
+def oracle(sync):
+    """(loss of the global batch, gradients) as the reference computes them: one run on the concatenated batch (sync) or one
+    run per shard with its own BatchNorm statistics (local)."""
+    m = RefEAGCN(9, 24, W1, W2, 32, 16, T, 0.0, n_layers=2).double()
+    m.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+    m.train()
+    pieces = [(0, BS * world)] if sync else [shard_range(BS * world, r, world) for r in range(world)]
+    total = 0.0
+    for a, b in pieces:
+        d = [t[a:b].double() if t.is_floating_point() else t[a:b] for t in dense_all]
+        out, _, _ = m(*d)
+        loss = bce_sum(out, labels_all[a:b]) / n_tot
+        loss.backward()
+        total += float(loss)
+    return total, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+for sync in (False, True):
+    torch.manual_seed(1)
+    model = EAGCN(9, 24, *W1, *W2, 32, 16, T, 0.0, n_layers=2, graph=True, validate='deferred', sync_bn=sync).to(dev).train()
+    model.load_state_dict(ref.state_dict(), strict=True)
+    red = GradientAllReducer(model.parameters(), model=model)
+    want_loss, want = oracle(sync)
+    for step in range(5):                         # eager + capture on both slots, then replays
+        for p in model.parameters():
+            p.grad = None
+        if step:                                  # (BatchNorm running statistics move every step; the gradients do not depend on them)
+            pass
+        loss, (out, _, _) = model.fused_step(shard, labels, 'class', bw_dev, 'dp', reducer=red)
+        torch.cuda.synchronize()
+        # the ranks' losses c_r * S_r / n_r average to the global loss
+        lt = loss.detach().clone().reshape(1)
+        dist.all_reduce(lt, op=dist.ReduceOp.SUM)
+        got_loss = float(lt) / world
+        assert abs(got_loss - want_loss) <= 2e-5 * max(1.0, abs(want_loss)), (sync, step, got_loss, want_loss)
+        scale = max(v.abs().max().item() for v in want.values())
+        worst = (0.0, '')
+        for k, p in model.named_parameters():
+            if k not in want:
+                continue
+            g = p.grad.detach().double().cpu()
+            e = (g - want[k]).abs().max().item()
+            tol = 2e-5 * want[k].abs().max().item() + 2e-6 * scale
+            assert e <= tol, ('sync' if sync else 'local', step, k, e, tol)
+            worst = max(worst, (e / max(want[k].abs().max().item(), 1e-30), k))
+        # identical on every rank
+        flat = model.flat_grad_buffer()
+        assert flat is not None
+        chk = flat.double().sum().reshape(1)
+        gathered = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(gathered, chk)
+        assert all(torch.equal(gathered[0], c) for c in gathered), [float(c) for c in gathered]
+    runner = next(iter(model._runners.values()))
+    print('rank %d %s-BN: loss %.6f (oracle %.6f), worst gradient error / own max %.1e (%s), all-reduce %s, sync-BN hook calls %s'
+          % (rank, 'sync' if sync else 'local', got_loss, want_loss, worst[0], worst[1],
+             'captured in the step graph' if runner.comm_in_graph else 'host-issued after the graph (capture of the collective failed)',
+             model.plan().stats.calls if sync else '-'), flush=True)
+    if sync:
+        assert model.plan().stats.calls > 0 and model.plan().stats.error is None, model.plan().stats.error
+dist.barrier()
+dist.destroy_process_group()
+print('DIST_MULTI_OK rank %d of %d' % (rank, world), flush=True)

@@ -19,3 +19,39 @@ def test_rccl_world1_flat_buffer_allreduce_in_graph_mode():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dist_world1_check.py')], env=env, capture_output=True,
                        text=True, timeout=540)
     assert r.returncode == 0 and 'DIST_WORLD1_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def _run_multi(world, port):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    script = os.path.join(ROOT, 'tests', 'dist_multi_check.py')
+    if world == 1:
+        env.update(EAGCN_FORCE_DIST='1', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+        cmd = [sys.executable, script]
+    else:
+        for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+            env.pop(k, None)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), script]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840)
+    assert r.returncode == 0 and r.stdout.count('DIST_MULTI_OK') == world, (r.stdout[-3000:], r.stderr[-4000:])
+    return r.stdout
+
+
+@pytest.mark.timeout(900)
+def test_data_parallel_step_world1_in_graph_allreduce_and_sync_bn():
+    """The multi-rank check with ONE rank (EAGCN_FORCE_DIST=1): RCCL collectives captured inside the step graph, the 'dp' loss
+    scale, the sync-BatchNorm hook between the reduction and finalize kernels -- all against the CPU oracle."""
+    out = _run_multi(1, 29541)
+    assert 'captured in the step graph' in out, out[-2000:]
+
+
+@pytest.mark.timeout(900)
+def test_data_parallel_step_multi_gpu_vs_oracle():
+    """N >= 2 ranks over RCCL/xGMI (skipped on a single-GPU box): averaged gradients == the oracle on the sharded (local-BN)
+    and on the concatenated (sync-BN) batch, identical on every rank, collective inside the captured step graph."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip('needs at least 2 GPUs (found %d)' % n)
+    out = _run_multi(min(n, 4), 29551)
+    print(out[-3000:])

@@ -103,6 +103,17 @@ def _worker_flat(rank, world, port, q):
     red()
     ok_inplace = model.flat_grad_buffer().data_ptr() == flat_before and model.a.grad.data_ptr() == flat_before
     err_flat = max(float((model.a.grad - ga_all.mean(0)).abs().max()), float((model.b.grad - gb_all.mean(0)).abs().max()))
+    # the bucketed form the graph-mode step uses (GraphRunner._call_backward_comm): upper bucket started asynchronously, work done
+    # in between, lower bucket afterwards -- same averages, in place
+    model.backward_into_flat(ga_all[rank], gb_all[rank])
+    flat = model.flat_grad_buffer()
+    assert red.active()
+    upper = red.start(flat[12:])
+    filler = torch.randn(64, 64) @ torch.randn(64, 64)              # (stands for the first layer's backward)
+    upper.wait()
+    red.start(flat[:12]).wait()
+    err_flat = max(err_flat, float((model.a.grad - ga_all.mean(0)).abs().max()), float((model.b.grad - gb_all.mean(0)).abs().max()),
+                   0.0 * float(filler.sum()))
 
     # ---- BCE: per-shard normalisation vs the reference's normalisation on the concatenated batch (train.py:328-331)
     T = 3
