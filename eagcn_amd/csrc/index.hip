@@ -11,6 +11,8 @@
 // side can fail loudly instead of computing something else.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -114,6 +116,201 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
             if (deg > 0) {                           // (no single-word counters here: 5k same-address atomics cost 60 us;
                 atomicMax(&nat[b], i + 1);           //  these are one word per molecule)
                 atomicAdd(&ecnt[b], deg);
+            }
+        }
+    }
+    bad_adj = wave_sum(bad_adj);
+    bad_rel = wave_sum(bad_rel);
+    if (lane == 0) {
+        if (bad_adj) atomicAdd(&meta[EAGCN_META_BAD_ADJ], bad_adj);
+        if (bad_rel) atomicAdd(&meta[EAGCN_META_BAD_REL], bad_rel);
+    }
+}
+
+// ---- streaming scan (the default when N is a multiple of 4 and adj is 16-byte aligned) ----------------------------------------
+// One wavefront takes RPW consecutive padded rows.  (1) ALL adjacency loads of those rows are issued up front as 16-byte loads
+// (lane = four consecutive columns), so a wave has RPW x N x 4 bytes in flight instead of one row's 4-byte pieces.  (2) Degrees
+// come from ballots (no cross-lane reduction).  (3) The bonds of the RPW rows are compacted into ONE list in LDS, and the
+// relation channels of the whole list are gathered TOGETHER: lane c takes channel c of every bond, eight bonds per batch, so the
+// ~38 single-sector loads per bond that one lane used to issue in five dependent batches are spread over the wave and overlap --
+// one memory round trip per list of up to SCAN_CAP bonds instead of five per bonded row.  One-hotness is checked with one LDS
+// word per (bond, view): +0x10000 + (channel + 1) for a channel equal to 1, +0x1000000 for any other non-zero value.
+// (4) Every lane then packs the codes of its own four columns from that word and the code rows leave as before.
+constexpr int SCAN_CAP = 64;                 // bonds gathered per pass (a wave whose rows hold more runs several passes)
+template <int NIT, int RPW>
+__global__ __launch_bounds__(256) void index_scan4_kernel(const float* __restrict__ adj, RelPtrs rel, int B, int N, int Ncap, int K,
+                                                           int ldc, uint8_t* __restrict__ code, int32_t* __restrict__ deg_bn,
+                                                           int32_t* __restrict__ nat, int32_t* __restrict__ ecnt,
+                                                           int32_t* __restrict__ meta) {
+    __shared__ int list_s[4][SCAN_CAP];                  // per wave: (row in the wave << 10) | column
+    __shared__ unsigned res_s[4][SCAN_CAP][EAGCN_MAX_VIEWS];
+    __shared__ int rowb_s[4][RPW], rowi_s[4][RPW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row_first = ((long)blockIdx.x * 4 + wave) * RPW;
+    const long nrows = (long)B * N;
+    if (row_first >= nrows) return;                      // (wave-uniform)
+    const size_t plane = (size_t)N * N;
+    const int nf4 = N >> 2;
+    float4 a[RPW][NIT];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const long row = row_first + rr;
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int f = lane + 64 * t;
+            a[rr][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nrows && f < nf4) a[rr][t] = *reinterpret_cast<const float4*>(adj + (size_t)row * N + 4 * f);
+        }
+    }
+    if (lane < RPW) {
+        const long row = min(row_first + lane, nrows - 1);
+        rowb_s[wave][lane] = (int)(row / N);
+        rowi_s[wave][lane] = (int)(row % N);
+    }
+    // channel slot(s) of this lane: c = lane + 64 cc of the concatenated channel list -> (view, channel)
+    int ctot = 0;
+#pragma unroll
+    for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) ctot += k < K ? rel.c[k] : 0;
+    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    // ---- degrees, bond positions ------------------------------------------------------------------------------------------
+    int bad_adj = 0, bad_rel = 0;
+    int deg[RPW];                                        // (wave-uniform)
+    int posb[RPW][NIT];                                  // position of this lane's first bond of (row, trip) in the wave's list
+    int total = 0;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        deg[rr] = 0;
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const float v[4] = {a[rr][t].x, a[rr][t].y, a[rr][t].z, a[rr][t].w};
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool bond = v[u] != 0.0f;
+                if (bond && v[u] != 1.0f) ++bad_adj;
+                cnt += bond ? 1 : 0;
+            }
+            // exclusive prefix of cnt (0..4) over the lanes: three ballots
+            const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+            const int before = __popcll(b0 & lt_mask) + 2 * __popcll(b1 & lt_mask) + 4 * __popcll(b2 & lt_mask);
+            const int all = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+            posb[rr][t] = total + before;
+            total += all;
+            deg[rr] += all;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- gather the relation channels of the bonds, SCAN_CAP at a time ------------------------------------------------------
+    uint32_t packed[RPW][NIT][EAGCN_MAX_VIEWS];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+        for (int t = 0; t < NIT; ++t)
+#pragma unroll
+            for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) packed[rr][t][k] = 0u;
+    for (int base = 0; base < total; base += SCAN_CAP) {
+        const int nb = min(SCAN_CAP, total - base);
+        // (a) list + cleared result words of this pass
+        for (int e = lane; e < nb; e += 64)
+#pragma unroll
+            for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) res_s[wave][e][k] = 0u;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) {
+                const float v[4] = {a[rr][t].x, a[rr][t].y, a[rr][t].z, a[rr][t].w};
+                int pos = posb[rr][t] - base;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (v[u] != 0.0f) {
+                        if (pos >= 0 && pos < nb) list_s[wave][pos] = (rr << 10) | ((lane + 64 * t) * 4 + u);
+                        ++pos;
+                    }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // (b) lane c: channel c of every listed bond, eight bonds in flight
+        for (int c = lane; c < ctot; c += 64) {
+            int k = 0, c0 = 0;
+#pragma unroll
+            for (int v = 0; v < EAGCN_MAX_VIEWS; ++v)
+                if (v < K && c >= c0 + rel.c[v]) { c0 += rel.c[v]; k = v + 1; }
+            const int ch = c - c0;
+            const float* pk = nullptr;
+            int ck = 1;
+#pragma unroll
+            for (int v = 0; v < EAGCN_MAX_VIEWS; ++v)
+                if (v == k) { pk = rel.p[v]; ck = rel.c[v]; }
+            for (int e0 = 0; e0 < nb; e0 += 8) {
+                float val[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u, nb - 1);
+                    const int ent = list_s[wave][e];
+                    const int rr = ent >> 10, j = ent & 1023;
+                    val[u] = pk[((size_t)rowb_s[wave][rr] * ck + ch) * plane + (size_t)rowi_s[wave][rr] * N + j];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u < nb && val[u] != 0.0f)
+                        atomicAdd(&res_s[wave][e0 + u][k], val[u] == 1.0f ? (0x10000u + (unsigned)ch + 1u) : 0x1000000u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // (c) every lane: the codes of its own bonds of this pass
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) {
+                const float v[4] = {a[rr][t].x, a[rr][t].y, a[rr][t].z, a[rr][t].w};
+                int pos = posb[rr][t] - base;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (v[u] != 0.0f) {
+                        if (pos >= 0 && pos < nb) {
+#pragma unroll
+                            for (int k = 0; k < EAGCN_MAX_VIEWS; ++k)
+                                if (k < K) {
+                                    const unsigned w = res_s[wave][pos][k];
+                                    const unsigned ones = (w >> 16) & 255u, other = w >> 24;
+                                    if (ones != 1u || other != 0u) ++bad_rel;
+                                    // (valid input: exactly one channel is 1 and the low half is its index + 1; otherwise the
+                                    //  batch is rejected through meta[BAD_REL] and the value is irrelevant)
+                                    packed[rr][t][k] |= ((ones == 1u ? (w & 0xFFFFu) : 1u) & 255u) << (8 * u);
+                                }
+                        }
+                        ++pos;
+                    }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- code rows, degrees, per-molecule extents ---------------------------------------------------------------------------
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const long row = row_first + rr;
+        if (row >= nrows) break;                         // wave-uniform
+        const int b = rowb_s[wave][rr], i = rowi_s[wave][rr];
+        // (a row without bonds keeps whatever its code row held: no consumer gives it weight, see index_scan_kernel)
+        if (deg[rr] > 0) {
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) {
+                const int j0 = (lane + 64 * t) * 4;
+                if (j0 < ldc) {
+#pragma unroll
+                    for (int k = 0; k < EAGCN_MAX_VIEWS; ++k)
+                        if (k < K)
+                            *reinterpret_cast<uint32_t*>(code + (((size_t)k * B + b) * Ncap + i) * ldc + j0) = packed[rr][t][k];
+                }
+            }
+        }
+        if (lane == 0) {
+            deg_bn[(size_t)b * Ncap + i] = deg[rr];
+            if (deg[rr] > 0) {
+                atomicMax(&nat[b], i + 1);
+                atomicAdd(&ecnt[b], deg[rr]);
             }
         }
     }
@@ -476,15 +673,27 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     const unsigned sgrid = (unsigned)((rows + 4 * RPW - 1) / (4 * RPW));
     const int nit = cdiv((Nin + 15) / 16 * 16, 256);
     EAGCN_CHECK_ARG(nit <= 4, "eagcn_index_build: N=%d exceeds the supported 1024 atoms", b->N);
+    // streaming scan: 16-byte adjacency loads, several rows per wave, the channel gather of a wave's bonds batched over its lanes
+    static const bool scan4 = [] { const char* v = getenv("EAGCN_SCAN4"); return !(v && v[0] == '0'); }();
+    if (scan4 && (Nin & 3) == 0 && (reinterpret_cast<uintptr_t>(adj) & 15) == 0) {
+#define EAGCN_SCAN4(NIT, R) index_scan4_kernel<NIT, R><<<(unsigned)((rows + 4 * R - 1) / (4 * R)), 256, 0, s>>>(adj, rp, b->B, Nin, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->ecnt, b->meta)
+        if (Nin <= 256) EAGCN_SCAN4(1, 8);
+        else if (Nin <= 512) EAGCN_SCAN4(2, 4);
+        else EAGCN_SCAN4(4, 2);
+#undef EAGCN_SCAN4
+        EAGCN_LAUNCH_CHECK();
+    } else
+    {
 #define EAGCN_SCAN(NIT) index_scan_kernel<NIT, RPW><<<sgrid, 256, 0, s>>>(adj, rp, b->B, Nin, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->ecnt, b->meta)
-    switch (nit) {
-        case 1: EAGCN_SCAN(1); break;
-        case 2: EAGCN_SCAN(2); break;
-        case 3: EAGCN_SCAN(3); break;
-        default: EAGCN_SCAN(4); break;
-    }
+        switch (nit) {
+            case 1: EAGCN_SCAN(1); break;
+            case 2: EAGCN_SCAN(2); break;
+            case 3: EAGCN_SCAN(3); break;
+            default: EAGCN_SCAN(4); break;
+        }
 #undef EAGCN_SCAN
-    EAGCN_LAUNCH_CHECK();
+        EAGCN_LAUNCH_CHECK();
+    }
     index_offsets_kernel<<<1, 1024, 0, s>>>(b->nat, b->B, b->deg_bn, b->B * b->N, b->row0, b->tile0, b->meta, b->T, b->ecnt, b->edge0, b->E, b->n_logical > 0 ? b->n_logical : 0);
     EAGCN_LAUNCH_CHECK();
     EAGCN_HIP(hipMemcpyAsync(host_meta, b->meta, EAGCN_META_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, s));

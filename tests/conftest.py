@@ -64,6 +64,14 @@ def _report_lines():
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
     lines = _report_lines()
+    try:
+        from helpers import ARBITRATED
+    except Exception:
+        ARBITRATED = []
+    if ARBITRATED:
+        terminalreporter.write_sep('-', 'gradients arbitrated against the float64 oracle (error / own max: HIP, fp32 reference; ratio)')
+        for test, name, eh, er, ratio in ARBITRATED:
+            terminalreporter.write_line('%-80s %-44s e_hip %.1e  e_ref %.1e  ratio %.2f' % (test.replace('tests/', ''), name, eh, er, ratio))
     if not lines:
         return
     terminalreporter.write_sep('-', 'achieved parity errors (HIP vs oracle / golden vectors)')

@@ -94,3 +94,33 @@ def assert_grad_close(got, ref, scale, name='', rtol=2e-5, floor=1e-6):
     own = err / rmax if rmax >= 1e-3 * float(scale) and rmax > 0 else None
     _note('grad', name, err / max(float(scale), 1e-300), bound / max(float(scale), 1e-300), own)
     assert err <= bound, (name, err, bound)
+
+
+ARBITRATED = []       # (test, tensor, e_hip64/own, e_ref64/own, ratio): every gradient that needed the fp64 oracle
+
+
+def assert_grad_parity(got, ref32, ref64_fn, scale, name, rtol=1e-5, floor=2e-6, slack=2.0, note=''):
+    """Three-way gradient parity.  Passes when
+        |got - ref32|_max <= rtol * |ref32|_max + floor * scale          (plain: 1e-5 of the tensor's OWN largest entry; the
+                                                                          floor covers analytically-zero gradients), or
+        |got - ref64|_max <= slack * |ref32 - ref64|_max + 1e-6 * scale  (the HIP gradient is as close to the exact one as
+                                                                          the fp32 reference itself is).
+    ref64_fn() -> the float64 oracle's gradient of the same tensor (evaluated only when the plain test fails).  Every
+    arbitrated tensor is recorded with both errors and printed in the terminal summary."""
+    got = torch.as_tensor(got, dtype=torch.float64).cpu()
+    ref32 = torch.as_tensor(ref32, dtype=torch.float64)
+    assert got.shape == ref32.shape, (name, got.shape, ref32.shape)
+    rmax = ref32.abs().max().item() if ref32.numel() else 0.0
+    err = (got - ref32).abs().max().item() if ref32.numel() else 0.0
+    bound = rtol * rmax + floor * float(scale)
+    own = err / rmax if rmax >= 1e-3 * float(scale) and rmax > 0 else None
+    _note('grad', name, err / max(float(scale), 1e-300), bound / max(float(scale), 1e-300), own)
+    if err <= bound:
+        return
+    ref64 = torch.as_tensor(ref64_fn(), dtype=torch.float64)
+    e_hip = (got - ref64).abs().max().item()
+    e_ref = (ref32 - ref64).abs().max().item()
+    o64 = max(ref64.abs().max().item(), 1e-300)
+    test = os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]
+    ARBITRATED.append((test, name + note, e_hip / o64, e_ref / o64, e_hip / max(e_ref, 1e-300)))
+    assert e_hip <= slack * e_ref + 1e-6 * float(scale), (name, 'e_hip', e_hip, 'e_ref', e_ref, 'vs fp64; plain error', err, 'bound', bound)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import Golden, assert_grad_close, build_oracle_model, golden_cases, rel_err
+from helpers import assert_grad_parity, Golden, assert_grad_close, build_oracle_model, golden_cases, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -118,19 +118,17 @@ def test_model_golden(name):
     got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
     assert set(got) == set(grads), set(got) ^ set(grads)
     scale = max(np.abs(v).max() for v in grads.values())
-    f64 = None
+    # every gradient: 1e-5 of the tensor's own largest entry against the reference's fixture, or -- the ill-conditioned cases
+    # (BatchNorm over a few dozen rows, four layers deep) -- as close to the float64 oracle's gradient as the reference's own
+    # fp32 gradient is (x2); arbitrated tensors are listed with both errors in the terminal summary
+    f64 = {}
+
+    def exact(k):
+        if not f64:
+            f64.update(_f64_grads(g))
+        return f64[k]
     for k, ref in grads.items():
-        try:
-            assert_grad_close(got[k], ref, scale, k, rtol=2e-5, floor=2e-6)
-        except AssertionError:
-            # ill-conditioned case (BatchNorm over a few dozen rows, 4 layers deep): arbitrate with the
-            # oracle in float64 -- the HIP result may not be further from the exact gradient than
-            # 4x the reference's own fp32 rounding error
-            if f64 is None:
-                f64 = _f64_grads(g)
-            e_ref = (torch.from_numpy(ref).double() - f64[k]).abs().max().item()
-            e_hip = (got[k].double().cpu() - f64[k]).abs().max().item()
-            assert e_hip <= 4.0 * e_ref + 2e-6 * scale, (k, e_hip, e_ref)
+        assert_grad_parity(got[k], ref, lambda k=k: exact(k), scale, k, rtol=1e-5, floor=2e-6, slack=2.0)
     sd = model.state_dict()
     for k, ref in g.group('sd_after/').items():
         assert rel_err(sd[k].double().cpu(), ref) < TOL, k
@@ -161,54 +159,46 @@ def test_model_vs_oracle_tox21_shape(structure, n_layers, B, n_max):
     hip = EAGCN(28, 24, *w1, *w2, 256, 64, 12, 0.0, structure=structure, n_layers=n_layers).cuda()
     hip.load_state_dict(ref.state_dict(), strict=True)
     cpu = mb.dense()
-    refs = [(ref, cpu)]
-    if B > 512:
-        # beyond ~20 k padded rows fp32 is not enough to pin the gradients: against the fp64 oracle the fp32 CPU oracle
-        # is off by up to 2e-3 (tests/probe_large_batch.py; BatchNorm sums, relu boundaries), sometimes the HIP path
-        # with it (Concate 640: both 1.9e-3, equal to each other), sometimes not (Weighted_sum 576: HIP 2e-6, fp32
-        # oracle 1.7e-3).  The HIP result has to agree with ONE of the two oracles to the usual tolerance.
-        ref64 = RefEAGCN(28, 24, w1, w2, 256, 64, 12, 0.0, structure=structure, n_layers=n_layers).double()
-        ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
-        refs.append((ref64, [t.double() if t.is_floating_point() else t for t in cpu]))
     gsel = torch.randn(B, 12)
     out_h, _, gr_h = hip(*_dev(cpu))
     (out_h * gsel.cuda()).sum().backward()
     gh = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
-    cand = []
-    for m, inp in refs:
-        out_r, _, gr_r = m(*inp)
-        (out_r * gsel.to(out_r.dtype)).sum().backward()
-        cand.append((out_r.detach(), gr_r.detach(), {k: p.grad for k, p in m.named_parameters() if p.grad is not None}))
-    assert min(rel_err(out_h.detach().cpu(), c[0]) for c in cand) < TOL
-    assert min(rel_err(gr_h.detach().cpu(), c[1]) for c in cand) < TOL
-    assert set(cand[0][2]) == set(gh)
-    scale = max(v.abs().max().item() for v in cand[0][2].values())
+    out_r, _, gr_r = ref(*cpu)
+    (out_r * gsel).sum().backward()
+    g32 = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    # the float64 oracle on the same inputs: the exact answer both fp32 evaluations are measured against where they differ
+    # (beyond ~20 k padded rows the fp32 CPU oracle itself is off by up to 2e-3 in some gradients: BatchNorm sums, relu
+    # boundaries; tests/probe_large_batch.py)
+    cache = {}
+
+    def exact():
+        if not cache:
+            ref64 = RefEAGCN(28, 24, w1, w2, 256, 64, 12, 0.0, structure=structure, n_layers=n_layers).double()
+            ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+            out_x, _, gr_x = ref64(*[t.double() if t.is_floating_point() else t for t in cpu])
+            (out_x * gsel.double()).sum().backward()
+            cache.update(out=out_x.detach(), gr=gr_x.detach(), g={k: p.grad for k, p in ref64.named_parameters() if p.grad is not None})
+        return cache
+    for name, h, r in (('out', out_h, out_r), ('graph_rep', gr_h, gr_r)):
+        e = rel_err(h.detach().cpu(), r.detach(), name)
+        if e >= TOL:                                   # (large batches only) as close to the exact output as the fp32 oracle is
+            x = exact()['out' if name == 'out' else 'gr']
+            e_hip = (h.detach().double().cpu() - x).abs().max().item()
+            e_ref = (r.detach().double() - x).abs().max().item()
+            assert e_hip <= 2.0 * e_ref + 1e-6 * x.abs().max().item(), (name, e, e_hip, e_ref)
+    if B <= 64:
+        # where does the forward error come from?  Both fp32 evaluations against the float64 oracle (recorded in the report): the
+        # HIP path has to be within 3e-6 of the exact output at the headline widths -- the rest of its distance to the fp32
+        # oracle is that oracle's own rounding
+        x = exact()
+        e_hip = rel_err(out_h.detach().cpu(), x['out'], 'out: HIP vs float64 oracle')
+        e_ref = rel_err(out_r.detach(), x['out'], 'out: fp32 oracle vs float64 oracle')
+        print('forward error vs the float64 oracle [%s %d %d %d]: HIP %.1e, fp32 CPU oracle %.1e' % (structure, n_layers, B, n_max, e_hip, e_ref))
+        assert e_hip <= 3e-6, (e_hip, e_ref)
+    assert set(g32) == set(gh)
+    scale = max(v.abs().max().item() for v in g32.values())
     for k in gh:
-        errs = []
-        for c in cand:
-            try:
-                assert_grad_close(gh[k], c[2][k], scale, k, rtol=1e-4, floor=5e-6)
-                errs = None
-                break
-            except AssertionError as e:
-                errs.append(e)
-        if errs:
-            raise errs[0]
-
-
-@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0)])
-@pytest.mark.parametrize('M,N,K', [(100, 64, 24), (1000, 704, 400), (37, 16, 8), (4608, 400, 704),
-                                   (4096, 2048, 1024)])      # the last one takes the 128x128 tile configuration
-def test_gemm_f32(ta, tb, M, N, K):
-    from eagcn_amd import ops
-    if ta and M % 4:
-        M = (M + 3) // 4 * 4
-    torch.manual_seed(1)
-    a = torch.randn((K, M) if ta else (M, K), device='cuda')
-    b = torch.randn((N, K) if tb else (K, N), device='cuda')
-    c = ops.gemm(a, b, bool(ta), bool(tb))
-    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
-    assert rel_err(c.double().cpu(), ref.cpu()) < 2e-6
+        assert_grad_parity(gh[k], g32[k], lambda k=k: exact()['g'][k], scale, k, rtol=1e-5, floor=2e-6, slack=2.0)
 
 
 @pytest.mark.parametrize('T,FIN,FP', [(4809, 400, 704), (64, 400, 704), (37, 128, 144), (1000, 256, 80), (20003, 400, 704),
@@ -1097,7 +1087,7 @@ def test_gcn_baseline_graph_mode_and_training_vs_oracle():
 @pytest.mark.gpu
 def test_gat_layer_training_mode_with_injected_dropout_masks():
     """The GAT baseline layer in TRAINING mode (attention dropout 0.5, layers.py:104,133, + layer dropout): the kernels'
-    counter-based keep-scales are regenerated here and applied to the oracle's attention matrix and output by hand."""
+    counter-based keep-scales are regenerated here and injected into the ORACLE's layer (RefGAT) in place of its dropout calls."""
     from eagcn_amd import ops
     from eagcn_amd.layers import GAT
     from eagcn_amd.synthetic import make_batch
@@ -1136,22 +1126,28 @@ def test_gat_layer_training_mode_with_injected_dropout_masks():
         thr = np.uint64(min(4294967295.0, float(np.float32(p_layer)) * 4294967296.0))
         z = _mix64(seed, r * np.uint64(Fp) + np.arange(fout).astype(np.uint64)[None, :]) & np.uint64(0xFFFFFFFF)
         out_scale[b, :n, :] = torch.from_numpy(np.where(z >= thr, np.float32(1.0) / (np.float32(1.0) - np.float32(p_layer)), np.float32(0.0)))
-    Wr, ar = W.clone().requires_grad_(True), a.clone().requires_grad_(True)
-    m = adj.max(dim=2, keepdim=True)[0]
-    A = adj + m * torch.eye(N)
-    outs = []
-    for b in range(B):
-        h = afm[b] @ Wr
-        e = F.leaky_relu((h @ ar[:fout]) + (h @ ar[fout:]).t(), 0.2)
-        att = torch.where(A[b] > 0, e, torch.full_like(e, -9e15))
-        att = torch.where(A[b] > 0, F.softmax(att, dim=1), torch.zeros_like(e)) * att_scale[b]
-        outs.append(F.relu((att @ h) * out_scale[b]))
-    ref = torch.stack(outs)
-    (ref * gout).sum().backward()
-    assert rel_err(got.detach().cpu(), ref.detach(), 'GAT layer, training mode, injected masks') < 1e-5
-    scale = max(Wr.grad.abs().max().item(), ar.grad.abs().max().item())
-    assert_grad_close(layer.graph_conv.W.grad.cpu(), Wr.grad.numpy(), scale, 'graph_conv.W', rtol=2e-5, floor=2e-6)
-    assert_grad_close(layer.graph_conv.a.grad.cpu(), ar.grad.numpy(), scale, 'graph_conv.a', rtol=2e-5, floor=2e-6)
+    # ---- the ORACLE's GAT layer (oracle/eagcn_ref.py RefGAT = layers.py:99-203 restated, pinned to the reference's eval-mode
+    #      fixtures) with its two F.dropout calls replaced by the regenerated keep-scales: B attention matrices, then the output
+    import oracle.eagcn_ref as R
+    ref_layer = R.RefGAT(fin, fout, p_layer)
+    with torch.no_grad():
+        ref_layer.graph_conv.W.copy_(W)
+        ref_layer.graph_conv.a.copy_(a)
+    ref_layer.train()
+    queue = [att_scale[b] for b in range(B)] + [out_scale]
+    orig = R.F.dropout
+    R.F.dropout = lambda x, p=0.5, training=True, inplace=False: x * queue.pop(0) if training else x
+    try:
+        ref, _ = ref_layer(adj, afm)
+        (ref * gout).sum().backward()
+        assert not queue
+    finally:
+        R.F.dropout = orig
+    Wg, ag = ref_layer.graph_conv.W.grad, ref_layer.graph_conv.a.grad
+    assert rel_err(got.detach().cpu(), ref.detach(), 'GAT layer, training mode, injected masks, vs oracle.RefGAT') < 1e-5
+    scale = max(Wg.abs().max().item(), ag.abs().max().item())
+    assert_grad_close(layer.graph_conv.W.grad.cpu(), Wg.numpy(), scale, 'graph_conv.W', rtol=2e-5, floor=2e-6)
+    assert_grad_close(layer.graph_conv.a.grad.cpu(), ag.numpy(), scale, 'graph_conv.a', rtol=2e-5, floor=2e-6)
 
 
 @pytest.mark.gpu
