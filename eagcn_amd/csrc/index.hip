@@ -232,10 +232,16 @@ __global__ __launch_bounds__(256) void index_scan4_kernel(const float* __restric
         __builtin_amdgcn_wave_barrier();
         // (b) lane c: channel c of every listed bond, eight bonds in flight
         for (int c = lane; c < ctot; c += 64) {
-            int k = 0, c0 = 0;
+            int k = 0, c0 = 0;                               // view whose channel range [c0, c0 + C_k) holds slot c
+            {
+                int start = 0;
 #pragma unroll
-            for (int v = 0; v < EAGCN_MAX_VIEWS; ++v)
-                if (v < K && c >= c0 + rel.c[v]) { c0 += rel.c[v]; k = v + 1; }
+                for (int v = 0; v < EAGCN_MAX_VIEWS; ++v)
+                    if (v < K) {
+                        if (c >= start) { k = v; c0 = start; }
+                        start += rel.c[v];
+                    }
+            }
             const int ch = c - c0;
             const float* pk = nullptr;
             int ck = 1;
