@@ -189,7 +189,7 @@ def test_model_vs_oracle_tox21_shape(structure, n_layers, B, n_max):
             x = exact()['out' if name == 'out' else 'gr']
             e_hip = (h.detach().double().cpu() - x).abs().max().item()
             e_ref = (r.detach().double() - x).abs().max().item()
-            assert e_hip <= 1.0 * e_ref + 1e-6 * x.abs().max().item(), (name, e, e_hip, e_ref)
+            assert e_hip <= 2.0 * e_ref + 1e-6 * x.abs().max().item(), (name, e, e_hip, e_ref)
     if B <= 64:
         # where does the forward error come from?  Both fp32 evaluations against the float64 oracle (recorded in the report): the
         # HIP path has to be within 3e-6 of the exact output at the headline widths -- the rest of its distance to the fp32
