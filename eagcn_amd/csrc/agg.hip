@@ -32,7 +32,10 @@
 namespace eagcn {
 
 // Variant for large batches: one WAVEFRONT per tile (four tiles per workgroup in flight); with thousands of
-// small tiles this keeps 4x more tiles in flight than the K-split variant below.
+// small tiles this keeps 4x more tiles in flight than the K-split variant below.  Same operand layout as that variant: the CT
+// column tiles are taken four at a time so that a lane's four B-operand values (and its four results) are ONE float4 -- 16
+// adjacent lanes cover 256 contiguous bytes of a row (round 2 fed this kernel with 4-byte loads: four times the memory
+// instructions of the K-split kernel for the same bytes, at the batch sizes where the aggregation is the largest item).
 template <int CT, bool TRANS>
 __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, const int by, const int gx) {
     __shared__ float sig_s[256];
@@ -41,32 +44,55 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
     const int ntile_k = (a.vc.off[k + 1] - a.vc.off[k]) / 16;
     const int ct0 = cc * CT;
     if (ct0 >= ntile_k) return;                       // uniform for the whole workgroup
+    const eagcn_batch& bt = a.bt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // independent loads at the head of the wave, requested together: its first tile's descriptor (inside the tile CAPACITY:
+    // always a legal address), the device-side tile count, sigmoid(self_r), the sigmoid table
+    const int tile_first = bx * 4 + wave;
+    int4 ti_next = reinterpret_cast<const int4*>(bt.tile_info)[min(tile_first, max(bt.n_tiles - 1, 0))];
+    const float r = a.rsig[k];
+    const float sig_v = a.sig[k * 256 + tid];
     const int ntiles = dev_tiles(a.bt);
     const int nlog = dev_n(a.bt);
     if (bx * 4 >= ntiles) return;        // capacity-sized grid: no tile for this workgroup (its
                                                       // stats slab is not read either: bn_finalize counts live slabs)
     const int nct = min(CT, ntile_k - ct0);
     const int c0 = a.vc.off[k] + ct0 * 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
-    sig_s[tid] = a.sig[k * 256 + tid];
+    constexpr int Q = CT / 4;
+    const int ncol = nct * 16;                        // valid columns of this chunk
+    auto tile_col0 = [&](int ct) { return ct < 4 * Q ? (ct >> 2) * 64 : Q * 64 + (ct - 4 * Q) * 16; };   // first column a tile touches
+    auto lane_col = [&](int ct) { return ct < 4 * Q ? (ct >> 2) * 64 + 4 * li + (ct & 3) : Q * 64 + (ct - 4 * Q) * 16 + li; };
+    // B operands of one source row for all tiles (zero where the column is outside the chunk)
+    auto load_row = [&](const float* rowp, bool ok, float (&bv)[CT]) {
+#pragma unroll
+        for (int m = 0; m < Q; ++m) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && m * 64 + 4 * li < ncol) v = *reinterpret_cast<const float4*>(rowp + m * 64 + 4 * li);
+            bv[4 * m + 0] = v.x; bv[4 * m + 1] = v.y; bv[4 * m + 2] = v.z; bv[4 * m + 3] = v.w;
+        }
+#pragma unroll
+        for (int ct = 4 * Q; ct < CT; ++ct) {
+            const int c = Q * 64 + (ct - 4 * Q) * 16 + li;
+            bv[ct] = (ok && c < ncol) ? rowp[c] : 0.0f;
+        }
+    };
+    sig_s[tid] = sig_v;
     if (!TRANS) for (int i = tid; i < CT * 16 * 2; i += 256) st_s[i] = 0.0;
     __syncthreads();
-    const float r = a.rsig[k];
-    const eagcn_batch& bt = a.bt;
     // (BatchNorm partial sums are accumulated in LDS with fp64 atomics, not in 4*CT registers per lane: that keeps
     //  the kernel at four waves per SIMD)
 
-    for (int tile = bx * 4 + wave; tile < ntiles; tile += gx * 4) {
-        const int b = bt.tile_mol[tile];
-        const int rt = tile - bt.tile0[b];
-        const int n = bt.nat[b], r0 = bt.row0[b];
+    for (int tile = tile_first; tile < ntiles; tile += gx * 4) {
+        const int4 ti = ti_next;
+        if (tile + gx * 4 < ntiles) ti_next = reinterpret_cast<const int4*>(bt.tile_info)[tile + gx * 4];
+        const int b = ti.x, rt = ti.y, n = ti.z, r0 = ti.w;
         const uint8_t* codeb = bt.code + ((size_t)k * bt.B + b) * bt.N * bt.ldc;
         const int ia = rt * 16 + li;                  // A-operand row of this lane = output row
         f32x4 acc[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* sbase = a.src + (size_t)r0 * a.lds + c0 + li;
+        const float* sbase = a.src + (size_t)r0 * a.lds + c0;
 
         if (!TRANS) {
             const float mi = (ia < n) ? bt.row_m[r0 + ia] : 0.0f;
@@ -81,9 +107,7 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int j = j0 + 4 * t + q;
-                    const float* srow = sbase + (size_t)min(j, n - 1) * a.lds;
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) bv[t][ct] = (j < n && ct < nct) ? srow[ct * 16] : 0.0f;
+                    load_row(sbase + (size_t)min(j, n - 1) * a.lds, j < n, bv[t]);
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -97,7 +121,7 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
                         dsum += u;
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct)
-                            if (ct < nct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv[t][ct], acc[ct], 0, 0, 0);
+                            if (tile_col0(ct) < ncol) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv[t][ct], acc[ct], 0, 0, 0);
                     }
                 }
             }
@@ -109,27 +133,27 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
             float scr[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) scr[g] = __shfl(sc, q * 4 + g);
+            // results scaled in place, BatchNorm partial sums per column (the four waves add concurrently), float4 / scalar stores
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-                if (ct < nct) {
+            for (int ct = 0; ct < CT; ++ct) {
+                const int lc = lane_col(ct);
+                if (lc < ncol) {
                     double t1 = 0.0, t2 = 0.0;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int row = rt * 16 + q * 4 + g;
-                        if (row < n) {
-                            const float y = acc[ct][g] * scr[g];
-                            a.dst[(size_t)(r0 + row) * a.ldd + c0 + ct * 16 + li] = y;
-                            t1 += (double)y;
-                            t2 += (double)y * (double)y;
-                        }
+                        const float y = acc[ct][g] * scr[g];
+                        acc[ct][g] = y;
+                        if (row < n) { t1 += (double)y; t2 += (double)y * (double)y; }
                     }
                     t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
                     t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
-                    if (q == 0) {                     // the four waves of the workgroup add concurrently
-                        atomicAdd(&st_s[(ct * 16 + li) * 2 + 0], t1);
-                        atomicAdd(&st_s[(ct * 16 + li) * 2 + 1], t2);
+                    if (q == 0) {
+                        atomicAdd(&st_s[lc * 2 + 0], t1);
+                        atomicAdd(&st_s[lc * 2 + 1], t2);
                     }
                 }
+            }
         } else {
             // dP[j,:] = sum_i A^[i,j] dY'[i,:]  (rscale carries m_i / rowsum_i)
             for (int i0 = 0; i0 < n; i0 += 16) {
@@ -144,9 +168,7 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
                         cc4[t] = codeb[(size_t)i * bt.ldc + ia];
                         rs4[t] = a.rscale[(size_t)k * bt.T + r0 + i];
                     }
-                    const float* srow = sbase + (size_t)min(i, n - 1) * a.lds;
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) bv[t][ct] = (i < n && ct < nct) ? srow[ct * 16] : 0.0f;
+                    load_row(sbase + (size_t)min(i, n - 1) * a.lds, i < n, bv[t]);
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -157,19 +179,26 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
                         u *= rs4[t];
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct)
-                            if (ct < nct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv[t][ct], acc[ct], 0, 0, 0);
+                            if (tile_col0(ct) < ncol) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, bv[t][ct], acc[ct], 0, 0, 0);
                     }
                 }
             }
+        }
+        // stores: a lane's four results of a row are one float4 (columns 4 li .. 4 li + 3 of a 64-column block)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-                if (ct < nct) {
+        for (int g = 0; g < 4; ++g) {
+            const int row = rt * 16 + q * 4 + g;
+            if (row < n) {
+                float* drow = a.dst + (size_t)(r0 + row) * a.ldd + c0;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int row = rt * 16 + q * 4 + g;
-                        if (row < n) a.dst[(size_t)(r0 + row) * a.ldd + c0 + ct * 16 + li] = acc[ct][g];
-                    }
-                }
+                for (int m = 0; m < Q; ++m)
+                    if (m * 64 + 4 * li < ncol)
+                        *reinterpret_cast<float4*>(drow + m * 64 + 4 * li) =
+                            make_float4(acc[4 * m][g], acc[4 * m + 1][g], acc[4 * m + 2][g], acc[4 * m + 3][g]);
+#pragma unroll
+                for (int ct = 4 * Q; ct < CT; ++ct)
+                    if (lane_col(ct) < ncol) drow[lane_col(ct)] = acc[ct][g];
+            }
         }
     }
 
