@@ -476,10 +476,17 @@ static int launch_agg_t(const AggArgs& a, int ct, dim3 grid, bool ksplit, hipStr
     return EAGCN_OK;
 }
 
-// column tiles per workgroup: at most 10 (register budget); EAGCN_AGG_MAXCT lowers it (more, lighter workgroups)
+// column tiles per workgroup: at most 9 (register budget: the 10-tile variants spill a few registers in every form, and the
+// 8-tile forward variant of the wave-per-tile kernel spills 492 bytes per lane -- two full float4 groups and no scalar tile make
+// the allocator give up; an 8-tile layer runs the 9-tile instantiation with its last tile masked off instead);
+// EAGCN_AGG_MAXCT changes the cap (1..10)
 static int agg_max_ct() {
-    static const int v = [] { const char* e = getenv("EAGCN_AGG_MAXCT"); const int x = e ? atoi(e) : 10; return x < 1 ? 1 : (x > 10 ? 10 : x); }();
+    static const int v = [] { const char* e = getenv("EAGCN_AGG_MAXCT"); const int x = e ? atoi(e) : 9; return x < 1 ? 1 : (x > 10 ? 10 : x); }();
     return v;
+}
+static int agg_pick_ct(int tmax, int nchunk) {
+    const int ct = cdiv(tmax, nchunk);
+    return ct == 8 ? 9 : ct;
 }
 // number of workgroups along x (= number of stat partial slabs) used for a batch
 // Small batches (few hundred tiles, duration set by the largest molecule): one workgroup per tile, K split
@@ -497,7 +504,7 @@ int launch_agg(AggArgs a, bool trans, hipStream_t s) {
     for (int k = 0; k < a.vc.K; ++k) tmax = std::max(tmax, (a.vc.off[k + 1] - a.vc.off[k]) / 16);
     // balanced chunking: fewest chunks of at most 10 column tiles, then the smallest CT reaching it
     const int nchunk = cdiv(tmax, agg_max_ct());
-    const int ct = cdiv(tmax, nchunk);
+    const int ct = agg_pick_ct(tmax, nchunk);
     a.nchunk = nchunk;
     dim3 grid(agg_grid_x(&a.bt), a.vc.K * nchunk);
     ProfScope ps(PROF_AGG, s);
@@ -671,7 +678,7 @@ int launch_agg_edge(AggArgs a, const EdgeArgs& e, hipStream_t s) {
     int tmax = 0;
     for (int k = 0; k < a.vc.K; ++k) tmax = std::max(tmax, (a.vc.off[k + 1] - a.vc.off[k]) / 16);
     const int nchunk = cdiv(tmax, agg_max_ct());
-    const int ct = cdiv(tmax, nchunk);
+    const int ct = agg_pick_ct(tmax, nchunk);
     a.nchunk = nchunk;
     const int agx = agg_grid_x(&a.bt), egx = edge_grid_x(&a.bt);
     dim3 grid(agx + egx, a.vc.K * nchunk);
