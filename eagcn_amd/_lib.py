@@ -106,7 +106,7 @@ class Model(C.Structure):
     _fields_ = [('n_layers', C.c_int32), ('molfp_mode', C.c_int32), ('training', C.c_int32),
                 ('head_seed', C.c_uint64), ('head_seed_dev', _fp), ('input_packed', C.c_int32), ('aux_stream', _fp),
                 ('layer', LayerParams * 4), ('head', HeadParams), ('stats_hook', _fp), ('stats_user', _fp),
-                ('stats_world', C.c_int32), ('reserved_', C.c_int32)]
+                ('stats_world', C.c_int32), ('fuse_readout', C.c_int32)]
 
 
 # int hook(double* buf, int n, void* stream, void* user): cross-rank sum in place (sync-BatchNorm, eagcn_hip.h)
@@ -172,6 +172,7 @@ SIGNATURES = {
     'eagcn_model_scratch_bytes': (C.c_size_t, [C.POINTER(Batch), C.POINTER(Model)]),
     'eagcn_model_atom_rep': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), C.POINTER(C.c_size_t),
                                        C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    'eagcn_model_atom_rep_materialize': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, C.c_size_t, _fp]),
     'eagcn_model_pack_input': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, C.c_size_t, _fp]),
     'eagcn_model_forward': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, _fp, C.c_size_t, _fp,
                                       C.c_size_t, _fp, _fp, _fp]),

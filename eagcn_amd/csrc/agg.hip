@@ -571,7 +571,9 @@ __device__ __forceinline__ void edge_grad_body(const EdgeArgs& a, const int bx, 
         const float* yr = a.Y + (size_t)rr * a.ld + off;
         const uint8_t* crow = bt.code + (((size_t)k * bt.B + b) * bt.N + i) * bt.ldc;
         const int nmax = max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48)));
-        float rd = live ? dot16(dy, yr, sl, fp) : 0.0f;
+        // (view segments are zero-padded to a multiple of 16 columns and 16-byte aligned: 16-byte loads whenever the row stride is)
+        const bool vec = (a.ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.dY) | reinterpret_cast<uintptr_t>(a.Y) | reinterpret_cast<uintptr_t>(a.P)) & 15) == 0 && (off & 3) == 0;
+        float rd = !live ? 0.0f : (vec ? dot16v(dy, yr, sl, fp) : dot16(dy, yr, sl, fp));
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) rd += __shfl_xor(rd, o);
         int nh = 0;                                                // queued hits of this group (group-uniform)
@@ -589,7 +591,7 @@ __device__ __forceinline__ void edge_grad_body(const EdgeArgs& a, const int bx, 
                     pr[h] = a.P + (size_t)(hv[h] >= 0 ? (r0 + (hv[h] >> 8)) : rr) * a.ld + off;
                 }
                 float g[4];
-                dot16x4(dy, pr, sl, fp, g);
+                if (vec) dot16x4v(dy, pr, sl, fp, g); else dot16x4(dy, pr, sl, fp, g);
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
 #pragma unroll

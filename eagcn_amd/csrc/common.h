@@ -110,6 +110,49 @@ __device__ __forceinline__ void dot16x4(const float* __restrict__ a, const float
     }
 }
 
+// The same two dot products on 16-byte loads (rows that are 16-byte aligned and a multiple of 4 floats long: the padded view
+// segments of the layer matrices): lane sl takes the float4s sl, sl+16, ... -- 16 lanes cover 256 contiguous bytes per load, a
+// quarter of the memory instructions of the scalar forms above for the same bytes.
+constexpr int DOTV_U = 3;
+__device__ __forceinline__ float dot16v(const float* __restrict__ a, const float* __restrict__ b, int sl, int n) {
+    const int nf4 = n >> 2;
+    float acc = 0.0f;
+    for (int c0 = sl; c0 < nf4; c0 += 16 * DOTV_U) {
+        float4 x[DOTV_U], y[DOTV_U];
+#pragma unroll
+        for (int u = 0; u < DOTV_U; ++u) {
+            const int c = c0 + 16 * u;
+            const bool ok = c < nf4;
+            x[u] = ok ? *reinterpret_cast<const float4*>(a + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            y[u] = ok ? *reinterpret_cast<const float4*>(b + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < DOTV_U; ++u) acc += (x[u].x * y[u].x + x[u].y * y[u].y) + (x[u].z * y[u].z + x[u].w * y[u].w);
+    }
+    return acc;
+}
+__device__ __forceinline__ void dot16x4v(const float* __restrict__ a, const float* const (&p)[4], int sl, int n, float (&out)[4]) {
+    const int nf4 = n >> 2;
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    constexpr int U = 2;
+    for (int c0 = sl; c0 < nf4; c0 += 16 * U) {
+        float4 x[U], y[4][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + 16 * u;
+            const bool ok = c < nf4;
+            x[u] = ok ? *reinterpret_cast<const float4*>(a + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) y[h][u] = ok ? *reinterpret_cast<const float4*>(p[h] + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+                out[h] += (x[u].x * y[h][u].x + x[u].y * y[h][u].y) + (x[u].z * y[h][u].z + x[u].w * y[h][u].w);
+    }
+}
+
 // counter-based dropout stream: one 32-bit draw per (seed, element index)
 __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
     uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;

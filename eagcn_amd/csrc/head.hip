@@ -156,6 +156,13 @@ static eagcn_layout out_layout(const eagcn_layer_params* p) {
     return l;
 }
 
+// the top layer's output matrix is not built in the forward (eagcn_model.fuse_readout): Concate only -- its non-stored rows are
+// masked to zero, so the read-out sums nothing but packed rows
+static bool fused_readout(const eagcn_model* m) {
+    static const bool env = [] { const char* v = getenv("EAGCN_NO_FUSED_READOUT"); return !(v && v[0] == '1'); }();
+    return env && m->fuse_readout && m->layer[m->n_layers - 1].structure == EAGCN_STRUCT_CONCATE;
+}
+
 static void fill_drop(float p, int training, int* do_drop, uint32_t* thr, float* inv_keep) {
     *do_drop = (training && p > 0.0f) ? 1 : 0;
     *thr = (uint32_t)std::min(4294967295.0, (double)p * 4294967296.0);
@@ -183,6 +190,20 @@ extern "C" int eagcn_model_atom_rep(const eagcn_batch* b, const eagcn_model* m, 
     *pad_row_offset = s.pad_last_off;
     *ld = eagcn_layer_out_ld(&m->layer[m->n_layers - 1]);
     return EAGCN_OK;
+}
+
+extern "C" int eagcn_model_atom_rep_materialize(const eagcn_batch* b, const eagcn_model* m, void* saved, size_t saved_bytes,
+                                                 void* stream) {
+    EAGCN_CHECK_ARG(b && m && saved, "eagcn_model_atom_rep_materialize: null argument");
+    if (!fused_readout(m)) return EAGCN_OK;                  // the forward built the matrix itself
+    ModelSaved sv;
+    EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "eagcn_model_atom_rep_materialize: saved block too small");
+    const int l = m->n_layers - 1;
+    LayerSaved& L = sv.L[l];
+    eagcn_layer_bufs w;
+    memset(&w, 0, sizeof(w));
+    w.Y = L.Y; w.bn = L.bn; w.xout = L.xout; w.pad_row = L.pad_row; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
+    return layer_apply_impl(b, &m->layer[l], &w, stream);
 }
 
 extern "C" int eagcn_model_pack_input(const eagcn_batch* b, const eagcn_model* m, const float* afm, void* saved,
@@ -225,14 +246,24 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
         w.x = x; w.P = L.P; w.Y = L.Y; w.rscale = L.rscale; w.bn = L.bn; w.xout = L.xout; w.pad_row = L.pad_row;
         w.scratch = sc.layer; w.scratch_bytes = sc.layer_bytes; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
         w.stats_hook = m->stats_hook; w.stats_user = m->stats_user;
-        RC(layer_forward_impl(b, &m->layer[l], &w, stream, true));
+        RC(layer_forward_impl(b, &m->layer[l], &w, stream, true, l == m->n_layers - 1 && fused_readout(m)));
         x = L.xout;
     }
     const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
     const LayerSaved& LL = sv.L[m->n_layers - 1];
     const eagcn_layout lay = out_layout(last);
     const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
-    if (pad_sampled(m))
+    double *st_g = sc.hst, *st_1 = sc.hst + 2 * F + 2, *st_2 = sc.hst + 2 * (F + n1) + 4;
+    if (fused_readout(m)) {
+        // relu / dropout / mask of the top layer applied while the atoms are summed; Graph_BN's column sums in the same launch
+        ReadoutBn rb;
+        rb.Y = LL.Y; rb.ldy = LL.fp; rb.bn = LL.bn; rb.fp = LL.fp;
+        fill_drop(last->dropout, last->training, &rb.do_drop, &rb.thr, &rb.inv_keep);
+        rb.seed = last->seed; rb.seed_dev = last->seed_dev;
+        rb.size = size; rb.mode = m->molfp_mode; rb.g = sv.g; rb.F = F; rb.st = st_g;
+        rb.cnt0 = st_g + 2 * F; rb.cnt1 = st_1 + 2 * n1; rb.cnt2 = st_2 + 2 * n2;
+        RC(readout_bn_forward(b, &lay, rb, stream));
+    } else if (pad_sampled(m))
         RC(readout_forward_sampled(b, LL.xout, &lay, last, LL.bn + (size_t)LL.fp /* shift row of the BatchNorm table */, size,
                                    m->molfp_mode, sv.g, F, sv.pad_cnt, sv.padc, stream));
     else
@@ -240,7 +271,6 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
                                  size, m->molfp_mode, sv.g, F, stream));
     // head (head2.hip): every BatchNorm's sums come from the kernel that produces its input, its normalisation is
     // applied by the product that consumes it
-    double *st_g = sc.hst, *st_1 = sc.hst + 2 * F + 2, *st_2 = sc.hst + 2 * (F + n1) + 4;
     const bool sync = m->stats_hook && m->training;
     auto hook = [&](double* buf, int n) -> int {
         if (!sync) return EAGCN_OK;
@@ -250,7 +280,7 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
         }
         return EAGCN_OK;
     };
-    RC(head_colstats(sv.g, B, F, st_g, s, st_g + 2 * F, st_1 + 2 * n1, st_2 + 2 * n2));
+    if (!fused_readout(m)) RC(head_colstats(sv.g, B, F, st_g, s, st_g + 2 * F, st_1 + 2 * n1, st_2 + 2 * n2));
     RC(hook(st_g, 2 * F + 1));
     HeadDrop nodrop{0, 0u, 1.0f, 0, nullptr}, drop1 = nodrop;
     {

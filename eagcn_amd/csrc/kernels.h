@@ -188,10 +188,23 @@ int layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const
                         const float* dxout, const ReadoutGrad* rg, const float* dpad_row, float* dx,
                         const eagcn_layer_grads* g, void* stream, bool dpad_views = false,
                         const ZeroJob* zero_after = nullptr);
+// skip_apply: stop after the BatchNorm table (the caller applies it while it consumes Y: fused read-out of the top layer)
 int layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, void* stream,
-                       bool prepacked);
+                       bool prepacked, bool skip_apply = false);
+// relu / dropout / mask / view merge of a layer from its saved Y and BatchNorm table (what layer_forward_impl ends with)
+int layer_apply_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, void* stream);
 int pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const* ps, void* const* packed,
                     const size_t* packed_bytes, int n, void* stream, const ZeroJob* zj = nullptr);
+struct ReadoutBn {
+    const float* Y; int ldy;                 // [T][Fp] pre-BatchNorm (bias-free) aggregation output
+    const float* bn; int fp;                 // [4][Fp] scale / shift / ...
+    int do_drop; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
+    const int64_t* size; int mode;
+    float* g; int F;                         // [B][F]
+    double* st;                              // [2 F] sum g, sum g^2 (fp64 atomics; zero on entry)
+    double *cnt0, *cnt1, *cnt2;              // optional row-count slots of the head's BatchNorms (sync-BatchNorm)
+};
+int readout_bn_forward(const eagcn_batch* b, const eagcn_layout* lay, const ReadoutBn& a, void* stream);
 int readout_forward_sampled(const eagcn_batch* b, const float* x, const eagcn_layout* lay, const eagcn_layer_params* p,
                             const float* bn_sh, const int64_t* size, int mode, float* g, int F, uint16_t* cnt, float* padc,
                             void* stream);

@@ -775,6 +775,10 @@ static inline int ew_grid(size_t n) { return (int)std::max<size_t>(1, std::min<s
 
 }  // namespace eagcn
 
+static int apply_launch_(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, const eagcn::LayerDims& d,
+                         const float* colp, hipStream_t s);
+#define apply_launch apply_launch_
+
 using namespace eagcn;
 
 extern "C" int eagcn_pad16(int w) { return pad16(w); }
@@ -837,7 +841,7 @@ int eagcn::pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const
 }
 
 int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
-                              void* stream, bool prepacked) {
+                              void* stream, bool prepacked, bool skip_apply) {
     hipStream_t s = (hipStream_t)stream;
     int rc = check_layer(b, p, "eagcn_layer_forward");
     if (rc) return rc;
@@ -903,6 +907,7 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
         }
     }
     const double M = (double)b->B * (double)b->N;
+    {
     ProfScope psbn(PROF_BN, s);
     if (w->stats_hook && p->training) {
         // sync-BatchNorm: this rank's sums -> one vector, summed across the ranks by the caller's hook, finalize from that
@@ -922,9 +927,25 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
         bn_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.stats, nslab, d.fp, M, p->training, p->bn_eps,
                                                                 p->bn_momentum, sc.colp, pp, d.vc, w->bn, b->meta, tiles_per_wg, b->B, nullptr);
     EAGCN_LAUNCH_CHECK();
+    }
+    if (skip_apply) return EAGCN_OK;
+    return apply_launch(b, p, w, d, sc.colp, s);
+}
+
+int eagcn::layer_apply_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, void* stream) {
+    EAGCN_CHECK_ARG(b && p && w && w->bn && w->xout && w->pad_row && w->packed, "layer_apply: null buffer");
+    const LayerDims d = layer_dims(b, p);
+    Packed pk;
+    EAGCN_CHECK_ARG(carve_packed(w->packed, d, &pk) <= w->packed_bytes, "layer_apply: packed buffer too small");
+    return apply_launch(b, p, w, d, pk.colp, (hipStream_t)stream);
+}
+
+static int apply_launch_(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, const LayerDims& d,
+                         const float* colp, hipStream_t s) {
+    ProfScope psbn(PROF_BN, s);
     ApplyArgs aa;
     aa.bt = *b; aa.vc = d.vc; aa.structure = p->structure; aa.fp = d.fp; aa.Y = w->Y; aa.ldy = d.fp;
-    aa.bn = w->bn; aa.colp = sc.colp; aa.out = w->xout; aa.ldo = d.ldo; aa.pad_row = w->pad_row;
+    aa.bn = w->bn; aa.colp = colp; aa.out = w->xout; aa.ldo = d.ldo; aa.pad_row = w->pad_row;
     aa.do_drop = (p->training && p->dropout > 0.0f) ? 1 : 0;
     aa.thr = (uint32_t)std::min(4294967295.0, (double)p->dropout * 4294967296.0);
     aa.inv_keep = 1.0f / (1.0f - p->dropout);

@@ -120,6 +120,72 @@ __global__ __launch_bounds__(256) void readout_fwd_kernel(eagcn_batch bt, const 
     }
 }
 
+// Read-out straight from the pre-BatchNorm matrix of a Concate top layer: x = mask * dropout(relu(bn(y))) (layers.py:93-94, 313) is
+// formed on the operand load and summed over the atoms, and the column sums of g that Graph_BN needs (models.py:112) are taken
+// by the same launch -- three launches (bn_apply of the top layer, readout_fwd, head_colstats) and the write + re-read of the
+// top layer's [T, F] output become one.  The output matrix itself is only built when somebody asks for the atom
+// representations (eagcn_model_atom_rep_materialize).
+// grid (ceil(B/4), ceil(F/64)): one WAVE per molecule, 64 lanes = 64 exact columns, four rows in flight.
+__global__ __launch_bounds__(256) void readout_bn_fwd_kernel(eagcn_batch bt, ColMapD m, ReadoutBn a) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    const int f = blockIdx.y * 64 + lane;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (a.cnt0) *a.cnt0 = (double)bt.B;
+        if (a.cnt1) *a.cnt1 = (double)bt.B;
+        if (a.cnt2) *a.cnt2 = (double)bt.B;
+    }
+    const bool ok = b < bt.B && f < a.F;
+    const int cp = ok ? exact_to_packed(m, f) : 0;
+    float s = 0.0f;
+    if (ok) {
+        const uint64_t seed = a.do_drop ? (a.seed_dev ? *a.seed_dev : a.seed) : 0ull;
+        const int n = bt.nat[b], r0 = bt.row0[b];
+        const float sc = a.bn[BN_SC * a.fp + cp], sh = a.bn[BN_SH * a.fp + cp];
+        for (int i0 = 0; i0 < n; i0 += 4) {
+            float y[4], mk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u, n - 1);
+                y[u] = a.Y[(size_t)(r0 + i) * a.ldy + cp];
+                mk[u] = bt.row_m[r0 + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u < n) {
+                    float v = fmaxf(y[u] * sc + sh, 0.0f) * mk[u];
+                    if (a.do_drop) v *= drop_scale_el(seed, (uint64_t)(r0 + i0 + u) * a.fp + cp, a.thr, a.inv_keep);
+                    s += v;
+                }
+        }
+        // (non-stored rows of a Concate layer are masked to zero: nothing to add for them)
+        if (a.mode == 1) s *= 1.0f / (float)a.size[b];
+        a.g[(size_t)b * a.F + f] = s;
+    }
+    part[wave][lane] = ok ? s : 0.0f;
+    __syncthreads();
+    if (wave == 0 && f < a.F) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const double v = (double)part[w][lane];
+            s1 += v;
+            s2 += v * v;
+        }
+        atomicAdd(&a.st[2 * f], s1);
+        atomicAdd(&a.st[2 * f + 1], s2);
+    }
+}
+
+int readout_bn_forward(const eagcn_batch* b, const eagcn_layout* lay, const ReadoutBn& a, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_READOUT, s);
+    readout_bn_fwd_kernel<<<dim3(cdiv(b->B, 4), cdiv(a.F, 64)), 256, 0, s>>>(*b, make_colmap(lay), a);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
 // dx[r][cp] = dg[mol(r)][exact(cp)] / size: one thread per packed element, fully parallel
 __global__ __launch_bounds__(256) void readout_bwd_kernel(eagcn_batch bt, const float* __restrict__ dg, ColMapD m,
                                                            int ld, const int64_t* __restrict__ size, int mode,

@@ -163,6 +163,20 @@ class GraphRunner:
         self.saved, self.scratch, self.slots, self.index = [], None, [], None
         self._xout_views, self._pad_views = [], []
 
+    def materializer(self):
+        """Callable that builds the current slot's top-layer output matrix (atom representations) when the forward skipped it
+        (eagcn_model.fuse_readout); None when the forward builds it.  Valid until the slot's next forward, like the views."""
+        if not self.cms[self.cur].fuse_readout:
+            return None
+        cur, gen = self.cur, self.generation
+
+        def run():
+            if self.generation - gen >= 2:
+                raise L.EagcnHipError('atom representations of a forward that two newer forwards have overwritten')
+            L.check(L.load().eagcn_model_atom_rep_materialize(self.slots[cur].ref(), C.byref(self.cms[cur]), _ptr(self.saved[cur]),
+                                                              self.saved_bytes, _stream()), 'eagcn_model_atom_rep_materialize')
+        return run
+
     @property
     def xout_view(self):
         return self._xout_views[self.cur]

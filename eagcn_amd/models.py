@@ -51,19 +51,27 @@ class LazyAtomRep:
     """Deferred ``x2.data.cpu()`` (models.py:102): materialises the padded [B,N,F] host tensor on
     first use.  Supports what train.py:213-266 does with it (.view / indexing / .numpy / .shape)."""
 
-    def __init__(self, index, layout, packed, pad_row, n_out=None):
+    def __init__(self, index, layout, packed, pad_row, n_out=None, materialize=None):
         self._args = (index, layout, packed.detach(), None if pad_row is None else pad_row.detach())
         self._cpu = None
         self._n_out = n_out            # N of the caller's batch when the index was built for a larger (bucketed) N
+        self._materialize = materialize    # builds `packed` on the device first (the forward skipped it: fused read-out)
+
+    def _ensure(self):
+        if self._materialize is not None:
+            fn, self._materialize = self._materialize, None
+            fn()
 
     @property
     def packed(self):
         """(packed [T, ld] device tensor, pad_row, layout) without the padded host copy."""
+        self._ensure()
         index, layout, packed, pad_row = self._args
         return packed, pad_row, layout
 
     def cpu(self):
         if self._cpu is None:
+            self._ensure()
             index, layout, packed, pad_row = self._args
             with torch.no_grad():
                 dense = ops.unpack_rows(index, layout, packed, pad_row)
@@ -198,7 +206,9 @@ class EAGCN(nn.Module):
             if getattr(self, 'sync_bn', False):       # every BatchNorm over the GLOBAL batch (SURVEY.md 8e "BN modes (ii)")
                 from .parallel import StatsAllReducer
                 stats = StatsAllReducer()
-            self._plan = ops.ModelPlan(self.graph_layers(), head, self.n_afeat, self.molfp_mode, self.dropout, stats)
+            # atom_rep 'lazy' / 'none': the top layer's output matrix is built only if somebody reads the atom representations
+            fuse = self.atom_rep in ('lazy', 'none') and self.structure == 'Concate'
+            self._plan = ops.ModelPlan(self.graph_layers(), head, self.n_afeat, self.molfp_mode, self.dropout, stats, fuse)
         return self._plan
 
     # The plan and the graph runners hold ctypes structs with device pointers, captured HIP graphs and static
@@ -296,7 +306,7 @@ class EAGCN(nn.Module):
             return None
         pad = runner.pad_view if self.structure in ('Weighted_sum', 'GCN') else None
         rep = LazyAtomRep(runner.index, self.plan().last_layout, runner.xout_view, pad,
-                          runner.n_in if runner.n_in != runner.key[1] else None)
+                          runner.n_in if runner.n_in != runner.key[1] else None, runner.materializer())
         return rep.cpu() if self.atom_rep == 'eager' else rep
 
     def _graph_forward(self, adjs, afms, rels, size, bonds=None):
@@ -412,7 +422,7 @@ class EAGCN(nn.Module):
         atom_representations = None
         if holder is not None:
             pad = holder['pad_row'] if self.structure in ('Weighted_sum', 'GCN') else None
-            atom_representations = LazyAtomRep(index, plan.last_layout, holder['xout'], pad)
+            atom_representations = LazyAtomRep(index, plan.last_layout, holder['xout'], pad, None, holder.get('materialize'))
             if self.atom_rep == 'eager':
                 atom_representations = atom_representations.cpu()
         return out, atom_representations, graph_representation

@@ -723,9 +723,11 @@ class ModelPlan:
     """Static description of an EAGCN module for the model-level entry points: parameter order,
     layer specs with their chained column layouts, gradient-buffer offsets."""
 
-    def __init__(self, layers, head, n_afeat, molfp_mode, dropout, stats=None):
+    def __init__(self, layers, head, n_afeat, molfp_mode, dropout, stats=None, fuse_readout=False):
         # layers: list of GraphConv_Layer modules; head: dict of modules; stats: parallel.StatsAllReducer (sync-BatchNorm) or None
+        # fuse_readout: a Concate top layer's output matrix is only built on request (eagcn_model.fuse_readout)
         self.stats = stats
+        self.fuse_readout = bool(fuse_readout)
         self.layers = layers
         self.head = head
         self.molfp = 1 if molfp_mode == 'ave' else 0
@@ -830,6 +832,7 @@ class ModelPlan:
             setattr(hp, pre + '_b', mod.bias.data_ptr())
             setattr(hp, pre + '_rm', mod.running_mean.data_ptr())
             setattr(hp, pre + '_rv', mod.running_var.data_ptr())
+        m.fuse_readout = int(self.fuse_readout)
         if self.stats is not None:                    # sync-BatchNorm: cross-rank sums through eagcn_amd.parallel.StatsAllReducer
             m.stats_hook = C.cast(self.stats.cfn, C.c_void_p)
             m.stats_world = int(self.stats.world())
@@ -874,6 +877,15 @@ class _ModelFn(torch.autograd.Function):
             T = index.T
             holder['xout'] = saved[xo.value:xo.value + 4 * T * ld.value].view(torch.float32).view(T, ld.value)
             holder['pad_row'] = saved[po.value:po.value + 4 * ld.value].view(torch.float32)
+            if m.fuse_readout:
+                # the forward did not build the top layer's output matrix (its relu / dropout / mask ran inside the read-out):
+                # it is built from the saved pre-BatchNorm matrix the first time the atom representations are touched
+                mcopy = L.Model.from_buffer_copy(m)
+
+                def materialize(index=index, mcopy=mcopy, saved=saved, sbytes=sbytes):
+                    L.check(lib.eagcn_model_atom_rep_materialize(index.ref(), C.byref(mcopy), _ptr(saved), sbytes, _stream()),
+                            'eagcn_model_atom_rep_materialize')
+                holder['materialize'] = materialize
         # private copy: the cached struct is re-seeded by the next forward call
         ctx.plan, ctx.index, ctx.cmodel, ctx.saved_blob, ctx.size = plan, index, L.Model.from_buffer_copy(m), saved, size
         if not ctx.direct:

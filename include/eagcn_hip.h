@@ -339,7 +339,11 @@ typedef struct eagcn_model {
     void* stats_user;
     int32_t stats_world;                    /* ranks behind the hook (>= 1): the head's d gamma / d beta are formed from the
                                                summed sums and divided by it, so that the gradient AVERAGE over ranks is exact */
-    int32_t reserved_;
+    int32_t fuse_readout;                   /* 1: a Concate top layer does not materialise its output matrix in the forward: its
+                                               relu / dropout / mask are applied while the read-out sums the atoms (one launch
+                                               instead of bn_apply + read-out + column statistics).  The matrix
+                                               (atom_representations, models.py:102) is built on request by
+                                               eagcn_model_atom_rep_materialize.  Ignored for other structures.            */
 } eagcn_model;
 
 size_t eagcn_model_saved_bytes(const eagcn_batch* b, const eagcn_model* m);    /* kept forward -> backward */
@@ -347,6 +351,9 @@ size_t eagcn_model_scratch_bytes(const eagcn_batch* b, const eagcn_model* m);  /
 /* where the last layer's packed activations [T][ld] and pad_row [ld] live inside `saved` */
 int eagcn_model_atom_rep(const eagcn_batch* b, const eagcn_model* m, size_t* xout_offset,
                          size_t* pad_row_offset, int* ld);
+/* builds the last layer's packed output [T][ld] (+ pad_row) inside `saved` from the saved pre-BatchNorm matrix when the forward
+ * ran with fuse_readout = 1 (same values as a forward without the fusion, same dropout masks); a no-op otherwise */
+int eagcn_model_atom_rep_materialize(const eagcn_batch* b, const eagcn_model* m, void* saved, size_t saved_bytes, void* stream);
 /* packs afm [B][N][n_afeat] into the input slot of `saved` (the first step of eagcn_model_forward) */
 int eagcn_model_pack_input(const eagcn_batch* b, const eagcn_model* m, const float* afm, void* saved,
                            size_t saved_bytes, void* stream);
