@@ -127,52 +127,65 @@ __global__ __launch_bounds__(256) void readout_fwd_kernel(eagcn_batch bt, const 
 // representations (eagcn_model_atom_rep_materialize).
 // grid (ceil(B/4), ceil(F/64)): one WAVE per molecule, 64 lanes = 64 exact columns, four rows in flight.
 __global__ __launch_bounds__(256) void readout_bn_fwd_kernel(eagcn_batch bt, ColMapD m, ReadoutBn a) {
-    __shared__ float part[4][64];
+    // One workgroup per FOUR consecutive molecules: their packed rows are contiguous, and the four waves take them round-robin
+    // (eight rows in flight per wave) whatever molecule they belong to -- a 132-atom molecule next to three 16-atom ones costs
+    // every wave a quarter of the rows instead of one wave all 132.  Each wave keeps one partial sum per molecule.
+    __shared__ float part[4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x * 4 + wave;
+    const int b0 = blockIdx.x * 4;
     const int f = blockIdx.y * 64 + lane;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         if (a.cnt0) *a.cnt0 = (double)bt.B;
         if (a.cnt1) *a.cnt1 = (double)bt.B;
         if (a.cnt2) *a.cnt2 = (double)bt.B;
     }
-    const bool ok = b < bt.B && f < a.F;
-    const int cp = ok ? exact_to_packed(m, f) : 0;
-    float s = 0.0f;
-    if (ok) {
-        const uint64_t seed = a.do_drop ? (a.seed_dev ? *a.seed_dev : a.seed) : 0ull;
-        const int n = bt.nat[b], r0 = bt.row0[b];
-        const float sc = a.bn[BN_SC * a.fp + cp], sh = a.bn[BN_SH * a.fp + cp];
-        for (int i0 = 0; i0 < n; i0 += 4) {
-            float y[4], mk[4];
+    const int nb = min(4, bt.B - b0);
+    const bool okf = f < a.F;
+    const int cp = okf ? exact_to_packed(m, f) : 0;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int rbeg = bt.row0[b0], rend = bt.row0[b0 + nb];
+    int bnd[4];                                            // first row of the next molecule, per molecule of the group
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = min(i0 + u, n - 1);
-                y[u] = a.Y[(size_t)(r0 + i) * a.ldy + cp];
-                mk[u] = bt.row_m[r0 + i];
+    for (int j = 0; j < 4; ++j) bnd[j] = bt.row0[min(b0 + j + 1, b0 + nb)];
+    if (okf) {
+        const uint64_t seed = a.do_drop ? (a.seed_dev ? *a.seed_dev : a.seed) : 0ull;
+        const float sc = a.bn[BN_SC * a.fp + cp], sh = a.bn[BN_SH * a.fp + cp];
+        for (int r0 = rbeg + wave; r0 < rend; r0 += 32) {
+            float y[8], mk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = min(r0 + 4 * u, rend - 1);
+                y[u] = a.Y[(size_t)r * a.ldy + cp];
+                mk[u] = bt.row_m[r];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (i0 + u < n) {
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + 4 * u;
+                if (r < rend) {
                     float v = fmaxf(y[u] * sc + sh, 0.0f) * mk[u];
-                    if (a.do_drop) v *= drop_scale_el(seed, (uint64_t)(r0 + i0 + u) * a.fp + cp, a.thr, a.inv_keep);
-                    s += v;
+                    if (a.do_drop) v *= drop_scale_el(seed, (uint64_t)r * a.fp + cp, a.thr, a.inv_keep);
+                    const int mi = (r >= bnd[0] ? 1 : 0) + (r >= bnd[1] ? 1 : 0) + (r >= bnd[2] ? 1 : 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[j] += mi == j ? v : 0.0f;
                 }
+            }
         }
-        // (non-stored rows of a Concate layer are masked to zero: nothing to add for them)
-        if (a.mode == 1) s *= 1.0f / (float)a.size[b];
-        a.g[(size_t)b * a.F + f] = s;
     }
-    part[wave][lane] = ok ? s : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[wave][j][lane] = s[j];
     __syncthreads();
-    if (wave == 0 && f < a.F) {
+    if (wave == 0 && okf) {
+        // (non-stored rows of a Concate layer are masked to zero: nothing to add for them)
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const double v = (double)part[w][lane];
-            s1 += v;
-            s2 += v * v;
-        }
+        for (int j = 0; j < 4; ++j)
+            if (j < nb) {
+                float v = (part[0][j][lane] + part[1][j][lane]) + (part[2][j][lane] + part[3][j][lane]);
+                if (a.mode == 1) v *= 1.0f / (float)a.size[b0 + j];
+                a.g[(size_t)(b0 + j) * a.F + f] = v;
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
+            }
         atomicAdd(&a.st[2 * f], s1);
         atomicAdd(&a.st[2 * f + 1], s2);
     }
