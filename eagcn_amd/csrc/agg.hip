@@ -635,13 +635,25 @@ __device__ __forceinline__ void edge_grad_body(const EdgeArgs& a, const int bx, 
     }
     if (sl == 0) dr_s[wave * 4 + grp] = dr_acc;
     __syncthreads();
-    // slab[bx][k][0..255] = bond-type histogram, slab[..][k][256] = self term
-    double* out = a.datt + ((size_t)bx * a.vc.K + k) * EDGE_SLAB;
-    out[tid] = h_s[tid];
-    if (tid == 0) {
-        double t = 0.0;
-        for (int q = 0; q < 16; ++q) t += dr_s[q];
-        out[256] = t;
+    // slab[bx][k][0..255] = bond-type histogram, slab[..][k][256] = self term -- or the non-zero bins added to one of the shared
+    // accumulator slabs
+    if (a.atomic) {
+        double* out = a.datt + ((size_t)(bx & (EDGE_COPIES - 1)) * a.vc.K + k) * EDGE_SLAB;
+        const double v = h_s[tid];
+        if (v != 0.0) atomicAdd(&out[tid], v);
+        if (tid == 0) {
+            double t = 0.0;
+            for (int q = 0; q < 16; ++q) t += dr_s[q];
+            if (t != 0.0) atomicAdd(&out[256], t);
+        }
+    } else {
+        double* out = a.datt + ((size_t)bx * a.vc.K + k) * EDGE_SLAB;
+        out[tid] = h_s[tid];
+        if (tid == 0) {
+            double t = 0.0;
+            for (int q = 0; q < 16; ++q) t += dr_s[q];
+            out[256] = t;
+        }
     }
 }
 

@@ -539,13 +539,21 @@ __global__ void g3_zero_kernel(unsigned* __restrict__ p, int n, double* __restri
     if (i < n) p[i] = 0u;
     if (i < nz) z[i] = 0.0;
 }
+// words to clear from the first hand-off flag on: the flags, and -- when the caller's region continues with the edge-gradient
+// accumulators of kernels.h (every layer scratch carving does) -- those as well
+static int g3_clear_words(size_t bytes) {
+    const size_t ranges = (size_t)gemm3_grid() * 4;
+    size_t n = align256(ranges * sizeof(unsigned));
+    if (bytes >= gemm3_workspace_bytes() + edge_acc_bytes()) n += edge_acc_bytes();
+    return (int)(n / sizeof(unsigned));
+}
 int gemm3_clear_flags(void* workspace, size_t bytes, hipStream_t s, double* zero, int nzero) {
     float* ws; unsigned* flags;
     int rc = g3_prepare(workspace, bytes, &ws, &flags);
     if (rc) return rc;
     // a KERNEL, not hipMemsetAsync: as a memset node of a captured graph the clear was not ordered with the kernel nodes
     // around it on replay (ROCm 7.2: owners then read parked tiles of an earlier launch; tests/probe_graph_replay.py)
-    const int n = gemm3_grid() * 4;
+    const int n = g3_clear_words(bytes);
     g3_zero_kernel<<<cdiv(std::max(n, nzero), 256), 256, 0, s>>>(flags, n, zero, zero ? nzero : 0);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
@@ -555,7 +563,7 @@ int gemm3_zero_job(void* workspace, size_t bytes, double* zero, int nzero, ZeroJ
     float* ws; unsigned* flags;
     int rc = g3_prepare(workspace, bytes, &ws, &flags);
     if (rc) return rc;
-    out->u = flags; out->nu = gemm3_grid() * 4; out->d = zero; out->nd = zero ? nzero : 0;
+    out->u = flags; out->nu = g3_clear_words(bytes); out->d = zero; out->nd = zero ? nzero : 0;
     return EAGCN_OK;
 }
 

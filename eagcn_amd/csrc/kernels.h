@@ -24,9 +24,17 @@ struct EdgeArgs {
     ViewCols vc;
     const float* dY; const float* Y; const float* P; int ld;
     const float* sig; const float* rsig; const float* rscale;
-    double* datt;                // [grid.x][K][EDGE_SLAB] per-workgroup partials: 256 codes + self term
+    double* datt;                // [grid.x][K][EDGE_SLAB] per-workgroup partials: 256 codes + self term ...
+    int atomic;                  // ... or (atomic != 0) [EDGE_COPIES][K][EDGE_SLAB] shared accumulators (fp64 atomics)
 };
 constexpr int EDGE_SLAB = 264;
+// The edge-gradient workgroups add their bond-type histograms (a dozen non-zero bins each) to one of EDGE_COPIES fp64 accumulator
+// slabs instead of writing a slab of their own: the reduction that follows reads 8 slabs, not one per workgroup (12.7 MB at
+// batch 1024).  The accumulators live right behind the GEMM hand-off workspace in every layer scratch carving -- same place for
+// every layer and direction, never used for anything else --, are cleared together with the hand-off flags once per API call
+// and zeroed again by the reduction that drains them.
+constexpr int EDGE_COPIES = 8;
+inline size_t edge_acc_bytes() { return align256((size_t)EDGE_COPIES * EAGCN_MAX_VIEWS * EDGE_SLAB * sizeof(double)); }
 int edge_grid_x(const eagcn_batch* b);
 int launch_edge_grad(const EdgeArgs& a, hipStream_t s);
 int launch_agg_edge(AggArgs a, const EdgeArgs& e, hipStream_t s);   // transposed aggregation + edge gradients, one grid

@@ -532,9 +532,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(eagcn_batch bt, int f
 // ceil(K*EDGE_SLAB / 16) blocks for the edge-gradient partials (16 lanes per entry)
 __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtrs pp, ViewCols vc, ColMapD in,
                                                             int ld_in, int fp, const float* __restrict__ dWcat,
-                                                            int nsplit, size_t slab, const double* __restrict__ datt,
+                                                            int nsplit, size_t slab, double* __restrict__ datt,
                                                             int nedge, const float* __restrict__ rsig, int wblocks,
-                                                            const int32_t* __restrict__ meta, int xk_G) {
+                                                            const int32_t* __restrict__ meta, int xk_G, int edge_drain) {
     nedge = nedge < 0 ? -nedge : min(nedge, (meta[EAGCN_META_T] + 15) / 16);   // edge-gradient workgroups that had rows (< 0: all wrote)
     nsplit = max(1, min(nsplit, meta[EAGCN_META_T] >> 7));     // split-K partials actually written (gemm.hip eff_splits)
     if ((int)blockIdx.x < wblocks) {
@@ -591,6 +591,13 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) t += v[u];
+            if (edge_drain && er < tot) {                  // shared accumulator slabs: every element is read by exactly one lane
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int z = z0 + 16 * u;
+                    if (z < nedge) datt[(size_t)z * tot + e] = 0.0;
+                }
+            }
         }
     } else if (c >= 1 && c <= pp.rel_c[k]) {
         const float* vec = pp.rel_vec[k];
@@ -682,7 +689,7 @@ static bool gemm3_layer(int ld_in) {
 }
 
 struct Packed { float *Wcat, *WcatT, *colp, *sig, *rsig; };
-struct FwdScratch { void* gws; float *Wcat, *WcatT, *colp, *sig, *rsig; double* stats; double* gsum; };
+struct FwdScratch { void* gws; double* eacc; float *Wcat, *WcatT, *colp, *sig, *rsig; double* stats; double* gsum; };
 static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
     Carver c(base);
     Packed t;
@@ -697,6 +704,7 @@ static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
 struct BwdScratch {
     void* gws;                   // GEMM hand-off workspace: FIRST in both carvings, so that every layer of a model and both
                                  // directions share one region (one flag clear per API call, kernels.h gemm3_clear_flags)
+    double* eacc;                // edge-gradient accumulator slabs (kernels.h EDGE_COPIES): right behind it, zero between uses
     float *Wcat, *WcatT, *colp, *sig, *rsig, *dY, *dP, *cc, *dWcat;
     double *slab, *slab_da, *datt, *gsum;
 };
@@ -704,6 +712,7 @@ static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, Fw
     Carver c(base);
     FwdScratch t;
     t.gws = c.take<char>(gemm3_workspace_bytes());
+    t.eacc = (double*)c.take<char>(edge_acc_bytes());        // (same place in both carvings: kernels.h EDGE_COPIES)
     t.Wcat = c.take<float>(d.wslab);
     t.WcatT = c.take<float>(d.wslab);
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
@@ -718,6 +727,7 @@ static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, Bw
     Carver c(base);
     BwdScratch t;
     t.gws = c.take<char>(gemm3_workspace_bytes());
+    t.eacc = (double*)c.take<char>(edge_acc_bytes());
     t.Wcat = c.take<float>(d.wslab);
     t.WcatT = c.take<float>(d.wslab);
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
@@ -1077,9 +1087,13 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = nullptr; a.nchunk = 1;
         EdgeArgs e;
         e.bt = *b; e.vc = d.vc; e.dY = sc.dY; e.Y = w->Y; e.P = w->P; e.ld = d.fp; e.sig = sc.sig;
-        e.rsig = sc.rsig; e.rscale = w->rscale; e.datt = sc.datt;
+        e.rsig = sc.rsig; e.rscale = w->rscale; e.datt = sc.datt; e.atomic = 0;
+        static const bool edge_atomic = [] { const char* v = getenv("EAGCN_EDGE_SLABS"); return !(v && v[0] == '1'); }();
+        bool general_rel = false;                     // (code books: the reduction reads a view's whole histogram per channel)
+        for (int k = 0; k < p->K; ++k) general_rel = general_rel || pp.rel_vec[k] != nullptr;
+        if (edge_atomic && !sagg_enabled() && !general_rel) { e.datt = sc.eacc; e.atomic = 1; }
         static const bool colaunch = [] { const char* v = getenv("EAGCN_NO_COLAUNCH"); return !(v && v[0] == '1'); }();
-        nedge = edge_grid_x(b);
+        nedge = e.atomic ? -EDGE_COPIES : edge_grid_x(b);
         if (sagg_enabled()) {
             // transposed aggregation + edge gradients + BatchNorm-backward affine in one kernel over the bond lists
             SAggBwd sa;
@@ -1139,10 +1153,12 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     }
     {
         const int wblocks = nsplit > 0 ? cdiv((int)d.wslab, 256) : 0;
+        double* edge_src = nedge == -EDGE_COPIES && !sagg_enabled() ? sc.eacc : sc.datt;
+        const int edge_drain = edge_src == sc.eacc ? 1 : 0;       // shared accumulators: zeroed again by the threads that read them
         ProfScope psu(PROF_PACK, side);
         unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, side>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
-                                                                                    nsplit, d.wslab, sc.datt, nedge, sc.rsig,
-                                                                                    wblocks, b->meta, xk_G);
+                                                                                    nsplit, d.wslab, edge_src, nedge, sc.rsig,
+                                                                                    wblocks, b->meta, xk_G, edge_drain);
         EAGCN_LAUNCH_CHECK();
     }
     // join: the caller reuses the scratch block (dY', dP, partial slabs) for the next layer
