@@ -88,6 +88,16 @@ struct ReadoutGrad {
     const float* dg; int F;      // [B][F] gradient of the molecule fingerprints
     const int64_t* size; int mode;
     ColMapD map;                 // layout of the layer output (packed column -> exact column)
+    // Graph_BN's backward folded in (Concate top layer of the model engine: one launch less): dg is then the gradient of the
+    // NORMALISED fingerprints (d gn) and the kernel forms  dg = sc (dgn - c1 - (g - mu) inv c2)  per column on the way in,
+    // c1 / c2 = (sum dgn, sum dgn * xhat) / rows from the sums the head's last backward launch accumulated; block (0,0) writes
+    // d Graph_BN.weight / .bias.  gmat == nullptr: dg is used as it is.
+    const float* gmat;           // [B][F] fingerprints g (pre-BatchNorm)
+    const float* gbn;            // [4][F] Graph_BN table (scale, shift, mean, invstd: head2.hip HT_*)
+    const double* gsb;           // [2 F] sum dgn, sum dgn * xhat
+    const double* gcnt;          // optional global row count (sync-BatchNorm), else gB
+    float* d_gamma; float* d_beta;
+    int gB, gtraining; float gscale;
 };
 // ---- wave-autonomous balanced GEMM (gemm3.hip): NT (ta=0,tb=1) and TN (ta=1,tb=0) forms --------------------------------
 struct G2Prob {                  // one product C[M,N] = op(A).op(B) in one of the three operand forms of a layer
@@ -191,11 +201,19 @@ int head_fwd(const HeadFwd& a, hipStream_t s);
 int head_bwd(const HeadBwd& a, hipStream_t s);
 int head_gbn_bwd(const HeadGbn& a, hipStream_t s);
 
+// The final reduction of a layer's edge gradients (8 shared accumulator slabs -> d att.weight, d self_r) handed to the NEXT
+// layer's first backward kernel instead of a launch of its own (unpack_grads has nothing else to do for a layer on the balanced
+// GEMM): eacc == nullptr means nothing is pending.
+struct EdgeDrain {
+    double* eacc; int K;
+    float* datt_w[EAGCN_MAX_VIEWS]; float* dself_r[EAGCN_MAX_VIEWS]; int channels[EAGCN_MAX_VIEWS];
+    const float* rsig;           // [K] sigmoid(self_r) of the layer the gradients belong to
+};
 // dpad_views: dpad_row holds one gradient row per VIEW ([K][ld_out]: sampled dropout of the non-stored rows) instead of one
 int layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                         const float* dxout, const ReadoutGrad* rg, const float* dpad_row, float* dx,
                         const eagcn_layer_grads* g, void* stream, bool dpad_views = false,
-                        const ZeroJob* zero_after = nullptr);
+                        const ZeroJob* zero_after = nullptr, const EdgeDrain* drain_in = nullptr, EdgeDrain* drain_out = nullptr);
 // skip_apply: stop after the BatchNorm table (the caller applies it while it consumes Y: fused read-out of the top layer)
 int layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, void* stream,
                        bool prepacked, bool skip_apply = false);

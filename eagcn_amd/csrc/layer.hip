@@ -323,6 +323,7 @@ struct BwdArgs {
     double* slab_da;             // [grid][MAX_VIEWS]
     int do_drop; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
     double* zero; int nzero;     // fp64 words cleared on the way (the head's backward sums, for the next backward call)
+    EdgeDrain drain;             // pending edge-gradient reduction of the layer above (eacc == nullptr: none)
 };
 
 // One workgroup owns BWD_ROWS consecutive-strided rows; a thread owns FOUR adjacent columns (one float4 per row
@@ -341,8 +342,33 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     // the grid is sized for the row CAPACITY: only the first ceil(rows / BWD_ROWS) workgroups work (and write a
     // slab); bn_bwd_finalize derives the same count from the device-side row count
     const int nwg = max(1, min((int)gridDim.x, (rows + BWD_ROWS - 1) / BWD_ROWS));
-    if (blockIdx.x == 0 && blockIdx.y == 0 && a.zero)
-        for (int i = threadIdx.x; i < a.nzero; i += blockDim.x) a.zero[i] = 0.0;
+    if (a.drain.eacc && blockIdx.x == 0 && blockIdx.y == 0) {
+        // the layer above left its bond-type histograms in the shared accumulator slabs: reduce them into its d att.weight /
+        // d self_r and leave the slabs zero for this layer's own edge gradients (agg_edge runs after this kernel)
+        const int K = a.drain.K;
+        for (int e = threadIdx.x; e < K * EDGE_SLAB; e += blockDim.x) {
+            const int k = e / EDGE_SLAB, c = e - k * EDGE_SLAB;
+            if (c > 256) continue;
+            double v[EDGE_COPIES];
+#pragma unroll
+            for (int z = 0; z < EDGE_COPIES; ++z) v[z] = a.drain.eacc[((size_t)z * K + k) * EDGE_SLAB + c];
+            double t = 0.0;
+#pragma unroll
+            for (int z = 0; z < EDGE_COPIES; ++z) { t += v[z]; a.drain.eacc[((size_t)z * K + k) * EDGE_SLAB + c] = 0.0; }
+            float* dw = nullptr;
+            float* dr = nullptr;
+            int ch = 0;
+#pragma unroll
+            for (int q = 0; q < EAGCN_MAX_VIEWS; ++q)
+                if (q == k) { dw = a.drain.datt_w[q]; dr = a.drain.dself_r[q]; ch = a.drain.channels[q]; }
+            if (c == 256) {
+                const double r = (double)a.drain.rsig[k];
+                dr[0] = (float)(t * r * (1.0 - r));
+            } else if (c >= 1 && c <= ch) {
+                dw[c - 1] = (float)t;
+            }
+        }
+    }
     if ((int)blockIdx.x >= nwg) return;
     if (threadIdx.x < EAGCN_MAX_VIEWS) da_s[threadIdx.x] = 0.0;
     __syncthreads();
@@ -352,6 +378,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) da[k] = 0.0;
     // grid.y cuts the columns into chunks of 1024 (one pass of the workgroup): a wide layer (Fp = 6320 at the HIV widths) is
     // limited to a few hundred row blocks by the size of its partial slabs -- too few waves to stream at HBM rate
+    if constexpr (DG) {
+        if (a.rg.gmat && blockIdx.x == 0 && blockIdx.y == 0)      // d Graph_BN.weight / .bias (its backward is folded in below)
+            for (int f = threadIdx.x; f < a.rg.F; f += blockDim.x) {
+                a.rg.d_gamma[f] = (float)(a.rg.gsb[2 * f + 1] * (double)a.rg.gscale);
+                a.rg.d_beta[f] = (float)(a.rg.gsb[2 * f] * (double)a.rg.gscale);
+            }
+    }
     const int c_lo = blockIdx.y * (int)blockDim.x * 4;
     for (int cp = c_lo + threadIdx.x * 4; cp < min(fp, c_lo + (int)blockDim.x * 4); cp += blockDim.x * 4) {
         const int k = col_view(a.vc, cp), f = cp - a.vc.off[k];
@@ -383,6 +416,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
             ce4 = ce0 >= 0 && ce3 == ce0 + 3 && (ce0 & 3) == 0 && (a.rg.F & 3) == 0 &&
                   (reinterpret_cast<uintptr_t>(a.rg.dg) & 15) == 0;
         }
+        // Graph_BN's backward on the way in (ReadoutGrad::gmat): per-column coefficients of dg = al dgn + be g + ga
+        float gal[4] = {1.f, 1.f, 1.f, 1.f}, gbe[4] = {0.f, 0.f, 0.f, 0.f}, gga[4] = {0.f, 0.f, 0.f, 0.f};
+        bool gfold = false;
+        if constexpr (DG) {
+            gfold = a.rg.gmat != nullptr;
+            if (gfold) {
+                const double Bn = (a.rg.gcnt && a.rg.gtraining) ? *a.rg.gcnt : (double)a.rg.gB;
+                const int ce[4] = {ce0, ce1, ce2, ce3};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ce[j] >= 0) {
+                        const float sc = a.rg.gbn[0 * a.rg.F + ce[j]], mu = a.rg.gbn[2 * a.rg.F + ce[j]], inv = a.rg.gbn[3 * a.rg.F + ce[j]];
+                        const float c1 = a.rg.gtraining ? (float)(a.rg.gsb[2 * ce[j]] / Bn) : 0.0f;
+                        const float c2 = a.rg.gtraining ? (float)(a.rg.gsb[2 * ce[j] + 1] / Bn) : 0.0f;
+                        gal[j] = sc;
+                        gbe[j] = -sc * inv * c2;
+                        gga[j] = sc * (inv * c2 * mu - c1);
+                    }
+            }
+        }
         double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, dak = 0.0;
         for (int rb = blockIdx.x; rb < rows; rb += BWD_ROWS * nwg) {
             float4 yv[BWD_ROWS], upv[BWD_ROWS];
@@ -404,6 +457,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
                             v.y = ce1 >= 0 ? g[ce1] : 0.0f;
                             v.z = ce2 >= 0 ? g[ce2] : 0.0f;
                             v.w = ce3 >= 0 ? g[ce3] : 0.0f;
+                        }
+                        if (gfold) {
+                            const float* gm = a.rg.gmat + (size_t)mol * a.rg.F;
+                            float4 gv;
+                            if (ce4) {
+                                gv = *reinterpret_cast<const float4*>(gm + ce0);
+                            } else {
+                                gv.x = ce0 >= 0 ? gm[ce0] : 0.0f;
+                                gv.y = ce1 >= 0 ? gm[ce1] : 0.0f;
+                                gv.z = ce2 >= 0 ? gm[ce2] : 0.0f;
+                                gv.w = ce3 >= 0 ? gm[ce3] : 0.0f;
+                            }
+                            v.x = ce0 >= 0 ? gal[0] * v.x + gbe[0] * gv.x + gga[0] : 0.0f;
+                            v.y = ce1 >= 0 ? gal[1] * v.y + gbe[1] * gv.y + gga[1] : 0.0f;
+                            v.z = ce2 >= 0 ? gal[2] * v.z + gbe[2] * gv.z + gga[2] : 0.0f;
+                            v.w = ce3 >= 0 ? gal[3] * v.w + gbe[3] * gv.w + gga[3] : 0.0f;
                         }
                         if (a.rg.mode == 1) {
                             const float is = 1.0f / (float)a.rg.size[mol];
@@ -473,7 +542,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
                                                                const float* __restrict__ bn, ViewCols vc,
                                                                GradPtrs gp, float* __restrict__ cc, const int32_t* __restrict__ meta, int nvirt,
                                                                int batch_B, int da_chunks, int da_stride,
-                                                               const double* __restrict__ gsum) {
+                                                               const double* __restrict__ gsum, double* __restrict__ zero, int nzero) {
+    // fp64 words cleared on the way (the head's backward sums, for the next backward call; every reader -- the reduction in
+    // front of this launch reads Graph_BN's sums -- is done by now)
+    if (blockIdx.x == 0 && zero)
+        for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0.0;
     if (meta[EAGCN_META_NLOG] > 0) M = (double)batch_B * (double)meta[EAGCN_META_NLOG];
     nslab = max(1, min(nslab, (meta[EAGCN_META_T] + nvirt + BWD_ROWS - 1) / BWD_ROWS));   // slabs actually written
     const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
@@ -979,7 +1052,9 @@ extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_para
 
 int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                                const float* dxout, const ReadoutGrad* rg, const float* dpad_row, float* dx,
-                               const eagcn_layer_grads* g, void* stream, bool dpad_views, const ZeroJob* zero_after) {
+                               const eagcn_layer_grads* g, void* stream, bool dpad_views, const ZeroJob* zero_after,
+                               const EdgeDrain* drain_in, EdgeDrain* drain_out) {
+    if (drain_out) drain_out->eacc = nullptr;
     hipStream_t s = (hipStream_t)stream;
     int rc = check_layer(b, p, "eagcn_layer_backward");
     if (rc) return rc;
@@ -1035,6 +1110,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     ba.seed_dev = p->seed_dev;
     ba.zero = zero_after ? zero_after->d : nullptr;
     ba.nzero = zero_after ? zero_after->nd : 0;
+    if (drain_in && drain_in->eacc) ba.drain = *drain_in; else memset(&ba.drain, 0, sizeof(ba.drain));
     const int rows = b->T + ba.nvirt;
     const int gxb = std::max(1, std::min(rows, d.gxb));
     const double M = (double)b->B * (double)b->N;
@@ -1066,10 +1142,10 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         }
         if (gxb > 64)
             bn_bwd_finalize_kernel<64><<<cdiv(d.fp, 4), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
-                                                                       d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb, gsum);
+                                                                       d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb, gsum, ba.zero, ba.nzero);
         else
             bn_bwd_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
-                                                                        d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb, gsum);
+                                                                        d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb, gsum, ba.zero, ba.nzero);
         EAGCN_LAUNCH_CHECK();
         if (b->T > 0 && !sagg_enabled()) {        // (the bond-list aggregation applies this affine while it stages dH)
             bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
@@ -1155,6 +1231,15 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         const int wblocks = nsplit > 0 ? cdiv((int)d.wslab, 256) : 0;
         double* edge_src = nedge == -EDGE_COPIES && !sagg_enabled() ? sc.eacc : sc.datt;
         const int edge_drain = edge_src == sc.eacc ? 1 : 0;       // shared accumulators: zeroed again by the threads that read them
+        static const bool defer_env = [] { const char* v = getenv("EAGCN_NO_EDGE_DEFER"); return !(v && v[0] == '1'); }();
+        if (defer_env && drain_out && edge_drain && wblocks == 0 && !forked && b->T > 0) {
+            // nothing but the edge reduction is left for this layer: the next layer's first backward kernel does it (one launch less)
+            drain_out->eacc = sc.eacc; drain_out->K = p->K; drain_out->rsig = sc.rsig;
+            for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) {
+                drain_out->datt_w[k] = gp.datt_w[k]; drain_out->dself_r[k] = gp.dself_r[k]; drain_out->channels[k] = pp.channels[k];
+            }
+            return EAGCN_OK;
+        }
         ProfScope psu(PROF_PACK, side);
         unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, side>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
                                                                                     nsplit, d.wslab, edge_src, nedge, sc.rsig,
