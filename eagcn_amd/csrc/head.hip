@@ -342,10 +342,6 @@ extern "C" int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_mode
     const eagcn_layout lay = out_layout(last);
     const bool weighted = last->structure == EAGCN_STRUCT_WEIGHTED;
     const bool sampled = pad_sampled(m);
-    static const bool fold_env = [] { const char* v = getenv("EAGCN_NO_GBN_FOLD"); return !(v && v[0] == '1'); }();
-    const bool gbn_folded = fold_env && !weighted;
-    bool gbn_sync = m->stats_hook && m->training;
-    float gbn_scale = gbn_sync && m->stats_world > 1 ? 1.0f / (float)m->stats_world : 1.0f;
     if (with_head) {
         // head backward (head2.hip): den3 -> bn_den2 -> den2 -> bn_den1 -> den1 -> Graph_BN, one launch per dense layer
         // (d input + d weight), each BatchNorm's backward sums taken by the launch in front of it
@@ -386,14 +382,11 @@ extern "C" int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_mode
         if (sync) { b1.cnt_y = cn_1; b1.gscale = gscale; }
         RC(head_bwd(b1, s));
         RC(hook(sb_g, 2 * F));
-        // Graph_BN's backward: folded into the top layer's first backward kernel (ReadoutGrad) for a Concate top layer; Weighted_sum
-        // needs d g materialised (the gradient of its non-stored rows is taken from it below)
-        gbn_sync = sync; gbn_scale = gscale;
-        if (!gbn_folded) {
-            HeadGbn bg{B, F, sc.dgn, sv.g, sv.bn_g, sb_g, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training};
-            if (sync) { bg.cnt = cn_g; bg.gscale = gscale; }
-            RC(head_gbn_bwd(bg, s));
-        }
+        // (folding Graph_BN's backward into the top layer's first backward kernel was measured: a wash at B = 256, +11 us at
+        //  B = 1024 -- every packed row then gathers two molecule rows instead of one; it stays a 5 us launch of its own)
+        HeadGbn bg{B, F, sc.dgn, sv.g, sv.bn_g, sb_g, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training};
+        if (sync) { bg.cnt = cn_g; bg.gscale = gscale; }
+        RC(head_gbn_bwd(bg, s));
         // read-out backward: evaluated inside the last layer's first backward kernel (ReadoutGrad); only the
         // gradient of the common non-stored row of Weighted_sum needs a (tiny) launch of its own
         if (sampled) RC(readout_backward_pad_views(b, sc.dg, &lay, size, m->molfp_mode, F, last->K, sv.pad_cnt, last->dropout, sc.dpad, stream));
@@ -402,12 +395,6 @@ extern "C" int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_mode
     ReadoutGrad rgd;
     memset(&rgd, 0, sizeof(rgd));
     rgd.dg = sc.dg; rgd.F = F; rgd.size = size; rgd.mode = m->molfp_mode; rgd.map = make_colmap(&lay);
-    if (gbn_folded) {
-        rgd.dg = sc.dgn; rgd.gmat = sv.g; rgd.gbn = sv.bn_g; rgd.gsb = sc.hsb;
-        rgd.gcnt = gbn_sync ? sc.hst + 2 * F : nullptr;
-        rgd.d_gamma = hg->d_gbn_w; rgd.d_beta = hg->d_gbn_b;
-        rgd.gB = B; rgd.gtraining = m->training; rgd.gscale = gbn_scale;
-    }
     const int top_l = m->n_layers - 1;
     EdgeDrain pend_in, pend_out;
     pend_in.eacc = nullptr;

@@ -88,16 +88,6 @@ struct ReadoutGrad {
     const float* dg; int F;      // [B][F] gradient of the molecule fingerprints
     const int64_t* size; int mode;
     ColMapD map;                 // layout of the layer output (packed column -> exact column)
-    // Graph_BN's backward folded in (Concate top layer of the model engine: one launch less): dg is then the gradient of the
-    // NORMALISED fingerprints (d gn) and the kernel forms  dg = sc (dgn - c1 - (g - mu) inv c2)  per column on the way in,
-    // c1 / c2 = (sum dgn, sum dgn * xhat) / rows from the sums the head's last backward launch accumulated; block (0,0) writes
-    // d Graph_BN.weight / .bias.  gmat == nullptr: dg is used as it is.
-    const float* gmat;           // [B][F] fingerprints g (pre-BatchNorm)
-    const float* gbn;            // [4][F] Graph_BN table (scale, shift, mean, invstd: head2.hip HT_*)
-    const double* gsb;           // [2 F] sum dgn, sum dgn * xhat
-    const double* gcnt;          // optional global row count (sync-BatchNorm), else gB
-    float* d_gamma; float* d_beta;
-    int gB, gtraining; float gscale;
 };
 // ---- wave-autonomous balanced GEMM (gemm3.hip): NT (ta=0,tb=1) and TN (ta=1,tb=0) forms --------------------------------
 struct G2Prob {                  // one product C[M,N] = op(A).op(B) in one of the three operand forms of a layer

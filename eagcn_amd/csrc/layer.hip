@@ -378,13 +378,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) da[k] = 0.0;
     // grid.y cuts the columns into chunks of 1024 (one pass of the workgroup): a wide layer (Fp = 6320 at the HIV widths) is
     // limited to a few hundred row blocks by the size of its partial slabs -- too few waves to stream at HBM rate
-    if constexpr (DG) {
-        if (a.rg.gmat && blockIdx.x == 0 && blockIdx.y == 0)      // d Graph_BN.weight / .bias (its backward is folded in below)
-            for (int f = threadIdx.x; f < a.rg.F; f += blockDim.x) {
-                a.rg.d_gamma[f] = (float)(a.rg.gsb[2 * f + 1] * (double)a.rg.gscale);
-                a.rg.d_beta[f] = (float)(a.rg.gsb[2 * f] * (double)a.rg.gscale);
-            }
-    }
     const int c_lo = blockIdx.y * (int)blockDim.x * 4;
     for (int cp = c_lo + threadIdx.x * 4; cp < min(fp, c_lo + (int)blockDim.x * 4); cp += blockDim.x * 4) {
         const int k = col_view(a.vc, cp), f = cp - a.vc.off[k];
@@ -416,26 +409,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
             ce4 = ce0 >= 0 && ce3 == ce0 + 3 && (ce0 & 3) == 0 && (a.rg.F & 3) == 0 &&
                   (reinterpret_cast<uintptr_t>(a.rg.dg) & 15) == 0;
         }
-        // Graph_BN's backward on the way in (ReadoutGrad::gmat): per-column coefficients of dg = al dgn + be g + ga
-        float gal[4] = {1.f, 1.f, 1.f, 1.f}, gbe[4] = {0.f, 0.f, 0.f, 0.f}, gga[4] = {0.f, 0.f, 0.f, 0.f};
-        bool gfold = false;
-        if constexpr (DG) {
-            gfold = a.rg.gmat != nullptr;
-            if (gfold) {
-                const double Bn = (a.rg.gcnt && a.rg.gtraining) ? *a.rg.gcnt : (double)a.rg.gB;
-                const int ce[4] = {ce0, ce1, ce2, ce3};
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (ce[j] >= 0) {
-                        const float sc = a.rg.gbn[0 * a.rg.F + ce[j]], mu = a.rg.gbn[2 * a.rg.F + ce[j]], inv = a.rg.gbn[3 * a.rg.F + ce[j]];
-                        const float c1 = a.rg.gtraining ? (float)(a.rg.gsb[2 * ce[j]] / Bn) : 0.0f;
-                        const float c2 = a.rg.gtraining ? (float)(a.rg.gsb[2 * ce[j] + 1] / Bn) : 0.0f;
-                        gal[j] = sc;
-                        gbe[j] = -sc * inv * c2;
-                        gga[j] = sc * (inv * c2 * mu - c1);
-                    }
-            }
-        }
         double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, dak = 0.0;
         for (int rb = blockIdx.x; rb < rows; rb += BWD_ROWS * nwg) {
             float4 yv[BWD_ROWS], upv[BWD_ROWS];
@@ -457,22 +430,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
                             v.y = ce1 >= 0 ? g[ce1] : 0.0f;
                             v.z = ce2 >= 0 ? g[ce2] : 0.0f;
                             v.w = ce3 >= 0 ? g[ce3] : 0.0f;
-                        }
-                        if (gfold) {
-                            const float* gm = a.rg.gmat + (size_t)mol * a.rg.F;
-                            float4 gv;
-                            if (ce4) {
-                                gv = *reinterpret_cast<const float4*>(gm + ce0);
-                            } else {
-                                gv.x = ce0 >= 0 ? gm[ce0] : 0.0f;
-                                gv.y = ce1 >= 0 ? gm[ce1] : 0.0f;
-                                gv.z = ce2 >= 0 ? gm[ce2] : 0.0f;
-                                gv.w = ce3 >= 0 ? gm[ce3] : 0.0f;
-                            }
-                            v.x = ce0 >= 0 ? gal[0] * v.x + gbe[0] * gv.x + gga[0] : 0.0f;
-                            v.y = ce1 >= 0 ? gal[1] * v.y + gbe[1] * gv.y + gga[1] : 0.0f;
-                            v.z = ce2 >= 0 ? gal[2] * v.z + gbe[2] * gv.z + gga[2] : 0.0f;
-                            v.w = ce3 >= 0 ? gal[3] * v.w + gbe[3] * gv.w + gga[3] : 0.0f;
                         }
                         if (a.rg.mode == 1) {
                             const float is = 1.0f / (float)a.rg.size[mol];
