@@ -36,14 +36,11 @@ __device__ __forceinline__ uint64_t head_seed(const HeadDrop& d) { return d.seed
 // The four waves split the k-steps; the partial tiles are summed through LDS and returned to wave 0.
 __device__ __forceinline__ void keep(f32x4& v) { asm volatile("" : "+v"(v)); }   // the load feeding v is not sunk / predicated
 
-// HEAD_NW waves per workgroup split the k-steps: eight when the launch has at most one tile per CU (round 3; always four before)
-// -- the products are chains of dependent load batches, and at Tox21 batch sizes most CUs had nothing else to run.
-// (a launch with more tiles than CUs keeps four: an eight-wave workgroup of this register footprint is alone on its CU)
-template <bool QUAD, int STEPS, int HEAD_NW, class FA, class FB>
+template <bool QUAD, int STEPS, class FA, class FB>
 __device__ __forceinline__ void head_tile(int K, const FA& fa, const FB& fb, f32x4* red, f32x4 (&acc)[4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4;
     const int nsteps = (K + 15) >> 4;
-    const int per = (((nsteps + HEAD_NW - 1) / HEAD_NW) + STEPS - 1) / STEPS * STEPS;      // k-steps per wave, a multiple of STEPS
+    const int per = (((nsteps + 3) >> 2) + STEPS - 1) / STEPS * STEPS;      // k-steps per wave, a multiple of STEPS
     const int sb = wave * per, se = min(nsteps, sb + per);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -79,16 +76,12 @@ __device__ __forceinline__ void head_tile(int K, const FA& fa, const FB& fb, f32
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) red[(j * HEAD_NW + wave) * 64 + lane] = acc[j];
+    for (int j = 0; j < 4; ++j) red[(j * 4 + wave) * 64 + lane] = acc[j];
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int w = 0; w < HEAD_NW; w += 2) t += red[(j * HEAD_NW + w) * 64 + lane] + red[(j * HEAD_NW + w + 1) * 64 + lane];
-            acc[j] = t;
-        }
+        for (int j = 0; j < 4; ++j)
+            acc[j] = (red[(j * 4) * 64 + lane] + red[(j * 4 + 1) * 64 + lane]) + (red[(j * 4 + 2) * 64 + lane] + red[(j * 4 + 3) * 64 + lane]);
     }
 }
 
@@ -136,12 +129,12 @@ struct HfB {                     // B side (QUAD): W[k][col0 .. col0+3]
     __device__ __forceinline__ f32x4 xf(Raw v, int k) const { return k < K ? zero_beyond(v, col0, N) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
 };
 
-template <bool VEC, bool DROP, int HEAD_NW>
-__global__ __launch_bounds__(64 * HEAD_NW) void head_fwd_kernel(HeadFwd a) {
+template <bool VEC, bool DROP>
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwd a) {
     extern __shared__ __attribute__((aligned(16))) float tab[];          // [2][Kp]: scale, shift
     const int Kp = (a.K + 3) & ~3;
     const double Bn = (a.cnt_in && a.training) ? *a.cnt_in : (double)a.B;      // rows of the BatchNorm (all ranks with sync-BatchNorm)
-    for (int k = threadIdx.x; k < a.K; k += 64 * HEAD_NW) {
+    for (int k = threadIdx.x; k < a.K; k += 256) {
         float mu, inv;
         if (a.training) {
             const double mean = a.st_in[2 * k] / Bn;
@@ -176,7 +169,7 @@ __global__ __launch_bounds__(64 * HEAD_NW) void head_fwd_kernel(HeadFwd a) {
                             DROP ? head_seed(a.drop) : 0, a.drop.thr, a.drop.inv_keep};
     const HfB<VEC> fb{a.W, a.K, a.N, col0};
     f32x4 acc[4];
-    head_tile<true, 4, HEAD_NW>(a.K, fa, fb, red, acc);
+    head_tile<true, 4>(a.K, fa, fb, red, acc);
     if (threadIdx.x >= 64) return;
     // D layout of tile j: column 4 li + j, rows 4q + r
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -280,12 +273,12 @@ struct HbB_b {                   // (b) B side (QUAD): dy_eff[b][n0 .. n0+3]
     __device__ __forceinline__ f32x4 xf(const Raw& r, int b) const { return g.tr(r, b, n0); }
 };
 
-template <bool VEC, bool DROP, int HEAD_NW>
-__global__ __launch_bounds__(64 * HEAD_NW) void head_bwd_kernel(HeadBwd a) {
+template <bool VEC, bool DROP>
+__global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwd a) {
     extern __shared__ __attribute__((aligned(16))) float tab[];          // [3][Np]: al, be, ga of dy_eff
     const int Np = (a.N + 3) & ~3;
     const double Bn = (a.cnt_y && a.training) ? *a.cnt_y : (double)a.B;
-    for (int n = threadIdx.x; n < a.N; n += 64 * HEAD_NW) {
+    for (int n = threadIdx.x; n < a.N; n += 256) {
         float al = 1.0f, be = 0.0f, ga = 0.0f;
         if (a.bny) {
             const float sc = a.bny[HT_SC * a.N + n], mu = a.bny[HT_MU * a.N + n], inv = a.bny[HT_INV * a.N + n];
@@ -313,7 +306,7 @@ __global__ __launch_bounds__(64 * HEAD_NW) void head_bwd_kernel(HeadBwd a) {
         const int rb = tile / nkb64, kb = tile - rb * nkb64;
         const HbA_a<VEC> fa{dyf, min(rb * 16 + li, a.B - 1)};
         const HbB_a<VEC> fb{a.W, a.K, a.N, kb * 64 + li};
-        head_tile<false, 2, HEAD_NW>(a.N, fa, fb, red, acc);
+        head_tile<false, 2>(a.N, fa, fb, red, acc);
         if (threadIdx.x >= 64) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -351,7 +344,7 @@ __global__ __launch_bounds__(64 * HEAD_NW) void head_bwd_kernel(HeadBwd a) {
         const HbA_b<DROP> fa{a.x, a.B, a.K, k, a.bnp[HT_SC * a.K + k], a.bnp[HT_SH * a.K + k], a.relu_p ? 0.0f : -INFINITY,
                              seed, a.drop.thr, a.drop.inv_keep};
         const HbB_b<VEC> fb{dyf, n0};
-        head_tile<true, 2, HEAD_NW>(a.B, fa, fb, red, acc);
+        head_tile<true, 2>(a.B, fa, fb, red, acc);
         if (threadIdx.x >= 64) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -417,50 +410,31 @@ int head_colstats(const float* g, int B, int F, double* st, hipStream_t s, doubl
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
-static int head_ncu() {
-    static const int n = [] {
-        int dev = 0, v = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            v = prop.multiProcessorCount;
-        (void)hipGetLastError();
-        return v;
-    }();
-    return n;
-}
-template <int NW>
-static void head_fwd_launch(const HeadFwd& a, int tiles, bool vec, hipStream_t s) {
-    const size_t lds = (size_t)2 * ((a.K + 3) & ~3) * sizeof(float) + (size_t)NW * 4096;
-    if (vec && a.drop.on) head_fwd_kernel<true, true, NW><<<tiles, 64 * NW, lds, s>>>(a);
-    else if (vec) head_fwd_kernel<true, false, NW><<<tiles, 64 * NW, lds, s>>>(a);
-    else if (a.drop.on) head_fwd_kernel<false, true, NW><<<tiles, 64 * NW, lds, s>>>(a);
-    else head_fwd_kernel<false, false, NW><<<tiles, 64 * NW, lds, s>>>(a);
-}
 int head_fwd(const HeadFwd& a, hipStream_t s) {
     const int tiles = cdiv(a.B, 16) * cdiv(a.N, 64);
-    EAGCN_CHECK_ARG((size_t)2 * ((a.K + 3) & ~3) * sizeof(float) + 8 * 4096 <= 64 * 1024, "head: %d input features exceed the table size", a.K);
+    const size_t lds = (size_t)2 * ((a.K + 3) & ~3) * sizeof(float) + 16384;
+    EAGCN_CHECK_ARG(lds <= 64 * 1024, "head: %d input features exceed the table size", a.K);
     ProfScope ps(PROF_HEAD, s, 2.0 * a.B * a.K * a.N);
     const bool vec = (a.K & 3) == 0 && (a.N & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.W)) & 15) == 0;
-    if (tiles <= head_ncu()) head_fwd_launch<8>(a, tiles, vec, s); else head_fwd_launch<4>(a, tiles, vec, s);
+    if (vec && a.drop.on) head_fwd_kernel<true, true><<<tiles, 256, lds, s>>>(a);
+    else if (vec) head_fwd_kernel<true, false><<<tiles, 256, lds, s>>>(a);
+    else if (a.drop.on) head_fwd_kernel<false, true><<<tiles, 256, lds, s>>>(a);
+    else head_fwd_kernel<false, false><<<tiles, 256, lds, s>>>(a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
-template <int NW>
-static void head_bwd_launch(const HeadBwd& a, int tiles, bool vec, hipStream_t s) {
-    const size_t lds = (size_t)3 * ((a.N + 3) & ~3) * sizeof(float) + (size_t)NW * 4096;
-    if (vec && a.drop.on) head_bwd_kernel<true, true, NW><<<tiles, 64 * NW, lds, s>>>(a);
-    else if (vec) head_bwd_kernel<true, false, NW><<<tiles, 64 * NW, lds, s>>>(a);
-    else if (a.drop.on) head_bwd_kernel<false, true, NW><<<tiles, 64 * NW, lds, s>>>(a);
-    else head_bwd_kernel<false, false, NW><<<tiles, 64 * NW, lds, s>>>(a);
-}
 int head_bwd(const HeadBwd& a, hipStream_t s) {
     const int tiles = cdiv(a.B, 16) * cdiv(a.K, 64) + cdiv(a.K, 16) * cdiv(a.N, 64);
-    EAGCN_CHECK_ARG((size_t)3 * ((a.N + 3) & ~3) * sizeof(float) + 8 * 4096 <= 64 * 1024, "head: %d output features exceed the table size", a.N);
+    const size_t lds = (size_t)3 * ((a.N + 3) & ~3) * sizeof(float) + 16384;
+    EAGCN_CHECK_ARG(lds <= 64 * 1024, "head: %d output features exceed the table size", a.N);
     ProfScope ps(PROF_HEAD, s, 4.0 * a.B * a.K * a.N);
     const uintptr_t al = reinterpret_cast<uintptr_t>(a.dy) | reinterpret_cast<uintptr_t>(a.W) | reinterpret_cast<uintptr_t>(a.y) |
                          reinterpret_cast<uintptr_t>(a.extra);
     const bool vec = (a.N & 3) == 0 && (al & 15) == 0;
-    if (tiles <= head_ncu()) head_bwd_launch<8>(a, tiles, vec, s); else head_bwd_launch<4>(a, tiles, vec, s);
+    if (vec && a.drop.on) head_bwd_kernel<true, true><<<tiles, 256, lds, s>>>(a);
+    else if (vec) head_bwd_kernel<true, false><<<tiles, 256, lds, s>>>(a);
+    else if (a.drop.on) head_bwd_kernel<false, true><<<tiles, 256, lds, s>>>(a);
+    else head_bwd_kernel<false, false><<<tiles, 256, lds, s>>>(a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

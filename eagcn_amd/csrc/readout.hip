@@ -127,60 +127,46 @@ __global__ __launch_bounds__(256) void readout_fwd_kernel(eagcn_batch bt, const 
 // representations (eagcn_model_atom_rep_materialize).
 // grid (ceil(B/4), ceil(F/64)): one WAVE per molecule, 64 lanes = 64 exact columns, four rows in flight.
 __global__ __launch_bounds__(256) void readout_bn_fwd_kernel(eagcn_batch bt, ColMapD m, ReadoutBn a) {
-    // One workgroup per FOUR consecutive molecules x 256 PACKED columns: the molecules' packed rows are contiguous, and the four
-    // waves take them round-robin (four rows in flight per wave) whatever molecule they belong to -- a 132-atom molecule next to
-    // three 16-atom ones costs every wave a quarter of the rows instead of one wave all 132.  A lane owns four adjacent packed
-    // columns (one 16-byte load per row: a wave reads 1 KB of a row at a time) and keeps one partial sum per molecule; padded
-    // columns of a view segment carry zeros and are dropped when the sums are written to the exact columns of g.
-    __shared__ float4 part[4][4][64];
+    // One workgroup per FOUR consecutive molecules: their packed rows are contiguous, and the four waves take them round-robin
+    // (eight rows in flight per wave) whatever molecule they belong to -- a 132-atom molecule next to three 16-atom ones costs
+    // every wave a quarter of the rows instead of one wave all 132.  Each wave keeps one partial sum per molecule.
+    __shared__ float part[4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b0 = blockIdx.x * 4;
-    const int cp = (blockIdx.y * 64 + lane) * 4;                // first of this lane's four packed columns
+    const int f = blockIdx.y * 64 + lane;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         if (a.cnt0) *a.cnt0 = (double)bt.B;
         if (a.cnt1) *a.cnt1 = (double)bt.B;
         if (a.cnt2) *a.cnt2 = (double)bt.B;
     }
     const int nb = min(4, bt.B - b0);
-    const bool okc = cp < a.fp;
-    float4 s[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool okf = f < a.F;
+    const int cp = okf ? exact_to_packed(m, f) : 0;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int rbeg = bt.row0[b0], rend = bt.row0[b0 + nb];
     int bnd[4];                                            // first row of the next molecule, per molecule of the group
 #pragma unroll
     for (int j = 0; j < 4; ++j) bnd[j] = bt.row0[min(b0 + j + 1, b0 + nb)];
-    if (okc) {
+    if (okf) {
         const uint64_t seed = a.do_drop ? (a.seed_dev ? *a.seed_dev : a.seed) : 0ull;
-        const float4 sc = *reinterpret_cast<const float4*>(a.bn + BN_SC * a.fp + cp);
-        const float4 sh = *reinterpret_cast<const float4*>(a.bn + BN_SH * a.fp + cp);
-        for (int r0 = rbeg + wave; r0 < rend; r0 += 16) {
-            float4 y[4];
-            float mk[4];
+        const float sc = a.bn[BN_SC * a.fp + cp], sh = a.bn[BN_SH * a.fp + cp];
+        for (int r0 = rbeg + wave; r0 < rend; r0 += 32) {
+            float y[8], mk[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int r = min(r0 + 4 * u, rend - 1);
-                y[u] = *reinterpret_cast<const float4*>(a.Y + (size_t)r * a.ldy + cp);
+                y[u] = a.Y[(size_t)r * a.ldy + cp];
                 mk[u] = bt.row_m[r];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int r = r0 + 4 * u;
                 if (r < rend) {
-                    float4 v;
-                    v.x = fmaxf(y[u].x * sc.x + sh.x, 0.0f) * mk[u];
-                    v.y = fmaxf(y[u].y * sc.y + sh.y, 0.0f) * mk[u];
-                    v.z = fmaxf(y[u].z * sc.z + sh.z, 0.0f) * mk[u];
-                    v.w = fmaxf(y[u].w * sc.w + sh.w, 0.0f) * mk[u];
-                    if (a.do_drop) {
-                        float ds[4];
-                        drop_scale4(seed, (uint64_t)r * a.fp + cp, a.thr, a.inv_keep, ds);
-                        v.x *= ds[0]; v.y *= ds[1]; v.z *= ds[2]; v.w *= ds[3];
-                    }
+                    float v = fmaxf(y[u] * sc + sh, 0.0f) * mk[u];
+                    if (a.do_drop) v *= drop_scale_el(seed, (uint64_t)r * a.fp + cp, a.thr, a.inv_keep);
                     const int mi = (r >= bnd[0] ? 1 : 0) + (r >= bnd[1] ? 1 : 0) + (r >= bnd[2] ? 1 : 0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (mi == j) { s[j].x += v.x; s[j].y += v.y; s[j].z += v.z; s[j].w += v.w; }
+                    for (int j = 0; j < 4; ++j) s[j] += mi == j ? v : 0.0f;
                 }
             }
         }
@@ -188,50 +174,27 @@ __global__ __launch_bounds__(256) void readout_bn_fwd_kernel(eagcn_batch bt, Col
 #pragma unroll
     for (int j = 0; j < 4; ++j) part[wave][j][lane] = s[j];
     __syncthreads();
-    if (wave == 0 && okc) {
+    if (wave == 0 && okf) {
         // (non-stored rows of a Concate layer are masked to zero: nothing to add for them)
-        double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-        int fe[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {                          // exact column of each of the four packed columns (-1: padding)
-            int eo = 0, po = 0, ce = -1;
-            for (int sg = 0; sg < m.nseg; ++sg) {
-                if (cp + e < po + m.p[sg]) { ce = (cp + e - po < m.w[sg]) ? eo + (cp + e - po) : -1; break; }
-                eo += m.w[sg];
-                po += m.p[sg];
-            }
-            fe[e] = ce;
-        }
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (j < nb) {
-                float4 t = part[0][j][lane];
-                const float4 t1 = part[1][j][lane], t2 = part[2][j][lane], t3 = part[3][j][lane];
-                t.x = (t.x + t1.x) + (t2.x + t3.x); t.y = (t.y + t1.y) + (t2.y + t3.y);
-                t.z = (t.z + t1.z) + (t2.z + t3.z); t.w = (t.w + t1.w) + (t2.w + t3.w);
-                const float inv = a.mode == 1 ? 1.0f / (float)a.size[b0 + j] : 1.0f;
-                const float v[4] = {t.x * inv, t.y * inv, t.z * inv, t.w * inv};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (fe[e] >= 0) {
-                        a.g[(size_t)(b0 + j) * a.F + fe[e]] = v[e];
-                        s1[e] += (double)v[e];
-                        s2[e] += (double)v[e] * (double)v[e];
-                    }
+                float v = (part[0][j][lane] + part[1][j][lane]) + (part[2][j][lane] + part[3][j][lane]);
+                if (a.mode == 1) v *= 1.0f / (float)a.size[b0 + j];
+                a.g[(size_t)(b0 + j) * a.F + f] = v;
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
             }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (fe[e] >= 0) {
-                atomicAdd(&a.st[2 * fe[e]], s1[e]);
-                atomicAdd(&a.st[2 * fe[e] + 1], s2[e]);
-            }
+        atomicAdd(&a.st[2 * f], s1);
+        atomicAdd(&a.st[2 * f + 1], s2);
     }
 }
 
 int readout_bn_forward(const eagcn_batch* b, const eagcn_layout* lay, const ReadoutBn& a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_READOUT, s);
-    readout_bn_fwd_kernel<<<dim3(cdiv(b->B, 4), cdiv(a.fp, 256)), 256, 0, s>>>(*b, make_colmap(lay), a);
+    readout_bn_fwd_kernel<<<dim3(cdiv(b->B, 4), cdiv(a.F, 64)), 256, 0, s>>>(*b, make_colmap(lay), a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
