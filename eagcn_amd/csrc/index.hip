@@ -755,7 +755,7 @@ extern "C" int eagcn_index_rows(const eagcn_batch* b, void* stream) {
     ProfScope ps(PROF_INDEX, s);
     index_rows_kernel<<<b->B, 256, 0, s>>>(*b);
     EAGCN_LAUNCH_CHECK();
-    if (!sagg_enabled() && !b->build_lists) return EAGCN_OK;   // bond lists: GAT layers (gat.hip) and the opt-in aggregation of sagg.hip
+    if (!b->build_lists) return EAGCN_OK;   // bond lists: GAT layers (gat.hip)
     const int W = (b->N + 31) / 32;
     if (b->N <= 512) index_csr_kernel<true><<<b->B, 256, (size_t)b->N * W * sizeof(uint32_t), s>>>(*b, W);
     else index_csr_kernel<false><<<b->B, 256, 0, s>>>(*b, W);

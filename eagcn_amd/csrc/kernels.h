@@ -39,33 +39,7 @@ int edge_grid_x(const eagcn_batch* b);
 int launch_edge_grad(const EdgeArgs& a, hipStream_t s);
 int launch_agg_edge(AggArgs a, const EdgeArgs& e, hipStream_t s);   // transposed aggregation + edge gradients, one grid
 
-// ---- bond-list aggregation (sagg.hip) -------------------------------------------------------------------------------
 enum { BN_SC = 0, BN_SH, BN_MU, BN_INV };     // rows of a layer's [4][Fp] BatchNorm coefficient table
-struct SAggFwd {
-    eagcn_batch bt;
-    ViewCols vc;
-    const float* P; float* Y; int ld;          // [T][ld] (ld = Fp)
-    const float* sig; const float* rsig;       // [K][256] sigmoid(att weight) by bond code, [K] sigmoid(self_r)
-    float* rscale;                             // [K][T] m_i / rowsum_i (written)
-    double* stats;                             // [grid.x * nsplit][Fp][2] partial (sum y, sum y^2), or null (eval mode)
-    int nsplit;
-};
-struct SAggBwd {
-    eagcn_batch bt;
-    ViewCols vc;
-    int fp;
-    const float* dH; const float* Y; const float* P;   // [T][fp]: d loss / d BN input before the affine, saved Y', saved P
-    const float* bn; const float* cc;          // [4][fp] coefficient table, [2][fp] mean(dH), mean(dH xhat) (bn_bwd_finalize)
-    float* dP;                                 // [T][fp]
-    const float* sig; const float* rsig; const float* rscale;
-    double* datt;                              // [grid.x * nsplit][K][EDGE_SLAB]
-    int nsplit;
-};
-bool sagg_enabled();
-int sagg_grid_x(const eagcn_batch* b);
-int sagg_nsplit(const eagcn_batch* b, int fmax);
-int launch_sagg_fwd(const SAggFwd& a, hipStream_t s);
-int launch_sagg_bwd(const SAggBwd& a, hipStream_t s);
 
 struct ColMapD {                 // exact <-> packed column map of a layout
     int nseg;

@@ -677,7 +677,7 @@ struct Carver {
 
 struct LayerDims {
     ViewCols vc;
-    int fp, ld_in, fin, ldo, gx, gxb, nsplit, snsplit, sslabs;
+    int fp, ld_in, fin, ldo, gx, gxb, nsplit;
     size_t wslab;
 };
 static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
@@ -688,12 +688,6 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     d.fin = layout_width(&p->in);
     d.ldo = p->structure == EAGCN_STRUCT_CONCATE ? d.fp : pad16(p->width[0]);
     d.gx = agg_grid_x(b);
-    {
-        int fmax = 16;
-        for (int k = 0; k < p->K; ++k) fmax = std::max(fmax, d.vc.off[k + 1] - d.vc.off[k]);
-        d.snsplit = sagg_nsplit(b, fmax);
-        d.sslabs = sagg_grid_x(b) * d.snsplit;           // partial slabs of the bond-list aggregation (sagg.hip)
-    }
     // row-partial slabs of the BatchNorm backward: 7 rows per workgroup, at most 2048 workgroups and at most
     // 32 MB of fp64 partials (wide layers: Fp = 6320 -> 331 workgroups).  Fewer, longer workgroups were measured
     // slower (the kernel is bound by its instruction stream and one memory round trip per 7-row batch, not by the
@@ -748,7 +742,7 @@ static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, Fw
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
     t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
-    t.stats = c.take<double>((size_t)std::max(d.gx, d.sslabs) * d.fp * 2);
+    t.stats = c.take<double>((size_t)d.gx * d.fp * 2);
     t.gsum = c.take<double>((size_t)2 * d.fp + 8);
     if (s) *s = t;
     return c.off;
@@ -769,7 +763,7 @@ static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, Bw
     t.dWcat = c.take<float>(d.wslab * std::max(d.nsplit, G3_XSEG));
     t.slab = c.take<double>((size_t)d.gxb * d.fp * 2);
     t.slab_da = c.take<double>((size_t)d.gxb * cdiv(d.fp, 1024) * EAGCN_MAX_VIEWS);
-    t.datt = c.take<double>((size_t)std::max(edge_grid_x(b), d.sslabs) * EAGCN_MAX_VIEWS * EDGE_SLAB);
+    t.datt = c.take<double>((size_t)edge_grid_x(b) * EAGCN_MAX_VIEWS * EDGE_SLAB);
     t.gsum = c.take<double>((size_t)2 * d.fp + 8);
     if (s) *s = t;
     return c.off;
@@ -929,15 +923,7 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
             rc = launch_gemm(g, s);
         }
         if (rc) return rc;
-        if (sagg_enabled()) {
-            SAggFwd a;
-            a.bt = *b; a.vc = d.vc; a.P = w->P; a.Y = w->Y; a.ld = d.fp; a.sig = sc.sig; a.rsig = sc.rsig;
-            a.rscale = w->rscale; a.stats = p->training ? sc.stats : nullptr; a.nsplit = d.snsplit;
-            rc = launch_sagg_fwd(a, s);
-            if (rc) return rc;
-            nslab = sagg_grid_x(b);
-            tiles_per_wg = 0;
-        } else {
+        {
             AggArgs a;
             a.bt = *b; a.vc = d.vc; a.src = w->P; a.lds = d.fp; a.dst = w->Y; a.ldd = d.fp;
             a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = sc.stats; a.nchunk = 1;
@@ -1104,7 +1090,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             bn_bwd_finalize_kernel<16><<<cdiv(d.fp, 16), 256, 0, s>>>(sc.slab, sc.slab_da, gxb, d.fp, M, p->training, w->bn,
                                                                         d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb, gsum, ba.zero, ba.nzero);
         EAGCN_LAUNCH_CHECK();
-        if (b->T > 0 && !sagg_enabled()) {        // (the bond-list aggregation applies this affine while it stages dH)
+        if (b->T > 0) {
             bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
             EAGCN_LAUNCH_CHECK();
         }
@@ -1124,18 +1110,10 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         static const bool edge_atomic = [] { const char* v = getenv("EAGCN_EDGE_SLABS"); return !(v && v[0] == '1'); }();
         bool general_rel = false;                     // (code books: the reduction reads a view's whole histogram per channel)
         for (int k = 0; k < p->K; ++k) general_rel = general_rel || pp.rel_vec[k] != nullptr;
-        if (edge_atomic && !sagg_enabled() && !general_rel) { e.datt = sc.eacc; e.atomic = 1; }
+        if (edge_atomic && !general_rel) { e.datt = sc.eacc; e.atomic = 1; }
         static const bool colaunch = [] { const char* v = getenv("EAGCN_NO_COLAUNCH"); return !(v && v[0] == '1'); }();
         nedge = e.atomic ? -EDGE_COPIES : edge_grid_x(b);
-        if (sagg_enabled()) {
-            // transposed aggregation + edge gradients + BatchNorm-backward affine in one kernel over the bond lists
-            SAggBwd sa;
-            sa.bt = *b; sa.vc = d.vc; sa.fp = d.fp; sa.dH = sc.dY; sa.Y = w->Y; sa.P = w->P; sa.bn = w->bn; sa.cc = sc.cc;
-            sa.dP = sc.dP; sa.sig = sc.sig; sa.rsig = sc.rsig; sa.rscale = w->rscale; sa.datt = sc.datt; sa.nsplit = d.snsplit;
-            rc = launch_sagg_bwd(sa, s);
-            if (rc) return rc;
-            nedge = -d.sslabs;
-        } else if (!forked && colaunch) {
+        if (!forked && colaunch) {
             rc = launch_agg_edge(a, e, s);                                       // one grid for both
             if (rc) return rc;
         } else {
@@ -1186,7 +1164,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     }
     {
         const int wblocks = nsplit > 0 ? cdiv((int)d.wslab, 256) : 0;
-        double* edge_src = nedge == -EDGE_COPIES && !sagg_enabled() ? sc.eacc : sc.datt;
+        double* edge_src = nedge == -EDGE_COPIES ? sc.eacc : sc.datt;
         const int edge_drain = edge_src == sc.eacc ? 1 : 0;       // shared accumulators: zeroed again by the threads that read them
         static const bool defer_env = [] { const char* v = getenv("EAGCN_NO_EDGE_DEFER"); return !(v && v[0] == '1'); }();
         if (defer_env && drain_out && edge_drain && wblocks == 0 && !forked && b->T > 0) {

@@ -48,7 +48,7 @@ class StaticIndex:
         self.code = torch.empty((K, B, N, self.ldc), dtype=torch.uint8, device=device)
         blob = torch.zeros(B * N + 3 * B + 2 + L.META_WORDS + 2 * B + 2, **i32)
         rows = torch.zeros(8 * self.T + 5 * self.n_tiles, **i32)
-        # bond lists (csrc/sagg.hip): capacity in directed bonds; a molecular graph has 2-2.5 per atom
+        # bond lists (GAT layers, csrc/gat.hip): capacity in directed bonds; a molecular graph has 2-2.5 per atom
         self.E = int(edge_cap) if edge_cap else min(self.T * N, max(8 * self.T, 1024))
         self._ptrs = torch.zeros(4 * self.T + 4 * B, **i32)
         self._edges = torch.zeros(6 * self.E + 2, **i32)       # nbr | tnbr | ecode (u64) | tcode (u64)

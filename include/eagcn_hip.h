@@ -109,9 +109,8 @@ typedef struct eagcn_batch {
        most 255 per view).  NULL (the default): code c+1 means the one-hot vector e_c, i.e. sigma(w[c]).                 */
     const float* rel_vec[EAGCN_MAX_VIEWS];
     int32_t rel_c[EAGCN_MAX_VIEWS];         /* channels of view k's attention weight when rel_vec[k] is set           */
-    /* Bond lists (built by eagcn_index_rows from the code maps): the attention matrix of layers.py:82-90 is
-       sigma(w[type]) at the bonds, sigma(self_r) on the diagonal and 1e-9 everywhere else, so the aggregation
-       kernels walk these lists instead of a dense N x N operand (csrc/sagg.hip).                           */
+    /* Bond lists (built by eagcn_index_rows from the code maps when build_lists is set): the GAT baseline layers
+       (csrc/gat.hip, layers.py:99-203) walk them -- scores per atom, softmax over the deg+1 entries of a row.       */
     int32_t E;                              /* CAPACITY of the four edge arrays (directed bonds)             */
     int32_t n_logical;                      /* HOST input of the index entry points: padded size N_in <= N of the caller's
                                                tensors for this batch (their row stride), 0 = N; mirrored to meta[NLOG] */
