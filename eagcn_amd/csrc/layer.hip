@@ -695,8 +695,7 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     {
         const long by_rows = cdiv(b->T + 1, BWD_ROWS);
         const long by_bytes = std::max<long>(64, (32L << 20) / ((long)d.fp * 16));
-        static const long cap = [] { const char* v = getenv("EAGCN_BWD_GXB"); const long x = v ? atol(v) : 2048; return x < 64 ? 64L : x; }();
-        d.gxb = (int)std::max<long>(1, std::min<long>(std::min<long>(by_rows, cap), by_bytes));
+        d.gxb = (int)std::max<long>(1, std::min<long>(std::min<long>(by_rows, 2048), by_bytes));
     }
     const int tiles = cdiv(d.ld_in, 64) * cdiv(d.fp, 64);
     d.nsplit = std::max(1, std::min(std::max(1, 1024 / tiles), cdiv(std::max(b->T, 1), 128)));

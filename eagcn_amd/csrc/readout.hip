@@ -125,111 +125,76 @@ __global__ __launch_bounds__(256) void readout_fwd_kernel(eagcn_batch bt, const 
 // by the same launch -- three launches (bn_apply of the top layer, readout_fwd, head_colstats) and the write + re-read of the
 // top layer's [T, F] output become one.  The output matrix itself is only built when somebody asks for the atom
 // representations (eagcn_model_atom_rep_materialize).
-// MPW molecules per workgroup (their packed rows are contiguous); the four waves take the rows round-robin (eight in flight per
-// wave) whatever molecule they belong to -- a 132-atom molecule next to small ones costs every wave a quarter of the rows
-// instead of one wave all 132.  A lane owns TWO adjacent packed columns: one 8-byte load per row and ONE dropout hash per row (the
-// stream draws two elements per 64-bit hash); padded columns of a view segment carry zeros and are dropped when the sums are
-// written to the exact columns of g.
-template <int MPW>
+// grid (ceil(B/4), ceil(F/64)): one WAVE per molecule, 64 lanes = 64 exact columns, four rows in flight.
 __global__ __launch_bounds__(256) void readout_bn_fwd_kernel(eagcn_batch bt, ColMapD m, ReadoutBn a) {
-    __shared__ float2 part[4][MPW][64];
+    // One workgroup per FOUR consecutive molecules: their packed rows are contiguous, and the four waves take them round-robin
+    // (eight rows in flight per wave) whatever molecule they belong to -- a 132-atom molecule next to three 16-atom ones costs
+    // every wave a quarter of the rows instead of one wave all 132.  Each wave keeps one partial sum per molecule.
+    __shared__ float part[4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b0 = blockIdx.x * MPW;
-    const int cp = (blockIdx.y * 64 + lane) * 2;                // first of this lane's two packed columns
+    const int b0 = blockIdx.x * 4;
+    const int f = blockIdx.y * 64 + lane;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         if (a.cnt0) *a.cnt0 = (double)bt.B;
         if (a.cnt1) *a.cnt1 = (double)bt.B;
         if (a.cnt2) *a.cnt2 = (double)bt.B;
     }
-    const int nb = min(MPW, bt.B - b0);
-    const bool okc = cp < a.fp;
-    float2 s[MPW];
-#pragma unroll
-    for (int j = 0; j < MPW; ++j) s[j] = make_float2(0.f, 0.f);
+    const int nb = min(4, bt.B - b0);
+    const bool okf = f < a.F;
+    const int cp = okf ? exact_to_packed(m, f) : 0;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int rbeg = bt.row0[b0], rend = bt.row0[b0 + nb];
-    int bnd[MPW];                                          // first row of the next molecule, per molecule of the group
+    int bnd[4];                                            // first row of the next molecule, per molecule of the group
 #pragma unroll
-    for (int j = 0; j < MPW; ++j) bnd[j] = bt.row0[min(b0 + j + 1, b0 + nb)];
-    if (okc) {
+    for (int j = 0; j < 4; ++j) bnd[j] = bt.row0[min(b0 + j + 1, b0 + nb)];
+    if (okf) {
         const uint64_t seed = a.do_drop ? (a.seed_dev ? *a.seed_dev : a.seed) : 0ull;
-        const float2 sc = *reinterpret_cast<const float2*>(a.bn + BN_SC * a.fp + cp);
-        const float2 sh = *reinterpret_cast<const float2*>(a.bn + BN_SH * a.fp + cp);
+        const float sc = a.bn[BN_SC * a.fp + cp], sh = a.bn[BN_SH * a.fp + cp];
         for (int r0 = rbeg + wave; r0 < rend; r0 += 32) {
-            float2 y[8];
-            float mk[8];
+            float y[8], mk[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int r = min(r0 + 4 * u, rend - 1);
-                y[u] = *reinterpret_cast<const float2*>(a.Y + (size_t)r * a.ldy + cp);
+                y[u] = a.Y[(size_t)r * a.ldy + cp];
                 mk[u] = bt.row_m[r];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int r = r0 + 4 * u;
                 if (r < rend) {
-                    float vx = fmaxf(y[u].x * sc.x + sh.x, 0.0f) * mk[u];
-                    float vy = fmaxf(y[u].y * sc.y + sh.y, 0.0f) * mk[u];
-                    if (a.do_drop) {                                   // (element index r * fp + cp is even: low / high half)
-                        const uint64_t z = rng_u64(seed, ((uint64_t)r * a.fp + cp) >> 1);
-                        vx *= (uint32_t)z >= a.thr ? a.inv_keep : 0.0f;
-                        vy *= (uint32_t)(z >> 32) >= a.thr ? a.inv_keep : 0.0f;
-                    }
-                    int mi = 0;
+                    float v = fmaxf(y[u] * sc + sh, 0.0f) * mk[u];
+                    if (a.do_drop) v *= drop_scale_el(seed, (uint64_t)r * a.fp + cp, a.thr, a.inv_keep);
+                    const int mi = (r >= bnd[0] ? 1 : 0) + (r >= bnd[1] ? 1 : 0) + (r >= bnd[2] ? 1 : 0);
 #pragma unroll
-                    for (int j = 0; j + 1 < MPW; ++j) mi += r >= bnd[j] ? 1 : 0;
-#pragma unroll
-                    for (int j = 0; j < MPW; ++j)
-                        if (mi == j) { s[j].x += vx; s[j].y += vy; }
+                    for (int j = 0; j < 4; ++j) s[j] += mi == j ? v : 0.0f;
                 }
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < MPW; ++j) part[wave][j][lane] = s[j];
+    for (int j = 0; j < 4; ++j) part[wave][j][lane] = s[j];
     __syncthreads();
-    if (wave == 0 && okc) {
+    if (wave == 0 && okf) {
         // (non-stored rows of a Concate layer are masked to zero: nothing to add for them)
-        double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
-        int fe[2];
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {                          // exact column of each packed column (-1: padding)
-            int eo = 0, po = 0, ce = -1;
-            for (int sg = 0; sg < m.nseg; ++sg) {
-                if (cp + e < po + m.p[sg]) { ce = (cp + e - po < m.w[sg]) ? eo + (cp + e - po) : -1; break; }
-                eo += m.w[sg];
-                po += m.p[sg];
-            }
-            fe[e] = ce;
-        }
-#pragma unroll
-        for (int j = 0; j < MPW; ++j)
+        for (int j = 0; j < 4; ++j)
             if (j < nb) {
-                const float2 t0 = part[0][j][lane], t1 = part[1][j][lane], t2 = part[2][j][lane], t3 = part[3][j][lane];
-                const float inv = a.mode == 1 ? 1.0f / (float)a.size[b0 + j] : 1.0f;
-                const float v[2] = {((t0.x + t1.x) + (t2.x + t3.x)) * inv, ((t0.y + t1.y) + (t2.y + t3.y)) * inv};
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    if (fe[e] >= 0) {
-                        a.g[(size_t)(b0 + j) * a.F + fe[e]] = v[e];
-                        s1[e] += (double)v[e];
-                        s2[e] += (double)v[e] * (double)v[e];
-                    }
+                float v = (part[0][j][lane] + part[1][j][lane]) + (part[2][j][lane] + part[3][j][lane]);
+                if (a.mode == 1) v *= 1.0f / (float)a.size[b0 + j];
+                a.g[(size_t)(b0 + j) * a.F + f] = v;
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
             }
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            if (fe[e] >= 0) {
-                atomicAdd(&a.st[2 * fe[e]], s1[e]);
-                atomicAdd(&a.st[2 * fe[e] + 1], s2[e]);
-            }
+        atomicAdd(&a.st[2 * f], s1);
+        atomicAdd(&a.st[2 * f + 1], s2);
     }
 }
 
 int readout_bn_forward(const eagcn_batch* b, const eagcn_layout* lay, const ReadoutBn& a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_READOUT, s);
-    // two molecules per workgroup at Tox21 batch sizes (more, lighter workgroups: the launch is a latency chain there), four beyond
-    if (b->B <= 512) readout_bn_fwd_kernel<2><<<dim3(cdiv(b->B, 2), cdiv(a.fp, 128)), 256, 0, s>>>(*b, make_colmap(lay), a);
-    else readout_bn_fwd_kernel<4><<<dim3(cdiv(b->B, 4), cdiv(a.fp, 128)), 256, 0, s>>>(*b, make_colmap(lay), a);
+    readout_bn_fwd_kernel<<<dim3(cdiv(b->B, 4), cdiv(a.F, 64)), 256, 0, s>>>(*b, make_colmap(lay), a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
