@@ -104,8 +104,8 @@ static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model*
     // three segments [2 w sums | row count | pad], one per BatchNorm of the head (the count rides with the sums through the
     // sync-BatchNorm hook)
     s.n_hst = 2 * (h->f_in + h->n_den1 + h->n_den2) + 6;
-    s.hst = c.take<double>((size_t)2 * s.n_hst);
-    s.hsb = s.hst + s.n_hst;
+    s.hst = c.take<double>((size_t)(HEAD_COPIES + 1) * s.n_hst);     // HEAD_COPIES replicas of the forward sums (kernels.h)
+    s.hsb = s.hst + (size_t)HEAD_COPIES * s.n_hst;
     s.da2 = c.take<float>(B * h->n_den2);
     s.da1 = c.take<float>(B * h->n_den1);
     s.dgn = c.take<float>(B * h->f_in);
@@ -228,7 +228,7 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_forward: scratch too small");
     const eagcn_head_params* h = &m->head;
     ZeroJob zj;                                   // hand-off flags + the head's sums: cleared by the packing launch below
-    RC(gemm3_zero_job(sc.layer, sc.layer_bytes, sc.hst, 2 * sc.n_hst, &zj));
+    RC(gemm3_zero_job(sc.layer, sc.layer_bytes, sc.hst, (HEAD_COPIES + 1) * sc.n_hst, &zj));
     if (!m->input_packed)
         RC(eagcn_pack_rows(b, afm, layout_width(&m->layer[0].in), &m->layer[0].in, sv.x0, stream));
     const float* x = sv.x0;
@@ -254,6 +254,8 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     const eagcn_layout lay = out_layout(last);
     const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
     double *st_g = sc.hst, *st_1 = sc.hst + 2 * F + 2, *st_2 = sc.hst + 2 * (F + n1) + 4;
+    // replicas of the forward sums (one with sync-BatchNorm: the hook all-reduces the first block in place)
+    const int copies = (m->stats_hook && m->training) ? 1 : HEAD_COPIES;
     if (fused_readout(m)) {
         // relu / dropout / mask of the top layer applied while the atoms are summed; Graph_BN's column sums in the same launch
         ReadoutBn rb;
@@ -262,6 +264,7 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
         rb.seed = last->seed; rb.seed_dev = last->seed_dev;
         rb.size = size; rb.mode = m->molfp_mode; rb.g = sv.g; rb.F = F; rb.st = st_g;
         rb.cnt0 = st_g + 2 * F; rb.cnt1 = st_1 + 2 * n1; rb.cnt2 = st_2 + 2 * n2;
+        rb.st_copies = copies; rb.st_stride = sc.n_hst;
         RC(readout_bn_forward(b, &lay, rb, stream));
     } else if (pad_sampled(m))
         RC(readout_forward_sampled(b, LL.xout, &lay, last, LL.bn + (size_t)LL.fp /* shift row of the BatchNorm table */, size,
@@ -291,16 +294,19 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     HeadFwd f1{B, F, n1, sv.g, st_g, h->gbn_w, h->gbn_b, h->gbn_rm, h->gbn_rv, sv.bn_g, h->den1_w, sv.h1, nullptr, st_1,
                m->training, 0, h->bn_eps, h->bn_momentum, nodrop};
     if (sync) f1.cnt_in = st_g + 2 * F;
+    f1.st_copies = copies; f1.st_stride = sc.n_hst;
     RC(head_fwd(f1, s));
     RC(hook(st_1, 2 * n1 + 1));
     HeadFwd f2{B, n1, n2, sv.h1, st_1, h->bn1_w, h->bn1_b, h->bn1_rm, h->bn1_rv, sv.bn_1, h->den2_w, sv.h2, graph_rep, st_2,
                m->training, 1, h->bn_eps, h->bn_momentum, drop1};
     if (sync) f2.cnt_in = st_1 + 2 * n1;
+    f2.st_copies = copies; f2.st_stride = sc.n_hst;
     RC(head_fwd(f2, s));
     RC(hook(st_2, 2 * n2 + 1));
     HeadFwd f3{B, n2, nc, sv.h2, st_2, h->bn2_w, h->bn2_b, h->bn2_rm, h->bn2_rv, sv.bn_2, h->den3_w, out, nullptr, nullptr,
                m->training, 1, h->bn_eps, h->bn_momentum, nodrop};
     if (sync) f3.cnt_in = st_2 + 2 * n2;
+    f3.st_copies = copies; f3.st_stride = sc.n_hst;
     RC(head_fwd(f3, s));
     return EAGCN_OK;
 }

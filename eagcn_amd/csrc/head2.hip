@@ -137,8 +137,21 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwd a) {
     for (int k = threadIdx.x; k < a.K; k += 256) {
         float mu, inv;
         if (a.training) {
-            const double mean = a.st_in[2 * k] / Bn;
-            double var = a.st_in[2 * k + 1] / Bn - mean * mean;
+            double v1[HEAD_COPIES], v2[HEAD_COPIES];                  // all replicas' loads in flight together
+#pragma unroll
+            for (int c = 0; c < HEAD_COPIES; ++c) {
+                const size_t o = (size_t)(c < a.st_copies ? c : 0) * a.st_stride + 2 * k;
+                v1[c] = a.st_in[o];
+                v2[c] = a.st_in[o + 1];
+            }
+            double t1 = v1[0], t2 = v2[0];
+#pragma unroll
+            for (int c = 1; c < HEAD_COPIES; ++c) {
+                t1 += c < a.st_copies ? v1[c] : 0.0;
+                t2 += c < a.st_copies ? v2[c] : 0.0;
+            }
+            const double mean = t1 / Bn;
+            double var = t2 / Bn - mean * mean;
             var = var > 0.0 ? var : 0.0;
             mu = (float)mean;
             inv = (float)(1.0 / sqrt(var + (double)a.eps));
@@ -189,14 +202,15 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwd a) {
         }
     }
     if (a.st_out) {
+        double* so = a.st_out + (size_t)(rb % a.st_copies) * a.st_stride;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             double t1 = s1[j], t2 = s2[j];
             t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
             t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
             if (q == 0 && col0 + j < a.N) {
-                atomicAdd(&a.st_out[2 * (col0 + j)], t1);
-                atomicAdd(&a.st_out[2 * (col0 + j) + 1], t2);
+                atomicAdd(&so[2 * (col0 + j)], t1);
+                atomicAdd(&so[2 * (col0 + j) + 1], t2);
             }
         }
     }
@@ -411,6 +425,7 @@ int head_colstats(const float* g, int B, int F, double* st, hipStream_t s, doubl
     return EAGCN_OK;
 }
 int head_fwd(const HeadFwd& a, hipStream_t s) {
+    EAGCN_CHECK_ARG(a.st_copies >= 1 && a.st_copies <= HEAD_COPIES, "head: %d replicas of the BatchNorm sums", a.st_copies);
     const int tiles = cdiv(a.B, 16) * cdiv(a.N, 64);
     const size_t lds = (size_t)2 * ((a.K + 3) & ~3) * sizeof(float) + 16384;
     EAGCN_CHECK_ARG(lds <= 64 * 1024, "head: %d input features exceed the table size", a.K);

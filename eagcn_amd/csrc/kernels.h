@@ -140,6 +140,7 @@ int launch_gemm3_pair(const GemmDesc& dx, const GemmDesc& dw, const DwScatter* s
                       size_t xk_slab = 0);
 
 // ---- model head (head2.hip) -----------------------------------------------------------------------------------------------
+constexpr int HEAD_COPIES = 8;  // replicas of the head's forward BatchNorm sums (one with sync-BatchNorm: the hook reduces ONE block)
 struct HeadDrop { int on; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev; };
 struct HeadFwd {                 // y = act(bn(x)) . W  (+ column sums of y)
     int B, K, N;
@@ -147,6 +148,10 @@ struct HeadFwd {                 // y = act(bn(x)) . W  (+ column sums of y)
     const float* W; float* y; float* y2; double* st_out;
     int training, relu; float eps, momentum; HeadDrop drop;
     const double* cnt_in = nullptr;      // sync-BatchNorm: rows of the BatchNorm over ALL ranks (st_in holds their summed sums)
+    // the sums live in st_copies replicas, st_stride doubles apart: a producer workgroup adds to replica (row tile % copies),
+    // the consumer adds the replicas up (fp64 atomics on one 128-byte line are served one after the other, ~11 ns each: 1024
+    // arrivals per line at B = 1024 kept den1 / den2 waiting 11 us each)
+    int st_copies = 1, st_stride = 0;
 };
 struct HeadBwd {                 // backward of  y = act(bn_p(x)) . W : d(bn_p output) with its sums, and dW
     int B, K, N;
@@ -192,6 +197,7 @@ struct ReadoutBn {
     const int64_t* size; int mode;
     float* g; int F;                         // [B][F]
     double* st;                              // [2 F] sum g, sum g^2 (fp64 atomics; zero on entry)
+    int st_copies = 1, st_stride = 0;        // replicas of st (HeadFwd): workgroup x adds to replica x % st_copies
     double *cnt0, *cnt1, *cnt2;              // optional row-count slots of the head's BatchNorms (sync-BatchNorm)
 };
 int readout_bn_forward(const eagcn_batch* b, const eagcn_layout* lay, const ReadoutBn& a, void* stream);

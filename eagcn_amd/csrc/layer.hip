@@ -267,11 +267,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
         }
     }
     const int T = dev_rows(a.bt);
+    // (element index -> (row, column group) with a 32-bit division: T * columns / 4 of any batch that fits the index fits 31 bits)
     if (a.structure == EAGCN_STRUCT_CONCATE) {
-        const int g4 = fp / 4;
-        const size_t total = (size_t)T * g4;
-        for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-            const int r = (int)(e / g4), c = (int)(e % g4) * 4;
+        const uint32_t g4 = fp / 4;
+        const uint32_t total = (uint32_t)T * g4;
+        for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+            const int r = (int)(e / g4), c = (int)(e - (uint32_t)r * g4) * 4;
             const float4 y = *reinterpret_cast<const float4*>(a.Y + (size_t)r * a.ldy + c);
             const float4 sc = *reinterpret_cast<const float4*>(a.bn + BN_SC * fp + c);
             const float4 sh = *reinterpret_cast<const float4*>(a.bn + BN_SH * fp + c);
@@ -289,17 +290,37 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
             *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + c) = o;
         }
     } else {
-        const size_t total = (size_t)T * a.ldo;
-        for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-            const int r = (int)(e / a.ldo), f = (int)(e % a.ldo);
-            float acc = 0.0f;
-            for (int k = 0; k < a.vc.K; ++k) {
-                const int cp = a.vc.off[k] + f;
-                float p = fmaxf(a.Y[(size_t)r * a.ldy + cp] * a.bn[BN_SC * fp + cp] + a.bn[BN_SH * fp + cp], 0.0f);
-                if (a.do_drop) p *= drop_scale_el(seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep);
-                acc += a.colp[CP_AVEW * fp + cp] * p;
-            }
-            a.out[e] = acc;
+        // weighted sum over the views: a thread owns four adjacent output columns, the K view loads of a row are independent
+        // 16-byte loads (view column ranges and the output pitch are multiples of 16)
+        const uint32_t g4 = a.ldo / 4;
+        const uint32_t total = (uint32_t)T * g4;
+        for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+            const int r = (int)(e / g4), f = (int)(e - (uint32_t)r * g4) * 4;
+            float4 y[EAGCN_MAX_VIEWS];
+#pragma unroll
+            for (int k = 0; k < EAGCN_MAX_VIEWS; ++k)
+                if (k < a.vc.K) y[k] = *reinterpret_cast<const float4*>(a.Y + (size_t)r * a.ldy + a.vc.off[k] + f);
+            float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < EAGCN_MAX_VIEWS; ++k)
+                if (k < a.vc.K) {
+                    const int cp = a.vc.off[k] + f;
+                    const float4 sc = *reinterpret_cast<const float4*>(a.bn + BN_SC * fp + cp);
+                    const float4 sh = *reinterpret_cast<const float4*>(a.bn + BN_SH * fp + cp);
+                    const float4 w = *reinterpret_cast<const float4*>(a.colp + CP_AVEW * fp + cp);
+                    float4 p;
+                    p.x = fmaxf(y[k].x * sc.x + sh.x, 0.0f);
+                    p.y = fmaxf(y[k].y * sc.y + sh.y, 0.0f);
+                    p.z = fmaxf(y[k].z * sc.z + sh.z, 0.0f);
+                    p.w = fmaxf(y[k].w * sc.w + sh.w, 0.0f);
+                    if (a.do_drop) {
+                        float ds[4];
+                        drop_scale4(seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep, ds);
+                        p.x *= ds[0]; p.y *= ds[1]; p.z *= ds[2]; p.w *= ds[3];
+                    }
+                    acc.x += w.x * p.x; acc.y += w.y * p.y; acc.z += w.z * p.z; acc.w += w.w * p.w;
+                }
+            *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + f) = acc;
         }
     }
 }
@@ -539,10 +560,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(eagcn_batch bt, int fp, const float* __restrict__ Y, int ldy,
                                                             const float* __restrict__ bn,
                                                             const float* __restrict__ cc, float* __restrict__ dH) {
-    const int g4 = fp / 4;
-    const size_t total = (size_t)dev_rows(bt) * g4;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(e / g4), c = (int)(e % g4) * 4;
+    const uint32_t g4 = fp / 4;
+    const uint32_t total = (uint32_t)dev_rows(bt) * g4;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int r = (int)(e / g4), c = (int)(e - (uint32_t)r * g4) * 4;
         const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)r * ldy + c);
         float4 d = *reinterpret_cast<float4*>(dH + (size_t)r * fp + c);
         const float4 sc = *reinterpret_cast<const float4*>(bn + BN_SC * fp + c);
@@ -789,6 +810,10 @@ static int check_layer(const eagcn_batch* b, const eagcn_layer_params* p, const 
     }
     if (p->structure == EAGCN_STRUCT_WEIGHTED) EAGCN_CHECK_ARG(p->ave_w, "%s: Weighted_sum needs ave_w", who);
     EAGCN_CHECK_ARG(p->dropout >= 0.0f && p->dropout < 1.0f, "%s: dropout %f out of [0,1)", who, p->dropout);
+    // the elementwise BatchNorm passes index (row, 4-column group) pairs with 32 bits
+    EAGCN_CHECK_ARG((uint64_t)std::max(b->T, 0) * (uint64_t)view_cols(p).off[p->K] / 4 < (1ull << 32),
+                    "%s: %d rows x %d packed columns exceed the 32-bit element index of the BatchNorm passes", who, b->T,
+                    view_cols(p).off[p->K]);
     return EAGCN_OK;
 }
 

@@ -64,25 +64,48 @@ __global__ __launch_bounds__(256) void readout_pad_sample_kernel(eagcn_batch bt,
     a.padc[(size_t)b * a.ld + c] = acc;
 }
 // d(value of the non-stored rows of view k, column c) = sum_b cnt[b][k][c] / (1-p) * dg[b][c] / size[b]
-__global__ __launch_bounds__(256) void readout_bwd_pad_views_kernel(eagcn_batch bt, const float* __restrict__ dg, ColMapD m,
-                                                                     int ld, const int64_t* __restrict__ size, int mode, int F,
-                                                                     int K, const uint16_t* __restrict__ cnt, float inv_keep,
-                                                                     float* __restrict__ dpad) {
-    const int cp = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (cp >= ld) return;
+// grid (ceil(ld / 64), K), 1024 threads: lane = packed column, the sixteen waves split the molecules -- eight molecules'
+// loads in flight per wave, every wave's share and the sixteen partial sums added in a fixed order (a single thread per column
+// walking all B molecules was a 1024-deep chain of dependent loads on 25 workgroups: 299 us at B = 1024, ld = 1250)
+__global__ __launch_bounds__(1024) void readout_bwd_pad_views_kernel(eagcn_batch bt, const float* __restrict__ dg, ColMapD m,
+                                                                      int ld, const int64_t* __restrict__ size, int mode, int F,
+                                                                      int K, const uint16_t* __restrict__ cnt, float inv_keep,
+                                                                      float* __restrict__ dpad) {
+    __shared__ double part[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cp = blockIdx.x * 64 + lane, k = blockIdx.y;
     int eo = 0, po = 0, ce = -1;
-    for (int s = 0; s < m.nseg; ++s) {
-        if (cp < po + m.p[s]) { ce = (cp - po < m.w[s]) ? eo + (cp - po) : -1; break; }
-        eo += m.w[s];
-        po += m.p[s];
-    }
-    double acc = 0.0;
-    if (ce >= 0)
-        for (int b = 0; b < bt.B; ++b) {
-            const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
-            acc += (double)((float)cnt[((size_t)b * K + k) * ld + cp] * inv_keep * dg[(size_t)b * F + ce] * inv);
+    if (cp < ld)
+        for (int s = 0; s < m.nseg; ++s) {
+            if (cp < po + m.p[s]) { ce = (cp - po < m.w[s]) ? eo + (cp - po) : -1; break; }
+            eo += m.w[s];
+            po += m.p[s];
         }
-    dpad[(size_t)k * ld + cp] = (float)acc;
+    double acc = 0.0;
+    if (ce >= 0) {
+        const int per = (bt.B + 15) >> 4;
+        const int b0 = wave * per, b1 = min(bt.B, b0 + per);
+        for (int b = b0; b < b1; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int bb = min(b + u, b1 - 1);
+                const float inv = mode == 1 ? 1.0f / (float)size[bb] : 1.0f;
+                const float t = (float)cnt[((size_t)bb * K + k) * ld + cp] * inv_keep * dg[(size_t)bb * F + ce] * inv;
+                v[u] = b + u < b1 ? t : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && cp < ld) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w][lane];
+        dpad[(size_t)k * ld + cp] = (float)t;
+    }
 }
 
 // grid (B, ceil(F/64)); 4 wavefronts split the molecule's rows, 64 lanes own 64 exact columns.
@@ -186,8 +209,9 @@ __global__ __launch_bounds__(256) void readout_bn_fwd_kernel(eagcn_batch bt, Col
                 s1 += (double)v;
                 s2 += (double)v * (double)v;
             }
-        atomicAdd(&a.st[2 * f], s1);
-        atomicAdd(&a.st[2 * f + 1], s2);
+        double* st = a.st + (size_t)(blockIdx.x % a.st_copies) * a.st_stride;
+        atomicAdd(&st[2 * f], s1);
+        atomicAdd(&st[2 * f + 1], s2);
     }
 }
 
@@ -218,25 +242,46 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(eagcn_batch bt, const 
     }
 }
 
-// d pad_row[c] = sum_b (N - nat[b]) * dg[b][c] / size[b]
-__global__ __launch_bounds__(256) void readout_bwd_pad_kernel(eagcn_batch bt, const float* __restrict__ dg, ColMapD m,
-                                                               int ld, const int64_t* __restrict__ size, int mode,
-                                                               int F, float* __restrict__ dpad) {
-    const int cp = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cp >= ld) return;
+// d pad_row[c] = sum_b (N - nat[b]) * dg[b][c] / size[b]; grid ceil(ld / 64), 1024 threads, the molecules split over the
+// sixteen waves like readout_bwd_pad_views_kernel
+__global__ __launch_bounds__(1024) void readout_bwd_pad_kernel(eagcn_batch bt, const float* __restrict__ dg, ColMapD m,
+                                                                int ld, const int64_t* __restrict__ size, int mode,
+                                                                int F, float* __restrict__ dpad) {
+    __shared__ double part[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cp = blockIdx.x * 64 + lane;
     int eo = 0, po = 0, ce = -1;
-    for (int s = 0; s < m.nseg; ++s) {
-        if (cp < po + m.p[s]) { ce = (cp - po < m.w[s]) ? eo + (cp - po) : -1; break; }
-        eo += m.w[s];
-        po += m.p[s];
-    }
-    double acc = 0.0;
-    if (ce >= 0)
-        for (int b = 0; b < bt.B; ++b) {
-            const float inv = mode == 1 ? 1.0f / (float)size[b] : 1.0f;
-            acc += (double)((float)(dev_n(bt) - bt.nat[b]) * dg[(size_t)b * F + ce] * inv);
+    if (cp < ld)
+        for (int s = 0; s < m.nseg; ++s) {
+            if (cp < po + m.p[s]) { ce = (cp - po < m.w[s]) ? eo + (cp - po) : -1; break; }
+            eo += m.w[s];
+            po += m.p[s];
         }
-    dpad[cp] = (float)acc;
+    double acc = 0.0;
+    if (ce >= 0) {
+        const int per = (bt.B + 15) >> 4, n = dev_n(bt);
+        const int b0 = wave * per, b1 = min(bt.B, b0 + per);
+        for (int b = b0; b < b1; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int bb = min(b + u, b1 - 1);
+                const float inv = mode == 1 ? 1.0f / (float)size[bb] : 1.0f;
+                const float t = (float)(n - bt.nat[bb]) * dg[(size_t)bb * F + ce] * inv;
+                v[u] = b + u < b1 ? t : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && cp < ld) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w][lane];
+        dpad[cp] = (float)t;
+    }
 }
 
 // forward read-out with the non-stored rows' dropout SAMPLED (Weighted_sum, training, p > 0): fills cnt / padc, then sums
@@ -264,7 +309,7 @@ int readout_backward_pad_views(const eagcn_batch* b, const float* dg, const eagc
                                int F, int K, const uint16_t* cnt, float dropout, float* dpad, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_READOUT, s);
-    readout_bwd_pad_views_kernel<<<dim3(cdiv(layout_ld(lay), 256), K), 256, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size,
+    readout_bwd_pad_views_kernel<<<dim3(cdiv(layout_ld(lay), 64), K), 1024, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size,
                                                                                 mode, F, K, cnt, 1.0f / (1.0f - dropout), dpad);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
@@ -274,7 +319,7 @@ int readout_backward_pad(const eagcn_batch* b, const float* dg, const eagcn_layo
                          int mode, int F, float* dpad_row, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_READOUT, s);
-    readout_bwd_pad_kernel<<<cdiv(layout_ld(lay), 256), 256, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size,
+    readout_bwd_pad_kernel<<<cdiv(layout_ld(lay), 64), 1024, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size,
                                                                    mode, F, dpad_row);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
@@ -314,7 +359,7 @@ extern "C" int eagcn_readout_backward(const eagcn_batch* b, const float* dg, con
     }
     EAGCN_LAUNCH_CHECK();
     if (dpad_row) {
-        readout_bwd_pad_kernel<<<cdiv(layout_ld(lay), 256), 256, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size,
+        readout_bwd_pad_kernel<<<cdiv(layout_ld(lay), 64), 1024, 0, s>>>(*b, dg, make_colmap(lay), layout_ld(lay), size,
                                                                        mode, F, dpad_row);
         EAGCN_LAUNCH_CHECK();
     }
