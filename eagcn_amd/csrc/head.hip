@@ -91,6 +91,7 @@ static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m
 
 struct ModelScratch {
     float *da2, *da1, *dgn, *dg, *dxa, *dxb, *dpad;
+    float* hdw; int hdw_ks;      // row-chunk partials of the head's weight gradients (HeadBwd.ks): [ks][F n1 + n1 n2 + n2 nclass]
     double* hst; int n_hst;      // BatchNorm sums of the head: [f_in + n_den1 + n_den2][2], forward ...
     double* hsb;                 // ... and backward.  Both are cleared by the forward's parameter-packing launch; the backward clears
                                  // its own again on the way out (bn_bwd_reduce of the top layer), for a second backward call
@@ -110,6 +111,9 @@ static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model*
     s.da1 = c.take<float>(B * h->n_den1);
     s.dgn = c.take<float>(B * h->f_in);
     s.dg = c.take<float>(B * h->f_in);
+    s.hdw_ks = head_dw_chunks(b->B);
+    s.hdw = c.take<float>(s.hdw_ks > 1 ? (size_t)s.hdw_ks * ((size_t)h->f_in * h->n_den1 + (size_t)h->n_den1 * h->n_den2 +
+                                                             (size_t)h->n_den2 * h->nclass) : 1);
     int ldmax = 0;
     size_t lbytes = 0;
     for (int l = 0; l < m->n_layers; ++l) {
@@ -374,24 +378,38 @@ extern "C" int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_mode
         // dense 3: y = out (no BatchNorm behind it), input a2 = relu(bn_den2(h2))
         HeadBwd b3{B, n2, nc, sv.h2, sv.bn_2, 1, nodrop, h->den3_w, dout, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                    sc.da2, sb_2, hg->d_den3_w, m->training};
+        // large batches: the weight gradients leave as row-chunk partials, summed by the Graph_BN backward launch below
+        const int ks = sc.hdw_ks;
+        float* part3 = sc.hdw;
+        float* part2 = part3 + (size_t)ks * n2 * nc;
+        float* part1 = part2 + (size_t)ks * n1 * n2;
+        if (ks > 1) { b3.ks = ks; b3.dW_part = part3; }
         RC(head_bwd(b3, s));
         RC(hook(sb_2, 2 * n2));
         // dense 2: y = h2 followed by bn_den2 (+ the gradient that reaches graph_representation directly), input a1
         HeadBwd b2{B, n1, n2, sv.h1, sv.bn_1, 1, drop1, h->den2_w, sc.da2, sv.h2, sv.bn_2, sb_2, dgraph_rep, hg->d_bn2_w, hg->d_bn2_b,
                    sc.da1, sb_1, hg->d_den2_w, m->training};
         if (sync) { b2.cnt_y = cn_2; b2.gscale = gscale; }
+        if (ks > 1) { b2.ks = ks; b2.dW_part = part2; }
         RC(head_bwd(b2, s));
         RC(hook(sb_1, 2 * n1));
         // dense 1: y = h1 followed by bn_den1, input gn = Graph_BN(g)
         HeadBwd b1{B, F, n1, sv.g, sv.bn_g, 0, nodrop, h->den1_w, sc.da1, sv.h1, sv.bn_1, sb_1, nullptr, hg->d_bn1_w, hg->d_bn1_b,
                    sc.dgn, sb_g, hg->d_den1_w, m->training};
         if (sync) { b1.cnt_y = cn_1; b1.gscale = gscale; }
+        if (ks > 1) { b1.ks = ks; b1.dW_part = part1; }
         RC(head_bwd(b1, s));
         RC(hook(sb_g, 2 * F));
         // (folding Graph_BN's backward into the top layer's first backward kernel was measured: a wash at B = 256, +11 us at
         //  B = 1024 -- every packed row then gathers two molecule rows instead of one; it stays a 5 us launch of its own)
         HeadGbn bg{B, F, sc.dgn, sv.g, sv.bn_g, sb_g, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training};
         if (sync) { bg.cnt = cn_g; bg.gscale = gscale; }
+        if (ks > 1) {
+            bg.sum[0] = HeadDwSum{hg->d_den3_w, part3, n2 * nc, ks};
+            bg.sum[1] = HeadDwSum{hg->d_den2_w, part2, n1 * n2, ks};
+            bg.sum[2] = HeadDwSum{hg->d_den1_w, part1, F * n1, ks};
+            bg.nsum = 3;
+        }
         RC(head_gbn_bwd(bg, s));
         // read-out backward: evaluated inside the last layer's first backward kernel (ReadoutGrad); only the
         // gradient of the common non-stored row of Weighted_sum needs a (tiny) launch of its own

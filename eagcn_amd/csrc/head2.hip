@@ -36,10 +36,11 @@ __device__ __forceinline__ uint64_t head_seed(const HeadDrop& d) { return d.seed
 // The four waves split the k-steps; the partial tiles are summed through LDS and returned to wave 0.
 __device__ __forceinline__ void keep(f32x4& v) { asm volatile("" : "+v"(v)); }   // the load feeding v is not sunk / predicated
 
+// The reduction runs over k0 <= k < k1 (k0 a multiple of 16; the functors zero whatever lies beyond the operands' extents).
 template <bool QUAD, int STEPS, class FA, class FB>
-__device__ __forceinline__ void head_tile(int K, const FA& fa, const FB& fb, f32x4* red, f32x4 (&acc)[4]) {
+__device__ __forceinline__ void head_tile(int k0, int k1, const FA& fa, const FB& fb, f32x4* red, f32x4 (&acc)[4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4;
-    const int nsteps = (K + 15) >> 4;
+    const int nsteps = max(0, (k1 - k0 + 15) >> 4);
     const int per = (((nsteps + 3) >> 2) + STEPS - 1) / STEPS * STEPS;      // k-steps per wave, a multiple of STEPS
     const int sb = wave * per, se = min(nsteps, sb + per);
 #pragma unroll
@@ -49,7 +50,7 @@ __device__ __forceinline__ void head_tile(int K, const FA& fa, const FB& fb, f32
         typename FB::Raw rb[STEPS][4];
 #pragma unroll
         for (int u = 0; u < STEPS; ++u) {
-            const int kq = (st + u) * 16 + 4 * q;
+            const int kq = k0 + (st + u) * 16 + 4 * q;
             ra[u] = fa.load(kq);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -60,7 +61,7 @@ __device__ __forceinline__ void head_tile(int K, const FA& fa, const FB& fb, f32
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < STEPS; ++u) {
-            const int kq = (st + u) * 16 + 4 * q;
+            const int kq = k0 + (st + u) * 16 + 4 * q;
             const f32x4 a = fa.xf(ra[u], kq);
             f32x4 b[4];
 #pragma unroll
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwd a) {
                             DROP ? head_seed(a.drop) : 0, a.drop.thr, a.drop.inv_keep};
     const HfB<VEC> fb{a.W, a.K, a.N, col0};
     f32x4 acc[4];
-    head_tile<true, 4>(a.K, fa, fb, red, acc);
+    head_tile<true, 4>(0, a.K, fa, fb, red, acc);
     if (threadIdx.x >= 64) return;
     // D layout of tile j: column 4 li + j, rows 4q + r
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwd a) {
         const int rb = tile / nkb64, kb = tile - rb * nkb64;
         const HbA_a<VEC> fa{dyf, min(rb * 16 + li, a.B - 1)};
         const HbB_a<VEC> fb{a.W, a.K, a.N, kb * 64 + li};
-        head_tile<false, 2>(a.N, fa, fb, red, acc);
+        head_tile<false, 2>(0, a.N, fa, fb, red, acc);
         if (threadIdx.x >= 64) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -352,13 +353,19 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwd a) {
         }
     } else {
         // (b) dW[k][n] = sum_b a[b][k] dy_eff[b][n],  a = drop(relu(bn_p(x)));  tile: 16 input features x 64 output features
-        const int t = tile - tiles_a;
+        int t = tile - tiles_a;
+        const int tiles_b = ((a.K + 15) >> 4) * nnb64;
+        const int chunk = t / tiles_b;                    // row chunk of the reduction (HeadBwd.ks)
+        t -= chunk * tiles_b;
+        const int rows_per = ((nrb + a.ks - 1) / a.ks) * 16;
+        const int r0 = chunk * rows_per, r1 = min(a.B, r0 + rows_per);
+        float* __restrict__ dW = a.ks > 1 ? a.dW_part + (size_t)chunk * a.K * a.N : a.dW;
         const int kb = t / nnb64, nb = t - kb * nnb64;
         const int k = min(kb * 16 + li, a.K - 1), n0 = nb * 64 + 4 * li;
         const HbA_b<DROP> fa{a.x, a.B, a.K, k, a.bnp[HT_SC * a.K + k], a.bnp[HT_SH * a.K + k], a.relu_p ? 0.0f : -INFINITY,
                              seed, a.drop.thr, a.drop.inv_keep};
         const HbB_b<VEC> fb{dyf, n0};
-        head_tile<true, 2>(a.B, fa, fb, red, acc);
+        head_tile<true, 2>(r0, r1, fa, fb, red, acc);
         if (threadIdx.x >= 64) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwd a) {
             if (ok < a.K) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (n0 + j < a.N) a.dW[(size_t)ok * a.N + n0 + j] = acc[j][r];
+                    if (n0 + j < a.N) dW[(size_t)ok * a.N + n0 + j] = acc[j][r];
             }
         }
     }
@@ -383,6 +390,19 @@ __global__ __launch_bounds__(256) void head_gbn_bwd_kernel(HeadGbn a) {
         const float c1 = a.training ? (float)(s1 / Bn) : 0.0f, c2 = a.training ? (float)(s2 / Bn) : 0.0f;
         a.dg[e] = sc * (a.dgn[e] - c1 - (a.g[e] - mu) * inv * c2);
         if (e < (size_t)a.F) { a.dgamma[f] = (float)(s2 * (double)a.gscale); a.dbeta[f] = (float)(s1 * (double)a.gscale); }
+    }
+    // weight gradients of the dense layers that left as row-chunk partials (HeadBwd.ks): summed in chunk order
+    for (int j = 0; j < a.nsum; ++j) {
+        const HeadDwSum q = a.sum[j];
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < q.n; i += gridDim.x * blockDim.x) {
+            float v[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = q.part[(size_t)min(c, q.ks - 1) * q.n + i];
+            float t = v[0];
+#pragma unroll
+            for (int c = 1; c < 16; ++c) t += c < q.ks ? v[c] : 0.0f;
+            q.dst[i] = t;
+        }
     }
 }
 
@@ -439,7 +459,8 @@ int head_fwd(const HeadFwd& a, hipStream_t s) {
     return EAGCN_OK;
 }
 int head_bwd(const HeadBwd& a, hipStream_t s) {
-    const int tiles = cdiv(a.B, 16) * cdiv(a.K, 64) + cdiv(a.K, 16) * cdiv(a.N, 64);
+    EAGCN_CHECK_ARG(a.ks >= 1 && a.ks <= 16 && (a.ks == 1 || a.dW_part), "head: %d row chunks of the weight gradient", a.ks);
+    const int tiles = cdiv(a.B, 16) * cdiv(a.K, 64) + cdiv(a.K, 16) * cdiv(a.N, 64) * a.ks;
     const size_t lds = (size_t)3 * ((a.N + 3) & ~3) * sizeof(float) + 16384;
     EAGCN_CHECK_ARG(lds <= 64 * 1024, "head: %d output features exceed the table size", a.N);
     ProfScope ps(PROF_HEAD, s, 4.0 * a.B * a.K * a.N);

@@ -160,9 +160,16 @@ struct HeadBwd {                 // backward of  y = act(bn_p(x)) . W : d(bn_p o
     float *dgamma_y, *dbeta_y; float* dyp; double* sb_p; float* dW; int training;
     const double* cnt_y = nullptr;       // sync-BatchNorm: global row count of the BatchNorm behind y (sb_y: sums of all ranks)
     float gscale = 1.0f;                 // ... and 1 / world: d gamma / d beta = this rank's share of the summed sums
+    // ks > 1: the weight gradient's reduction over the B batch rows is cut into ks row chunks, one workgroup per (tile, chunk);
+    // chunk c's partial goes to dW_part + c * K * N and head_gbn_bwd adds the partials up in chunk order (a tile's whole
+    // reduction in one workgroup is a chain of B / 128 dependent load batches: 8 at B = 1024, the longest pole of the launch)
+    int ks = 1; float* dW_part = nullptr;
 };
+inline int head_dw_chunks(int B) { return B > 256 ? (B + 255) / 256 < 16 ? (B + 255) / 256 : 16 : 1; }
+struct HeadDwSum { float* dst; const float* part; int n, ks; };     // dst[i] = sum_c part[c * n + i]
 struct HeadGbn { int B, F; const float *dgn, *g, *bn; const double* sb; float *dg, *dgamma, *dbeta; int training;
-                 const double* cnt = nullptr; float gscale = 1.0f; };
+                 const double* cnt = nullptr; float gscale = 1.0f;
+                 HeadDwSum sum[3] = {}; int nsum = 0; };            // partial weight gradients of the dense layers (HeadBwd.ks)
 // cnt (optional): three slots that receive B as a double (row counts of the head's BatchNorms, summed with the statistics)
 int head_colstats(const float* g, int B, int F, double* st, hipStream_t s, double* cnt0 = nullptr, double* cnt1 = nullptr,
                   double* cnt2 = nullptr);
