@@ -289,7 +289,7 @@ struct HbB_b {                   // (b) B side (QUAD): dy_eff[b][n0 .. n0+3]
 };
 
 template <bool VEC, bool DROP>
-__global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwd a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void head_bwd_kernel(HeadBwd a) {   // (164 registers, three waves per SIMD: 174 and two without the hint)
     extern __shared__ __attribute__((aligned(16))) float tab[];          // [3][Np]: al, be, ga of dy_eff
     const int Np = (a.N + 3) & ~3;
     const double Bn = (a.cnt_y && a.training) ? *a.cnt_y : (double)a.B;

@@ -181,12 +181,33 @@ __global__ __launch_bounds__(256) void readout_bn_fwd_kernel(eagcn_batch bt, Col
                 y[u] = a.Y[(size_t)r * a.ldy + cp];
                 mk[u] = bt.row_m[r];
             }
+            float ds[8];
+            if (a.do_drop && a.pair) {
+                // one 64-bit draw serves the two adjacent columns of a lane pair (drop_scale_el): the even lane draws for row
+                // u, the odd lane for row u + 1 and they swap -- half the hashes (the kernel is bound by their 64-bit multiplies)
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    const int rs = r0 + 4 * (u + (lane & 1));
+                    const uint64_t zo = rng_u64(seed, ((uint64_t)rs * a.fp + cp) >> 1);
+                    const uint32_t plo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)zo, 0xB1, 0xF, 0xF, true);
+                    const uint32_t phi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(zo >> 32), 0xB1, 0xF, 0xF, true);
+                    // row u: the even lane's draw, low half for the even column, high half for the odd one; row u + 1: the odd lane's
+                    const uint32_t d0 = (lane & 1) ? phi : (uint32_t)zo;
+                    const uint32_t d1 = (lane & 1) ? (uint32_t)(zo >> 32) : plo;
+                    ds[u] = d0 >= a.thr ? a.inv_keep : 0.0f;
+                    ds[u + 1] = d1 >= a.thr ? a.inv_keep : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    ds[u] = a.do_drop ? drop_scale_el(seed, (uint64_t)(r0 + 4 * u) * a.fp + cp, a.thr, a.inv_keep) : 1.0f;
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int r = r0 + 4 * u;
                 if (r < rend) {
                     float v = fmaxf(y[u] * sc + sh, 0.0f) * mk[u];
-                    if (a.do_drop) v *= drop_scale_el(seed, (uint64_t)r * a.fp + cp, a.thr, a.inv_keep);
+                    if (a.do_drop) v *= ds[u];
                     const int mi = (r >= bnd[0] ? 1 : 0) + (r >= bnd[1] ? 1 : 0) + (r >= bnd[2] ? 1 : 0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) s[j] += mi == j ? v : 0.0f;
@@ -218,7 +239,11 @@ __global__ __launch_bounds__(256) void readout_bn_fwd_kernel(eagcn_batch bt, Col
 int readout_bn_forward(const eagcn_batch* b, const eagcn_layout* lay, const ReadoutBn& a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_READOUT, s);
-    readout_bn_fwd_kernel<<<dim3(cdiv(b->B, 4), cdiv(a.F, 64)), 256, 0, s>>>(*b, make_colmap(lay), a);
+    ReadoutBn aa = a;
+    // lanes 2i, 2i+1 hold the two halves of one dropout draw when every column range starts and ends on an even column
+    aa.pair = (a.fp & 1) == 0 && (a.F & 1) == 0;
+    for (int sg = 0; sg < lay->nseg; ++sg) aa.pair = aa.pair && (lay->width[sg] & 1) == 0 && (lay->pad[sg] & 1) == 0;
+    readout_bn_fwd_kernel<<<dim3(cdiv(b->B, 4), cdiv(a.F, 64)), 256, 0, s>>>(*b, make_colmap(lay), aa);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
