@@ -180,20 +180,23 @@ __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_
     return rng_u32(seed, idx) >= thr ? inv_keep : 0.0f;
 }
 
-// Dropout of the STORED rows of a graph-conv layer (element index r * Fp + column): one 64-bit hash serves two adjacent
-// elements -- the even index takes its low 32 bits, the odd one the high 32 bits -- so that the backward pass, which
-// regenerates the mask instead of reading it, pays two hashes per float4 (it was bound by the integer multiplies of four).
+// Dropout of the STORED rows of a graph-conv layer (element index r * Fp + column): one 64-bit hash serves FOUR adjacent
+// elements -- element idx takes the 16-bit field idx & 3 of the draw of idx >> 2 and is kept when that field is >= p * 2^16 (the
+// granularity of the non-stored rows' draws, readout.hip; p = 0.3 is held to 3e-6) -- because the passes that apply or
+// regenerate the mask (bn_apply, the fused read-out, bn_bwd_reduce) were bound by the hash's 64-bit multiplies: a 64-bit
+// multiply is four quarter-rate 32-bit ones, ~200 cycles per hash and wave.  thr = p * 2^32 as everywhere else.
 __device__ __forceinline__ float drop_scale_el(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
-    const uint64_t z = rng_u64(seed, idx >> 1);
-    return ((idx & 1) ? (uint32_t)(z >> 32) : (uint32_t)z) >= thr ? inv_keep : 0.0f;
+    const uint64_t z = rng_u64(seed, idx >> 2);
+    return ((uint32_t)(z >> (16 * (int)(idx & 3))) & 0xFFFFu) >= (thr >> 16) ? inv_keep : 0.0f;
 }
 // four adjacent elements starting at an index that is a multiple of 4
 __device__ __forceinline__ void drop_scale4(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep, float (&out)[4]) {
-    const uint64_t z0 = rng_u64(seed, idx >> 1), z1 = rng_u64(seed, (idx >> 1) + 1);
-    out[0] = (uint32_t)z0 >= thr ? inv_keep : 0.0f;
-    out[1] = (uint32_t)(z0 >> 32) >= thr ? inv_keep : 0.0f;
-    out[2] = (uint32_t)z1 >= thr ? inv_keep : 0.0f;
-    out[3] = (uint32_t)(z1 >> 32) >= thr ? inv_keep : 0.0f;
+    const uint64_t z = rng_u64(seed, idx >> 2);
+    const uint32_t lo = (uint32_t)z, hi = (uint32_t)(z >> 32), t16 = thr >> 16;
+    out[0] = (lo & 0xFFFFu) >= t16 ? inv_keep : 0.0f;
+    out[1] = (lo >> 16) >= t16 ? inv_keep : 0.0f;
+    out[2] = (hi & 0xFFFFu) >= t16 ? inv_keep : 0.0f;
+    out[3] = (hi >> 16) >= t16 ? inv_keep : 0.0f;
 }
 
 // ---- actual extents live in device memory ----------------------------------------------------------

@@ -205,7 +205,7 @@ struct ReadoutBn {
     float* g; int F;                         // [B][F]
     double* st;                              // [2 F] sum g, sum g^2 (fp64 atomics; zero on entry)
     int st_copies = 1, st_stride = 0;        // replicas of st (HeadFwd): workgroup x adds to replica x % st_copies
-    bool pair = false;                       // set by the launcher: adjacent lanes share a dropout draw
+    bool pair = false;                       // set by the launcher: a lane quad shares a dropout draw
     double *cnt0, *cnt1, *cnt2;              // optional row-count slots of the head's BatchNorms (sync-BatchNorm)
 };
 int readout_bn_forward(const eagcn_batch* b, const eagcn_layout* lay, const ReadoutBn& a, void* stream);

@@ -589,7 +589,11 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
     nedge = nedge < 0 ? -nedge : min(nedge, (meta[EAGCN_META_T] + 15) / 16);   // edge-gradient workgroups that had rows (< 0: all wrote)
     nsplit = max(1, min(nsplit, meta[EAGCN_META_T] >> 7));     // split-K partials actually written (gemm.hip eff_splits)
     if ((int)blockIdx.x < wblocks) {
-        const int e = blockIdx.x * blockDim.x + threadIdx.x;
+        // split-K slabs: FOUR lanes per element, each adds every fourth slab (the first layer's weight gradient leaves gemm.hip
+        // as up to 146 slabs: one thread per element was a chain of 37 dependent load rounds, 14 us at B = 1024)
+        const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+        const int sub = xk_G > 0 ? 0 : (tid & 3);
+        const int e = xk_G > 0 ? tid : (tid >> 2);
         if (e >= ld_in * fp) return;
         const int ip = e / fp, cp = e % fp;
         const int k = col_view(vc, cp), f = cp - vc.off[k];
@@ -611,16 +615,18 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
             gp.dW[k][(size_t)fi * vc.width[k] + f] = T > 0 ? t : 0.0f;
             return;
         }
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-        int z = 0;
-        for (; z + 4 <= nsplit; z += 4) {
-            s0 += dWcat[(size_t)(z + 0) * slab + e];
-            s1 += dWcat[(size_t)(z + 1) * slab + e];
-            s2 += dWcat[(size_t)(z + 2) * slab + e];
-            s3 += dWcat[(size_t)(z + 3) * slab + e];
+        float s0 = 0.0f, s1 = 0.0f;
+        int z = sub;
+#pragma unroll 4
+        for (; z + 4 < nsplit; z += 8) {
+            s0 += dWcat[(size_t)z * slab + e];
+            s1 += dWcat[(size_t)(z + 4) * slab + e];
         }
-        for (; z < nsplit; ++z) s0 += dWcat[(size_t)z * slab + e];
-        gp.dW[k][(size_t)fi * vc.width[k] + f] = (s0 + s1) + (s2 + s3);
+        if (z < nsplit) s0 += dWcat[(size_t)z * slab + e];
+        float t = s0 + s1;
+        t += __shfl_xor(t, 1);
+        t += __shfl_xor(t, 2);
+        if (sub == 0) gp.dW[k][(size_t)fi * vc.width[k] + f] = t;
         return;
     }
     // edge-gradient partials [nedge][K][EDGE_SLAB]: entry c in 1..C_k -> d att_w[c-1]; entry 256 -> self term.
@@ -1188,7 +1194,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             EAGCN_HIP(hipMemsetAsync(gp.dW[k], 0, (size_t)d.fin * p->width[k] * sizeof(float), side));
     }
     {
-        const int wblocks = nsplit > 0 ? cdiv((int)d.wslab, 256) : 0;
+        const int wblocks = nsplit > 0 ? cdiv((int)d.wslab * (xk_G > 0 ? 1 : 4), 256) : 0;     // (four lanes per element, unpack_grads)
         double* edge_src = nedge == -EDGE_COPIES ? sc.eacc : sc.datt;
         const int edge_drain = edge_src == sc.eacc ? 1 : 0;       // shared accumulators: zeroed again by the threads that read them
         static const bool defer_env = [] { const char* v = getenv("EAGCN_NO_EDGE_DEFER"); return !(v && v[0] == '1'); }();

@@ -183,19 +183,30 @@ __global__ __launch_bounds__(256) void readout_bn_fwd_kernel(eagcn_batch bt, Col
             }
             float ds[8];
             if (a.do_drop && a.pair) {
-                // one 64-bit draw serves the two adjacent columns of a lane pair (drop_scale_el): the even lane draws for row
-                // u, the odd lane for row u + 1 and they swap -- half the hashes (the kernel is bound by their 64-bit multiplies)
+                // one 64-bit draw serves the four adjacent columns of a lane quad (drop_scale_el): lane j of the quad draws for
+                // row 4 h + j of this round's eight and every lane picks its own 16-bit field out of the four draws -- a quarter
+                // of the hashes (the kernel is bound by their 64-bit multiplies)
 #pragma unroll
-                for (int u = 0; u < 8; u += 2) {
-                    const int rs = r0 + 4 * (u + (lane & 1));
-                    const uint64_t zo = rng_u64(seed, ((uint64_t)rs * a.fp + cp) >> 1);
-                    const uint32_t plo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)zo, 0xB1, 0xF, 0xF, true);
-                    const uint32_t phi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(zo >> 32), 0xB1, 0xF, 0xF, true);
-                    // row u: the even lane's draw, low half for the even column, high half for the odd one; row u + 1: the odd lane's
-                    const uint32_t d0 = (lane & 1) ? phi : (uint32_t)zo;
-                    const uint32_t d1 = (lane & 1) ? (uint32_t)(zo >> 32) : plo;
-                    ds[u] = d0 >= a.thr ? a.inv_keep : 0.0f;
-                    ds[u + 1] = d1 >= a.thr ? a.inv_keep : 0.0f;
+                for (int h = 0; h < 2; ++h) {
+                    const int rs = r0 + 4 * (4 * h + (lane & 3));
+                    const uint64_t zo = rng_u64(seed, ((uint64_t)rs * a.fp + cp) >> 2);
+                    const int lo = (int)(uint32_t)zo, hi = (int)(uint32_t)(zo >> 32);
+                    uint32_t w[4];                         // the half of row j's draw that holds this lane's field
+                    {
+                        const uint32_t l0 = (uint32_t)__builtin_amdgcn_mov_dpp(lo, 0x00, 0xF, 0xF, true);
+                        const uint32_t h0 = (uint32_t)__builtin_amdgcn_mov_dpp(hi, 0x00, 0xF, 0xF, true);
+                        const uint32_t l1 = (uint32_t)__builtin_amdgcn_mov_dpp(lo, 0x55, 0xF, 0xF, true);
+                        const uint32_t h1 = (uint32_t)__builtin_amdgcn_mov_dpp(hi, 0x55, 0xF, 0xF, true);
+                        const uint32_t l2 = (uint32_t)__builtin_amdgcn_mov_dpp(lo, 0xAA, 0xF, 0xF, true);
+                        const uint32_t h2 = (uint32_t)__builtin_amdgcn_mov_dpp(hi, 0xAA, 0xF, 0xF, true);
+                        const uint32_t l3 = (uint32_t)__builtin_amdgcn_mov_dpp(lo, 0xFF, 0xF, 0xF, true);
+                        const uint32_t h3 = (uint32_t)__builtin_amdgcn_mov_dpp(hi, 0xFF, 0xF, 0xF, true);
+                        const bool up = (lane & 2) != 0;
+                        w[0] = up ? h0 : l0; w[1] = up ? h1 : l1; w[2] = up ? h2 : l2; w[3] = up ? h3 : l3;
+                    }
+                    const int sh = 16 * (lane & 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ds[4 * h + j] = ((w[j] >> sh) & 0xFFFFu) >= (a.thr >> 16) ? a.inv_keep : 0.0f;
                 }
             } else {
 #pragma unroll
@@ -240,9 +251,9 @@ int readout_bn_forward(const eagcn_batch* b, const eagcn_layout* lay, const Read
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_READOUT, s);
     ReadoutBn aa = a;
-    // lanes 2i, 2i+1 hold the two halves of one dropout draw when every column range starts and ends on an even column
-    aa.pair = (a.fp & 1) == 0 && (a.F & 1) == 0;
-    for (int sg = 0; sg < lay->nseg; ++sg) aa.pair = aa.pair && (lay->width[sg] & 1) == 0 && (lay->pad[sg] & 1) == 0;
+    // lanes 4i .. 4i+3 hold the four fields of one dropout draw when every column range starts and ends on a multiple of four
+    aa.pair = (a.fp & 3) == 0 && (a.F & 3) == 0;
+    for (int sg = 0; sg < lay->nseg; ++sg) aa.pair = aa.pair && (lay->width[sg] & 3) == 0 && (lay->pad[sg] & 3) == 0;
     readout_bn_fwd_kernel<<<dim3(cdiv(b->B, 4), cdiv(a.F, 64)), 256, 0, s>>>(*b, make_colmap(lay), aa);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;

@@ -949,9 +949,9 @@ def _hip_dropout_masks(mb, widths_per_layer, structure, n_den1, p, seed):
                     r = (row0[b] + np.arange(n)).astype(np.uint64)[:, None]
                     cp = (off[k] + np.arange(w)).astype(np.uint64)[None, :]
                     idx = r * np.uint64(fp) + cp                      # csrc/common.h drop_scale4 / drop_scale_el: one hash
-                    z = _mix64(seed_l, idx >> np.uint64(1))           # per PAIR of elements, low half even, high half odd
-                    z = np.where((idx & np.uint64(1)) == np.uint64(1), z >> np.uint64(32), z & np.uint64(0xFFFFFFFF))
-                    m[b, :n, :] = np.where(z >= thr, inv_keep, np.float32(0.0))
+                    z = _mix64(seed_l, idx >> np.uint64(2))           # per FOUR elements, element idx takes 16-bit field idx & 3
+                    z = (z >> (np.uint64(16) * (idx & np.uint64(3)))) & np.uint64(0xFFFF)
+                    m[b, :n, :] = np.where(z >= (thr >> np.uint64(16)), inv_keep, np.float32(0.0))
                 if structure == 'Weighted_sum' and l == L - 1 and n < N:
                     i = np.arange(n, N)
                     g4 = (N + 3) // 4
