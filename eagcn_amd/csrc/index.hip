@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
 // (4) Every lane then packs the codes of its own four columns from that word and the code rows leave as before.
 constexpr int SCAN_CAP = 64;                 // bonds gathered per pass (a wave whose rows hold more runs several passes)
 template <int NIT, int RPW>
-__global__ __launch_bounds__(256) void index_scan4_kernel(const float* __restrict__ adj, RelPtrs rel, int B, int N, int Ncap, int K,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))          // (168 registers; 190 and two waves per SIMD without the hint)
+void index_scan4_kernel(const float* __restrict__ adj, RelPtrs rel, int B, int N, int Ncap, int K,
                                                            int ldc, uint8_t* __restrict__ code, int32_t* __restrict__ deg_bn,
                                                            int32_t* __restrict__ nat, int32_t* __restrict__ ecnt,
                                                            int32_t* __restrict__ meta) {
@@ -595,10 +596,9 @@ __device__ __forceinline__ int packed_to_exact(const ColMap& m, int cp) {
 
 __global__ __launch_bounds__(256) void pack_rows_kernel(eagcn_batch bt, const float* __restrict__ dense,
                                                          int F, ColMap m, int ld, float* __restrict__ packed, int Nin) {
-    const size_t total = (size_t)dev_rows(bt) * ld;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (size_t)gridDim.x * blockDim.x) {
-        int r = (int)(e / ld), cp = (int)(e % ld);
+    const uint32_t total = (uint32_t)dev_rows(bt) * (uint32_t)ld;         // (rows x input features: far below 2^32)
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        int r = (int)(e / (uint32_t)ld), cp = (int)(e - (uint32_t)r * (uint32_t)ld);
         int ce = packed_to_exact(m, cp);
         float v = 0.0f;
         if (ce >= 0) v = dense[((size_t)bt.row_mol[r] * Nin + bt.row_loc[r]) * F + ce];      // Nin: padded size of the caller's tensor
