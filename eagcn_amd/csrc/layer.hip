@@ -345,6 +345,8 @@ struct BwdArgs {
     int do_drop; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
     double* zero; int nzero;     // fp64 words cleared on the way (the head's backward sums, for the next backward call)
     EdgeDrain drain;             // pending edge-gradient reduction of the layer above (eacc == nullptr: none)
+    const float* cc;             // APPLY pass: [2][fp] means of dH and of dH * xhat (bn_bwd_finalize)
+    int store_dh;                // first pass also stores dH (EAGCN_BWD_STORE_DH=1: the elementwise second pass of round 2 reads it)
 };
 
 // One workgroup owns BWD_ROWS consecutive-strided rows; a thread owns FOUR adjacent columns (one float4 per row
@@ -354,16 +356,21 @@ struct BwdArgs {
 // Compile-time variants (structure, per-molecule upstream gradient, dropout): the general kernel carried every path at once
 // -- 7.7 k instructions, scalar registers spilled to vector lanes, a few hundred exec-mask branches -- and was bound by
 // that, not by memory.
-template <bool WEIGHTED, bool DG, bool DROP>
+// Two passes share this body, so that both form dH = upstream * dropout * relu' in exactly the same way:
+//   APPLY = false: the column sums of dH and dH * xhat (fp64 slabs); dH itself is NOT stored;
+//   APPLY = true (after bn_bwd_finalize): dH is formed again and dY' = sc * (dH - c1 - xhat * c2) is written.
+// (Round 2 stored dH in the first pass and re-read it in an elementwise second one: one write and one read of T x Fp floats
+//  more than re-forming it from Y and the upstream gradient, which the second pass reads anyway or gathers per molecule.)
+template <bool WEIGHTED, bool DG, bool DROP, bool APPLY>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
     __shared__ double da_s[EAGCN_MAX_VIEWS];
     const uint64_t seed = DROP ? (a.seed_dev ? *a.seed_dev : a.seed) : 0ull;
     const int fp = a.fp, T = min(a.meta[EAGCN_META_T], a.Tcap);
-    const int rows = T + a.nvirt;
+    const int rows = T + (APPLY ? 0 : a.nvirt);
     // the grid is sized for the row CAPACITY: only the first ceil(rows / BWD_ROWS) workgroups work (and write a
     // slab); bn_bwd_finalize derives the same count from the device-side row count
     const int nwg = max(1, min((int)gridDim.x, (rows + BWD_ROWS - 1) / BWD_ROWS));
-    if (a.drain.eacc && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (!APPLY && a.drain.eacc && blockIdx.x == 0 && blockIdx.y == 0) {
         // the layer above left its bond-type histograms in the shared accumulator slabs: reduce them into its d att.weight /
         // d self_r and leave the slabs zero for this layer's own edge gradients (agg_edge runs after this kernel)
         const int K = a.drain.K;
@@ -390,9 +397,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
             }
         }
     }
-    if ((int)blockIdx.x >= nwg) return;
-    if (threadIdx.x < EAGCN_MAX_VIEWS) da_s[threadIdx.x] = 0.0;
-    __syncthreads();
+    if ((int)blockIdx.x >= nwg || (APPLY && T == 0)) return;
+    if constexpr (!APPLY) {
+        if (threadIdx.x < EAGCN_MAX_VIEWS) da_s[threadIdx.x] = 0.0;
+        __syncthreads();
+    }
     constexpr bool weighted = WEIGHTED;
     double da[EAGCN_MAX_VIEWS];
 #pragma unroll
@@ -407,6 +416,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
         const float4 mu = *reinterpret_cast<const float4*>(a.bn + BN_MU * fp + cp);
         const float4 iv = *reinterpret_cast<const float4*>(a.bn + BN_INV * fp + cp);
         const float4 aw = *reinterpret_cast<const float4*>(a.colp + CP_AVEW * fp + cp);
+        float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), c2 = c1;
+        if constexpr (APPLY) {
+            c1 = *reinterpret_cast<const float4*>(a.cc + cp);
+            c2 = *reinterpret_cast<const float4*>(a.cc + fp + cp);
+        }
         const int cu = weighted ? f : cp;           // first column of the upstream gradient
         // ... and its exact column when that gradient is per molecule (ce4: the four columns are consecutive
         // exact columns, 16-byte aligned -> one load; otherwise each is looked up on its own)
@@ -477,6 +491,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
                 const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
                 const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, ivv[4] = {iv.x, iv.y, iv.z, iv.w};
                 const float awv[4] = {aw.x, aw.y, aw.z, aw.w};
+                const float c1v[4] = {c1.x, c1.y, c1.z, c1.w}, c2v[4] = {c2.x, c2.y, c2.z, c2.w};
                 float dh[4], dsv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
                 if (DROP && r < T) drop_scale4(seed, (uint64_t)r * fp + cp, a.thr, a.inv_keep, dsv);
 #pragma unroll
@@ -484,24 +499,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BwdArgs a) {
                     float up = uu[j];
                     const float ds = dsv[j];
                     const float h = yy[j] * scv[j] + shv[j];
-                    if (weighted) { dak += (double)(up * ds * fmaxf(h, 0.0f)); up *= awv[j]; }
+                    if (weighted) { if constexpr (!APPLY) dak += (double)(up * ds * fmaxf(h, 0.0f)); up *= awv[j]; }
                     dh[j] = h > 0.0f ? up * ds : 0.0f;
                     const float xh = (yy[j] - muv[j]) * ivv[j];
-                    s1[j] += (double)dh[j];
-                    s2[j] += (double)(dh[j] * xh);
+                    if constexpr (APPLY) {
+                        dh[j] = scv[j] * (dh[j] - c1v[j] - xh * c2v[j]);
+                    } else {
+                        s1[j] += (double)dh[j];
+                        s2[j] += (double)(dh[j] * xh);
+                    }
                 }
-                if (r < T) *reinterpret_cast<float4*>(a.dH + (size_t)r * fp + cp) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+                if ((APPLY || a.store_dh) && r < T)
+                    *reinterpret_cast<float4*>(a.dH + (size_t)r * fp + cp) = make_float4(dh[0], dh[1], dh[2], dh[3]);
             }
         }
-        double* sl = a.slab + ((size_t)blockIdx.x * fp + cp) * 2;
-        *reinterpret_cast<double4*>(sl) = make_double4(s1[0], s2[0], s1[1], s2[1]);
-        *reinterpret_cast<double4*>(sl + 4) = make_double4(s1[2], s2[2], s1[3], s2[3]);
-        if (weighted) {
+        if constexpr (!APPLY) {
+            double* sl = a.slab + ((size_t)blockIdx.x * fp + cp) * 2;
+            *reinterpret_cast<double4*>(sl) = make_double4(s1[0], s2[0], s1[1], s2[1]);
+            *reinterpret_cast<double4*>(sl + 4) = make_double4(s1[2], s2[2], s1[3], s2[3]);
+            if (weighted) {
 #pragma unroll
-            for (int v = 0; v < EAGCN_MAX_VIEWS; ++v) da[v] += (v == k) ? dak : 0.0;
+                for (int v = 0; v < EAGCN_MAX_VIEWS; ++v) da[v] += (v == k) ? dak : 0.0;
+            }
         }
     }
-    if (weighted) {
+    if (weighted && !APPLY) {
 #pragma unroll
         for (int v = 0; v < EAGCN_MAX_VIEWS; ++v) {
             const double t = wave_sum(da[v]);
@@ -1013,6 +1035,26 @@ static int apply_launch_(const eagcn_batch* b, const eagcn_layer_params* p, cons
     return EAGCN_OK;
 }
 
+// Second pass of the BatchNorm backward: re-form dH in the reduction kernel's body (APPLY) or read the dH the first pass stored
+// (elementwise bn_bwd_apply_kernel).  Weighted_sum: the upstream gradient is K times narrower than dH, re-forming it saves a
+// write and a read of T x Fp floats (HIV widths: 9.74 -> 9.53 ms per step).  Concate: the upstream gradient is as wide as dH
+// and the plain elementwise pass is the lighter kernel (B = 256: 0.456 vs 0.459 ms; B = 1024: equal).
+// EAGCN_BWD_STORE_DH=1 / 0 forces one or the other.
+static bool bn_bwd_two_pass(bool weighted) {
+    static const int force = [] { const char* v = getenv("EAGCN_BWD_STORE_DH"); return v ? (v[0] == '1' ? 1 : 0) : -1; }();
+    return force < 0 ? weighted : force == 0;
+}
+// the two passes of bn_bwd_reduce_kernel (apply = false: sums, apply = true: dY') in their compile-time variants
+static void launch_bn_bwd_pass(bool apply, bool wt, bool dg, bool dr, dim3 grid, const BwdArgs& ba, hipStream_t s) {
+#define EAGCN_BWD(W, G, D) do { if (apply) bn_bwd_reduce_kernel<W, G, D, true><<<grid, 256, 0, s>>>(ba); \
+                                else bn_bwd_reduce_kernel<W, G, D, false><<<grid, 256, 0, s>>>(ba); } while (0)
+    if (wt) { if (dg) { if (dr) EAGCN_BWD(true, true, true); else EAGCN_BWD(true, true, false); }
+              else    { if (dr) EAGCN_BWD(true, false, true); else EAGCN_BWD(true, false, false); } }
+    else    { if (dg) { if (dr) EAGCN_BWD(false, true, true); else EAGCN_BWD(false, true, false); }
+              else    { if (dr) EAGCN_BWD(false, false, true); else EAGCN_BWD(false, false, false); } }
+#undef EAGCN_BWD
+}
+
 extern "C" int eagcn_layer_backward(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
                                     const float* dxout, const float* dpad_row, float* dx,
                                     const eagcn_layer_grads* g, void* stream) {
@@ -1094,12 +1136,9 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         {
             const bool wt = p->structure == EAGCN_STRUCT_WEIGHTED, dg = ba.rg.dg != nullptr, dr = ba.do_drop != 0;
             const dim3 grid(gxb, ny);
-#define EAGCN_BWD(W, G, D) bn_bwd_reduce_kernel<W, G, D><<<grid, 256, 0, s>>>(ba)
-            if (wt) { if (dg) { if (dr) EAGCN_BWD(true, true, true); else EAGCN_BWD(true, true, false); }
-                      else    { if (dr) EAGCN_BWD(true, false, true); else EAGCN_BWD(true, false, false); } }
-            else    { if (dg) { if (dr) EAGCN_BWD(false, true, true); else EAGCN_BWD(false, true, false); }
-                      else    { if (dr) EAGCN_BWD(false, false, true); else EAGCN_BWD(false, false, false); } }
-#undef EAGCN_BWD
+            ba.cc = sc.cc;
+            ba.store_dh = bn_bwd_two_pass(wt) ? 0 : 1;
+            launch_bn_bwd_pass(false, wt, dg, dr, grid, ba, s);
         }
         EAGCN_LAUNCH_CHECK();
         const double* gsum = nullptr;
@@ -1122,7 +1161,10 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
                                                                         d.vc, gp, sc.cc, b->meta, ba.nvirt, b->B, ny, gxb, gsum, ba.zero, ba.nzero);
         EAGCN_LAUNCH_CHECK();
         if (b->T > 0) {
-            bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
+            // second pass of the same kernel body: dH formed again, dY' written (sc.dY)
+            const bool wt = p->structure == EAGCN_STRUCT_WEIGHTED, dg = ba.rg.dg != nullptr, dr = ba.do_drop != 0;
+            if (bn_bwd_two_pass(wt)) launch_bn_bwd_pass(true, wt, dg, dr, dim3(std::max(1, std::min(b->T, d.gxb)), ny), ba, s);
+            else bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
             EAGCN_LAUNCH_CHECK();
         }
     }
