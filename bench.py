@@ -470,8 +470,14 @@ def main():
                 c1 = dict(WORKLOADS['tox21_c2'], nclass=1)
                 mb1 = make_batch(B=64, n_max=c1['n_max'], n_med=c1['n_med'], rel_channels=rel_channels(c1), seed=4321, n_tasks=1, task='class')
                 out['cpu_baseline_configs0'] = cpu_baseline(c1, mb1, args.dropout, bce_w_of(c1), steps=args.cpu_steps)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist.is_initialized():
+        # orderly teardown: no captured graph (they hold RCCL kernels) and no pending collective outlives the communicator
+        import gc
+        torch.cuda.synchronize()
+        gc.collect()
+        dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

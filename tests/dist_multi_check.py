@@ -111,6 +111,12 @@ for sync in (False, True):
              model.plan().stats.calls if sync else '-'), flush=True)
     if sync:
         assert model.plan().stats.calls > 0 and model.plan().stats.error is None, model.plan().stats.error
+# orderly teardown: the captured graphs (they hold RCCL kernels) and every pending collective go before the communicator
 dist.barrier()
-dist.destroy_process_group()
+torch.cuda.synchronize()
+del model, red, runner
+import gc
+gc.collect()
+torch.cuda.synchronize()
 print('DIST_MULTI_OK rank %d of %d' % (rank, world), flush=True)
+dist.destroy_process_group()
