@@ -50,7 +50,7 @@ def set_bond_lists(c, small_ptr, ptrs, edges, E):
 class GatParams(C.Structure):
     _fields_ = [('fin', C.c_int32), ('ld_in', C.c_int32), ('F', C.c_int32), ('training', C.c_int32),
                 ('alpha', C.c_float), ('att_dropout', C.c_float), ('dropout', C.c_float), ('reserved_', C.c_float),
-                ('seed', C.c_uint64), ('W', _fp), ('a', _fp)]
+                ('seed', C.c_uint64), ('W', _fp), ('a', _fp), ('seed_dev', C.c_void_p)]
 
 
 POOL_MAX = 8

@@ -25,8 +25,9 @@ struct GatArgs {
     const float* h; const float* a;
     float* s12;                  // [2][T]
     float alpha;
-    int att_drop; uint32_t att_thr; float att_inv; uint64_t att_seed;
-    int do_drop; uint32_t thr; float inv_keep; uint64_t seed;
+    int att_drop; uint32_t att_thr; float att_inv; uint64_t att_seed_;
+    int do_drop; uint32_t thr; float inv_keep; uint64_t seed_;
+    const uint64_t* seed_dev;    // the stream's seed lives in device memory (a captured launch draws fresh masks every replay)
     float* xout;
     const float* dxout;
     float* gbuf;                 // [E] per row-list entry: dp, then g
@@ -36,6 +37,10 @@ struct GatArgs {
     float* dh;                   // [T][Fp]
     float* da;                   // [2F]
 };
+constexpr uint64_t GAT_ATT_STREAM = 0xA77E17105EEDull;
+__device__ __forceinline__ uint64_t gat_seed(const GatArgs& a) { return a.seed_dev ? *a.seed_dev : a.seed_; }
+__device__ __forceinline__ uint64_t gat_att_seed(const GatArgs& a) { return a.seed_dev ? (*a.seed_dev ^ GAT_ATT_STREAM) : a.att_seed_; }
+
 
 __device__ __forceinline__ float lrelu(float v, float alpha) { return v > 0.0f ? v : alpha * v; }
 __device__ __forceinline__ float group_sum16(float v) {
@@ -75,7 +80,7 @@ __device__ __forceinline__ RowSoft gat_row_soft(const GatArgs& a, int r, int r0,
 // attention weight of entry (row r -> local column jl) after the attention dropout
 __device__ __forceinline__ float gat_q(const GatArgs& a, int r, int jl, float s1i, float s2j, const RowSoft& rs) {
     const float p = __expf(lrelu(s1i + s2j, a.alpha) - rs.mx) / rs.Z;
-    return a.att_drop ? p * drop_scale(a.att_seed, (uint64_t)r * 1024ull + (uint64_t)jl, a.att_thr, a.att_inv) : p;
+    return a.att_drop ? p * drop_scale(gat_att_seed(a), (uint64_t)r * 1024ull + (uint64_t)jl, a.att_thr, a.att_inv) : p;
 }
 
 __global__ __launch_bounds__(256) void gat_attend_fwd_kernel(GatArgs a) {
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) void gat_attend_fwd_kernel(GatArgs a) {
             float o[4] = {fmaxf(acc.x, 0.0f), fmaxf(acc.y, 0.0f), fmaxf(acc.z, 0.0f), fmaxf(acc.w, 0.0f)};
             if (a.do_drop) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) o[u] *= drop_scale(a.seed, (uint64_t)r * a.Fp + c + u, a.thr, a.inv_keep);
+                for (int u = 0; u < 4; ++u) o[u] *= drop_scale(gat_seed(a), (uint64_t)r * a.Fp + c + u, a.thr, a.inv_keep);
             }
             *reinterpret_cast<float4*>(xo + c) = make_float4(o[0], o[1], o[2], o[3]);
         }
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256) void gat_attend_fwd_kernel(GatArgs a) {
 __device__ __forceinline__ float gat_dhp(const GatArgs& a, int r, int c) {
     const size_t o = (size_t)r * a.Fp + c;
     if (!(a.xout[o] > 0.0f)) return 0.0f;
-    const float ds = a.do_drop ? drop_scale(a.seed, (uint64_t)r * a.Fp + c, a.thr, a.inv_keep) : 1.0f;
+    const float ds = a.do_drop ? drop_scale(gat_seed(a), (uint64_t)r * a.Fp + c, a.thr, a.inv_keep) : 1.0f;
     return a.dxout[o] * ds;
 }
 
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void gat_bwd_rows_kernel(GatArgs a) {
             const float dq = group_sum16(part);
             const float pre = s1i + s2[r0 + jl];
             const float p = __expf(lrelu(pre, a.alpha) - rs.mx) / rs.Z;
-            const float d = a.att_drop ? drop_scale(a.att_seed, (uint64_t)r * 1024ull + (uint64_t)jl, a.att_thr, a.att_inv) : 1.0f;
+            const float d = a.att_drop ? drop_scale(gat_att_seed(a), (uint64_t)r * 1024ull + (uint64_t)jl, a.att_thr, a.att_inv) : 1.0f;
             const float dp = dq * d;
             rowdot += p * dp;
             if (e < 0) dp_self = dp;
@@ -278,11 +283,12 @@ static GatArgs gat_args(const eagcn_batch* b, const eagcn_gat_params* p, const f
     a.att_drop = (p->training && p->att_dropout > 0.0f) ? 1 : 0;
     a.att_thr = (uint32_t)std::min(4294967295.0, (double)p->att_dropout * 4294967296.0);
     a.att_inv = 1.0f / (1.0f - p->att_dropout);
-    a.att_seed = p->seed ^ 0xA77E17105EEDull;
+    a.att_seed_ = p->seed ^ GAT_ATT_STREAM;
     a.do_drop = (p->training && p->dropout > 0.0f) ? 1 : 0;
     a.thr = (uint32_t)std::min(4294967295.0, (double)p->dropout * 4294967296.0);
     a.inv_keep = 1.0f / (1.0f - p->dropout);
-    a.seed = p->seed;
+    a.seed_ = p->seed;
+    a.seed_dev = p->seed_dev;
     return a;
 }
 static inline int row_grid(int T) { return std::max(1, std::min(cdiv(std::max(T, 1), 16), 2048)); }

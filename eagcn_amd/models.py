@@ -111,13 +111,9 @@ class EAGCN(nn.Module):
             rel_channels = [n_bfeat, 4, 2, 2, 2][:K]
         if structure not in ('Concate', 'Weighted_sum', 'GCN', 'GAT'):
             raise ValueError("structure must be 'Concate', 'Weighted_sum' or one of the baselines 'GCN' / 'GAT' (models.py:50-73)")
-        if structure == 'GAT' and graph:
-            raise ValueError("structure='GAT' runs layer by layer on the eager engine (graph=False)")
         if molfp_mode not in ('sum', 'ave', 'pool'):
             raise ValueError("molfp_mode must be 'sum', 'ave' or 'pool' (models.py:104-111)")
         if molfp_mode == 'pool':
-            if graph:
-                raise ValueError("molfp_mode='pool' (Diff_Pooling) runs on the eager engine (graph=False)")
             if structure in ('Concate', 'Weighted_sum') and n_layers != 4:
                 raise ValueError("molfp_mode='pool' reads the attention matrix of layer 4 (last=True, layers.py:319-324)")
         self.pool_num = int(pool_num)
@@ -187,13 +183,14 @@ class EAGCN(nn.Module):
     def graph_layers(self):
         return [getattr(self, 'layer%d' % (i + 1)) for i in range(self.n_layers)]
 
-    def forward_layers(self, index, afms):
-        """Packed activations after every graph-conv layer: list of (x, pad_row, layout)."""
+    def forward_layers(self, index, afms, seeds=None):
+        """Packed activations after every graph-conv layer: list of (x, pad_row, layout).  `seeds`: one dropout seed per layer
+        (ints, or 1-element int64 device tensors -- graph mode: the kernels read them from device memory); default: drawn."""
         layout = ops.ColLayout.single(self.n_afeat)
         x = ops.pack_rows(index, layout, afms)
         outs = []
-        for layer in self.graph_layers():
-            x, pad_row, layout = layer.forward_packed(index, x, layout)
+        for l, layer in enumerate(self.graph_layers()):
+            x, pad_row, layout = layer.forward_packed(index, x, layout, None if seeds is None else seeds[l])
             outs.append((x, pad_row, layout))
         return outs
 
@@ -301,6 +298,33 @@ class EAGCN(nn.Module):
         runner.rel_vectors = None if general is None else bonds.rel_vectors
         return runner, adjs, rels, afms, size, seed, btuple
 
+    def _composed_runner(self, adjs, afms, rels, size):
+        """Validated dense inputs and the cached graph_composed.ComposedRunner of this batch shape (GAT / pool models)."""
+        from .graph_composed import ComposedRunner
+        adjs = ops._need_cuda_f32(adjs, 'adjs')
+        afms = ops._need_cuda_f32(afms, 'afms')
+        if self.structure in ('GCN', 'GAT'):
+            rels = rels[:1]
+        rels = [ops._need_cuda_f32(r, 'relation tensor %d' % i) for i, r in enumerate(rels)]
+        B, N = adjs.shape[0], adjs.shape[1]
+        if adjs.dim() != 3 or adjs.shape[2] != N or afms.shape != (B, N, self.n_afeat) or len(rels) != self.K:
+            raise ops.L.EagcnHipError('inconsistent batch tensors: adjs %s afms %s, %d relation tensors'
+                                      % (tuple(adjs.shape), tuple(afms.shape), len(rels)))
+        channels = tuple(int(r.shape[1]) for r in rels)
+        if self.structure not in ('GCN', 'GAT'):
+            self._check_channels(channels)
+        key = ('composed', B, N, channels)
+        runner = self._runners.pop(key, None)
+        if runner is None:
+            while len(self._runners) >= max(1, self.max_runners):
+                self._runners.pop(next(iter(self._runners))).release()
+            runner = ComposedRunner(self, B, N, channels, afms.device, self.row_cap, self.edge_cap, self.validate,
+                                    static_outputs=(self.graph_outputs == 'static'))
+        self._runners[key] = runner
+        if size is not None and isinstance(size, torch.Tensor):
+            size = size.to(device=afms.device, dtype=torch.int64)
+        return runner, adjs, rels, afms, size
+
     def _atom_rep(self, runner):
         if self.atom_rep == 'none':
             return None
@@ -330,6 +354,21 @@ class EAGCN(nn.Module):
         ``loss.backward()`` would."""
         if not (self.graph and self.training and torch.is_grad_enabled()):
             raise ops.L.EagcnHipError('fused_step needs graph=True, training mode and grad enabled')
+        if self.structure == 'GAT' or self.molfp_mode == 'pool':
+            # no model-level plan: the layer-by-layer step (forward_composed + fused loss + autograd backward) is captured as
+            # one graph over static buffers (graph_composed.ComposedRunner)
+            if bonds is not None or reducer is not None or isinstance(scale, str):
+                raise ops.L.EagcnHipError("fused_step of a GAT / pool model takes the dense batch, no reducer and a tensor scale")
+            adjs, afms, *rels_and_size = batch
+            *rels, size = rels_and_size
+            runner, adjs, rels, afms, size = self._composed_runner(adjs, afms, rels, size)
+            kind = 'mse' if task == 'reg' else 'bce'
+            if kind == 'bce':
+                if bce_weight is None:
+                    raise ops.L.EagcnHipError('fused_step: the classification loss needs bce_weight ([T,2]; training.set_weight)')
+                if not isinstance(bce_weight, torch.Tensor):
+                    bce_weight = torch.tensor(bce_weight, dtype=torch.float32, device=afms.device)
+            return runner.train_step(adjs, rels, afms, size, labels, kind, bce_weight, scale)
         if bonds is None:
             adjs, afms, *rels_and_size = batch
             *rels, size = rels_and_size
@@ -366,6 +405,9 @@ class EAGCN(nn.Module):
             adjs = ops._need_cuda_f32(adjs, 'adjs')
             return self.forward_compact(bonds_from_dense(adjs, rels), afms, size)
         if self.structure == 'GAT' or self.molfp_mode == 'pool':     # layer-level entry points + composed head
+            if self.graph and not self.training and not torch.is_grad_enabled():
+                runner, adjs, rels, afms, size = self._composed_runner(adjs, afms, rels, size)
+                return runner.eval_forward(adjs, rels, afms, size)   # forward-only graph (train.py:130-211 under no_grad)
             return self.forward_composed(adjs, afms, *rels, size)
         if self.structure == 'GCN':
             rels = rels[:1]                                          # Vanilla_GCN only needs the bond positions (= adj)
@@ -454,8 +496,8 @@ class EAGCN(nn.Module):
         index = ops.BatchIndex(adjs, rels, bond_lists=(self.structure == 'GAT'))
         return self._forward_composed_index(index, afms, size)
 
-    def _forward_composed_index(self, index, afms, size):
-        x, pad_row, layout = self.forward_layers(index, afms)[-1]
+    def _forward_composed_index(self, index, afms, size, seeds=None):
+        x, pad_row, layout = self.forward_layers(index, afms, seeds)[-1]
         pad = pad_row if self.structure in ('Weighted_sum', 'GCN') else None
         if self.molfp_mode == 'pool':                                      # models.py:104-106
             g = self.pool1.pooled_sum(index, layout, x, pad, self.graph_layers()[-1])

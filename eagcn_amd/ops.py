@@ -299,6 +299,16 @@ def unpack_rows(index, layout, packed, pad_row=None):
 # ------------------------------------------------------------------------------------------------
 # graph-conv layer
 # ------------------------------------------------------------------------------------------------
+def _seed_fields(seed):
+    """(host value, device pointer) of a dropout seed: an int, or a 1-element int64 DEVICE tensor -- the kernels then read the
+    seed from device memory, so a captured launch draws fresh masks on every replay (graph mode)."""
+    if isinstance(seed, torch.Tensor):
+        if not seed.is_cuda or seed.dtype != torch.int64 or seed.numel() != 1:
+            raise L.EagcnHipError('a device seed must be a 1-element int64 device tensor')
+        return 0, seed.data_ptr()
+    return int(seed) & (2 ** 63 - 1), None
+
+
 class LayerSpec:
     """Static description of one multi-view layer (what the C struct needs besides pointers)."""
 
@@ -323,7 +333,8 @@ class LayerSpec:
         for k, w in enumerate(self.widths):
             p.width[k] = w
         p.inp = self.in_layout.c
-        p.dropout, p.bn_eps, p.bn_momentum, p.seed = self.dropout, self.bn_eps, self.bn_momentum, int(seed)
+        p.dropout, p.bn_eps, p.bn_momentum = self.dropout, self.bn_eps, self.bn_momentum
+        p.seed, p.seed_dev = _seed_fields(seed)
         for k, v in enumerate(views):
             p.att_w[k], p.self_r[k], p.W[k] = v['att_w'].data_ptr(), v['self_r'].data_ptr(), v['W'].data_ptr()
             p.bias[k], p.gamma[k], p.beta[k] = v['bias'].data_ptr(), v['gamma'].data_ptr(), v['beta'].data_ptr()
@@ -435,7 +446,8 @@ class _GatFn(torch.autograd.Function):
             raise L.EagcnHipError('GAT layer: x %s W %s a %s for fin=%d ld=%d F=%d' % (tuple(x.shape), tuple(W.shape), tuple(a.shape), fin, ld_in, F))
         p = L.GatParams()
         p.fin, p.ld_in, p.F, p.training = fin, ld_in, F, int(bool(training))
-        p.alpha, p.att_dropout, p.dropout, p.seed = float(alpha), float(att_dropout), float(dropout), int(seed) & (2 ** 63 - 1)
+        p.alpha, p.att_dropout, p.dropout = float(alpha), float(att_dropout), float(dropout)
+        p.seed, p.seed_dev = _seed_fields(seed)
         p.W, p.a = W.data_ptr(), a.data_ptr()
         Fp = (F + 15) // 16 * 16
         f32 = dict(dtype=torch.float32, device=x.device)
@@ -456,7 +468,8 @@ class _GatFn(torch.autograd.Function):
         index = ctx.index
         p = L.GatParams()
         p.fin, p.ld_in, p.F, p.training = fin, ld_in, F, int(bool(training))
-        p.alpha, p.att_dropout, p.dropout, p.seed = float(alpha), float(att_dropout), float(dropout), int(seed) & (2 ** 63 - 1)
+        p.alpha, p.att_dropout, p.dropout = float(alpha), float(att_dropout), float(dropout)
+        p.seed, p.seed_dev = _seed_fields(seed)
         p.W, p.a = W.data_ptr(), a.data_ptr()
         dxout = dxout.contiguous()
         dW, da = torch.empty_like(W), torch.empty_like(a)
@@ -580,7 +593,9 @@ class _PoolMix(torch.autograd.Function):
     @staticmethod
     def forward(ctx, index, layout, A, padsum, x, pad_row):
         F = layout.width
-        AX = torch.empty((max(index.T, 1), F), dtype=torch.float32, device=x.device)
+        # (zeros: with a capacity-sized index the rows beyond the batch's atoms are not written, and the flat GEMMs behind
+        #  this matrix run over all of them)
+        AX = torch.zeros((max(index.T, 1), F), dtype=torch.float32, device=x.device)
         L.check(L.load().eagcn_pool_mix_forward(index.ref(), C.byref(layout.c), _ptr(A), A.shape[1], _ptr(padsum), _ptr(x),
                                                 _ptr(pad_row), _ptr(AX), F, _stream()), 'eagcn_pool_mix_forward')
         ctx.index, ctx.layout = index, layout
@@ -621,7 +636,7 @@ class _PoolReduce(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dg):
         Z, S, Pm = ctx.saved_tensors
-        dZ = torch.empty_like(Z)
+        dZ = torch.zeros_like(Z)                            # (rows beyond the batch's atoms stay zero: see _PoolMix.forward)
         L.check(L.load().eagcn_pool_reduce_backward(ctx.index.ref(), _ptr(Z), Z.shape[1], ctx.F, ctx.P, _ptr(S), _ptr(Pm),
                                                     _ptr(dg.contiguous()), _ptr(dZ), _stream()), 'eagcn_pool_reduce_backward')
         return None, None, None, dZ

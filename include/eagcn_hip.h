@@ -233,6 +233,7 @@ typedef struct eagcn_gat_params {
     uint64_t seed;
     const float* W;                         /* [fin][F]  graph_conv.W                                                   */
     const float* a;                         /* [2F]      graph_conv.a                                                   */
+    const uint64_t* seed_dev;               /* optional: the seed is read from device memory (captured launches)       */
 } eagcn_gat_params;
 size_t eagcn_gat_scratch_bytes(const eagcn_batch* b, int F);
 int eagcn_gat_forward(const eagcn_batch* b, const eagcn_gat_params* p, const float* x, float* h, float* s12, float* xout,

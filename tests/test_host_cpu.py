@@ -80,8 +80,8 @@ def test_aliases_and_layer_count_extension():
     from eagcn_amd import EAGCN
     gat = EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, structure='GAT')     # baselines of models.py:63-73
     assert gat.layer4.graph_conv.W.shape == (40, 80) and gat.layer1.graph_conv.a.shape == (80, 1) and gat.den1.in_features == 80
-    with pytest.raises(ValueError):
-        EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, structure='GAT', graph=True)   # GAT runs on the eager engine
+    g2 = EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, structure='GAT', graph=True)   # captured layer-by-layer step
+    assert g2.graph and g2.structure == 'GAT'                                          # (graph_composed.ComposedRunner)
     with pytest.raises(ValueError):
         EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, structure='Pool')
 
@@ -225,8 +225,7 @@ def test_model_pickles_and_deepcopies_after_planning():
 
 def test_pool_constructor_contract():
     from eagcn_amd import EAGCN
-    with pytest.raises(ValueError):
-        EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, molfp_mode='pool', graph=True)
+    assert EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, molfp_mode='pool', graph=True).graph   # captured layer-by-layer step
     with pytest.raises(ValueError):
         EAGCN(28, 24, *[8] * 5, *[8] * 5, 8, 8, 1, 0.0, molfp_mode='pool', n_layers=2)       # A of layers.py:319-324 needs layer 4
     with pytest.raises(ValueError):
