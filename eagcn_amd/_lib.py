@@ -154,6 +154,8 @@ SIGNATURES = {
                                          _fp, _fp, _fp]),
     'eagcn_gemm_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int,
                                  _fp, C.c_int, _fp]),
+    'eagcn_gemm_f32_dev': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int,
+                                     _fp, C.c_int, _fp, C.c_int, _fp]),
     'eagcn_gemm_sk_workspace_bytes': (C.c_size_t, []),
     'eagcn_gemm_f32_sk': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int,
                                     _fp, C.c_int, _fp, C.c_size_t, _fp]),

@@ -429,3 +429,13 @@ extern "C" int eagcn_gemm_f32(int ta, int tb, int M, int N, int K, const float* 
     GemmDesc g{ta, tb, M, N, K, A, lda, B, ldb, C, ldc, 1, 0};
     return launch_gemm(g, (hipStream_t)stream);
 }
+
+// The same product with ONE extent taken from device memory (M and K are then capacities: grid and strides): which = 0: the
+// rows of A / C, which = 2: the reduction length.  Products over the packed rows of a capacity-sized batch index (graph mode).
+extern "C" int eagcn_gemm_f32_dev(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
+                                  int ldb, float* C, int ldc, const int32_t* extent_dev, int which, void* stream) {
+    EAGCN_CHECK_ARG(A && B && C && extent_dev && (which == 0 || which == 2), "eagcn_gemm_f32_dev: bad argument");
+    GemmDesc g{ta, tb, M, N, K, A, lda, B, ldb, C, ldc, 1, 0};
+    if (which == 0) g.M_dev = extent_dev; else g.K_dev = extent_dev;
+    return launch_gemm(g, (hipStream_t)stream);
+}

@@ -655,7 +655,7 @@ def pool_readout(index, layout, x, pad_row, w_feature, w_assign, mode='attention
         return torch.zeros((index.B, F), dtype=torch.float32, device=x.device)
     A, _rinv, padsum = _PoolAttention.apply(index, POOL_MODES[mode], ave_a, self_r, *att_w)
     AX = _PoolMix.apply(index, layout, A, padsum, x, pad_row)
-    Z = dense_mm(AX, torch.cat([w_feature, w_assign], dim=1))          # one flat GEMM for both bases (layers.py:40)
+    Z = dense_mm(AX, torch.cat([w_feature, w_assign], dim=1), index)   # one flat GEMM for both bases (layers.py:40)
     return _PoolReduce.apply(index, F, P, Z)
 
 
@@ -668,23 +668,26 @@ class _DenseMM(torch.autograd.Function):
     two backward products (dx = dy @ W^T, dW = x^T @ dy)."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, index=None):
         x = _need_cuda_f32(x, 'dense input')
         w = _need_cuda_f32(w, 'dense weight')
         ctx.save_for_backward(x, w)
-        return gemm(x, w)
+        ctx.index = index
+        return gemm(x, w, rows_of=index, which=0)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = gemm(dy, w, tb=True) if ctx.needs_input_grad[0] else None
-        dw = gemm(x, dy, ta=True) if ctx.needs_input_grad[1] else None
-        return dx, dw
+        dx = gemm(dy, w, tb=True, rows_of=ctx.index, which=0) if ctx.needs_input_grad[0] else None
+        dw = gemm(x, dy, ta=True, rows_of=ctx.index, which=2) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
 
 
-def dense_mm(x, w):
-    return _DenseMM.apply(x, w)
+def dense_mm(x, w, index=None):
+    """x @ w; with `index` the rows of x are the packed rows of that batch index: their count is read on the device (a
+    capacity-sized index of graph mode holds far fewer atoms than rows), rows beyond it are neither read nor written."""
+    return _DenseMM.apply(x, w, index)
 
 
 def _pad2(t, rows, cols):
@@ -695,9 +698,10 @@ def _pad2(t, rows, cols):
     return t if (pr == 0 and pc == 0) else torch.nn.functional.pad(t, (0, pc, 0, pr))
 
 
-def gemm(a, b, ta=False, tb=False):
+def gemm(a, b, ta=False, tb=False, rows_of=None, which=0):
     """C = op(A) @ op(B) on the fp32 matrix cores (no autograd; used by the head and by tests).
-    ta: A is stored [K,M]; tb: B is stored [N,K]."""
+    ta: A is stored [K,M]; tb: B is stored [N,K].  rows_of (a batch index): the extent `which` (0: rows of A and C, 2: the
+    reduction length) is the index's packed row count, read on the device."""
     M = a.shape[1] if ta else a.shape[0]
     Ka = a.shape[0] if ta else a.shape[1]
     N = b.shape[0] if tb else b.shape[1]
@@ -709,6 +713,14 @@ def gemm(a, b, ta=False, tb=False):
     Mp = a.shape[1] if ta else M
     Np = N if tb else b.shape[1]
     Kp = a.shape[0] if ta else a.shape[1]
+    if rows_of is not None:
+        # (zeros: the rows beyond the device-side count are not written)
+        c = torch.zeros((Mp, Np), dtype=torch.float32, device=a.device) if which == 0 else \
+            torch.empty((Mp, Np), dtype=torch.float32, device=a.device)
+        L.check(L.load().eagcn_gemm_f32_dev(int(ta), int(tb), Mp, Np, Kp, _ptr(a), a.shape[1], _ptr(b), b.shape[1], _ptr(c), Np,
+                                            C.c_void_p(int(rows_of.c.meta) + 4 * L.META_T), int(which), _stream()),
+                'eagcn_gemm_f32_dev')
+        return c if (Mp == M and Np == N) else c[:M, :N].contiguous()
     c = torch.empty((Mp, Np), dtype=torch.float32, device=a.device)
     L.check(L.load().eagcn_gemm_f32(int(ta), int(tb), Mp, Np, Kp, _ptr(a), a.shape[1], _ptr(b), b.shape[1],
                                     _ptr(c), Np, _stream()), 'eagcn_gemm_f32')

@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--dr', type=float, default=0.3)
     ap.add_argument('--print-freq', type=int, default=50)
     ap.add_argument('--n-train', type=int, default=8, help='distinct synthetic training batches (cycled)')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay of the step')
     ap.add_argument('--loader', default='dense', choices=('dense', 'compact'),
                     help="dense: the reference's collate tensors; compact: bond list + unpadded rows (collate_compact)")
     args = ap.parse_args()
@@ -64,11 +65,14 @@ def main():
     bce_w = None
     if task == 'class':
         bce_w = torch.tensor(training.set_weight(torch.cat([l.cpu() for _, l in train_set]), T), device=dev)
-    graph = args.arch != 'GAT' and args.molfp != 'pool'       # (those two run layer by layer on the eager engine)
+    # GAT and the pool read-out have no model-level plan: their graph mode is the captured layer-by-layer step
+    # (eagcn_amd/graph_composed.py), which takes the dense batch
+    composed = args.arch == 'GAT' or args.molfp == 'pool'
+    graph = not args.no_graph and not (composed and args.loader == 'compact')
     if args.molfp == 'pool' and args.arch in ('Concate', 'Weighted_sum'):
         args.layers = 4                                        # the pool read-out needs layer 4's attention matrix
     model = EAGCN(n_bfeat, 24, *w1, *w2, d1, d2, T, args.dr, structure=args.arch, molfp_mode=args.molfp, n_layers=args.layers,
-                  graph=graph, overlap_index=graph, validate='deferred' if graph else 'sync',
+                  graph=graph, overlap_index=graph and not composed, validate='deferred' if graph else 'sync',
                   n_bucket=16 if (args.loader == 'compact' and graph) else 0).to(dev)
     model.apply(weights_init)
     opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)

@@ -396,6 +396,10 @@ int eagcn_set_gemm_mode(int mode);
 /* C[M,N] = op(A).op(B); ta/tb: 0 = as stored, 1 = transposed; leading dimensions in floats */
 int eagcn_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
                    int ldb, float* C, int ldc, void* stream);
+/* the same product with one extent read from device memory (M / K are then capacities): which = 0 the rows of A and C,
+   which = 2 the reduction length -- products over the packed rows of a capacity-sized batch index (eagcn_batch.meta[0]) */
+int eagcn_gemm_f32_dev(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
+                       int ldb, float* C, int ldc, const int32_t* extent_dev, int which, void* stream);
 
 /* ---- persistent, balanced ("stream-K") form of the same products: the kernel the layer products run on ---------
  * A launch is a fixed grid; the iteration space (tiles x k-tiles, counted on the device) is cut into equal ranges, tiles
