@@ -307,7 +307,8 @@ extern "C" int eagcn_gat_forward(const eagcn_batch* b, const eagcn_gat_params* p
     if (b->T == 0) return EAGCN_OK;
     EAGCN_CHECK_ARG(x && h && s12 && xout, "eagcn_gat_forward: null buffer");
     const int Fp = pad16(p->F);
-    EAGCN_HIP(hipMemsetAsync(h, 0, (size_t)b->T * Fp * sizeof(float), s));        // (padding columns of h stay zero)
+    rc = zero_fill(h, (size_t)b->T * Fp * sizeof(float), s);                       // (padding columns of h stay zero)
+    if (rc) return rc;
     GemmDesc g{0, 0, b->T, p->F, p->fin, x, p->ld_in, p->W, p->F, h, Fp, 1, 0};
     g.M_dev = b->meta + EAGCN_META_T;
     rc = launch_gemm(g, s);
@@ -330,8 +331,10 @@ extern "C" int eagcn_gat_backward(const eagcn_batch* b, const eagcn_gat_params* 
     if (rc) return rc;
     EAGCN_CHECK_ARG(dW && da, "eagcn_gat_backward: null gradient buffer");
     if (b->T == 0) {
-        EAGCN_HIP(hipMemsetAsync(dW, 0, (size_t)p->fin * p->F * sizeof(float), s));
-        EAGCN_HIP(hipMemsetAsync(da, 0, (size_t)2 * p->F * sizeof(float), s));
+        rc = zero_fill(dW, (size_t)p->fin * p->F * sizeof(float), s);
+        if (rc) return rc;
+        rc = zero_fill(da, (size_t)2 * p->F * sizeof(float), s);
+        if (rc) return rc;
         return EAGCN_OK;
     }
     EAGCN_CHECK_ARG(x && h && s12 && xout && dxout && scratch, "eagcn_gat_backward: null buffer");
@@ -355,7 +358,8 @@ extern "C" int eagcn_gat_backward(const eagcn_batch* b, const eagcn_gat_params* 
     rc = launch_gemm(gw, s);
     if (rc) return rc;
     if (dx) {
-        EAGCN_HIP(hipMemsetAsync(dx, 0, (size_t)b->T * p->ld_in * sizeof(float), s));   // padding columns of dx
+        rc = zero_fill(dx, (size_t)b->T * p->ld_in * sizeof(float), s);               // padding columns of dx
+        if (rc) return rc;
         GemmDesc gx{0, 1, b->T, p->fin, p->F, sc.dh, Fp, p->W, p->F, dx, p->ld_in, 1, 0};
         gx.M_dev = b->meta + EAGCN_META_T;
         rc = launch_gemm(gx, s);

@@ -559,6 +559,20 @@ int gemm3_clear_flags(void* workspace, size_t bytes, hipStream_t s, double* zero
     return EAGCN_OK;
 }
 
+// Zero-fill by a KERNEL (see gemm3_clear_flags: a memset node of a captured graph is not ordered with its neighbours on replay):
+// every clear that can end up inside a captured sequence goes through here.  p 4-byte aligned, bytes a multiple of 4.
+__global__ void zero_words_kernel(unsigned* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+int zero_fill(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return EAGCN_OK;
+    EAGCN_CHECK_ARG(p && (bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 3) == 0, "zero_fill: unaligned region");
+    const size_t n = bytes / 4;
+    zero_words_kernel<<<(unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 4096)), 256, 0, s>>>((unsigned*)p, n);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
 int gemm3_zero_job(void* workspace, size_t bytes, double* zero, int nzero, ZeroJob* out) {
     float* ws; unsigned* flags;
     int rc = g3_prepare(workspace, bytes, &ws, &flags);
@@ -674,7 +688,7 @@ extern "C" int eagcn_gemm_pair_sk_slabs(int M0, int N0, int K0, const float* A0,
     EAGCN_CHECK_ARG(slab >= (size_t)M1 * ldc1, "eagcn_gemm_pair_sk_slabs: slab stride smaller than one matrix");
     GemmDesc g0{0, 1, M0, N0, K0, A0, lda0, B0, ldb0, C0, ldc0, 1, 0};
     GemmDesc g1{1, 0, M1, N1, K1, A1, lda1, B1, ldb1, C1, ldc1, 1, 0};
-    EAGCN_HIP(hipMemsetAsync(C1, 0, slab * G3_XSEG * sizeof(float), (hipStream_t)stream));
+    { int rcz = zero_fill(C1, slab * G3_XSEG * sizeof(float), (hipStream_t)stream); if (rcz) return rcz; }
     int rc = gemm3_clear_flags(workspace, workspace_bytes, (hipStream_t)stream);
     return rc ? rc : launch_gemm3_pair(g0, g1, nullptr, workspace, workspace_bytes, (hipStream_t)stream, slab);
 }

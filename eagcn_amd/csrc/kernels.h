@@ -133,6 +133,9 @@ int gemm3_failed();              // sticky, host-visible: a hand-off of some ear
 int gemm_mode();             // 0 fp32 MFMA (default, parity path) | 1 exact bf16 x 6 | 2 plain bf16 operands (gemm.hip)
 struct ZeroJob { unsigned* u; int nu; double* d; int nd; };
 int gemm3_zero_job(void* workspace, size_t bytes, double* zero, int nzero, ZeroJob* out);
+// zero-fill by a kernel (memset NODES of a captured graph are not ordered with their neighbours on replay, ROCm 7.x): for every
+// clear that can sit inside a captured sequence
+int zero_fill(void* p, size_t bytes, hipStream_t s);
 bool gemm3_ok(const GemmDesc& g);
 int launch_gemm3(const GemmDesc& g, const DwScatter* sc, void* workspace, size_t bytes, hipStream_t s);
 // xk_slab > 0: XCD-local schedule, dW leaves as G3_XSEG partial slabs dw.C + x * xk_slab (sc must be null)

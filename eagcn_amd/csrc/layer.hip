@@ -1233,7 +1233,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         // a batch without a single bond has no packed row: no product ran, the weight gradients are exactly zero (the edge
         // partials below are summed over zero workgroups; the BatchNorm gradients came from the row-less reduction above)
         for (int k = 0; k < p->K; ++k)
-            EAGCN_HIP(hipMemsetAsync(gp.dW[k], 0, (size_t)d.fin * p->width[k] * sizeof(float), side));
+            { int rcz = zero_fill(gp.dW[k], (size_t)d.fin * p->width[k] * sizeof(float), side); if (rcz) return rcz; }
     }
     {
         const int wblocks = nsplit > 0 ? cdiv((int)d.wslab * (xk_G > 0 ? 1 : 4), 256) : 0;     // (four lanes per element, unpack_grads)

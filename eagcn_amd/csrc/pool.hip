@@ -429,7 +429,7 @@ extern "C" int eagcn_pool_attention_backward(const eagcn_batch* b, const eagcn_p
     }
     ProfScope ps(PROF_READOUT, s);
     double* acc = (double*)scratch;
-    EAGCN_HIP(hipMemsetAsync(acc, 0, POOL_ACC * sizeof(double), s));
+    { int rcz = zero_fill(acc, POOL_ACC * sizeof(double), s); if (rcz) return rcz; }       // (a kernel: see kernels.h zero_fill)
     const int grid = std::max(1, std::min(rows_grid(b), 512));
     pool_att_bwd_kernel<<<grid, 256, 0, s>>>(*b, pool_att(p), A, lda, rinv, dA, acc);
     EAGCN_LAUNCH_CHECK();
