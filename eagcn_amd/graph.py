@@ -31,6 +31,9 @@ _RING = 4
 # the head / BatchNorm backward (latency chains on a few CUs) instead of beside the layer products (measured round 2:
 # 0.5228 -> 0.5175 ms/step at B=256, 1.2386 -> 1.2162 at B=1024; the wave-per-SIMD GEMM is sensitive to co-runners)
 _SIDE_AFTER_FWD = os.environ.get('EAGCN_SIDE_AFTER_FWD', '1') == '1'
+# a data-parallel step whose gradient all-reduce cannot be captured into the step graph is an ERROR instead of a (warned)
+# fallback to a host-issued collective: bench.py --require-in-graph-allreduce, tools/run_scale.sh
+_REQUIRE_IN_GRAPH = os.environ.get('EAGCN_REQUIRE_IN_GRAPH_ALLREDUCE', '0') == '1'
 
 
 class StaticIndex:
@@ -537,6 +540,7 @@ class GraphRunner:
             torch.cuda.synchronize(self.device)
             L.load().eagcn_prof_enable(0)
             g = torch.cuda.CUDAGraph()
+            captured, failure = True, None
             try:
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self._call_forward()
@@ -545,11 +549,25 @@ class GraphRunner:
                         self._call_backward_comm(comm)
                     else:
                         self._call_backward()
-                if in_graph:
-                    self.comm_in_graph = True
-            except Exception:
+            except L.EagcnHipError:
+                raise                                         # one of OUR launches failed: never hidden behind a re-capture
+            except Exception as e:                            # noqa: BLE001 -- the capture of the collective failed on this stack
                 if not in_graph:
                     raise
+                captured, failure = False, e
+            if in_graph:
+                # every rank must replay the SAME collective sequence: a rank whose capture failed while the others replay
+                # in-graph all-reduces would hang them.  One MIN-reduction of the success flag decides for all ranks.
+                ok = comm.agree(captured)
+                if ok:
+                    self.comm_in_graph = True
+                elif _REQUIRE_IN_GRAPH:
+                    raise L.EagcnHipError('the gradient all-reduce could not be captured into the step graph on every rank '
+                                          '(EAGCN_REQUIRE_IN_GRAPH_ALLREDUCE=1): %r' % (failure,))
+            if in_graph and not self.comm_in_graph:
+                import warnings
+                warnings.warn('eagcn_amd: the gradient all-reduce could not be captured into the step graph (%r); falling back '
+                              'to one host-issued all-reduce behind every replay' % (failure,), RuntimeWarning)
                 # the collective could not be captured: step graph without it, host-issued all-reduce behind every replay
                 torch.cuda.synchronize(self.device)
                 self.comm_in_graph, in_graph = False, False

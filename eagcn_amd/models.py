@@ -383,8 +383,9 @@ class EAGCN(nn.Module):
         if kind == 'bce' and not isinstance(bce_weight, torch.Tensor):
             if bce_weight is None:
                 raise ops.L.EagcnHipError('fused_step: the classification loss needs bce_weight ([T,2]; training.set_weight)')
-            # the list set_weight returns (utils.py:681-700), as the eager losses accept it; converted once per list object
-            key = id(bce_weight)
+            # the list set_weight returns (utils.py:681-700), as the eager losses accept it; converted once per CONTENT (2 T floats:
+            # a list object's id can be recycled, and a list can be edited in place)
+            key = tuple(tuple(float(v) for v in row) for row in bce_weight)
             if getattr(self, '_bce_weight_cache', (None, None))[0] != key:
                 self._bce_weight_cache = (key, torch.tensor(bce_weight, dtype=torch.float32, device=afms.device))
             bce_weight = self._bce_weight_cache[1]
@@ -469,6 +470,13 @@ class EAGCN(nn.Module):
                 atom_representations = atom_representations.cpu()
         return out, atom_representations, graph_representation
 
+    def release_graphs(self):
+        """Destroy every captured HIP graph and static buffer of this model NOW (they are rebuilt by the next forward).  Orderly
+        shutdown of a data-parallel run: the step graphs hold RCCL kernels and must be gone before the process group."""
+        runners, self._runners = self._runners, {}
+        for r in runners.values():
+            r.release()
+
     def flat_grad_buffer(self):
         """The single fp32 buffer that holds every hot-path parameter gradient after a backward in
         grad_mode='direct' or graph mode (``p.grad`` are views of it); None otherwise."""
@@ -476,6 +484,8 @@ class EAGCN(nn.Module):
             return next((i for i, p in enumerate(plan.params) if p.requires_grad), None)
         if self.graph and self._runners:
             for r in self._runners.values():
+                if not hasattr(r, 'flat_acc'):       # graph_composed.ComposedRunner (GAT / pool): gradients live in its graph's pool
+                    continue
                 i = first_live(r.plan)
                 if i is not None and r.plan.params[i].grad is r.acc_views[i]:
                     return r.flat_acc

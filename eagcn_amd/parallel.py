@@ -173,6 +173,16 @@ class GradientAllReducer:
             return False
         return dist.get_world_size(self.group) > 1 or os.environ.get('EAGCN_FORCE_DIST', '0') == '1'
 
+    def agree(self, ok):
+        """True iff `ok` holds on EVERY rank (one MIN-reduction of a flag; host sync).  Used once per captured step graph: a
+        rank whose capture of the in-graph collective failed must not leave the others replaying collectives it never issues."""
+        if not dist.is_initialized():
+            return bool(ok)
+        dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(self.group) == 'nccl' else torch.device('cpu')
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
+
     def start(self, t):
         """Asynchronous in-place average of a contiguous device tensor (a bucket of the flat gradient buffer): returns the
         work handle; ``.wait()`` orders the current stream behind it.  Capturable: inside a HIP-graph capture the collective

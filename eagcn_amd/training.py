@@ -122,6 +122,11 @@ def train_step(model, optimizer, batch, labels, task, bce_weight=None, dp_global
     optimizer.zero_grad(set_to_none=True)
     if fused is None:
         fused = bool(getattr(model, 'graph', False)) and model.training and hasattr(model, 'fused_step')
+        # the captured step of the GAT / pool models (graph_composed) takes no reducer and no 'dp' scale: those go through the
+        # unfused path below, which handles both
+        composed = getattr(model, 'structure', None) == 'GAT' or getattr(model, 'molfp_mode', None) == 'pool'
+        if fused and composed and (reducer is not None or dp_global_norm):
+            fused = False
     if fused:
         # the global BCE normalisation ('dp': a 1-element collective issued with the batch's preparatory work) and the gradient
         # average (captured into the step graph, upper bucket overlapped with the first layer's backward) are part of the step

@@ -44,5 +44,12 @@ assert abs(res['plain'][0] - res['dist'][0]) <= 1e-6 * max(1.0, abs(res['plain']
 for k, g in res['plain'][1].items():
     d = (res['dist'][1][k] - g).abs().max().item()
     assert d <= 1e-6 * max(g.abs().max().item(), 1e-30) + 1e-12, (k, d)
+# same shutdown order as tests/dist_multi_check.py: graphs and buffers, then the process group, then out through os._exit
+torch.cuda.synchronize()
+model.release_graphs()
+del model, red
 dist.destroy_process_group()
-print('DIST_WORLD1_OK')
+print('DIST_WORLD1_OK', flush=True)
+sys.stdout.flush()
+sys.stderr.flush()
+os._exit(0)

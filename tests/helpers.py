@@ -96,17 +96,33 @@ def assert_grad_close(got, ref, scale, name='', rtol=2e-5, floor=1e-6):
     assert err <= bound, (name, err, bound)
 
 
-ARBITRATED = []       # (test, tensor, e_hip64/own, e_ref64/own, ratio): every gradient that needed the fp64 oracle
+VIOLATIONS = []       # EAGCN_PARITY_COLLECT=1: (test, tensor, ratio, allowed, plain error / own max) of every tensor beyond its bound
+ARBITRATED = []       # (test, tensor, e_hip64/own, e_ref64/own, ratio, known bound or None): every gradient that needed the fp64 oracle
 
 
-def assert_grad_parity(got, ref32, ref64_fn, scale, name, rtol=1e-5, floor=2e-6, slack=2.0, note=''):
-    """Three-way gradient parity (VERDICT round 2, item 5).  Passes when
+def f64_grads(ref, run):
+    """Parameter gradients of a float64 twin of the oracle module `ref` (same parameters and buffers) under
+    ``run(model, cast)``; ``cast`` turns a float32 tensor into float64 and leaves everything else alone.  The exact answer the
+    three-way comparison of assert_grad_parity measures both fp32 evaluations against."""
+    import copy
+    twin = copy.deepcopy(ref).double()
+    twin.zero_grad(set_to_none=True)
+    twin.train(ref.training)
+    run(twin, lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t)
+    return {k: p.grad.detach() for k, p in twin.named_parameters() if p.grad is not None}
+
+
+def assert_grad_parity(got, ref32, ref64_fn, scale, name, rtol=1e-5, floor=2e-6, slack=1.0, note='', known=None):
+    """Three-way gradient parity.  Passes when
         |got - ref32|_max <= rtol * |ref32|_max + floor * scale          (plain: 1e-5 of the tensor's OWN largest entry; the
                                                                           floor covers analytically-zero gradients), or
         |got - ref64|_max <= slack * |ref32 - ref64|_max + 1e-6 * scale  (the HIP gradient is as close to the exact one as
-                                                                          the fp32 reference itself is).
+                                                                          the fp32 reference itself is: slack = 1).
     ref64_fn() -> the float64 oracle's gradient of the same tensor (evaluated only when the plain test fails).  Every
-    arbitrated tensor is recorded with both errors and printed in the terminal summary."""
+    arbitrated tensor is recorded with both errors and printed in the terminal summary.
+    `known`: {tensor name: bound} -- the NAMED exceptions of a test: tensors measured farther from the float64 gradient than
+    the fp32 reference is (ratio > 1), each with the bound its measured ratio is held to (measured x 1.1), so that a
+    regression of such a tensor shows instead of disappearing under a blanket slack."""
     got = torch.as_tensor(got, dtype=torch.float64).cpu()
     ref32 = torch.as_tensor(ref32, dtype=torch.float64)
     assert got.shape == ref32.shape, (name, got.shape, ref32.shape)
@@ -122,5 +138,18 @@ def assert_grad_parity(got, ref32, ref64_fn, scale, name, rtol=1e-5, floor=2e-6,
     e_ref = (ref32 - ref64).abs().max().item()
     o64 = max(ref64.abs().max().item(), 1e-300)
     test = os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]
-    ARBITRATED.append((test, name + note, e_hip / o64, e_ref / o64, e_hip / max(e_ref, 1e-300)))
-    assert e_hip <= slack * e_ref + 1e-6 * float(scale), (name, 'e_hip', e_hip, 'e_ref', e_ref, 'vs fp64; plain error', err, 'bound', bound)
+    kb = None
+    if known:
+        for key, val in known.items():
+            if key == name or name.endswith(' ' + key) or name.startswith(key + ' '):
+                kb = float(val)
+    ARBITRATED.append((test, name + note, e_hip / o64, e_ref / o64, e_hip / max(e_ref, 1e-300), kb))
+    lim = kb if kb is not None else slack
+    ok = e_hip <= lim * e_ref + 1e-6 * float(scale)
+    if not ok and os.environ.get('EAGCN_PARITY_COLLECT', '0') == '1':
+        # survey mode (one GPU run lists EVERY tensor beyond its bound instead of stopping at the first): recorded, printed in
+        # the terminal summary, and the session fails at its end (tests/conftest.py)
+        VIOLATIONS.append((test, name + note, e_hip / max(e_ref, 1e-300), lim, err / max(rmax, 1e-300)))
+        return
+    assert ok, (name, 'e_hip', e_hip, 'e_ref', e_ref, 'ratio', e_hip / max(e_ref, 1e-300),
+                'allowed', lim, 'vs fp64; plain error', err, 'bound', bound)

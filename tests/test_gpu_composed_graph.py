@@ -106,3 +106,37 @@ def test_replays_draw_fresh_dropout_masks_and_eval_graph_equals_eager_eval(case)
             _close(g_g, g_e, '%s eval graph_rep' % case)
     runner = next(iter(graph._runners.values()))
     assert runner.eval_graph is not None and runner.replays == 7
+
+
+@pytest.mark.parametrize('case', ['GAT-sum', 'Concate-pool'])
+def test_gradient_reducer_and_train_step_on_a_composed_graph_model(case):
+    """The data-parallel helpers on a graph-mode GAT / pool model: its runners are ComposedRunners (no flat gradient buffer):
+    flat_grad_buffer() answers None instead of raising, GradientAllReducer falls back to its generic path, and
+    training.train_step with a reducer / the global loss normalisation takes the unfused path (the captured step of these
+    models accepts neither) and yields the same gradients as the captured step."""
+    from eagcn_amd.parallel import GradientAllReducer
+    from eagcn_amd.training import train_step
+    _, graph = _models(case, 0.0)
+    dense, labels, bw = _batch(7)
+    for p in graph.parameters():
+        p.grad = None
+    loss0, _ = graph.fused_step(dense, labels, 'class', bw)          # a ComposedRunner now sits in graph._runners
+    want = {k: p.grad.clone() for k, p in graph.named_parameters() if p.grad is not None}
+    assert graph.flat_grad_buffer() is None
+    red = GradientAllReducer(graph.parameters(), model=graph)
+    assert red._model_flat_buffer() is None
+    red()                                                            # (no process group: a no-op, but it must not raise)
+
+    class _NoStep:                                                   # the gradients are compared, not a parameter update
+        def zero_grad(self, set_to_none=True):
+            for p in graph.parameters():
+                p.grad = None
+
+        def step(self):
+            pass
+    sd = {k: v.clone() for k, v in graph.state_dict().items()}
+    graph.load_state_dict(sd)
+    loss1 = train_step(graph, _NoStep(), dense, labels, 'class', bw, dp_global_norm=True, reducer=red)
+    _close(loss1.detach(), loss0.detach(), 'loss')
+    for k, g in want.items():
+        _close(dict(graph.named_parameters())[k].grad, g, k, tol=1e-5)

@@ -37,12 +37,6 @@ def _run_multi(world, port):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840)
     if r.returncode != 0 or r.stdout.count('DIST_MULTI_OK') != world:
         _dump('dist_multi_world%d_rc%d' % (world, r.returncode), r)
-    if r.returncode < 0 and r.stdout.count('DIST_MULTI_OK') == world:
-        # every check passed on every rank and the interpreter was killed by a signal on its way out (seen once in ~25 runs
-        # on a 1-GPU box: SIGABRT from a background thread of the process group while the process was exiting; the outputs
-        # are kept under gpurun_out/).  The numerical checks are what this test is about: report it, do not fail on it.
-        print('NOTE: rank process(es) ended with signal %d after all checks had passed; outputs saved' % -r.returncode)
-        return r.stdout
     assert r.returncode == 0 and r.stdout.count('DIST_MULTI_OK') == world, (r.stdout[-3000:], r.stderr[-4000:])
     return r.stdout
 

@@ -96,4 +96,7 @@ def test_engine_composition_and_graph_agree_at_full_size(name):
     for i, (out, g) in enumerate(res[1:], 1):
         assert rel_err(out.cpu(), ref_out.cpu(), '%s run %d' % (name, i)) < 1e-5, i
         for k in ref_g:
-            assert_grad_close(g[k], ref_g[k].cpu(), scale, '%s (run %d)' % (k, i), rtol=1e-4, floor=2e-5)
+            # HIP path against HIP path (no oracle finishes at these sizes): 1e-5 of the tensor's own largest entry plus a floor of
+            # 1e-5 of the case's largest gradient for the re-associated sums of the two routes (fused / separate read-out, slab
+            # order)
+            assert_grad_close(g[k], ref_g[k].cpu(), scale, '%s (run %d)' % (k, i), rtol=1e-5, floor=1e-5)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_grad_parity, Golden, assert_grad_close, build_oracle_model, golden_cases, rel_err
+from helpers import assert_grad_parity, f64_grads, Golden, assert_grad_close, build_oracle_model, golden_cases, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -20,6 +20,18 @@ def _hip_model(meta, n_layers=4):
     return EAGCN(meta['n_bfeat'], meta['n_afeat'], *meta['widths1'], *meta['widths2'], meta['dens'][0],
                  meta['dens'][1], meta['nclass'], 0.0, structure=meta['structure'], molfp_mode=meta['molfp'],
                  n_layers=n_layers)
+
+
+# Named exceptions of the three-way gradient comparison (helpers.assert_grad_parity): the tensors measured FARTHER from the float64
+# gradient than the reference's own fp32 gradient is, each held to its measured ratio x 1.1.  Every other gradient of every
+# case is either within 1e-5 of the fp32 reference (relative to the tensor's own largest entry) or at most as far from the
+# float64 gradient as the fp32 reference is (ratio <= 1).  A tensor regressing beyond its entry fails its test.
+KNOWN_FARTHER = {
+    # both evaluations of a 28-row BatchNorm four layers deep: 1.7e-5 vs 5.0e-6 of the tensor's own max (measured ratio 3.65)
+    'model_concate_isolated': {'layer2.block4.batch_norm.bn.weight': 4.0},
+    # a view whose BatchNorm sees 3 x 270 rows: 1.4e-3 vs 4.2e-4 (measured ratio 3.3)
+    'tox21_shape[Concate-2-3-270]': {'layer2.block4.graph_conv.weight': 3.7},
+}
 
 
 def _f64_grads(g):
@@ -127,12 +139,11 @@ def test_model_golden(name):
         if not f64:
             f64.update(_f64_grads(g))
         return f64[k]
-    # measured (gpurun_out/r3g): of the ~80 tensors that need the arbitration across all fixtures, all but one are 2-15x CLOSER to
-    # the float64 gradient than the reference's own fp32 gradient (ratios 0.06-0.55); the isolated-atoms case holds the exception
-    # (layer2.block4.batch_norm.bn.weight: 1.7e-5 vs 5.0e-6 of its own max, both evaluations of a 28-row BatchNorm four layers deep)
-    slack = 4.0 if name == 'model_concate_isolated' else 1.0
+    # measured: of the ~80 tensors that need the arbitration across all fixtures, all but the NAMED ones (KNOWN_FARTHER) are
+    # 2-15x CLOSER to the float64 gradient than the reference's own fp32 gradient (ratios 0.06-0.55)
     for k, ref in grads.items():
-        assert_grad_parity(got[k], ref, lambda k=k: exact(k), scale, k, rtol=1e-5, floor=2e-6, slack=slack)
+        assert_grad_parity(got[k], ref, lambda k=k: exact(k), scale, k, rtol=1e-5, floor=2e-6, slack=1.0,
+                           known=KNOWN_FARTHER.get(name))
     sd = model.state_dict()
     for k, ref in g.group('sd_after/').items():
         assert rel_err(sd[k].double().cpu(), ref) < TOL, k
@@ -201,11 +212,64 @@ def test_model_vs_oracle_tox21_shape(structure, n_layers, B, n_max):
         assert e_hip <= 3e-6, (e_hip, e_ref)
     assert set(g32) == set(gh)
     scale = max(v.abs().max().item() for v in g32.values())
-    # (HIP is 2-10x closer to the float64 gradient than the fp32 CPU oracle in every arbitrated tensor except one of the 3-molecule
-    #  270-atom case: layer2.block4.graph_conv.weight 1.4e-3 vs 4.2e-4 -- a view whose BatchNorm sees 3 x 270 rows)
-    slack = 4.0 if (B, n_max) == (3, 270) else 1.0
+    # (HIP is 2-10x closer to the float64 gradient than the fp32 CPU oracle in every arbitrated tensor except the named ones)
     for k in gh:
-        assert_grad_parity(gh[k], g32[k], lambda k=k: exact()['g'][k], scale, k, rtol=1e-5, floor=2e-6, slack=slack)
+        assert_grad_parity(gh[k], g32[k], lambda k=k: exact()['g'][k], scale, k, rtol=1e-5, floor=2e-6, slack=1.0,
+                           known=KNOWN_FARTHER.get('tox21_shape[%s-%d-%d-%d]' % (structure, n_layers, B, n_max)))
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_configs0_shape_single_task_bce_vs_oracle(graph):
+    """BASELINE.json configs[0] on the HIP path: Tox21 widths 80 / 140, 2-layer 5-view Concate, ONE task, batch 64, N_pad 132,
+    the weighted masked BCE of train.py:326-331 (fused loss kernel) -- loss, outputs and every gradient against the oracle."""
+    from eagcn_amd import EAGCN, losses
+    from eagcn_amd.synthetic import bce_weights, make_batch
+    from oracle.eagcn_ref import RefEAGCN, classification_loss, weights_init_
+    torch.manual_seed(8)
+    w1, w2 = [80] * 5, [140] * 5
+    mb = make_batch(B=64, n_max=132, n_med=16, rel_channels=(28, 4, 2, 2, 2), seed=64, n_tasks=1)
+    ref = RefEAGCN(28, 24, w1, w2, 256, 64, 1, 0.0, n_layers=2)
+    weights_init_(ref)
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    hip = EAGCN(28, 24, *w1, *w2, 256, 64, 1, 0.0, n_layers=2, grad_mode='direct', graph=graph).cuda().train()
+    hip.load_state_dict(sd0, strict=True)
+    cpu = mb.dense()
+    labels = torch.from_numpy(mb.labels)
+    bw = bce_weights(1)
+    out_r, _, gr_r = ref(*cpu)
+    loss_r = classification_loss(out_r, labels, bw)
+    loss_r.backward()
+    g32 = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    x64 = {}
+
+    def exact():
+        if not x64:
+            def run(m, c):
+                o = m(*[c(t) for t in cpu])[0]
+                wt = c(torch.as_tensor(bw, dtype=torch.float32))
+                wv = ((labels == 1).double() * wt[:, 0].view(1, -1) + (labels == 0).double() * wt[:, 1].view(1, -1)).view(-1)
+                n = ((labels == 1) | (labels == 0)).sum().double()
+                (torch.nn.functional.binary_cross_entropy_with_logits(o.view(-1), labels.double().view(-1), weight=wv,
+                                                                      reduction='sum') / n).backward()
+            x64.update(f64_grads(ref, run))
+        return x64
+    scale = max(v.abs().max().item() for v in g32.values())
+    for rep in range(3 if graph else 1):
+        hip.load_state_dict(sd0, strict=True)
+        for p in hip.parameters():
+            p.grad = None
+        out_h, _, gr_h = hip(*_dev(cpu))
+        loss_h = losses.fused_classification_loss(out_h, labels.cuda(), torch.tensor(bw, device='cuda'))
+        loss_h.backward()
+        tag = 'configs0 %s%d' % ('graph' if graph else 'eager', rep)
+        assert rel_err(out_h.detach().cpu(), out_r.detach(), tag + ' out') < TOL
+        assert rel_err(gr_h.detach().cpu(), gr_r.detach(), tag + ' graph_rep') < TOL
+        assert abs(float(loss_h.detach()) - float(loss_r)) <= 1e-5 * max(1.0, abs(float(loss_r)))
+        gh = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+        assert set(gh) == set(g32)
+        for k in gh:
+            assert_grad_parity(gh[k], g32[k], lambda k=k: exact()[k], scale, '%s %s' % (tag, k), rtol=1e-5, floor=2e-6,
+                               known=KNOWN_FARTHER.get('configs0'))
 
 
 @pytest.mark.parametrize('T,FIN,FP', [(4809, 400, 704), (64, 400, 704), (37, 128, 144), (1000, 256, 80), (20003, 400, 704),
@@ -685,6 +749,12 @@ def test_view_counts_other_than_five(K, structure):
     (out_r * gsel).sum().backward()
     gr = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
     scale = max(v.abs().max().item() for v in gr.values())
+    x64 = {}
+
+    def exact():
+        if not x64:
+            x64.update(f64_grads(ref, lambda m, c: (m(*[c(t) for t in cpu])[0] * c(gsel)).sum().backward()))
+        return x64
     for graph in (False, True):
         hip = EAGCN(chans[0], 24, n_den1=20, n_den2=10, nclass=2, dropout=0.0, structure=structure, n_layers=2,
                     widths1=w1, widths2=w2, rel_channels=chans, grad_mode='direct', graph=graph).cuda().train()
@@ -696,7 +766,8 @@ def test_view_counts_other_than_five(K, structure):
         gh = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
         assert set(gr) == set(gh)
         for k in gr:
-            assert_grad_close(gh[k], gr[k], scale, '%s (graph=%s)' % (k, graph), rtol=1e-4, floor=5e-6)
+            assert_grad_parity(gh[k], gr[k], lambda k=k: exact()[k], scale, '%s (graph=%s)' % (k, graph), rtol=1e-5, floor=2e-6,
+                               known=KNOWN_FARTHER.get('view_counts[%d-%s]' % (K, structure)))
 
 
 # ---- BASELINE.json configs at their stated widths / padding, against the CPU oracle ---------------------------------
@@ -850,8 +921,6 @@ def test_compact_input_golden(name, graph):
     g = Golden(name)
     if g.meta['loss'] != 'proj':
         pytest.skip('loss fixtures are covered by test_fused_losses_golden')
-    if graph and g.meta['molfp'] == 'pool':
-        pytest.skip("molfp_mode='pool' runs on the eager engine only")
     model = _hip_model(g.meta)
     model.grad_mode, model.graph = 'direct', graph
     model.load_state_dict(g.state_dict(), strict=True)
@@ -870,16 +939,15 @@ def test_compact_input_golden(name, graph):
      (graph_rep * torch.from_numpy(g.z['gout_graph_rep']).cuda()).sum()).backward()
     got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
     assert set(got) == set(grads)
-    f64 = None
+    f64 = {}
+
+    def exact(k):
+        if not f64:
+            f64.update(_f64_grads(g))
+        return f64[k]
     for k, ref in grads.items():
-        try:
-            assert_grad_close(got[k], ref, scale, k, rtol=2e-5, floor=2e-6)
-        except AssertionError:
-            if f64 is None:
-                f64 = _f64_grads(g)
-            e_ref = (torch.from_numpy(ref).double() - f64[k]).abs().max().item()
-            e_hip = (got[k].double().cpu() - f64[k]).abs().max().item()
-            assert e_hip <= 4.0 * e_ref + 2e-6 * scale, (k, e_hip, e_ref)
+        assert_grad_parity(got[k], ref, lambda k=k: exact(k), scale, k, rtol=1e-5, floor=2e-6, slack=1.0,
+                           known=KNOWN_FARTHER.get(name))
 
 
 @pytest.mark.parametrize('name', ['model_concate_eval', 'model_weighted_eval'])
@@ -1067,6 +1135,12 @@ def test_gcn_baseline_graph_mode_and_training_vs_oracle():
         ref.zero_grad()
         out_r, _, gr_r = ref(*dense)
         regression_loss(out_r, labels).backward()
+        x64 = {}
+
+        def exact(dense=dense, labels=labels, x64=x64):
+            if not x64:
+                x64.update(f64_grads(ref, lambda m, c: regression_loss(m(*[c(t) for t in dense])[0], c(labels)).backward()))
+            return x64
         for graph, m in models.items():
             for p in m.parameters():
                 p.grad = None
@@ -1079,7 +1153,8 @@ def test_gcn_baseline_graph_mode_and_training_vs_oracle():
             for k, p in ref.named_parameters():
                 if p.grad is None:
                     continue
-                assert_grad_close(got[k].grad.cpu(), p.grad.numpy(), scale, k + ' (graph=%s)' % graph, rtol=1e-4, floor=5e-6)
+                assert_grad_parity(got[k].grad.cpu(), p.grad, lambda k=k: exact()[k], scale, k + ' (graph=%s)' % graph,
+                                   rtol=1e-5, floor=2e-6, known=KNOWN_FARTHER.get('gcn_baseline'))
     sd_r = ref.state_dict()
     for graph, m in models.items():
         for k, v in m.state_dict().items():
@@ -1183,6 +1258,15 @@ def test_batch_without_any_bond(structure):
             ref.zero_grad()
             out_r, _, gr_r = ref(*dense)
             (out_r.sum() + gr_r.sum()).backward()
+            x64 = {}
+
+            def exact(dense=dense, x64=x64):
+                if not x64:
+                    def run(mm, c):
+                        o, _, g_ = mm(*[c(t) for t in dense])
+                        (o.sum() + g_.sum()).backward()
+                    x64.update(f64_grads(ref, run))
+                return x64
             for p in m.parameters():
                 p.grad = None
             out, atom_rep, gr = m(*_dev(dense))
@@ -1204,7 +1288,8 @@ def test_batch_without_any_bond(structure):
                     # BatchNorms see zero variance and every pre-activation sits exactly ON the relu boundary, where the
                     # gradient is decided by the last bit of (x - mean) -- not a property of the kernels
                     continue
-                assert_grad_close(g.cpu(), p.grad.numpy(), max(scale, 1e-3), '%s (%s)' % (k, tag), rtol=1e-4, floor=5e-6)
+                assert_grad_parity(g.cpu(), p.grad, lambda k=k: exact()[k], max(scale, 1e-3), '%s (%s)' % (k, tag), rtol=1e-5,
+                                   floor=2e-6, known=KNOWN_FARTHER.get('no_bond[%s]' % structure))
         sd_r = ref.state_dict()
         for k, v in m.state_dict().items():
             if 'running' in k:
@@ -1237,9 +1322,19 @@ def test_maximum_sizes(n_max, channels):
     assert rel_err(atom_rep.cpu(), atom_r, 'atom_rep') < 1e-5
     got = dict(m.named_parameters())
     scale = max(p.grad.abs().max().item() for p in ref.parameters() if p.grad is not None)
+    x64 = {}
+
+    def exact():
+        if not x64:
+            def run(mm, c):
+                o, _, g_ = mm(*[c(t) for t in dense])
+                (o.sum() + g_.sum()).backward()
+            x64.update(f64_grads(ref, run))
+        return x64
     for k, p in ref.named_parameters():
         if p.grad is not None:
-            assert_grad_close(got[k].grad.cpu(), p.grad.numpy(), scale, k, rtol=1e-4, floor=5e-6)
+            assert_grad_parity(got[k].grad.cpu(), p.grad, lambda k=k: exact()[k], scale, k, rtol=1e-5, floor=2e-6,
+                               known=KNOWN_FARTHER.get('maximum_sizes[%d-%d]' % (n_max, channels[0])))
 
 
 @pytest.mark.gpu
@@ -1285,6 +1380,16 @@ def test_self_loops_and_directed_bonds_dense_signature():
     assert rel_err(atom_rep.cpu(), atom_r, 'atom_rep') < 1e-5
     got = dict(m.named_parameters())
     scale = max(p.grad.abs().max().item() for p in ref.parameters() if p.grad is not None)
+    x64 = {}
+
+    def exact():
+        if not x64:
+            def run(mm, c):
+                o, _, g_ = mm(*[c(t) for t in dense])
+                (o.sum() + g_.sum()).backward()
+            x64.update(f64_grads(ref, run))
+        return x64
     for k, p in ref.named_parameters():
         if p.grad is not None:
-            assert_grad_close(got[k].grad.cpu(), p.grad.numpy(), scale, k, rtol=1e-4, floor=5e-6)
+            assert_grad_parity(got[k].grad.cpu(), p.grad, lambda k=k: exact()[k], scale, k, rtol=1e-5, floor=2e-6,
+                               known=KNOWN_FARTHER.get('self_loops'))
