@@ -79,7 +79,7 @@ class LayerBufs(C.Structure):
     _fields_ = [('x', _fp), ('P', _fp), ('Y', _fp), ('rscale', _fp), ('bn', _fp), ('xout', _fp),
                 ('pad_row', _fp), ('scratch', _fp), ('scratch_bytes', C.c_size_t),
                 ('aux_stream', _fp), ('packed', _fp), ('packed_bytes', C.c_size_t),
-                ('stats_hook', _fp), ('stats_user', _fp)]
+                ('stats_hook', _fp), ('stats_user', _fp), ('x_planes', _fp), ('xout_planes', _fp)]
 
 
 class LayerGrads(C.Structure):
@@ -128,6 +128,12 @@ SIGNATURES = {
     'eagcn_index_from_bonds': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.POINTER(Batch), _fp, _fp]),
     'eagcn_index_rows': (C.c_int, [C.POINTER(Batch), _fp]),
     'eagcn_set_gemm_mode': (C.c_int, [C.c_int]),
+    'eagcn_bx3_split': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_size_t, C.c_int, _fp]),
+    'eagcn_gemm_bx3': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, C.c_int, _fp, C.c_size_t, C.c_int, _fp, C.c_int,
+                                 C.c_int, C.c_size_t, C.c_int, _fp]),
+    'eagcn_gemm_bx3_pair': (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, C.c_int, _fp, C.c_size_t, C.c_int, _fp, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, C.c_int, _fp, C.c_size_t, C.c_int, _fp, C.c_int,
+                                      C.c_int, C.c_size_t, C.c_int, _fp]),
     'eagcn_pack_rows': (C.c_int, [C.POINTER(Batch), _fp, C.c_int, C.POINTER(Layout), _fp, _fp]),
     'eagcn_unpack_rows': (C.c_int, [C.POINTER(Batch), _fp, C.POINTER(Layout), _fp, _fp, C.c_int, _fp]),
     'eagcn_pad_rows': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),

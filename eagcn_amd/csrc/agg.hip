@@ -189,6 +189,17 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
         for (int g = 0; g < 4; ++g) {
             const int row = rt * 16 + q * 4 + g;
             if (row < n) {
+                if (TRANS && a.planes.p) {            // dP for the plane GEMMs (gemm_bx3.hip): split here, once
+                    const size_t e0 = (size_t)(r0 + row) * a.ldd + c0;
+#pragma unroll
+                    for (int m = 0; m < Q; ++m)
+                        if (m * 64 + 4 * li < ncol)
+                            bx_store4(a.planes, e0 + m * 64 + 4 * li, make_float4(acc[4 * m][g], acc[4 * m + 1][g], acc[4 * m + 2][g], acc[4 * m + 3][g]));
+#pragma unroll
+                    for (int ct = 4 * Q; ct < CT; ++ct)
+                        if (lane_col(ct) < ncol) bx_store1(a.planes, e0 + lane_col(ct), acc[ct][g]);
+                    continue;
+                }
                 float* drow = a.dst + (size_t)(r0 + row) * a.ldd + c0;
 #pragma unroll
                 for (int m = 0; m < Q; ++m)
@@ -427,6 +438,17 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
                 for (int g = 0; g < 4; ++g) {
                     const int row = rt * 16 + q * 4 + g;
                     if (row < n) {
+                        if (a.planes.p) {             // dP for the plane GEMMs (gemm_bx3.hip): split here, once
+                            const size_t e0 = (size_t)(r0 + row) * a.ldd + c0;
+#pragma unroll
+                            for (int m = 0; m < Q; ++m)
+                                if (m * 64 + 4 * li < ncol)
+                                    bx_store4(a.planes, e0 + m * 64 + 4 * li, make_float4(acc[4 * m][g], acc[4 * m + 1][g], acc[4 * m + 2][g], acc[4 * m + 3][g]));
+#pragma unroll
+                            for (int ct = 4 * Q; ct < CT; ++ct)
+                                if (lane_col(ct) < ncol) bx_store1(a.planes, e0 + lane_col(ct), acc[ct][g]);
+                            continue;
+                        }
                         float* drow = a.dst + (size_t)(r0 + row) * a.ldd + c0;
 #pragma unroll
                         for (int m = 0; m < Q; ++m)

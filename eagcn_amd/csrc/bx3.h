@@ -1,0 +1,79 @@
+// bf16 plane images of fp32 matrices: the operand format of csrc/gemm_bx3.hip, written by the kernels that PRODUCE a matrix.
+//   three planes (exact):  x = x0 + x1 + x2, each piece the top 8 significand bits of what the pieces before it left over
+//                          (truncation of the bit pattern; every remainder is computed exactly in fp32), plane q at
+//                          planes + q * pstride (elements), same row-major [rows][ld] geometry as the fp32 matrix;
+//   one plane (bf16 mode): round to nearest even.
+#pragma once
+#include "common.h"
+
+namespace eagcn {
+
+struct BxPlanes {                // bf16 planes of a row-major matrix
+    const uint16_t* p;           // plane 0; plane q at p + q * pstride
+    size_t pstride;              // elements between planes
+    int ld;                      // elements between rows
+};
+struct BxOut {                   // the same, as an output of a producer kernel (p == nullptr: not requested)
+    uint16_t* p; size_t pstride; int np;
+};
+
+__device__ __forceinline__ uint32_t bx1_round(float v) {       // bf16 bits (in the HIGH half), round to nearest even
+    const uint32_t b = __float_as_uint(v);
+    return (b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u;
+}
+// x = x0 + x1 + x2 exactly, every piece the bf16 NEAREST to what the pieces before it left over (remainders are exact in fp32:
+// |x - x0| <= 2^-9 |x| has at most 16 significant bits, the next one at most 8).  Rounding instead of truncating makes the
+// pieces' signs independent, so the three dropped piece products of a GEMM (gemm_bx3.hip) are <= 3 * 2^-26 |a b| and do not
+// all pull towards zero (truncation measured a one-sided 2.5 eps of sum |a||b| that does not average out over k).
+__device__ __forceinline__ void bx3_split(float v, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
+    h0 = bx1_round(v);
+    const float r1 = v - __uint_as_float(h0);
+    h1 = bx1_round(r1);
+    const float r2 = r1 - __uint_as_float(h1);
+    h2 = bx1_round(r2);
+}
+// four adjacent elements (idx a multiple of 4): one 8-byte store per plane
+__device__ __forceinline__ void bx3_store4(uint16_t* __restrict__ pl, size_t pstride, size_t idx, const float4 v) {
+    uint32_t h[3][4];
+    bx3_split(v.x, h[0][0], h[1][0], h[2][0]);
+    bx3_split(v.y, h[0][1], h[1][1], h[2][1]);
+    bx3_split(v.z, h[0][2], h[1][2], h[2][2]);
+    bx3_split(v.w, h[0][3], h[1][3], h[2][3]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        *reinterpret_cast<uint2*>(pl + (size_t)q * pstride + idx) = make_uint2((h[q][0] >> 16) | h[q][1], (h[q][2] >> 16) | h[q][3]);
+}
+__device__ __forceinline__ void bx1_store4(uint16_t* __restrict__ pl, size_t idx, const float4 v) {
+    *reinterpret_cast<uint2*>(pl + idx) = make_uint2((bx1_round(v.x) >> 16) | bx1_round(v.y), (bx1_round(v.z) >> 16) | bx1_round(v.w));
+}
+__device__ __forceinline__ void bx_store4(const BxOut& o, size_t idx, const float4 v) {
+    if (o.np == 3) bx3_store4(o.p, o.pstride, idx, v); else bx1_store4(o.p, idx, v);
+}
+// one element (scalar tails)
+__device__ __forceinline__ void bx_store1(const BxOut& o, size_t idx, float v) {
+    if (o.np == 3) {
+        uint32_t h0, h1, h2;
+        bx3_split(v, h0, h1, h2);
+        o.p[idx] = (uint16_t)(h0 >> 16); o.p[o.pstride + idx] = (uint16_t)(h1 >> 16); o.p[2 * o.pstride + idx] = (uint16_t)(h2 >> 16);
+    } else {
+        o.p[idx] = (uint16_t)(bx1_round(v) >> 16);
+    }
+}
+
+// one product of the plane GEMM (csrc/gemm_bx3.hip)
+struct BxProb {
+    BxPlanes A, B;
+    float* C; int ldc;
+    int M, N, K;                 // static extents (capacities where a device-side count exists)
+    const int* M_dev;            // NT: actual rows of A / C
+    const int* K_dev;            // TN: actual reduction length (packed rows)
+    int tn;                      // 0: C = A[M,K] . B[N,K]^T;  1: C = A[K,M]^T . B[K,N]
+    int splits; size_t slab;     // TN: k-chunk z goes to C + z * slab
+};
+bool bx3_ok(const BxProb& p);
+int bx3_grid();
+// np = 3: exact fp32 products from three planes; np = 1: plain bf16 operands.  p1 (optional): second product in the same launch
+int launch_bx3(const BxProb& p0, const BxProb* p1, int np, hipStream_t s, double work, int prof_tag);
+int launch_bx3_split(const float* x, int rows, const int* rows_dev, int ld, uint16_t* planes, size_t pstride, int np, hipStream_t s);
+
+}  // namespace eagcn

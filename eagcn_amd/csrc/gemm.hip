@@ -338,7 +338,9 @@ static int launch_cfg(const GemmDesc& g, hipStream_t s) {
 // 2 = plain bf16 operands (rounded to nearest even on the way into LDS, ONE bf16 MFMA product, fp32 accumulation): the
 // "bf16" of BASELINE.json configs[1]; NOT the parity path (products carry 2^-9 relative rounding per operand).
 static int g_gemm_x6 = [] { const char* e = getenv("EAGCN_GEMM_X6"); return e ? atoi(e) : 0; }();
-static int use_x6(const GemmDesc& g) { return (g_gemm_x6 != 0 && g.K >= 64 && g.prof_tag != PROF_HEAD) ? (g_gemm_x6 == 2 ? 2 : 1) : 0; }
+// (modes 3 / 4 -- operand planes written by the producers, gemm_bx3.hip -- are decided per layer in layer.hip; whatever still
+//  reaches this file in those modes runs on the fp32 matrix path)
+static int use_x6(const GemmDesc& g) { return ((g_gemm_x6 == 1 || g_gemm_x6 == 2) && g.K >= 64 && g.prof_tag != PROF_HEAD) ? g_gemm_x6 : 0; }
 int gemm_mode() { return g_gemm_x6; }
 template <int BM, int BN, int X6>
 static int launch_x6_cfg(const GemmDesc& g, hipStream_t s) {

@@ -33,7 +33,8 @@ struct Carver2 {
     }
 };
 
-struct LayerSaved { float *P, *Y, *rscale, *bn, *xout, *pad_row; void* packed; size_t packed_bytes; int fp, ldo, ld_in; };
+struct LayerSaved { float *P, *Y, *rscale, *bn, *xout, *pad_row; void* packed; size_t packed_bytes; int fp, ldo, ld_in;
+                    uint16_t* xout_planes; };      // operand planes of the NEXT layer's products (gemm modes 3 / 4), or null
 struct ModelSaved {
     float* x0;
     LayerSaved L[4];
@@ -69,6 +70,9 @@ static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m
         L.pad_row = c.take<float>(L.ldo);
         L.packed_bytes = eagcn_layer_packed_bytes(b, p);
         L.packed = c.take<char>(L.packed_bytes);
+        // the layer above reads this layer's output through bf16 operand planes when its products run on gemm_bx3.hip
+        const int np = (l + 1 < m->n_layers && L.ldo >= 128 && (L.ldo & 15) == 0) ? gemm_planes() : 0;
+        L.xout_planes = np ? c.take<uint16_t>((size_t)np * T * L.ldo) : nullptr;
     }
     const eagcn_head_params* h = &m->head;
     const size_t B = (size_t)b->B;
@@ -250,6 +254,7 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
         w.x = x; w.P = L.P; w.Y = L.Y; w.rscale = L.rscale; w.bn = L.bn; w.xout = L.xout; w.pad_row = L.pad_row;
         w.scratch = sc.layer; w.scratch_bytes = sc.layer_bytes; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
         w.stats_hook = m->stats_hook; w.stats_user = m->stats_user;
+        w.x_planes = l > 0 ? sv.L[l - 1].xout_planes : nullptr; w.xout_planes = L.xout_planes;
         RC(layer_forward_impl(b, &m->layer[l], &w, stream, true, l == m->n_layers - 1 && fused_readout(m)));
         x = L.xout;
     }
@@ -436,6 +441,7 @@ extern "C" int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_mode
         w.scratch = sc.layer; w.scratch_bytes = sc.layer_bytes; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
         w.aux_stream = m->aux_stream;
         w.stats_hook = m->stats_hook; w.stats_user = m->stats_user;
+        w.x_planes = l > 0 ? sv.L[l - 1].xout_planes : nullptr;
         const bool top = l == top_l;
         const float* dpad = (weighted && top) ? sc.dpad : nullptr;
         // (a layer that has only its edge-gradient reduction left hands it to the next layer's first kernel -- if one follows in

@@ -1,5 +1,6 @@
 // Argument blocks and launchers shared between the HIP translation units.
 #pragma once
+#include "bx3.h"
 #include "common.h"
 
 namespace eagcn {
@@ -14,6 +15,7 @@ struct AggArgs {
     float* rscale;               // [K][T] m_i/rowsum_i: written by forward, read by transposed
     double* stats;               // forward: [grid.x][Fp][2] partial (sum y, sum y^2)
     int nchunk;
+    BxOut planes = {nullptr, 0, 0};   // transposed: dP leaves as bf16 planes INSTEAD of the fp32 matrix (only the plane GEMMs read it)
 };
 int agg_grid_x(const eagcn_batch* b);
 bool agg_ksplit(const eagcn_batch* b);
@@ -130,7 +132,9 @@ int gemm3_failed();              // sticky, host-visible: a hand-off of some ear
         }                                                                                                              \
     } while (0)
 // words another kernel clears on the way (instead of a launch of its own): the hand-off flags of gemm3.hip and fp64 sums
-int gemm_mode();             // 0 fp32 MFMA (default, parity path) | 1 exact bf16 x 6 | 2 plain bf16 operands (gemm.hip)
+int gemm_mode();             // 0 fp32 MFMA | 1 exact bf16 x 6, split by the consumer | 2 plain bf16 operands (gemm.hip)
+                             // 3 exact bf16 x 3 PLANES written by the producers | 4 ONE bf16 plane (gemm_bx3.hip)
+inline int gemm_planes() { const int m = gemm_mode(); return m == 3 ? 3 : m == 4 ? 1 : 0; }
 struct ZeroJob { unsigned* u; int nu; double* d; int nd; };
 int gemm3_zero_job(void* workspace, size_t bytes, double* zero, int nzero, ZeroJob* out);
 // zero-fill by a kernel (memset NODES of a captured graph are not ordered with their neighbours on replay, ROCm 7.x): for every

@@ -73,7 +73,8 @@ __device__ __forceinline__ int packed_to_exact(const ColMapD& m, int cp) {
 // ---- parameter packing -------------------------------------------------------------------------
 __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const ViewCols& vc, const ColMapD& in, int ld_in,
                                                  int fp, float* __restrict__ Wcat, float* __restrict__ WcatT,
-                                                 float* __restrict__ colp, float* __restrict__ sig, float* __restrict__ rsig) {
+                                                 float* __restrict__ colp, float* __restrict__ sig, float* __restrict__ rsig,
+                                                 const BxOut wp = BxOut{nullptr, 0, 0}, const BxOut wtp = BxOut{nullptr, 0, 0}) {
     // 32 x 32 tiles through LDS: Wcat rows AND the rows of its transpose are written as contiguous 128-byte runs (the
     // transpose used to leave as 4-byte stores ld_in floats apart: one cache line per lane)
     __shared__ float tile[32][33];
@@ -93,6 +94,7 @@ __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const View
                     const int fi = packed_to_exact(in, ip);
                     if (fi >= 0 && f < vc.width[k]) v = pp.W[k][(size_t)fi * vc.width[k] + f];
                     Wcat[(size_t)ip * fp + cp] = v;
+                    if (wp.p) bx_store1(wp, (size_t)ip * fp + cp, v);        // operand planes of the plane GEMMs (gemm_bx3.hip)
                 }
                 tile[ty + 8 * j][tx] = v;
             }
@@ -102,7 +104,10 @@ __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const View
         for (int j = 0; j < 4; ++j) {
             const int cp = cp0 + ty + 8 * j, ip = ip0 + tx;
             // [Fp][ld_in]: the K-contiguous B operand of the forward product (NT form)
-            if (cp < fp && ip < ld_in) WcatT[(size_t)cp * ld_in + ip] = tile[tx][ty + 8 * j];
+            if (cp < fp && ip < ld_in) {
+                WcatT[(size_t)cp * ld_in + ip] = tile[tx][ty + 8 * j];
+                if (wtp.p) bx_store1(wtp, (size_t)cp * ld_in + ip, tile[tx][ty + 8 * j]);
+            }
         }
         __syncthreads();
     }
@@ -125,14 +130,15 @@ __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const View
 __global__ __launch_bounds__(256) void pack_params_kernel(ParamPtrs pp, ViewCols vc, ColMapD in, int ld_in, int fp,
                                                            float* __restrict__ Wcat, float* __restrict__ WcatT,
                                                            float* __restrict__ colp, float* __restrict__ sig,
-                                                           float* __restrict__ rsig) {
-    pack_params_body(pp, vc, in, ld_in, fp, Wcat, WcatT, colp, sig, rsig);
+                                                           float* __restrict__ rsig, BxOut wp, BxOut wtp) {
+    pack_params_body(pp, vc, in, ld_in, fp, Wcat, WcatT, colp, sig, rsig, wp, wtp);
 }
 // every layer of a model in one launch (blockIdx.y = layer): the parameters of all layers are known before the
 // first layer runs, and each packing launch is a few microseconds of fixed cost on the critical path
 struct PackJob {
     ParamPtrs pp; ViewCols vc; ColMapD in; int ld_in, fp;
     float *Wcat, *WcatT, *colp, *sig, *rsig;
+    BxOut wp, wtp;
 };
 struct PackJobs { PackJob j0, j1, j2, j3; };
 __global__ __launch_bounds__(256) void pack_params_multi_kernel(PackJobs jobs, ZeroJob zj) {
@@ -144,10 +150,10 @@ __global__ __launch_bounds__(256) void pack_params_multi_kernel(PackJobs jobs, Z
         }
     }
     // (an if-chain, not an indexed array: indexing the by-value argument block dynamically would move it to scratch)
-    if (blockIdx.y == 0) pack_params_body(jobs.j0.pp, jobs.j0.vc, jobs.j0.in, jobs.j0.ld_in, jobs.j0.fp, jobs.j0.Wcat, jobs.j0.WcatT, jobs.j0.colp, jobs.j0.sig, jobs.j0.rsig);
-    else if (blockIdx.y == 1) pack_params_body(jobs.j1.pp, jobs.j1.vc, jobs.j1.in, jobs.j1.ld_in, jobs.j1.fp, jobs.j1.Wcat, jobs.j1.WcatT, jobs.j1.colp, jobs.j1.sig, jobs.j1.rsig);
-    else if (blockIdx.y == 2) pack_params_body(jobs.j2.pp, jobs.j2.vc, jobs.j2.in, jobs.j2.ld_in, jobs.j2.fp, jobs.j2.Wcat, jobs.j2.WcatT, jobs.j2.colp, jobs.j2.sig, jobs.j2.rsig);
-    else pack_params_body(jobs.j3.pp, jobs.j3.vc, jobs.j3.in, jobs.j3.ld_in, jobs.j3.fp, jobs.j3.Wcat, jobs.j3.WcatT, jobs.j3.colp, jobs.j3.sig, jobs.j3.rsig);
+    if (blockIdx.y == 0) pack_params_body(jobs.j0.pp, jobs.j0.vc, jobs.j0.in, jobs.j0.ld_in, jobs.j0.fp, jobs.j0.Wcat, jobs.j0.WcatT, jobs.j0.colp, jobs.j0.sig, jobs.j0.rsig, jobs.j0.wp, jobs.j0.wtp);
+    else if (blockIdx.y == 1) pack_params_body(jobs.j1.pp, jobs.j1.vc, jobs.j1.in, jobs.j1.ld_in, jobs.j1.fp, jobs.j1.Wcat, jobs.j1.WcatT, jobs.j1.colp, jobs.j1.sig, jobs.j1.rsig, jobs.j1.wp, jobs.j1.wtp);
+    else if (blockIdx.y == 2) pack_params_body(jobs.j2.pp, jobs.j2.vc, jobs.j2.in, jobs.j2.ld_in, jobs.j2.fp, jobs.j2.Wcat, jobs.j2.WcatT, jobs.j2.colp, jobs.j2.sig, jobs.j2.rsig, jobs.j2.wp, jobs.j2.wtp);
+    else pack_params_body(jobs.j3.pp, jobs.j3.vc, jobs.j3.in, jobs.j3.ld_in, jobs.j3.fp, jobs.j3.Wcat, jobs.j3.WcatT, jobs.j3.colp, jobs.j3.sig, jobs.j3.rsig, jobs.j3.wp, jobs.j3.wtp);
 }
 
 // sum of per-workgroup partial pairs slab[s][cp][0..1] over s, L (16 or 64) lanes per column: with hundreds of
@@ -249,6 +255,7 @@ struct ApplyArgs {
     float* out; int ldo;
     float* pad_row;
     int do_drop; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
+    BxOut planes;                // optional: the operand planes of the next layer's products (gemm_bx3.hip), written here
 };
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
@@ -288,6 +295,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
                 o.x *= ds[0]; o.y *= ds[1]; o.z *= ds[2]; o.w *= ds[3];
             }
             *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + c) = o;
+            if (a.planes.p) bx_store4(a.planes, (size_t)r * a.ldo + c, o);
         }
     } else {
         // weighted sum over the views: a thread owns four adjacent output columns, the K view loads of a row are independent
@@ -321,6 +329,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
                     acc.x += w.x * p.x; acc.y += w.y * p.y; acc.z += w.z * p.z; acc.w += w.w * p.w;
                 }
             *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + f) = acc;
+            if (a.planes.p) bx_store4(a.planes, (size_t)r * a.ldo + f, acc);
         }
     }
 }
@@ -609,7 +618,9 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
                                                             int nedge, const float* __restrict__ rsig, int wblocks,
                                                             const int32_t* __restrict__ meta, int xk_G, int edge_drain) {
     nedge = nedge < 0 ? -nedge : min(nedge, (meta[EAGCN_META_T] + 15) / 16);   // edge-gradient workgroups that had rows (< 0: all wrote)
-    nsplit = max(1, min(nsplit, meta[EAGCN_META_T] >> 7));     // split-K partials actually written (gemm.hip eff_splits)
+    // split-K partials actually written: gemm.hip writes eff_splits of them; the plane GEMM (gemm_bx3.hip) writes every one of
+    // its k-chunk slabs (an empty chunk stores zeros) and passes the count negated
+    nsplit = nsplit < 0 ? -nsplit : max(1, min(nsplit, meta[EAGCN_META_T] >> 7));
     if ((int)blockIdx.x < wblocks) {
         // split-K slabs: FOUR lanes per element, each adds every fourth slab (the first layer's weight gradient leaves gemm.hip
         // as up to 146 slabs: one thread per element was a chain of 37 dependent load rounds, 14 us at B = 1024)
@@ -728,6 +739,8 @@ struct LayerDims {
     ViewCols vc;
     int fp, ld_in, fin, ldo, gx, gxb, nsplit;
     size_t wslab;
+    int np;                      // 3 / 1: this layer's products run from bf16 operand planes (gemm_bx3.hip); 0: fp32 operands
+    int bx_splits;               // ... and its weight gradient leaves as this many k-chunk slabs
 };
 static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     LayerDims d;
@@ -749,6 +762,14 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     const int tiles = cdiv(d.ld_in, 64) * cdiv(d.fp, 64);
     d.nsplit = std::max(1, std::min(std::max(1, 1024 / tiles), cdiv(std::max(b->T, 1), 128)));
     d.wslab = (size_t)d.ld_in * d.fp;
+    // plane GEMMs (gemm modes 3 / 4): the hidden layers (the 24-feature first layer stays on the fp32 kernels of gemm.hip)
+    d.np = (d.ld_in >= 128 && (d.ld_in & 15) == 0 && (d.fp & 15) == 0) ? gemm_planes() : 0;
+    {   // k-chunks of the weight gradient: enough work items to fill the chip next to the dX tiles, each at least 8 k-tiles long
+        const int tiles128 = cdiv(d.ld_in, 128) * cdiv(d.fp, 128);
+        const int by_fill = cdiv(2 * bx3_grid(), tiles128);
+        const int by_len = std::max(1, cdiv(std::max(b->T, 1), 256));
+        d.bx_splits = std::max(1, std::min(std::min(by_fill, by_len), 32));
+    }
     return d;
 }
 
@@ -761,8 +782,9 @@ static bool gemm3_layer(int ld_in) {
     return on && ld_in >= 128 && gemm_mode() != 2;       // (the bf16 mode runs on the LDS-tiled kernels of gemm.hip)
 }
 
-struct Packed { float *Wcat, *WcatT, *colp, *sig, *rsig; };
-struct FwdScratch { void* gws; double* eacc; float *Wcat, *WcatT, *colp, *sig, *rsig; double* stats; double* gsum; };
+struct Packed { float *Wcat, *WcatT, *colp, *sig, *rsig; uint16_t *Wp, *WTp; };   // Wp / WTp: [np][ld_in * fp] operand planes
+struct FwdScratch { void* gws; double* eacc; float *Wcat, *WcatT, *colp, *sig, *rsig; uint16_t *Wp, *WTp; double* stats; double* gsum;
+                    uint16_t* xp; };           // xp: planes of x when the caller did not bring them (layer-level path)
 static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
     Carver c(base);
     Packed t;
@@ -771,6 +793,8 @@ static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
     t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
+    t.Wp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wslab : 1);
+    t.WTp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wslab : 1);
     if (s) *s = t;
     return c.off;
 }
@@ -779,7 +803,9 @@ struct BwdScratch {
                                  // directions share one region (one flag clear per API call, kernels.h gemm3_clear_flags)
     double* eacc;                // edge-gradient accumulator slabs (kernels.h EDGE_COPIES): right behind it, zero between uses
     float *Wcat, *WcatT, *colp, *sig, *rsig, *dY, *dP, *cc, *dWcat;
+    uint16_t *Wp, *WTp;
     double *slab, *slab_da, *datt, *gsum;
+    uint16_t *dPp, *xp;          // planes of dP (written by the transposed aggregation) and of x when the caller did not bring them
 };
 static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, FwdScratch* s) {
     Carver c(base);
@@ -791,8 +817,11 @@ static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, Fw
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
     t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
+    t.Wp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wslab : 1);
+    t.WTp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wslab : 1);
     t.stats = c.take<double>((size_t)d.gx * d.fp * 2);
     t.gsum = c.take<double>((size_t)2 * d.fp + 8);
+    t.xp = c.take<uint16_t>(d.np ? (size_t)d.np * std::max(b->T, 1) * d.ld_in : 1);
     if (s) *s = t;
     return c.off;
 }
@@ -806,14 +835,18 @@ static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, Bw
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
     t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
+    t.Wp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wslab : 1);
+    t.WTp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wslab : 1);
     t.dY = c.take<float>((size_t)std::max(b->T, 1) * d.fp);
     t.dP = c.take<float>((size_t)std::max(b->T, 1) * d.fp);
     t.cc = c.take<float>((size_t)2 * d.fp);
-    t.dWcat = c.take<float>(d.wslab * std::max(d.nsplit, G3_XSEG));
+    t.dWcat = c.take<float>(d.wslab * std::max(std::max(d.nsplit, G3_XSEG), d.np ? d.bx_splits : 1));
     t.slab = c.take<double>((size_t)d.gxb * d.fp * 2);
     t.slab_da = c.take<double>((size_t)d.gxb * cdiv(d.fp, 1024) * EAGCN_MAX_VIEWS);
     t.datt = c.take<double>((size_t)edge_grid_x(b) * EAGCN_MAX_VIEWS * EDGE_SLAB);
     t.gsum = c.take<double>((size_t)2 * d.fp + 8);
+    t.dPp = c.take<uint16_t>(d.np ? (size_t)d.np * std::max(b->T, 1) * d.fp : 1);
+    t.xp = c.take<uint16_t>(d.np ? (size_t)d.np * std::max(b->T, 1) * d.ld_in : 1);
     if (s) *s = t;
     return c.off;
 }
@@ -917,6 +950,8 @@ int eagcn::pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const
         jobs[l].pp = param_ptrs(b, ps[ll]); jobs[l].vc = d.vc; jobs[l].in = make_colmap(&ps[ll]->in);
         jobs[l].ld_in = d.ld_in; jobs[l].fp = d.fp;
         jobs[l].Wcat = pk.Wcat; jobs[l].WcatT = pk.WcatT; jobs[l].colp = pk.colp; jobs[l].sig = pk.sig; jobs[l].rsig = pk.rsig;
+        jobs[l].wp = BxOut{d.np ? pk.Wp : nullptr, d.wslab, d.np};
+        jobs[l].wtp = BxOut{d.np ? pk.WTp : nullptr, d.wslab, d.np};
         if (l < n) wmax = std::max(wmax, d.wslab);
     }
     PackJobs pj{jobs[0], jobs[1], jobs[2], jobs[3]};
@@ -951,11 +986,14 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
             return EAGCN_ERR_SCRATCH;
         }
         sc.Wcat = pk.Wcat; sc.WcatT = pk.WcatT; sc.colp = pk.colp; sc.sig = pk.sig; sc.rsig = pk.rsig;
+        sc.Wp = pk.Wp; sc.WTp = pk.WTp;
     }
     EAGCN_CHECK_ARG(!prepacked || w->packed, "eagcn_layer_forward: prepacked parameters need the packed block");
     if (!prepacked) {
         ProfScope ps(PROF_PACK, s);
-        pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.WcatT, sc.colp, sc.sig, sc.rsig);
+        pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.WcatT, sc.colp, sc.sig, sc.rsig,
+                                                            BxOut{d.np ? sc.Wp : nullptr, d.wslab, d.np},
+                                                            BxOut{d.np ? sc.WTp : nullptr, d.wslab, d.np});
     }
     EAGCN_LAUNCH_CHECK();
     // algorithmic flops of the flat transform: exact widths, packed rows
@@ -968,7 +1006,23 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
         // that are not 16-byte aligned fall back to the workgroup-tiled kernel
         GemmDesc g3{0, 1, b->T, d.fp, d.ld_in, w->x, d.ld_in, sc.WcatT, d.ld_in, w->P, d.fp, 1, 0, gemm_work};
         g3.M_dev = b->meta + EAGCN_META_T;
-        if (gemm3_layer(d.ld_in) && gemm3_ok(g3)) {
+        BxProb bp;
+        memset(&bp, 0, sizeof(bp));
+        if (d.np) {
+            // the same product from bf16 operand planes (gemm_bx3.hip): x planes from the layer below, or split here
+            const size_t xstride = (size_t)b->T * d.ld_in;
+            const uint16_t* xp = w->x_planes;
+            if (!xp) {
+                rc = launch_bx3_split(w->x, b->T, b->meta + EAGCN_META_T, d.ld_in, sc.xp, xstride, d.np, s);
+                if (rc) return rc;
+                xp = sc.xp;
+            }
+            bp.A = BxPlanes{xp, xstride, d.ld_in}; bp.B = BxPlanes{sc.WTp, d.wslab, d.ld_in}; bp.C = w->P; bp.ldc = d.fp;
+            bp.M = b->T; bp.N = d.fp; bp.K = d.ld_in; bp.M_dev = b->meta + EAGCN_META_T; bp.tn = 0; bp.splits = 1;
+        }
+        if (d.np && bx3_ok(bp)) {
+            rc = launch_bx3(bp, nullptr, d.np, s, gemm_work, PROF_GEMM);
+        } else if (gemm3_layer(d.ld_in) && gemm3_ok(g3)) {
             rc = launch_gemm3(g3, nullptr, sc.gws, gemm3_workspace_bytes(), s);
         } else {
             GemmDesc g{0, 0, b->T, d.fp, d.ld_in, w->x, d.ld_in, sc.Wcat, d.fp, w->P, d.fp, 1, 0, gemm_work};
@@ -1030,6 +1084,7 @@ static int apply_launch_(const eagcn_batch* b, const eagcn_layer_params* p, cons
     aa.inv_keep = 1.0f / (1.0f - p->dropout);
     aa.seed = p->seed;
     aa.seed_dev = p->seed_dev;
+    aa.planes = BxOut{gemm_planes() ? w->xout_planes : nullptr, (size_t)b->T * d.ldo, gemm_planes()};
     bn_apply_kernel<<<ew_grid((size_t)std::max(b->T, 1) * d.ldo / 4), 256, 0, s>>>(aa);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
@@ -1103,9 +1158,12 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             return EAGCN_ERR_SCRATCH;
         }
         sc.Wcat = pk.Wcat; sc.WcatT = pk.WcatT; sc.colp = pk.colp; sc.sig = pk.sig; sc.rsig = pk.rsig;
+        sc.Wp = pk.Wp; sc.WTp = pk.WTp;
     } else {
         ProfScope ps(PROF_PACK, s);
-        pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.WcatT, sc.colp, sc.sig, sc.rsig);
+        pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.WcatT, sc.colp, sc.sig, sc.rsig,
+                                                            BxOut{d.np ? sc.Wp : nullptr, d.wslab, d.np},
+                                                            BxOut{d.np ? sc.WTp : nullptr, d.wslab, d.np});
     }
     EAGCN_LAUNCH_CHECK();
     double fsum = 0.0;
@@ -1169,6 +1227,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         }
     }
     int nsplit = 0, nedge = 0, xk_G = 0;
+    bool bx_slabs = false;       // dWcat holds the k-chunk slabs of the plane GEMM (all of them written)
     // side = stream for work that is off the dX critical path (edge gradients, dW product, gradient
     // unpacking); with no auxiliary stream everything stays in order on s
     hipStream_t side = w->aux_stream ? (hipStream_t)w->aux_stream : s;
@@ -1177,6 +1236,28 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         AggArgs a;
         a.bt = *b; a.vc = d.vc; a.src = sc.dY; a.lds = d.fp; a.dst = sc.dP; a.ldd = d.fp;
         a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = nullptr; a.nchunk = 1;
+        // plane GEMMs (gemm_bx3.hip): dX = dP.Wcat^T (NT) and dW = X^T.dP (TN, k-chunk slabs summed by unpack_grads) in one
+        // persistent launch; dP leaves the transposed aggregation as bf16 planes and is never written as fp32
+        const size_t xstride = (size_t)b->T * d.ld_in, pstride = (size_t)b->T * d.fp;
+        BxProb bx, bw;
+        memset(&bx, 0, sizeof(bx));
+        memset(&bw, 0, sizeof(bw));
+        bool use_bx = false;
+        if (d.np && !w->aux_stream) {
+            bx.A = BxPlanes{sc.dPp, pstride, d.fp}; bx.B = BxPlanes{sc.Wp, d.wslab, d.fp}; bx.C = dx; bx.ldc = d.ld_in;
+            bx.M = b->T; bx.N = d.ld_in; bx.K = d.fp; bx.M_dev = b->meta + EAGCN_META_T; bx.tn = 0; bx.splits = 1;
+            bw.A = BxPlanes{w->x_planes ? w->x_planes : sc.xp, xstride, d.ld_in}; bw.B = BxPlanes{sc.dPp, pstride, d.fp};
+            bw.C = sc.dWcat; bw.ldc = d.fp; bw.M = d.ld_in; bw.N = d.fp; bw.K = b->T; bw.K_dev = b->meta + EAGCN_META_T; bw.tn = 1;
+            bw.splits = d.bx_splits; bw.slab = d.wslab;
+            use_bx = bx3_ok(bw) && (!dx || bx3_ok(bx));
+        }
+        if (use_bx) {
+            a.planes = BxOut{sc.dPp, pstride, d.np};
+            if (!w->x_planes) {
+                rc = launch_bx3_split(w->x, b->T, b->meta + EAGCN_META_T, d.ld_in, sc.xp, xstride, d.np, s);
+                if (rc) return rc;
+            }
+        }
         EdgeArgs e;
         e.bt = *b; e.vc = d.vc; e.dY = sc.dY; e.Y = w->Y; e.P = w->P; e.ld = d.fp; e.sig = sc.sig;
         e.rsig = sc.rsig; e.rscale = w->rscale; e.datt = sc.datt; e.atomic = 0;
@@ -1208,7 +1289,12 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) dsc.dW[k] = gp.dW[k];
         dsc.vc = d.vc;
         dsc.in = in;
-        if (use3 && !forked && dx && gemm3_layer(d.ld_in) && gemm3_ok(gw) && gemm3_ok(gx) && gemm3_xk_enabled()) {
+        if (use_bx) {
+            rc = dx ? launch_bx3(bx, &bw, d.np, s, 2.0 * gemm_work, PROF_GEMM_PAIR) : launch_bx3(bw, nullptr, d.np, s, gemm_work, PROF_GEMM);
+            if (rc) return rc;
+            nsplit = d.bx_splits;                         // partial slabs of dWcat: summed and scattered by unpack_grads below
+            bx_slabs = true;
+        } else if (use3 && !forked && dx && gemm3_layer(d.ld_in) && gemm3_ok(gw) && gemm3_ok(gx) && gemm3_xk_enabled()) {
             // wave-autonomous balanced kernel, XCD-local schedule: dX and dW in one launch, every XCD works on its own eighth of
             // the packed rows for BOTH products; dW leaves as one partial slab per XCD, summed by unpack_grads below
             rc = launch_gemm3_pair(gx, gw, nullptr, sc.gws, gemm3_workspace_bytes(), s, d.wslab);
@@ -1250,7 +1336,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         }
         ProfScope psu(PROF_PACK, side);
         unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, side>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
-                                                                                    nsplit, d.wslab, edge_src, nedge, sc.rsig,
+                                                                                    bx_slabs ? -nsplit : nsplit, d.wslab, edge_src, nedge, sc.rsig,
                                                                                     wblocks, b->meta, xk_G, edge_drain);
         EAGCN_LAUNCH_CHECK();
     }

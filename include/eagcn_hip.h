@@ -182,6 +182,12 @@ typedef struct eagcn_layer_bufs {
     size_t packed_bytes;                    /* the re-laid parameters here and backward reuses them */
     eagcn_allreduce_fn stats_hook;          /* sync-BatchNorm: cross-rank sum of the BatchNorm partial sums (NULL: local-BN) */
     void* stats_user;
+    /* bf16 plane images (gemm mode 3 / 4, csrc/gemm_bx3.hip: the layer products run on the bf16 matrix cores from operands    */
+    /* their producers already split): x_planes = the planes of x ([planes][T][ld_in] bf16, plane stride T * ld_in; three planes */
+    /* in mode 3, one in mode 4), written by the layer below through ITS xout_planes; NULL: the layer splits x itself (one more  */
+    /* launch) / does not write them.  Ignored in the fp32 modes and for layers narrower than 128 input columns.                */
+    const uint16_t* x_planes;
+    uint16_t* xout_planes;                  /* [planes][T][ld_out]                                                            */
 } eagcn_layer_bufs;
 
 typedef struct eagcn_layer_grads {
@@ -387,10 +393,31 @@ int eagcn_mse_loss(const float* pred, const float* target, int n, float* loss, f
 int eagcn_eval_append(const float* logits, const float* labels, int B, int T, int classification, float* scores,
                       float* targets, uint8_t* valid, int64_t row_offset, void* stream);
 
-/* Matrix-core path of the layer products: 0 = fp32 MFMA (default: exact fp32 products, the reference's torch.mm
- * semantics, layers.py:40), 1 = every fp32 operand split exactly into three bf16 pieces and six bf16 MFMA
- * products accumulated in fp32 (same accuracy, see csrc/gemm_x6.h).  Returns the previous mode. */
+/* Matrix-core path of the layer products (the reference's torch.mm and its two autograd products, layers.py:40):
+ *   0 = fp32 MFMA: exact fp32 products, a k-ordered fmaf chain (csrc/gemm3.hip);
+ *   1 = every fp32 operand split into three bf16 pieces by the CONSUMER on its way into LDS, six bf16 MFMA products
+ *       accumulated in fp32 (csrc/gemm_x6.h; kept for comparison);
+ *   2 = operands rounded to bf16 by the consumer, ONE product (csrc/gemm_x6.h; NOT the parity path);
+ *   3 = exact fp32 products at the bf16 matrix rate: the PRODUCERS of a matrix (BatchNorm apply, transposed aggregation,
+ *       parameter packing) write it as three bf16 planes, the products run from them by LDS-DMA (csrc/gemm_bx3.hip);
+ *   4 = the same kernels on ONE bf16 plane (operands rounded to bf16, fp32 accumulation): BASELINE configs[1] "bf16".
+ * The mode is read when a model's buffers are sized: set it before the first forward.  Returns the previous mode. */
 int eagcn_set_gemm_mode(int mode);
+
+/* ---- the plane GEMM of modes 3 / 4 as stand-alone entry points (tests, tools/bx3_bench.cpp) -----------------------------
+ * planes of a row-major fp32 matrix [rows][ld]: np = 3: x = x0 + x1 + x2 exactly (each piece the bf16 nearest to what the
+ * pieces before it left over), np = 1: round to nearest even; plane q at planes + q * plane_stride (elements) */
+int eagcn_bx3_split(const float* x, int rows, int ld, uint16_t* planes, size_t plane_stride, int np, void* stream);
+/* tn = 0: C[M,N] = A[M,K].B[N,K]^T (planes of A [M][lda] and B [N][ldb], K a multiple of 16);
+ * tn = 1: C[M,N] = A[K,M]^T.B[K,N] (planes [K][lda], [K][ldb]) as `splits` k-chunk slabs C + z * slab whose sum is the product.
+ * lda / ldb multiples of 8, planes 16-byte aligned. */
+int eagcn_gemm_bx3(int tn, int M, int N, int K, const uint16_t* A, size_t a_pstride, int lda, const uint16_t* B,
+                   size_t b_pstride, int ldb, float* C, int ldc, int splits, size_t slab, int np, void* stream);
+/* an NT product and a TN product (the dX / dW pair of a layer's backward) in ONE persistent launch */
+int eagcn_gemm_bx3_pair(int M0, int N0, int K0, const uint16_t* A0, size_t a0_pstride, int lda0, const uint16_t* B0,
+                        size_t b0_pstride, int ldb0, float* C0, int ldc0, int M1, int N1, int K1, const uint16_t* A1,
+                        size_t a1_pstride, int lda1, const uint16_t* B1, size_t b1_pstride, int ldb1, float* C1, int ldc1,
+                        int splits, size_t slab, int np, void* stream);
 
 /* ---- plain fp32 MFMA GEMM (head / tests) ------------------------------------------------------ */
 /* C[M,N] = op(A).op(B); ta/tb: 0 = as stored, 1 = transposed; leading dimensions in floats */
