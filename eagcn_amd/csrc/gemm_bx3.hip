@@ -47,20 +47,15 @@ typedef short bx_s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* bx_lds_ptr;
 
 constexpr int BX_BK = 32;
+constexpr int BX_NC = 4;                     // compute waves: 2 x 2, one 64 x 64 accumulator block each (one per SIMD)
+constexpr int BX_NL = 2;                     // loader waves
+constexpr int BX_BM = 128, BX_BN = 128;
+constexpr int BX_APL = BX_BM * 64, BX_BPL = BX_BN * 64;          // bytes of one plane image of a k-tile
+constexpr int BX_STAGE = 3 * (BX_APL + BX_BPL);                  // 48 KB
+constexpr int BX_NS = 3;                                         // LDS stages (144 KB)
+constexpr int BX_APW = BX_BM / 16 / BX_NL, BX_BPW = BX_BN / 16 / BX_NL;   // 1 KB DMA pieces per loader wave and plane
 
 extern __shared__ __attribute__((aligned(1024))) unsigned char bx_smem[];
-
-template <int WM, int WN>
-struct BxCfg {
-    static constexpr int NW = WM * WN;
-    static constexpr int BM = 64 * WM, BN = 64 * WN;
-    static constexpr int APL = BM * 64, BPL = BN * 64;             // bytes of one plane image of a k-tile
-    static constexpr int STAGE = 3 * (APL + BPL);
-    static constexpr int NS = (3 * STAGE <= 160 * 1024) ? 3 : 2;
-    static constexpr int APW = BM / 16 / NW, BPW = BN / 16 / NW;   // 1 KB DMA pieces per wave and plane
-    static constexpr int PPT = 3 * (APW + BPW);                    // DMA instructions per wave and k-tile
-    static_assert(APW >= 1 && BPW >= 1 && (BM / 16) % NW == 0 && (BN / 16) % NW == 0, "tile too small for the wave count");
-};
 
 template <int N>
 __device__ __forceinline__ void bx_wait_vm() {
@@ -68,69 +63,161 @@ __device__ __forceinline__ void bx_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// One output tile (or one k-chunk of it): k-tiles [kt0, kt1) of BX_BK.  NP = 3: exact split; NP = 1: plain bf16 operands.
-template <bool TN, int WM, int WN, int NP, int DBG = 0>
-__device__ __forceinline__ void bx_tile(const BxProb& p, const int Mx, const int Kx, const int tm, const int tn, const int kt0,
-                                        const int kt1, float* __restrict__ Cz) {
-    using Cf = BxCfg<WM, WN>;
-    constexpr int BM = Cf::BM, BN = Cf::BN, NS = Cf::NS, APW = Cf::APW, BPW = Cf::BPW;
-    constexpr int PPT = NP * (APW + BPW);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int m0 = tm * BM, n0 = tn * BN;
+// ---- work units --------------------------------------------------------------------------------------------------------------------
+// NT: a unit is an output tile (all its k-tiles); TN: a (tile, k-chunk) item, chunk z -> slab z.  Unit order: NT: column tile
+// fastest (the tiles of a row panel are neighbours); TN: k-chunk MAJOR -- the tiles of one k-chunk are neighbours and share its
+// rows of both operands in their XCD's L2 (tile-major order measured a 13 % L2 hit rate: every byte of X and dP crossed the
+// fabric once per tile, profiles/r04_bx3_tcc_v1.txt).
+struct BxUnits { int tiles_m, tiles_n, splits, kt_total, kt_per; int n; };
+__device__ __forceinline__ int bx_mx(const BxProb& p) { return (!p.tn && p.M_dev) ? min(*p.M_dev, p.M) : p.M; }
+__device__ __forceinline__ int bx_kx(const BxProb& p) { return (p.tn && p.K_dev) ? min(*p.K_dev, p.K) : p.K; }
+__device__ __forceinline__ BxUnits bx_units(const BxProb& p, int Mx, int Kx) {
+    BxUnits u;
+    u.tiles_m = (Mx + BX_BM - 1) / BX_BM;
+    u.tiles_n = (p.N + BX_BN - 1) / BX_BN;
+    u.kt_total = max(1, (Kx + BX_BK - 1) / BX_BK);
+    u.splits = p.tn ? max(1, p.splits) : 1;
+    u.kt_per = (u.kt_total + u.splits - 1) / u.splits;
+    u.n = u.tiles_m * u.tiles_n * u.splits;
+    return u;
+}
+// the units of ONE problem that this workgroup owns: ids first, first + step, ... (count of them)
+struct BxStream { BxUnits u; int Mx, Kx, first, step, count; };
+struct BxUnit { int tm, tn, kt0, nk, z; };
+// (__host__ __device__: it is called from a lambda, which clang treats as host + device code in its host pass)
+__host__ __device__ __forceinline__ BxUnit bx_unit(const BxProb& p, const BxStream& st, int j) {
+    const int id = st.first + j * st.step;
+    BxUnit r;
+    if (!p.tn) {
+        r.tm = id / st.u.tiles_n; r.tn = id - r.tm * st.u.tiles_n; r.kt0 = 0; r.nk = st.u.kt_total; r.z = 0;
+    } else {
+        const int tiles = st.u.tiles_m * st.u.tiles_n;
+        r.z = id / tiles;
+        const int tile = id - r.z * tiles;
+        r.tm = tile / st.u.tiles_n; r.tn = tile - r.tm * st.u.tiles_n;
+        const int k0 = r.z * st.u.kt_per, k1 = k0 + st.u.kt_per;
+        r.kt0 = k0 < st.u.kt_total ? k0 : st.u.kt_total;
+        r.nk = (k1 < st.u.kt_total ? k1 : st.u.kt_total) - r.kt0;
+    }
+    return r;
+}
+__device__ __forceinline__ int bx_total_tiles(const BxProb& p, const BxStream& st) {
+    if (!p.tn) return st.count * st.u.kt_total;
+    int t = 0;
+    for (int j = 0; j < st.count; ++j) t += bx_unit(p, st, j).nk;
+    return t;
+}
 
-    // ---- buffer descriptors: one per operand plane, num_records from the ACTUAL extents (rows beyond them read as zero) --------
-    // NT: A rows = M, B rows = N;  TN: rows of both = K
-    const unsigned arows = TN ? (unsigned)Kx : (unsigned)Mx;
-    const unsigned brows = TN ? (unsigned)Kx : (unsigned)p.N;
-    __amdgpu_buffer_rsrc_t ra[NP], rb[NP];
+// ---- loader waves ------------------------------------------------------------------------------------------------------------------
+// Two waves do nothing but LDS-DMA: wave lw requests every second 1 KB piece of the three (NP) planes of both operands of a
+// k-tile -- 8 NP instructions -- for k-tile k + 2 while the compute waves multiply k-tile k.  (Issued by the compute waves
+// themselves the twelve requests per wave and k-tile held the wave's issue port while the matrix pipe idled: fill alone 65 us,
+// products alone 59 us, together 99 us at 19 200 x 400 x 720 -- profiles/r04_bx3_probe_v1.txt.)
+template <bool TN, int NP>
+__device__ __forceinline__ void bx_loader(const BxProb& p, const BxStream& st, const int lw) {
+    constexpr int PPL = NP * (BX_APW + BX_BPW);
+    const int lane = threadIdx.x & 63;
+    // buffer descriptors: one per operand plane, num_records from the ACTUAL extents (rows beyond them read as zero)
+    const unsigned arows = TN ? (unsigned)st.Kx : (unsigned)st.Mx;
+    const unsigned brows = TN ? (unsigned)st.Kx : (unsigned)p.N;
+    __amdgpu_buffer_rsrc_t ra[3], rb[3];           // (fixed size: clang's host pass rejects the DMA builtin on an array of dependent extent)
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         ra[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A.p + (size_t)q * p.A.pstride), 0, (int)(arows * (unsigned)p.A.ld * 2u), 0x00020000);
         rb[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B.p + (size_t)q * p.B.pstride), 0, (int)(brows * (unsigned)p.B.ld * 2u), 0x00020000);
     }
-
-    // ---- DMA source offsets (bytes) of this lane's piece(s), for k-tile kt0; advanced by `astep` / `bstep` per k-tile -------------
-    unsigned va[APW], vb[BPW];
-    unsigned astep, bstep;
-    if constexpr (!TN) {
-        astep = bstep = BX_BK * 2;
+    // per-lane source offsets (bytes) RELATIVE to the unit's origin; the swizzle of the LDS image lives here (DMA writes lane-linear)
+    unsigned ra_[BX_APW], rb_[BX_BPW];
+    const unsigned astep = TN ? (unsigned)BX_BK * (unsigned)p.A.ld * 2u : BX_BK * 2u;
+    const unsigned bstep = TN ? (unsigned)BX_BK * (unsigned)p.B.ld * 2u : BX_BK * 2u;
 #pragma unroll
-        for (int u = 0; u < APW; ++u) {
-            const int r = (wave * APW + u) * 16 + (lane >> 2);                  // row of the tile image
-            const int cs = (lane & 3) ^ ((r >> 2) & 3);                         // source chunk for LDS chunk (lane & 3)
-            va[u] = ((unsigned)(m0 + r) * (unsigned)p.A.ld + (unsigned)(kt0 * BX_BK + cs * 8)) * 2u;
-        }
-#pragma unroll
-        for (int u = 0; u < BPW; ++u) {
-            const int r = (wave * BPW + u) * 16 + (lane >> 2);
-            const int cs = (lane & 3) ^ ((r >> 2) & 3);
-            vb[u] = ((unsigned)(n0 + r) * (unsigned)p.B.ld + (unsigned)(kt0 * BX_BK + cs * 8)) * 2u;
-        }
-    } else {
-        astep = (unsigned)BX_BK * (unsigned)p.A.ld * 2u;
-        bstep = (unsigned)BX_BK * (unsigned)p.B.ld * 2u;
-#pragma unroll
-        for (int u = 0; u < APW; ++u) {
-            const int byte = (wave * APW + u) * 1024 + lane * 16;               // position in the [32 k][BM] image
-            const int kr = byte / (BM * 2), cp = (byte % (BM * 2)) >> 4;
-            const int cs = cp ^ ((kr & 3) << 2);
-            va[u] = ((unsigned)(kt0 * BX_BK + kr) * (unsigned)p.A.ld + (unsigned)(m0 + cs * 8)) * 2u;
-        }
-#pragma unroll
-        for (int u = 0; u < BPW; ++u) {
-            const int byte = (wave * BPW + u) * 1024 + lane * 16;
-            const int kr = byte / (BN * 2), cp = (byte % (BN * 2)) >> 4;
-            const int cs = cp ^ ((kr & 3) << 2);
-            vb[u] = ((unsigned)(kt0 * BX_BK + kr) * (unsigned)p.B.ld + (unsigned)(n0 + cs * 8)) * 2u;
+    for (int u = 0; u < BX_APW; ++u) {
+        const int pc = lw + BX_NL * u;                                          // piece of the plane image
+        if constexpr (!TN) {
+            const int r = pc * 16 + (lane >> 2), cs = (lane & 3) ^ ((r >> 2) & 3);
+            ra_[u] = ((unsigned)r * (unsigned)p.A.ld + (unsigned)(cs * 8)) * 2u;
+        } else {
+            const int byte = pc * 1024 + lane * 16, kr = byte / (BX_BM * 2), cp = (byte % (BX_BM * 2)) >> 4;
+            ra_[u] = ((unsigned)kr * (unsigned)p.A.ld + (unsigned)((cp ^ ((kr & 3) << 2)) * 8)) * 2u;
         }
     }
-    // ---- fragment read offsets (bytes inside a plane image) ----------------------------------------------------------------------
-    // NT: lane (i = lane & 31, kg = lane >> 5) reads the 8 k of chunk 2 s + kg of row (64 w + 32 t + i)
-    // TN: 16-lane block b = lane >> 4, c = lane & 15: the block reads [4 k][16 rows]; the lane supplies the address of k-row
-    //     (c >> 2), rows 4 (c & 3) .. + 3 of the block and receives the 4 k of row c: blocks 0 / 1 = rows 0-15 / 16-31 at
-    //     k 0-7, blocks 2 / 3 the same rows at k 8-15 (operand layout of the 32 x 32 x 16 MFMA)
+#pragma unroll
+    for (int u = 0; u < BX_BPW; ++u) {
+        const int pc = lw + BX_NL * u;
+        if constexpr (!TN) {
+            const int r = pc * 16 + (lane >> 2), cs = (lane & 3) ^ ((r >> 2) & 3);
+            rb_[u] = ((unsigned)r * (unsigned)p.B.ld + (unsigned)(cs * 8)) * 2u;
+        } else {
+            const int byte = pc * 1024 + lane * 16, kr = byte / (BX_BN * 2), cp = (byte % (BX_BN * 2)) >> 4;
+            rb_[u] = ((unsigned)kr * (unsigned)p.B.ld + (unsigned)((cp ^ ((kr & 3) << 2)) * 8)) * 2u;
+        }
+    }
+    const unsigned OOB = 0xFFFFFF00u;                  // beyond every num_records (bx3_ok keeps planes below 4e9 bytes)
+    // NT: the last k-tile of a product may hold fewer than 32 valid k (K is a multiple of 8): the chunks beyond K are requested
+    // out of range, i.e. arrive as zeros, and the compute waves multiply every k-tile in full
+    int kca[BX_APW], kcb[BX_BPW];                      // k offset of this lane's source chunk inside a k-tile (NT)
+#pragma unroll
+    for (int u = 0; u < BX_APW; ++u) { const int r = (lw + BX_NL * u) * 16 + (lane >> 2); kca[u] = 8 * ((lane & 3) ^ ((r >> 2) & 3)); }
+#pragma unroll
+    for (int u = 0; u < BX_BPW; ++u) { const int r = (lw + BX_NL * u) * 16 + (lane >> 2); kcb[u] = 8 * ((lane & 3) ^ ((r >> 2) & 3)); }
+    // iterator over the k-tiles of the stream
+    int j = -1, left = 0, kpos = 0;                    // kpos: first k of the current k-tile (NT)
+    unsigned oa = 0, ob = 0;                           // byte offsets of the current k-tile's origin in A / B
+    auto issue_next = [&](int stage) __attribute__((always_inline)) {
+        while (left == 0 && j + 1 < st.count) {        // next unit that has k-tiles
+            ++j;
+            const BxUnit un = bx_unit(p, st, j);
+            left = un.nk;
+            kpos = un.kt0 * BX_BK;
+            if constexpr (!TN) {
+                oa = ((unsigned)(un.tm * BX_BM) * (unsigned)p.A.ld + (unsigned)(un.kt0 * BX_BK)) * 2u;
+                ob = ((unsigned)(un.tn * BX_BN) * (unsigned)p.B.ld + (unsigned)(un.kt0 * BX_BK)) * 2u;
+            } else {
+                oa = ((unsigned)(un.kt0 * BX_BK) * (unsigned)p.A.ld + (unsigned)(un.tm * BX_BM)) * 2u;
+                ob = ((unsigned)(un.kt0 * BX_BK) * (unsigned)p.B.ld + (unsigned)(un.tn * BX_BN)) * 2u;
+            }
+        }
+        const bool real = left > 0;                    // behind the last k-tile: zero fills (out-of-range requests, no traffic) keep
+        unsigned char* sb = bx_smem + stage * BX_STAGE;   // the counted vmcnt uniform
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+#pragma unroll
+            for (int u = 0; u < BX_APW; ++u)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra[q], (bx_lds_ptr)(sb + q * BX_APL + (lw + BX_NL * u) * 1024), 16,
+                                                         (int)((real && (TN || kpos + kca[u] < st.Kx)) ? oa + ra_[u] : OOB), 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < BX_BPW; ++u)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb[q], (bx_lds_ptr)(sb + 3 * BX_APL + q * BX_BPL + (lw + BX_NL * u) * 1024), 16,
+                                                         (int)((real && (TN || kpos + kcb[u] < st.Kx)) ? ob + rb_[u] : OOB), 0, 0, 0);
+        }
+        if (real) { oa += astep; ob += bstep; kpos += BX_BK; --left; }
+    };
+    const int total = bx_total_tiles(p, st);
+    issue_next(0);
+    issue_next(1);
+    bx_wait_vm<PPL>();                                 // k-tile 0 has landed (this wave's share of it)
+    __builtin_amdgcn_s_barrier();                      // B_P
+    int stage = 2;
+    for (int k = 0; k < total; ++k) {
+        issue_next(stage);                             // k-tile k + 2 -> the stage nobody has read since barrier k - 1
+        if (++stage == BX_NS) stage = 0;
+        bx_wait_vm<PPL>();                             // k-tile k + 1 has landed
+        __builtin_amdgcn_s_barrier();                  // B_k
+    }
+    bx_wait_vm<0>();                                   // the zero fills behind the last k-tile
+    __builtin_amdgcn_s_barrier();                      // B_end
+}
+
+// ---- compute waves -----------------------------------------------------------------------------------------------------------------
+// fragment read offsets (bytes inside a plane image):
+//   NT: lane (i = lane & 31, kg = lane >> 5) reads the 8 k of chunk 2 s + kg of row (64 w + 32 t + i)
+//   TN: 16-lane block b = lane >> 4, c = lane & 15: the block reads [4 k][16 rows]; the lane supplies the address of k-row
+//       (c >> 2), rows 4 (c & 3) .. + 3 of the block and receives the 4 k of row c: blocks 0 / 1 = rows 0-15 / 16-31 at
+//       k 0-7, blocks 2 / 3 the same rows at k 8-15 (operand layout of the 32 x 32 x 16 MFMA)
+template <bool TN, int NP, int DBG>
+__device__ __forceinline__ void bx_compute(const BxProb& p, const BxStream& st, const int wave) {
+    const int lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
     int fa[2], fb[2];                                  // NT: per k16-step s; TN: per 32-row tile t
     if constexpr (!TN) {
         const int i = lane & 31, kg = lane >> 5, x = (i >> 2) & 3;
@@ -144,8 +231,8 @@ __device__ __forceinline__ void bx_tile(const BxProb& p, const int Mx, const int
         const int cb = 2 * (b & 1) + ((c & 3) >> 1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            fa[t] = (8 * (b >> 1) + r) * (BM * 2) + ((((wm * 8 + 4 * t) ^ (r << 2)) + cb) << 4) + 8 * (c & 1);
-            fb[t] = (8 * (b >> 1) + r) * (BN * 2) + ((((wn * 8 + 4 * t) ^ (r << 2)) + cb) << 4) + 8 * (c & 1);
+            fa[t] = (8 * (b >> 1) + r) * (BX_BM * 2) + ((((wm * 8 + 4 * t) ^ (r << 2)) + cb) << 4) + 8 * (c & 1);
+            fb[t] = (8 * (b >> 1) + r) * (BX_BN * 2) + ((((wn * 8 + 4 * t) ^ (r << 2)) + cb) << 4) + 8 * (c & 1);
         }
     }
     auto frag = [&](const unsigned char* plane, int t, int s, bool is_a) __attribute__((always_inline)) -> bx_bf16x8 {
@@ -153,7 +240,7 @@ __device__ __forceinline__ void bx_tile(const BxProb& p, const int Mx, const int
             const int off = (is_a ? fa[s] : fb[s]) + t * 32 * 64;
             return __builtin_bit_cast(bx_bf16x8, *reinterpret_cast<const bx_u32x4*>(plane + off));
         } else {
-            const int rs = (is_a ? BM : BN) * 2;
+            const int rs = (is_a ? BX_BM : BX_BN) * 2;
             const int off = (is_a ? fa[t] : fb[t]) + 16 * s * rs;
             const bx_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bx_s16x4 __attribute__((address_space(3)))*)(plane + off));
             const bx_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bx_s16x4 __attribute__((address_space(3)))*)(plane + off + 4 * rs));
@@ -162,45 +249,33 @@ __device__ __forceinline__ void bx_tile(const BxProb& p, const int Mx, const int
             return __builtin_bit_cast(bx_bf16x8, v);
         }
     };
-
     bx_f32x16 acc[2][2];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ---- software pipeline -------------------------------------------------------------------------------------------------------
-    // Two fragment sets: while the 8 NP MFMAs of one 16-k step run on one set, the ds_reads of the next step fill the other, and
-    // the DMA instructions of k-tile kt + NS - 1 are issued BETWEEN the MFMAs (a DMA instruction holds the wave's issue port
-    // for 60-180 cycles, MI355X_MICROARCH.md: twelve of them in a block in front of the MFMAs left the matrix pipes idle 60 % of
-    // the time -- profiles/r04_bx3_sq_v0.txt).  The loop body has no branch: DMA requests beyond the last k-tile are sent with an
-    // out-of-range offset (the descriptor's range check answers with zeros, no memory traffic), so the counted vmcnt is the
-    // same in every iteration.  Order per k-tile:
-    //   phase A   reads (kt, s = 1) -> set 1 | DMA (kt + NS - 1) | MFMAs on set 0 = (kt, s = 0)
-    //   vmcnt: k-tile kt + 1 has landed for this wave; lgkmcnt(0): this wave's reads of tile kt are complete; barrier
-    //   phase B   reads (kt + 1, s = 0) -> set 0 | MFMAs on set 1 = (kt, s = 1)
-    const int nk = kt1 - kt0;
-    const unsigned OOB = 0xFFFFFF00u;                  // beyond every num_records (bx3_ok keeps planes below 4e9 bytes)
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+    };
     bx_bf16x8 a0[2][NP], b0[2][NP], a1[2][NP], b1[2][NP];
-    auto load_set = [&](bx_bf16x8 (&fa_)[2][NP], bx_bf16x8 (&fb_)[2][NP], int st, int s) __attribute__((always_inline)) {
+    auto load_set = [&](bx_bf16x8 (&fa_)[2][NP], bx_bf16x8 (&fb_)[2][NP], int stg, int s) __attribute__((always_inline)) {
         if constexpr (DBG == 1) return;
-        const unsigned char* sa = bx_smem + st * Cf::STAGE;
-        const unsigned char* sbp = sa + 3 * Cf::APL;
+        const unsigned char* sa = bx_smem + stg * BX_STAGE;
+        const unsigned char* sbp = sa + 3 * BX_APL;
 #pragma unroll
         for (int q = 0; q < NP; ++q)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                fa_[t][q] = frag(sa + q * Cf::APL, t, s, true);
-                fb_[t][q] = frag(sbp + q * Cf::BPL, t, s, false);
+                fa_[t][q] = frag(sa + q * BX_APL, t, s, true);
+                fb_[t][q] = frag(sbp + q * BX_BPL, t, s, false);
             }
     };
     auto mma_set = [&](const bx_bf16x8 (&af)[2][NP], const bx_bf16x8 (&bf)[2][NP]) __attribute__((always_inline)) {
         // six piece products per output tile, smallest first; consecutive MFMAs go to different accumulators
 #define EAGCN_BX_PROD(PA, PB)                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                       \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                     \
+        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[jj][PB], acc[i][jj], 0, 0, 0);
         if constexpr (DBG == 1) return;                // (probe: fill only)
         if constexpr (NP == 3) {
             EAGCN_BX_PROD(2, 0)
@@ -212,147 +287,126 @@ __device__ __forceinline__ void bx_tile(const BxProb& p, const int Mx, const int
         EAGCN_BX_PROD(0, 0)
 #undef EAGCN_BX_PROD
     };
-    auto issue_or_skip = [&](int stage, bool real) __attribute__((always_inline)) {
-        if constexpr (DBG == 2) return;                // (probe: compute only, on whatever the LDS holds)
-        unsigned char* sb = bx_smem + stage * Cf::STAGE;
+    // D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    auto store_unit = [&](const BxUnit& un) __attribute__((always_inline)) {
+        float* __restrict__ Cz = p.C + (size_t)un.z * p.slab;
+        const int Mlim = TN ? p.M : st.Mx;
+        const int m0 = un.tm * BX_BM + wm * 64, n0 = un.tn * BX_BN + wn * 64;
+        if (m0 + 64 <= Mlim && n0 + 64 <= p.N) {       // whole block inside the matrix: no predicates
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int u = 0; u < APW; ++u)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra[q], (bx_lds_ptr)(sb + q * Cf::APL + (wave * APW + u) * 1024), 16,
-                                                         (int)(real ? va[u] : OOB), 0, 0, 0);
+                for (int jj = 0; jj < 2; ++jj) {
+                    float* cp = Cz + (size_t)(m0 + i * 32 + 4 * (lane >> 5)) * p.ldc + n0 + jj * 32 + (lane & 31);
 #pragma unroll
-            for (int u = 0; u < BPW; ++u)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb[q], (bx_lds_ptr)(sb + 3 * Cf::APL + q * Cf::BPL + (wave * BPW + u) * 1024), 16,
-                                                         (int)(real ? vb[u] : OOB), 0, 0, 0);
+                    for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][jj][r];
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int col = n0 + jj * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (row < Mlim && col < p.N) Cz[(size_t)row * p.ldc + col] = acc[i][jj][r];
+                    }
+                }
         }
-#pragma unroll
-        for (int u = 0; u < APW; ++u) va[u] += astep;
-#pragma unroll
-        for (int u = 0; u < BPW; ++u) vb[u] += bstep;
     };
-    // prologue: NS - 1 tiles requested (tiles beyond nk as zero fills), tile 0 awaited, set 0 = (0, s = 0)
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue_or_skip(s, s < nk);
-    bx_wait_vm<PPT * (NS - 2)>();
-    __builtin_amdgcn_s_barrier();
+    // ---- the stream: one barrier per k-tile -------------------------------------------------------------------------------------
+    //   phase A   reads (k, s = 1) -> set 1 | MFMAs on set 0 = (k, s = 0)
+    //   lgkmcnt(0): this wave's reads of k-tile k are complete; barrier k: k-tile k + 1 has landed, k-tile k's stage is free
+    //   phase B   reads (k + 1, s = 0) -> set 0 | MFMAs on set 1 = (k, s = 1)
+    // A unit ends with the store of its accumulators while set 0 already holds the next unit's first half and the loader waves
+    // keep requesting: no pipeline drain between units.
+    const int total = bx_total_tiles(p, st);
+    zero_acc();
+    int j = 0;
+    BxUnit un = st.count > 0 ? bx_unit(p, st, 0) : BxUnit{0, 0, 0, 1 << 30, 0};
+    while (j < st.count && un.nk == 0) {               // (empty k-chunks store zeros)
+        store_unit(un);
+        if (++j < st.count) un = bx_unit(p, st, j);
+    }
+    int rem = un.nk;
+    __builtin_amdgcn_s_barrier();                      // B_P
     load_set(a0, b0, 0, 0);
     int stage = 0;
-    // the last k-tile of an NT product may hold only 16 valid k (K is a multiple of 16): its second half is skipped
-    const bool half_tail = !TN && (kt1 * BX_BK > Kx);
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int k = 0; k < total; ++k) {
         int st_next = stage + 1;
-        if (st_next == NS) st_next = 0;
-        int st_dma = stage + NS - 1;
-        if (st_dma >= NS) st_dma -= NS;
+        if (st_next == BX_NS) st_next = 0;
         // ---- phase A
         load_set(a1, b1, stage, 1);
-        issue_or_skip(st_dma, kt + NS - 1 < nk);
         mma_set(a0, b0);
 #pragma unroll
         for (int g = 0; g < 4 * NP; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TN ? 2 : 1, 0);
         }
-        // ---- k-tile kt + 1 is complete for every wave; nobody reads tile kt's stage after this barrier
         __builtin_amdgcn_sched_barrier(0);             // (nothing of phase A sinks below: MFMAs are not memory operations)
-        bx_wait_vm<PPT * (NS - 2)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                  // B_k
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase B
         load_set(a0, b0, st_next, 0);
-        if (!(half_tail && kt == nk - 1)) mma_set(a1, b1);
+        mma_set(a1, b1);
 #pragma unroll
         for (int g = 0; g < 4 * NP; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TN ? 2 : 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         stage = st_next;
+        if (--rem == 0) {                              // the unit is complete
+            store_unit(un);
+            zero_acc();
+            do {
+                if (++j < st.count) un = bx_unit(p, st, j); else un.nk = 1 << 30;
+                if (j < st.count && un.nk == 0) store_unit(un);
+            } while (j < st.count && un.nk == 0);
+            rem = un.nk;
+        }
     }
-    // the zero-fill requests behind the last k-tile have landed and every wave is done with the LDS stages before the next unit's
-    // prologue overwrites them
-    bx_wait_vm<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                      // B_end: every wave is done with the LDS stages
+}
 
-    // ---- epilogue: D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) ------------------------------------------
-    const int Mlim = TN ? p.M : Mx;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < Mlim && col < p.N) Cz[(size_t)row * p.ldc + col] = acc[i][j][r];
+// XCD x (dispatch slot b runs on XCD b % 8) owns the contiguous units [x n / 8, (x + 1) n / 8) of a problem; its workgroups take
+// them round-robin, starting at slot `rot` (the workgroups that drew one unit more of the first problem draw one less of the second)
+__device__ __forceinline__ BxStream bx_stream(const BxProb& p, int rot, int& rot_out) {
+    BxStream st;
+    st.Mx = bx_mx(p); st.Kx = bx_kx(p);
+    st.u = bx_units(p, st.Mx, st.Kx);
+    const int xcd = blockIdx.x & 7, per = max(1, (int)gridDim.x >> 3);
+    const int slot = (((int)blockIdx.x >> 3) - rot % per + per) % per;
+    const int lo = (int)(((long)st.u.n * xcd) >> 3), hi = (int)(((long)st.u.n * (xcd + 1)) >> 3);
+    st.first = lo + slot; st.step = per;
+    st.count = hi - lo > slot ? (hi - lo - slot + per - 1) / per : 0;
+    rot_out = (rot + (hi - lo)) % per;
+    return st;
+}
+
+// up to two problems in one persistent launch (the dX / dW pair of a layer's backward): 4 compute waves + 2 loader waves per CU
+template <int NP, int DBG = 0>
+__global__ __launch_bounds__(64 * (BX_NC + BX_NL), 2) void bx3_kernel(BxProb p0, BxProb p1, int has1) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int rot = 0, rot1 = 0;
+    // the HEAVIER units first (longest-processing-time order inside a workgroup's run): the k-chunks of a dW before the dX tiles
+    for (int pass = 0; pass < (has1 ? 2 : 1); ++pass) {
+        const BxProb& p = (has1 && pass == 0) ? p1 : p0;
+        const BxStream st = bx_stream(p, rot, rot1);
+        rot = rot1;
+        if (wave < BX_NC) {
+            if (p.tn) bx_compute<true, NP, DBG>(p, st, wave); else bx_compute<false, NP, DBG>(p, st, wave);
+        } else {
+            if constexpr (DBG != 2) {
+                if (p.tn) bx_loader<true, NP>(p, st, wave - BX_NC); else bx_loader<false, NP>(p, st, wave - BX_NC);
+            } else {                                   // (probe: products only, on whatever the LDS holds)
+                const int total = bx_total_tiles(p, st);
+                for (int k = 0; k < total + 2; ++k) __builtin_amdgcn_s_barrier();
             }
         }
-}
-
-__device__ __forceinline__ int bx_mx(const BxProb& p) { return (!p.tn && p.M_dev) ? min(*p.M_dev, p.M) : p.M; }
-__device__ __forceinline__ int bx_kx(const BxProb& p) { return (p.tn && p.K_dev) ? min(*p.K_dev, p.K) : p.K; }
-
-// work units of one problem: NT: output tiles; TN: (tile, k-chunk) items, chunk z -> slab z
-struct BxUnits { int tiles_m, tiles_n, splits, kt_total, kt_per; int n; };
-__device__ __forceinline__ BxUnits bx_units(const BxProb& p, int Mx, int Kx, int BM, int BN) {
-    BxUnits u;
-    u.tiles_m = (Mx + BM - 1) / BM;
-    u.tiles_n = (p.N + BN - 1) / BN;
-    u.kt_total = max(1, (Kx + BX_BK - 1) / BX_BK);
-    u.splits = p.tn ? max(1, p.splits) : 1;
-    u.kt_per = (u.kt_total + u.splits - 1) / u.splits;
-    u.n = u.tiles_m * u.tiles_n * u.splits;
-    return u;
-}
-
-template <int WM, int WN, int NP, int DBG>
-__device__ __forceinline__ void bx_run_unit(const BxProb& p, const BxUnits& u, int Mx, int Kx, int id) {
-    // unit order: NT: column tile fastest (the tiles of a row panel are neighbours); TN: k-chunk MAJOR -- the tiles of one k-chunk
-    // are neighbours and share its rows of both operands in their XCD's L2 (tile-major order measured a 13 % L2 hit rate: every
-    // byte of X and dP crossed the fabric once per tile, profiles/r04_bx3_tcc_v1.txt)
-    if (!p.tn) {
-        const int tm = id / u.tiles_n, tn = id - tm * u.tiles_n;
-        bx_tile<false, WM, WN, NP, DBG>(p, Mx, Kx, tm, tn, 0, u.kt_total, p.C);
-    } else {
-        const int tiles = u.tiles_m * u.tiles_n;
-        const int z = id / tiles, tile = id - z * tiles;
-        const int tm = tile / u.tiles_n, tn = tile - tm * u.tiles_n;
-        const int kt0 = min(z * u.kt_per, u.kt_total), kt1 = min(kt0 + u.kt_per, u.kt_total);
-        bx_tile<true, WM, WN, NP, DBG>(p, Mx, Kx, tm, tn, kt0, kt1, p.C + (size_t)z * p.slab);       // (an empty chunk stores zeros)
-    }
-}
-
-// up to two problems in one persistent launch (the dX / dW pair of a layer's backward)
-template <int WM, int WN, int NP, int DBG = 0>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void bx3_kernel(BxProb p0, BxProb p1, int has1) {
-    using Cf = BxCfg<WM, WN>;
-    const int G = gridDim.x;
-    const int Mx0 = bx_mx(p0), Kx0 = bx_kx(p0);
-    const BxUnits u0 = bx_units(p0, Mx0, Kx0, Cf::BM, Cf::BN);
-    int Mx1 = 0, Kx1 = 0;
-    BxUnits u1;
-    u1.n = 0;
-    if (has1) {
-        Mx1 = bx_mx(p1);
-        Kx1 = bx_kx(p1);
-        u1 = bx_units(p1, Mx1, Kx1, Cf::BM, Cf::BN);
-    }
-    const int total = u0.n + u1.n;
-    // XCD x (dispatch slot b runs on XCD b % 8) owns the contiguous units [x chunk, (x + 1) chunk); its G / 8 workgroups take them
-    // round-robin
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = max(1, G >> 3);
-    const int chunk = (total + 7) >> 3;
-    const int lo = xcd * chunk, hi = min(total, lo + chunk);
-    for (int id = lo + slot; id < hi; id += per) {
-        // (ONE instantiation of each form: the problem is selected by value, not by a second copy of the tile code)
-        const bool second = id >= u0.n;
-        const BxProb& p = second ? p1 : p0;
-        const BxUnits& u = second ? u1 : u0;
-        bx_run_unit<WM, WN, NP, DBG>(p, u, second ? Mx1 : Mx0, second ? Kx1 : Kx0, second ? id - u0.n : id);
     }
 }
 
@@ -401,20 +455,19 @@ bool bx3_ok(const BxProb& p) {
     // 32-bit byte offsets inside a plane (buffer descriptor + voffset)
     const double arows = p.tn ? p.K : p.M, brows = p.tn ? p.K : p.N;
     if ((arows + 256) * p.A.ld * 2.0 >= 4.0e9 || (brows + 256) * p.B.ld * 2.0 >= 4.0e9) return false;
-    if (!p.tn) return (p.K & 15) == 0 && p.K <= p.A.ld && p.K <= p.B.ld && !p.K_dev;
+    if (!p.tn) return (p.K & 7) == 0 && p.K <= p.A.ld && p.K <= p.B.ld && !p.K_dev;
     return !p.M_dev && p.M <= p.A.ld && p.N <= p.B.ld && p.splits >= 1 && (p.splits == 1 || p.slab >= (size_t)p.M * p.ldc);
 }
 
-template <int WM, int WN, int NP, int DBG = 0>
+template <int NP, int DBG = 0>
 static int bx3_launch_cfg(const BxProb& p0, const BxProb* p1, hipStream_t s) {
-    using Cf = BxCfg<WM, WN>;
-    constexpr int lds = Cf::NS * Cf::STAGE;
+    constexpr int lds = BX_NS * BX_STAGE;
     static bool attr_done = false;
     if (!attr_done) {
-        EAGCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bx3_kernel<WM, WN, NP, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        EAGCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bx3_kernel<NP, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    bx3_kernel<WM, WN, NP, DBG><<<bx3_grid(), 64 * WM * WN, lds, s>>>(p0, p1 ? *p1 : p0, p1 ? 1 : 0);
+    bx3_kernel<NP, DBG><<<bx3_grid(), 64 * (BX_NC + BX_NL), lds, s>>>(p0, p1 ? *p1 : p0, p1 ? 1 : 0);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
@@ -424,19 +477,10 @@ int launch_bx3(const BxProb& p0, const BxProb* p1, int np, hipStream_t s, double
     EAGCN_CHECK_ARG(bx3_ok(p0) && (!p1 || bx3_ok(*p1)), "bx3 gemm: operands not aligned / extents unsupported");
     EAGCN_CHECK_ARG(np == 1 || np == 3, "bx3 gemm: 1 or 3 planes");
     ProfScope ps(prof_tag, s, work);
-    // tile choice: the 8-wave 256 x 128 tile halves the L2 -> LDS traffic per flop but needs enough row panels to fill the chip
-    static const int forced = [] { const char* e = getenv("EAGCN_BX3_TILE"); return e ? atoi(e) : -1; }();
-    int big = forced;
-    if (big < 0) {
-        const long rows = p0.tn ? p0.M : p0.M;       // (capacity; the kernel counts its units from the device-side extents)
-        big = 0;
-        (void)rows;
-    }
     static const int dbg = [] { const char* e = getenv("EAGCN_BX3_DBG"); return e ? atoi(e) : 0; }();     // probes (wrong results!)
-    if (np == 3 && dbg == 1) return bx3_launch_cfg<2, 2, 3, 1>(p0, p1, s);
-    if (np == 3 && dbg == 2) return bx3_launch_cfg<2, 2, 3, 2>(p0, p1, s);
-    if (np == 3) return big == 1 ? bx3_launch_cfg<4, 2, 3>(p0, p1, s) : bx3_launch_cfg<2, 2, 3>(p0, p1, s);
-    return big == 1 ? bx3_launch_cfg<4, 2, 1>(p0, p1, s) : bx3_launch_cfg<2, 2, 1>(p0, p1, s);
+    if (np == 3 && dbg == 1) return bx3_launch_cfg<3, 1>(p0, p1, s);
+    if (np == 3 && dbg == 2) return bx3_launch_cfg<3, 2>(p0, p1, s);
+    return np == 3 ? bx3_launch_cfg<3>(p0, p1, s) : bx3_launch_cfg<1>(p0, p1, s);
 }
 
 }  // namespace eagcn
