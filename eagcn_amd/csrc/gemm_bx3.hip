@@ -48,10 +48,11 @@ typedef __attribute__((address_space(3))) void* bx_lds_ptr;
 
 constexpr int BX_BK = 32;
 constexpr int BX_NC = 4;                     // compute waves: 2 x 2, one 64 x 64 accumulator block each (one per SIMD)
-constexpr int BX_NL = 2;                     // loader waves
+constexpr int BX_NL = 2;                     // loader waves (four measured the same: the fill is bound by the 64-byte row segments of the NT image, profiles/r04_lds_fill_probe.txt)
 constexpr int BX_BM = 128, BX_BN = 128;
 constexpr int BX_APL = BX_BM * 64, BX_BPL = BX_BN * 64;          // bytes of one plane image of a k-tile
 constexpr int BX_STAGE = 3 * (BX_APL + BX_BPL);                  // 48 KB
+constexpr int BX_MIN_CHUNK = 8;               // shortest k-chunk of a split-K product, in k-tiles
 constexpr int BX_NS = 3;                                         // LDS stages (144 KB)
 constexpr int BX_APW = BX_BM / 16 / BX_NL, BX_BPW = BX_BN / 16 / BX_NL;   // 1 KB DMA pieces per loader wave and plane
 
@@ -76,8 +77,12 @@ __device__ __forceinline__ BxUnits bx_units(const BxProb& p, int Mx, int Kx) {
     u.tiles_m = (Mx + BX_BM - 1) / BX_BM;
     u.tiles_n = (p.N + BX_BN - 1) / BX_BN;
     u.kt_total = max(1, (Kx + BX_BK - 1) / BX_BK);
+    // TN: `splits` slabs are written whatever the actual K (the consumer sums all of them); the k-tiles are spread over as many
+    // of them as keeps a chunk at least BX_MIN_CHUNK k-tiles long (capacity-sized launches: the actual K may be a fraction of the
+    // capacity the host sized `splits` for) -- the remaining chunks are empty and store zeros
     u.splits = p.tn ? max(1, p.splits) : 1;
-    u.kt_per = (u.kt_total + u.splits - 1) / u.splits;
+    const int used = max(1, min(u.splits, u.kt_total / BX_MIN_CHUNK));
+    u.kt_per = (u.kt_total + used - 1) / used;
     u.n = u.tiles_m * u.tiles_n * u.splits;
     return u;
 }
