@@ -70,6 +70,13 @@ struct BxProb {
     int tn;                      // 0: C = A[M,K] . B[N,K]^T;  1: C = A[K,M]^T . B[K,N]
     int splits; size_t slab;     // TN: k-chunk z goes to C + z * slab
 };
+// k-chunk slabs a split-K (TN) product of actual reduction length K really writes: chunks at least 8 k-tiles (256 rows) long.
+// Shared by the kernel and by whoever sums the slabs (layer.hip unpack_grads): the host sizes `splits` for a CAPACITY.
+__host__ __device__ inline int bx3_used_splits(int splits, int K) {
+    const int kt = K > 32 ? (K + 31) / 32 : 1, u = kt / 8;
+    const int s = splits < u ? splits : u;
+    return s > 1 ? s : 1;
+}
 bool bx3_ok(const BxProb& p);
 int bx3_grid();
 // np = 3: exact fp32 products from three planes; np = 1: plain bf16 operands.  p1 (optional): second product in the same launch

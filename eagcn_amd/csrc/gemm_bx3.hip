@@ -52,7 +52,6 @@ constexpr int BX_NL = 2;                     // loader waves (four measured the 
 constexpr int BX_BM = 128, BX_BN = 128;
 constexpr int BX_APL = BX_BM * 64, BX_BPL = BX_BN * 64;          // bytes of one plane image of a k-tile
 constexpr int BX_STAGE = 3 * (BX_APL + BX_BPL);                  // 48 KB
-constexpr int BX_MIN_CHUNK = 8;               // shortest k-chunk of a split-K product, in k-tiles
 constexpr int BX_NS = 3;                                         // LDS stages (144 KB)
 constexpr int BX_APW = BX_BM / 16 / BX_NL, BX_BPW = BX_BN / 16 / BX_NL;   // 1 KB DMA pieces per loader wave and plane
 
@@ -77,12 +76,10 @@ __device__ __forceinline__ BxUnits bx_units(const BxProb& p, int Mx, int Kx) {
     u.tiles_m = (Mx + BX_BM - 1) / BX_BM;
     u.tiles_n = (p.N + BX_BN - 1) / BX_BN;
     u.kt_total = max(1, (Kx + BX_BK - 1) / BX_BK);
-    // TN: `splits` slabs are written whatever the actual K (the consumer sums all of them); the k-tiles are spread over as many
-    // of them as keeps a chunk at least BX_MIN_CHUNK k-tiles long (capacity-sized launches: the actual K may be a fraction of the
-    // capacity the host sized `splits` for) -- the remaining chunks are empty and store zeros
-    u.splits = p.tn ? max(1, p.splits) : 1;
-    const int used = max(1, min(u.splits, u.kt_total / BX_MIN_CHUNK));
-    u.kt_per = (u.kt_total + used - 1) / used;
+    // TN: the k-tiles are spread over bx3_used_splits() chunks (at least 8 k-tiles each; capacity-sized launches: the actual K may
+    // be a fraction of the capacity the host sized `splits` for); only those slabs are written, and the consumer sums only those
+    u.splits = p.tn ? bx3_used_splits(max(1, p.splits), Kx) : 1;
+    u.kt_per = (u.kt_total + u.splits - 1) / u.splits;
     u.n = u.tiles_m * u.tiles_n * u.splits;
     return u;
 }
@@ -254,14 +251,21 @@ __device__ __forceinline__ void bx_compute(const BxProb& p, const BxStream& st, 
             return __builtin_bit_cast(bx_bf16x8, v);
         }
     };
-    bx_f32x16 acc[2][2];
+    // TWO accumulators per output tile.  v_mfma_f32_32x32x16_bf16 does not round its accumulation to nearest: a same-sign
+    // reduction through ONE accumulator drifts by about -2.7e-11 K relative (tools/bx3_bench bias: -6e-7 at K = 25 000, -3e-6 at
+    // 100 000; the fp32 MFMA stays at 1e-9), because every one of the six piece products of a k-step costs the running sum a
+    // truncation at ITS magnitude.  Five of the six carry a weight of 2^-8 or less: they go to `lo`, whose own magnitude is 2^-8
+    // of the result (its truncations are worth 2^-32 of the result), and `hi` sees ONE instruction per k-step -- the exact
+    // products a0.b0 -- i.e. a sixth of the truncations and of the drift (about -4e-8 over the 8192-row k-chunks the host
+    // cuts a weight gradient into).  hi + lo (v_add_f32: round to nearest even) is formed once, in the epilogue.
+    bx_f32x16 acc[2][2], lo[2][2];
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+                for (int r = 0; r < 16; ++r) { acc[i][jj][r] = 0.f; lo[i][jj][r] = 0.f; }
     };
     bx_bf16x8 a0[2][NP], b0[2][NP], a1[2][NP], b1[2][NP];
     auto load_set = [&](bx_bf16x8 (&fa_)[2][NP], bx_bf16x8 (&fb_)[2][NP], int stg, int s) __attribute__((always_inline)) {
@@ -278,18 +282,18 @@ __device__ __forceinline__ void bx_compute(const BxProb& p, const BxStream& st, 
     };
     auto mma_set = [&](const bx_bf16x8 (&af)[2][NP], const bx_bf16x8 (&bf)[2][NP]) __attribute__((always_inline)) {
         // six piece products per output tile, smallest first; consecutive MFMAs go to different accumulators
-#define EAGCN_BX_PROD(PA, PB)                                                                                          \
+#define EAGCN_BX_PROD(ACC, PA, PB)                                                                                     \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                     \
-        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[jj][PB], acc[i][jj], 0, 0, 0);
+        ACC[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[jj][PB], ACC[i][jj], 0, 0, 0);
         if constexpr (DBG == 1) return;                // (probe: fill only)
         if constexpr (NP == 3) {
-            EAGCN_BX_PROD(2, 0)
-            EAGCN_BX_PROD(1, 1)
-            EAGCN_BX_PROD(0, 2)
-            EAGCN_BX_PROD(1, 0)
-            EAGCN_BX_PROD(0, 1)
+            EAGCN_BX_PROD(lo, 2, 0)
+            EAGCN_BX_PROD(lo, 1, 1)
+            EAGCN_BX_PROD(lo, 0, 2)
+            EAGCN_BX_PROD(lo, 1, 0)
+            EAGCN_BX_PROD(lo, 0, 1)
         }
-        EAGCN_BX_PROD(0, 0)
+        EAGCN_BX_PROD(acc, 0, 0)
 #undef EAGCN_BX_PROD
     };
     // D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -304,7 +308,7 @@ __device__ __forceinline__ void bx_compute(const BxProb& p, const BxStream& st, 
                 for (int jj = 0; jj < 2; ++jj) {
                     float* cp = Cz + (size_t)(m0 + i * 32 + 4 * (lane >> 5)) * p.ldc + n0 + jj * 32 + (lane & 31);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][jj][r];
+                    for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][jj][r] + lo[i][jj][r];
                 }
         } else {
 #pragma unroll
@@ -315,7 +319,7 @@ __device__ __forceinline__ void bx_compute(const BxProb& p, const BxStream& st, 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        if (row < Mlim && col < p.N) Cz[(size_t)row * p.ldc + col] = acc[i][jj][r];
+                        if (row < Mlim && col < p.N) Cz[(size_t)row * p.ldc + col] = acc[i][jj][r] + lo[i][jj][r];
                     }
                 }
         }
@@ -510,6 +514,8 @@ extern "C" int eagcn_gemm_bx3(int tn, int M, int N, int K, const uint16_t* A, si
     p.M = M; p.N = N; p.K = K; p.tn = tn; p.splits = tn ? std::max(1, splits) : 1; p.slab = slab;
     return launch_bx3(p, nullptr, np, (hipStream_t)stream, 2.0 * M * N * K, PROF_GEMM);
 }
+
+extern "C" int eagcn_bx3_used_splits(int splits, int K) { return bx3_used_splits(splits < 1 ? 1 : splits, K); }
 
 /* the dX / dW pair of a layer's backward in ONE persistent launch: problem 0 NT, problem 1 TN with split-K slabs */
 extern "C" int eagcn_gemm_bx3_pair(int M0, int N0, int K0, const uint16_t* A0, size_t a0_pstride, int lda0, const uint16_t* B0,

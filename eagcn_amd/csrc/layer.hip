@@ -618,9 +618,9 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
                                                             int nedge, const float* __restrict__ rsig, int wblocks,
                                                             const int32_t* __restrict__ meta, int xk_G, int edge_drain) {
     nedge = nedge < 0 ? -nedge : min(nedge, (meta[EAGCN_META_T] + 15) / 16);   // edge-gradient workgroups that had rows (< 0: all wrote)
-    // split-K partials actually written: gemm.hip writes eff_splits of them; the plane GEMM (gemm_bx3.hip) writes every one of
-    // its k-chunk slabs (an empty chunk stores zeros) and passes the count negated
-    nsplit = nsplit < 0 ? -nsplit : max(1, min(nsplit, meta[EAGCN_META_T] >> 7));
+    // split-K partials actually written: gemm.hip writes eff_splits of them; the plane GEMM (gemm_bx3.hip) passes its slab count
+    // negated and writes bx3_used_splits() of them
+    nsplit = nsplit < 0 ? bx3_used_splits(-nsplit, meta[EAGCN_META_T]) : max(1, min(nsplit, meta[EAGCN_META_T] >> 7));
     if ((int)blockIdx.x < wblocks) {
         // split-K slabs: FOUR lanes per element, each adds every fourth slab (the first layer's weight gradient leaves gemm.hip
         // as up to 146 slabs: one thread per element was a chain of 37 dependent load rounds, 14 us at B = 1024)
@@ -768,7 +768,9 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
         const int tiles128 = cdiv(d.ld_in, 128) * cdiv(d.fp, 128);
         const int by_fill = cdiv(2 * bx3_grid(), tiles128);
         const int by_len = std::max(1, cdiv(std::max(b->T, 1), 256));
-        d.bx_splits = std::max(1, std::min(std::min(by_fill, by_len), 32));
+        // ... and at most 4096 rows long (accumulation chains of gemm_bx3.hip: the bf16 MFMA accumulate drifts), up to 64 slabs
+        const int by_drift = cdiv(std::max(b->T, 1), 4096);
+        d.bx_splits = std::max(1, std::min(std::max(std::min(std::min(by_fill, by_len), 32), by_drift), 64));
     }
     return d;
 }

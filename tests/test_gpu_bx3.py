@@ -1,0 +1,159 @@
+"""The plane GEMM of gemm mode 3 (csrc/gemm_bx3.hip; reference layers.py:40 `torch.mm` and its two autograd products) through its
+C-ABI entry points: exactness of the three-way bf16 split, both operand forms against float64 (edges: extents that are not tile
+multiples, k tails, empty / single k-chunks, one launch for the dX / dW pair), the drift of long same-sign reductions, and the
+whole model in mode 3 against mode 0 (fp32 MFMA) at widths where every hidden layer runs on it."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from eagcn_amd import _lib as L
+    return L.load(), L
+
+
+def _planes(x, np_=3):
+    """bf16 planes of a contiguous fp32 CUDA matrix [R, ld] -> (int16 tensor [np, R * ld padded], plane stride)."""
+    lib, L = _lib()
+    R, ld = x.shape
+    stride = (R * ld + 63) // 64 * 64
+    pl = torch.zeros(np_ * stride, dtype=torch.int16, device='cuda')
+    L.check(lib.eagcn_bx3_split(C.c_void_p(x.data_ptr()), R, ld, C.c_void_p(pl.data_ptr()), stride, np_, None), 'eagcn_bx3_split')
+    return pl, stride
+
+
+def _bf16_to_f32(p):
+    return (p.to(torch.int32) << 16).view(torch.float32)
+
+
+def test_split_is_exact():
+    torch.manual_seed(0)
+    x = torch.randn(37, 64, device='cuda') * torch.logspace(-20, 20, 64, device='cuda')
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1.17549435e-38, 2.0 ** -100], device='cuda')
+    pl, stride = _planes(x)
+    parts = [_bf16_to_f32(pl[q * stride:q * stride + x.numel()]).view_as(x).double() for q in range(3)]
+    assert torch.equal((parts[0] + parts[1] + parts[2]).float(), x), 'x0 + x1 + x2 must reproduce x bit for bit'
+    # every piece is the bf16 nearest to what is left: |x1| <= 2^-8 |x0|, |x2| <= 2^-8 |x1|
+    assert (parts[1].abs() <= parts[0].abs() * 2.0 ** -8 + 1e-300).all() and (parts[2].abs() <= parts[1].abs() * 2.0 ** -8 + 1e-300).all()
+    one, _ = _planes(x, 1)
+    assert torch.equal(_bf16_to_f32(one[:x.numel()]).view_as(x), x.to(torch.bfloat16).float())      # round to nearest even
+
+
+def _gemm(tn, A, B, M, N, K, splits=1):
+    lib, L = _lib()
+    pa, sa = _planes(A)
+    pb, sb = _planes(B)
+    ldc = (N + 3) // 4 * 4
+    slab = M * ldc
+    Cm = torch.full((max(splits, 1) * slab,), float('nan'), device='cuda')
+    L.check(lib.eagcn_gemm_bx3(tn, M, N, K, C.c_void_p(pa.data_ptr()), sa, A.shape[1], C.c_void_p(pb.data_ptr()), sb, B.shape[1],
+                               C.c_void_p(Cm.data_ptr()), ldc, splits, slab, 3, None), 'eagcn_gemm_bx3')
+    used = lib.eagcn_bx3_used_splits(splits, K) if tn else 1
+    return Cm.view(max(splits, 1), M, ldc)[:used, :, :N].double().sum(0), Cm.view(max(splits, 1), M, ldc)
+
+
+def _err(got, A64, B64, tn):
+    ref = A64.t() @ B64 if tn else A64 @ B64.t()
+    den = A64.abs().t() @ B64.abs() if tn else A64.abs() @ B64.abs().t()
+    return ((got - ref).abs() / den.clamp_min(1e-300)).max().item()
+
+
+@pytest.mark.parametrize('M,N,K,pad', [(128, 128, 32, 0), (100, 90, 48, 8), (4809, 720, 400, 16), (37, 16, 128, 0), (300, 200, 24, 8),
+                                       (2500, 1264, 512, 0), (1, 1, 8, 0)])
+def test_nt_product_vs_float64(M, N, K, pad):
+    """C = A.B^T (forward P = X.Wcat^T and dX = dP.Wcat: both operands K-contiguous); K a multiple of 8, leading dimensions larger than
+    K (whatever follows the k range in a row must not reach a result)."""
+    torch.manual_seed(M + N + K)
+    A = torch.full((M, K + pad), 7.0e30, device='cuda')
+    B = torch.full((N, K + pad), -3.0e30, device='cuda')
+    A[:, :K] = torch.randn(M, K, device='cuda')
+    B[:, :K] = torch.randn(N, K, device='cuda') * 0.05
+    got, raw = _gemm(0, A, B, M, N, K)
+    e = _err(got, A[:, :K].double(), B[:, :K].double(), False)
+    assert e <= 8 * 2.0 ** -24, e
+    assert torch.isnan(raw[0, :, N:]).all(), 'columns beyond N were written'
+
+
+@pytest.mark.parametrize('M,N,K,splits', [(128, 128, 32, 1), (100, 90, 75, 1), (400, 720, 4809, 6), (400, 720, 4809, 1), (512, 1024, 3000, 3),
+                                          (128, 16, 37, 2), (64, 64, 700, 64), (8, 8, 1, 1)])
+def test_tn_product_vs_float64(M, N, K, splits):
+    """C = A^T.B (dW = X^T.dP: the reduction runs over the packed rows) as k-chunk slabs; rows beyond K read as zero; slabs beyond
+    eagcn_bx3_used_splits are not written."""
+    lib, _ = _lib()
+    torch.manual_seed(M * 3 + N + K)
+    A = torch.randn(K, (M + 7) // 8 * 8, device='cuda')
+    B = torch.randn(K, (N + 7) // 8 * 8 + 8, device='cuda')
+    got, raw = _gemm(1, A, B, M, N, K, splits)
+    e = _err(got, A[:, :M].double(), B[:, :N].double(), True)
+    assert e <= 8 * 2.0 ** -24, e
+    used = lib.eagcn_bx3_used_splits(splits, K)
+    assert 1 <= used <= splits and torch.isnan(raw[used:]).all() and not torch.isnan(raw[:used, :, :N]).any()
+
+
+def test_pair_launch_equals_the_two_products():
+    lib, L = _lib()
+    torch.manual_seed(5)
+    T, FIN, FP, splits = 3000, 256, 400, 4
+    X = torch.randn(T, FIN, device='cuda').relu()
+    dP = torch.randn(T, FP, device='cuda')
+    W = torch.randn(FIN, FP, device='cuda') * 0.05
+    dx_ref, _ = _gemm(0, dP, W, T, FIN, FP)
+    dw_ref, _ = _gemm(1, X, dP, FIN, FP, T, splits)
+    px, sx = _planes(X)
+    pp, sp = _planes(dP)
+    pw, sw = _planes(W)
+    dX = torch.zeros(T, FIN, device='cuda')
+    dW = torch.zeros(splits, FIN, FP, device='cuda')
+    L.check(lib.eagcn_gemm_bx3_pair(T, FIN, FP, C.c_void_p(pp.data_ptr()), sp, FP, C.c_void_p(pw.data_ptr()), sw, FP, C.c_void_p(dX.data_ptr()), FIN,
+                                    FIN, FP, T, C.c_void_p(px.data_ptr()), sx, FIN, C.c_void_p(pp.data_ptr()), sp, FP, C.c_void_p(dW.data_ptr()), FP,
+                                    splits, FIN * FP, 3, None), 'eagcn_gemm_bx3_pair')
+    used = lib.eagcn_bx3_used_splits(splits, T)
+    assert torch.equal(dX.double(), dx_ref) and torch.equal(dW[:used].double().sum(0), dw_ref), 'a unit computes the same bits in either launch'
+
+
+def test_long_same_sign_reduction_does_not_drift():
+    """The bf16 MFMA accumulate is not round-to-nearest; the kernel keeps the exact leading products apart from the five small ones
+    (gemm_bx3.hip): a 4096-row chunk -- the longest chain the layer path cuts -- stays within 2e-8 of the float64 sum on average."""
+    torch.manual_seed(9)
+    K = 4096
+    A = torch.rand(K, 128, device='cuda')
+    B = torch.rand(K, 128, device='cuda')
+    got, _ = _gemm(1, A, B, 128, 128, K, 1)
+    ref = A.double().t() @ B.double()
+    rel = (got - ref) / ref
+    assert abs(rel.mean().item()) <= 2e-8 and rel.abs().max().item() <= 3e-6, (rel.mean().item(), rel.abs().max().item())
+
+
+@pytest.mark.parametrize('structure', ['Concate', 'Weighted_sum'])
+def test_model_in_plane_mode_against_fp32_mfma_mode(structure):
+    """Same model, same batch: gemm mode 3 (the default) against mode 0 (fp32 MFMA): outputs to 1e-5, every gradient to 1e-5 of its
+    own largest entry + 2e-6 of the case's (the two differ in the rounding of the layer products only)."""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.synthetic import make_batch
+    lib, _ = _lib()
+    mb = make_batch(B=48, n_max=60, n_med=16, rel_channels=(28, 4, 2, 2, 2), seed=21)
+    dense = [t.cuda() for t in mb.dense()]
+    res = {}
+    for mode in (0, 3):
+        old = lib.eagcn_set_gemm_mode(mode)
+        try:
+            torch.manual_seed(3)
+            m = EAGCN(28, 24, *[48] * 5, *[64] * 5, 64, 32, 3, 0.0, structure=structure, n_layers=3, grad_mode='direct').cuda().train()
+            torch.manual_seed(4)
+            cot = torch.randn(48, 3, device='cuda')
+            out, _, gr = m(*dense)
+            ((out * cot).sum() + 0.1 * gr.sum()).backward()
+            res[mode] = (out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        finally:
+            lib.eagcn_set_gemm_mode(old)
+    o0, g0 = res[0]
+    o3, g3 = res[3]
+    assert ((o3 - o0).abs().max() / o0.abs().max()).item() < 1e-5
+    scale = max(v.abs().max().item() for v in g0.values())
+    for k, v in g0.items():
+        d = (g3[k] - v).abs().max().item()
+        assert d <= 1e-5 * v.abs().max().item() + 2e-6 * scale, (k, d, v.abs().max().item(), scale)

@@ -37,6 +37,16 @@ def _setup(name, **kw):
                   widths1=c['w1'], widths2=c['w2'], rel_channels=chans, structure=c['structure'],
                   n_layers=c['n_layers'], **kw)
     model.apply(weights_init)
+    # Two evaluations of the same model that differ in ROUNDING (molecules permuted, fused against composed read-out, torch's head
+    # against head2.hip) are compared here at batch sizes where a single flipped relu of the HEAD shows: with 1024 x (n_den1 +
+    # n_den2) pre-activations one of them sits within fp32 rounding of zero in almost every instance, and relu' of that unit
+    # decides a 1 / B share of several gradients (measured: bn_den1.bias 9e-4, den1.weight 7e-4, layer1.ave.weight 1.5e-4 between two
+    # bit-deterministic paths whose forward outputs agree to 9e-7).  The head's BatchNorm shifts are therefore moved to +6 sigma:
+    # its relus stay on their linear branch, every other operation (and every layer relu: those kernels see identical inputs
+    # in both evaluations) is exercised as it is; the head's relu gating is pinned by the oracle tests at small sizes.
+    with torch.no_grad():
+        model.bn_den1.bias.fill_(6.0)
+        model.bn_den2.bias.fill_(6.0)
     return c, mb, model.cuda().train()
 
 

@@ -105,7 +105,7 @@ static void check_tn(int M, int N, int K, int splits, int cap_extra) {
     Mat A(K, M, lda, 1.0f, cap_extra), B(K, N, ldb, 1.0f, cap_extra);
     const size_t slab = (size_t)M * ldc;
     float* dC; CK(hipMalloc(&dC, slab * splits * 4));
-    CK(hipMemset(dC, 0xFF, slab * splits * 4));
+    CK(hipMemset(dC, 0, slab * splits * 4));          // (chunks beyond bx3_used_splits are not written)
     RC(eagcn_gemm_bx3(1, M, N, K, A.pl, A.pstride, lda, B.pl, B.pstride, ldb, dC, ldc, splits, slab, 3, nullptr));
     CK(hipDeviceSynchronize());
     std::vector<float> Cs(slab * splits), C(slab, 0.f);
@@ -166,8 +166,71 @@ static void time_layer(const char* name, int T, int FIN, int FP, int iters) {
     (void)hipFree(P); (void)hipFree(dX); (void)hipFree(dW); (void)hipFree(ws);
 }
 
+// signed error of long same-sign reductions: does the accumulation round or truncate?
+static void bias_test(int K) {
+    const int M = 128, N = 128;
+    const int lda = M, ldb = N, ldc = N;
+    Mat A(K, M, lda, 1.0f), B(K, N, ldb, 1.0f);
+    for (auto& v : A.h) v = fabsf(v);
+    for (auto& v : B.h) v = fabsf(v);
+    CK(hipMemcpy(A.d, A.h.data(), A.h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B.d, B.h.data(), B.h.size() * 4, hipMemcpyHostToDevice));
+    RC(eagcn_bx3_split(A.d, K, lda, A.pl, A.pstride, 3, nullptr));
+    RC(eagcn_bx3_split(B.d, K, ldb, B.pl, B.pstride, 3, nullptr));
+    float *dC, *dC2; CK(hipMalloc(&dC, M * ldc * 4)); CK(hipMalloc(&dC2, M * ldc * 4));
+    size_t wsb = eagcn_gemm_sk_workspace_bytes();
+    void* ws; CK(hipMalloc(&ws, wsb));
+    CK(hipMemset(dC, 0, M * ldc * 4));
+    RC(eagcn_gemm_bx3(1, M, N, K, A.pl, A.pstride, lda, B.pl, B.pstride, ldb, dC, ldc, 1, (size_t)M * ldc, 3, nullptr));
+    RC(eagcn_gemm_f32_sk(1, 0, M, N, K, A.d, lda, B.d, ldb, dC2, ldc, ws, wsb, nullptr));
+    CK(hipDeviceSynchronize());
+    std::vector<float> C(M * ldc), C2(M * ldc);
+    CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(C2.data(), dC2, C2.size() * 4, hipMemcpyDeviceToHost));
+    double sb = 0, s2 = 0, mb = 0, m2 = 0; int n = 0;
+    for (int i = 0; i < M; i += 3) for (int j = 0; j < N; j += 5) {
+        double s = 0; for (int k = 0; k < K; ++k) s += (double)A.h[(size_t)k * lda + i] * B.h[(size_t)k * ldb + j];
+        const double e1 = (C[i * ldc + j] - s) / s, e2 = (C2[i * ldc + j] - s) / s;
+        sb += e1; s2 += e2; mb = fmax(mb, fabs(e1)); m2 = fmax(m2, fabs(e2)); ++n;
+    }
+    printf("same-sign reduction K=%6d: bx3 mean signed rel err %+.2e (max %.2e) | fp32 MFMA %+.2e (max %.2e)   [eps = 6e-8]\n", K, sb / n, mb, s2 / n, m2);
+    (void)hipFree(dC); (void)hipFree(dC2); (void)hipFree(ws);
+}
+
+// heavy cancellation: nearly constant A columns against zero-mean B columns (what a BatchNorm backward feeds the weight gradient)
+static void cancel_test(int K, float spread) {
+    const int M = 128, N = 128;
+    const int lda = M, ldb = N, ldc = N;
+    Mat A(K, M, lda, 1.0f), B(K, N, ldb, 1.0f);
+    for (auto& v : A.h) v = 1.0f + spread * v;
+    for (int j = 0; j < N; ++j) { double m = 0; for (int k = 0; k < K; ++k) m += B.h[(size_t)k * ldb + j]; m /= K; for (int k = 0; k < K; ++k) B.h[(size_t)k * ldb + j] -= (float)m; }
+    CK(hipMemcpy(A.d, A.h.data(), A.h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B.d, B.h.data(), B.h.size() * 4, hipMemcpyHostToDevice));
+    RC(eagcn_bx3_split(A.d, K, lda, A.pl, A.pstride, 3, nullptr));
+    RC(eagcn_bx3_split(B.d, K, ldb, B.pl, B.pstride, 3, nullptr));
+    float *dC, *dC2; CK(hipMalloc(&dC, M * ldc * 4)); CK(hipMalloc(&dC2, M * ldc * 4));
+    size_t wsb = eagcn_gemm_sk_workspace_bytes();
+    void* ws; CK(hipMalloc(&ws, wsb));
+    CK(hipMemset(dC, 0, M * ldc * 4));
+    RC(eagcn_gemm_bx3(1, M, N, K, A.pl, A.pstride, lda, B.pl, B.pstride, ldb, dC, ldc, 1, (size_t)M * ldc, 3, nullptr));
+    RC(eagcn_gemm_f32_sk(1, 0, M, N, K, A.d, lda, B.d, ldb, dC2, ldc, ws, wsb, nullptr));
+    CK(hipDeviceSynchronize());
+    std::vector<float> C(M * ldc), C2(M * ldc);
+    CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(C2.data(), dC2, C2.size() * 4, hipMemcpyDeviceToHost));
+    double num1 = 0, num2 = 0, den = 0, sab = 0; int n = 0;
+    for (int i = 0; i < M; i += 3) for (int j = 0; j < N; j += 5) {
+        double s = 0, sa = 0; for (int k = 0; k < K; ++k) { const double t = (double)A.h[(size_t)k * lda + i] * B.h[(size_t)k * ldb + j]; s += t; sa += fabs(t); }
+        num1 = fmax(num1, fabs(C[i * ldc + j] - s)); num2 = fmax(num2, fabs(C2[i * ldc + j] - s)); den = fmax(den, fabs(s)); sab = fmax(sab, sa); ++n;
+    }
+    printf("cancellation K=%6d spread %.0e: max|result| / sum|a||b| = %.1e;  max err / max|result|: bx3 %.2e | fp32 MFMA %.2e\n", K, spread, den / sab, num1 / den, num2 / den);
+    (void)hipFree(dC); (void)hipFree(dC2); (void)hipFree(ws);
+}
+
 int main(int argc, char** argv) {
     const char* mode = argc > 1 ? argv[1] : "check";
+    if (!strcmp(mode, "cancel")) { cancel_test(25000, 1.0f); cancel_test(25000, 1e-1f); cancel_test(25000, 1e-2f); cancel_test(25000, 1e-3f); cancel_test(4096, 1e-2f); return 0; }
+    if (!strcmp(mode, "bias")) { bias_test(512); bias_test(4096); bias_test(25000); bias_test(100000); return 0; }
     printf("abi %d\n", eagcn_abi_version());
     if (!strcmp(mode, "check")) {
         check_nt(128, 128, 32, 0);
