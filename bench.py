@@ -47,6 +47,11 @@ WORKLOADS = {
                      all_full=True, task='reg'),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 (v_mfma_f32_32x32x16_bf16); an exact fp32 product costs SIX of them (gemm_bx3.hip)
+GEMM_MODES = {0: 'f32 (fp32 MFMA v_mfma_f32_16x16x4_f32, exact fp32 products)',
+              3: 'f32 (bf16x3 split, fp32 accumulate): every fp32 operand leaves its producer as three bf16 planes, six v_mfma_f32_32x32x16_bf16 '
+                 'piece products per 16 k rebuild the fp32 product (csrc/gemm_bx3.hip); aggregation, BatchNorm, head, first layer fp32',
+              4: 'bf16 operands (ONE plane, round to nearest even), fp32 accumulate: BASELINE configs[1] as written; NOT the parity path'}
 PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join('profiles', 'r03_pmc_traffic.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')) else 'r02_pmc_traffic.json')
 
@@ -355,13 +360,23 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--eval-throughput', action='store_true',
                     help='also time the eval-mode forward (forward-only graph under no_grad); reported as an extra field')
+    ap.add_argument('--gemm-mode', type=int, default=None, help='layer products: 3 (default) bf16x3 planes on the bf16 matrix cores, 0 fp32 MFMA, '
+                    '4 one bf16 plane (eagcn_set_gemm_mode)')
+    ap.add_argument('--require-in-graph-allreduce', action='store_true',
+                    help='N > 1: fail instead of falling back to a host-issued all-reduce when the collective cannot be captured into the step graph')
     ap.add_argument('--input', default='dense', choices=('dense', 'compact'),
                     help="dense: the reference's collate tensors (headline); compact: bond list via forward_compact")
     args = ap.parse_args()
 
+    if args.require_in_graph_allreduce:
+        os.environ['EAGCN_REQUIRE_IN_GRAPH_ALLREDUCE'] = '1'      # (read by eagcn_amd.graph at import)
     from eagcn_amd import _lib
     from eagcn_amd.parallel import GradientAllReducer, init_distributed
     lib = _lib.load()                                    # fail loudly if the HIP library is missing
+    if args.gemm_mode is not None:
+        lib.eagcn_set_gemm_mode(args.gemm_mode)
+    gemm_mode = lib.eagcn_set_gemm_mode(0)
+    lib.eagcn_set_gemm_mode(gemm_mode)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU path')
     rank, world, local = init_distributed()
@@ -380,14 +395,14 @@ def main():
         pair = kern.get('gemm_pair', (0.0, 0.0, 0))[2] > 0
         g_ms, g_work, g_n = kern['gemm_pair'] if pair else kern['gemm']
         achieved = (g_work / (g_ms * 1e-3)) / 1e12 if g_ms > 0 else 0.0
-        traffic, traffic_src = committed_traffic('gemm3_kernel<false, true') if args.workload == 'tox21_c2' and B == 256 else (None, None)
+        traffic, traffic_src = committed_traffic('bx3_kernel' if gemm_mode == 3 else 'gemm3_kernel<false, true') if args.workload == 'tox21_c2' and B == 256 else (None, None)
         prof_steps = res['prof_steps']
         out = {
             'metric': 'molecules/sec fwd+bwd, 2-layer 5-view EAGCN, Tox21 batch' if args.workload == 'tox21_c2'
                       else 'molecules/sec fwd+bwd, EAGCN %s' % args.workload,
             'value': head['value'], 'unit': 'molecules/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': GEMM_MODES.get(gemm_mode, 'f32 (gemm mode %d)' % gemm_mode), 'data': 'synthetic',
             'repeats': args.repeats, 'value_min': head['value_min'], 'value_max': head['value_max'],
             'timing': 'median of %d timed blocks of %d steps each (barrier + synchronize around every block, max over ranks); '
                       'value_min / value_max = slowest / fastest block' % (args.repeats, args.steps),
@@ -402,10 +417,17 @@ def main():
                        'global_batch': world * B, 'atoms_per_batch': int(mb.sizes.sum()),
                        'parallelism': 'dp%d' % world},
             'algorithmic_gflop_per_step': head['algorithmic_gflop_per_step'],
-            'roofline': {'kernel': 'gemm3_kernel<false, true, true> (dX = dP.W^T and dW = X^T.dP of a hidden layer in one balanced launch, fp32 MFMA)'
-                                   if pair else 'layer GEMMs (flat X.[W_1..W_K] transform and its backward products)',
-                         'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+            'roofline': {'kernel': (('bx3_kernel<3> (dX = dP.W^T and dW = X^T.dP of a hidden layer in one persistent launch from bf16x3 operand planes: '
+                                     '6 x v_mfma_f32_32x32x16_bf16 per exact fp32 product)' if gemm_mode == 3 else
+                                     'gemm3_kernel<false, true, true> (dX = dP.W^T and dW = X^T.dP of a hidden layer in one balanced launch, fp32 MFMA)')
+                                    if pair else 'layer GEMMs (flat X.[W_1..W_K] transform and its backward products)'),
+                         'bound': 'mfma', 'achieved': round(achieved, 3),
+                         # the peak of the instruction actually issued: dense bf16 / 6 piece products in mode 3, the fp32 MFMA rate in mode 0
+                         'peak': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if (gemm_mode == 3 and pair) else PEAK_FP32_MFMA_TFLOPS,
+                         'peak_fp32_mfma': PEAK_FP32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s',
+                         'frac': round(achieved / ((PEAK_BF16_MFMA_TFLOPS / 6.0) if (gemm_mode == 3 and pair) else PEAK_FP32_MFMA_TFLOPS), 4),
+                         'frac_of_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          'step_frac': head['step_frac'],
                          'step_frac_note': 'whole step: algorithmic_gflop_per_step / ms_per_step / peak',
                          'hbm': {'algorithmic_mbytes_per_step': head['algorithmic_mbytes_per_step'], 'peak_gbs': PEAK_HBM_GBS,
@@ -437,10 +459,14 @@ def main():
         keep = (args.repeats, args.steps, args.warmup)
         keep_rotate = args.rotate
         extra = {}
-        for key, (wname, wb, steps, mode) in (('b1024', ('tox21_c2', 1024, 30, 0)), ('hiv_c3', ('hiv_c3', 1024, 10, 0)),
-                                               ('lipo_c4', ('lipo_c4', 512, 30, 0)), ('c5_synth', ('c5_synth', 1024, 6, 0)),
-                                               ('c2_bf16_products', ('tox21_c2', 256, 50, 2)),
-                                               ('c2_rotate4', ('tox21_c2', 256, 50, 0)), ('b1024_rotate4', ('tox21_c2', 1024, 30, 0))):
+        M = gemm_mode
+        for key, (wname, wb, steps, mode) in (('b1024', ('tox21_c2', 1024, 30, M)), ('hiv_c3', ('hiv_c3', 1024, 10, M)),
+                                               ('lipo_c4', ('lipo_c4', 512, 30, M)), ('c5_synth', ('c5_synth', 1024, 6, M)),
+                                               # the same steps with the layer products on the fp32 MFMA (gemm mode 0: round 3's path)
+                                               ('c2_fp32_mfma', ('tox21_c2', 256, 50, 0)), ('b1024_fp32_mfma', ('tox21_c2', 1024, 30, 0)),
+                                               ('hiv_c3_fp32_mfma', ('hiv_c3', 1024, 10, 0)), ('c5_synth_fp32_mfma', ('c5_synth', 1024, 6, 0)),
+                                               ('c2_bf16', ('tox21_c2', 256, 50, 4)), ('b1024_bf16', ('tox21_c2', 1024, 30, 4)),
+                                               ('c2_rotate4', ('tox21_c2', 256, 50, M)), ('b1024_rotate4', ('tox21_c2', 1024, 30, M))):
             del res
             torch.cuda.empty_cache()
             args.repeats, args.steps, args.warmup = 5, steps, 4
@@ -453,10 +479,10 @@ def main():
             e = summarize(res, args, world)
             e['workload'] = '%s, batch %d, N_pad %d, %d blocks of %d steps%s' % (wname, wb, res['N'], args.repeats, args.steps,
                                                                                  ', 4 distinct resident batches round-robin (the side-stream index build reads fresh data every step)' if args.rotate > 1 else '')
-            if mode == 2:
-                e['dtype'] = ('BASELINE configs[1] as written: hidden-layer products X.W, dP.W^T, X^T.dP with bf16 operands '
-                              '(round to nearest even, one bf16 MFMA product, fp32 accumulate); aggregation, BatchNorm, head and '
-                              'first layer fp32.  NOT the parity path: error vs the fp32 oracle in tests/test_gpu_bf16.py')
+            e['dtype'] = GEMM_MODES.get(mode, 'gemm mode %d' % mode)
+            if mode == 4:
+                e['dtype'] += (': hidden-layer products X.W, dP.W^T, X^T.dP from ONE bf16 plane per operand, written by the producers; '
+                               'aggregation, BatchNorm, head and first layer fp32; error vs the fp32 oracle in tests/test_gpu_bf16.py')
             extra[key] = e
         args.repeats, args.steps, args.warmup = keep
         args.rotate = keep_rotate

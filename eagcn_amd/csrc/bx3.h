@@ -70,11 +70,18 @@ struct BxProb {
     int tn;                      // 0: C = A[M,K] . B[N,K]^T;  1: C = A[K,M]^T . B[K,N]
     int splits; size_t slab;     // TN: k-chunk z goes to C + z * slab
 };
-// k-chunk slabs a split-K (TN) product of actual reduction length K really writes: chunks at least 8 k-tiles (256 rows) long.
-// Shared by the kernel and by whoever sums the slabs (layer.hip unpack_grads): the host sizes `splits` for a CAPACITY.
-__host__ __device__ inline int bx3_used_splits(int splits, int K) {
-    const int kt = K > 32 ? (K + 31) / 32 : 1, u = kt / 8;
-    const int s = splits < u ? splits : u;
+// k-chunk slabs a split-K (TN) product of actual reduction length K over `tiles` output tiles really writes -- shared by the
+// kernel and by whoever sums the slabs (layer.hip unpack_grads); the host sizes the slab buffer (`cap`) for a CAPACITY:
+//   * enough chunks to give every CU about two work units, but none shorter than 24 k-tiles (768 rows: about the length of a
+//     dX tile of the same launch, and few enough slabs that summing them stays cheap);
+//   * never longer than 4096 rows (accumulation chains of gemm_bx3.hip: the bf16 MFMA accumulate drifts).
+__host__ __device__ inline int bx3_used_splits(int cap, int K, int tiles) {
+    const int kt = K > 32 ? (K + 31) / 32 : 1;
+    const int fill = (512 + tiles - 1) / (tiles > 0 ? tiles : 1), len = kt / 24;
+    int s = fill < len ? fill : len;
+    const int drift = (K + 4095) / 4096;
+    s = s > drift ? s : drift;
+    s = s < cap ? s : cap;
     return s > 1 ? s : 1;
 }
 bool bx3_ok(const BxProb& p);

@@ -76,9 +76,9 @@ __device__ __forceinline__ BxUnits bx_units(const BxProb& p, int Mx, int Kx) {
     u.tiles_m = (Mx + BX_BM - 1) / BX_BM;
     u.tiles_n = (p.N + BX_BN - 1) / BX_BN;
     u.kt_total = max(1, (Kx + BX_BK - 1) / BX_BK);
-    // TN: the k-tiles are spread over bx3_used_splits() chunks (at least 8 k-tiles each; capacity-sized launches: the actual K may
-    // be a fraction of the capacity the host sized `splits` for); only those slabs are written, and the consumer sums only those
-    u.splits = p.tn ? bx3_used_splits(max(1, p.splits), Kx) : 1;
+    // TN: the k-tiles are spread over bx3_used_splits() chunks (bx3.h; capacity-sized launches: the actual K may be a fraction of the
+    // capacity the host sized `splits` for); only those slabs are written, and the consumer sums only those
+    u.splits = p.tn ? bx3_used_splits(max(1, p.splits), Kx, u.tiles_m * u.tiles_n) : 1;
     u.kt_per = (u.kt_total + u.splits - 1) / u.splits;
     u.n = u.tiles_m * u.tiles_n * u.splits;
     return u;
@@ -515,7 +515,9 @@ extern "C" int eagcn_gemm_bx3(int tn, int M, int N, int K, const uint16_t* A, si
     return launch_bx3(p, nullptr, np, (hipStream_t)stream, 2.0 * M * N * K, PROF_GEMM);
 }
 
-extern "C" int eagcn_bx3_used_splits(int splits, int K) { return bx3_used_splits(splits < 1 ? 1 : splits, K); }
+extern "C" int eagcn_bx3_used_splits(int splits, int M, int N, int K) {
+    return bx3_used_splits(splits < 1 ? 1 : splits, K, cdiv(M, BX_BM) * cdiv(N, BX_BN));
+}
 
 /* the dX / dW pair of a layer's backward in ONE persistent launch: problem 0 NT, problem 1 TN with split-K slabs */
 extern "C" int eagcn_gemm_bx3_pair(int M0, int N0, int K0, const uint16_t* A0, size_t a0_pstride, int lda0, const uint16_t* B0,

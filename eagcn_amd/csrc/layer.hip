@@ -94,7 +94,6 @@ __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const View
                     const int fi = packed_to_exact(in, ip);
                     if (fi >= 0 && f < vc.width[k]) v = pp.W[k][(size_t)fi * vc.width[k] + f];
                     Wcat[(size_t)ip * fp + cp] = v;
-                    if (wp.p) bx_store1(wp, (size_t)ip * fp + cp, v);        // operand planes of the plane GEMMs (gemm_bx3.hip)
                 }
                 tile[ty + 8 * j][tx] = v;
             }
@@ -104,10 +103,16 @@ __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const View
         for (int j = 0; j < 4; ++j) {
             const int cp = cp0 + ty + 8 * j, ip = ip0 + tx;
             // [Fp][ld_in]: the K-contiguous B operand of the forward product (NT form)
-            if (cp < fp && ip < ld_in) {
-                WcatT[(size_t)cp * ld_in + ip] = tile[tx][ty + 8 * j];
-                if (wtp.p) bx_store1(wtp, (size_t)cp * ld_in + ip, tile[tx][ty + 8 * j]);
-            }
+            if (cp < fp && ip < ld_in) WcatT[(size_t)cp * ld_in + ip] = tile[tx][ty + 8 * j];
+        }
+        // operand planes of the plane GEMMs (gemm_bx3.hip) of both matrices, four adjacent elements per thread (8-byte stores:
+        // scalar 2-byte stores made this launch four times as long); fp and ld_in are multiples of 16 for every layer that has planes
+        if (wp.p) {
+            const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) << 2;
+            if (ip0 + r < ld_in && cp0 + c4 < fp)
+                bx_store4(wp, (size_t)(ip0 + r) * fp + cp0 + c4, make_float4(tile[r][c4], tile[r][c4 + 1], tile[r][c4 + 2], tile[r][c4 + 3]));
+            if (cp0 + r < fp && ip0 + c4 < ld_in)
+                bx_store4(wtp, (size_t)(cp0 + r) * ld_in + ip0 + c4, make_float4(tile[c4][r], tile[c4 + 1][r], tile[c4 + 2][r], tile[c4 + 3][r]));
         }
         __syncthreads();
     }
@@ -620,7 +625,7 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
     nedge = nedge < 0 ? -nedge : min(nedge, (meta[EAGCN_META_T] + 15) / 16);   // edge-gradient workgroups that had rows (< 0: all wrote)
     // split-K partials actually written: gemm.hip writes eff_splits of them; the plane GEMM (gemm_bx3.hip) passes its slab count
     // negated and writes bx3_used_splits() of them
-    nsplit = nsplit < 0 ? bx3_used_splits(-nsplit, meta[EAGCN_META_T]) : max(1, min(nsplit, meta[EAGCN_META_T] >> 7));
+    nsplit = nsplit < 0 ? bx3_used_splits(-nsplit, meta[EAGCN_META_T], ((ld_in + 127) >> 7) * ((fp + 127) >> 7)) : max(1, min(nsplit, meta[EAGCN_META_T] >> 7));
     if ((int)blockIdx.x < wblocks) {
         // split-K slabs: FOUR lanes per element, each adds every fourth slab (the first layer's weight gradient leaves gemm.hip
         // as up to 146 slabs: one thread per element was a chain of 37 dependent load rounds, 14 us at B = 1024)
@@ -764,14 +769,10 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     d.wslab = (size_t)d.ld_in * d.fp;
     // plane GEMMs (gemm modes 3 / 4): the hidden layers (the 24-feature first layer stays on the fp32 kernels of gemm.hip)
     d.np = (d.ld_in >= 128 && (d.ld_in & 15) == 0 && (d.fp & 15) == 0) ? gemm_planes() : 0;
-    {   // k-chunks of the weight gradient: enough work items to fill the chip next to the dX tiles, each at least 8 k-tiles long
-        const int tiles128 = cdiv(d.ld_in, 128) * cdiv(d.fp, 128);
-        const int by_fill = cdiv(2 * bx3_grid(), tiles128);
-        const int by_len = std::max(1, cdiv(std::max(b->T, 1), 256));
-        // ... and at most 4096 rows long (accumulation chains of gemm_bx3.hip: the bf16 MFMA accumulate drifts), up to 64 slabs
-        const int by_drift = cdiv(std::max(b->T, 1), 4096);
-        d.bx_splits = std::max(1, std::min(std::max(std::min(std::min(by_fill, by_len), 32), by_drift), 64));
-    }
+    // slab capacity of the weight gradient's k-chunks (how many are used is decided on the device from the actual row count:
+    // bx3.h bx3_used_splits)
+    d.bx_splits = std::max(1, std::min(64, std::max(cdiv(std::max(b->T, 1), 4096), std::min(cdiv(512, cdiv(d.ld_in, 128) * cdiv(d.fp, 128)),
+                                                                                           cdiv(std::max(b->T, 1), 768)))));
     return d;
 }
 

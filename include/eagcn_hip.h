@@ -409,10 +409,10 @@ int eagcn_set_gemm_mode(int mode);
  * pieces before it left over), np = 1: round to nearest even; plane q at planes + q * plane_stride (elements) */
 int eagcn_bx3_split(const float* x, int rows, int ld, uint16_t* planes, size_t plane_stride, int np, void* stream);
 /* tn = 0: C[M,N] = A[M,K].B[N,K]^T (planes of A [M][lda] and B [N][ldb], K a multiple of 8);
- * tn = 1: C[M,N] = A[K,M]^T.B[K,N] (planes [K][lda], [K][ldb]) as k-chunk slabs C + z * slab, z < eagcn_bx3_used_splits(splits, K)
- *         (chunks are at least 256 rows of K long; slabs beyond that count are NOT written), whose sum is the product.
+ * tn = 1: C[M,N] = A[K,M]^T.B[K,N] (planes [K][lda], [K][ldb]) as k-chunk slabs C + z * slab, z < eagcn_bx3_used_splits(splits, M, N, K)
+ *         (at least 768 and at most 4096 rows of K per chunk; slabs beyond that count are NOT written), whose sum is the product.
  * lda / ldb multiples of 8, planes 16-byte aligned. */
-int eagcn_bx3_used_splits(int splits, int K);
+int eagcn_bx3_used_splits(int splits, int M, int N, int K);
 int eagcn_gemm_bx3(int tn, int M, int N, int K, const uint16_t* A, size_t a_pstride, int lda, const uint16_t* B,
                    size_t b_pstride, int ldb, float* C, int ldc, int splits, size_t slab, int np, void* stream);
 /* an NT product and a TN product (the dX / dW pair of a layer's backward) in ONE persistent launch */

@@ -52,7 +52,7 @@ def _gemm(tn, A, B, M, N, K, splits=1):
     Cm = torch.full((max(splits, 1) * slab,), float('nan'), device='cuda')
     L.check(lib.eagcn_gemm_bx3(tn, M, N, K, C.c_void_p(pa.data_ptr()), sa, A.shape[1], C.c_void_p(pb.data_ptr()), sb, B.shape[1],
                                C.c_void_p(Cm.data_ptr()), ldc, splits, slab, 3, None), 'eagcn_gemm_bx3')
-    used = lib.eagcn_bx3_used_splits(splits, K) if tn else 1
+    used = lib.eagcn_bx3_used_splits(splits, M, N, K) if tn else 1
     return Cm.view(max(splits, 1), M, ldc)[:used, :, :N].double().sum(0), Cm.view(max(splits, 1), M, ldc)
 
 
@@ -90,7 +90,7 @@ def test_tn_product_vs_float64(M, N, K, splits):
     got, raw = _gemm(1, A, B, M, N, K, splits)
     e = _err(got, A[:, :M].double(), B[:, :N].double(), True)
     assert e <= 8 * 2.0 ** -24, e
-    used = lib.eagcn_bx3_used_splits(splits, K)
+    used = lib.eagcn_bx3_used_splits(splits, M, N, K)
     assert 1 <= used <= splits and torch.isnan(raw[used:]).all() and not torch.isnan(raw[:used, :, :N]).any()
 
 
@@ -111,7 +111,7 @@ def test_pair_launch_equals_the_two_products():
     L.check(lib.eagcn_gemm_bx3_pair(T, FIN, FP, C.c_void_p(pp.data_ptr()), sp, FP, C.c_void_p(pw.data_ptr()), sw, FP, C.c_void_p(dX.data_ptr()), FIN,
                                     FIN, FP, T, C.c_void_p(px.data_ptr()), sx, FIN, C.c_void_p(pp.data_ptr()), sp, FP, C.c_void_p(dW.data_ptr()), FP,
                                     splits, FIN * FP, 3, None), 'eagcn_gemm_bx3_pair')
-    used = lib.eagcn_bx3_used_splits(splits, T)
+    used = lib.eagcn_bx3_used_splits(splits, FIN, FP, T)
     assert torch.equal(dX.double(), dx_ref) and torch.equal(dW[:used].double().sum(0), dw_ref), 'a unit computes the same bits in either launch'
 
 

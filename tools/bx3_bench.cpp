@@ -135,13 +135,7 @@ static void time_layer(const char* name, int T, int FIN, int FP, int iters) {
     // forward P = X.WcatT^T (NT, M=T, N=FP, K=FIN); dX = dP.Wcat^T (NT, M=T, N=FIN, K=FP); dW = X^T.dP (TN, M=FIN, N=FP, K=T)
     Mat X(T, FIN, FIN), WT(FP, FIN, FIN, 0.05f), W(FIN, FP, FP, 0.05f), dP(T, FP, FP);
     float *P, *dX, *dW; 
-    int splits = 1;
-    {   // dW items about as long as a dX tile
-        const int tiles = ((FIN + 127) / 128) * ((FP + 127) / 128);
-        const int kt = (T + 31) / 32, kx = (FP + 31) / 32;
-        splits = kt / kx; if (splits < 1) splits = 1;
-        while (splits > 1 && tiles * splits > 1024) --splits;
-    }
+    int splits = 64;        // slab CAPACITY, as the layer path passes it: the kernel decides how many chunks it uses (bx3.h)
     if (getenv("BX3_SPLITS")) splits = atoi(getenv("BX3_SPLITS"));
     const size_t slab = (size_t)FIN * FP;
     CK(hipMalloc(&P, (size_t)T * FP * 4)); CK(hipMalloc(&dX, (size_t)T * FIN * 4)); CK(hipMalloc(&dW, slab * splits * 4));
@@ -149,7 +143,7 @@ static void time_layer(const char* name, int T, int FIN, int FP, int iters) {
     void* ws; CK(hipMalloc(&ws, wsb));
     const double f1 = 2.0 * T * FIN * FP;
     float t;
-    printf("%s: T=%d F_in=%d Fp=%d (dW splits %d)\n", name, T, FIN, FP, splits);
+    printf("%s: T=%d F_in=%d Fp=%d (dW k-chunks used: %d)\n", name, T, FIN, FP, eagcn_bx3_used_splits(splits, FIN, FP, T));
     t = time_fn(iters, [&] { RC(eagcn_gemm_bx3(0, T, FP, FIN, X.pl, X.pstride, FIN, WT.pl, WT.pstride, FIN, P, FP, 1, 0, 3, nullptr)); });
     printf("  forward   bx3 %8.1f us  %6.1f TF", t, f1 / t * 1e-6);
     t = time_fn(iters, [&] { RC(eagcn_gemm_f32_sk(0, 1, T, FP, FIN, X.d, FIN, WT.d, FIN, P, FP, ws, wsb, nullptr)); });
