@@ -20,6 +20,10 @@ struct AggArgs {
 int agg_grid_x(const eagcn_batch* b);
 bool agg_ksplit(const eagcn_batch* b);
 int launch_agg(AggArgs a, bool trans, hipStream_t s);
+// the same operator over the bond lists of the index (sagg.hip): gather + one rank-one term per molecule instead of the dense block
+bool sagg_use(const eagcn_batch* b);          // this batch takes that path (policy + the index carries bond lists)
+int sagg_grid_x(const eagcn_batch* b);        // its workgroups along x = BatchNorm partial slabs, all of them written
+int launch_sagg(AggArgs a, bool trans, hipStream_t s);
 
 struct EdgeArgs {
     eagcn_batch bt;

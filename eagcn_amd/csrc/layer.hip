@@ -1037,9 +1037,15 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
             AggArgs a;
             a.bt = *b; a.vc = d.vc; a.src = w->P; a.lds = d.fp; a.dst = w->Y; a.ldd = d.fp;
             a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = sc.stats; a.nchunk = 1;
-            rc = launch_agg(a, false, s);
+            if (sagg_use(b)) {                                 // bond-list aggregation (sagg.hip): every slab is written
+                rc = launch_sagg(a, false, s);
+                nslab = sagg_grid_x(b);
+                tiles_per_wg = 0;
+            } else {
+                rc = launch_agg(a, false, s);
+                nslab = d.gx;
+            }
             if (rc) return rc;
-            nslab = d.gx;
         }
     }
     const double M = (double)b->B * (double)b->N;
@@ -1270,7 +1276,13 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         if (edge_atomic && !general_rel) { e.datt = sc.eacc; e.atomic = 1; }
         static const bool colaunch = [] { const char* v = getenv("EAGCN_NO_COLAUNCH"); return !(v && v[0] == '1'); }();
         nedge = e.atomic ? -EDGE_COPIES : edge_grid_x(b);
-        if (!forked && colaunch) {
+        if (sagg_use(b)) {                                                       // bond-list aggregation (sagg.hip)
+            if (forked) { rc = stream_after(side, s); if (rc) return rc; }
+            rc = launch_edge_grad(e, side);
+            if (rc) return rc;
+            rc = launch_sagg(a, true, s);
+            if (rc) return rc;
+        } else if (!forked && colaunch) {
             rc = launch_agg_edge(a, e, s);                                       // one grid for both
             if (rc) return rc;
         } else {

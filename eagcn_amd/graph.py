@@ -72,6 +72,10 @@ class StaticIndex:
         ob = rb + 16 * T + 16 * self.n_tiles
         c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = ob, ob + 4 * T, ob + 8 * T, ob + 12 * T, ob + 16 * T
         L.set_bond_lists(c, base + 4 * (B * N + 3 * B + 2 + L.META_WORDS), self._ptrs, self._edges, self.E)
+        # bond lists: built when the library takes the bond-list form of the aggregation for this shape (csrc/sagg.hip); the GAT
+        # runner sets the flag itself
+        self.bond_lists = bool(L.load().eagcn_agg_wants_bond_lists(B, N))
+        c.build_lists = 1 if self.bond_lists else 0
         # general relation vectors (layers.py:82 with arbitrary channel values): a static 255-row code book per view
         self.relvec = None
         if rel_c is not None:

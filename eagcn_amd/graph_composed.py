@@ -36,8 +36,8 @@ class ComposedRunner:
         self.validate, self.static_outputs = validate, bool(static_outputs)
         gat = model.structure == 'GAT'
         self.index = StaticIndex(B, N, channels, device, row_cap if row_cap else B * N, edge_cap)
-        self.index.bond_lists = gat
-        self.index.c.build_lists = 1 if gat else 0
+        self.index.bond_lists = gat or self.index.bond_lists
+        self.index.c.build_lists = 1 if self.index.bond_lists else 0
         f32 = dict(dtype=torch.float32, device=device)
         nclass = int(model.den3.weight.shape[1])
         self.afm = torch.zeros((B, N, model.n_afeat), **f32)

@@ -216,6 +216,9 @@ class BatchIndex:
         self._ptrs = torch.zeros(4 * T + 4 * B, **i32)
         self._edges = torch.empty(6 * self.E + 2, **i32)
         L.set_bond_lists(c, base + 4 * (B * N + 3 * B + 2 + L.META_WORDS), self._ptrs, self._edges, self.E)
+        # bond lists: the GAT layers, and the bond-list form of the aggregation where the library picks it (csrc/sagg.hip)
+        if lib.eagcn_agg_wants_bond_lists(B, N):
+            self.bond_lists = True
         c.build_lists = 1 if getattr(self, 'bond_lists', False) else 0
         L.check(lib.eagcn_index_rows(C.byref(c), C.c_void_p(main.cuda_stream)), 'eagcn_index_rows')
         for t in (self.code, blob):

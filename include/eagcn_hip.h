@@ -200,6 +200,11 @@ typedef struct eagcn_layer_grads {
     float* dave_w;                          /* [K] or NULL                                      */
 } eagcn_layer_grads;
 
+/* 1 when batches of this shape take the bond-list form of the aggregation (csrc/sagg.hip: gather over the bonds + one rank-one
+ * term per molecule instead of the dense nat x nat block; opt-in: EAGCN_AGG=sparse, padded sizes up to 256 atoms): the index must
+ * then carry bond lists -- set eagcn_batch.build_lists = 1 before eagcn_index_rows. */
+int eagcn_agg_wants_bond_lists(int B, int N);
+
 /* ---- library ------------------------------------------------------------------------------- */
 int eagcn_abi_version(void);
 size_t eagcn_struct_size(int which);   /* 0 batch, 1 layout, 2 layer_params, 3 layer_bufs, 4 layer_grads,

@@ -157,3 +157,45 @@ def test_model_in_plane_mode_against_fp32_mfma_mode(structure):
     for k, v in g0.items():
         d = (g3[k] - v).abs().max().item()
         assert d <= 1e-5 * v.abs().max().item() + 2e-6 * scale, (k, d, v.abs().max().item(), scale)
+
+
+def test_bond_list_aggregation_opt_in_matches_the_dense_kernels():
+    """csrc/sagg.hip (EAGCN_AGG=sparse, opt-in): the aggregation as a gather over the bond lists plus ONE rank-one term per molecule
+    -- the same operator as the matrix-core kernels of agg.hip (reference layers.py:82-92), exact including the 1e-9 filler.
+    Run in a subprocess (the policy is read once per process): outputs and every gradient against the default path."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, torch
+sys.path.insert(0, %r)
+from eagcn_amd import EAGCN
+from eagcn_amd.synthetic import make_batch
+mb = make_batch(B=24, n_max=70, n_med=25, rel_channels=(28, 4, 2, 2, 2), seed=31, isolated_frac=0.05)
+dense = [t.cuda() for t in mb.dense()]
+torch.manual_seed(3)
+m = EAGCN(28, 24, *[48] * 5, *[64] * 5, 64, 32, 3, 0.0, structure=sys.argv[1], n_layers=2, grad_mode='direct').cuda().train()
+torch.manual_seed(4)
+cot = torch.randn(24, 3, device='cuda')
+out, _, gr = m(*dense)
+((out * cot).sum() + 0.1 * gr.sum()).backward()
+torch.save({'out': out.detach().cpu(), 'g': {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}}, sys.argv[2])
+''' % root
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for structure in ('Concate', 'Weighted_sum'):
+            for mode in ('dense', 'sparse'):
+                path = os.path.join(d, '%s_%s.pt' % (structure, mode))
+                env = dict(os.environ, EAGCN_AGG=mode)
+                r = subprocess.run([sys.executable, '-c', code, structure, path], env=env, capture_output=True, text=True, timeout=300)
+                assert r.returncode == 0, r.stderr[-2000:]
+                res[(structure, mode)] = torch.load(path)
+    for structure in ('Concate', 'Weighted_sum'):
+        a, b = res[(structure, 'dense')], res[(structure, 'sparse')]
+        assert ((a['out'] - b['out']).abs().max() / a['out'].abs().max()).item() < 1e-5
+        scale = max(v.abs().max().item() for v in a['g'].values())
+        for k, v in a['g'].items():
+            dd = (b['g'][k] - v).abs().max().item()
+            assert dd <= 1e-5 * v.abs().max().item() + 2e-6 * scale, (structure, k, dd, v.abs().max().item(), scale)
