@@ -219,6 +219,16 @@ def run_workload(name, B, args, lib, dev, rank, world, reducer_cls, detail):
     params = list(model.parameters())
 
     fused = (not args.eager) and not args.separate_graphs
+    # --optimizer: the whole training iteration of train.py:310-334 (zero_grad, forward, loss, backward, Adam(lr, weight_decay)).
+    # 'flat' = eagcn_amd.optim.FlatAdam, ONE kernel over the flat parameter buffer, captured into the step graph;
+    # 'torch' = torch.optim.Adam (foreach) on the same parameters, launched by the host behind every step graph.
+    opt_kind = getattr(args, 'optimizer', 'none')
+    optimizer = None
+    if opt_kind == 'flat':
+        from eagcn_amd.optim import FlatAdam
+        optimizer = FlatAdam(model, lr=1e-4, weight_decay=1e-4)
+    elif opt_kind == 'torch':
+        optimizer = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
 
     def step():
         i = counter[0] % nrot       # resident batches taken round-robin (--rotate; 1: the same batch every step)
@@ -232,7 +242,10 @@ def run_workload(name, B, args, lib, dev, rank, world, reducer_cls, detail):
             # backward) and the global BCE normalisation is a 1-element collective issued with the batch preparation
             batch = dense if compact is None else (compact[1], compact[2])
             loss, _ = model.fused_step(batch, labels, cfg['task'], bce_w_dev, 'dp' if (world > 1 and cfg['task'] == 'class') else None,
-                                       bonds=None if compact is None else compact[0], reducer=reducer if world > 1 else None)
+                                       bonds=None if compact is None else compact[0], reducer=reducer if world > 1 else None,
+                                       **({'optimizer': optimizer} if opt_kind == 'flat' else {}))
+            if opt_kind == 'torch':
+                optimizer.step()
             return loss
         out, _, _ = model(*dense) if compact is None else model.forward_compact(*compact)
         if cfg['task'] == 'class':
@@ -241,6 +254,8 @@ def run_workload(name, B, args, lib, dev, rank, world, reducer_cls, detail):
             loss = fused_regression_loss(out, labels)
         loss.backward()
         reducer()
+        if optimizer is not None:
+            optimizer.step()
         return loss
 
     for _ in range(args.warmup):
@@ -353,6 +368,9 @@ def main():
     ap.add_argument('--dropout', type=float, default=0.3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--rotate', type=int, default=1, help='distinct HBM-resident batches per rank, taken round-robin (1: the same batch every step)')
+    ap.add_argument('--optimizer', choices=('none', 'flat', 'torch'), default='none',
+                    help="add the optimizer step to the timed step: 'flat' = eagcn_amd.optim.FlatAdam inside the step graph, 'torch' = torch.optim.Adam "
+                         "behind it (the headline metric is fwd+bwd: BASELINE.json; extra.train_step carries the whole iteration)")
     ap.add_argument('--no-extras', action='store_true', help='skip the extra single-GPU shapes (north-star batch 1024, HIV, Lipo, C5)')
     ap.add_argument('--eager', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--separate-graphs', action='store_true', help='graph mode with separate forward / backward graphs and an eager loss kernel '
@@ -458,6 +476,7 @@ def main():
     if world == 1 and not args.no_extras and args.workload == 'tox21_c2' and args.batch is None and not args.eager:
         keep = (args.repeats, args.steps, args.warmup)
         keep_rotate = args.rotate
+        keep_opt = args.optimizer
         extra = {}
         M = gemm_mode
         for key, (wname, wb, steps, mode) in (('b1024', ('tox21_c2', 1024, 30, M)), ('hiv_c3', ('hiv_c3', 1024, 10, M)),
@@ -466,11 +485,15 @@ def main():
                                                ('c2_fp32_mfma', ('tox21_c2', 256, 50, 0)), ('b1024_fp32_mfma', ('tox21_c2', 1024, 30, 0)),
                                                ('hiv_c3_fp32_mfma', ('hiv_c3', 1024, 10, 0)), ('c5_synth_fp32_mfma', ('c5_synth', 1024, 6, 0)),
                                                ('c2_bf16', ('tox21_c2', 256, 50, 4)), ('b1024_bf16', ('tox21_c2', 1024, 30, 4)),
-                                               ('c2_rotate4', ('tox21_c2', 256, 50, M)), ('b1024_rotate4', ('tox21_c2', 1024, 30, M))):
+                                               ('c2_rotate4', ('tox21_c2', 256, 50, M)), ('b1024_rotate4', ('tox21_c2', 1024, 30, M)),
+                                               # the WHOLE training iteration (train.py:310-334): + Adam(lr, weight_decay)
+                                               ('train_step', ('tox21_c2', 256, 50, M)), ('train_step_torch_adam', ('tox21_c2', 256, 50, M)),
+                                               ('b1024_train_step', ('tox21_c2', 1024, 30, M))):
             del res
             torch.cuda.empty_cache()
             args.repeats, args.steps, args.warmup = 5, steps, 4
             args.rotate = 4 if key.endswith('rotate4') else 1
+            args.optimizer = 'torch' if key.endswith('torch_adam') else ('flat' if 'train_step' in key else keep_opt)
             old_mode = lib.eagcn_set_gemm_mode(mode)         # fresh model + fresh graphs per workload: captured with this mode
             try:
                 res = run_workload(wname, wb, args, lib, dev, rank, world, GradientAllReducer, detail=False)
@@ -483,7 +506,12 @@ def main():
             if mode == 4:
                 e['dtype'] += (': hidden-layer products X.W, dP.W^T, X^T.dP from ONE bf16 plane per operand, written by the producers; '
                                'aggregation, BatchNorm, head and first layer fp32; error vs the fp32 oracle in tests/test_gpu_bf16.py')
+            if 'train_step' in key:
+                e['step'] = ('zero_grad + forward + loss + backward + Adam(lr, weight_decay=1e-4) [train.py:310-334]: ' +
+                             ('torch.optim.Adam (foreach) launched by the host behind every step graph' if args.optimizer == 'torch' else
+                              'eagcn_amd.optim.FlatAdam, one kernel over the flat parameter buffer, captured as the last launch of the step graph'))
             extra[key] = e
+        args.optimizer = keep_opt
         args.repeats, args.steps, args.warmup = keep
         args.rotate = keep_rotate
         out['extra'] = extra

@@ -128,6 +128,7 @@ SIGNATURES = {
     'eagcn_index_from_bonds': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.POINTER(Batch), _fp, _fp]),
     'eagcn_index_rows': (C.c_int, [C.POINTER(Batch), _fp]),
     'eagcn_set_gemm_mode': (C.c_int, [C.c_int]),
+    'eagcn_adam_step': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     'eagcn_agg_wants_bond_lists': (C.c_int, [C.c_int, C.c_int]),
     'eagcn_bx3_used_splits': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'eagcn_bx3_split': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_size_t, C.c_int, _fp]),

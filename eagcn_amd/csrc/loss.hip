@@ -191,3 +191,56 @@ extern "C" int eagcn_mse_loss(const float* pred, const float* target, int n, flo
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
+
+// ---- optimizer step of the training loop (train.py:303 `optim.Adam(model.parameters(), lr, weight_decay=wd)`, train.py:334) -----------
+// One launch over ONE flat fp32 buffer that holds every hot-path parameter (the gradients arrive in a buffer of the same layout:
+// eagcn_amd/ops.py ModelPlan.offsets), instead of torch's foreach step over ~100 tensors.  torch.optim.Adam semantics, fp32:
+//     g += wd p ; m = m + (1 - b1)(g - m) ; v = b2 v + (1 - b2) g g ; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// Capturable: the hyper-parameters and the step count live in DEVICE memory (a replayed graph re-reads them; a learning-rate
+// schedule writes one float), the step count is advanced by the workgroup that finishes last (every workgroup has read it by
+// then).  hyper = {lr, beta1, beta2, eps, weight_decay}.
+namespace eagcn {
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, size_t n4, const float* __restrict__ hyper,
+                                                        long long* __restrict__ step, unsigned* __restrict__ done) {
+    const long long t = *step + 1;
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+    // (torch forms the bias corrections on the host in double precision)
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    const float step_size = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float* pe = &pp.x; float* me = &mm.x; float* ve = &vv.x; const float* ge = &gg.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = ge[e] + wd * pe[e];
+            me[e] = me[e] + (1.0f - b1) * (gr - me[e]);
+            ve[e] = b2 * ve[e] + (1.0f - b2) * gr * gr;
+            const float denom = sqrtf(ve[e]) * inv_sqrt_bc2 + eps;
+            pe[e] = pe[e] - step_size * (me[e] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    __shared__ unsigned ticket;
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(done, 1u);
+    __syncthreads();
+    if (ticket == gridDim.x - 1 && threadIdx.x == 0) { *done = 0u; *step = t; }
+}
+}  // namespace eagcn
+
+extern "C" int eagcn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper_dev,
+                               int64_t* step_dev, uint32_t* ticket_dev, void* stream) {
+    EAGCN_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && hyper_dev && step_dev && ticket_dev, "eagcn_adam_step: null argument");
+    EAGCN_CHECK_ARG(n >= 0 && (n & 3) == 0, "eagcn_adam_step: the flat buffers hold a multiple of 4 floats (ModelPlan pads every parameter)");
+    EAGCN_CHECK_ARG(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+                      reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0, "eagcn_adam_step: buffers must be 16-byte aligned");
+    if (n == 0) return EAGCN_OK;
+    const size_t n4 = (size_t)n / 4;
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>((n4 + 255) / 256, 1024));
+    eagcn::adam_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n4, hyper_dev, (long long*)step_dev,
+                                                                    ticket_dev);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}

@@ -504,7 +504,7 @@ class GraphRunner:
         comm.start(self.flat_acc[:cut]).wait()
 
     def train_step(self, adj, rels, afm, size, seed, labels, kind, weight=None, scale=None, overlap=False, bonds=None,
-                   comm=None):
+                   comm=None, optimizer=None):
         """forward -> fused loss (csrc/loss.hip) -> backward of one batch as a single captured graph: no launch boundary
         between the three, one host call per step.  Returns the loss (device scalar); out / graph_representation are read
         with outputs(), the parameter gradients are attached exactly as backward() does.  `comm` (a GradientAllReducer with
@@ -530,17 +530,30 @@ class GraphRunner:
             self.dgr.zero_()
             self.dgr_is_zero = True
         keep, grads = self._before_grads()
+        if optimizer is not None and (keep is not None or any(g is not None for g in grads)):
+            raise L.EagcnHipError('train_step(optimizer=...): the update is part of the step graph and uses this step\'s gradients; '
+                                  'call optimizer.zero_grad() (set_to_none) before the step')
         self._prepare(adj, rels, afm, size, seed, overlap, bonds, labels=labels, dp_scale=scale)
         cur = self.cur
         in_graph = comm is not None and self.comm_in_graph is not False
-        key = (kind, scale is not None, in_graph)
-        if self.graphs[cur][2] is None or self.step_kind[cur] != key:
+        # `optimizer` (eagcn_amd.optim.FlatAdam): the parameter update is the last launch of the captured step (its hyper-parameters
+        # and step count live in device memory)
+        key = (kind, scale is not None, in_graph, id(optimizer) if optimizer is not None else None)
+
+        def update():
+            if optimizer is not None:
+                optimizer.launch(self.flat_acc)
+        first_eager = self.graphs[cur][2] is None or self.step_kind[cur] != key
+        if first_eager:
             self._call_forward()                              # eager (first use of the slot / of this loss): the warm-up
             self._call_loss(key[0], key[1])
             if in_graph:
                 self._call_backward_comm(comm)
             else:
                 self._call_backward()
+                if comm is not None:
+                    comm()                                    # (host-issued average: the update below needs the averaged gradients)
+            update()
             torch.cuda.synchronize(self.device)
             L.load().eagcn_prof_enable(0)
             g = torch.cuda.CUDAGraph()
@@ -551,8 +564,11 @@ class GraphRunner:
                     self._call_loss(key[0], key[1])
                     if in_graph:
                         self._call_backward_comm(comm)
+                        update()
                     else:
                         self._call_backward()
+                        if comm is None:
+                            update()
             except L.EagcnHipError:
                 raise                                         # one of OUR launches failed: never hidden behind a re-capture
             except Exception as e:                            # noqa: BLE001 -- the capture of the collective failed on this stack
@@ -575,7 +591,7 @@ class GraphRunner:
                 # the collective could not be captured: step graph without it, host-issued all-reduce behind every replay
                 torch.cuda.synchronize(self.device)
                 self.comm_in_graph, in_graph = False, False
-                key = (kind, scale is not None, False)
+                key = (kind, scale is not None, False, key[3])
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self._call_forward()
@@ -589,8 +605,9 @@ class GraphRunner:
         self.fwd_done = None            # (no launch boundary after the forward any more: the next index build only waits
                                         #  for its slot and runs under this step's kernels)
         self._attach_grads(keep, grads)
-        if comm is not None and not in_graph:
+        if comm is not None and not in_graph and not first_eager:
             comm()                                            # one in-place average of the flat buffer, issued by the host
+            update()                                          # ... and the update behind it (outside the graph in this fallback)
         return self.loss_static[cur].detach() if self.static_outputs else self.loss_static[cur].clone()
 
 

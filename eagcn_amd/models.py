@@ -339,7 +339,7 @@ class EAGCN(nn.Module):
         out, graph_representation = G.graph_forward(runner, adjs, rels, afms, size, seed, self.overlap_index, btuple)
         return out, self._atom_rep(runner), graph_representation
 
-    def fused_step(self, batch, labels, task, bce_weight=None, scale=None, bonds=None, reducer=None):
+    def fused_step(self, batch, labels, task, bce_weight=None, scale=None, bonds=None, reducer=None, optimizer=None):
         """forward -> loss -> backward of one training batch as ONE captured graph launch (graph mode only): the inner
         loop of train.py:310-334 without the launch boundaries between the three phases.  `batch` is the reference's
         forward argument tuple (adjs, afms, TypeAtt, ..., size) -- or (afms, size) together with `bonds` for a compact
@@ -349,7 +349,9 @@ class EAGCN(nn.Module):
         labels by a 1-element collective issued with the batch's other preparatory work (on the side stream under the
         previous step when overlap_index is on).  `reducer` (parallel.GradientAllReducer): the gradient average over
         the ranks is part of the step -- captured INTO the step graph, the bucket of the upper layers + head starting
-        while the first layer's backward still runs; the caller does not call the reducer again.  Returns (loss, (out,
+        while the first layer's backward still runs; the caller does not call the reducer again.  `optimizer` (an
+        eagcn_amd.optim.FlatAdam over this model): the parameter update (train.py:334) is the last launch of the same graph --
+        the caller does not call ``optimizer.step()``; gradients must not be accumulated across steps then.  Returns (loss, (out,
         atom_representations, graph_representation)); the parameter gradients are attached to ``p.grad`` as
         ``loss.backward()`` would."""
         if not (self.graph and self.training and torch.is_grad_enabled()):
@@ -357,8 +359,8 @@ class EAGCN(nn.Module):
         if self.structure == 'GAT' or self.molfp_mode == 'pool':
             # no model-level plan: the layer-by-layer step (forward_composed + fused loss + autograd backward) is captured as
             # one graph over static buffers (graph_composed.ComposedRunner)
-            if bonds is not None or reducer is not None or isinstance(scale, str):
-                raise ops.L.EagcnHipError("fused_step of a GAT / pool model takes the dense batch, no reducer and a tensor scale")
+            if bonds is not None or reducer is not None or isinstance(scale, str) or optimizer is not None:
+                raise ops.L.EagcnHipError("fused_step of a GAT / pool model takes the dense batch, no reducer / optimizer and a tensor scale")
             adjs, afms, *rels_and_size = batch
             *rels, size = rels_and_size
             runner, adjs, rels, afms, size = self._composed_runner(adjs, afms, rels, size)
@@ -389,8 +391,10 @@ class EAGCN(nn.Module):
             if getattr(self, '_bce_weight_cache', (None, None))[0] != key:
                 self._bce_weight_cache = (key, torch.tensor(bce_weight, dtype=torch.float32, device=afms.device))
             bce_weight = self._bce_weight_cache[1]
+        if optimizer is not None and (getattr(optimizer, 'model', None) is not self or not hasattr(optimizer, 'launch')):
+            raise ops.L.EagcnHipError('fused_step(optimizer=...) takes the eagcn_amd.optim.FlatAdam built over this model')
         loss = runner.train_step(adjs, rels, afms, size, seed, labels, kind, bce_weight, scale, self.overlap_index, btuple,
-                                 comm=reducer)
+                                 comm=reducer, optimizer=optimizer)
         out, graph_representation = runner.outputs()
         return loss, (out, self._atom_rep(runner), graph_representation)
 

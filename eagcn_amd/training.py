@@ -130,8 +130,13 @@ def train_step(model, optimizer, batch, labels, task, bce_weight=None, dp_global
     if fused:
         # the global BCE normalisation ('dp': a 1-element collective issued with the batch's preparatory work) and the gradient
         # average (captured into the step graph, upper bucket overlapped with the first layer's backward) are part of the step
-        loss, _ = model.fused_step(batch, labels, task, bce_weight, 'dp' if dp_global_norm else None, bonds=bonds, reducer=reducer)
-        optimizer.step()
+        from .optim import FlatAdam
+        composed = getattr(model, 'structure', None) == 'GAT' or getattr(model, 'molfp_mode', None) == 'pool'
+        in_graph = isinstance(optimizer, FlatAdam) and not composed      # the update is the last launch of the step graph
+        loss, _ = model.fused_step(batch, labels, task, bce_weight, 'dp' if dp_global_norm else None, bonds=bonds, reducer=reducer,
+                                   **({'optimizer': optimizer} if in_graph else {}))
+        if not in_graph:
+            optimizer.step()
         return loss
     else:
         out, _, _ = model(*batch) if bonds is None else model.forward_compact(bonds, *batch)

@@ -393,6 +393,14 @@ int eagcn_bce_loss(const float* logits, const float* labels, const float* class_
                    float* loss, float* dlogits, void* stream);
 int eagcn_mse_loss(const float* pred, const float* target, int n, float* loss, float* dpred, void* stream);
 
+/* ---- optimizer step (train.py:303 `optim.Adam(..., weight_decay=wd)`, train.py:334) as ONE launch over flat fp32 buffers: every
+ * hot-path parameter in one buffer, gradients / first / second moments in buffers of the same layout (n floats, a multiple of 4,
+ * 16-byte aligned).  torch.optim.Adam arithmetic.  hyper_dev = {lr, beta1, beta2, eps, weight_decay} and the step count *step_dev
+ * (advanced by the launch) live in device memory, so the launch can sit in a captured graph; *ticket_dev must be 0 on entry
+ * (the launch leaves it 0). */
+int eagcn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper_dev,
+                    int64_t* step_dev, uint32_t* ticket_dev, void* stream);
+
 /* ---- evaluation outputs (train.py:130-211): append one batch to device-resident [cap][T] buffers at row `row_offset`:
  * scores = sigmoid(logits) (classification = 1) or the predictions (0), targets = labels, valid = label in {0,1} / 1 ---- */
 int eagcn_eval_append(const float* logits, const float* labels, int B, int T, int classification, float* scores,

@@ -111,6 +111,10 @@ for sync in (False, True):
              model.plan().stats.calls if sync else '-'), flush=True)
     if sync:
         assert model.plan().stats.calls > 0 and model.plan().stats.error is None, model.plan().stats.error
+        # ONE collective per layer and direction (the sums of all K views travel as one vector of 2 * width + 1 doubles:
+        # csrc/layer.hip eagcn_layer_forward / _backward) + one per head BatchNorm and direction; the hook runs only while a step
+        # is issued eagerly or captured (2 slots x (eager + capture)), replays carry the collectives as graph nodes
+        assert model.plan().stats.calls <= 4 * (2 * 2 + 6), model.plan().stats.calls
     else:
         torch.cuda.synchronize()
         model.release_graphs()            # the local-BN model's step graphs (RCCL nodes) go before the next model captures its own

@@ -15,8 +15,11 @@ from helpers import rel_err
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize('optim', ['torch', 'flat'])
 @pytest.mark.parametrize('task', ['class', 'reg'])
-def test_fifty_adam_steps_track_the_oracle(task):
+def test_fifty_adam_steps_track_the_oracle(task, optim):
+    """optim='flat': the update is eagcn_amd.optim.FlatAdam -- one kernel over the flat parameter buffer, captured into the step
+    graph -- against torch.optim.Adam on the oracle; same bars."""
     from sklearn import metrics
     from eagcn_amd import EAGCN, training
     from eagcn_amd.synthetic import make_batch
@@ -38,7 +41,11 @@ def test_fifty_adam_steps_track_the_oracle(task):
     cpu64 = [([t.double() if t.is_floating_point() else t for t in d], l) for d, l in cpu]
     opt_r = torch.optim.Adam(ref.parameters(), lr=5e-4, weight_decay=1e-4)
     opt_x = torch.optim.Adam(ref64.parameters(), lr=5e-4, weight_decay=1e-4)
-    opt_h = torch.optim.Adam(hip.parameters(), lr=5e-4, weight_decay=1e-4)
+    if optim == 'flat':
+        from eagcn_amd.optim import FlatAdam
+        opt_h = FlatAdam(hip, lr=5e-4, weight_decay=1e-4)
+    else:
+        opt_h = torch.optim.Adam(hip.parameters(), lr=5e-4, weight_decay=1e-4)
 
     def loss_of(out, l):
         if task == 'reg':
@@ -113,6 +120,11 @@ def test_fifty_adam_steps_track_the_oracle(task):
     rel_err(torch.tensor([pworst]), torch.tensor([0.0]), 'worst HIP distance to the fp64 trajectory over %d compared tensor-steps '
             '(median window %d steps)' % (n_cmp, wl[len(wl) // 2]))
     assert loss_x[-1] < loss_x[0] and loss_h[-1] < loss_h[0]                      # it trains
+    if optim == 'flat':
+        assert int(opt_h.step_count) == 50 and int(opt_h.ticket) == 0
+        for n, p in hip.named_parameters():                                       # the parameters ARE the flat buffer
+            if p.grad is not None:
+                assert opt_h.flat.data_ptr() <= p.data_ptr() < opt_h.flat.data_ptr() + 4 * opt_h.flat.numel(), n
     for k, v in hip.state_dict().items():
         if k.endswith('num_batches_tracked'):
             assert int(v) == 50, k
@@ -136,3 +148,42 @@ def test_fifty_adam_steps_track_the_oracle(task):
         want = float(np.sqrt(metrics.mean_squared_error(outs.numpy().ravel(), labels.numpy().ravel())))
         assert abs(got - want) < 1e-3 * max(want, 1.0), (got, want)
     assert hip.training
+
+
+@pytest.mark.parametrize('wd', [0.0, 1e-4])
+def test_flat_adam_kernel_matches_torch_adam(wd):
+    """eagcn_adam_step on its own: the same gradients fed to FlatAdam and to torch.optim.Adam (train.py:303), 20 steps; the two are
+    the same fp32 arithmetic up to the order of two multiplications (a few ulp per step)."""
+    from eagcn_amd import EAGCN
+    from eagcn_amd.optim import FlatAdam
+    w1, w2 = [16, 12, 8, 8, 8], [24, 12, 12, 12, 12]
+    torch.manual_seed(5)
+    a = EAGCN(9, 24, *w1, *w2, 32, 16, 3, 0.0, n_layers=2).cuda()
+    b = EAGCN(9, 24, *w1, *w2, 32, 16, 3, 0.0, n_layers=2).cuda()
+    b.load_state_dict(a.state_dict())
+    plan_a, plan_b = a.plan(), b.plan()
+    opt_a = FlatAdam(a, lr=1e-3, weight_decay=wd)
+    live_b = [p for p in plan_b.params if p.requires_grad]
+    opt_b = torch.optim.Adam(live_b, lr=1e-3, weight_decay=wd)
+    g = torch.Generator(device='cuda').manual_seed(1)
+    for step in range(20):
+        if step == 10:
+            opt_a.set_lr(3e-4)
+            opt_b.param_groups[0]['lr'] = 3e-4
+        for pa, pb in zip(plan_a.params, plan_b.params):
+            if not pa.requires_grad:
+                continue
+            gr = torch.randn(pa.shape, device='cuda', generator=g) * (10.0 ** float(torch.randint(-6, 1, (1,))))
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        opt_a.step()
+        opt_b.step()
+    worst = 0.0
+    for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+        worst = max(worst, (pa - pb).abs().max().item() / max(pb.abs().max().item(), 1e-3))
+    print('FlatAdam vs torch.optim.Adam after 20 steps (wd=%g): worst |dp| / max|p| = %.2e' % (wd, worst))
+    assert worst < 2e-6, worst
+    st = opt_b.state[live_b[0]]
+    i0 = next(i for i, p in enumerate(plan_a.params) if p.requires_grad)
+    m0 = plan_a.grad_views(opt_a.exp_avg)[i0]
+    assert torch.allclose(m0, st['exp_avg'], rtol=1e-5, atol=1e-12)
+    assert int(opt_a.step_count) == 20
