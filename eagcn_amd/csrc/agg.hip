@@ -23,6 +23,7 @@
 // constant vector (Weighted_sum); they enter the row sum exactly and are dropped from the product
 // (relative contribution <= N*1e-9).
 #include <algorithm>
+#include <type_traits>
 
 #include <stdlib.h>
 
@@ -48,14 +49,26 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // independent loads at the head of the wave, requested together: its first tile's descriptor (inside the tile CAPACITY:
     // always a legal address), the device-side tile count, sigmoid(self_r), the sigmoid table
-    const int tile_first = bx * 4 + wave;
-    int4 ti_next = reinterpret_cast<const int4*>(bt.tile_info)[min(tile_first, max(bt.n_tiles - 1, 0))];
     const float r = a.rsig[k];
     const float sig_v = a.sig[k * 256 + tid];
     const int ntiles = dev_tiles(a.bt);
     const int nlog = dev_n(a.bt);
     if (bx * 4 >= ntiles) return;        // capacity-sized grid: no tile for this workgroup (its
                                                       // stats slab is not read either: bn_finalize counts live slabs)
+    // Which tiles a workgroup takes.  Pass p of the grid covers the tiles [p gx 4, (p+1) gx 4); the tiles of a molecule are
+    // consecutive and all of them read the molecule's slice of the source matrix.  Workgroup bx runs on XCD (bx + const) % 8:
+    // handed out in dispatch order, the four workgroups that share a 256-atom molecule's slice sit on four XCDs and each of
+    // the four L2s fetches it.  With a.xcd the workgroups of one XCD take a CONTIGUOUS range of the pass instead (a bijection
+    // of the live workgroups of the pass, from the device-side tile count), so a slice is fetched into one L2.
+    auto pass_tile = [&](int base) -> int {
+        if (!a.xcd) return base + bx * 4 + wave;
+        const int nl = min(gx, (ntiles - base + 3) >> 2);
+        if (bx >= nl) return ntiles;
+        const int q8 = nl >> 3, r8 = nl & 7, x = bx & 7;
+        return base + ((x * q8 + min(x, r8) + (bx >> 3)) << 2) + wave;
+    };
+    const int tile_first = pass_tile(0);
+    int4 ti_next = reinterpret_cast<const int4*>(bt.tile_info)[min(tile_first, max(ntiles - 1, 0))];
     const int nct = min(CT, ntile_k - ct0);
     const int c0 = a.vc.off[k] + ct0 * 16;
     const int li = lane & 15, q = lane >> 4;
@@ -77,15 +90,29 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
             bv[ct] = (ok && c < ncol) ? rowp[c] : 0.0f;
         }
     };
+    // the same for a row that is known to be inside and the first NA column tiles of the chunk (NA = CT, or 4 Q: the float4 groups
+    // only -- an 8-tile layer runs the 9-tile instantiation with its last tile masked off): no predicate on any load
+    auto load_row_full = [&](const float* rowp, float (&bv)[CT], auto na_c) {
+        constexpr int NA = decltype(na_c)::value;
+#pragma unroll
+        for (int m = 0; m < Q; ++m) {
+            const float4 v = *reinterpret_cast<const float4*>(rowp + m * 64 + 4 * li);
+            bv[4 * m + 0] = v.x; bv[4 * m + 1] = v.y; bv[4 * m + 2] = v.z; bv[4 * m + 3] = v.w;
+        }
+#pragma unroll
+        for (int ct = 4 * Q; ct < NA; ++ct) bv[ct] = rowp[Q * 64 + (ct - 4 * Q) * 16 + li];
+    };
     sig_s[tid] = sig_v;
     if (!TRANS) for (int i = tid; i < CT * 16 * 2; i += 256) st_s[i] = 0.0;
     __syncthreads();
     // (BatchNorm partial sums are accumulated in LDS with fp64 atomics, not in 4*CT registers per lane: that keeps
     //  the kernel at four waves per SIMD)
 
-    for (int tile = tile_first; tile < ntiles; tile += gx * 4) {
+    for (int base = 0, tile = tile_first; tile < ntiles; ) {
         const int4 ti = ti_next;
-        if (tile + gx * 4 < ntiles) ti_next = reinterpret_cast<const int4*>(bt.tile_info)[tile + gx * 4];
+        base += gx * 4;
+        tile = base < ntiles ? pass_tile(base) : ntiles;
+        if (tile < ntiles) ti_next = reinterpret_cast<const int4*>(bt.tile_info)[tile];
         const int b = ti.x, rt = ti.y, n = ti.z, r0 = ti.w;
         const uint8_t* codeb = bt.code + ((size_t)k * bt.B + b) * bt.N * bt.ldc;
         const int ia = rt * 16 + li;                  // A-operand row of this lane = output row
@@ -97,7 +124,55 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
         if (!TRANS) {
             const float mi = (ia < n) ? bt.row_m[r0 + ia] : 0.0f;
             float dsum = 0.0f;
-            for (int j0 = 0; j0 < n; j0 += 16) {
+            int j0 = 0;
+            // Blocks of 16 source rows that lie inside the molecule, for a row tile and a column chunk that are full: the same
+            // arithmetic in the same order as the general block below with every predicate known -- no branch around any load
+            // or MFMA (the general block compiles to ~60 branches per 16 columns and ran the matrix pipes at 41 % at N = 256:
+            // profiles/r04_agg_sq_c5.txt).
+            // Software pipeline over the blocks: the registers of k-step t are re-loaded for the NEXT block as soon as the MFMAs of
+            // k-step t have read them, so every load has three k-steps of this wave's MFMAs (times the other waves' turns on the
+            // pipe) to land in -- the kernel at N = 256 was a load round trip (~1.9 us under load) in front of every block, the
+            // matrix pipes 40-47 % busy (profiles/r04_agg_sq_c5.txt).
+            auto fast_fwd = [&](auto na_c) {
+                constexpr int NA = decltype(na_c)::value;
+                const uint8_t* crow = codeb + (size_t)ia * bt.ldc;
+                if (j0 + 16 > n) return;
+                float bv[4][CT];
+                uint4 cw = *reinterpret_cast<const uint4*>(crow + j0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) load_row_full(sbase + (size_t)(j0 + 4 * t + q) * a.lds, bv[t], na_c);
+                auto block = [&](auto more_c) {
+                    constexpr bool MORE = decltype(more_c)::value;
+                    const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+                    if constexpr (MORE) cw = *reinterpret_cast<const uint4*>(crow + j0 + 16);
+                    float u4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint32_t c = (w[t] >> (8 * q)) & 255u;
+                        float u = sig_s[c] + (c == 0u ? TINY : 0.0f);
+                        if (j0 + 4 * t + q == ia) u += r * mi;
+                        dsum += u;
+                        u4[t] = u;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int ct = 0; ct < NA; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u4[t], bv[t][ct], acc[ct], 0, 0, 0);
+                        if constexpr (MORE) {
+                            load_row_full(sbase + (size_t)(j0 + 16 + 4 * t + q) * a.lds, bv[t], na_c);
+                            __builtin_amdgcn_sched_barrier(0);    // (the scheduler otherwise sinks all re-loads to the block's end)
+                        }
+                    }
+                    j0 += 16;
+                };
+                while (j0 + 32 <= n) block(std::true_type{});
+                block(std::false_type{});
+            };
+            if (rt * 16 + 16 <= n) {
+                if (nct == CT) fast_fwd(std::integral_constant<int, CT>{});
+                else if (Q > 0 && nct == 4 * Q) fast_fwd(std::integral_constant<int, (Q > 0 ? 4 * Q : CT)>{});
+            }
+            for (; j0 < n; j0 += 16) {
                 uint4 cw = make_uint4(0u, 0u, 0u, 0u);
                 if (ia < n) cw = *reinterpret_cast<const uint4*>(codeb + (size_t)ia * bt.ldc + j0);
                 const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
@@ -156,7 +231,54 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
             }
         } else {
             // dP[j,:] = sum_i A^[i,j] dY'[i,:]  (rscale carries m_i / rowsum_i)
-            for (int i0 = 0; i0 < n; i0 += 16) {
+            int i0 = 0;
+            auto fast_trans = [&](auto na_c) {                // (see the forward form above)
+                constexpr int NA = decltype(na_c)::value;
+                const uint8_t* ccol = codeb + ia;
+                const float* rsp = a.rscale + (size_t)k * bt.T + r0;
+                if (i0 + 16 > n) return;
+                uint32_t cc4[4];
+                float rs4[4], bv[4][CT];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int i = i0 + 4 * t + q;
+                    cc4[t] = ccol[(size_t)i * bt.ldc];
+                    rs4[t] = rsp[i];
+                    load_row_full(sbase + (size_t)i * a.lds, bv[t], na_c);
+                }
+                auto block = [&](auto more_c) {
+                    constexpr bool MORE = decltype(more_c)::value;
+                    float u4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float u = sig_s[cc4[t]] + (cc4[t] == 0u ? TINY : 0.0f);
+                        if (i0 + 4 * t + q == ia) u += r;
+                        u4[t] = u * rs4[t];
+                        if constexpr (MORE) {
+                            const int i = i0 + 16 + 4 * t + q;
+                            cc4[t] = ccol[(size_t)i * bt.ldc];
+                            rs4[t] = rsp[i];
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int ct = 0; ct < NA; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(u4[t], bv[t][ct], acc[ct], 0, 0, 0);
+                        if constexpr (MORE) {
+                            load_row_full(sbase + (size_t)(i0 + 16 + 4 * t + q) * a.lds, bv[t], na_c);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    i0 += 16;
+                };
+                while (i0 + 32 <= n) block(std::true_type{});
+                block(std::false_type{});
+            };
+            if (rt * 16 + 16 <= n) {
+                if (nct == CT) fast_trans(std::integral_constant<int, CT>{});
+                else if (Q > 0 && nct == 4 * Q) fast_trans(std::integral_constant<int, (Q > 0 ? 4 * Q : CT)>{});
+            }
+            for (; i0 < n; i0 += 16) {
                 uint32_t cc4[4];
                 float rs4[4], bv[4][CT];
 #pragma unroll
@@ -190,14 +312,13 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
             const int row = rt * 16 + q * 4 + g;
             if (row < n) {
                 if (TRANS && a.planes.p) {            // dP for the plane GEMMs (gemm_bx3.hip): split here, once
-                    const size_t e0 = (size_t)(r0 + row) * a.ldd + c0;
 #pragma unroll
                     for (int m = 0; m < Q; ++m)
                         if (m * 64 + 4 * li < ncol)
-                            bx_store4(a.planes, e0 + m * 64 + 4 * li, make_float4(acc[4 * m][g], acc[4 * m + 1][g], acc[4 * m + 2][g], acc[4 * m + 3][g]));
+                            bx_store4(a.planes, r0 + row, c0 + m * 64 + 4 * li, make_float4(acc[4 * m][g], acc[4 * m + 1][g], acc[4 * m + 2][g], acc[4 * m + 3][g]));
 #pragma unroll
                     for (int ct = 4 * Q; ct < CT; ++ct)
-                        if (lane_col(ct) < ncol) bx_store1(a.planes, e0 + lane_col(ct), acc[ct][g]);
+                        if (lane_col(ct) < ncol) bx_store1(a.planes, r0 + row, c0 + lane_col(ct), acc[ct][g]);
                     continue;
                 }
                 float* drow = a.dst + (size_t)(r0 + row) * a.ldd + c0;
@@ -439,14 +560,13 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
                     const int row = rt * 16 + q * 4 + g;
                     if (row < n) {
                         if (a.planes.p) {             // dP for the plane GEMMs (gemm_bx3.hip): split here, once
-                            const size_t e0 = (size_t)(r0 + row) * a.ldd + c0;
 #pragma unroll
                             for (int m = 0; m < Q; ++m)
                                 if (m * 64 + 4 * li < ncol)
-                                    bx_store4(a.planes, e0 + m * 64 + 4 * li, make_float4(acc[4 * m][g], acc[4 * m + 1][g], acc[4 * m + 2][g], acc[4 * m + 3][g]));
+                                    bx_store4(a.planes, r0 + row, c0 + m * 64 + 4 * li, make_float4(acc[4 * m][g], acc[4 * m + 1][g], acc[4 * m + 2][g], acc[4 * m + 3][g]));
 #pragma unroll
                             for (int ct = 4 * Q; ct < CT; ++ct)
-                                if (lane_col(ct) < ncol) bx_store1(a.planes, e0 + lane_col(ct), acc[ct][g]);
+                                if (lane_col(ct) < ncol) bx_store1(a.planes, r0 + row, c0 + lane_col(ct), acc[ct][g]);
                             continue;
                         }
                         float* drow = a.dst + (size_t)(r0 + row) * a.ldd + c0;
@@ -506,6 +626,11 @@ static int agg_max_ct() {
     static const int v = [] { const char* e = getenv("EAGCN_AGG_MAXCT"); const int x = e ? atoi(e) : 9; return x < 1 ? 1 : (x > 10 ? 10 : x); }();
     return v;
 }
+// wave-per-tile variant: XCD-contiguous tile handout (agg_wave_body); EAGCN_AGG_XCD=0 hands the tiles out in dispatch order
+static int agg_xcd() {
+    static const int v = [] { const char* e = getenv("EAGCN_AGG_XCD"); return e ? atoi(e) : 1; }();
+    return v;
+}
 static int agg_pick_ct(int tmax, int nchunk) {
     const int ct = cdiv(tmax, nchunk);
     return ct == 8 ? 9 : ct;
@@ -528,6 +653,7 @@ int launch_agg(AggArgs a, bool trans, hipStream_t s) {
     const int nchunk = cdiv(tmax, agg_max_ct());
     const int ct = agg_pick_ct(tmax, nchunk);
     a.nchunk = nchunk;
+    a.xcd = agg_xcd();
     dim3 grid(agg_grid_x(&a.bt), a.vc.K * nchunk);
     ProfScope ps(PROF_AGG, s);
     const bool ks = agg_ksplit(&a.bt);
@@ -716,6 +842,7 @@ int launch_agg_edge(AggArgs a, const EdgeArgs& e, hipStream_t s) {
     const int nchunk = cdiv(tmax, agg_max_ct());
     const int ct = agg_pick_ct(tmax, nchunk);
     a.nchunk = nchunk;
+    a.xcd = agg_xcd();
     const int agx = agg_grid_x(&a.bt), egx = edge_grid_x(&a.bt);
     dim3 grid(agx + egx, a.vc.K * nchunk);
     const bool ks = agg_ksplit(&a.bt);

@@ -1,21 +1,34 @@
 // bf16 plane images of fp32 matrices: the operand format of csrc/gemm_bx3.hip, written by the kernels that PRODUCE a matrix.
 //   three planes (exact):  x = x0 + x1 + x2, each piece the top 8 significand bits of what the pieces before it left over
-//                          (truncation of the bit pattern; every remainder is computed exactly in fp32), plane q at
-//                          planes + q * pstride (elements), same row-major [rows][ld] geometry as the fp32 matrix;
+//                          (every remainder is computed exactly in fp32), plane q at planes + q * pstride (elements);
 //   one plane (bf16 mode): round to nearest even.
+// Geometry of a plane: PANEL-MAJOR.  The columns are cut into panels of 32; a panel holds all `rows` (the row CAPACITY of the
+// image) rows of its 32 columns, 64 bytes per row, and inside a row the four 16-byte chunks are stored XOR-swizzled by the row:
+//     element (r, c)  ->  ((c >> 5) * rows + r) * 32  +  ((((c >> 3) & 3) ^ ((r >> 2) & 3)) << 3)  +  (c & 7)
+// This IS the LDS image the GEMM multiplies from (gemm_bx3.hip): a 128-row x 32-k operand tile is 8 KB of CONTIGUOUS memory and
+// a k-major 32-k x 128-column tile four contiguous 2 KB pieces, so every LDS-DMA instruction of the GEMM copies 1 KB of
+// consecutive bytes, lane-linear.  (With row-major planes a k-contiguous tile was 128 segments of 64 bytes and the fill ran
+// at 15-20 bytes per clock and CU against 23-56 for contiguous kilobytes: profiles/r04_lds_fill_probe.txt.)
 #pragma once
 #include "common.h"
 
 namespace eagcn {
 
-struct BxPlanes {                // bf16 planes of a row-major matrix
+struct BxPlanes {                // bf16 planes of a matrix
     const uint16_t* p;           // plane 0; plane q at p + q * pstride
-    size_t pstride;              // elements between planes
-    int ld;                      // elements between rows
+    size_t pstride;              // elements between planes (>= bx_plane_elems(rows, ld))
+    int ld;                      // columns the image holds (a multiple of 8; the panels cover ceil(ld / 32) * 32)
+    int rows;                    // row capacity of the image (the panel pitch)
 };
 struct BxOut {                   // the same, as an output of a producer kernel (p == nullptr: not requested)
-    uint16_t* p; size_t pstride; int np;
+    uint16_t* p; size_t pstride; int np; int rows;
 };
+// elements of one plane image
+__host__ __device__ inline size_t bx_plane_elems(int rows, int ld) { return (size_t)((ld + 31) >> 5) * 32u * (size_t)(rows > 0 ? rows : 1); }
+// element index of (r, c) inside a plane image of row capacity `rows`
+__host__ __device__ inline size_t bx_addr(int rows, int r, int c) {
+    return ((size_t)(c >> 5) * (size_t)rows + (size_t)r) * 32u + (size_t)(((((c >> 3) & 3) ^ ((r >> 2) & 3)) << 3) + (c & 7));
+}
 
 __device__ __forceinline__ uint32_t bx1_round(float v) {       // bf16 bits (in the HIGH half), round to nearest even
     const uint32_t b = __float_as_uint(v);
@@ -46,11 +59,14 @@ __device__ __forceinline__ void bx3_store4(uint16_t* __restrict__ pl, size_t pst
 __device__ __forceinline__ void bx1_store4(uint16_t* __restrict__ pl, size_t idx, const float4 v) {
     *reinterpret_cast<uint2*>(pl + idx) = make_uint2((bx1_round(v.x) >> 16) | bx1_round(v.y), (bx1_round(v.z) >> 16) | bx1_round(v.w));
 }
-__device__ __forceinline__ void bx_store4(const BxOut& o, size_t idx, const float4 v) {
+// four adjacent columns c .. c + 3 (c a multiple of 4) of row r
+__device__ __forceinline__ void bx_store4(const BxOut& o, int r, int c, const float4 v) {
+    const size_t idx = bx_addr(o.rows, r, c);
     if (o.np == 3) bx3_store4(o.p, o.pstride, idx, v); else bx1_store4(o.p, idx, v);
 }
 // one element (scalar tails)
-__device__ __forceinline__ void bx_store1(const BxOut& o, size_t idx, float v) {
+__device__ __forceinline__ void bx_store1(const BxOut& o, int r, int c, float v) {
+    const size_t idx = bx_addr(o.rows, r, c);
     if (o.np == 3) {
         uint32_t h0, h1, h2;
         bx3_split(v, h0, h1, h2);
@@ -88,6 +104,7 @@ bool bx3_ok(const BxProb& p);
 int bx3_grid();
 // np = 3: exact fp32 products from three planes; np = 1: plain bf16 operands.  p1 (optional): second product in the same launch
 int launch_bx3(const BxProb& p0, const BxProb* p1, int np, hipStream_t s, double work, int prof_tag);
-int launch_bx3_split(const float* x, int rows, const int* rows_dev, int ld, uint16_t* planes, size_t pstride, int np, hipStream_t s);
+// fp32 [rows][ld] -> plane images of row capacity rows_cap
+int launch_bx3_split(const float* x, int rows, const int* rows_dev, int ld, uint16_t* planes, size_t pstride, int rows_cap, int np, hipStream_t s);
 
 }  // namespace eagcn

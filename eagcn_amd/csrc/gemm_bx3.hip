@@ -16,14 +16,18 @@
 //   NT  C[M,N] = A[M,K] . B[N,K]^T   both operands K-contiguous: forward (X . WcatT^T) and dX = dP . Wcat^T
 //   TN  C[M,N] = A[K,M]^T . B[K,N]   both operands K-major:      dW = X^T . dP, K = packed rows, split-K over `splits` slabs
 // Workgroup tile (64 WM) x (64 WN) x 32, one wave per 64 x 64 (2 x 2 MFMA tiles of 32 x 32, 64 accumulator registers).
-// LDS image of one operand plane and k-tile:
-//   NT  [rows][32 k]  = 64 bytes per row; 16-byte chunk c of row r sits at chunk c ^ ((r >> 2) & 3)
-//   TN  [32 k][rows]  = 2 rows bytes per k;  16-byte chunk c of k-row r sits at chunk c ^ ((r & 3) << 2)
-// both conflict-free for the lane groups their fragment reads are served in (ds_read_b128 / ds_read_b64_tr_b16: the transposing
-// read hands a lane the four k-consecutive values of ITS column out of a [4 k][16 column] block -- tools/probes/bx3_probe.hip
-// pins the mapping).  LDS-DMA writes lane-linear (base + 16 lane), so the swizzle lives in the per-lane SOURCE address.
-// Out-of-range rows (M / K tails, device-side extents) read as ZERO through the range check of the buffer descriptors, whose
-// num_records are built from the actual extents.
+// Operand planes are PANEL-MAJOR (bx3.h): 32-column panels of all rows, 64 bytes per row, the four 16-byte chunks of a row
+// XOR-swizzled by (row >> 2) & 3 -- the global image IS the LDS image, every LDS-DMA instruction copies 1 KB of consecutive bytes:
+//   NT  operand tile = 128 rows of ONE panel (k-tile kt = panel kt): 8 KB contiguous; LDS [128 rows][64 B]
+//   TN  operand tile = 32 k-rows of FOUR panels (128 columns):       4 x 2 KB;        LDS [4 panels][32 k-rows][64 B]
+// (round-4 first version: row-major planes, a k-contiguous tile was 128 x 64-byte segments and the fill ran at 15-20 B/clk/CU:
+// forward 73 us, pair 160 us at 19 200 rows; profiles/r04_lds_fill_probe.txt.)
+// Fragment reads: NT ds_read_b128 of chunk (2 s + kg) ^ ((row >> 2) & 3); TN ds_read_b64_tr_b16 (the transposing read hands a lane
+// the four k-consecutive values of ITS column out of a [4 k][16 column] block -- tools/probes/bx3_probe.hip pins the mapping): a
+// 16-lane block touches 4 k-rows x 32 bytes, a half wave 4 rows x 64 bytes = 256 distinct bytes.
+// What is NOT inside the actual extents: k beyond K (NT: chunks of the last panel; TN: rows beyond the device-side row count) is
+// requested out of range per lane and arrives as ZERO; rows / columns beyond M / N hold whatever the image holds there -- they
+// only reach output rows / columns that are never stored.
 // Pipeline: NS LDS stages (3 for 128 x 128, 2 for the 8-wave tiles); tile kt + NS - 1 is in flight while tile kt is multiplied;
 // one raw s_barrier and one counted s_waitcnt vmcnt per k-tile, nothing else.
 // Scheduling: PERSISTENT -- one workgroup per CU walks a contiguous run of work units (output tiles, or (tile, k-chunk) items of
@@ -119,51 +123,47 @@ template <bool TN, int NP>
 __device__ __forceinline__ void bx_loader(const BxProb& p, const BxStream& st, const int lw) {
     constexpr int PPL = NP * (BX_APW + BX_BPW);
     const int lane = threadIdx.x & 63;
-    // buffer descriptors: one per operand plane, num_records from the ACTUAL extents (rows beyond them read as zero)
-    const unsigned arows = TN ? (unsigned)st.Kx : (unsigned)st.Mx;
-    const unsigned brows = TN ? (unsigned)st.Kx : (unsigned)p.N;
+    // buffer descriptors: one per operand plane over the whole image
+    const unsigned apanel = (unsigned)p.A.rows * 64u, bpanel = (unsigned)p.B.rows * 64u;      // bytes of one 32-column panel
+    const unsigned abytes = (unsigned)((p.A.ld + 31) >> 5) * apanel, bbytes = (unsigned)((p.B.ld + 31) >> 5) * bpanel;
     __amdgpu_buffer_rsrc_t ra[3], rb[3];           // (fixed size: clang's host pass rejects the DMA builtin on an array of dependent extent)
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-        ra[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A.p + (size_t)q * p.A.pstride), 0, (int)(arows * (unsigned)p.A.ld * 2u), 0x00020000);
-        rb[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B.p + (size_t)q * p.B.pstride), 0, (int)(brows * (unsigned)p.B.ld * 2u), 0x00020000);
+        ra[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A.p + (size_t)q * p.A.pstride), 0, (int)abytes, 0x00020000);
+        rb[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B.p + (size_t)q * p.B.pstride), 0, (int)bbytes, 0x00020000);
     }
-    // per-lane source offsets (bytes) RELATIVE to the unit's origin; the swizzle of the LDS image lives here (DMA writes lane-linear)
+    // per-lane source offsets (bytes) RELATIVE to the k-tile's origin: piece pc of an operand's tile image is 1 KB of consecutive
+    // bytes (NT: rows 16 pc .. of the k-tile's panel; TN: rows 16 (pc & 1) .. of the tile's panel pc >> 1), lane-linear
     unsigned ra_[BX_APW], rb_[BX_BPW];
-    const unsigned astep = TN ? (unsigned)BX_BK * (unsigned)p.A.ld * 2u : BX_BK * 2u;
-    const unsigned bstep = TN ? (unsigned)BX_BK * (unsigned)p.B.ld * 2u : BX_BK * 2u;
+    const unsigned astep = TN ? BX_BK * 64u : apanel;                  // k-tile to k-tile
+    const unsigned bstep = TN ? BX_BK * 64u : bpanel;
 #pragma unroll
     for (int u = 0; u < BX_APW; ++u) {
-        const int pc = lw + BX_NL * u;                                          // piece of the plane image
-        if constexpr (!TN) {
-            const int r = pc * 16 + (lane >> 2), cs = (lane & 3) ^ ((r >> 2) & 3);
-            ra_[u] = ((unsigned)r * (unsigned)p.A.ld + (unsigned)(cs * 8)) * 2u;
-        } else {
-            const int byte = pc * 1024 + lane * 16, kr = byte / (BX_BM * 2), cp = (byte % (BX_BM * 2)) >> 4;
-            ra_[u] = ((unsigned)kr * (unsigned)p.A.ld + (unsigned)((cp ^ ((kr & 3) << 2)) * 8)) * 2u;
-        }
+        const int pc = lw + BX_NL * u;
+        ra_[u] = TN ? (unsigned)(pc >> 1) * apanel + (unsigned)((pc & 1) * 1024 + lane * 16) : (unsigned)(pc * 1024 + lane * 16);
     }
 #pragma unroll
     for (int u = 0; u < BX_BPW; ++u) {
         const int pc = lw + BX_NL * u;
-        if constexpr (!TN) {
-            const int r = pc * 16 + (lane >> 2), cs = (lane & 3) ^ ((r >> 2) & 3);
-            rb_[u] = ((unsigned)r * (unsigned)p.B.ld + (unsigned)(cs * 8)) * 2u;
-        } else {
-            const int byte = pc * 1024 + lane * 16, kr = byte / (BX_BN * 2), cp = (byte % (BX_BN * 2)) >> 4;
-            rb_[u] = ((unsigned)kr * (unsigned)p.B.ld + (unsigned)((cp ^ ((kr & 3) << 2)) * 8)) * 2u;
-        }
+        rb_[u] = TN ? (unsigned)(pc >> 1) * bpanel + (unsigned)((pc & 1) * 1024 + lane * 16) : (unsigned)(pc * 1024 + lane * 16);
     }
-    const unsigned OOB = 0xFFFFFF00u;                  // beyond every num_records (bx3_ok keeps planes below 4e9 bytes)
-    // NT: the last k-tile of a product may hold fewer than 32 valid k (K is a multiple of 8): the chunks beyond K are requested
-    // out of range, i.e. arrive as zeros, and the compute waves multiply every k-tile in full
-    int kca[BX_APW], kcb[BX_BPW];                      // k offset of this lane's source chunk inside a k-tile (NT)
+    const unsigned OOB = 0xFFFFFF00u;                  // beyond every num_records (bx3_ok keeps the images below 4e9 bytes)
+    // k beyond the actual K arrives as zeros (requested out of range), and the compute waves multiply every k-tile in full:
+    //   NT: the last panel may hold fewer than 32 valid k (K is a multiple of 8): the lane's LOGICAL chunk decides
+    //   TN: k-rows beyond the (device-side) row count: the lane's row decides
+    int kca[BX_APW], kcb[BX_BPW];                      // k offset of this lane's 16 bytes inside a k-tile
 #pragma unroll
-    for (int u = 0; u < BX_APW; ++u) { const int r = (lw + BX_NL * u) * 16 + (lane >> 2); kca[u] = 8 * ((lane & 3) ^ ((r >> 2) & 3)); }
+    for (int u = 0; u < BX_APW; ++u) {
+        const int pc = lw + BX_NL * u, r = pc * 16 + (lane >> 2);
+        kca[u] = TN ? (pc & 1) * 16 + (lane >> 2) : 8 * ((lane & 3) ^ ((r >> 2) & 3));
+    }
 #pragma unroll
-    for (int u = 0; u < BX_BPW; ++u) { const int r = (lw + BX_NL * u) * 16 + (lane >> 2); kcb[u] = 8 * ((lane & 3) ^ ((r >> 2) & 3)); }
+    for (int u = 0; u < BX_BPW; ++u) {
+        const int pc = lw + BX_NL * u, r = pc * 16 + (lane >> 2);
+        kcb[u] = TN ? (pc & 1) * 16 + (lane >> 2) : 8 * ((lane & 3) ^ ((r >> 2) & 3));
+    }
     // iterator over the k-tiles of the stream
-    int j = -1, left = 0, kpos = 0;                    // kpos: first k of the current k-tile (NT)
+    int j = -1, left = 0, kpos = 0;                    // kpos: first k of the current k-tile
     unsigned oa = 0, ob = 0;                           // byte offsets of the current k-tile's origin in A / B
     auto issue_next = [&](int stage) __attribute__((always_inline)) {
         while (left == 0 && j + 1 < st.count) {        // next unit that has k-tiles
@@ -171,12 +171,12 @@ __device__ __forceinline__ void bx_loader(const BxProb& p, const BxStream& st, c
             const BxUnit un = bx_unit(p, st, j);
             left = un.nk;
             kpos = un.kt0 * BX_BK;
-            if constexpr (!TN) {
-                oa = ((unsigned)(un.tm * BX_BM) * (unsigned)p.A.ld + (unsigned)(un.kt0 * BX_BK)) * 2u;
-                ob = ((unsigned)(un.tn * BX_BN) * (unsigned)p.B.ld + (unsigned)(un.kt0 * BX_BK)) * 2u;
-            } else {
-                oa = ((unsigned)(un.kt0 * BX_BK) * (unsigned)p.A.ld + (unsigned)(un.tm * BX_BM)) * 2u;
-                ob = ((unsigned)(un.kt0 * BX_BK) * (unsigned)p.B.ld + (unsigned)(un.tn * BX_BN)) * 2u;
+            if constexpr (!TN) {                       // panel kt0, rows of the tile
+                oa = (unsigned)un.kt0 * apanel + (unsigned)(un.tm * BX_BM) * 64u;
+                ob = (unsigned)un.kt0 * bpanel + (unsigned)(un.tn * BX_BN) * 64u;
+            } else {                                   // the tile's first panel, k-row kt0 * 32
+                oa = (unsigned)(un.tm * (BX_BM / 32)) * apanel + (unsigned)(un.kt0 * BX_BK) * 64u;
+                ob = (unsigned)(un.tn * (BX_BN / 32)) * bpanel + (unsigned)(un.kt0 * BX_BK) * 64u;
             }
         }
         const bool real = left > 0;                    // behind the last k-tile: zero fills (out-of-range requests, no traffic) keep
@@ -186,11 +186,11 @@ __device__ __forceinline__ void bx_loader(const BxProb& p, const BxStream& st, c
 #pragma unroll
             for (int u = 0; u < BX_APW; ++u)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra[q], (bx_lds_ptr)(sb + q * BX_APL + (lw + BX_NL * u) * 1024), 16,
-                                                         (int)((real && (TN || kpos + kca[u] < st.Kx)) ? oa + ra_[u] : OOB), 0, 0, 0);
+                                                         (int)((real && kpos + kca[u] < st.Kx) ? oa + ra_[u] : OOB), 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < BX_BPW; ++u)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb[q], (bx_lds_ptr)(sb + 3 * BX_APL + q * BX_BPL + (lw + BX_NL * u) * 1024), 16,
-                                                         (int)((real && (TN || kpos + kcb[u] < st.Kx)) ? ob + rb_[u] : OOB), 0, 0, 0);
+                                                         (int)((real && kpos + kcb[u] < st.Kx) ? ob + rb_[u] : OOB), 0, 0, 0);
         }
         if (real) { oa += astep; ob += bstep; kpos += BX_BK; --left; }
     };
@@ -220,7 +220,7 @@ template <bool TN, int NP, int DBG>
 __device__ __forceinline__ void bx_compute(const BxProb& p, const BxStream& st, const int wave) {
     const int lane = threadIdx.x & 63;
     const int wm = wave >> 1, wn = wave & 1;
-    int fa[2], fb[2];                                  // NT: per k16-step s; TN: per 32-row tile t
+    int fa[2], fb[2], fah[2], fbh[2];                  // NT: per k16-step s; TN: per 32-column tile t (lo / hi: k-rows +0 / +4)
     if constexpr (!TN) {
         const int i = lane & 31, kg = lane >> 5, x = (i >> 2) & 3;
 #pragma unroll
@@ -229,12 +229,16 @@ __device__ __forceinline__ void bx_compute(const BxProb& p, const BxStream& st, 
             fb[s] = (wn * 64 + i) * 64 + (((2 * s + kg) ^ x) << 4);
         }
     } else {
-        const int b = lane >> 4, c = lane & 15, r = c >> 2;
-        const int cb = 2 * (b & 1) + ((c & 3) >> 1);
+        // block b, lane c: k-row 8 (b >> 1) + (c >> 2) [+ 4], columns 16 (b & 1) + 4 (c & 3) .. + 3 of the 32-column tile = panel
+        // (2 w + t) of the image: logical chunk 2 (b & 1) + ((c & 3) >> 1), swizzled by (k-row >> 2) & 3 = 2 (b >> 1) [+ 1]
+        const int b = lane >> 4, c = lane & 15;
+        const int row = 8 * (b >> 1) + (c >> 2), ch = 2 * (b & 1) + ((c & 3) >> 1), half = 8 * (c & 1);
+        const int lo_off = row * 64 + ((ch ^ (2 * (b >> 1))) << 4) + half;
+        const int hi_off = (row + 4) * 64 + ((ch ^ (2 * (b >> 1) + 1)) << 4) + half;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            fa[t] = (8 * (b >> 1) + r) * (BX_BM * 2) + ((((wm * 8 + 4 * t) ^ (r << 2)) + cb) << 4) + 8 * (c & 1);
-            fb[t] = (8 * (b >> 1) + r) * (BX_BN * 2) + ((((wn * 8 + 4 * t) ^ (r << 2)) + cb) << 4) + 8 * (c & 1);
+            fa[t] = (2 * wm + t) * 2048 + lo_off; fah[t] = (2 * wm + t) * 2048 + hi_off;
+            fb[t] = (2 * wn + t) * 2048 + lo_off; fbh[t] = (2 * wn + t) * 2048 + hi_off;
         }
     }
     auto frag = [&](const unsigned char* plane, int t, int s, bool is_a) __attribute__((always_inline)) -> bx_bf16x8 {
@@ -242,10 +246,9 @@ __device__ __forceinline__ void bx_compute(const BxProb& p, const BxStream& st, 
             const int off = (is_a ? fa[s] : fb[s]) + t * 32 * 64;
             return __builtin_bit_cast(bx_bf16x8, *reinterpret_cast<const bx_u32x4*>(plane + off));
         } else {
-            const int rs = (is_a ? BX_BM : BX_BN) * 2;
-            const int off = (is_a ? fa[t] : fb[t]) + 16 * s * rs;
+            const int off = (is_a ? fa[t] : fb[t]) + 16 * s * 64, offh = (is_a ? fah[t] : fbh[t]) + 16 * s * 64;
             const bx_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bx_s16x4 __attribute__((address_space(3)))*)(plane + off));
-            const bx_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bx_s16x4 __attribute__((address_space(3)))*)(plane + off + 4 * rs));
+            const bx_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bx_s16x4 __attribute__((address_space(3)))*)(plane + offh));
             typedef short s16x8 __attribute__((ext_vector_type(8)));
             const s16x8 v = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             return __builtin_bit_cast(bx_bf16x8, v);
@@ -423,13 +426,14 @@ __global__ __launch_bounds__(64 * (BX_NC + BX_NL), 2) void bx3_kernel(BxProb p0,
 // fp32 matrix [rows][ld] -> three bf16 planes (stand-alone conversion: C-ABI entry, tests, layer-level path; the model engine's
 // producers write the planes in their own epilogues)
 __global__ __launch_bounds__(256) void bx3_split_kernel(const float* __restrict__ x, int rows, const int* __restrict__ rows_dev, int ld,
-                                                       uint16_t* __restrict__ pl, size_t pstride, int np) {
+                                                       uint16_t* __restrict__ pl, size_t pstride, int rows_cap, int np) {
     const int R = rows_dev ? min(*rows_dev, rows) : rows;
-    const size_t n4 = (size_t)R * ld / 4;
+    const int ld4 = ld >> 2;
+    const size_t n4 = (size_t)R * ld4;
+    const BxOut o{pl, pstride, np, rows_cap};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const float4 v = *reinterpret_cast<const float4*>(x + 4 * i);
-        if (np == 3) bx3_store4(pl, pstride, 4 * i, v);
-        else bx1_store4(pl, 4 * i, v);
+        const int r = (int)(i / ld4), c = (int)(i - (size_t)r * ld4) << 2;
+        bx_store4(o, r, c, *reinterpret_cast<const float4*>(x + 4 * i));
     }
 }
 
@@ -447,12 +451,13 @@ int bx3_grid() {
     return g;
 }
 
-int launch_bx3_split(const float* x, int rows, const int* rows_dev, int ld, uint16_t* planes, size_t pstride, int np, hipStream_t s) {
-    EAGCN_CHECK_ARG(x && planes && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(planes) & 7) == 0 &&
-                        (pstride & 3) == 0, "bx3_split: operands must be 16-byte aligned with ld a multiple of 4");
+int launch_bx3_split(const float* x, int rows, const int* rows_dev, int ld, uint16_t* planes, size_t pstride, int rows_cap, int np, hipStream_t s) {
+    EAGCN_CHECK_ARG(x && planes && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 &&
+                        (pstride & 7) == 0, "bx3_split: operands must be 16-byte aligned with ld a multiple of 4");
+    EAGCN_CHECK_ARG(rows <= rows_cap && pstride >= bx_plane_elems(rows_cap, ld), "bx3_split: %d rows do not fit the plane image (capacity %d rows)", rows, rows_cap);
     if (rows <= 0) return EAGCN_OK;
     const size_t n4 = (size_t)rows * ld / 4;
-    bx3_split_kernel<<<(unsigned)std::max<size_t>(1, std::min<size_t>((n4 + 255) / 256, 4096)), 256, 0, s>>>(x, rows, rows_dev, ld, planes, pstride, np);
+    bx3_split_kernel<<<(unsigned)std::max<size_t>(1, std::min<size_t>((n4 + 255) / 256, 4096)), 256, 0, s>>>(x, rows, rows_dev, ld, planes, pstride, rows_cap, np);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
@@ -461,9 +466,13 @@ bool bx3_ok(const BxProb& p) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A.p || !p.B.p || !p.C) return false;
     if ((p.A.ld & 7) || (p.B.ld & 7) || (reinterpret_cast<uintptr_t>(p.A.p) & 15) || (reinterpret_cast<uintptr_t>(p.B.p) & 15)) return false;
     if ((p.A.pstride & 7) || (p.B.pstride & 7)) return false;
-    // 32-bit byte offsets inside a plane (buffer descriptor + voffset)
-    const double arows = p.tn ? p.K : p.M, brows = p.tn ? p.K : p.N;
-    if ((arows + 256) * p.A.ld * 2.0 >= 4.0e9 || (brows + 256) * p.B.ld * 2.0 >= 4.0e9) return false;
+    if (p.A.pstride < bx_plane_elems(p.A.rows, p.A.ld) || p.B.pstride < bx_plane_elems(p.B.rows, p.B.ld)) return false;
+    // the images hold the operands' rows; 32-bit byte offsets inside an image (buffer descriptor + voffset, tiles may reach 128 rows /
+    // four panels beyond the extents)
+    const int arows = p.tn ? p.K : p.M, brows = p.tn ? p.K : p.N;
+    if (arows > p.A.rows || brows > p.B.rows) return false;
+    if (((double)bx_plane_elems(p.A.rows, p.A.ld) + 5.0 * 64 * p.A.rows) * 2.0 >= 4.0e9 ||
+        ((double)bx_plane_elems(p.B.rows, p.B.ld) + 5.0 * 64 * p.B.rows) * 2.0 >= 4.0e9) return false;
     if (!p.tn) return (p.K & 7) == 0 && p.K <= p.A.ld && p.K <= p.B.ld && !p.K_dev;
     return !p.M_dev && p.M <= p.A.ld && p.N <= p.B.ld && p.splits >= 1 && (p.splits == 1 || p.slab >= (size_t)p.M * p.ldc);
 }
@@ -496,21 +505,23 @@ int launch_bx3(const BxProb& p0, const BxProb* p1, int np, hipStream_t s, double
 
 using namespace eagcn;
 
-/* planes of a row-major fp32 matrix: three bf16 planes (np = 3: x = x0 + x1 + x2 exactly) or one (np = 1: round to nearest even),
- * plane q at planes + q * plane_stride (elements); reference-free helper of the C-ABI product below and of tests */
-extern "C" int eagcn_bx3_split(const float* x, int rows, int ld, uint16_t* planes, size_t plane_stride, int np, void* stream) {
+/* plane images (PANEL-MAJOR, include/eagcn_hip.h) of a row-major fp32 matrix [rows][ld]: three bf16 planes (np = 3: x = x0 + x1 + x2
+ * exactly) or one (np = 1: round to nearest even), plane q at planes + q * plane_stride (elements), images of row capacity rows_cap */
+extern "C" int eagcn_bx3_split(const float* x, int rows, int ld, uint16_t* planes, size_t plane_stride, int rows_cap, int np, void* stream) {
     EAGCN_CHECK_ARG(np == 1 || np == 3, "eagcn_bx3_split: np must be 1 or 3");
-    return launch_bx3_split(x, rows, nullptr, ld, planes, plane_stride, np, (hipStream_t)stream);
+    return launch_bx3_split(x, rows, nullptr, ld, planes, plane_stride, rows_cap, np, (hipStream_t)stream);
 }
 
-/* C = op(A) . op(B) from bf16 planes.  tn = 0: C[M,N] = A[M,K] . B[N,K]^T (A planes [M][lda], B planes [N][ldb]);
- * tn = 1: C[M,N] = A[K,M]^T . B[K,N] (planes [K][lda], [K][ldb]) written as `splits` partial slabs C + z * slab (their sum is the
- * product).  Optional second problem in the same launch (has1). */
-extern "C" int eagcn_gemm_bx3(int tn, int M, int N, int K, const uint16_t* A, size_t a_pstride, int lda, const uint16_t* B,
-                              size_t b_pstride, int ldb, float* C, int ldc, int splits, size_t slab, int np, void* stream) {
+extern "C" size_t eagcn_bx3_plane_elems(int rows_cap, int ld) { return bx_plane_elems(rows_cap, ld); }
+
+/* C = op(A) . op(B) from bf16 plane images.  tn = 0: C[M,N] = A[M,K] . B[N,K]^T (images of [a_rows >= M][lda >= K], [b_rows >= N][ldb >= K]);
+ * tn = 1: C[M,N] = A[K,M]^T . B[K,N] (images of [a_rows >= K][lda >= M], [b_rows >= K][ldb >= N]) written as partial slabs
+ * C + z * slab (their sum is the product; eagcn_bx3_used_splits of them are written). */
+extern "C" int eagcn_gemm_bx3(int tn, int M, int N, int K, const uint16_t* A, size_t a_pstride, int lda, int a_rows, const uint16_t* B,
+                              size_t b_pstride, int ldb, int b_rows, float* C, int ldc, int splits, size_t slab, int np, void* stream) {
     BxProb p;
     memset(&p, 0, sizeof(p));
-    p.A = BxPlanes{A, a_pstride, lda}; p.B = BxPlanes{B, b_pstride, ldb}; p.C = C; p.ldc = ldc;
+    p.A = BxPlanes{A, a_pstride, lda, a_rows}; p.B = BxPlanes{B, b_pstride, ldb, b_rows}; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K; p.tn = tn; p.splits = tn ? std::max(1, splits) : 1; p.slab = slab;
     return launch_bx3(p, nullptr, np, (hipStream_t)stream, 2.0 * M * N * K, PROF_GEMM);
 }
@@ -520,16 +531,16 @@ extern "C" int eagcn_bx3_used_splits(int splits, int M, int N, int K) {
 }
 
 /* the dX / dW pair of a layer's backward in ONE persistent launch: problem 0 NT, problem 1 TN with split-K slabs */
-extern "C" int eagcn_gemm_bx3_pair(int M0, int N0, int K0, const uint16_t* A0, size_t a0_pstride, int lda0, const uint16_t* B0,
-                                   size_t b0_pstride, int ldb0, float* C0, int ldc0, int M1, int N1, int K1, const uint16_t* A1,
-                                   size_t a1_pstride, int lda1, const uint16_t* B1, size_t b1_pstride, int ldb1, float* C1, int ldc1,
-                                   int splits, size_t slab, int np, void* stream) {
+extern "C" int eagcn_gemm_bx3_pair(int M0, int N0, int K0, const uint16_t* A0, size_t a0_pstride, int lda0, int a0_rows, const uint16_t* B0,
+                                   size_t b0_pstride, int ldb0, int b0_rows, float* C0, int ldc0, int M1, int N1, int K1, const uint16_t* A1,
+                                   size_t a1_pstride, int lda1, int a1_rows, const uint16_t* B1, size_t b1_pstride, int ldb1, int b1_rows,
+                                   float* C1, int ldc1, int splits, size_t slab, int np, void* stream) {
     BxProb p, q;
     memset(&p, 0, sizeof(p));
     memset(&q, 0, sizeof(q));
-    p.A = BxPlanes{A0, a0_pstride, lda0}; p.B = BxPlanes{B0, b0_pstride, ldb0}; p.C = C0; p.ldc = ldc0;
+    p.A = BxPlanes{A0, a0_pstride, lda0, a0_rows}; p.B = BxPlanes{B0, b0_pstride, ldb0, b0_rows}; p.C = C0; p.ldc = ldc0;
     p.M = M0; p.N = N0; p.K = K0; p.tn = 0; p.splits = 1;
-    q.A = BxPlanes{A1, a1_pstride, lda1}; q.B = BxPlanes{B1, b1_pstride, ldb1}; q.C = C1; q.ldc = ldc1;
+    q.A = BxPlanes{A1, a1_pstride, lda1, a1_rows}; q.B = BxPlanes{B1, b1_pstride, ldb1, b1_rows}; q.C = C1; q.ldc = ldc1;
     q.M = M1; q.N = N1; q.K = K1; q.tn = 1; q.splits = std::max(1, splits); q.slab = slab;
     return launch_bx3(p, &q, np, (hipStream_t)stream, 2.0 * M0 * N0 * K0 + 2.0 * M1 * N1 * K1, PROF_GEMM_PAIR);
 }

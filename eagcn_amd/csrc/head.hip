@@ -72,7 +72,7 @@ static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m
         L.packed = c.take<char>(L.packed_bytes);
         // the layer above reads this layer's output through bf16 operand planes when its products run on gemm_bx3.hip
         const int np = (l + 1 < m->n_layers && L.ldo >= 128 && (L.ldo & 15) == 0) ? gemm_planes() : 0;
-        L.xout_planes = np ? c.take<uint16_t>((size_t)np * T * L.ldo) : nullptr;
+        L.xout_planes = np ? c.take<uint16_t>((size_t)np * bx_plane_elems(T, L.ldo)) : nullptr;
     }
     const eagcn_head_params* h = &m->head;
     const size_t B = (size_t)b->B;

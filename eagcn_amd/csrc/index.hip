@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void index_scan_kernel(const float* __restrict
 // word per (bond, view): +0x10000 + (channel + 1) for a channel equal to 1, +0x1000000 for any other non-zero value.
 // (4) Every lane then packs the codes of its own four columns from that word and the code rows leave as before.
 constexpr int SCAN_CAP = 64;                 // bonds gathered per pass (a wave whose rows hold more runs several passes)
-template <int NIT, int RPW>
+// AL = elements per adjacency load: 4 (N a multiple of 4: every row 16-byte aligned), 2 (N even: 8-byte loads, e.g. the HIV
+// set's N = 222) or 1 (odd N); the lane -> column map (lane f owns columns 4 f .. 4 f + 3) is the same in all three.
+template <int NIT, int RPW, int AL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))          // (168 registers; 190 and two waves per SIMD without the hint)
 void index_scan4_kernel(const float* __restrict__ adj, RelPtrs rel, int B, int N, int Ncap, int K,
                                                            int ldc, uint8_t* __restrict__ code, int32_t* __restrict__ deg_bn,
@@ -151,16 +153,29 @@ void index_scan4_kernel(const float* __restrict__ adj, RelPtrs rel, int B, int N
     const long nrows = (long)B * N;
     if (row_first >= nrows) return;                      // (wave-uniform)
     const size_t plane = (size_t)N * N;
-    const int nf4 = N >> 2;
     float4 a[RPW][NIT];
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const long row = row_first + rr;
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
-            const int f = lane + 64 * t;
+            const int j0 = (lane + 64 * t) * 4;
             a[rr][t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < nrows && f < nf4) a[rr][t] = *reinterpret_cast<const float4*>(adj + (size_t)row * N + 4 * f);
+            if (row < nrows && j0 < N) {
+                const float* p = adj + (size_t)row * N + j0;
+                if constexpr (AL == 4) a[rr][t] = *reinterpret_cast<const float4*>(p);
+                else if constexpr (AL == 2) {
+                    const float2 lo = *reinterpret_cast<const float2*>(p);
+                    float2 hi = make_float2(0.f, 0.f);
+                    if (j0 + 2 < N) hi = *reinterpret_cast<const float2*>(p + 2);
+                    a[rr][t] = make_float4(lo.x, lo.y, hi.x, hi.y);
+                } else {
+                    a[rr][t].x = p[0];
+                    if (j0 + 1 < N) a[rr][t].y = p[1];
+                    if (j0 + 2 < N) a[rr][t].z = p[2];
+                    if (j0 + 3 < N) a[rr][t].w = p[3];
+                }
+            }
         }
     }
     if (lane < RPW) {
@@ -686,12 +701,17 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     EAGCN_CHECK_ARG(nit <= 4, "eagcn_index_build: N=%d exceeds the supported 1024 atoms", b->N);
     // streaming scan: 16-byte adjacency loads, several rows per wave, the channel gather of a wave's bonds batched over its lanes
     static const bool scan4 = [] { const char* v = getenv("EAGCN_SCAN4"); return !(v && v[0] == '0'); }();
-    if (scan4 && (Nin & 3) == 0 && (reinterpret_cast<uintptr_t>(adj) & 15) == 0) {
-#define EAGCN_SCAN4(NIT, R) index_scan4_kernel<NIT, R><<<(unsigned)((rows + 4 * R - 1) / (4 * R)), 256, 0, s>>>(adj, rp, b->B, Nin, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->ecnt, b->meta)
+    if (scan4) {
+        // widest aligned adjacency load the row stride and the base pointer allow
+        const uintptr_t ap = reinterpret_cast<uintptr_t>(adj);
+        const int al = ((Nin & 3) == 0 && (ap & 15) == 0) ? 4 : (((Nin & 1) == 0 && (ap & 7) == 0) ? 2 : 1);
+#define EAGCN_SCAN4_AL(NIT, R, AL) index_scan4_kernel<NIT, R, AL><<<(unsigned)((rows + 4 * R - 1) / (4 * R)), 256, 0, s>>>(adj, rp, b->B, Nin, b->N, b->K, b->ldc, b->code, b->deg_bn, b->nat, b->ecnt, b->meta)
+#define EAGCN_SCAN4(NIT, R) do { if (al == 4) EAGCN_SCAN4_AL(NIT, R, 4); else if (al == 2) EAGCN_SCAN4_AL(NIT, R, 2); else EAGCN_SCAN4_AL(NIT, R, 1); } while (0)
         if (Nin <= 256) EAGCN_SCAN4(1, 8);
         else if (Nin <= 512) EAGCN_SCAN4(2, 4);
         else EAGCN_SCAN4(4, 2);
 #undef EAGCN_SCAN4
+#undef EAGCN_SCAN4_AL
         EAGCN_LAUNCH_CHECK();
     } else
     {

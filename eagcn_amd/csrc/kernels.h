@@ -15,7 +15,8 @@ struct AggArgs {
     float* rscale;               // [K][T] m_i/rowsum_i: written by forward, read by transposed
     double* stats;               // forward: [grid.x][Fp][2] partial (sum y, sum y^2)
     int nchunk;
-    BxOut planes = {nullptr, 0, 0};   // transposed: dP leaves as bf16 planes INSTEAD of the fp32 matrix (only the plane GEMMs read it)
+    int xcd = 0;                 // wave-per-tile variant: tiles handed out so that an XCD works on CONTIGUOUS tiles (agg.hip)
+    BxOut planes = {nullptr, 0, 0, 0};   // transposed: dP leaves as bf16 planes INSTEAD of the fp32 matrix (only the plane GEMMs read it)
 };
 int agg_grid_x(const eagcn_batch* b);
 bool agg_ksplit(const eagcn_batch* b);

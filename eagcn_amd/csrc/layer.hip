@@ -74,7 +74,7 @@ __device__ __forceinline__ int packed_to_exact(const ColMapD& m, int cp) {
 __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const ViewCols& vc, const ColMapD& in, int ld_in,
                                                  int fp, float* __restrict__ Wcat, float* __restrict__ WcatT,
                                                  float* __restrict__ colp, float* __restrict__ sig, float* __restrict__ rsig,
-                                                 const BxOut wp = BxOut{nullptr, 0, 0}, const BxOut wtp = BxOut{nullptr, 0, 0}) {
+                                                 const BxOut wp = BxOut{nullptr, 0, 0, 0}, const BxOut wtp = BxOut{nullptr, 0, 0, 0}) {
     // 32 x 32 tiles through LDS: Wcat rows AND the rows of its transpose are written as contiguous 128-byte runs (the
     // transpose used to leave as 4-byte stores ld_in floats apart: one cache line per lane)
     __shared__ float tile[32][33];
@@ -110,9 +110,9 @@ __device__ __forceinline__ void pack_params_body(const ParamPtrs& pp, const View
         if (wp.p) {
             const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) << 2;
             if (ip0 + r < ld_in && cp0 + c4 < fp)
-                bx_store4(wp, (size_t)(ip0 + r) * fp + cp0 + c4, make_float4(tile[r][c4], tile[r][c4 + 1], tile[r][c4 + 2], tile[r][c4 + 3]));
+                bx_store4(wp, ip0 + r, cp0 + c4, make_float4(tile[r][c4], tile[r][c4 + 1], tile[r][c4 + 2], tile[r][c4 + 3]));
             if (cp0 + r < fp && ip0 + c4 < ld_in)
-                bx_store4(wtp, (size_t)(cp0 + r) * ld_in + ip0 + c4, make_float4(tile[c4][r], tile[c4 + 1][r], tile[c4 + 2][r], tile[c4 + 3][r]));
+                bx_store4(wtp, cp0 + r, ip0 + c4, make_float4(tile[c4][r], tile[c4 + 1][r], tile[c4 + 2][r], tile[c4 + 3][r]));
         }
         __syncthreads();
     }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
                 o.x *= ds[0]; o.y *= ds[1]; o.z *= ds[2]; o.w *= ds[3];
             }
             *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + c) = o;
-            if (a.planes.p) bx_store4(a.planes, (size_t)r * a.ldo + c, o);
+            if (a.planes.p) bx_store4(a.planes, r, c, o);
         }
     } else {
         // weighted sum over the views: a thread owns four adjacent output columns, the K view loads of a row are independent
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
                     acc.x += w.x * p.x; acc.y += w.y * p.y; acc.z += w.z * p.z; acc.w += w.w * p.w;
                 }
             *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + f) = acc;
-            if (a.planes.p) bx_store4(a.planes, (size_t)r * a.ldo + f, acc);
+            if (a.planes.p) bx_store4(a.planes, r, f, acc);
         }
     }
 }
@@ -744,6 +744,7 @@ struct LayerDims {
     ViewCols vc;
     int fp, ld_in, fin, ldo, gx, gxb, nsplit;
     size_t wslab;
+    size_t wpslab, wtpslab;      // plane images (bx3.h) of Wcat [ld_in rows][fp] and WcatT [fp rows][ld_in]
     int np;                      // 3 / 1: this layer's products run from bf16 operand planes (gemm_bx3.hip); 0: fp32 operands
     int bx_splits;               // ... and its weight gradient leaves as this many k-chunk slabs
 };
@@ -767,6 +768,8 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     const int tiles = cdiv(d.ld_in, 64) * cdiv(d.fp, 64);
     d.nsplit = std::max(1, std::min(std::max(1, 1024 / tiles), cdiv(std::max(b->T, 1), 128)));
     d.wslab = (size_t)d.ld_in * d.fp;
+    d.wpslab = bx_plane_elems(d.ld_in, d.fp);
+    d.wtpslab = bx_plane_elems(d.fp, d.ld_in);
     // plane GEMMs (gemm modes 3 / 4): the hidden layers (the 24-feature first layer stays on the fp32 kernels of gemm.hip)
     d.np = (d.ld_in >= 128 && (d.ld_in & 15) == 0 && (d.fp & 15) == 0) ? gemm_planes() : 0;
     // slab capacity of the weight gradient's k-chunks (how many are used is decided on the device from the actual row count:
@@ -796,8 +799,8 @@ static size_t carve_packed(void* base, const LayerDims& d, Packed* s) {
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
     t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
-    t.Wp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wslab : 1);
-    t.WTp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wslab : 1);
+    t.Wp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wpslab : 1);
+    t.WTp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wtpslab : 1);
     if (s) *s = t;
     return c.off;
 }
@@ -820,11 +823,11 @@ static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, Fw
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
     t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
-    t.Wp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wslab : 1);
-    t.WTp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wslab : 1);
+    t.Wp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wpslab : 1);
+    t.WTp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wtpslab : 1);
     t.stats = c.take<double>((size_t)d.gx * d.fp * 2);
     t.gsum = c.take<double>((size_t)2 * d.fp + 8);
-    t.xp = c.take<uint16_t>(d.np ? (size_t)d.np * std::max(b->T, 1) * d.ld_in : 1);
+    t.xp = c.take<uint16_t>(d.np ? (size_t)d.np * bx_plane_elems(b->T, d.ld_in) : 1);
     if (s) *s = t;
     return c.off;
 }
@@ -838,8 +841,8 @@ static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, Bw
     t.colp = c.take<float>((size_t)CP_ROWS * d.fp);
     t.sig = c.take<float>(EAGCN_MAX_VIEWS * 256);
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
-    t.Wp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wslab : 1);
-    t.WTp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wslab : 1);
+    t.Wp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wpslab : 1);
+    t.WTp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wtpslab : 1);
     t.dY = c.take<float>((size_t)std::max(b->T, 1) * d.fp);
     t.dP = c.take<float>((size_t)std::max(b->T, 1) * d.fp);
     t.cc = c.take<float>((size_t)2 * d.fp);
@@ -848,8 +851,8 @@ static size_t carve_bwd(void* base, const eagcn_batch* b, const LayerDims& d, Bw
     t.slab_da = c.take<double>((size_t)d.gxb * cdiv(d.fp, 1024) * EAGCN_MAX_VIEWS);
     t.datt = c.take<double>((size_t)edge_grid_x(b) * EAGCN_MAX_VIEWS * EDGE_SLAB);
     t.gsum = c.take<double>((size_t)2 * d.fp + 8);
-    t.dPp = c.take<uint16_t>(d.np ? (size_t)d.np * std::max(b->T, 1) * d.fp : 1);
-    t.xp = c.take<uint16_t>(d.np ? (size_t)d.np * std::max(b->T, 1) * d.ld_in : 1);
+    t.dPp = c.take<uint16_t>(d.np ? (size_t)d.np * bx_plane_elems(b->T, d.fp) : 1);
+    t.xp = c.take<uint16_t>(d.np ? (size_t)d.np * bx_plane_elems(b->T, d.ld_in) : 1);
     if (s) *s = t;
     return c.off;
 }
@@ -953,8 +956,8 @@ int eagcn::pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const
         jobs[l].pp = param_ptrs(b, ps[ll]); jobs[l].vc = d.vc; jobs[l].in = make_colmap(&ps[ll]->in);
         jobs[l].ld_in = d.ld_in; jobs[l].fp = d.fp;
         jobs[l].Wcat = pk.Wcat; jobs[l].WcatT = pk.WcatT; jobs[l].colp = pk.colp; jobs[l].sig = pk.sig; jobs[l].rsig = pk.rsig;
-        jobs[l].wp = BxOut{d.np ? pk.Wp : nullptr, d.wslab, d.np};
-        jobs[l].wtp = BxOut{d.np ? pk.WTp : nullptr, d.wslab, d.np};
+        jobs[l].wp = BxOut{d.np ? pk.Wp : nullptr, d.wpslab, d.np, d.ld_in};
+        jobs[l].wtp = BxOut{d.np ? pk.WTp : nullptr, d.wtpslab, d.np, d.fp};
         if (l < n) wmax = std::max(wmax, d.wslab);
     }
     PackJobs pj{jobs[0], jobs[1], jobs[2], jobs[3]};
@@ -995,8 +998,8 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
     if (!prepacked) {
         ProfScope ps(PROF_PACK, s);
         pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.WcatT, sc.colp, sc.sig, sc.rsig,
-                                                            BxOut{d.np ? sc.Wp : nullptr, d.wslab, d.np},
-                                                            BxOut{d.np ? sc.WTp : nullptr, d.wslab, d.np});
+                                                            BxOut{d.np ? sc.Wp : nullptr, d.wpslab, d.np, d.ld_in},
+                                                            BxOut{d.np ? sc.WTp : nullptr, d.wtpslab, d.np, d.fp});
     }
     EAGCN_LAUNCH_CHECK();
     // algorithmic flops of the flat transform: exact widths, packed rows
@@ -1013,14 +1016,14 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
         memset(&bp, 0, sizeof(bp));
         if (d.np) {
             // the same product from bf16 operand planes (gemm_bx3.hip): x planes from the layer below, or split here
-            const size_t xstride = (size_t)b->T * d.ld_in;
+            const size_t xstride = bx_plane_elems(b->T, d.ld_in);
             const uint16_t* xp = w->x_planes;
             if (!xp) {
-                rc = launch_bx3_split(w->x, b->T, b->meta + EAGCN_META_T, d.ld_in, sc.xp, xstride, d.np, s);
+                rc = launch_bx3_split(w->x, b->T, b->meta + EAGCN_META_T, d.ld_in, sc.xp, xstride, b->T, d.np, s);
                 if (rc) return rc;
                 xp = sc.xp;
             }
-            bp.A = BxPlanes{xp, xstride, d.ld_in}; bp.B = BxPlanes{sc.WTp, d.wslab, d.ld_in}; bp.C = w->P; bp.ldc = d.fp;
+            bp.A = BxPlanes{xp, xstride, d.ld_in, b->T}; bp.B = BxPlanes{sc.WTp, d.wtpslab, d.ld_in, d.fp}; bp.C = w->P; bp.ldc = d.fp;
             bp.M = b->T; bp.N = d.fp; bp.K = d.ld_in; bp.M_dev = b->meta + EAGCN_META_T; bp.tn = 0; bp.splits = 1;
         }
         if (d.np && bx3_ok(bp)) {
@@ -1093,7 +1096,7 @@ static int apply_launch_(const eagcn_batch* b, const eagcn_layer_params* p, cons
     aa.inv_keep = 1.0f / (1.0f - p->dropout);
     aa.seed = p->seed;
     aa.seed_dev = p->seed_dev;
-    aa.planes = BxOut{gemm_planes() ? w->xout_planes : nullptr, (size_t)b->T * d.ldo, gemm_planes()};
+    aa.planes = BxOut{gemm_planes() ? w->xout_planes : nullptr, bx_plane_elems(b->T, d.ldo), gemm_planes(), b->T};
     bn_apply_kernel<<<ew_grid((size_t)std::max(b->T, 1) * d.ldo / 4), 256, 0, s>>>(aa);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
@@ -1171,8 +1174,8 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     } else {
         ProfScope ps(PROF_PACK, s);
         pack_params_kernel<<<ew_grid(d.wslab), 256, 0, s>>>(pp, d.vc, in, d.ld_in, d.fp, sc.Wcat, sc.WcatT, sc.colp, sc.sig, sc.rsig,
-                                                            BxOut{d.np ? sc.Wp : nullptr, d.wslab, d.np},
-                                                            BxOut{d.np ? sc.WTp : nullptr, d.wslab, d.np});
+                                                            BxOut{d.np ? sc.Wp : nullptr, d.wpslab, d.np, d.ld_in},
+                                                            BxOut{d.np ? sc.WTp : nullptr, d.wtpslab, d.np, d.fp});
     }
     EAGCN_LAUNCH_CHECK();
     double fsum = 0.0;
@@ -1247,23 +1250,23 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = nullptr; a.nchunk = 1;
         // plane GEMMs (gemm_bx3.hip): dX = dP.Wcat^T (NT) and dW = X^T.dP (TN, k-chunk slabs summed by unpack_grads) in one
         // persistent launch; dP leaves the transposed aggregation as bf16 planes and is never written as fp32
-        const size_t xstride = (size_t)b->T * d.ld_in, pstride = (size_t)b->T * d.fp;
+        const size_t xstride = bx_plane_elems(b->T, d.ld_in), pstride = bx_plane_elems(b->T, d.fp);
         BxProb bx, bw;
         memset(&bx, 0, sizeof(bx));
         memset(&bw, 0, sizeof(bw));
         bool use_bx = false;
         if (d.np && !w->aux_stream) {
-            bx.A = BxPlanes{sc.dPp, pstride, d.fp}; bx.B = BxPlanes{sc.Wp, d.wslab, d.fp}; bx.C = dx; bx.ldc = d.ld_in;
+            bx.A = BxPlanes{sc.dPp, pstride, d.fp, b->T}; bx.B = BxPlanes{sc.Wp, d.wpslab, d.fp, d.ld_in}; bx.C = dx; bx.ldc = d.ld_in;
             bx.M = b->T; bx.N = d.ld_in; bx.K = d.fp; bx.M_dev = b->meta + EAGCN_META_T; bx.tn = 0; bx.splits = 1;
-            bw.A = BxPlanes{w->x_planes ? w->x_planes : sc.xp, xstride, d.ld_in}; bw.B = BxPlanes{sc.dPp, pstride, d.fp};
+            bw.A = BxPlanes{w->x_planes ? w->x_planes : sc.xp, xstride, d.ld_in, b->T}; bw.B = BxPlanes{sc.dPp, pstride, d.fp, b->T};
             bw.C = sc.dWcat; bw.ldc = d.fp; bw.M = d.ld_in; bw.N = d.fp; bw.K = b->T; bw.K_dev = b->meta + EAGCN_META_T; bw.tn = 1;
             bw.splits = d.bx_splits; bw.slab = d.wslab;
             use_bx = bx3_ok(bw) && (!dx || bx3_ok(bx));
         }
         if (use_bx) {
-            a.planes = BxOut{sc.dPp, pstride, d.np};
+            a.planes = BxOut{sc.dPp, pstride, d.np, b->T};
             if (!w->x_planes) {
-                rc = launch_bx3_split(w->x, b->T, b->meta + EAGCN_META_T, d.ld_in, sc.xp, xstride, d.np, s);
+                rc = launch_bx3_split(w->x, b->T, b->meta + EAGCN_META_T, d.ld_in, sc.xp, xstride, b->T, d.np, s);
                 if (rc) return rc;
             }
         }

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void sagg_kernel(AggArgs a) {
                     y.w = acc[q].w + rs * self[q].w + TINY * (S.w - bs[q].w);
                 }
                 if (col_ok) {
-                    if (TRANS && a.planes.p) bx_store4(a.planes, (size_t)row * a.ldd + c0, y);
+                    if (TRANS && a.planes.p) bx_store4(a.planes, row, c0, y);
                     else *reinterpret_cast<float4*>(a.dst + (size_t)row * a.ldd + c0) = y;
                 }
             }

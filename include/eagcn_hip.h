@@ -418,21 +418,27 @@ int eagcn_eval_append(const float* logits, const float* labels, int B, int T, in
 int eagcn_set_gemm_mode(int mode);
 
 /* ---- the plane GEMM of modes 3 / 4 as stand-alone entry points (tests, tools/bx3_bench.cpp) -----------------------------
- * planes of a row-major fp32 matrix [rows][ld]: np = 3: x = x0 + x1 + x2 exactly (each piece the bf16 nearest to what the
- * pieces before it left over), np = 1: round to nearest even; plane q at planes + q * plane_stride (elements) */
-int eagcn_bx3_split(const float* x, int rows, int ld, uint16_t* planes, size_t plane_stride, int np, void* stream);
-/* tn = 0: C[M,N] = A[M,K].B[N,K]^T (planes of A [M][lda] and B [N][ldb], K a multiple of 8);
- * tn = 1: C[M,N] = A[K,M]^T.B[K,N] (planes [K][lda], [K][ldb]) as k-chunk slabs C + z * slab, z < eagcn_bx3_used_splits(splits, M, N, K)
- *         (at least 768 and at most 4096 rows of K per chunk; slabs beyond that count are NOT written), whose sum is the product.
- * lda / ldb multiples of 8, planes 16-byte aligned. */
+ * PLANE IMAGE of a matrix with `rows_cap` rows and ld columns (ld a multiple of 8): the columns are cut into panels of 32, a panel
+ * holds the rows_cap rows of its 32 columns at 64 bytes per row, and the four 16-byte chunks of a row are XOR-swizzled by the row:
+ *     element (r, c) at  ((c >> 5) * rows_cap + r) * 32 + ((((c >> 3) & 3) ^ ((r >> 2) & 3)) << 3) + (c & 7)      [bf16 elements]
+ * (the layout the GEMM's LDS-DMA copies verbatim: every 1 KB it moves is contiguous); eagcn_bx3_plane_elems(rows_cap, ld) elements.
+ * eagcn_bx3_split writes the images of a row-major fp32 matrix [rows][ld], rows <= rows_cap: np = 3: x = x0 + x1 + x2 exactly (each
+ * piece the bf16 nearest to what the pieces before it left over), np = 1: round to nearest even; plane q at planes + q *
+ * plane_stride (elements, >= eagcn_bx3_plane_elems, a multiple of 8); planes 16-byte aligned. */
+size_t eagcn_bx3_plane_elems(int rows_cap, int ld);
+int eagcn_bx3_split(const float* x, int rows, int ld, uint16_t* planes, size_t plane_stride, int rows_cap, int np, void* stream);
+/* tn = 0: C[M,N] = A[M,K].B[N,K]^T (images of A [a_rows >= M][lda >= K] and B [b_rows >= N][ldb >= K], K a multiple of 8);
+ * tn = 1: C[M,N] = A[K,M]^T.B[K,N] (images [a_rows >= K][lda >= M], [b_rows >= K][ldb >= N]) as k-chunk slabs C + z * slab,
+ *         z < eagcn_bx3_used_splits(splits, M, N, K) (at least 768 and at most 4096 rows of K per chunk; slabs beyond that count are
+ *         NOT written), whose sum is the product. */
 int eagcn_bx3_used_splits(int splits, int M, int N, int K);
-int eagcn_gemm_bx3(int tn, int M, int N, int K, const uint16_t* A, size_t a_pstride, int lda, const uint16_t* B,
-                   size_t b_pstride, int ldb, float* C, int ldc, int splits, size_t slab, int np, void* stream);
+int eagcn_gemm_bx3(int tn, int M, int N, int K, const uint16_t* A, size_t a_pstride, int lda, int a_rows, const uint16_t* B,
+                   size_t b_pstride, int ldb, int b_rows, float* C, int ldc, int splits, size_t slab, int np, void* stream);
 /* an NT product and a TN product (the dX / dW pair of a layer's backward) in ONE persistent launch */
-int eagcn_gemm_bx3_pair(int M0, int N0, int K0, const uint16_t* A0, size_t a0_pstride, int lda0, const uint16_t* B0,
-                        size_t b0_pstride, int ldb0, float* C0, int ldc0, int M1, int N1, int K1, const uint16_t* A1,
-                        size_t a1_pstride, int lda1, const uint16_t* B1, size_t b1_pstride, int ldb1, float* C1, int ldc1,
-                        int splits, size_t slab, int np, void* stream);
+int eagcn_gemm_bx3_pair(int M0, int N0, int K0, const uint16_t* A0, size_t a0_pstride, int lda0, int a0_rows, const uint16_t* B0,
+                        size_t b0_pstride, int ldb0, int b0_rows, float* C0, int ldc0, int M1, int N1, int K1, const uint16_t* A1,
+                        size_t a1_pstride, int lda1, int a1_rows, const uint16_t* B1, size_t b1_pstride, int ldb1, int b1_rows,
+                        float* C1, int ldc1, int splits, size_t slab, int np, void* stream);
 
 /* ---- plain fp32 MFMA GEMM (head / tests) ------------------------------------------------------ */
 /* C[M,N] = op(A).op(B); ta/tb: 0 = as stored, 1 = transposed; leading dimensions in floats */

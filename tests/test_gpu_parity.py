@@ -28,7 +28,10 @@ def _hip_model(meta, n_layers=4):
 # float64 gradient as the fp32 reference is (ratio <= 1).  A tensor regressing beyond its entry fails its test.
 KNOWN_FARTHER = {
     # both evaluations of a 28-row BatchNorm four layers deep: 1.7e-5 vs 5.0e-6 of the tensor's own max (measured ratio 3.65)
-    'model_concate_isolated': {'layer2.block4.batch_norm.bn.weight': 4.0},
+    # (round 3 held this WHOLE case to 4x; the tensors beyond 1x, each with its measured ratio x 1.1 -- layer widths 27 / 32: the
+    #  fp32-MFMA products, not the plane GEMMs)
+    'model_concate_isolated': {'layer2.block4.batch_norm.bn.weight': 4.0, 'layer2.block4.graph_conv.weight': 1.3,
+                               'layer3.block1.graph_conv.weight': 1.6, 'layer4.block1.batch_norm.bn.bias': 1.9},
     # a view whose BatchNorm sees 3 x 270 rows: 1.4e-3 vs 4.2e-4 (measured ratio 3.3)
     'tox21_shape[Concate-2-3-270]': {'layer2.block4.graph_conv.weight': 3.7},
 }
