@@ -183,11 +183,12 @@ typedef struct eagcn_layer_bufs {
     eagcn_allreduce_fn stats_hook;          /* sync-BatchNorm: cross-rank sum of the BatchNorm partial sums (NULL: local-BN) */
     void* stats_user;
     /* bf16 plane images (gemm mode 3 / 4, csrc/gemm_bx3.hip: the layer products run on the bf16 matrix cores from operands    */
-    /* their producers already split): x_planes = the planes of x ([planes][T][ld_in] bf16, plane stride T * ld_in; three planes */
-    /* in mode 3, one in mode 4), written by the layer below through ITS xout_planes; NULL: the layer splits x itself (one more  */
-    /* launch) / does not write them.  Ignored in the fp32 modes and for layers narrower than 128 input columns.                */
+    /* their producers already split): x_planes = the plane images of x (panel-major images of row capacity eagcn_batch.T and   */
+    /* ld_in columns, plane stride eagcn_bx3_plane_elems(T, ld_in) -- layout below at eagcn_bx3_split; three planes in mode 3,   */
+    /* one in mode 4), written by the layer below through ITS xout_planes; NULL: the layer splits x itself (one more launch) /   */
+    /* does not write them.  Ignored in the fp32 modes and for layers narrower than 128 input columns.                          */
     const uint16_t* x_planes;
-    uint16_t* xout_planes;                  /* [planes][T][ld_out]                                                            */
+    uint16_t* xout_planes;                  /* [planes] images of [T rows][ld_out], stride eagcn_bx3_plane_elems(T, ld_out)    */
 } eagcn_layer_bufs;
 
 typedef struct eagcn_layer_grads {

@@ -16,14 +16,24 @@ def _lib():
     return L.load(), L
 
 
-def _planes(x, np_=3):
-    """bf16 planes of a contiguous fp32 CUDA matrix [R, ld] -> (int16 tensor [np, R * ld padded], plane stride)."""
+def _planes(x, np_=3, spare_rows=5):
+    """Plane images (panel-major, include/eagcn_hip.h) of a contiguous fp32 CUDA matrix [R, ld] -> (int16 tensor, plane stride, row
+    capacity).  The images are pre-filled with bf16 NaNs and given a few spare rows: whatever the split does not write (spare rows,
+    the columns between ld and the end of the last 32-column panel) must never reach a stored result."""
     lib, L = _lib()
     R, ld = x.shape
-    stride = (R * ld + 63) // 64 * 64
-    pl = torch.zeros(np_ * stride, dtype=torch.int16, device='cuda')
-    L.check(lib.eagcn_bx3_split(C.c_void_p(x.data_ptr()), R, ld, C.c_void_p(pl.data_ptr()), stride, np_, None), 'eagcn_bx3_split')
-    return pl, stride
+    cap = R + spare_rows
+    stride = (int(lib.eagcn_bx3_plane_elems(cap, ld)) + 63) // 64 * 64
+    pl = torch.full((np_ * stride,), 0x7FC0, dtype=torch.int16, device='cuda')
+    L.check(lib.eagcn_bx3_split(C.c_void_p(x.data_ptr()), R, ld, C.c_void_p(pl.data_ptr()), stride, cap, np_, None), 'eagcn_bx3_split')
+    return pl, stride, cap
+
+
+def _image_index(R, ld, cap):
+    """element index of (r, c) inside a plane image (the formula of include/eagcn_hip.h), as an [R, ld] LongTensor"""
+    r = torch.arange(R, device='cuda').view(-1, 1)
+    c = torch.arange(ld, device='cuda').view(1, -1)
+    return ((c >> 5) * cap + r) * 32 + ((((c >> 3) & 3) ^ ((r >> 2) & 3)) << 3) + (c & 7)
 
 
 def _bf16_to_f32(p):
@@ -34,23 +44,27 @@ def test_split_is_exact():
     torch.manual_seed(0)
     x = torch.randn(37, 64, device='cuda') * torch.logspace(-20, 20, 64, device='cuda')
     x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1.17549435e-38, 2.0 ** -100], device='cuda')
-    pl, stride = _planes(x)
-    parts = [_bf16_to_f32(pl[q * stride:q * stride + x.numel()]).view_as(x).double() for q in range(3)]
+    pl, stride, cap = _planes(x)
+    idx = _image_index(x.shape[0], x.shape[1], cap)
+    parts = [_bf16_to_f32(pl[q * stride:(q + 1) * stride][idx]).double() for q in range(3)]
     assert torch.equal((parts[0] + parts[1] + parts[2]).float(), x), 'x0 + x1 + x2 must reproduce x bit for bit'
     # every piece is the bf16 nearest to what is left: |x1| <= 2^-8 |x0|, |x2| <= 2^-8 |x1|
     assert (parts[1].abs() <= parts[0].abs() * 2.0 ** -8 + 1e-300).all() and (parts[2].abs() <= parts[1].abs() * 2.0 ** -8 + 1e-300).all()
-    one, _ = _planes(x, 1)
-    assert torch.equal(_bf16_to_f32(one[:x.numel()]).view_as(x), x.to(torch.bfloat16).float())      # round to nearest even
+    one, _, cap1 = _planes(x, 1)
+    assert torch.equal(_bf16_to_f32(one[_image_index(x.shape[0], x.shape[1], cap1)]), x.to(torch.bfloat16).float())      # round to nearest even
+    written = torch.zeros(one.numel(), dtype=torch.bool, device='cuda')
+    written[_image_index(x.shape[0], x.shape[1], cap1).reshape(-1)] = True
+    assert (one[~written] == 0x7FC0).all(), 'the split writes the elements of the matrix and nothing else'
 
 
 def _gemm(tn, A, B, M, N, K, splits=1):
     lib, L = _lib()
-    pa, sa = _planes(A)
-    pb, sb = _planes(B)
+    pa, sa, ra = _planes(A)
+    pb, sb, rb = _planes(B)
     ldc = (N + 3) // 4 * 4
     slab = M * ldc
     Cm = torch.full((max(splits, 1) * slab,), float('nan'), device='cuda')
-    L.check(lib.eagcn_gemm_bx3(tn, M, N, K, C.c_void_p(pa.data_ptr()), sa, A.shape[1], C.c_void_p(pb.data_ptr()), sb, B.shape[1],
+    L.check(lib.eagcn_gemm_bx3(tn, M, N, K, C.c_void_p(pa.data_ptr()), sa, A.shape[1], ra, C.c_void_p(pb.data_ptr()), sb, B.shape[1], rb,
                                C.c_void_p(Cm.data_ptr()), ldc, splits, slab, 3, None), 'eagcn_gemm_bx3')
     used = lib.eagcn_bx3_used_splits(splits, M, N, K) if tn else 1
     return Cm.view(max(splits, 1), M, ldc)[:used, :, :N].double().sum(0), Cm.view(max(splits, 1), M, ldc)
@@ -103,13 +117,13 @@ def test_pair_launch_equals_the_two_products():
     W = torch.randn(FIN, FP, device='cuda') * 0.05
     dx_ref, _ = _gemm(0, dP, W, T, FIN, FP)
     dw_ref, _ = _gemm(1, X, dP, FIN, FP, T, splits)
-    px, sx = _planes(X)
-    pp, sp = _planes(dP)
-    pw, sw = _planes(W)
+    px, sx, rx = _planes(X)
+    pp, sp, rp = _planes(dP)
+    pw, sw, rw = _planes(W)
     dX = torch.zeros(T, FIN, device='cuda')
     dW = torch.zeros(splits, FIN, FP, device='cuda')
-    L.check(lib.eagcn_gemm_bx3_pair(T, FIN, FP, C.c_void_p(pp.data_ptr()), sp, FP, C.c_void_p(pw.data_ptr()), sw, FP, C.c_void_p(dX.data_ptr()), FIN,
-                                    FIN, FP, T, C.c_void_p(px.data_ptr()), sx, FIN, C.c_void_p(pp.data_ptr()), sp, FP, C.c_void_p(dW.data_ptr()), FP,
+    L.check(lib.eagcn_gemm_bx3_pair(T, FIN, FP, C.c_void_p(pp.data_ptr()), sp, FP, rp, C.c_void_p(pw.data_ptr()), sw, FP, rw, C.c_void_p(dX.data_ptr()), FIN,
+                                    FIN, FP, T, C.c_void_p(px.data_ptr()), sx, FIN, rx, C.c_void_p(pp.data_ptr()), sp, FP, rp, C.c_void_p(dW.data_ptr()), FP,
                                     splits, FIN * FP, 3, None), 'eagcn_gemm_bx3_pair')
     used = lib.eagcn_bx3_used_splits(splits, FIN, FP, T)
     assert torch.equal(dX.double(), dx_ref) and torch.equal(dW[:used].double().sum(0), dw_ref), 'a unit computes the same bits in either launch'

@@ -27,15 +27,18 @@ struct Mat {
     float* d = nullptr;
     uint16_t* pl = nullptr;
     size_t pstride = 0;
+    int cap = 0;                 // row capacity of the plane images
     Mat(int r, int c, int ld_, float scale = 1.0f, int extra_rows = 0) : rows(r), cols(c), ld(ld_), h((size_t)(r + extra_rows) * ld_, 0.f) {
         for (int i = 0; i < r; ++i) for (int j = 0; j < c; ++j) h[(size_t)i * ld + j] = scale * frand();
         // rows beyond `rows` (capacity) and columns beyond `cols` hold NaN-free garbage that must never reach a result
         for (int i = r; i < r + extra_rows; ++i) for (int j = 0; j < ld; ++j) h[(size_t)i * ld + j] = 1.0e30f;
         CK(hipMalloc(&d, h.size() * 4));
         CK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-        pstride = ((h.size() + 63) / 64) * 64;
+        cap = r + extra_rows;
+        pstride = ((eagcn_bx3_plane_elems(cap, ld) + 63) / 64) * 64;
         CK(hipMalloc(&pl, 3 * pstride * 2));
-        RC(eagcn_bx3_split(d, r + extra_rows, ld, pl, pstride, 3, nullptr));
+        CK(hipMemset(pl, 0x7F, 3 * pstride * 2));          // (bf16 NaNs wherever the split does not write)
+        RC(eagcn_bx3_split(d, r + extra_rows, ld, pl, pstride, cap, 3, nullptr));
     }
     ~Mat() { (void)hipFree(d); (void)hipFree(pl); }
 };
@@ -78,7 +81,7 @@ static void check_nt(int M, int N, int K, int cap_extra) {
     int* dM; CK(hipMalloc(&dM, 4)); CK(hipMemcpy(dM, &M, 4, hipMemcpyHostToDevice));
     // capacity-sized call with the device-side row count is what the model engine issues; the C entry takes static extents, so
     // run it with the exact M (rows beyond are then never touched) ...
-    RC(eagcn_gemm_bx3(0, M, N, K, A.pl, A.pstride, lda, B.pl, B.pstride, ldb, dC, ldc, 1, 0, 3, nullptr));
+    RC(eagcn_gemm_bx3(0, M, N, K, A.pl, A.pstride, lda, A.cap, B.pl, B.pstride, ldb, B.cap, dC, ldc, 1, 0, 3, nullptr));
     CK(hipDeviceSynchronize());
     std::vector<float> C((size_t)M * ldc);
     CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
@@ -106,7 +109,7 @@ static void check_tn(int M, int N, int K, int splits, int cap_extra) {
     const size_t slab = (size_t)M * ldc;
     float* dC; CK(hipMalloc(&dC, slab * splits * 4));
     CK(hipMemset(dC, 0, slab * splits * 4));          // (chunks beyond bx3_used_splits are not written)
-    RC(eagcn_gemm_bx3(1, M, N, K, A.pl, A.pstride, lda, B.pl, B.pstride, ldb, dC, ldc, splits, slab, 3, nullptr));
+    RC(eagcn_gemm_bx3(1, M, N, K, A.pl, A.pstride, lda, A.cap, B.pl, B.pstride, ldb, B.cap, dC, ldc, splits, slab, 3, nullptr));
     CK(hipDeviceSynchronize());
     std::vector<float> Cs(slab * splits), C(slab, 0.f);
     CK(hipMemcpy(Cs.data(), dC, Cs.size() * 4, hipMemcpyDeviceToHost));
@@ -144,16 +147,16 @@ static void time_layer(const char* name, int T, int FIN, int FP, int iters) {
     const double f1 = 2.0 * T * FIN * FP;
     float t;
     printf("%s: T=%d F_in=%d Fp=%d (dW k-chunks used: %d)\n", name, T, FIN, FP, eagcn_bx3_used_splits(splits, FIN, FP, T));
-    t = time_fn(iters, [&] { RC(eagcn_gemm_bx3(0, T, FP, FIN, X.pl, X.pstride, FIN, WT.pl, WT.pstride, FIN, P, FP, 1, 0, 3, nullptr)); });
+    t = time_fn(iters, [&] { RC(eagcn_gemm_bx3(0, T, FP, FIN, X.pl, X.pstride, FIN, X.cap, WT.pl, WT.pstride, FIN, WT.cap, P, FP, 1, 0, 3, nullptr)); });
     printf("  forward   bx3 %8.1f us  %6.1f TF", t, f1 / t * 1e-6);
     t = time_fn(iters, [&] { RC(eagcn_gemm_f32_sk(0, 1, T, FP, FIN, X.d, FIN, WT.d, FIN, P, FP, ws, wsb, nullptr)); });
     printf("   | fp32 MFMA %8.1f us  %6.1f TF\n", t, f1 / t * 1e-6);
-    t = time_fn(iters, [&] { RC(eagcn_gemm_bx3(0, T, FIN, FP, dP.pl, dP.pstride, FP, W.pl, W.pstride, FP, dX, FIN, 1, 0, 3, nullptr)); });
+    t = time_fn(iters, [&] { RC(eagcn_gemm_bx3(0, T, FIN, FP, dP.pl, dP.pstride, FP, dP.cap, W.pl, W.pstride, FP, W.cap, dX, FIN, 1, 0, 3, nullptr)); });
     printf("  dX        bx3 %8.1f us  %6.1f TF\n", t, f1 / t * 1e-6);
-    t = time_fn(iters, [&] { RC(eagcn_gemm_bx3(1, FIN, FP, T, X.pl, X.pstride, FIN, dP.pl, dP.pstride, FP, dW, FP, splits, slab, 3, nullptr)); });
+    t = time_fn(iters, [&] { RC(eagcn_gemm_bx3(1, FIN, FP, T, X.pl, X.pstride, FIN, X.cap, dP.pl, dP.pstride, FP, dP.cap, dW, FP, splits, slab, 3, nullptr)); });
     printf("  dW        bx3 %8.1f us  %6.1f TF\n", t, f1 / t * 1e-6);
-    t = time_fn(iters, [&] { RC(eagcn_gemm_bx3_pair(T, FIN, FP, dP.pl, dP.pstride, FP, W.pl, W.pstride, FP, dX, FIN, FIN, FP, T, X.pl, X.pstride, FIN, dP.pl,
-                                                    dP.pstride, FP, dW, FP, splits, slab, 3, nullptr)); });
+    t = time_fn(iters, [&] { RC(eagcn_gemm_bx3_pair(T, FIN, FP, dP.pl, dP.pstride, FP, dP.cap, W.pl, W.pstride, FP, W.cap, dX, FIN, FIN, FP, T, X.pl, X.pstride, FIN, X.cap, dP.pl,
+                                                    dP.pstride, FP, dP.cap, dW, FP, splits, slab, 3, nullptr)); });
     printf("  dX + dW   bx3 %8.1f us  %6.1f TF", t, 2 * f1 / t * 1e-6);
     t = time_fn(iters, [&] { RC(eagcn_gemm_pair_sk(T, FIN, FP, dP.d, FP, W.d, FP, dX, FIN, FIN, FP, T, X.d, FIN, dP.d, FP, dW, FP, ws, wsb, nullptr)); });
     printf("   | fp32 MFMA %8.1f us  %6.1f TF\n", t, 2 * f1 / t * 1e-6);
@@ -169,13 +172,13 @@ static void bias_test(int K) {
     for (auto& v : B.h) v = fabsf(v);
     CK(hipMemcpy(A.d, A.h.data(), A.h.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(B.d, B.h.data(), B.h.size() * 4, hipMemcpyHostToDevice));
-    RC(eagcn_bx3_split(A.d, K, lda, A.pl, A.pstride, 3, nullptr));
-    RC(eagcn_bx3_split(B.d, K, ldb, B.pl, B.pstride, 3, nullptr));
+    RC(eagcn_bx3_split(A.d, K, lda, A.pl, A.pstride, A.cap, 3, nullptr));
+    RC(eagcn_bx3_split(B.d, K, ldb, B.pl, B.pstride, B.cap, 3, nullptr));
     float *dC, *dC2; CK(hipMalloc(&dC, M * ldc * 4)); CK(hipMalloc(&dC2, M * ldc * 4));
     size_t wsb = eagcn_gemm_sk_workspace_bytes();
     void* ws; CK(hipMalloc(&ws, wsb));
     CK(hipMemset(dC, 0, M * ldc * 4));
-    RC(eagcn_gemm_bx3(1, M, N, K, A.pl, A.pstride, lda, B.pl, B.pstride, ldb, dC, ldc, 1, (size_t)M * ldc, 3, nullptr));
+    RC(eagcn_gemm_bx3(1, M, N, K, A.pl, A.pstride, lda, A.cap, B.pl, B.pstride, ldb, B.cap, dC, ldc, 1, (size_t)M * ldc, 3, nullptr));
     RC(eagcn_gemm_f32_sk(1, 0, M, N, K, A.d, lda, B.d, ldb, dC2, ldc, ws, wsb, nullptr));
     CK(hipDeviceSynchronize());
     std::vector<float> C(M * ldc), C2(M * ldc);
@@ -200,13 +203,13 @@ static void cancel_test(int K, float spread) {
     for (int j = 0; j < N; ++j) { double m = 0; for (int k = 0; k < K; ++k) m += B.h[(size_t)k * ldb + j]; m /= K; for (int k = 0; k < K; ++k) B.h[(size_t)k * ldb + j] -= (float)m; }
     CK(hipMemcpy(A.d, A.h.data(), A.h.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(B.d, B.h.data(), B.h.size() * 4, hipMemcpyHostToDevice));
-    RC(eagcn_bx3_split(A.d, K, lda, A.pl, A.pstride, 3, nullptr));
-    RC(eagcn_bx3_split(B.d, K, ldb, B.pl, B.pstride, 3, nullptr));
+    RC(eagcn_bx3_split(A.d, K, lda, A.pl, A.pstride, A.cap, 3, nullptr));
+    RC(eagcn_bx3_split(B.d, K, ldb, B.pl, B.pstride, B.cap, 3, nullptr));
     float *dC, *dC2; CK(hipMalloc(&dC, M * ldc * 4)); CK(hipMalloc(&dC2, M * ldc * 4));
     size_t wsb = eagcn_gemm_sk_workspace_bytes();
     void* ws; CK(hipMalloc(&ws, wsb));
     CK(hipMemset(dC, 0, M * ldc * 4));
-    RC(eagcn_gemm_bx3(1, M, N, K, A.pl, A.pstride, lda, B.pl, B.pstride, ldb, dC, ldc, 1, (size_t)M * ldc, 3, nullptr));
+    RC(eagcn_gemm_bx3(1, M, N, K, A.pl, A.pstride, lda, A.cap, B.pl, B.pstride, ldb, B.cap, dC, ldc, 1, (size_t)M * ldc, 3, nullptr));
     RC(eagcn_gemm_f32_sk(1, 0, M, N, K, A.d, lda, B.d, ldb, dC2, ldc, ws, wsb, nullptr));
     CK(hipDeviceSynchronize());
     std::vector<float> C(M * ldc), C2(M * ldc);
