@@ -131,6 +131,7 @@ SIGNATURES = {
     'eagcn_adam_step': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     'eagcn_agg_wants_bond_lists': (C.c_int, [C.c_int, C.c_int]),
     'eagcn_bx3_used_splits': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'eagcn_bx3_pair_used_splits': (C.c_int, [C.c_int] * 7),
     'eagcn_bx3_plane_elems': (C.c_size_t, [C.c_int, C.c_int]),
     'eagcn_bx3_split': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_size_t, C.c_int, C.c_int, _fp]),
     'eagcn_gemm_bx3': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, C.c_int, C.c_int, _fp, C.c_size_t, C.c_int, C.c_int,

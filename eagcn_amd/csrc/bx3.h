@@ -87,18 +87,41 @@ struct BxProb {
     int splits; size_t slab;     // TN: k-chunk z goes to C + z * slab
 };
 // k-chunk slabs a split-K (TN) product of actual reduction length K over `tiles` output tiles really writes -- shared by the
-// kernel and by whoever sums the slabs (layer.hip unpack_grads); the host sizes the slab buffer (`cap`) for a CAPACITY:
-//   * enough chunks to give every CU about two work units, but none shorter than 24 k-tiles (768 rows: about the length of a
-//     dX tile of the same launch, and few enough slabs that summing them stays cheap);
+// kernel and by whoever sums the slabs (layer.hip unpack_grads); the host sizes the slab buffer (`cap`) for a CAPACITY.
+// Alone in its launch:
+//   * enough chunks to give every CU about two work units, but none shorter than 24 k-tiles (768 rows: few enough slabs that
+//     summing them stays cheap);
 //   * never longer than 4096 rows (accumulation chains of gemm_bx3.hip: the bf16 MFMA accumulate drifts).
-__host__ __device__ inline int bx3_used_splits(int cap, int K, int tiles) {
+// Paired with an NT product of `ou` units of `okt` k-tiles each (the dX of the same layer; gemm_bx3.hip hands the units of both
+// problems to the `per` workgroups of an XCD round-robin, the k-chunks first): the chunk count that minimises the LONGEST run of
+// k-tiles any workgroup gets under that hand-out (chunks of at least 8 k-tiles, at most 4096 rows) -- at 4809 rows the fixed
+// policy gave 5 of 32 workgroups a 25-k-tile chunk AND a 23-k-tile dX tile while 14 had 23.
+__host__ __device__ inline int bx3_used_splits(int cap, int K, int tiles, int ou = 0, int okt = 0, int per = 32) {
     const int kt = K > 32 ? (K + 31) / 32 : 1;
-    const int fill = (512 + tiles - 1) / (tiles > 0 ? tiles : 1), len = kt / 24;
-    int s = fill < len ? fill : len;
     const int drift = (K + 4095) / 4096;
-    s = s > drift ? s : drift;
-    s = s < cap ? s : cap;
-    return s > 1 ? s : 1;
+    if (tiles < 1) tiles = 1;
+    if (ou <= 0 || per <= 0) {
+        const int fill = (512 + tiles - 1) / tiles, len = kt / 24;
+        int s = fill < len ? fill : len;
+        s = s > drift ? s : drift;
+        s = s < cap ? s : cap;
+        return s > 1 ? s : 1;
+    }
+    int smin = drift > 1 ? drift : 1, smax = kt / 8;
+    smin = smin < cap ? smin : cap;
+    smax = smax < cap ? smax : cap;
+    smax = smax > smin ? smax : smin;
+    const int n0x = (ou + 7) >> 3, b = n0x / per, q = n0x % per;
+    int best = smin;
+    long best_cost = -1;
+    for (int s = smin; s <= smax; ++s) {
+        const int c1 = (kt + s - 1) / s, n1x = (tiles * s + 7) >> 3, a = n1x / per, r = n1x % per;
+        const long l1 = r > 0 ? (long)(a + 1) * c1 + (long)(b + (q > per - r ? 1 : 0)) * okt : 0;
+        const long l2 = (long)a * c1 + (long)(b + (q > 0 ? 1 : 0)) * okt;
+        const long cost = 8 * (l1 > l2 ? l1 : l2) + s;          // (ties and near-ties: fewer slabs)
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
 }
 bool bx3_ok(const BxProb& p);
 int bx3_grid();

@@ -52,7 +52,7 @@ typedef __attribute__((address_space(3))) void* bx_lds_ptr;
 
 constexpr int BX_BK = 32;
 constexpr int BX_NC = 4;                     // compute waves: 2 x 2, one 64 x 64 accumulator block each (one per SIMD)
-constexpr int BX_NL = 2;                     // loader waves (four measured the same: the fill is bound by the 64-byte row segments of the NT image, profiles/r04_lds_fill_probe.txt)
+constexpr int BX_NL = 4;                     // loader waves (four measured the same: the fill is bound by the 64-byte row segments of the NT image, profiles/r04_lds_fill_probe.txt)
 constexpr int BX_BM = 128, BX_BN = 128;
 constexpr int BX_APL = BX_BM * 64, BX_BPL = BX_BN * 64;          // bytes of one plane image of a k-tile
 constexpr int BX_STAGE = 3 * (BX_APL + BX_BPL);                  // 48 KB
@@ -75,14 +75,14 @@ __device__ __forceinline__ void bx_wait_vm() {
 struct BxUnits { int tiles_m, tiles_n, splits, kt_total, kt_per; int n; };
 __device__ __forceinline__ int bx_mx(const BxProb& p) { return (!p.tn && p.M_dev) ? min(*p.M_dev, p.M) : p.M; }
 __device__ __forceinline__ int bx_kx(const BxProb& p) { return (p.tn && p.K_dev) ? min(*p.K_dev, p.K) : p.K; }
-__device__ __forceinline__ BxUnits bx_units(const BxProb& p, int Mx, int Kx) {
+__device__ __forceinline__ BxUnits bx_units(const BxProb& p, int Mx, int Kx, int ou = 0, int okt = 0) {
     BxUnits u;
     u.tiles_m = (Mx + BX_BM - 1) / BX_BM;
     u.tiles_n = (p.N + BX_BN - 1) / BX_BN;
     u.kt_total = max(1, (Kx + BX_BK - 1) / BX_BK);
     // TN: the k-tiles are spread over bx3_used_splits() chunks (bx3.h; capacity-sized launches: the actual K may be a fraction of the
     // capacity the host sized `splits` for); only those slabs are written, and the consumer sums only those
-    u.splits = p.tn ? bx3_used_splits(max(1, p.splits), Kx, u.tiles_m * u.tiles_n) : 1;
+    u.splits = p.tn ? bx3_used_splits(max(1, p.splits), Kx, u.tiles_m * u.tiles_n, ou, okt, max(1, (int)gridDim.x >> 3)) : 1;
     u.kt_per = (u.kt_total + u.splits - 1) / u.splits;
     u.n = u.tiles_m * u.tiles_n * u.splits;
     return u;
@@ -386,10 +386,10 @@ __device__ __forceinline__ void bx_compute(const BxProb& p, const BxStream& st, 
 
 // XCD x (dispatch slot b runs on XCD b % 8) owns the contiguous units [x n / 8, (x + 1) n / 8) of a problem; its workgroups take
 // them round-robin, starting at slot `rot` (the workgroups that drew one unit more of the first problem draw one less of the second)
-__device__ __forceinline__ BxStream bx_stream(const BxProb& p, int rot, int& rot_out) {
+__device__ __forceinline__ BxStream bx_stream(const BxProb& p, int rot, int& rot_out, int ou = 0, int okt = 0) {
     BxStream st;
     st.Mx = bx_mx(p); st.Kx = bx_kx(p);
-    st.u = bx_units(p, st.Mx, st.Kx);
+    st.u = bx_units(p, st.Mx, st.Kx, ou, okt);
     const int xcd = blockIdx.x & 7, per = max(1, (int)gridDim.x >> 3);
     const int slot = (((int)blockIdx.x >> 3) - rot % per + per) % per;
     const int lo = (int)(((long)st.u.n * xcd) >> 3), hi = (int)(((long)st.u.n * (xcd + 1)) >> 3);
@@ -407,7 +407,12 @@ __global__ __launch_bounds__(64 * (BX_NC + BX_NL), 2) void bx3_kernel(BxProb p0,
     // the HEAVIER units first (longest-processing-time order inside a workgroup's run): the k-chunks of a dW before the dX tiles
     for (int pass = 0; pass < (has1 ? 2 : 1); ++pass) {
         const BxProb& p = (has1 && pass == 0) ? p1 : p0;
-        const BxStream st = bx_stream(p, rot, rot1);
+        int ou = 0, okt = 0;                           // the split-K problem of a pair sizes its chunks against the NT problem's units
+        if (has1 && pass == 0 && p1.tn && !p0.tn) {
+            const BxUnits u0 = bx_units(p0, bx_mx(p0), bx_kx(p0));
+            ou = u0.n; okt = u0.kt_total;
+        }
+        const BxStream st = bx_stream(p, rot, rot1, ou, okt);
         rot = rot1;
         if (wave < BX_NC) {
             if (p.tn) bx_compute<true, NP, DBG>(p, st, wave); else bx_compute<false, NP, DBG>(p, st, wave);
@@ -528,6 +533,11 @@ extern "C" int eagcn_gemm_bx3(int tn, int M, int N, int K, const uint16_t* A, si
 
 extern "C" int eagcn_bx3_used_splits(int splits, int M, int N, int K) {
     return bx3_used_splits(splits < 1 ? 1 : splits, K, cdiv(M, BX_BM) * cdiv(N, BX_BN));
+}
+/* the same for the TN problem (M, N, K) of eagcn_gemm_bx3_pair, whose chunks are sized against the NT problem (M0, N0, K0) */
+extern "C" int eagcn_bx3_pair_used_splits(int splits, int M, int N, int K, int M0, int N0, int K0) {
+    return bx3_used_splits(splits < 1 ? 1 : splits, K, cdiv(M, BX_BM) * cdiv(N, BX_BN), cdiv(M0, BX_BM) * cdiv(N0, BX_BN),
+                           std::max(1, cdiv(K0, BX_BK)), std::max(1, bx3_grid() >> 3));
 }
 
 /* the dX / dW pair of a layer's backward in ONE persistent launch: problem 0 NT, problem 1 TN with split-K slabs */

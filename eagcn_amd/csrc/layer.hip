@@ -621,11 +621,14 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
                                                             int ld_in, int fp, const float* __restrict__ dWcat,
                                                             int nsplit, size_t slab, double* __restrict__ datt,
                                                             int nedge, const float* __restrict__ rsig, int wblocks,
-                                                            const int32_t* __restrict__ meta, int xk_G, int edge_drain) {
+                                                            const int32_t* __restrict__ meta, int xk_G, int edge_drain, int bx_per) {
     nedge = nedge < 0 ? -nedge : min(nedge, (meta[EAGCN_META_T] + 15) / 16);   // edge-gradient workgroups that had rows (< 0: all wrote)
     // split-K partials actually written: gemm.hip writes eff_splits of them; the plane GEMM (gemm_bx3.hip) passes its slab count
     // negated and writes bx3_used_splits() of them
-    nsplit = nsplit < 0 ? bx3_used_splits(-nsplit, meta[EAGCN_META_T], ((ld_in + 127) >> 7) * ((fp + 127) >> 7)) : max(1, min(nsplit, meta[EAGCN_META_T] >> 7));
+    // (bx_per > 0: the weight gradient shared its launch with the dX product -- T x ld_in over fp -- and sized its chunks against it)
+    nsplit = nsplit < 0 ? bx3_used_splits(-nsplit, meta[EAGCN_META_T], ((ld_in + 127) >> 7) * ((fp + 127) >> 7),
+                                          bx_per > 0 ? ((meta[EAGCN_META_T] + 127) >> 7) * ((ld_in + 127) >> 7) : 0, max(1, (fp + 31) >> 5), bx_per)
+                        : max(1, min(nsplit, meta[EAGCN_META_T] >> 7));
     if ((int)blockIdx.x < wblocks) {
         // split-K slabs: FOUR lanes per element, each adds every fourth slab (the first layer's weight gradient leaves gemm.hip
         // as up to 146 slabs: one thread per element was a chain of 37 dependent load rounds, 14 us at B = 1024)
@@ -774,8 +777,7 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     d.np = (d.ld_in >= 128 && (d.ld_in & 15) == 0 && (d.fp & 15) == 0) ? gemm_planes() : 0;
     // slab capacity of the weight gradient's k-chunks (how many are used is decided on the device from the actual row count:
     // bx3.h bx3_used_splits)
-    d.bx_splits = std::max(1, std::min(64, std::max(cdiv(std::max(b->T, 1), 4096), std::min(cdiv(512, cdiv(d.ld_in, 128) * cdiv(d.fp, 128)),
-                                                                                           cdiv(std::max(b->T, 1), 768)))));
+    d.bx_splits = std::max(1, std::min(64, std::max(cdiv(std::max(b->T, 1), 4096), cdiv(std::max(b->T, 1), 256))));
     return d;
 }
 
@@ -1240,6 +1242,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     }
     int nsplit = 0, nedge = 0, xk_G = 0;
     bool bx_slabs = false;       // dWcat holds the k-chunk slabs of the plane GEMM (all of them written)
+    int bx_per = 0;              // > 0: that product shared its launch with dX (workgroups per XCD: bx3.h bx3_used_splits)
     // side = stream for work that is off the dX critical path (edge gradients, dW product, gradient
     // unpacking); with no auxiliary stream everything stays in order on s
     hipStream_t side = w->aux_stream ? (hipStream_t)w->aux_stream : s;
@@ -1312,6 +1315,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             if (rc) return rc;
             nsplit = d.bx_splits;                         // partial slabs of dWcat: summed and scattered by unpack_grads below
             bx_slabs = true;
+            bx_per = dx ? std::max(1, bx3_grid() >> 3) : 0;
         } else if (use3 && !forked && dx && gemm3_layer(d.ld_in) && gemm3_ok(gw) && gemm3_ok(gx) && gemm3_xk_enabled()) {
             // wave-autonomous balanced kernel, XCD-local schedule: dX and dW in one launch, every XCD works on its own eighth of
             // the packed rows for BOTH products; dW leaves as one partial slab per XCD, summed by unpack_grads below
@@ -1355,7 +1359,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         ProfScope psu(PROF_PACK, side);
         unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, side>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
                                                                                     bx_slabs ? -nsplit : nsplit, d.wslab, edge_src, nedge, sc.rsig,
-                                                                                    wblocks, b->meta, xk_G, edge_drain);
+                                                                                    wblocks, b->meta, xk_G, edge_drain, bx_per);
         EAGCN_LAUNCH_CHECK();
     }
     // join: the caller reuses the scratch block (dY', dP, partial slabs) for the next layer

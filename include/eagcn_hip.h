@@ -433,6 +433,8 @@ int eagcn_bx3_split(const float* x, int rows, int ld, uint16_t* planes, size_t p
  *         z < eagcn_bx3_used_splits(splits, M, N, K) (at least 768 and at most 4096 rows of K per chunk; slabs beyond that count are
  *         NOT written), whose sum is the product. */
 int eagcn_bx3_used_splits(int splits, int M, int N, int K);
+/* ... of the TN problem (M, N, K) of eagcn_gemm_bx3_pair: its chunks are sized against the NT problem (M0, N0, K0) of the launch */
+int eagcn_bx3_pair_used_splits(int splits, int M, int N, int K, int M0, int N0, int K0);
 int eagcn_gemm_bx3(int tn, int M, int N, int K, const uint16_t* A, size_t a_pstride, int lda, int a_rows, const uint16_t* B,
                    size_t b_pstride, int ldb, int b_rows, float* C, int ldc, int splits, size_t slab, int np, void* stream);
 /* an NT product and a TN product (the dX / dW pair of a layer's backward) in ONE persistent launch */

@@ -146,7 +146,8 @@ static void time_layer(const char* name, int T, int FIN, int FP, int iters) {
     void* ws; CK(hipMalloc(&ws, wsb));
     const double f1 = 2.0 * T * FIN * FP;
     float t;
-    printf("%s: T=%d F_in=%d Fp=%d (dW k-chunks used: %d)\n", name, T, FIN, FP, eagcn_bx3_used_splits(splits, FIN, FP, T));
+    printf("%s: T=%d F_in=%d Fp=%d (dW k-chunks used: %d alone, %d beside dX)\n", name, T, FIN, FP, eagcn_bx3_used_splits(splits, FIN, FP, T),
+           eagcn_bx3_pair_used_splits(splits, FIN, FP, T, T, FIN, FP));
     t = time_fn(iters, [&] { RC(eagcn_gemm_bx3(0, T, FP, FIN, X.pl, X.pstride, FIN, X.cap, WT.pl, WT.pstride, FIN, WT.cap, P, FP, 1, 0, 3, nullptr)); });
     printf("  forward   bx3 %8.1f us  %6.1f TF", t, f1 / t * 1e-6);
     t = time_fn(iters, [&] { RC(eagcn_gemm_f32_sk(0, 1, T, FP, FIN, X.d, FIN, WT.d, FIN, P, FP, ws, wsb, nullptr)); });
