@@ -53,7 +53,8 @@ GEMM_MODES = {0: 'f32 (fp32 MFMA v_mfma_f32_16x16x4_f32, exact fp32 products)',
                  'piece products per 16 k rebuild the fp32 product (csrc/gemm_bx3.hip); aggregation, BatchNorm, head, first layer fp32',
               4: 'bf16 operands (ONE plane, round to nearest even), fp32 accumulate: BASELINE configs[1] as written; NOT the parity path'}
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = os.path.join('profiles', 'r03_pmc_traffic.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')) else 'r02_pmc_traffic.json')
+PMC_FILE = next((os.path.join('profiles', f) for f in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
+                 if os.path.exists(os.path.join(ROOT, 'profiles', f))), os.path.join('profiles', 'r04_pmc_traffic.json'))
 
 
 def rel_channels(cfg):
@@ -126,7 +127,7 @@ def committed_traffic(kernel_substr):
         table = json.load(open(os.path.join(ROOT, PMC_FILE)))
     except Exception:
         return None, None
-    big = [v for k, v in table.items() if kernel_substr in k]
+    big = [v for k, v in table.items() if all(part in k for part in kernel_substr.split('|'))]
     n = sum(v['launches'] for v in big)
     if not n:
         return None, None
@@ -413,7 +414,7 @@ def main():
         pair = kern.get('gemm_pair', (0.0, 0.0, 0))[2] > 0
         g_ms, g_work, g_n = kern['gemm_pair'] if pair else kern['gemm']
         achieved = (g_work / (g_ms * 1e-3)) / 1e12 if g_ms > 0 else 0.0
-        traffic, traffic_src = committed_traffic('bx3_kernel' if gemm_mode == 3 else 'gemm3_kernel<false, true') if args.workload == 'tox21_c2' and B == 256 else (None, None)
+        traffic, traffic_src = committed_traffic('bx3_kernel|pair' if gemm_mode == 3 else 'gemm3_kernel<false, true') if args.workload == 'tox21_c2' and B == 256 else (None, None)
         prof_steps = res['prof_steps']
         out = {
             'metric': 'molecules/sec fwd+bwd, 2-layer 5-view EAGCN, Tox21 batch' if args.workload == 'tox21_c2'

@@ -96,33 +96,58 @@ struct BxProb {
 // problems to the `per` workgroups of an XCD round-robin, the k-chunks first): the chunk count that minimises the LONGEST run of
 // k-tiles any workgroup gets under that hand-out (chunks of at least 8 k-tiles, at most 4096 rows) -- at 4809 rows the fixed
 // policy gave 5 of 32 workgroups a 25-k-tile chunk AND a 23-k-tile dX tile while 14 had 23.
-__host__ __device__ inline int bx3_used_splits(int cap, int K, int tiles, int ou = 0, int okt = 0, int per = 32) {
-    const int kt = K > 32 ? (K + 31) / 32 : 1;
+// (cost of chunk count s under the hand-out: 8 x the longest run of k-tiles + s, so that near-ties take fewer slabs)
+__host__ __device__ inline int bx3_split_cost(int s, int kt, int tiles, int n0x, int okt, int per) {
+    const int b = n0x / per, q = n0x % per;
+    const int c1 = (kt + s - 1) / s, n1x = (tiles * s + 7) >> 3, a = n1x / per, r = n1x % per;
+    const int l1 = r > 0 ? (a + 1) * c1 + (b + (q > per - r ? 1 : 0)) * okt : 0;
+    const int l2 = a * c1 + (b + (q > 0 ? 1 : 0)) * okt;
+    return 8 * (l1 > l2 ? l1 : l2) + s;
+}
+__host__ __device__ inline void bx3_split_range(int cap, int K, int& kt, int& smin, int& smax) {
+    kt = K > 32 ? (K + 31) / 32 : 1;
     const int drift = (K + 4095) / 4096;
+    smin = drift > 1 ? drift : 1;
+    smax = kt / 8;
+    smin = smin < cap ? smin : cap;
+    smax = smax < cap ? smax : cap;
+    smax = smax > smin ? smax : smin;
+    if (smax > smin + 63) smax = smin + 63;              // (64 candidates: one per lane of the wave-parallel form below)
+}
+__host__ __device__ inline int bx3_used_splits(int cap, int K, int tiles, int ou = 0, int okt = 0, int per = 32) {
     if (tiles < 1) tiles = 1;
     if (ou <= 0 || per <= 0) {
+        const int kt = K > 32 ? (K + 31) / 32 : 1, drift = (K + 4095) / 4096;
         const int fill = (512 + tiles - 1) / tiles, len = kt / 24;
         int s = fill < len ? fill : len;
         s = s > drift ? s : drift;
         s = s < cap ? s : cap;
         return s > 1 ? s : 1;
     }
-    int smin = drift > 1 ? drift : 1, smax = kt / 8;
-    smin = smin < cap ? smin : cap;
-    smax = smax < cap ? smax : cap;
-    smax = smax > smin ? smax : smin;
-    const int n0x = (ou + 7) >> 3, b = n0x / per, q = n0x % per;
-    int best = smin;
-    long best_cost = -1;
+    int kt, smin, smax;
+    bx3_split_range(cap, K, kt, smin, smax);
+    int best = smin, best_cost = -1;
     for (int s = smin; s <= smax; ++s) {
-        const int c1 = (kt + s - 1) / s, n1x = (tiles * s + 7) >> 3, a = n1x / per, r = n1x % per;
-        const long l1 = r > 0 ? (long)(a + 1) * c1 + (long)(b + (q > per - r ? 1 : 0)) * okt : 0;
-        const long l2 = (long)a * c1 + (long)(b + (q > 0 ? 1 : 0)) * okt;
-        const long cost = 8 * (l1 > l2 ? l1 : l2) + s;          // (ties and near-ties: fewer slabs)
+        const int cost = bx3_split_cost(s, kt, tiles, (ou + 7) >> 3, okt, per);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
     }
     return best;
 }
+#if defined(__HIPCC__)
+// the same choice, one candidate per lane (every lane of the calling wave must take part): the serial search above is up to 64 x
+// three integer divisions -- evaluated by every thread of unpack_grads it made that launch 49 us instead of 14
+__device__ __forceinline__ int bx3_used_splits_wave(int cap, int K, int tiles, int ou, int okt, int per) {
+    if (ou <= 0 || per <= 0) return bx3_used_splits(cap, K, tiles);
+    if (tiles < 1) tiles = 1;
+    int kt, smin, smax;
+    bx3_split_range(cap, K, kt, smin, smax);
+    const int s = smin + (int)(threadIdx.x & 63);
+    int key = s <= smax ? bx3_split_cost(s, kt, tiles, (ou + 7) >> 3, okt, per) * 128 + s : 0x7FFFFFFF;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(key, o); key = other < key ? other : key; }
+    return key & 127;
+}
+#endif
 bool bx3_ok(const BxProb& p);
 int bx3_grid();
 // np = 3: exact fp32 products from three planes; np = 1: plain bf16 operands.  p1 (optional): second product in the same launch

@@ -52,7 +52,7 @@ typedef __attribute__((address_space(3))) void* bx_lds_ptr;
 
 constexpr int BX_BK = 32;
 constexpr int BX_NC = 4;                     // compute waves: 2 x 2, one 64 x 64 accumulator block each (one per SIMD)
-constexpr int BX_NL = 4;                     // loader waves (four measured the same: the fill is bound by the 64-byte row segments of the NT image, profiles/r04_lds_fill_probe.txt)
+constexpr int BX_NL = 2;                     // loader waves (four measured the same: the fill is bound by the 64-byte row segments of the NT image, profiles/r04_lds_fill_probe.txt)
 constexpr int BX_BM = 128, BX_BN = 128;
 constexpr int BX_APL = BX_BM * 64, BX_BPL = BX_BN * 64;          // bytes of one plane image of a k-tile
 constexpr int BX_STAGE = 3 * (BX_APL + BX_BPL);                  // 48 KB
@@ -82,7 +82,7 @@ __device__ __forceinline__ BxUnits bx_units(const BxProb& p, int Mx, int Kx, int
     u.kt_total = max(1, (Kx + BX_BK - 1) / BX_BK);
     // TN: the k-tiles are spread over bx3_used_splits() chunks (bx3.h; capacity-sized launches: the actual K may be a fraction of the
     // capacity the host sized `splits` for); only those slabs are written, and the consumer sums only those
-    u.splits = p.tn ? bx3_used_splits(max(1, p.splits), Kx, u.tiles_m * u.tiles_n, ou, okt, max(1, (int)gridDim.x >> 3)) : 1;
+    u.splits = p.tn ? bx3_used_splits_wave(max(1, p.splits), Kx, u.tiles_m * u.tiles_n, ou, okt, max(1, (int)gridDim.x >> 3)) : 1;
     u.kt_per = (u.kt_total + u.splits - 1) / u.splits;
     u.n = u.tiles_m * u.tiles_n * u.splits;
     return u;

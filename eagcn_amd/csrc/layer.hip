@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
     // split-K partials actually written: gemm.hip writes eff_splits of them; the plane GEMM (gemm_bx3.hip) passes its slab count
     // negated and writes bx3_used_splits() of them
     // (bx_per > 0: the weight gradient shared its launch with the dX product -- T x ld_in over fp -- and sized its chunks against it)
-    nsplit = nsplit < 0 ? bx3_used_splits(-nsplit, meta[EAGCN_META_T], ((ld_in + 127) >> 7) * ((fp + 127) >> 7),
+    nsplit = nsplit < 0 ? bx3_used_splits_wave(-nsplit, meta[EAGCN_META_T], ((ld_in + 127) >> 7) * ((fp + 127) >> 7),
                                           bx_per > 0 ? ((meta[EAGCN_META_T] + 127) >> 7) * ((ld_in + 127) >> 7) : 0, max(1, (fp + 31) >> 5), bx_per)
                         : max(1, min(nsplit, meta[EAGCN_META_T] >> 7));
     if ((int)blockIdx.x < wblocks) {

@@ -16,14 +16,20 @@ import sys
 
 
 def load(d, counter):
-    rows = csv.DictReader(open('%s/t_counter_collection.csv' % d))
+    rows = [r for r in csv.DictReader(open('%s/t_counter_collection.csv' % d)) if r['Counter_Name'] == counter]
+    rows.sort(key=lambda r: int(r.get('Dispatch_Id', 0) or 0))
     per = collections.defaultdict(list)
+    nth = collections.Counter()
     for r in rows:
-        if r['Counter_Name'] != counter:
-            continue
         name = r['Kernel_Name'].replace('void ', '').replace('eagcn::', '').split('(')[0]
         grid = int(r['Grid_Size']) // max(int(r['Workgroup_Size']), 1)
-        per[(name, 'big' if ('gemm' in name and grid >= 256) else '')].append(float(r['Counter_Value']))
+        tag = 'big' if ('gemm' in name and grid >= 256) else ''
+        if 'bx3_kernel' in name:
+            # the plane GEMM is ONE kernel for the forward product and for the dX + dW pair: in a 2-layer model's step its launches
+            # alternate (forward of layer 2, then the pair of layer 2) -- labelled by their order of dispatch
+            tag = 'forward product' if nth[name] % 2 == 0 else 'dX + dW pair'
+            nth[name] += 1
+        per[(name, tag)].append(float(r['Counter_Value']))
     return per
 
 
@@ -34,7 +40,7 @@ def main(fdir, wdir, out):
         n = len(f[key])
         fetch = sum(f[key]) / n * 1024 * 2            # KiB -> bytes, gfx950 half-count correction
         write = sum(w.get(key, [0.0])) / max(len(w.get(key, [0.0])), 1) * 1024
-        label = key[0] + (' [>=256 workgroups]' if key[1] else '')
+        label = key[0] + ((' [>=256 workgroups]' if key[1] == 'big' else ' [%s]' % key[1]) if key[1] else '')
         table[label] = {'launches': n, 'read_bytes_per_launch': fetch, 'write_bytes_per_launch': write,
                         'hbm_bytes_per_launch': fetch + write}
     json.dump(table, open(out + '.json', 'w'), indent=1, sort_keys=True)
