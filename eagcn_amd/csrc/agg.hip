@@ -639,7 +639,10 @@ static int agg_pick_ct(int tmax, int nchunk) {
 // Small batches (few hundred tiles, duration set by the largest molecule): one workgroup per tile, K split
 // over its waves.  Large batches: one wave per tile.  Measured on MI355X: K-split 115 vs 136 us/step at
 // B=256, but 377 vs 253 us/step at B=1024.
-bool agg_ksplit(const eagcn_batch* b) { return b->B <= 512; }
+bool agg_ksplit(const eagcn_batch* b) {
+    static const int maxb = [] { const char* e = getenv("EAGCN_AGG_KSPLIT_MAXB"); return e ? atoi(e) : 512; }();
+    return b->B <= maxb;
+}
 // number of workgroups along x = number of BatchNorm stat slabs
 int agg_grid_x(const eagcn_batch* b) {
     return agg_ksplit(b) ? std::max(1, std::min(b->n_tiles, 1024)) : std::max(1, std::min(cdiv(b->n_tiles, 4), 512));

@@ -149,6 +149,7 @@ __device__ __forceinline__ int bx3_used_splits_wave(int cap, int K, int tiles, i
 }
 #endif
 bool bx3_ok(const BxProb& p);
+bool bx3_pair_policy();          // EAGCN_BX3_PAIR_POLICY=0: the chunks of a paired dW are sized as if it ran alone
 int bx3_grid();
 // np = 3: exact fp32 products from three planes; np = 1: plain bf16 operands.  p1 (optional): second product in the same launch
 int launch_bx3(const BxProb& p0, const BxProb* p1, int np, hipStream_t s, double work, int prof_tag);

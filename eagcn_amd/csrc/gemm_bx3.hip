@@ -401,14 +401,14 @@ __device__ __forceinline__ BxStream bx_stream(const BxProb& p, int rot, int& rot
 
 // up to two problems in one persistent launch (the dX / dW pair of a layer's backward): 4 compute waves + 2 loader waves per CU
 template <int NP, int DBG = 0>
-__global__ __launch_bounds__(64 * (BX_NC + BX_NL), 2) void bx3_kernel(BxProb p0, BxProb p1, int has1) {
+__global__ __launch_bounds__(64 * (BX_NC + BX_NL), 2) void bx3_kernel(BxProb p0, BxProb p1, int has1, int pair_policy) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int rot = 0, rot1 = 0;
     // the HEAVIER units first (longest-processing-time order inside a workgroup's run): the k-chunks of a dW before the dX tiles
     for (int pass = 0; pass < (has1 ? 2 : 1); ++pass) {
         const BxProb& p = (has1 && pass == 0) ? p1 : p0;
         int ou = 0, okt = 0;                           // the split-K problem of a pair sizes its chunks against the NT problem's units
-        if (has1 && pass == 0 && p1.tn && !p0.tn) {
+        if (pair_policy && has1 && pass == 0 && p1.tn && !p0.tn) {
             const BxUnits u0 = bx_units(p0, bx_mx(p0), bx_kx(p0));
             ou = u0.n; okt = u0.kt_total;
         }
@@ -440,6 +440,11 @@ __global__ __launch_bounds__(256) void bx3_split_kernel(const float* __restrict_
         const int r = (int)(i / ld4), c = (int)(i - (size_t)r * ld4) << 2;
         bx_store4(o, r, c, *reinterpret_cast<const float4*>(x + 4 * i));
     }
+}
+
+bool bx3_pair_policy() {
+    static const bool v = [] { const char* e = getenv("EAGCN_BX3_PAIR_POLICY"); return !(e && e[0] == '0'); }();
+    return v;
 }
 
 int bx3_grid() {
@@ -490,7 +495,7 @@ static int bx3_launch_cfg(const BxProb& p0, const BxProb* p1, hipStream_t s) {
         EAGCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bx3_kernel<NP, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    bx3_kernel<NP, DBG><<<bx3_grid(), 64 * (BX_NC + BX_NL), lds, s>>>(p0, p1 ? *p1 : p0, p1 ? 1 : 0);
+    bx3_kernel<NP, DBG><<<bx3_grid(), 64 * (BX_NC + BX_NL), lds, s>>>(p0, p1 ? *p1 : p0, p1 ? 1 : 0, bx3_pair_policy() ? 1 : 0);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
@@ -536,7 +541,7 @@ extern "C" int eagcn_bx3_used_splits(int splits, int M, int N, int K) {
 }
 /* the same for the TN problem (M, N, K) of eagcn_gemm_bx3_pair, whose chunks are sized against the NT problem (M0, N0, K0) */
 extern "C" int eagcn_bx3_pair_used_splits(int splits, int M, int N, int K, int M0, int N0, int K0) {
-    return bx3_used_splits(splits < 1 ? 1 : splits, K, cdiv(M, BX_BM) * cdiv(N, BX_BN), cdiv(M0, BX_BM) * cdiv(N0, BX_BN),
+    return bx3_used_splits(splits < 1 ? 1 : splits, K, cdiv(M, BX_BM) * cdiv(N, BX_BN), bx3_pair_policy() ? cdiv(M0, BX_BM) * cdiv(N0, BX_BN) : 0,
                            std::max(1, cdiv(K0, BX_BK)), std::max(1, bx3_grid() >> 3));
 }
 

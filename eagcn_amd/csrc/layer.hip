@@ -1315,7 +1315,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             if (rc) return rc;
             nsplit = d.bx_splits;                         // partial slabs of dWcat: summed and scattered by unpack_grads below
             bx_slabs = true;
-            bx_per = dx ? std::max(1, bx3_grid() >> 3) : 0;
+            bx_per = (dx && bx3_pair_policy()) ? std::max(1, bx3_grid() >> 3) : 0;
         } else if (use3 && !forked && dx && gemm3_layer(d.ld_in) && gemm3_ok(gw) && gemm3_ok(gx) && gemm3_xk_enabled()) {
             // wave-autonomous balanced kernel, XCD-local schedule: dX and dW in one launch, every XCD works on its own eighth of
             // the packed rows for BOTH products; dW leaves as one partial slab per XCD, summed by unpack_grads below

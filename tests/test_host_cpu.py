@@ -278,3 +278,31 @@ def test_xcd_local_gemm_schedule_partitions_the_iteration_space():
             for x in range(9):
                 L = 4 * (x * qn + min(x, rn))
                 assert abs(a[x] * CT0 * ipt0 + T1 * c[x] - (L * per + min(L, rem))) <= T1 // 2 + 1, (x, a, c)
+
+
+def test_plane_image_layout_and_split_policy_host_side():
+    """The operand format of the plane GEMM (include/eagcn_hip.h, csrc/bx3.h): the documented element -> index map is a bijection
+    onto the image for every (rows, ld) and the image size is what eagcn_bx3_plane_elems returns; the k-chunk policy of the weight
+    gradient (pure host functions of the C ABI: no GPU involved) keeps its promises -- between 1 and the slab capacity, chunks of
+    at most 4096 rows whenever the capacity allows it, at least 8 k-tiles per chunk beside a dX product, 24 alone."""
+    from eagcn_amd import _lib
+    lib = _lib.load()
+    for rows, ld in ((1, 8), (37, 64), (100, 400), (4809, 720), (5, 40)):
+        n = int(lib.eagcn_bx3_plane_elems(rows, ld))
+        assert n == (ld + 31) // 32 * 32 * rows
+        r = np.arange(rows)[:, None]
+        c = np.arange(ld)[None, :]
+        idx = ((c >> 5) * rows + r) * 32 + ((((c >> 3) & 3) ^ ((r >> 2) & 3)) << 3) + (c & 7)
+        assert idx.min() >= 0 and idx.max() < n and np.unique(idx).size == rows * ld
+        # four adjacent columns (c a multiple of 4) are contiguous: the producers' 8-byte stores
+        assert (np.diff(idx.reshape(rows, ld // 4, 4), axis=2) == 1).all()
+    for (M, N, K, cap) in ((400, 720, 4809, 19), (400, 720, 19200, 64), (512, 6320, 25000, 64), (512, 1024, 262144, 64), (128, 128, 37, 4),
+                           (400, 720, 100, 8)):
+        alone = lib.eagcn_bx3_used_splits(cap, M, N, K)
+        pair = lib.eagcn_bx3_pair_used_splits(cap, M, N, K, K, M, N)
+        kt = max(1, -(-K // 32))
+        for s, min_kt in ((alone, 24), (pair, 8)):
+            assert 1 <= s <= cap
+            if cap >= -(-K // 4096):
+                assert -(-kt // s) * 32 <= 4096 + 31, (M, N, K, s)
+            assert s == 1 or s == -(-K // 4096) or kt // s >= min_kt - 1 or kt // min_kt < 1, (M, N, K, s, min_kt)
