@@ -106,7 +106,7 @@ class Model(C.Structure):
     _fields_ = [('n_layers', C.c_int32), ('molfp_mode', C.c_int32), ('training', C.c_int32),
                 ('head_seed', C.c_uint64), ('head_seed_dev', _fp), ('input_packed', C.c_int32), ('aux_stream', _fp),
                 ('layer', LayerParams * 4), ('head', HeadParams), ('stats_hook', _fp), ('stats_user', _fp),
-                ('stats_world', C.c_int32), ('fuse_readout', C.c_int32)]
+                ('stats_world', C.c_int32), ('fuse_readout', C.c_int32), ('fwd_signal', _fp)]
 
 
 # int hook(double* buf, int n, void* stream, void* user): cross-rank sum in place (sync-BatchNorm, eagcn_hip.h)
@@ -128,6 +128,7 @@ SIGNATURES = {
     'eagcn_index_from_bonds': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.POINTER(Batch), _fp, _fp]),
     'eagcn_index_rows': (C.c_int, [C.POINTER(Batch), _fp]),
     'eagcn_set_gemm_mode': (C.c_int, [C.c_int]),
+    'eagcn_stream_wait_counter': (C.c_int, [_fp, C.c_uint32, _fp]),
     'eagcn_adam_step': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     'eagcn_agg_wants_bond_lists': (C.c_int, [C.c_int, C.c_int]),
     'eagcn_bx3_used_splits': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

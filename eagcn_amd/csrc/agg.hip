@@ -14,7 +14,7 @@
 // sum is accumulated in the same loop and applied once in the epilogue (row scaling commutes with
 // the product), where the per-channel BatchNorm partial sums (sum y, sum y^2 in fp64) are taken as
 // well.  No LDS tile, no barrier in the main loop, any molecule size.
-// Small batches (B <= 512) use the K-split variant instead: one WORKGROUP per tile, the molecule's column
+// Small batches (B <= 256) use the K-split variant instead: one WORKGROUP per tile, the molecule's column
 // groups spread over its four waves.  The CT column tiles are mapped so that a lane's four B-operand values /
 // results form one float4 (256 contiguous bytes per row and 16 lanes).  BatchNorm partial sums live in LDS,
 // the register budget is held at 128 (4 waves per SIMD): the kernels are bound by round trips in flight.
@@ -637,10 +637,12 @@ static int agg_pick_ct(int tmax, int nchunk) {
 }
 // number of workgroups along x (= number of stat partial slabs) used for a batch
 // Small batches (few hundred tiles, duration set by the largest molecule): one workgroup per tile, K split
-// over its waves.  Large batches: one wave per tile.  Measured on MI355X: K-split 115 vs 136 us/step at
-// B=256, but 377 vs 253 us/step at B=1024.
+// over its waves.  Large batches: one wave per tile.  Measured on MI355X in round 1: K-split 115 vs 136 us/step at
+// B=256, but 377 vs 253 us/step at B=1024; round 4 (16-byte operand loads, branch-free pipelined block loop in the
+// wave-per-tile kernel): equal at B = 256 (0.455 ms either way), wave-per-tile ahead at B = 512 (Tox21 0.641 -> 0.616 ms,
+// Lipo 3-layer 1.557 -> 1.439 ms): the switch is at 256 (EAGCN_AGG_KSPLIT_MAXB).
 bool agg_ksplit(const eagcn_batch* b) {
-    static const int maxb = [] { const char* e = getenv("EAGCN_AGG_KSPLIT_MAXB"); return e ? atoi(e) : 512; }();
+    static const int maxb = [] { const char* e = getenv("EAGCN_AGG_KSPLIT_MAXB"); return e ? atoi(e) : 256; }();
     return b->B <= maxb;
 }
 // number of workgroups along x = number of BatchNorm stat slabs

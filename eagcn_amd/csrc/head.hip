@@ -19,6 +19,18 @@
 
 namespace eagcn {
 
+// step-position signal / wait (eagcn_model.fwd_signal, eagcn_stream_wait_counter)
+__global__ void fwd_signal_kernel(uint32_t* __restrict__ word) {
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void wait_counter_kernel(const uint32_t* __restrict__ word, uint32_t value) {
+    if (threadIdx.x == 0) {
+        // (signed distance: the counter may wrap)
+        while ((int32_t)(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+
 
 // ---- carving of the saved-for-backward block and of the transient scratch ---------------------------
 struct Carver2 {
@@ -281,6 +293,10 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     else
         RC(eagcn_readout_forward(b, LL.xout, &lay, last->structure == EAGCN_STRUCT_WEIGHTED ? LL.pad_row : nullptr,
                                  size, m->molfp_mode, sv.g, F, stream));
+    if (m->fwd_signal) {                              // (include/eagcn_hip.h eagcn_model.fwd_signal)
+        fwd_signal_kernel<<<1, 64, 0, s>>>(m->fwd_signal);
+        EAGCN_LAUNCH_CHECK();
+    }
     // head (head2.hip): every BatchNorm's sums come from the kernel that produces its input, its normalisation is
     // applied by the product that consumes it
     const bool sync = m->stats_hook && m->training;
@@ -453,5 +469,12 @@ extern "C" int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_mode
         if (l == layer_lo) pend_in.eacc = nullptr;
     }
     if (forked) RC(stream_after(s, side));                       // join: every gradient is complete on s
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_stream_wait_counter(const uint32_t* counter, uint32_t value, void* stream) {
+    EAGCN_CHECK_ARG(counter != nullptr, "eagcn_stream_wait_counter: null counter");
+    eagcn::wait_counter_kernel<<<1, 64, 0, (hipStream_t)stream>>>(counter, value);
+    EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

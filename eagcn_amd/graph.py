@@ -31,6 +31,15 @@ _RING = 4
 # the head / BatchNorm backward (latency chains on a few CUs) instead of beside the layer products (measured round 2:
 # 0.5228 -> 0.5175 ms/step at B=256, 1.2386 -> 1.2162 at B=1024; the wave-per-SIMD GEMM is sensitive to co-runners)
 _SIDE_AFTER_FWD = os.environ.get('EAGCN_SIDE_AFTER_FWD', '1') == '1'
+# EAGCN_SIDE_PLACED=1 (opt-in, measured SLOWER): one captured graph per step has no launch boundary behind the forward to hang an
+# event on, so the forward itself bumps a device word behind the read-out (eagcn_model.fwd_signal) and the side stream parks one
+# polling wavefront until the previous step has got there (eagcn_stream_wait_counter): the next batch's index scan then runs under
+# the head / loss / head-backward kernels instead of beside the persistent plane GEMMs (which it stretches from 150 to 189 us at
+# B = 1024, while the one-workgroup `index_offsets` waits 113 us for a CU: profiles/r04_b1024_step_timeline.txt).  Result (round 4,
+# two runs each): B = 1024 0.936 -> 0.970 ms, HIV 8.10 -> 8.86, C5 15.97 -> 17.38, Lipo 1.434 -> 1.465, B = 256 unchanged -- the
+# index build is 0.14-2.4 ms of side-stream work that needs the WHOLE previous step to hide in; holding it back until that step's
+# forward is over puts its tail on the critical path.  Being slowed down by co-runners is cheaper than not overlapping.
+_SIDE_PLACED = os.environ.get('EAGCN_SIDE_PLACED', '0') == '1'
 # a data-parallel step whose gradient all-reduce cannot be captured into the step graph is an ERROR instead of a (warned)
 # fallback to a host-issued collective: bench.py --require-in-graph-allreduce, tools/run_scale.sh
 _REQUIRE_IN_GRAPH = os.environ.get('EAGCN_REQUIRE_IN_GRAPH_ALLREDUCE', '0') == '1'
@@ -123,6 +132,8 @@ class GraphRunner:
         # Measured on MI355X at the Tox21 shape: replay got SLOWER (0.85 vs 0.77 ms/step), so off by default.
         if os.environ.get('EAGCN_AUX_STREAM', '0') == '1':
             self.aux = torch.cuda.Stream(device=self.device)
+        self.fwd_sig = torch.zeros(1, dtype=torch.int32, device=device)     # bumped by every executed forward (eagcn_model.fwd_signal)
+        self.fwd_issued = 0                                                  # ... and the number of forwards issued so far
         self.cms = [self._cmodel(i) for i in range(2)]
         m = self.cms[0]
         self.saved_bytes = lib.eagcn_model_saved_bytes(self.index.ref(), C.byref(m))
@@ -200,6 +211,8 @@ class GraphRunner:
             m.layer[l].seed_dev = sd + 8 * l
         m.head_seed_dev = sd + 8 * 4
         m.input_packed = 1
+        if _SIDE_PLACED:
+            m.fwd_signal = self.fwd_sig.data_ptr()
         if self.aux is not None:
             m.aux_stream = self.aux.cuda_stream
         return m
@@ -231,6 +244,8 @@ class GraphRunner:
     # -- the two launch sequences --------------------------------------------------------------------
     def _call_forward(self):
         lib = L.load()
+        if not torch.cuda.is_current_stream_capturing():
+            self.fwd_issued += 1                              # (a captured forward counts when its graph is replayed)
         size_ptr = _ptr(self.size_static[self.cur]) if self.plan.molfp else C.c_void_p(0)
         L.check(lib.eagcn_model_forward(self.index.ref(), C.byref(self.cms[self.cur]), C.c_void_p(0), size_ptr,
                                         _ptr(self.saved[self.cur]), self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.out),
@@ -322,6 +337,11 @@ class GraphRunner:
             # layer GEMMs and aggregations)
             if self.fwd_done is not None and _SIDE_AFTER_FWD:
                 side.wait_event(self.fwd_done)
+            elif _SIDE_PLACED and self.fwd_issued > 0:
+                # fused steps: until the forward of the step issued last has passed its read-out (it is already enqueued on the
+                # main stream, and the main stream never waits for anything issued behind this point of the side stream)
+                L.check(lib.eagcn_stream_wait_counter(C.c_void_p(self.fwd_sig.data_ptr()), self.fwd_issued & 0xFFFFFFFF,
+                                                      C.c_void_p(side.cuda_stream)), 'eagcn_stream_wait_counter')
             for t in (afm, adj, size, labels) + tuple(rels or ()) + tuple(bonds or ()):
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(side)                     # read on the side stream after this call returns
@@ -404,6 +424,7 @@ class GraphRunner:
             self._capture()
         else:
             self.graphs[cur][0].replay()
+            self.fwd_issued += 1
         if overlap:
             self.fwd_done = torch.cuda.Event()
             self.fwd_done.record(main)
@@ -602,6 +623,7 @@ class GraphRunner:
             self.graphs[cur][2], self.step_kind[cur] = g, key
         else:
             self.graphs[cur][2].replay()
+            self.fwd_issued += 1
         self.fwd_done = None            # (no launch boundary after the forward any more: the next index build only waits
                                         #  for its slot and runs under this step's kernels)
         self._attach_grads(keep, grads)

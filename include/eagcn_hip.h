@@ -356,7 +356,18 @@ typedef struct eagcn_model {
                                                instead of bn_apply + read-out + column statistics).  The matrix
                                                (atom_representations, models.py:102) is built on request by
                                                eagcn_model_atom_rep_materialize.  Ignored for other structures.            */
+    uint32_t* fwd_signal;                   /* optional device word: the forward adds 1 to it behind the read-out, i.e. when the
+                                               layer products / aggregations of the step have been issued and only short kernels
+                                               follow for a while (head, loss, head backward, the top BatchNorm backward).  Another
+                                               stream can wait for a count with eagcn_stream_wait_counter: the caller's batch
+                                               preparation for the NEXT step is placed under those kernels instead of beside the
+                                               persistent GEMMs (eagcn_amd/graph.py).  NULL: no signal                        */
 } eagcn_model;
+
+/* `stream` does not run anything issued behind this call until *counter (device memory, see eagcn_model.fwd_signal) >= value:
+ * one parked wavefront that polls the word.  The signalling work must already be enqueued (or be enqueued without waiting for
+ * this stream), otherwise the wait never ends. */
+int eagcn_stream_wait_counter(const uint32_t* counter, uint32_t value, void* stream);
 
 size_t eagcn_model_saved_bytes(const eagcn_batch* b, const eagcn_model* m);    /* kept forward -> backward */
 size_t eagcn_model_scratch_bytes(const eagcn_batch* b, const eagcn_model* m);  /* transient, either call  */
