@@ -23,8 +23,13 @@ __device__ __forceinline__ int exact_to_packed(const ColMapD& m, int ce) {
 // ---- dropout of the rows that are not stored (Weighted_sum has no row mask: reference layers.py:94 drops every element
 // of the padded [B,N,F] tensor independently, layers.py:315-316 sums the views, models.py:108 sums all N rows) ------------
 // A non-stored row of view k holds relu(shift_k[c]) in column c before dropout, so the read-out only needs HOW MANY of the
-// N - nat[b] non-stored rows keep (molecule b, view k, column c): cnt[b][k][c], drawn from the layer's dropout seed (16-bit
-// draws, four rows per 64-bit hash) and kept for the backward pass.  padc[b][c] = sum_k a_k relu(shift_k[c]) cnt / (1-p).
+// m = N - nat[b] non-stored rows keep (molecule b, view k, column c): cnt[b][k][c] ~ Binomial(m, q), q the keep probability of
+// the stored rows' 16-bit draws.  Round 3 drew the m Bernoulli variables (four per 64-bit hash: 50 hashes per count at the HIV
+// set's N = 222 -- 0.43 ms per step, bound by the hash's 64-bit multiplies).  Now: ONE 32-bit uniform per count, inverted
+// through the binomial CDF of its m -- a table of 32-bit thresholds t[m][j] = floor(2^32 P(X <= j)) built per forward by
+// `pad_binomial_table_kernel` (one thread per m; plain IEEE double operations in a fixed order, so that the test suite rebuilds
+// the same table in numpy: tests/test_gpu_parity.py _pad_counts) -- cnt = #{j < m : t[m][j] <= u}.  Kept for the backward pass.
+// padc[b][c] = sum_k a_k relu(shift_k[c]) cnt / (1-p).
 struct PadSample {
     int K, ld, fp;                           // views, output columns (one view's padded width), BatchNorm table stride
     int off[EAGCN_MAX_VIEWS];                // column offset of view k inside the [fp] tables
@@ -34,32 +39,61 @@ struct PadSample {
     uint32_t thr16; float inv_keep;
     uint16_t* cnt;                           // [B][K][ld]
     float* padc;                             // [B][ld]
+    const uint32_t* tab;                     // [N + 1][N + 1] thresholds (row m: entries 0 .. m)
+    int tab_ld;
 };
-__device__ __forceinline__ int pad_keep_count(uint64_t seed, int b, int N, int n, uint64_t col, uint64_t ncol, uint32_t thr16) {
-    const int g4 = (N + 3) >> 2;
-    int cnt = 0;
-    for (int i4 = n >> 2; i4 < g4; ++i4) {
-        const uint64_t z = rng_u64(seed, (PAD_STREAM_BASE + (uint64_t)b * g4 + i4) * ncol + col);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = 4 * i4 + e;
-            cnt += (i >= n && i < N && ((uint32_t)(z >> (16 * e)) & 0xFFFFu) >= thr16) ? 1 : 0;
-        }
+// Weights relative to the mode (no underflow for any m), then the running sum: every operation a correctly rounded IEEE double
+// operation issued explicitly (no fused multiply-add), in this order.
+__global__ __launch_bounds__(64) void pad_binomial_table_kernel(eagcn_batch bt, uint32_t thr16, uint32_t* __restrict__ tab,
+                                                                 double* __restrict__ w, int tab_ld) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m > dev_n(bt) || m >= tab_ld) return;
+    uint32_t* t = tab + (size_t)m * tab_ld;
+    double* wm = w + (size_t)m * tab_ld;
+    const double q = __dsub_rn(1.0, __ddiv_rn((double)thr16, 65536.0));           // keep probability of a 16-bit draw
+    const double r = __ddiv_rn(q, __dsub_rn(1.0, q));
+    int mode = (int)floor(__dmul_rn((double)(m + 1), q));
+    mode = mode < 0 ? 0 : (mode > m ? m : mode);
+    wm[mode] = 1.0;
+    double v = 1.0;
+    for (int k = mode; k < m; ++k) {                     // w[k+1] = w[k] (m - k) r / (k + 1)
+        v = __ddiv_rn(__dmul_rn(v, __dmul_rn((double)(m - k), r)), (double)(k + 1));
+        wm[k + 1] = v;
     }
-    return cnt;
+    v = 1.0;
+    for (int k = mode; k > 0; --k) {                     // w[k-1] = w[k] k / ((m - k + 1) r)
+        v = __ddiv_rn(__dmul_rn(v, (double)k), __dmul_rn((double)(m - k + 1), r));
+        wm[k - 1] = v;
+    }
+    double S = 0.0;
+    for (int k = 0; k <= m; ++k) S = __dadd_rn(S, wm[k]);
+    double c = 0.0;
+    for (int k = 0; k <= m; ++k) {
+        c = __dadd_rn(c, wm[k]);
+        const double y = __dmul_rn(__ddiv_rn(c, S), 4294967296.0);
+        t[k] = y >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)y;
+    }
 }
 __global__ __launch_bounds__(256) void readout_pad_sample_kernel(eagcn_batch bt, PadSample a) {
+    __shared__ uint32_t t_s[1025];
     const int b = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.ld) return;
     const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
-    const int n = bt.nat[b];
+    const int m = max(dev_n(bt) - bt.nat[b], 0);         // non-stored rows of this molecule
+    for (int j = threadIdx.x; j < m; j += blockDim.x) t_s[j] = a.tab[(size_t)m * a.tab_ld + j];
+    __syncthreads();
+    if (c >= a.ld) return;
     float acc = 0.0f;
     for (int k = 0; k < a.K; ++k) {
         const int cp = a.off[k] + c;
-        const int cnt = pad_keep_count(seed, b, dev_n(bt), n, (uint64_t)cp, (uint64_t)a.fp, a.thr16);
-        a.cnt[((size_t)b * a.K + k) * a.ld + c] = (uint16_t)cnt;
-        acc += a.ave_w[k] * fmaxf(a.bn_sh[cp], 0.0f) * ((float)cnt * a.inv_keep);
+        const uint32_t u = (uint32_t)(rng_u64(seed, (PAD_STREAM_BASE + (uint64_t)b) * (uint64_t)a.fp + (uint64_t)cp) >> 32);
+        int lo = 0, hi = m;                              // cnt = first j with t[j] > u (t is non-decreasing)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (t_s[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        a.cnt[((size_t)b * a.K + k) * a.ld + c] = (uint16_t)lo;
+        acc += a.ave_w[k] * fmaxf(a.bn_sh[cp], 0.0f) * ((float)lo * a.inv_keep);
     }
     a.padc[(size_t)b * a.ld + c] = acc;
 }
@@ -323,9 +357,10 @@ __global__ __launch_bounds__(1024) void readout_bwd_pad_kernel(eagcn_batch bt, c
 // forward read-out with the non-stored rows' dropout SAMPLED (Weighted_sum, training, p > 0): fills cnt / padc, then sums
 int readout_forward_sampled(const eagcn_batch* b, const float* x, const eagcn_layout* lay, const eagcn_layer_params* p,
                             const float* bn_sh, const int64_t* size, int mode, float* g, int F, uint16_t* cnt, float* padc,
-                            void* stream) {
+                            uint32_t* tab, double* tab_w, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int ld = layout_ld(lay);
+    EAGCN_CHECK_ARG(b->N <= 1024, "read-out: N=%d exceeds the supported 1024 atoms", b->N);
     PadSample a;
     a.K = p->K; a.ld = ld; a.fp = p->K * ld;
     for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) a.off[k] = k * ld;
@@ -333,7 +368,10 @@ int readout_forward_sampled(const eagcn_batch* b, const float* x, const eagcn_la
     a.thr16 = (uint32_t)std::min(65535.0, (double)p->dropout * 65536.0);
     a.inv_keep = 1.0f / (1.0f - p->dropout);
     a.cnt = cnt; a.padc = padc;
+    a.tab = tab; a.tab_ld = b->N + 1;
     ProfScope ps(PROF_READOUT, s);
+    pad_binomial_table_kernel<<<cdiv(b->N + 1, 64), 64, 0, s>>>(*b, a.thr16, tab, tab_w, a.tab_ld);
+    EAGCN_LAUNCH_CHECK();
     readout_pad_sample_kernel<<<dim3(cdiv(ld, 256), b->B), 256, 0, s>>>(*b, a);
     EAGCN_LAUNCH_CHECK();
     readout_fwd_kernel<<<dim3(b->B, cdiv(F, 64)), 256, 0, s>>>(*b, x, make_colmap(lay), ld, nullptr, padc, size, mode, g, F);

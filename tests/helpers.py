@@ -153,3 +153,32 @@ def assert_grad_parity(got, ref32, ref64_fn, scale, name, rtol=1e-5, floor=2e-6,
         return
     assert ok, (name, 'e_hip', e_hip, 'e_ref', e_ref, 'ratio', e_hip / max(e_ref, 1e-300),
                 'allowed', lim, 'vs fp64; plain error', err, 'bound', bound)
+
+
+def pad_thresholds(m, q):
+    """Row m of the binomial threshold table of csrc/readout.hip (pad_binomial_table_kernel), operation for operation in IEEE
+    double: weights relative to the mode, their running sum, t[j] = floor(2^32 P(X <= j))."""
+    f = np.float64
+    r = q / (f(1.0) - q)
+    mode = int(np.floor(f(m + 1) * q))
+    mode = min(max(mode, 0), m)
+    w = np.zeros(m + 1, dtype=np.float64)
+    w[mode] = 1.0
+    v = f(1.0)
+    for k in range(mode, m):
+        v = (v * (f(m - k) * r)) / f(k + 1)
+        w[k + 1] = v
+    v = f(1.0)
+    for k in range(mode, 0, -1):
+        v = (v * f(k)) / (f(m - k + 1) * r)
+        w[k - 1] = v
+    S = f(0.0)
+    for k in range(m + 1):
+        S = S + w[k]
+    c = f(0.0)
+    t = np.zeros(m + 1, dtype=np.uint64)
+    for k in range(m + 1):
+        c = c + w[k]
+        y = (c / S) * f(4294967296.0)
+        t[k] = np.uint64(4294967295) if y >= 4294967295.0 else np.uint64(int(y))
+    return t

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_grad_parity, f64_grads, Golden, assert_grad_close, build_oracle_model, golden_cases, rel_err
+from helpers import assert_grad_parity, f64_grads, Golden, assert_grad_close, build_oracle_model, golden_cases, rel_err, pad_thresholds
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -1024,13 +1024,15 @@ def _hip_dropout_masks(mb, widths_per_layer, structure, n_den1, p, seed):
                     z = (z >> (np.uint64(16) * (idx & np.uint64(3)))) & np.uint64(0xFFFF)
                     m[b, :n, :] = np.where(z >= (thr >> np.uint64(16)), inv_keep, np.float32(0.0))
                 if structure == 'Weighted_sum' and l == L - 1 and n < N:
-                    i = np.arange(n, N)
-                    g4 = (N + 3) // 4
-                    grp = (np.uint64(1 << 40) + np.uint64(b * g4) + (i // 4).astype(np.uint64))[:, None]
-                    cp = (off[k] + np.arange(w)).astype(np.uint64)[None, :]
-                    z = _mix64(seed_l, grp * np.uint64(fp) + cp)
-                    draw = (z >> (np.uint64(16) * (i % 4).astype(np.uint64))[:, None]) & np.uint64(0xFFFF)
-                    m[b, n:, :] = np.where(draw >= thr16, inv_keep, np.float32(0.0))
+                    # the non-stored rows all hold the same value, only HOW MANY are kept matters: the kernel draws that count
+                    # -- one 32-bit uniform per (molecule, view, column), inverted through the binomial thresholds of N - n
+                    # trials -- and the mask keeps the first `count` of them
+                    q = np.float64(1.0) - np.float64(int(thr16)) / np.float64(65536.0)
+                    t = pad_thresholds(N - n, q)[:N - n]
+                    cp = (off[k] + np.arange(w)).astype(np.uint64)
+                    u = _mix64(seed_l, (np.uint64(1 << 40) + np.uint64(b)) * np.uint64(fp) + cp) >> np.uint64(32)
+                    cnt = (t[None, :] <= u[:, None]).sum(axis=1)                       # [w]
+                    m[b, n:, :] = np.where(np.arange(N - n)[:, None] < cnt[None, :], inv_keep, np.float32(0.0))
             masks.append(torch.from_numpy(m))
     seed_h = (seed + 0x51ED27) & (2 ** 63 - 1)
     idx = (np.arange(B, dtype=np.uint64)[:, None] * np.uint64(n_den1) + np.arange(n_den1, dtype=np.uint64)[None, :])

@@ -306,3 +306,17 @@ def test_plane_image_layout_and_split_policy_host_side():
             if cap >= -(-K // 4096):
                 assert -(-kt // s) * 32 <= 4096 + 31, (M, N, K, s)
             assert s == 1 or s == -(-K // 4096) or kt // s >= min_kt - 1 or kt // min_kt < 1, (M, N, K, s, min_kt)
+
+
+def test_pad_row_binomial_thresholds_are_the_binomial_cdf():
+    """tests/helpers.py pad_thresholds = the numpy mirror of csrc/readout.hip pad_binomial_table_kernel (the kept-row counts of the
+    non-stored rows of a Weighted_sum layer under dropout are drawn by inverting these thresholds; the GPU test with injected masks
+    pins kernel == mirror): the mirror IS the binomial distribution -- every threshold within one unit of 2^-32 of scipy's CDF,
+    non-decreasing, the last one saturated."""
+    from scipy.stats import binom
+    from helpers import pad_thresholds
+    for m, q in ((0, 0.7), (1, 0.7), (5, 0.7), (60, 0.5), (197, 0.7), (222, 0.9), (1000, 0.7), (1024, 0.3)):
+        t = pad_thresholds(m, np.float64(q)).astype(np.float64)
+        ref = np.floor(binom.cdf(np.arange(m + 1), m, q) * 2.0 ** 32)
+        assert np.abs(t - np.minimum(ref, 4294967295.0)).max() <= 1.0, (m, q)
+        assert (np.diff(t) >= 0).all() and t[-1] == 4294967295.0
