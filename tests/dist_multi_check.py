@@ -68,18 +68,24 @@ def oracle(sync):
     return total, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
 
 
-for sync in (False, True):
+# (local-BN twice: the second time with the batch preparation -- and with it the one-element 'dp' loss-scale collective -- on the
+#  side stream, i.e. an eager collective issued while the previous step's graph with its captured all-reduces may still be replaying
+#  on the same communicator: the configuration bench.py and examples/train_synth.py run)
+for sync, overlap in ((False, False), (False, True), (True, False)):
     torch.manual_seed(1)
-    model = EAGCN(9, 24, *W1, *W2, 32, 16, T, 0.0, n_layers=2, graph=True, validate='deferred', sync_bn=sync).to(dev).train()
+    model = EAGCN(9, 24, *W1, *W2, 32, 16, T, 0.0, n_layers=2, graph=True, validate='deferred', sync_bn=sync,
+                  overlap_index=overlap).to(dev).train()
     model.load_state_dict(ref.state_dict(), strict=True)
     red = GradientAllReducer(model.parameters(), model=model)
     want_loss, want = oracle(sync)
-    for step in range(5):                         # eager + capture on both slots, then replays
+    nsteps = 12 if overlap else 5
+    for step in range(nsteps):                    # eager + capture on both slots, then replays
         for p in model.parameters():
             p.grad = None
-        if step:                                  # (BatchNorm running statistics move every step; the gradients do not depend on them)
-            pass
         loss, (out, _, _) = model.fused_step(shard, labels, 'class', bw_dev, 'dp', reducer=red)
+        if overlap and 4 <= step < nsteps - 1:
+            continue                              # replays back to back, no host synchronisation: the next step's eager collective
+                                                  # is issued while this step's graph (with its captured all-reduces) is in flight
         torch.cuda.synchronize()
         # the ranks' losses c_r * S_r / n_r average to the global loss
         lt = loss.detach().clone().reshape(1)
@@ -105,8 +111,8 @@ for sync in (False, True):
         dist.all_gather(gathered, chk)
         assert all(torch.equal(gathered[0], c) for c in gathered), [float(c) for c in gathered]
     runner = next(iter(model._runners.values()))
-    print('rank %d %s-BN: loss %.6f (oracle %.6f), worst gradient error / own max %.1e (%s), all-reduce %s, sync-BN hook calls %s'
-          % (rank, 'sync' if sync else 'local', got_loss, want_loss, worst[0], worst[1],
+    print('rank %d %s-BN%s: loss %.6f (oracle %.6f), worst gradient error / own max %.1e (%s), all-reduce %s, sync-BN hook calls %s'
+          % (rank, 'sync' if sync else 'local', ' (side-stream batch preparation)' if overlap else '', got_loss, want_loss, worst[0], worst[1],
              'captured in the step graph' if runner.comm_in_graph else 'host-issued after the graph (capture of the collective failed)',
              model.plan().stats.calls if sync else '-'), flush=True)
     if sync:
