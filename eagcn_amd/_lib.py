@@ -211,6 +211,9 @@ class EagcnHipError(RuntimeError):
     pass
 
 
+ABI_VERSION = 4    # include/eagcn_hip.h eagcn_abi_version(): struct layouts + signatures this binding was written against
+
+
 def load():
     """dlopen the HIP library (once).  Raises if it is not built -- there is no fallback path."""
     global _lib
@@ -221,6 +224,10 @@ def load():
             'libeagcn_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
             'or `python -m eagcn_amd.build`; eagcn_amd has no CPU fallback.' % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    lib.eagcn_abi_version.restype = C.c_int
+    if lib.eagcn_abi_version() != ABI_VERSION:
+        raise EagcnHipError('libeagcn_hip.so speaks ABI version %d, this binding version %d: rebuild it '
+                            '(`python -c "import __graft_entry__ as g; g.build()"`)' % (lib.eagcn_abi_version(), ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)        # AttributeError if the symbol is missing
         fn.restype = res

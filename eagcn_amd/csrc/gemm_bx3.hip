@@ -52,7 +52,7 @@ typedef __attribute__((address_space(3))) void* bx_lds_ptr;
 
 constexpr int BX_BK = 32;
 constexpr int BX_NC = 4;                     // compute waves: 2 x 2, one 64 x 64 accumulator block each (one per SIMD)
-constexpr int BX_NL = 2;                     // loader waves (four measured the same: the fill is bound by the 64-byte row segments of the NT image, profiles/r04_lds_fill_probe.txt)
+constexpr int BX_NL = 2;                     // loader waves (four measured the same, with row-major planes and with the panel-major images: DESIGN.md section 4)
 constexpr int BX_BM = 128, BX_BN = 128;
 constexpr int BX_APL = BX_BM * 64, BX_BPL = BX_BN * 64;          // bytes of one plane image of a k-tile
 constexpr int BX_STAGE = 3 * (BX_APL + BX_BPL);                  // 48 KB

@@ -207,7 +207,7 @@ typedef struct eagcn_layer_grads {
 int eagcn_agg_wants_bond_lists(int B, int N);
 
 /* ---- library ------------------------------------------------------------------------------- */
-int eagcn_abi_version(void);
+int eagcn_abi_version(void);           /* 4 (round 4); bumped with every struct-layout / signature change */
 size_t eagcn_struct_size(int which);   /* 0 batch, 1 layout, 2 layer_params, 3 layer_bufs, 4 layer_grads,
                                           5 head_params, 6 head_grads, 7 model, 8 gat_params, 9 pool_att */
 const char* eagcn_last_error(void);
