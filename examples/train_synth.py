@@ -38,6 +38,9 @@ def main():
     ap.add_argument('--print-freq', type=int, default=50)
     ap.add_argument('--n-train', type=int, default=8, help='distinct synthetic training batches (cycled)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay of the step')
+    ap.add_argument('--optimizer', default='flat', choices=('flat', 'torch'),
+                    help="train.py:303 Adam(lr, weight_decay): 'flat' = eagcn_amd.optim.FlatAdam (one kernel over a flat parameter "
+                         "buffer, inside the captured step; models with a model-level plan), 'torch' = torch.optim.Adam")
     ap.add_argument('--loader', default='dense', choices=('dense', 'compact'),
                     help="dense: the reference's collate tensors; compact: bond list + unpadded rows (collate_compact)")
     args = ap.parse_args()
@@ -75,7 +78,11 @@ def main():
                   graph=graph, overlap_index=graph and not composed, validate='deferred' if graph else 'sync',
                   n_bucket=16 if (args.loader == 'compact' and graph) else 0).to(dev)
     model.apply(weights_init)
-    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
+    if args.optimizer == 'flat' and not composed:
+        from eagcn_amd.optim import FlatAdam
+        opt = FlatAdam(model, lr=lr, weight_decay=wd)          # built after .to(dev) and weights_init: it re-homes the parameters
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
     t0 = time.perf_counter()
     for step in range(args.steps):
         b, labels = train_set[step % len(train_set)]
