@@ -2,7 +2,7 @@
 //
 // Why not the classic LDS-tiled workgroup kernel (gemm.hip): v_mfma_f32_16x16x4_f32 is exact fp32 at the fp32 VECTOR
 // rate (32 cycles per instruction and SIMD), 16x slower than the bf16 forms, so operand delivery is cheap relative to the
-// matrix pipe -- what costs is everything that PARKS a wave.  Counters of the workgroup kernels (profiles/r02_gemm_sq.txt):
+// matrix pipe -- what costs is everything that PARKS a wave.  Counters of the workgroup kernels (profiles/r02_sq_counters.txt):
 // waves spend 27-45 % of their life in s_waitcnt / s_barrier per 16 MFMAs (LDS round trips + the barrier that couples four
 // waves on four SIMDs, each fighting other workgroups' waves for its matrix pipe) and the pipes are only 50-56 % busy.
 // Here every WAVE owns a 64x64 output tile (16 accumulators = 64 VGPRs), takes its operand fragments STRAIGHT from

@@ -118,7 +118,7 @@ __device__ __forceinline__ int bx_total_tiles(const BxProb& p, const BxStream& s
 // Two waves do nothing but LDS-DMA: wave lw requests every second 1 KB piece of the three (NP) planes of both operands of a
 // k-tile -- 8 NP instructions -- for k-tile k + 2 while the compute waves multiply k-tile k.  (Issued by the compute waves
 // themselves the twelve requests per wave and k-tile held the wave's issue port while the matrix pipe idled: fill alone 65 us,
-// products alone 59 us, together 99 us at 19 200 x 400 x 720 -- profiles/r04_bx3_probe_v1.txt.)
+// products alone 59 us, together 99 us at 19 200 x 400 x 720 -- DESIGN.md section 4 (probes EAGCN_BX3_DBG=1 / 2).)
 template <bool TN, int NP>
 __device__ __forceinline__ void bx_loader(const BxProb& p, const BxStream& st, const int lw) {
     constexpr int PPL = NP * (BX_APW + BX_BPW);

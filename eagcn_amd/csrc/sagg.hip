@@ -8,7 +8,7 @@
 //     sum_j U[i,j] P[j,:] = sum_{bonds (i,j)} sigma_ij P[j,:] + r m_i P[i,:] + 1e-9 ( S_b - sum_{bonds (i,j)} P[j,:] ),   S_b = sum_{j < nat} P[j,:]
 // -- a gather of deg + 1 rows plus ONE rank-one term per molecule.  agg.hip multiplies the full nat x nat block on the fp32
 // matrix cores: for a 256-atom molecule 99 % of its MFMA work is a multiplication by 1e-9 (the K = 8 / N = 256 config spent
-// 8.6 of its 16.3 ms there: profiles/r04a_c5_kernel_trace.txt), and for wide layers over small molecules (HIV: 1264 columns per
+// 8.6 of its 16.3 ms there: profiles/r04_c5_synth_kernel_trace.txt), and for wide layers over small molecules (HIV: 1264 columns per
 // view) it streams P at 1 TB/s.  Round 2 tried this formulation and DROPPED the rank-one term (5e-7 relative: three parity
 // cases failed by 1.0-1.3x); here it is exact: a wavefront owns whole molecules, sums the molecule's rows once (S_b, in a
 // fixed order: deterministic), then walks its rows.

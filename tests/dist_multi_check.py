@@ -124,6 +124,47 @@ for sync, overlap in ((False, False), (False, True), (True, False)):
     else:
         torch.cuda.synchronize()
         model.release_graphs()            # the local-BN model's step graphs (RCCL nodes) go before the next model captures its own
+# ---- the whole data-parallel training iteration: in-graph gradient average, then the parameter update of FlatAdam as the last
+# launch of the same graph (it must see the AVERAGED gradients): three steps against torch.optim.Adam on the float64 oracle that
+# steps on the gradient of the global loss (local-BN: the sum over the shards' own runs)
+from eagcn_amd.optim import FlatAdam
+from eagcn_amd import training
+torch.cuda.synchronize()
+model.release_graphs()                    # (the sync-BN model's step graphs)
+torch.manual_seed(1)
+model = EAGCN(9, 24, *W1, *W2, 32, 16, T, 0.0, n_layers=2, graph=True, validate='deferred').to(dev).train()
+model.load_state_dict(ref.state_dict(), strict=True)
+opt = FlatAdam(model, lr=1e-3, weight_decay=1e-4)
+red = GradientAllReducer(model.parameters(), model=model)
+m64 = RefEAGCN(9, 24, W1, W2, 32, 16, T, 0.0, n_layers=2).double()
+m64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+m64.train()
+o64 = torch.optim.Adam(m64.parameters(), lr=1e-3, weight_decay=1e-4)
+for step in range(3):
+    training.train_step(model, opt, shard, labels, 'class', bw_dev, dp_global_norm=True, reducer=red)
+    o64.zero_grad()
+    for a, b in [shard_range(BS * world, r, world) for r in range(world)]:
+        d = [t[a:b].double() if t.is_floating_point() else t[a:b] for t in dense_all]
+        (bce_sum(m64(*d)[0], labels_all[a:b]) / n_tot).backward()
+    o64.step()
+torch.cuda.synchronize()
+worst = (0.0, '')
+sd64 = dict(m64.named_parameters())
+for k, p in model.named_parameters():
+    if sd64[k].grad is None or k.endswith('graph_conv.bias') or k == 'Graph_BN.bias':
+        continue                                   # (never trained / analytically-zero gradients: Adam turns their rounding noise into +-lr steps)
+    e = (p.detach().double().cpu() - sd64[k].detach()).abs().max().item() / max(sd64[k].detach().abs().max().item(), 1e-3)
+    worst = max(worst, (e, k))
+print('rank %d: three data-parallel FlatAdam iterations (update inside the step graph, behind the captured all-reduce): worst parameter '
+      'distance to torch.optim.Adam on the float64 oracle %.1e (%s)' % (rank, worst[0], worst[1]), flush=True)
+assert worst[0] < 2e-4, worst                      # three Adam steps of lr 1e-3 move a parameter by up to 3e-3: a missed average or a
+                                                   # stale gradient shows as 1e-3, rounding noise in small second moments as 1e-5
+chk = opt.flat.double().sum().reshape(1)
+gathered = [torch.zeros_like(chk) for _ in range(world)]
+dist.all_gather(gathered, chk)
+assert all(torch.equal(gathered[0], c) for c in gathered), 'the replicas diverged'
+torch.cuda.synchronize()
+model.release_graphs()
 # Orderly teardown, in dependency order: (1) every pending collective has completed on every rank, (2) the captured step graphs
 # -- they hold RCCL kernel nodes -- and the static buffers are destroyed explicitly (EAGCN.release_graphs), not whenever the
 # garbage collector gets to them, (3) the process group (communicator + its watchdog thread) goes, (4) the process leaves

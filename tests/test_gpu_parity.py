@@ -34,7 +34,19 @@ KNOWN_FARTHER = {
                                'layer3.block1.graph_conv.weight': 1.6, 'layer4.block1.batch_norm.bn.bias': 1.9},
     # a view whose BatchNorm sees 3 x 270 rows: 1.4e-3 vs 4.2e-4 (measured ratio 3.3)
     'tox21_shape[Concate-2-3-270]': {'layer2.block4.graph_conv.weight': 3.7},
+    # ONLY in gemm mode 0 (EAGCN_GEMM_X6=0: the fp32-MFMA stream-K kernel of round 3): one weight gradient of the configs[0] shape is
+    # 2.3x farther from the float64 gradient than the reference's own fp32 one (3.1e-5 vs 1.3e-5 of its own max); the default plane
+    # GEMM (mode 3) is inside 1x on every tensor of this case
+    'configs0@mode0': {'layer2.block2.graph_conv.weight': 2.6},
 }
+
+
+def _gemm_mode():
+    from eagcn_amd import _lib as L
+    lib = L.load()
+    mode = lib.eagcn_set_gemm_mode(3)
+    lib.eagcn_set_gemm_mode(mode)
+    return mode
 
 
 def _f64_grads(g):
@@ -272,7 +284,7 @@ def test_configs0_shape_single_task_bce_vs_oracle(graph):
         assert set(gh) == set(g32)
         for k in gh:
             assert_grad_parity(gh[k], g32[k], lambda k=k: exact()[k], scale, '%s %s' % (tag, k), rtol=1e-5, floor=2e-6,
-                               known=KNOWN_FARTHER.get('configs0'))
+                               known=KNOWN_FARTHER.get('configs0@mode0' if _gemm_mode() == 0 else 'configs0'))
 
 
 @pytest.mark.parametrize('T,FIN,FP', [(4809, 400, 704), (64, 400, 704), (37, 128, 144), (1000, 256, 80), (20003, 400, 704),
