@@ -54,7 +54,6 @@ struct ModelSaved {
     uint16_t* pad_cnt;           // [B][K][ldo]: kept non-stored rows per (molecule, view, column) (readout.hip), or unused
     float* padc;                 // [B][ldo]
     uint32_t* pad_tab;           // [(N + 1)^2] binomial thresholds of the non-stored rows' kept counts (readout.hip), or unused
-    double* pad_w;               // [(N + 1)^2] their weights (scratch of the table kernel)
     size_t xout_last_off, pad_last_off;
 };
 // the last layer's non-stored rows go through a SAMPLED dropout when they reach the read-out unmasked
@@ -103,7 +102,6 @@ static size_t carve_saved(void* base, const eagcn_batch* b, const eagcn_model* m
         s.pad_cnt = c.take<uint16_t>(need ? B * last->K * ldo : 1);
         s.padc = c.take<float>(need ? B * ldo : 1);
         const size_t nt = (size_t)(b->N + 1) * (b->N + 1);
-        s.pad_w = c.take<double>(need ? nt : 1);
         s.pad_tab = c.take<uint32_t>(need ? nt : 1);
     }
     if (out) *out = s;
@@ -294,7 +292,7 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
         RC(readout_bn_forward(b, &lay, rb, stream));
     } else if (pad_sampled(m))
         RC(readout_forward_sampled(b, LL.xout, &lay, last, LL.bn + (size_t)LL.fp /* shift row of the BatchNorm table */, size,
-                                   m->molfp_mode, sv.g, F, sv.pad_cnt, sv.padc, sv.pad_tab, sv.pad_w, stream));
+                                   m->molfp_mode, sv.g, F, sv.pad_cnt, sv.padc, sv.pad_tab, stream));
     else
         RC(eagcn_readout_forward(b, LL.xout, &lay, last->structure == EAGCN_STRUCT_WEIGHTED ? LL.pad_row : nullptr,
                                  size, m->molfp_mode, sv.g, F, stream));

@@ -223,7 +223,7 @@ struct ReadoutBn {
 int readout_bn_forward(const eagcn_batch* b, const eagcn_layout* lay, const ReadoutBn& a, void* stream);
 int readout_forward_sampled(const eagcn_batch* b, const float* x, const eagcn_layout* lay, const eagcn_layer_params* p,
                             const float* bn_sh, const int64_t* size, int mode, float* g, int F, uint16_t* cnt, float* padc,
-                            uint32_t* tab, double* tab_w, void* stream);   // tab / tab_w: (N + 1)^2 words / doubles of scratch
+                            uint32_t* tab, void* stream);   // tab: (N + 1)^2 words of scratch
 int readout_backward_pad_views(const eagcn_batch* b, const float* dg, const eagcn_layout* lay, const int64_t* size, int mode,
                                int F, int K, const uint16_t* cnt, float dropout, float* dpad, void* stream);
 int readout_backward_pad(const eagcn_batch* b, const float* dg, const eagcn_layout* lay, const int64_t* size,

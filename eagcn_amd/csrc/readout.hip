@@ -42,36 +42,51 @@ struct PadSample {
     const uint32_t* tab;                     // [N + 1][N + 1] thresholds (row m: entries 0 .. m)
     int tab_ld;
 };
-// Weights relative to the mode (no underflow for any m), then the running sum: every operation a correctly rounded IEEE double
-// operation issued explicitly (no fused multiply-add), in this order.
-__global__ __launch_bounds__(64) void pad_binomial_table_kernel(eagcn_batch bt, uint32_t thr16, uint32_t* __restrict__ tab,
-                                                                 double* __restrict__ w, int tab_ld) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m > dev_n(bt) || m >= tab_ld) return;
-    uint32_t* t = tab + (size_t)m * tab_ld;
-    double* wm = w + (size_t)m * tab_ld;
+// One workgroup per m, one thread per outcome k.  Weights relative to the mode (no underflow for any m): w[k] for k >= mode is the
+// product of the ratios w[j+1] / w[j] = (m - j) r / (j + 1) from the mode up, for k < mode the product of their inverses from the
+// mode down; then the running sum.  The three scans are Hillis-Steele scans (step d = 1, 2, 4, ...: x[i] <- x[i] op x[i -+ d], all from
+// the previous step's values), every operation a correctly rounded IEEE double operation issued explicitly (no fused multiply-add):
+// a fixed order that tests/helpers.py pad_thresholds repeats in numpy.  (A first version walked each row sequentially in one thread:
+// 151 us at N = 222 -- hundreds of dependent double divisions.)
+__global__ __launch_bounds__(1024) void pad_binomial_table_kernel(eagcn_batch bt, uint32_t thr16, uint32_t* __restrict__ tab, int tab_ld) {
+    __shared__ double x_s[2][1024];
+    const int m = blockIdx.x, k = threadIdx.x;
+    if (m > dev_n(bt) || m >= tab_ld) return;           // (uniform for the workgroup)
     const double q = __dsub_rn(1.0, __ddiv_rn((double)thr16, 65536.0));           // keep probability of a 16-bit draw
     const double r = __ddiv_rn(q, __dsub_rn(1.0, q));
     int mode = (int)floor(__dmul_rn((double)(m + 1), q));
     mode = mode < 0 ? 0 : (mode > m ? m : mode);
-    wm[mode] = 1.0;
-    double v = 1.0;
-    for (int k = mode; k < m; ++k) {                     // w[k+1] = w[k] (m - k) r / (k + 1)
-        v = __ddiv_rn(__dmul_rn(v, __dmul_rn((double)(m - k), r)), (double)(k + 1));
-        wm[k + 1] = v;
-    }
-    v = 1.0;
-    for (int k = mode; k > 0; --k) {                     // w[k-1] = w[k] k / ((m - k + 1) r)
-        v = __ddiv_rn(__dmul_rn(v, (double)k), __dmul_rn((double)(m - k + 1), r));
-        wm[k - 1] = v;
-    }
-    double S = 0.0;
-    for (int k = 0; k <= m; ++k) S = __dadd_rn(S, wm[k]);
-    double c = 0.0;
-    for (int k = 0; k <= m; ++k) {
-        c = __dadd_rn(c, wm[k]);
-        const double y = __dmul_rn(__ddiv_rn(c, S), 4294967296.0);
-        t[k] = y >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)y;
+    const bool in = k <= m;
+    // scan helper: `down` = suffix scan (x[i] op x[i + d]), else prefix scan (x[i] op x[i - d]); mul or add
+    auto scan = [&](double v, bool down, bool mul) -> double {
+        int cur = 0;
+        x_s[0][k] = v;
+        __syncthreads();
+        for (int d = 1; d <= m; d <<= 1) {
+            const int o = down ? k + d : k - d;
+            double y = x_s[cur][k];
+            if (in && o >= 0 && o <= m) y = mul ? __dmul_rn(y, x_s[cur][o]) : __dadd_rn(y, x_s[cur][o]);
+            x_s[cur ^ 1][k] = y;
+            __syncthreads();
+            cur ^= 1;
+        }
+        const double res = x_s[cur][k];
+        __syncthreads();
+        return res;
+    };
+    // up[k] = ratio w[k] / w[k-1] for k > mode, else 1;  dn[k] = w[k] / w[k+1] for k < mode, else 1
+    double up = 1.0, dn = 1.0;
+    if (in && k > mode) up = __ddiv_rn(__dmul_rn((double)(m - k + 1), r), (double)k);
+    if (in && k < mode) dn = __ddiv_rn((double)(k + 1), __dmul_rn((double)(m - k), r));
+    const double pu = scan(up, false, true), pd = scan(dn, true, true);
+    const double w = k >= mode ? pu : pd;
+    const double c = scan(in ? w : 0.0, false, false);   // running sum; the total is its last entry
+    __shared__ double S_s;
+    if (k == m) S_s = c;
+    __syncthreads();
+    if (in) {
+        const double y = __dmul_rn(__ddiv_rn(c, S_s), 4294967296.0);
+        tab[(size_t)m * tab_ld + k] = y >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)y;
     }
 }
 __global__ __launch_bounds__(256) void readout_pad_sample_kernel(eagcn_batch bt, PadSample a) {
@@ -357,10 +372,10 @@ __global__ __launch_bounds__(1024) void readout_bwd_pad_kernel(eagcn_batch bt, c
 // forward read-out with the non-stored rows' dropout SAMPLED (Weighted_sum, training, p > 0): fills cnt / padc, then sums
 int readout_forward_sampled(const eagcn_batch* b, const float* x, const eagcn_layout* lay, const eagcn_layer_params* p,
                             const float* bn_sh, const int64_t* size, int mode, float* g, int F, uint16_t* cnt, float* padc,
-                            uint32_t* tab, double* tab_w, void* stream) {
+                            uint32_t* tab, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int ld = layout_ld(lay);
-    EAGCN_CHECK_ARG(b->N <= 1024, "read-out: N=%d exceeds the supported 1024 atoms", b->N);
+    EAGCN_CHECK_ARG(b->N <= 1023, "read-out of a Weighted_sum layer under dropout: N=%d exceeds the 1023 atom slots its kept-row table is built for", b->N);
     PadSample a;
     a.K = p->K; a.ld = ld; a.fp = p->K * ld;
     for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) a.off[k] = k * ld;
@@ -370,7 +385,7 @@ int readout_forward_sampled(const eagcn_batch* b, const float* x, const eagcn_la
     a.cnt = cnt; a.padc = padc;
     a.tab = tab; a.tab_ld = b->N + 1;
     ProfScope ps(PROF_READOUT, s);
-    pad_binomial_table_kernel<<<cdiv(b->N + 1, 64), 64, 0, s>>>(*b, a.thr16, tab, tab_w, a.tab_ld);
+    pad_binomial_table_kernel<<<b->N + 1, 1024, 0, s>>>(*b, a.thr16, tab, a.tab_ld);
     EAGCN_LAUNCH_CHECK();
     readout_pad_sample_kernel<<<dim3(cdiv(ld, 256), b->B), 256, 0, s>>>(*b, a);
     EAGCN_LAUNCH_CHECK();

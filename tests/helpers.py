@@ -157,28 +157,36 @@ def assert_grad_parity(got, ref32, ref64_fn, scale, name, rtol=1e-5, floor=2e-6,
 
 def pad_thresholds(m, q):
     """Row m of the binomial threshold table of csrc/readout.hip (pad_binomial_table_kernel), operation for operation in IEEE
-    double: weights relative to the mode, their running sum, t[j] = floor(2^32 P(X <= j))."""
+    double: weights relative to the mode as Hillis-Steele product scans of the ratios (upwards from the mode, downwards from it),
+    their running sum as a Hillis-Steele sum scan, t[j] = floor(2^32 P(X <= j))."""
     f = np.float64
+    q = f(q)
     r = q / (f(1.0) - q)
     mode = int(np.floor(f(m + 1) * q))
     mode = min(max(mode, 0), m)
-    w = np.zeros(m + 1, dtype=np.float64)
-    w[mode] = 1.0
-    v = f(1.0)
-    for k in range(mode, m):
-        v = (v * (f(m - k) * r)) / f(k + 1)
-        w[k + 1] = v
-    v = f(1.0)
-    for k in range(mode, 0, -1):
-        v = (v * f(k)) / (f(m - k + 1) * r)
-        w[k - 1] = v
-    S = f(0.0)
-    for k in range(m + 1):
-        S = S + w[k]
-    c = f(0.0)
-    t = np.zeros(m + 1, dtype=np.uint64)
-    for k in range(m + 1):
-        c = c + w[k]
-        y = (c / S) * f(4294967296.0)
-        t[k] = np.uint64(4294967295) if y >= 4294967295.0 else np.uint64(int(y))
-    return t
+    k = np.arange(m + 1)
+    kf = k.astype(np.float64)
+
+    def scan(x, down, mul):
+        d = 1
+        while d <= m:
+            y = x.copy()
+            if down:
+                y[:m + 1 - d] = x[:m + 1 - d] * x[d:] if mul else x[:m + 1 - d] + x[d:]
+            else:
+                y[d:] = x[d:] * x[:m + 1 - d] if mul else x[d:] + x[:m + 1 - d]
+            x = y
+            d <<= 1
+        return x
+    up = np.ones(m + 1)
+    dn = np.ones(m + 1)
+    hi = k > mode
+    lo = k < mode
+    with np.errstate(divide='ignore', invalid='ignore'):
+        up[hi] = ((f(m) - kf[hi] + f(1.0)) * r) / kf[hi]
+        dn[lo] = (kf[lo] + f(1.0)) / ((f(m) - kf[lo]) * r)
+    w = np.where(k >= mode, scan(up, False, True), scan(dn, True, True))
+    c = scan(w, False, False)
+    y = (c / c[m]) * f(4294967296.0)
+    t = np.where(y >= 4294967295.0, 4294967295.0, np.floor(y))
+    return t.astype(np.uint64)
