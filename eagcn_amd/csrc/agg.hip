@@ -706,7 +706,16 @@ __device__ __forceinline__ void edge_grad_body(const EdgeArgs& a, const int bx, 
     __syncthreads();
     const int off = a.vc.off[k], fp = a.vc.off[k + 1] - a.vc.off[k];
     double dr_acc = 0.0;
-    for (int rblk = bx; rblk * 16 < Tn; rblk += nwg) {     // one trip unless the grid was capped
+    // Which row blocks a workgroup takes.  A row's bonds point at rows of the same molecule: the P rows it gathers are its
+    // molecule's slice.  Handed out in dispatch order the 16 workgroups of a 256-atom molecule sit on all eight XCDs and every L2
+    // fetches the slice (agg_edge at K = 8 / N = 256: 10.3 GB fetched per launch for 3.8 GB of operands); with a.xcd the workgroups
+    // of one XCD (same bx mod 8) take a contiguous range of the live blocks (a bijection, as in agg_wave_body).
+    int blk0 = bx;
+    if (a.xcd) {
+        const int q8 = nwg >> 3, r8 = nwg & 7, x = bx & 7;
+        blk0 = x * q8 + min(x, r8) + (bx >> 3);
+    }
+    for (int rblk = blk0; rblk * 16 < Tn; rblk += nwg) {     // one trip unless the grid was capped
         const int r = (rblk * 4 + wave) * 4 + grp;
         int4 info = make_int4(0, 0, 0, 0);
         float rs = 0.0f;
@@ -830,7 +839,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // one workgroup per 16 packed rows; workgroups beyond the actual row count exit at once
 int edge_grid_x(const eagcn_batch* b) { return std::max(1, std::min(cdiv(b->T, 16), 1024)); }
 
-int launch_edge_grad(const EdgeArgs& a, hipStream_t s) {
+int launch_edge_grad(const EdgeArgs& a_in, hipStream_t s) {
+    EdgeArgs a = a_in;
+    a.xcd = (agg_xcd() && !agg_ksplit(&a.bt)) ? 1 : 0;
     if (a.bt.T == 0) return EAGCN_OK;
     dim3 grid(edge_grid_x(&a.bt), a.vc.K);
     ProfScope ps(PROF_EDGE, s);
@@ -840,7 +851,9 @@ int launch_edge_grad(const EdgeArgs& a, hipStream_t s) {
 }
 
 // transposed aggregation + edge gradients in one launch (see agg_edge_kernel)
-int launch_agg_edge(AggArgs a, const EdgeArgs& e, hipStream_t s) {
+int launch_agg_edge(AggArgs a, const EdgeArgs& e_in, hipStream_t s) {
+    EdgeArgs e = e_in;
+    e.xcd = (agg_xcd() && !agg_ksplit(&a.bt)) ? 1 : 0;
     if (a.bt.n_tiles == 0 || a.bt.T == 0) return EAGCN_OK;
     int tmax = 0;
     for (int k = 0; k < a.vc.K; ++k) tmax = std::max(tmax, (a.vc.off[k + 1] - a.vc.off[k]) / 16);

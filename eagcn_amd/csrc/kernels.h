@@ -33,6 +33,7 @@ struct EdgeArgs {
     const float* sig; const float* rsig; const float* rscale;
     double* datt;                // [grid.x][K][EDGE_SLAB] per-workgroup partials: 256 codes + self term ...
     int atomic;                  // ... or (atomic != 0) [EDGE_COPIES][K][EDGE_SLAB] shared accumulators (fp64 atomics)
+    int xcd = 0;                 // row blocks handed out so that an XCD works on CONTIGUOUS packed rows (agg.hip edge_grad_body)
 };
 constexpr int EDGE_SLAB = 264;
 // The edge-gradient workgroups add their bond-type histograms (a dozen non-zero bins each) to one of EDGE_COPIES fp64 accumulator

@@ -43,6 +43,22 @@ _SIDE_PLACED = os.environ.get('EAGCN_SIDE_PLACED', '0') == '1'
 # a data-parallel step whose gradient all-reduce cannot be captured into the step graph is an ERROR instead of a (warned)
 # fallback to a host-issued collective: bench.py --require-in-graph-allreduce, tools/run_scale.sh
 _REQUIRE_IN_GRAPH = os.environ.get('EAGCN_REQUIRE_IN_GRAPH_ALLREDUCE', '0') == '1'
+# Capturing a graph that contains collectives, with torch.distributed initialised: the ProcessGroupNCCL watchdog thread polls the
+# end events of the EAGER collectives issued before (the warm-up step's all-reduces, the 'dp' loss-scale collective) every 100 ms, and
+# an event recorded on the communicator's stream cannot be queried while that stream is part of a capture (hipErrorCapturedEvent:
+# "operation not permitted on an event last recorded in a capturing stream") -- the watchdog dies with that exception and takes the
+# process with it (SIGABRT; seen in ~1 of 25 runs of tests/dist_multi_check.py: gpurun_out/dist_multi_world1_rc-6.txt).  So the
+# eager collectives are allowed to finish AND to be retired by the watchdog before a capture starts: synchronize + this many seconds.
+_CAPTURE_DRAIN_S = float(os.environ.get('EAGCN_CAPTURE_DRAIN_S', '0.35'))
+
+
+def _drain_collectives(device):
+    """Before capturing a graph in a process with an initialised process group (see _CAPTURE_DRAIN_S)."""
+    import torch.distributed as dist
+    torch.cuda.synchronize(device)
+    if dist.is_available() and dist.is_initialized() and _CAPTURE_DRAIN_S > 0:
+        import time
+        time.sleep(_CAPTURE_DRAIN_S)
 
 
 class StaticIndex:
@@ -270,7 +286,7 @@ class GraphRunner:
             keep = self.flat_acc.clone()              # (gradients of earlier backward passes may be attached to it)
             self._call_backward()
             self.flat_acc.copy_(keep)
-        torch.cuda.synchronize(self.device)
+        _drain_collectives(self.device)
         fwd = torch.cuda.CUDAGraph()
         # thread_local: other threads (e.g. the RCCL watchdog of torch.distributed) may touch the HIP API during capture
         with torch.cuda.graph(fwd, capture_error_mode='thread_local'):
@@ -575,7 +591,7 @@ class GraphRunner:
                 if comm is not None:
                     comm()                                    # (host-issued average: the update below needs the averaged gradients)
             update()
-            torch.cuda.synchronize(self.device)
+            _drain_collectives(self.device)
             L.load().eagcn_prof_enable(0)
             g = torch.cuda.CUDAGraph()
             captured, failure = True, None
@@ -610,7 +626,7 @@ class GraphRunner:
                 warnings.warn('eagcn_amd: the gradient all-reduce could not be captured into the step graph (%r); falling back '
                               'to one host-issued all-reduce behind every replay' % (failure,), RuntimeWarning)
                 # the collective could not be captured: step graph without it, host-issued all-reduce behind every replay
-                torch.cuda.synchronize(self.device)
+                _drain_collectives(self.device)
                 self.comm_in_graph, in_graph = False, False
                 key = (kind, scale is not None, False, key[3])
                 g = torch.cuda.CUDAGraph()
