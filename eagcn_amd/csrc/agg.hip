@@ -710,8 +710,11 @@ __device__ __forceinline__ void edge_grad_body(const EdgeArgs& a, const int bx, 
     // molecule's slice.  Handed out in dispatch order the 16 workgroups of a 256-atom molecule sit on all eight XCDs and every L2
     // fetches the slice (agg_edge at K = 8 / N = 256: 10.3 GB fetched per launch for 3.8 GB of operands); with a.xcd the workgroups
     // of one XCD (same bx mod 8) take a contiguous range of the live blocks (a bijection, as in agg_wave_body).
+    // (only for batches of LARGE molecules -- 64 packed rows per molecule on average, from the device-side row count: the remapped
+    //  block cannot use the descriptor prefetched above, one more dependent round trip per workgroup, which costs a batch of
+    //  19-atom molecules 6 % of its step and buys it nothing: their slices are a few rows)
     int blk0 = bx;
-    if (a.xcd) {
+    if (a.xcd && Tn >= 64 * bt.B) {
         const int q8 = nwg >> 3, r8 = nwg & 7, x = bx & 7;
         blk0 = x * q8 + min(x, r8) + (bx >> 3);
     }
