@@ -707,9 +707,11 @@ __device__ __forceinline__ void edge_grad_body(const EdgeArgs& a, const int bx, 
     const int off = a.vc.off[k], fp = a.vc.off[k + 1] - a.vc.off[k];
     double dr_acc = 0.0;
     // Which row blocks a workgroup takes.  A row's bonds point at rows of the same molecule: the P rows it gathers are its
-    // molecule's slice.  Handed out in dispatch order the 16 workgroups of a 256-atom molecule sit on all eight XCDs and every L2
-    // fetches the slice (agg_edge at K = 8 / N = 256: 10.3 GB fetched per launch for 3.8 GB of operands); with a.xcd the workgroups
-    // of one XCD (same bx mod 8) take a contiguous range of the live blocks (a bijection, as in agg_wave_body).
+    // molecule's slice.  Handed out in dispatch order the 16 workgroups of a 256-atom molecule sit on all eight XCDs; with a.xcd
+    // the workgroups of one XCD (same bx mod 8) take a contiguous range of the live blocks (a bijection, as in agg_wave_body) and
+    // the gathers of a molecule meet in one L2.  Measured at K = 8 / N = 256: agg_edge<9> 2.94 -> 2.73 ms, agg_edge<4> 1.87 -> 1.63 ms,
+    // the step 16.1 -> 15.4 ms -- with the memory-side FETCH_SIZE of the launch unchanged (5.06e6 KiB raw): what was saved is L2
+    // miss latency on the gather chains, not fabric bytes.
     // (only for batches of LARGE molecules -- 64 packed rows per molecule on average, from the device-side row count: the remapped
     //  block cannot use the descriptor prefetched above, one more dependent round trip per workgroup, which costs a batch of
     //  19-atom molecules 6 % of its step and buys it nothing: their slices are a few rows)
