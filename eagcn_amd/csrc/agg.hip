@@ -49,26 +49,32 @@ __device__ __forceinline__ void agg_wave_body(const AggArgs& a, const int bx, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // independent loads at the head of the wave, requested together: its first tile's descriptor (inside the tile CAPACITY:
     // always a legal address), the device-side tile count, sigmoid(self_r), the sigmoid table
+    const int tile_id0 = bx * 4 + wave;               // the tile this wave takes first when tiles go out in dispatch order
+    int4 ti_next = reinterpret_cast<const int4*>(bt.tile_info)[min(tile_id0, max(bt.n_tiles - 1, 0))];
     const float r = a.rsig[k];
     const float sig_v = a.sig[k * 256 + tid];
     const int ntiles = dev_tiles(a.bt);
     const int nlog = dev_n(a.bt);
     if (bx * 4 >= ntiles) return;        // capacity-sized grid: no tile for this workgroup (its
                                                       // stats slab is not read either: bn_finalize counts live slabs)
+    // (the XCD-contiguous hand-out below only for batches of LARGE molecules -- four row tiles per molecule on average, from the
+    //  device-side tile count: it makes the first descriptor a load that depends on that count, one more round trip per workgroup,
+    //  and the slices of 19-atom molecules are a few rows that nobody shares)
+    const bool xcd = a.xcd && ntiles >= 4 * bt.B;
     // Which tiles a workgroup takes.  Pass p of the grid covers the tiles [p gx 4, (p+1) gx 4); the tiles of a molecule are
     // consecutive and all of them read the molecule's slice of the source matrix.  Workgroup bx runs on XCD (bx + const) % 8:
     // handed out in dispatch order, the four workgroups that share a 256-atom molecule's slice sit on four XCDs and each of
     // the four L2s fetches it.  With a.xcd the workgroups of one XCD take a CONTIGUOUS range of the pass instead (a bijection
     // of the live workgroups of the pass, from the device-side tile count), so a slice is fetched into one L2.
     auto pass_tile = [&](int base) -> int {
-        if (!a.xcd) return base + bx * 4 + wave;
+        if (!xcd) return base + bx * 4 + wave;
         const int nl = min(gx, (ntiles - base + 3) >> 2);
         if (bx >= nl) return ntiles;
         const int q8 = nl >> 3, r8 = nl & 7, x = bx & 7;
         return base + ((x * q8 + min(x, r8) + (bx >> 3)) << 2) + wave;
     };
     const int tile_first = pass_tile(0);
-    int4 ti_next = reinterpret_cast<const int4*>(bt.tile_info)[min(tile_first, max(ntiles - 1, 0))];
+    if (xcd) ti_next = reinterpret_cast<const int4*>(bt.tile_info)[min(tile_first, max(ntiles - 1, 0))];
     const int nct = min(CT, ntile_k - ct0);
     const int c0 = a.vc.off[k] + ct0 * 16;
     const int li = lane & 15, q = lane >> 4;
