@@ -30,7 +30,7 @@ class Batch(C.Structure):
                 ('rel_vec', _fp * MAX_VIEWS), ('rel_c', C.c_int32 * MAX_VIEWS),
                 ('E', C.c_int32), ('n_logical', C.c_int32), ('ecnt', _fp), ('edge0', _fp), ('mol_info', _fp), ('row_ptr', _fp),
                 ('col_ptr', _fp), ('nbr', _fp), ('tnbr', _fp), ('ecode', _fp), ('tcode', _fp),
-                ('build_lists', C.c_int32), ('reserved_', C.c_int32)]
+                ('build_lists', C.c_int32), ('t_hint', C.c_int32)]
 
 
 def set_bond_lists(c, small_ptr, ptrs, edges, E):
@@ -132,6 +132,7 @@ SIGNATURES = {
     'eagcn_adam_step': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     'eagcn_agg_wants_bond_lists': (C.c_int, [C.c_int, C.c_int]),
     'eagcn_bx3_used_splits': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'eagcn_set_bx3_wide': (C.c_int, [C.c_int]),
     'eagcn_bx3_pair_used_splits': (C.c_int, [C.c_int] * 7),
     'eagcn_bx3_plane_elems': (C.c_size_t, [C.c_int, C.c_int]),
     'eagcn_bx3_split': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_size_t, C.c_int, C.c_int, _fp]),

@@ -142,17 +142,25 @@ __device__ __forceinline__ int bx3_used_splits_wave(int cap, int K, int tiles, i
     int kt, smin, smax;
     bx3_split_range(cap, K, kt, smin, smax);
     const int s = smin + (int)(threadIdx.x & 63);
-    int key = s <= smax ? bx3_split_cost(s, kt, tiles, (ou + 7) >> 3, okt, per) * 128 + s : 0x7FFFFFFF;
+    int key = s <= smax ? bx3_split_cost(s, kt, tiles, (ou + 7) >> 3, okt, per) * 1024 + s : 0x7FFFFFFF;      // (s < 1024: layer.hip caps the slab count)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(key, o); key = other < key ? other : key; }
-    return key & 127;
+    return key & 1023;
 }
 #endif
+// tile shapes: the 128 x 128 kernel (gemm_bx3.hip: 4 compute + 2 loader waves; launches of about one wave of tiles) and the 256 x 128
+// kernel (gemm_bx3w.hip: 8 compute waves, two per SIMD; launches with several waves of tiles).  Whoever sums split-K slabs is told
+// which one wrote them (the chunk policy counts tiles).
+constexpr int BX3_BM = 128, BX3_BN = 128, BX3W_BM = 256, BX3W_BN = 128;
 bool bx3_ok(const BxProb& p);
 bool bx3_pair_policy();          // EAGCN_BX3_PAIR_POLICY=0: the chunks of a paired dW are sized as if it ran alone
 int bx3_grid();
 // np = 3: exact fp32 products from three planes; np = 1: plain bf16 operands.  p1 (optional): second product in the same launch
-int launch_bx3(const BxProb& p0, const BxProb* p1, int np, hipStream_t s, double work, int prof_tag);
+int launch_bx3(const BxProb& p0, const BxProb* p1, int np, hipStream_t s, double work, int prof_tag, int wide = 0);
+int launch_bx3w(const BxProb& p0, const BxProb* p1, int np, hipStream_t s);          // gemm_bx3w.hip
+// the host's choice between the two kernels for a launch whose NT problem has about `rows` actual rows (0: unknown -> capacity):
+// EAGCN_BX3_WIDE = 0 never | 1 always | unset: by the number of 128 x 128 tiles against the CU count
+int bx3_pick_wide(const BxProb& p0, const BxProb* p1, int rows_hint);
 // fp32 [rows][ld] -> plane images of row capacity rows_cap
 int launch_bx3_split(const float* x, int rows, const int* rows_dev, int ld, uint16_t* planes, size_t pstride, int rows_cap, int np, hipStream_t s);
 

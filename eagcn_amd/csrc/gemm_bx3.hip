@@ -53,7 +53,7 @@ typedef __attribute__((address_space(3))) void* bx_lds_ptr;
 constexpr int BX_BK = 32;
 constexpr int BX_NC = 4;                     // compute waves: 2 x 2, one 64 x 64 accumulator block each (one per SIMD)
 constexpr int BX_NL = 2;                     // loader waves (four measured the same, with row-major planes and with the panel-major images: DESIGN.md section 4)
-constexpr int BX_BM = 128, BX_BN = 128;
+constexpr int BX_BM = BX3_BM, BX_BN = BX3_BN;
 constexpr int BX_APL = BX_BM * 64, BX_BPL = BX_BN * 64;          // bytes of one plane image of a k-tile
 constexpr int BX_STAGE = 3 * (BX_APL + BX_BPL);                  // 48 KB
 constexpr int BX_NS = 3;                                         // LDS stages (144 KB)
@@ -461,6 +461,30 @@ int bx3_grid() {
     return g;
 }
 
+// ---- which of the two kernels (bx3.h) -------------------------------------------------------------------------------------------------
+static int g_bx3_wide = [] { const char* e = getenv("EAGCN_BX3_WIDE"); return e ? atoi(e) : -1; }();      // -1 auto | 0 never | 1 always
+static int bx3_wide_min(bool pair) {
+    static const int v1 = [] { const char* e = getenv("EAGCN_BX3_WIDE_MIN"); return e ? atoi(e) : 80; }();
+    static const int v2 = [] { const char* e = getenv("EAGCN_BX3_WIDE_MIN_PAIR"); return e ? atoi(e) : 50; }();
+    return pair ? v2 : v1;
+}
+int bx3_pick_wide(const BxProb& p0, const BxProb* p1, int rows_hint) {
+    if (g_bx3_wide >= 0) return g_bx3_wide ? 1 : 0;
+    // Work of the launch in k-tiles of 128 x 128 tiles per CU.  The 256 x 128 kernel moves 25 % fewer operand bytes per flop into LDS
+    // (both kernels run at the rate their CUs can fill LDS, about 33 GB/s each at these footprints: DESIGN.md section 4) and keeps two
+    // compute waves per SIMD, but it has half as many tiles to hand out: it wins from about two waves of its tiles.  A launch with a
+    // split-K product balances at chunk granularity and switches earlier.  Measured (profiles/r05_bx3w_*): 4809 rows (12 / 27 k-tiles
+    // per CU forward / pair) 24 vs 37 us and 50 vs 61 us for the 128-tile kernel; 19 200 rows (46 / 108) 75 vs 70 and 167 vs 148 us for
+    // the 256-tile kernel; 14 000 x 512 x 1040 (62 / 124) 90 vs 105 and 181 vs 163; HIV and C5 widths 1.2-1.35x for the 256-tile kernel.
+    auto work = [&](const BxProb& p) -> double {
+        int M = p.M, K = p.K;
+        if (rows_hint > 0) { if (!p.tn) M = std::min(M, rows_hint); else K = std::min(K, rows_hint); }
+        return (double)cdiv(M, BX3_BM) * cdiv(p.N, BX3_BN) * std::max(1, cdiv(K, BX_BK));
+    };
+    const double w = work(p0) + (p1 ? work(*p1) : 0.0);
+    return w >= (double)bx3_wide_min(p1 != nullptr || p0.tn) * bx3_grid() ? 1 : 0;
+}
+
 int launch_bx3_split(const float* x, int rows, const int* rows_dev, int ld, uint16_t* planes, size_t pstride, int rows_cap, int np, hipStream_t s) {
     EAGCN_CHECK_ARG(x && planes && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 &&
                         (pstride & 7) == 0, "bx3_split: operands must be 16-byte aligned with ld a multiple of 4");
@@ -501,10 +525,11 @@ static int bx3_launch_cfg(const BxProb& p0, const BxProb* p1, hipStream_t s) {
 }
 
 // np = 3: exact products; np = 1: plain bf16 operands (one plane, one product)
-int launch_bx3(const BxProb& p0, const BxProb* p1, int np, hipStream_t s, double work, int prof_tag) {
+int launch_bx3(const BxProb& p0, const BxProb* p1, int np, hipStream_t s, double work, int prof_tag, int wide) {
     EAGCN_CHECK_ARG(bx3_ok(p0) && (!p1 || bx3_ok(*p1)), "bx3 gemm: operands not aligned / extents unsupported");
     EAGCN_CHECK_ARG(np == 1 || np == 3, "bx3 gemm: 1 or 3 planes");
     ProfScope ps(prof_tag, s, work);
+    if (wide) return launch_bx3w(p0, p1, np, s);
     static const int dbg = [] { const char* e = getenv("EAGCN_BX3_DBG"); return e ? atoi(e) : 0; }();     // probes (wrong results!)
     if (np == 3 && dbg == 1) return bx3_launch_cfg<3, 1>(p0, p1, s);
     if (np == 3 && dbg == 2) return bx3_launch_cfg<3, 2>(p0, p1, s);
@@ -533,15 +558,33 @@ extern "C" int eagcn_gemm_bx3(int tn, int M, int N, int K, const uint16_t* A, si
     memset(&p, 0, sizeof(p));
     p.A = BxPlanes{A, a_pstride, lda, a_rows}; p.B = BxPlanes{B, b_pstride, ldb, b_rows}; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K; p.tn = tn; p.splits = tn ? std::max(1, splits) : 1; p.slab = slab;
-    return launch_bx3(p, nullptr, np, (hipStream_t)stream, 2.0 * M * N * K, PROF_GEMM);
+    return launch_bx3(p, nullptr, np, (hipStream_t)stream, 2.0 * M * N * K, PROF_GEMM, bx3_pick_wide(p, nullptr, 0));
 }
 
+/* -1: the library picks the kernel of a plane-GEMM launch by its size (default) | 0: always the 128 x 128 kernel | 1: always the
+ * 256 x 128 kernel (csrc/gemm_bx3w.hip).  Returns the previous setting. */
+extern "C" int eagcn_set_bx3_wide(int mode) {
+    const int old = g_bx3_wide;
+    g_bx3_wide = mode < 0 ? -1 : (mode ? 1 : 0);
+    return old;
+}
+
+static BxProb bx3_dims(int tn, int M, int N, int K) {
+    BxProb p;
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.N = N; p.K = K; p.tn = tn;
+    return p;
+}
 extern "C" int eagcn_bx3_used_splits(int splits, int M, int N, int K) {
-    return bx3_used_splits(splits < 1 ? 1 : splits, K, cdiv(M, BX_BM) * cdiv(N, BX_BN));
+    const int wide = bx3_pick_wide(bx3_dims(1, M, N, K), nullptr, 0);
+    return bx3_used_splits(splits < 1 ? 1 : splits, K, cdiv(M, wide ? BX3W_BM : BX3_BM) * cdiv(N, wide ? BX3W_BN : BX3_BN));
 }
 /* the same for the TN problem (M, N, K) of eagcn_gemm_bx3_pair, whose chunks are sized against the NT problem (M0, N0, K0) */
 extern "C" int eagcn_bx3_pair_used_splits(int splits, int M, int N, int K, int M0, int N0, int K0) {
-    return bx3_used_splits(splits < 1 ? 1 : splits, K, cdiv(M, BX_BM) * cdiv(N, BX_BN), bx3_pair_policy() ? cdiv(M0, BX_BM) * cdiv(N0, BX_BN) : 0,
+    const BxProb q = bx3_dims(1, M, N, K);
+    const int wide = bx3_pick_wide(bx3_dims(0, M0, N0, K0), &q, 0);
+    const int bm = wide ? BX3W_BM : BX3_BM, bn = wide ? BX3W_BN : BX3_BN;
+    return bx3_used_splits(splits < 1 ? 1 : splits, K, cdiv(M, bm) * cdiv(N, bn), bx3_pair_policy() ? cdiv(M0, bm) * cdiv(N0, bn) : 0,
                            std::max(1, cdiv(K0, BX_BK)), std::max(1, bx3_grid() >> 3));
 }
 
@@ -557,5 +600,5 @@ extern "C" int eagcn_gemm_bx3_pair(int M0, int N0, int K0, const uint16_t* A0, s
     p.M = M0; p.N = N0; p.K = K0; p.tn = 0; p.splits = 1;
     q.A = BxPlanes{A1, a1_pstride, lda1, a1_rows}; q.B = BxPlanes{B1, b1_pstride, ldb1, b1_rows}; q.C = C1; q.ldc = ldc1;
     q.M = M1; q.N = N1; q.K = K1; q.tn = 1; q.splits = std::max(1, splits); q.slab = slab;
-    return launch_bx3(p, &q, np, (hipStream_t)stream, 2.0 * M0 * N0 * K0 + 2.0 * M1 * N1 * K1, PROF_GEMM_PAIR);
+    return launch_bx3(p, &q, np, (hipStream_t)stream, 2.0 * M0 * N0 * K0 + 2.0 * M1 * N1 * K1, PROF_GEMM_PAIR, bx3_pick_wide(p, &q, 0));
 }

@@ -621,13 +621,15 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
                                                             int ld_in, int fp, const float* __restrict__ dWcat,
                                                             int nsplit, size_t slab, double* __restrict__ datt,
                                                             int nedge, const float* __restrict__ rsig, int wblocks,
-                                                            const int32_t* __restrict__ meta, int xk_G, int edge_drain, int bx_per) {
+                                                            const int32_t* __restrict__ meta, int xk_G, int edge_drain, int bx_per, int bx_wide) {
     nedge = nedge < 0 ? -nedge : min(nedge, (meta[EAGCN_META_T] + 15) / 16);   // edge-gradient workgroups that had rows (< 0: all wrote)
     // split-K partials actually written: gemm.hip writes eff_splits of them; the plane GEMM (gemm_bx3.hip) passes its slab count
     // negated and writes bx3_used_splits() of them
     // (bx_per > 0: the weight gradient shared its launch with the dX product -- T x ld_in over fp -- and sized its chunks against it)
-    nsplit = nsplit < 0 ? bx3_used_splits_wave(-nsplit, meta[EAGCN_META_T], ((ld_in + 127) >> 7) * ((fp + 127) >> 7),
-                                          bx_per > 0 ? ((meta[EAGCN_META_T] + 127) >> 7) * ((ld_in + 127) >> 7) : 0, max(1, (fp + 31) >> 5), bx_per)
+    // (tiles of the kernel that wrote them: 128 x 128, or 256 x 128 for gemm_bx3w.hip)
+    const int bxm = bx_wide ? BX3W_BM : BX3_BM, bxn = bx_wide ? BX3W_BN : BX3_BN;
+    nsplit = nsplit < 0 ? bx3_used_splits_wave(-nsplit, meta[EAGCN_META_T], ((ld_in + bxm - 1) / bxm) * ((fp + bxn - 1) / bxn),
+                                          bx_per > 0 ? ((meta[EAGCN_META_T] + bxm - 1) / bxm) * ((ld_in + bxn - 1) / bxn) : 0, max(1, (fp + 31) >> 5), bx_per)
                         : max(1, min(nsplit, meta[EAGCN_META_T] >> 7));
     if ((int)blockIdx.x < wblocks) {
         // split-K slabs: FOUR lanes per element, each adds every fourth slab (the first layer's weight gradient leaves gemm.hip
@@ -777,7 +779,9 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     d.np = (d.ld_in >= 128 && (d.ld_in & 15) == 0 && (d.fp & 15) == 0) ? gemm_planes() : 0;
     // slab capacity of the weight gradient's k-chunks (how many are used is decided on the device from the actual row count:
     // bx3.h bx3_used_splits)
-    d.bx_splits = std::max(1, std::min(64, std::max(cdiv(std::max(b->T, 1), 4096), cdiv(std::max(b->T, 1), 256))));
+    // (at most 64 slabs, but never k-chunks beyond the 4096 rows gemm_bx3.hip's accumulation chains are bounded to: T > 262144 rows
+    //  takes more slabs instead of longer chunks; < 1024 = the key packing of bx3_used_splits_wave)
+    d.bx_splits = std::max(1, std::min(std::min(1023, std::max(64, cdiv(std::max(b->T, 1), 4096))), std::max(cdiv(std::max(b->T, 1), 4096), cdiv(std::max(b->T, 1), 256))));
     return d;
 }
 
@@ -1029,7 +1033,7 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
             bp.M = b->T; bp.N = d.fp; bp.K = d.ld_in; bp.M_dev = b->meta + EAGCN_META_T; bp.tn = 0; bp.splits = 1;
         }
         if (d.np && bx3_ok(bp)) {
-            rc = launch_bx3(bp, nullptr, d.np, s, gemm_work, PROF_GEMM);
+            rc = launch_bx3(bp, nullptr, d.np, s, gemm_work, PROF_GEMM, bx3_pick_wide(bp, nullptr, b->t_hint));
         } else if (gemm3_layer(d.ld_in) && gemm3_ok(g3)) {
             rc = launch_gemm3(g3, nullptr, sc.gws, gemm3_workspace_bytes(), s);
         } else {
@@ -1243,6 +1247,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     int nsplit = 0, nedge = 0, xk_G = 0;
     bool bx_slabs = false;       // dWcat holds the k-chunk slabs of the plane GEMM (all of them written)
     int bx_per = 0;              // > 0: that product shared its launch with dX (workgroups per XCD: bx3.h bx3_used_splits)
+    int bx_wide = 0;             // ... and which of the two plane-GEMM kernels wrote the slabs (the chunk policy counts ITS tiles)
     // side = stream for work that is off the dX critical path (edge gradients, dW product, gradient
     // unpacking); with no auxiliary stream everything stays in order on s
     hipStream_t side = w->aux_stream ? (hipStream_t)w->aux_stream : s;
@@ -1311,7 +1316,8 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         dsc.vc = d.vc;
         dsc.in = in;
         if (use_bx) {
-            rc = dx ? launch_bx3(bx, &bw, d.np, s, 2.0 * gemm_work, PROF_GEMM_PAIR) : launch_bx3(bw, nullptr, d.np, s, gemm_work, PROF_GEMM);
+            bx_wide = dx ? bx3_pick_wide(bx, &bw, b->t_hint) : bx3_pick_wide(bw, nullptr, b->t_hint);
+            rc = dx ? launch_bx3(bx, &bw, d.np, s, 2.0 * gemm_work, PROF_GEMM_PAIR, bx_wide) : launch_bx3(bw, nullptr, d.np, s, gemm_work, PROF_GEMM, bx_wide);
             if (rc) return rc;
             nsplit = d.bx_splits;                         // partial slabs of dWcat: summed and scattered by unpack_grads below
             bx_slabs = true;
@@ -1359,7 +1365,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         ProfScope psu(PROF_PACK, side);
         unpack_grads_kernel<<<wblocks + cdiv(p->K * EDGE_SLAB, 16), 256, 0, side>>>(gp, pp, d.vc, in, d.ld_in, d.fp, sc.dWcat,
                                                                                     bx_slabs ? -nsplit : nsplit, d.wslab, edge_src, nedge, sc.rsig,
-                                                                                    wblocks, b->meta, xk_G, edge_drain, bx_per);
+                                                                                    wblocks, b->meta, xk_G, edge_drain, bx_per, bx_wide);
         EAGCN_LAUNCH_CHECK();
     }
     // join: the caller reuses the scratch block (dY', dP, partial slabs) for the next layer

@@ -43,6 +43,8 @@ _SIDE_PLACED = os.environ.get('EAGCN_SIDE_PLACED', '0') == '1'
 # a data-parallel step whose gradient all-reduce cannot be captured into the step graph is an ERROR instead of a (warned)
 # fallback to a host-issued collective: bench.py --require-in-graph-allreduce, tools/run_scale.sh
 _REQUIRE_IN_GRAPH = os.environ.get('EAGCN_REQUIRE_IN_GRAPH_ALLREDUCE', '0') == '1'
+# EAGCN_COMM_IN_GRAPH=0: never try to capture the collective -- the host-issued fallback from the first step on (tests exercise it)
+_COMM_IN_GRAPH = os.environ.get('EAGCN_COMM_IN_GRAPH', '1') != '0'
 # Capturing a graph that contains collectives, with torch.distributed initialised: the ProcessGroupNCCL watchdog thread polls the
 # end events of the EAGER collectives issued before (the warm-up step's all-reduces, the 'dp' loss-scale collective) every 100 ms, and
 # an event recorded on the communicator's stream cannot be queried while that stream is part of a capture (hipErrorCapturedEvent:
@@ -171,7 +173,7 @@ class GraphRunner:
         self.weight_static = torch.zeros((m.head.nclass, 2), **f32)
         self.loss_static = [torch.zeros((), **f32) for _ in range(2)]
         self.scale_static = [torch.ones((), **f32) for _ in range(2)]      # per slot: written by the NEXT batch's preparation
-        self.comm_in_graph = None      # gradient all-reduce captured inside the step graph (None: not tried yet)
+        self.comm_in_graph = None if _COMM_IN_GRAPH else False   # gradient all-reduce captured inside the step graph (None: not tried yet)
         n = plan.offsets[-1]
         self.flat_acc = torch.zeros(n, **f32)               # the captured backward writes here; p.grad are views of it
         self.acc_views = plan.grad_views(self.flat_acc)
@@ -432,10 +434,23 @@ class GraphRunner:
             self.plan.nbt_pending += 1    # num_batches_tracked: counted on the host, written by ModelPlan.flush_nbt()
         return main
 
+    def _set_row_hint(self):
+        """Before a slot's sequences are captured: tell the library how many packed rows THIS batch holds (eagcn_batch.t_hint).
+        The captured launches are fixed for every later batch of the shape; the buffers are sized for row_cap (default B * N, 7x
+        the rows of a Tox21 batch), and the size-dependent kernel choices (the plane GEMM's tile shape) should follow the rows
+        batches of this shape really have.  One host wait, once per slot."""
+        slot = (self.step - 1) % _RING
+        ev = self.meta_event[slot]
+        if ev is not None:
+            ev.synchronize()
+        t = int(self.meta_host[slot][L.META_T])
+        self.index.c.t_hint = max(1, min(t, self.index.T)) if t > 0 else 0
+
     def forward(self, adj, rels, afm, size, seed, overlap=False, bonds=None):
         main = self._prepare(adj, rels, afm, size, seed, overlap, bonds)
         cur = self.cur
         if self.graphs[cur][0] is None:
+            self._set_row_hint()
             self._call_forward()                              # first use of a slot: eager (and the capture warm-up)
             self._capture()
         else:
@@ -582,6 +597,7 @@ class GraphRunner:
                 optimizer.launch(self.flat_acc)
         first_eager = self.graphs[cur][2] is None or self.step_kind[cur] != key
         if first_eager:
+            self._set_row_hint()
             self._call_forward()                              # eager (first use of the slot / of this loss): the warm-up
             self._call_loss(key[0], key[1])
             if in_graph:
@@ -589,7 +605,9 @@ class GraphRunner:
             else:
                 self._call_backward()
                 if comm is not None:
-                    comm()                                    # (host-issued average: the update below needs the averaged gradients)
+                    # host-issued average of the flat buffer itself (the .grad views are attached only below: after zero_grad they are
+                    # None here and GradientAllReducer.__call__ would find nothing to reduce); the update below needs the average
+                    comm.start(self.flat_acc).wait()
             update()
             _drain_collectives(self.device)
             L.load().eagcn_prof_enable(0)
@@ -607,6 +625,8 @@ class GraphRunner:
                         if comm is None:
                             update()
             except L.EagcnHipError:
+                if in_graph:
+                    comm.agree(False)                         # (the other ranks are waiting in agree() below: fail with them, not hang them)
                 raise                                         # one of OUR launches failed: never hidden behind a re-capture
             except Exception as e:                            # noqa: BLE001 -- the capture of the collective failed on this stack
                 if not in_graph:

@@ -208,6 +208,7 @@ class BatchIndex:
         self.tile_mol = rows[o + 4 * T:]
         self._rows = rows
         c.T, c.n_max, c.n_tiles = T, self.n_max, self.n_tiles
+        c.t_hint = int(self.rows)                            # (exact here; with a row_cap the buffers are larger than the batch)
         rb = rows.data_ptr()
         c.row_info, c.tile_info = rb, rb + 16 * T
         ob = rb + 4 * o

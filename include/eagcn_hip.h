@@ -125,7 +125,9 @@ typedef struct eagcn_batch {
     uint64_t* tcode;                        /* [E] column lists: the same for bond (i,j)                     */
     int32_t build_lists;                    /* HOST input of eagcn_index_rows: build the bond lists (GAT layers; the
                                                opt-in sparse aggregation builds them regardless)               */
-    int32_t reserved_;
+    int32_t t_hint;                         /* HOST hint: about how many packed rows batches of this shape really hold (0: unknown ->
+                                               T).  Only steers size-dependent kernel CHOICES whose launch is baked into a captured
+                                               graph (the plane GEMM's tile shape); every kernel is correct for any actual count.   */
 } eagcn_batch;
 
 /* column layout of a packed activation matrix */
@@ -444,6 +446,11 @@ int eagcn_bx3_split(const float* x, int rows, int ld, uint16_t* planes, size_t p
  *         z < eagcn_bx3_used_splits(splits, M, N, K) (at least 768 and at most 4096 rows of K per chunk; slabs beyond that count are
  *         NOT written), whose sum is the product. */
 int eagcn_bx3_used_splits(int splits, int M, int N, int K);
+/* Two kernels serve these entry points (csrc/bx3.h): 128 x 128 tiles, 4 compute + 2 loader waves (launches of about one wave of tiles)
+ * and 256 x 128 tiles, 8 compute waves = two per SIMD (csrc/gemm_bx3w.hip; launches with several waves of tiles).  mode -1: picked per
+ * launch by its size (default; EAGCN_BX3_WIDE in the environment presets it) | 0: always the first | 1: always the second.
+ * Returns the previous setting.  The used-splits queries follow the setting. */
+int eagcn_set_bx3_wide(int mode);
 /* ... of the TN problem (M, N, K) of eagcn_gemm_bx3_pair: its chunks are sized against the NT problem (M0, N0, K0) of the launch */
 int eagcn_bx3_pair_used_splits(int splits, int M, int N, int K, int M0, int N0, int K0);
 int eagcn_gemm_bx3(int tn, int M, int N, int K, const uint16_t* A, size_t a_pstride, int lda, int a_rows, const uint16_t* B,

@@ -16,6 +16,16 @@ def _lib():
     return L.load(), L
 
 
+@pytest.fixture(params=[0, 1], ids=['tile128x128', 'tile256x128'])
+def wide(request):
+    """Both kernels behind the entry points (csrc/bx3.h): gemm_bx3.hip (4 compute + 2 loader waves) and gemm_bx3w.hip (8 compute waves,
+    two per SIMD, staggered); the library picks by launch size, the tests force each."""
+    lib, _ = _lib()
+    old = lib.eagcn_set_bx3_wide(request.param)
+    yield request.param
+    lib.eagcn_set_bx3_wide(old)
+
+
 def _planes(x, np_=3, spare_rows=5):
     """Plane images (panel-major, include/eagcn_hip.h) of a contiguous fp32 CUDA matrix [R, ld] -> (int16 tensor, plane stride, row
     capacity).  The images are pre-filled with bf16 NaNs and given a few spare rows: whatever the split does not write (spare rows,
@@ -77,8 +87,8 @@ def _err(got, A64, B64, tn):
 
 
 @pytest.mark.parametrize('M,N,K,pad', [(128, 128, 32, 0), (100, 90, 48, 8), (4809, 720, 400, 16), (37, 16, 128, 0), (300, 200, 24, 8),
-                                       (2500, 1264, 512, 0), (1, 1, 8, 0)])
-def test_nt_product_vs_float64(M, N, K, pad):
+                                       (2500, 1264, 512, 0), (1, 1, 8, 0), (77000, 130, 72, 0), (257, 129, 40, 0)])
+def test_nt_product_vs_float64(M, N, K, pad, wide):
     """C = A.B^T (forward P = X.Wcat^T and dX = dP.Wcat: both operands K-contiguous); K a multiple of 8, leading dimensions larger than
     K (whatever follows the k range in a row must not reach a result)."""
     torch.manual_seed(M + N + K)
@@ -93,8 +103,8 @@ def test_nt_product_vs_float64(M, N, K, pad):
 
 
 @pytest.mark.parametrize('M,N,K,splits', [(128, 128, 32, 1), (100, 90, 75, 1), (400, 720, 4809, 6), (400, 720, 4809, 1), (512, 1024, 3000, 3),
-                                          (128, 16, 37, 2), (64, 64, 700, 64), (8, 8, 1, 1)])
-def test_tn_product_vs_float64(M, N, K, splits):
+                                          (128, 16, 37, 2), (64, 64, 700, 64), (8, 8, 1, 1), (300, 260, 33000, 40), (257, 129, 33, 1)])
+def test_tn_product_vs_float64(M, N, K, splits, wide):
     """C = A^T.B (dW = X^T.dP: the reduction runs over the packed rows) as k-chunk slabs; rows beyond K read as zero; slabs beyond
     eagcn_bx3_used_splits are not written."""
     lib, _ = _lib()
@@ -108,7 +118,7 @@ def test_tn_product_vs_float64(M, N, K, splits):
     assert 1 <= used <= splits and torch.isnan(raw[used:]).all() and not torch.isnan(raw[:used, :, :N]).any()
 
 
-def test_pair_launch_equals_the_two_products():
+def test_pair_launch_equals_the_two_products(wide):
     """dX + dW in one persistent launch: dX bit for bit what the separate launch computes; the weight gradient is cut into k-chunks
     sized against the dX units of the same launch (eagcn_bx3_pair_used_splits), so its bits depend on the cut -- held to the float64
     product like every other TN case, and the slabs beyond the used count stay untouched."""
@@ -135,7 +145,7 @@ def test_pair_launch_equals_the_two_products():
     assert e <= 8 * 2.0 ** -24, e
 
 
-def test_long_same_sign_reduction_does_not_drift():
+def test_long_same_sign_reduction_does_not_drift(wide):
     """The bf16 MFMA accumulate is not round-to-nearest; the kernel keeps the exact leading products apart from the five small ones
     (gemm_bx3.hip): a 4096-row chunk -- the longest chain the layer path cuts -- stays within 2e-8 of the float64 sum on average."""
     torch.manual_seed(9)
@@ -149,7 +159,7 @@ def test_long_same_sign_reduction_does_not_drift():
 
 
 @pytest.mark.parametrize('structure', ['Concate', 'Weighted_sum'])
-def test_model_in_plane_mode_against_fp32_mfma_mode(structure):
+def test_model_in_plane_mode_against_fp32_mfma_mode(structure, wide):
     """Same model, same batch: gemm mode 3 (the default) against mode 0 (fp32 MFMA): outputs to 1e-5, every gradient to 1e-5 of its
     own largest entry + 2e-6 of the case's (the two differ in the rounding of the layer products only)."""
     from eagcn_amd import EAGCN

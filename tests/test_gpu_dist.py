@@ -41,6 +41,29 @@ def _run_multi(world, port):
     return r.stdout
 
 
+@pytest.mark.timeout(900)
+def test_host_issued_allreduce_fallback_averages_before_the_update():
+    """EAGCN_COMM_IN_GRAPH=0: the collective is never captured; every step (a slot's first eager step included, where no .grad is
+    attached yet) must average the whole flat gradient buffer exactly once before FlatAdam consumes it."""
+    import torch
+    n = min(torch.cuda.device_count(), 4)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29561', HSA_ENABLE_IPC_MODE_LEGACY='0', EAGCN_COMM_IN_GRAPH='0')
+    script = os.path.join(ROOT, 'tests', 'dist_fallback_check.py')
+    if n < 2:
+        n = 1
+        env.update(EAGCN_FORCE_DIST='1', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+        cmd = [sys.executable, script]
+    else:
+        for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+            env.pop(k, None)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+               '--master-port', '29561', script]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840)
+    if r.returncode != 0 or r.stdout.count('DIST_FALLBACK_OK') != n:
+        _dump('dist_fallback_rc%d' % r.returncode, r)
+    assert r.returncode == 0 and r.stdout.count('DIST_FALLBACK_OK') == n, (r.stdout[-3000:], r.stderr[-4000:])
+
+
 def _dump(tag, r):
     """Keep the complete outputs of a failed rank launch (pytest elides long assertion messages)."""
     d = os.path.join(ROOT, 'gpurun_out')

@@ -177,3 +177,64 @@ def test_flat_buffer_allreduce_bce_global_norm_and_sync_bn_world2_gloo():
         assert err_bce < 1e-5, (rank, err_bce)
         assert err_bn < 1e-9, (rank, err_bn)
         assert unused_none
+
+
+# ---- four ranks, uneven shards (10 molecules -> 3 / 3 / 2 / 2), the BUCKETED asynchronous form of the graph-mode step -------------
+def _worker_ws4(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from eagcn_amd.parallel import dp_loss_scale
+    from oracle.eagcn_ref import classification_loss
+    torch.manual_seed(0)                                   # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    g = torch.Generator().manual_seed(5)
+    n_items = 10
+    x_all = torch.randn(n_items, 6, generator=g)
+    labels_all = torch.tensor([[1, 0, -1], [0, -1, -1], [-1, -1, -1], [1, 1, 0], [0, 0, 0], [1, -1, -1], [-1, -1, -1], [-1, 0, -1],
+                               [-1, -1, -1], [-1, -1, 1]], dtype=torch.float32)
+    bw = [[5.0, 1.2], [3.0, 1.1], [7.0, 1.05]]
+    lo, hi = shard_range(n_items, rank, world)
+    sizes = [b - a for a, b in (shard_range(n_items, r, world) for r in range(world))]
+    scale = dp_loss_scale(labels_all[lo:hi])               # this shard may hold no labelled entry at all (rank 3 has one)
+    (classification_loss(net(x_all[lo:hi]), labels_all[lo:hi], bw) * scale).backward()
+    params = list(net.parameters())
+    # the flat gradient buffer of graph mode: .grad are views of it; layer 1 = first bucket [0, cut), the rest = upper bucket
+    flat = torch.cat([p.grad.reshape(-1) for p in params]).clone()
+    o = 0
+    for p in params:
+        p.grad = flat[o:o + p.numel()].view_as(p)
+        o += p.numel()
+    cut = params[0].numel() + params[1].numel()
+    red = GradientAllReducer(params)
+    upper = red.start(flat[cut:])                          # started first (the upper layers finish their backward first) ...
+    filler = torch.randn(32, 32) @ torch.randn(32, 32)     # ... the first layer's backward runs beside it ...
+    upper.wait()
+    red.start(flat[:cut]).wait()                           # ... and its own bucket follows
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    ref.load_state_dict(net.state_dict())
+    classification_loss(ref(x_all), labels_all, bw).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    err = float((flat - want).abs().max() / want.abs().max()) + 0.0 * float(filler.sum())
+    views_ok = all(p.grad.data_ptr() >= flat.data_ptr() for p in params)
+    q.put((rank, sizes, err, views_ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bucketed_allreduce_uneven_shards_world4_gloo():
+    """SURVEY 8(e) at four ranks: 10 molecules shard 3 / 3 / 2 / 2; the global BCE normalisation ('dp' scale) times the bucketed,
+    asynchronously started average of the flat gradient buffer == the gradient of the reference's loss on the whole batch."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ws4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, sizes, err, views_ok in res:
+        assert sizes == [3, 3, 2, 2], sizes
+        assert err < 1e-5, (rank, err)
+        assert views_ok

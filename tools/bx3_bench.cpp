@@ -146,21 +146,27 @@ static void time_layer(const char* name, int T, int FIN, int FP, int iters) {
     void* ws; CK(hipMalloc(&ws, wsb));
     const double f1 = 2.0 * T * FIN * FP;
     float t;
-    printf("%s: T=%d F_in=%d Fp=%d (dW k-chunks used: %d alone, %d beside dX)\n", name, T, FIN, FP, eagcn_bx3_used_splits(splits, FIN, FP, T),
-           eagcn_bx3_pair_used_splits(splits, FIN, FP, T, T, FIN, FP));
-    t = time_fn(iters, [&] { RC(eagcn_gemm_bx3(0, T, FP, FIN, X.pl, X.pstride, FIN, X.cap, WT.pl, WT.pstride, FIN, WT.cap, P, FP, 1, 0, 3, nullptr)); });
-    printf("  forward   bx3 %8.1f us  %6.1f TF", t, f1 / t * 1e-6);
+    printf("%s: T=%d F_in=%d Fp=%d\n", name, T, FIN, FP);
+    // both kernels behind the entry points (csrc/bx3.h): 128 x 128 tiles (4 compute + 2 loader waves) | 256 x 128 tiles (8 compute waves)
+    float tf[2], tx[2], tw[2], tp[2]; int used[2], usedp[2];
+    for (int w = 0; w < 2; ++w) {
+        const int old = eagcn_set_bx3_wide(w);
+        used[w] = eagcn_bx3_used_splits(splits, FIN, FP, T); usedp[w] = eagcn_bx3_pair_used_splits(splits, FIN, FP, T, T, FIN, FP);
+        tf[w] = time_fn(iters, [&] { RC(eagcn_gemm_bx3(0, T, FP, FIN, X.pl, X.pstride, FIN, X.cap, WT.pl, WT.pstride, FIN, WT.cap, P, FP, 1, 0, 3, nullptr)); });
+        tx[w] = time_fn(iters, [&] { RC(eagcn_gemm_bx3(0, T, FIN, FP, dP.pl, dP.pstride, FP, dP.cap, W.pl, W.pstride, FP, W.cap, dX, FIN, 1, 0, 3, nullptr)); });
+        tw[w] = time_fn(iters, [&] { RC(eagcn_gemm_bx3(1, FIN, FP, T, X.pl, X.pstride, FIN, X.cap, dP.pl, dP.pstride, FP, dP.cap, dW, FP, splits, slab, 3, nullptr)); });
+        tp[w] = time_fn(iters, [&] { RC(eagcn_gemm_bx3_pair(T, FIN, FP, dP.pl, dP.pstride, FP, dP.cap, W.pl, W.pstride, FP, W.cap, dX, FIN, FIN, FP, T, X.pl, X.pstride, FIN, X.cap, dP.pl,
+                                                            dP.pstride, FP, dP.cap, dW, FP, splits, slab, 3, nullptr)); });
+        eagcn_set_bx3_wide(old);
+    }
+    printf("  (dW k-chunks used: 128-tile kernel %d alone / %d beside dX; 256-tile kernel %d / %d)\n", used[0], usedp[0], used[1], usedp[1]);
     t = time_fn(iters, [&] { RC(eagcn_gemm_f32_sk(0, 1, T, FP, FIN, X.d, FIN, WT.d, FIN, P, FP, ws, wsb, nullptr)); });
-    printf("   | fp32 MFMA %8.1f us  %6.1f TF\n", t, f1 / t * 1e-6);
-    t = time_fn(iters, [&] { RC(eagcn_gemm_bx3(0, T, FIN, FP, dP.pl, dP.pstride, FP, dP.cap, W.pl, W.pstride, FP, W.cap, dX, FIN, 1, 0, 3, nullptr)); });
-    printf("  dX        bx3 %8.1f us  %6.1f TF\n", t, f1 / t * 1e-6);
-    t = time_fn(iters, [&] { RC(eagcn_gemm_bx3(1, FIN, FP, T, X.pl, X.pstride, FIN, X.cap, dP.pl, dP.pstride, FP, dP.cap, dW, FP, splits, slab, 3, nullptr)); });
-    printf("  dW        bx3 %8.1f us  %6.1f TF\n", t, f1 / t * 1e-6);
-    t = time_fn(iters, [&] { RC(eagcn_gemm_bx3_pair(T, FIN, FP, dP.pl, dP.pstride, FP, dP.cap, W.pl, W.pstride, FP, W.cap, dX, FIN, FIN, FP, T, X.pl, X.pstride, FIN, X.cap, dP.pl,
-                                                    dP.pstride, FP, dP.cap, dW, FP, splits, slab, 3, nullptr)); });
-    printf("  dX + dW   bx3 %8.1f us  %6.1f TF", t, 2 * f1 / t * 1e-6);
+    printf("  forward   128x128 %8.1f us %6.1f TF | 256x128 %8.1f us %6.1f TF | fp32 MFMA %8.1f us %6.1f TF\n", tf[0], f1 / tf[0] * 1e-6, tf[1], f1 / tf[1] * 1e-6, t, f1 / t * 1e-6);
+    printf("  dX        128x128 %8.1f us %6.1f TF | 256x128 %8.1f us %6.1f TF\n", tx[0], f1 / tx[0] * 1e-6, tx[1], f1 / tx[1] * 1e-6);
+    printf("  dW        128x128 %8.1f us %6.1f TF | 256x128 %8.1f us %6.1f TF\n", tw[0], f1 / tw[0] * 1e-6, tw[1], f1 / tw[1] * 1e-6);
     t = time_fn(iters, [&] { RC(eagcn_gemm_pair_sk(T, FIN, FP, dP.d, FP, W.d, FP, dX, FIN, FIN, FP, T, X.d, FIN, dP.d, FP, dW, FP, ws, wsb, nullptr)); });
-    printf("   | fp32 MFMA %8.1f us  %6.1f TF\n", t, 2 * f1 / t * 1e-6);
+    printf("  dX + dW   128x128 %8.1f us %6.1f TF | 256x128 %8.1f us %6.1f TF | fp32 MFMA %8.1f us %6.1f TF\n", tp[0], 2 * f1 / tp[0] * 1e-6, tp[1], 2 * f1 / tp[1] * 1e-6, t, 2 * f1 / t * 1e-6);
+    fflush(stdout);
     (void)hipFree(P); (void)hipFree(dX); (void)hipFree(dW); (void)hipFree(ws);
 }
 
@@ -231,6 +237,11 @@ int main(int argc, char** argv) {
     if (!strcmp(mode, "bias")) { bias_test(512); bias_test(4096); bias_test(25000); bias_test(100000); return 0; }
     printf("abi %d\n", eagcn_abi_version());
     if (!strcmp(mode, "check")) {
+      for (int w = 0; w < 2; ++w) {
+        printf("---- %s kernel\n", w ? "256 x 128 (gemm_bx3w.hip)" : "128 x 128 (gemm_bx3.hip)");
+        eagcn_set_bx3_wide(w);
+        check_nt(77000, 130, 72, 0);
+        check_tn(300, 260, 33000, 40, 0);
         check_nt(128, 128, 32, 0);
         check_nt(128, 128, 64, 0);
         check_nt(100, 90, 48, 7);
@@ -246,8 +257,20 @@ int main(int argc, char** argv) {
         check_tn(400, 720, 4809, 1, 0);
         check_tn(512, 1024, 3000, 3, 0);
         check_tn(128, 16, 37, 2, 0);
+      }
+        eagcn_set_bx3_wide(-1);
         printf(fails ? "BX3_CHECK FAILED (%d)\n" : "BX3_CHECK OK\n", fails);
         return fails ? 1 : 0;
+    }
+    if (getenv("BX3_WIDE")) eagcn_set_bx3_wide(atoi(getenv("BX3_WIDE")));
+    if (!strcmp(mode, "fwd")) {          // fwd <T> <FIN> <FP> <iters> <wide>: the forward product only, one kernel (counter passes)
+        const int T = atoi(argv[2]), FIN = atoi(argv[3]), FP = atoi(argv[4]), iters = argc > 5 ? atoi(argv[5]) : 5;
+        eagcn_set_bx3_wide(argc > 6 ? atoi(argv[6]) : 1);
+        Mat X(T, FIN, FIN), WT(FP, FIN, FIN, 0.05f);
+        float* P; CK(hipMalloc(&P, (size_t)T * FP * 4));
+        const float t = time_fn(iters, [&] { RC(eagcn_gemm_bx3(0, T, FP, FIN, X.pl, X.pstride, FIN, X.cap, WT.pl, WT.pstride, FIN, WT.cap, P, FP, 1, 0, 3, nullptr)); });
+        printf("forward T=%d F_in=%d Fp=%d: %.1f us  %.1f TF\n", T, FIN, FP, t, 2.0 * T * FIN * FP / t * 1e-6);
+        return 0;
     }
     if (!strcmp(mode, "one")) {          // one <T> <FIN> <FP> <iters>: a single layer shape (profiling runs)
         time_layer("one", atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 5);
