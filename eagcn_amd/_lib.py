@@ -15,6 +15,7 @@ MAX_SEGS = 8
 META_WORDS = 16
 META_NLOG = 8
 META_T, META_NMAX, META_NTILES, META_BAD_ADJ, META_BAD_REL, META_NEDGE, META_OVERFLOW, META_EDGE_OVERFLOW = range(8)
+META_NBLK = 9
 STRUCT_CONCATE, STRUCT_WEIGHTED = 0, 1
 
 _fp = C.c_void_p   # device pointers travel as integers
@@ -30,16 +31,23 @@ class Batch(C.Structure):
                 ('rel_vec', _fp * MAX_VIEWS), ('rel_c', C.c_int32 * MAX_VIEWS),
                 ('E', C.c_int32), ('n_logical', C.c_int32), ('ecnt', _fp), ('edge0', _fp), ('mol_info', _fp), ('row_ptr', _fp),
                 ('col_ptr', _fp), ('nbr', _fp), ('tnbr', _fp), ('ecode', _fp), ('tcode', _fp),
-                ('build_lists', C.c_int32), ('t_hint', C.c_int32)]
+                ('build_lists', C.c_int32), ('t_hint', C.c_int32), ('blk', _fp)]
+
+
+def bond_ptrs_len(T, B):
+    return 4 * T + 4 * B + 8 * (B + 1) + 8
 
 
 def set_bond_lists(c, small_ptr, ptrs, edges, E):
     """Point the bond-list fields of a Batch at their buffers: `small_ptr` = device address of [ecnt B | edge0 B+1] int32,
-    `ptrs` = int32 [4*T + 4*B] (row_ptr | col_ptr | mol_info), `edges` = int32 [6*E + 2] (nbr | tnbr | ecode u64 | tcode u64)."""
+    `ptrs` = int32 [bond_ptrs_len(T, B)] (row_ptr | col_ptr | mol_info | blk), `edges` = int32 [6*E + 2]
+    (nbr | tnbr | ecode u64 | tcode u64)."""
     c.E = int(E)
     c.ecnt, c.edge0 = small_ptr, small_ptr + 4 * c.B
     pb, T = ptrs.data_ptr(), c.T
     c.row_ptr, c.col_ptr, c.mol_info = pb, pb + 8 * T, pb + 16 * T
+    blk = pb + 16 * T + 16 * c.B
+    c.blk = blk + (-blk) % 16 if ptrs.numel() >= bond_ptrs_len(T, c.B) else None      # (int4 records)
     eb = edges.data_ptr()
     c.nbr, c.tnbr = eb, eb + 4 * E
     code = eb + 8 * E
@@ -212,7 +220,7 @@ class EagcnHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4    # include/eagcn_hip.h eagcn_abi_version(): struct layouts + signatures this binding was written against
+ABI_VERSION = 5    # include/eagcn_hip.h eagcn_abi_version(): struct layouts + signatures this binding was written against
 
 
 def load():

@@ -485,6 +485,54 @@ __global__ __launch_bounds__(256) void index_rows_kernel(eagcn_batch bt) {
     }
 }
 
+// Row blocks of the LDS-staged aggregation (csrc/lagg.hip): whole molecules, packed greedily in batch order to at most LAGG_RB packed
+// rows and LAGG_MAXM molecules per block (a molecule larger than LAGG_RB rows gets a block of its own: the launcher never takes such a
+// batch).  Block q is described by two int4 records, blk[2q] = {first molecule, molecules, first packed row, rows} and blk[2q+1] =
+// {first list entry, list entries, 0, 0} -- everything a workgroup needs to request its data with ONE dependent load.  The packing is
+// sequential by nature; ONE wavefront does it 64 molecules at a time (prefix sum of the row counts, then one ballot per closed block).
+__global__ __launch_bounds__(64) void index_blocks_kernel(eagcn_batch bt) {
+    const int lane = threadIdx.x;
+    const int T = bt.meta[EAGCN_META_T];
+    int4* out = reinterpret_cast<int4*>(bt.blk);
+    int nb = 0, start = 0, rows = 0, cnt = 0;                        // the open block: first molecule, rows and molecules so far
+    int start_r0 = 0, start_e0 = 0;                                  // ... its first packed row and first list entry
+    auto close = [&](int end, int end_e0) {                          // molecules [start, end)
+        if (lane == 0) {
+            out[2 * nb] = make_int4(start, end - start, start_r0, rows);
+            out[2 * nb + 1] = make_int4(start_e0, end_e0 - start_e0, 0, 0);
+        }
+        ++nb; rows = 0; cnt = 0;
+    };
+    int last_e0 = 0;
+    for (int base = 0; base < bt.B && T > 0; base += 64) {
+        const int nv = min(64, bt.B - base);                         // molecules of this chunk
+        // one batch of loads per chunk (a closed block used to cost three dependent loads: 0.77 ms for 1024 one-molecule blocks)
+        const int n = lane < nv ? max(bt.nat[base + lane], 0) : 0;
+        const int r0v = bt.row0[min(base + lane, bt.B)], e0v = bt.edge0[min(base + lane, bt.B)];
+        const int e0_end = bt.edge0[min(base + 64, bt.B)];
+        int pre = n;                                                 // inclusive prefix of the row counts
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pre, o); if (lane >= o) pre += t; }
+        int pos = 0, before = 0;                                     // first molecule of the chunk not yet placed, rows in front of it
+        while (pos < nv) {
+            // lanes pos .. fit into the open block as long as rows and molecule count allow (monotone in the lane); an EMPTY block
+            // takes its first molecule whatever its size
+            const bool fits = lane >= pos && lane < nv &&
+                              ((rows + pre - before <= LAGG_RB && cnt + lane - pos + 1 <= LAGG_MAXM) || (cnt == 0 && lane == pos));
+            const int nfit = __popcll(__ballot(fits));
+            if (nfit > 0) {
+                if (cnt == 0) { start = base + pos; start_r0 = __shfl(r0v, pos); start_e0 = __shfl(e0v, pos); }
+                const int upto = __shfl(pre, pos + nfit - 1);
+                rows += upto - before; cnt += nfit; pos += nfit; before = upto;
+            }
+            if (pos < nv) close(base + pos, __shfl(e0v, pos));       // the next molecule does not fit: the block is complete
+        }
+        last_e0 = e0_end;
+    }
+    if (cnt > 0) close(bt.B, last_e0);
+    if (lane == 0) bt.meta[EAGCN_META_NBLK] = nb;
+}
+
 // Bond lists of one molecule (one workgroup each) from its code maps: row lists (bonds (i,j) of row i, j ascending) and
 // column lists (bonds (i,j) into column j, i ascending), each with the K per-view bond-type codes of the bond in one
 // 64-bit word.  Only bonds with both ends inside the molecule's nat rows are listed (what the dense kernels multiply,
@@ -775,7 +823,11 @@ extern "C" int eagcn_index_rows(const eagcn_batch* b, void* stream) {
     ProfScope ps(PROF_INDEX, s);
     index_rows_kernel<<<b->B, 256, 0, s>>>(*b);
     EAGCN_LAUNCH_CHECK();
-    if (!b->build_lists) return EAGCN_OK;   // bond lists: GAT layers (gat.hip)
+    if (!b->build_lists) return EAGCN_OK;   // bond lists: GAT layers (gat.hip), bond-list aggregation (lagg.hip)
+    if (b->blk) {
+        index_blocks_kernel<<<1, 64, 0, s>>>(*b);
+        EAGCN_LAUNCH_CHECK();
+    }
     const int W = (b->N + 31) / 32;
     if (b->N <= 512) index_csr_kernel<true><<<b->B, 256, (size_t)b->N * W * sizeof(uint32_t), s>>>(*b, W);
     else index_csr_kernel<false><<<b->B, 256, 0, s>>>(*b, W);

@@ -26,6 +26,16 @@ bool sagg_use(const eagcn_batch* b);          // this batch takes that path (pol
 int sagg_grid_x(const eagcn_batch* b);        // its workgroups along x = BatchNorm partial slabs, all of them written
 int launch_sagg(AggArgs a, bool trans, hipStream_t s);
 
+// ... and LDS-staged (lagg.hip): a workgroup owns a ROW BLOCK of whole molecules (eagcn_batch.blk) x a 32-column chunk of one view
+constexpr int LAGG_RB = 256;                 // packed rows per block (= the largest molecule the path takes)
+constexpr int LAGG_MAXM = 16;                // molecules per block
+struct EdgeArgs;
+int lagg_parts();
+bool lagg_use(const eagcn_batch* b);         // this batch takes that path (policy + the index carries bond lists and row blocks)
+int lagg_slabs(const eagcn_batch* b);        // capacity of its BatchNorm partial slabs (one per row block; meta[NBLK] of them are live)
+int launch_lagg_fwd(AggArgs a, hipStream_t s);
+int launch_lagg_bwd(AggArgs a, const EdgeArgs& e, hipStream_t s);   // transposed aggregation + edge gradients (e.atomic must be set)
+
 struct EdgeArgs {
     eagcn_batch bt;
     ViewCols vc;

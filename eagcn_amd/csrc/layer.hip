@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void bn_stats_sum_kernel(const double* __restr
                                                             int mode, int tiles_per_wg, int nvirt, int batch_B) {
     if (meta[EAGCN_META_NLOG] > 0) M = (double)batch_B * (double)meta[EAGCN_META_NLOG];
     if (mode == 1 && tiles_per_wg > 0) nslab = min(nslab, (meta[EAGCN_META_NTILES] + tiles_per_wg - 1) / tiles_per_wg);
+    if (mode == 1 && tiles_per_wg < 0) nslab = min(nslab, meta[EAGCN_META_NBLK]);      // (lagg.hip: one slab per row block)
     if (mode == 2) nslab = max(1, min(nslab, (meta[EAGCN_META_T] + nvirt + BWD_ROWS - 1) / BWD_ROWS));
     const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
     const int cp = min(cpr, fp - 1);
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     if (meta[EAGCN_META_NLOG] > 0) M = (double)batch_B * (double)meta[EAGCN_META_NLOG];    // (M was computed from the capacity N)
     if (M_dev) M = *M_dev;                             // sync-BatchNorm: rows of ALL ranks (slab = the all-reduced sums)
     if (tiles_per_wg > 0) nslab = min(nslab, (meta[EAGCN_META_NTILES] + tiles_per_wg - 1) / tiles_per_wg);   // (0: every slab is written)
+    if (tiles_per_wg < 0) nslab = min(nslab, meta[EAGCN_META_NBLK]);                    // (lagg.hip: one slab per row block)
     const int cpr = blockIdx.x * (256 / L) + threadIdx.x / L, sl = threadIdx.x % L;
     const int cp = min(cpr, fp - 1);
     double s1 = 0.0, s2 = 0.0;
@@ -748,6 +750,7 @@ struct Carver {
 struct LayerDims {
     ViewCols vc;
     int fp, ld_in, fin, ldo, gx, gxb, nsplit;
+    int gslab;                   // capacity of the forward BatchNorm partial slabs (the aggregation kernels' grids)
     size_t wslab;
     size_t wpslab, wtpslab;      // plane images (bx3.h) of Wcat [ld_in rows][fp] and WcatT [fp rows][ld_in]
     int np;                      // 3 / 1: this layer's products run from bf16 operand planes (gemm_bx3.hip); 0: fp32 operands
@@ -761,6 +764,7 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     d.fin = layout_width(&p->in);
     d.ldo = p->structure == EAGCN_STRUCT_CONCATE ? d.fp : pad16(p->width[0]);
     d.gx = agg_grid_x(b);
+    d.gslab = std::max(d.gx, lagg_use(b) ? lagg_slabs(b) : 0);
     // row-partial slabs of the BatchNorm backward: 7 rows per workgroup, at most 2048 workgroups and at most
     // 32 MB of fp64 partials (wide layers: Fp = 6320 -> 331 workgroups).  Fewer, longer workgroups were measured
     // slower (the kernel is bound by its instruction stream and one memory round trip per 7-row batch, not by the
@@ -831,7 +835,7 @@ static size_t carve_fwd(void* base, const eagcn_batch* b, const LayerDims& d, Fw
     t.rsig = c.take<float>(EAGCN_MAX_VIEWS);
     t.Wp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wpslab : 1);
     t.WTp = c.take<uint16_t>(d.np ? (size_t)d.np * d.wtpslab : 1);
-    t.stats = c.take<double>((size_t)d.gx * d.fp * 2);
+    t.stats = c.take<double>((size_t)d.gslab * d.fp * 2);
     t.gsum = c.take<double>((size_t)2 * d.fp + 8);
     t.xp = c.take<uint16_t>(d.np ? (size_t)d.np * bx_plane_elems(b->T, d.ld_in) : 1);
     if (s) *s = t;
@@ -1046,7 +1050,11 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
             AggArgs a;
             a.bt = *b; a.vc = d.vc; a.src = w->P; a.lds = d.fp; a.dst = w->Y; a.ldd = d.fp;
             a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = sc.stats; a.nchunk = 1;
-            if (sagg_use(b)) {                                 // bond-list aggregation (sagg.hip): every slab is written
+            if (lagg_use(b) && (lagg_parts() & 1)) {           // LDS-staged bond-list aggregation (lagg.hip): one slab per row block
+                rc = launch_lagg_fwd(a, s);
+                nslab = lagg_slabs(b);
+                tiles_per_wg = -1;
+            } else if (sagg_use(b)) {                          // bond-list aggregation (sagg.hip): every slab is written
                 rc = launch_sagg(a, false, s);
                 nslab = sagg_grid_x(b);
                 tiles_per_wg = 0;
@@ -1287,7 +1295,10 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         if (edge_atomic && !general_rel) { e.datt = sc.eacc; e.atomic = 1; }
         static const bool colaunch = [] { const char* v = getenv("EAGCN_NO_COLAUNCH"); return !(v && v[0] == '1'); }();
         nedge = e.atomic ? -EDGE_COPIES : edge_grid_x(b);
-        if (sagg_use(b)) {                                                       // bond-list aggregation (sagg.hip)
+        if (lagg_use(b) && e.atomic && (lagg_parts() & 2)) {                     // transposed aggregation + edge gradients from the same LDS gathers
+            rc = launch_lagg_bwd(a, e, s);
+            if (rc) return rc;
+        } else if (sagg_use(b)) {                                                // bond-list aggregation (sagg.hip)
             if (forked) { rc = stream_after(side, s); if (rc) return rc; }
             rc = launch_edge_grad(e, side);
             if (rc) return rc;

@@ -80,7 +80,7 @@ class StaticIndex:
         rows = torch.zeros(8 * self.T + 5 * self.n_tiles, **i32)
         # bond lists (GAT layers, csrc/gat.hip): capacity in directed bonds; a molecular graph has 2-2.5 per atom
         self.E = int(edge_cap) if edge_cap else min(self.T * N, max(8 * self.T, 1024))
-        self._ptrs = torch.zeros(4 * self.T + 4 * B, **i32)
+        self._ptrs = torch.zeros(L.bond_ptrs_len(self.T, B), **i32)
         self._edges = torch.zeros(6 * self.E + 2, **i32)       # nbr | tnbr | ecode (u64) | tcode (u64)
         self._blob, self._rows = blob, rows
         o = B * N

@@ -214,7 +214,7 @@ class BatchIndex:
         ob = rb + 4 * o
         c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = ob, ob + 4 * T, ob + 8 * T, ob + 12 * T, ob + 16 * T
         self.E = max(int(self.n_edges), 1)
-        self._ptrs = torch.zeros(4 * T + 4 * B, **i32)
+        self._ptrs = torch.zeros(L.bond_ptrs_len(T, B), **i32)
         self._edges = torch.empty(6 * self.E + 2, **i32)
         L.set_bond_lists(c, base + 4 * (B * N + 3 * B + 2 + L.META_WORDS), self._ptrs, self._edges, self.E)
         # bond lists: the GAT layers, and the bond-list form of the aggregation where the library picks it (csrc/sagg.hip)

@@ -78,6 +78,7 @@ extern "C" {
                                  (eagcn_batch.n_logical): the reference pads every batch to its own maximum (utils.py:583) and
                                  counts the padding rows in its BatchNorm statistics and filler weights, so kernels take
                                  B * N_logical, N_logical - nat[b] from here; 0 = eagcn_batch.N                           */
+#define EAGCN_META_NBLK 9     /* row blocks of eagcn_batch.blk (bond-list aggregation, csrc/lagg.hip)               */
 #define EAGCN_META_WORDS 16
 
 typedef struct eagcn_batch {
@@ -128,6 +129,11 @@ typedef struct eagcn_batch {
     int32_t t_hint;                         /* HOST hint: about how many packed rows batches of this shape really hold (0: unknown ->
                                                T).  Only steers size-dependent kernel CHOICES whose launch is baked into a captured
                                                graph (the plane GEMM's tile shape); every kernel is correct for any actual count.   */
+    int32_t* blk;                           /* [8 (B + 1)] (optional, 16-byte aligned; built by eagcn_index_rows with the bond lists):
+                                               ROW BLOCKS of the LDS-staged aggregation (csrc/lagg.hip) -- whole molecules, greedily
+                                               packed to at most 256 packed rows and 16 molecules; block q = two int4 records {first
+                                               molecule, molecules, first packed row, rows} {first list entry, entries, 0, 0};
+                                               meta[NBLK] blocks                                                                    */
 } eagcn_batch;
 
 /* column layout of a packed activation matrix */
@@ -209,7 +215,7 @@ typedef struct eagcn_layer_grads {
 int eagcn_agg_wants_bond_lists(int B, int N);
 
 /* ---- library ------------------------------------------------------------------------------- */
-int eagcn_abi_version(void);           /* 4 (round 4); bumped with every struct-layout / signature change */
+int eagcn_abi_version(void);           /* 5 (round 5); bumped with every struct-layout / signature change */
 size_t eagcn_struct_size(int which);   /* 0 batch, 1 layout, 2 layer_params, 3 layer_bufs, 4 layer_grads,
                                           5 head_params, 6 head_grads, 7 model, 8 gat_params, 9 pool_att */
 const char* eagcn_last_error(void);

@@ -173,6 +173,13 @@ def test_model_in_plane_mode_against_fp32_mfma_mode(structure, wide):
         try:
             torch.manual_seed(3)
             m = EAGCN(28, 24, *[48] * 5, *[64] * 5, 64, 32, 3, 0.0, structure=structure, n_layers=3, grad_mode='direct').cuda().train()
+            # the head's relus never gate (BatchNorm biases at +6, as tests/test_gpu_fullsize.py): with 48 molecules ONE head unit whose
+            # pre-activation sits within rounding of zero flips its gate between two arithmetically equivalent paths and moves the
+            # gradients of everything below it by 1/48 (seen when the aggregation kernel changed, round 5: den1 / Graph_BN / every
+            # ave.weight off by 1-5 % with outputs equal to 1e-6 and every saved activation equal to rounding)
+            with torch.no_grad():
+                m.bn_den1.bias.fill_(6.0)
+                m.bn_den2.bias.fill_(6.0)
             torch.manual_seed(4)
             cot = torch.randn(48, 3, device='cuda')
             out, _, gr = m(*dense)
