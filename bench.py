@@ -47,13 +47,13 @@ WORKLOADS = {
                      all_full=True, task='reg'),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 2.4 GHz
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 (v_mfma_f32_32x32x16_bf16); an exact fp32 product costs SIX of them (gemm_bx3.hip)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 (v_mfma_f32_32x32x16_bf16); an fp32-equivalent product costs SIX of them (gemm_bx3.hip)
 GEMM_MODES = {0: 'f32 (fp32 MFMA v_mfma_f32_16x16x4_f32, exact fp32 products)',
               3: 'f32 (bf16x3 split, fp32 accumulate): every fp32 operand leaves its producer as three bf16 planes, six v_mfma_f32_32x32x16_bf16 '
                  'piece products per 16 k rebuild the fp32 product (csrc/gemm_bx3.hip); aggregation, BatchNorm, head, first layer fp32',
               4: 'bf16 operands (ONE plane, round to nearest even), fp32 accumulate: BASELINE configs[1] as written; NOT the parity path'}
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = next((os.path.join('profiles', f) for f in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
+PMC_FILE = next((os.path.join('profiles', f) for f in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
                  if os.path.exists(os.path.join(ROOT, 'profiles', f))), os.path.join('profiles', 'r04_pmc_traffic.json'))
 
 
@@ -120,6 +120,22 @@ def algorithmic_bytes(cfg, sizes, n_pad):
     return dense, act
 
 
+def moved_bytes(cfg, mb):
+    """Bytes the DESIGN has to move per step (what `hbm_frac_moved` prices against 8 TB/s): the adjacency read once (4 B N_pad^2),
+    one 32-byte sector per (directed bond, relation channel) for the gathered one-hot channels, the uint8 bond codes written once
+    and read by the aggregation of every layer and direction, and the per-layer activation minimum of algorithmic_bytes().  The
+    84 %% of SURVEY 8(d)'s byte count that are dense one-hot relation planes are NOT in it: the index never streams them."""
+    chans = rel_channels(cfg)
+    K = len(chans)
+    E = int(mb.edges.shape[0])
+    rows = float(sum(int(n) for n in mb.sizes))
+    ldc = (mb.N + 15) // 16 * 16
+    adj = 4.0 * mb.B * mb.N * mb.N
+    gathered = 32.0 * E * sum(chans)
+    codes = K * rows * ldc * (1 + 3 * cfg['n_layers'])               # written once; read forward, transposed and by the edge gradients
+    return adj + gathered + codes + algorithmic_bytes(cfg, mb.sizes, mb.N)[1]
+
+
 def committed_traffic(kernel_substr):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of this command
     (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json; rocprofv3 cannot run inside bench.py)."""
@@ -134,7 +150,7 @@ def committed_traffic(kernel_substr):
     return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in big) / n, PMC_FILE
 
 
-def cpu_baseline(cfg, mb, dropout, bce_w, steps=5, warmup=2):
+def cpu_baseline(cfg, mb, dropout, bce_w, steps=5, warmup=2, threads=None):
     """The CPU oracle (oracle/eagcn_ref.py, kind 'port') timed on this host, same workload."""
     from oracle.eagcn_ref import RefEAGCN, classification_loss, regression_loss, weights_init_
     avail = os.cpu_count() or 1
@@ -157,8 +173,8 @@ def cpu_baseline(cfg, mb, dropout, bce_w, steps=5, warmup=2):
 
     # the many small ATen ops of this path do not scale to hundreds of threads: pick the fastest of a few thread counts,
     # each judged by the median of three steps after a warm-up step at that count, and report it as `cores`
-    best = (None, 1e30)
-    for nt in [c for c in (8, 16, 32, 64) if c <= avail] or [avail]:
+    best = (threads, 1e30)
+    for nt in ([] if threads else ([c for c in (8, 16, 32, 64) if c <= avail] or [avail])):
         torch.set_num_threads(nt)
         one_step()
         ts = []
@@ -190,9 +206,10 @@ def cpu_baseline(cfg, mb, dropout, bce_w, steps=5, warmup=2):
         pass
     return {'value': mb.B / med, 'unit': 'molecules/s', 'cores': cores, 'kind': 'port',
             'sample': '%d timed fwd+bwd steps (median, after %d warm-up) of the same %d-molecule batch (%d tasks, N_pad %d), '
-                      'oracle/eagcn_ref.py RefEAGCN on torch %s CPU, %d threads (fastest of 8/16/32/64 by the median of 3 warmed '
-                      'steps each), %s'
-                      % (steps, warmup, mb.B, cfg['nclass'], mb.N, torch.__version__, cores, model_name or 'unknown CPU')}
+                      'oracle/eagcn_ref.py RefEAGCN on torch %s CPU, %d threads (%s), %s'
+                      % (steps, warmup, mb.B, cfg['nclass'], mb.N, torch.__version__, cores,
+                         'the count found fastest at batch 256' if threads else 'fastest of 8/16/32/64 by the median of 3 warmed steps each',
+                         model_name or 'unknown CPU')}
 
 
 def run_workload(name, B, args, lib, dev, rank, world, reducer_cls, detail):
@@ -293,6 +310,7 @@ def run_workload(name, B, args, lib, dev, rank, world, reducer_cls, detail):
         raise SystemExit('non-finite loss')
     res = {'cfg': cfg, 'mb': mb, 'bce_w': bce_w, 'B': B, 'blocks': sorted(blocks),
            'gflop': algorithmic_flops(cfg, mb.sizes) / 1e9, 'N': mb.N, 'bytes': algorithmic_bytes(cfg, mb.sizes, mb.N),
+           'moved': moved_bytes(cfg, mb),
            'rank_ms': None, 'allreduce': None}
     if dist.is_initialized() and world > 1:
         mine = torch.tensor([sorted(blocks)[len(blocks) // 2] / args.steps * 1e3], dtype=torch.float64, device=dev)
@@ -360,6 +378,8 @@ def summarize(res, args, world):
             # "report both numbers per config; relevant roofline = max(T_flops, T_bytes)"
             'algorithmic_mbytes_per_step': {'dense_inputs': round(dense_b / 1e6, 1), 'activations': round(act_b / 1e6, 1)},
             'hbm_frac': round(t_hbm / ms, 4), 'relevant_roofline': 'hbm' if t_hbm > t_mfma else 'mfma',
+            # the same against the bytes the design must move (moved_bytes(): no dense one-hot planes)
+            'moved_mbytes_per_step': round(res['moved'] / 1e6, 1), 'hbm_frac_moved': round(res['moved'] / (PEAK_HBM_GBS * 1e6) / ms, 4),
             'relevant_frac': round(max(t_hbm, t_mfma) / ms, 4)}
 
 
@@ -442,7 +462,7 @@ def main():
                        'parallelism': 'dp%d' % world},
             'algorithmic_gflop_per_step': head['algorithmic_gflop_per_step'],
             'roofline': {'kernel': (('bx3_kernel<3> (dX = dP.W^T and dW = X^T.dP of a hidden layer in one persistent launch from bf16x3 operand planes: '
-                                     '6 x v_mfma_f32_32x32x16_bf16 per exact fp32 product)' if gemm_mode == 3 else
+                                     '6 x v_mfma_f32_32x32x16_bf16 per fp32-equivalent product: piece products to 3 x 2^-24, fp32 accumulate)' if gemm_mode == 3 else
                                      'gemm3_kernel<false, true, true> (dX = dP.W^T and dW = X^T.dP of a hidden layer in one balanced launch, fp32 MFMA)')
                                     if pair else 'layer GEMMs (flat X.[W_1..W_K] transform and its backward products)'),
                          'bound': 'mfma', 'achieved': round(achieved, 3),
@@ -460,6 +480,9 @@ def main():
                                          'signature delivers them, read once + per-layer activation minimum) / ms_per_step / 8 TB/s; the '
                                          'implementation streams adj and gathers the relation channels at the bonds only'},
                          'relevant': head['relevant_roofline'], 'relevant_step_frac': head['relevant_frac'],
+                         'hbm_frac_moved': head['hbm_frac_moved'], 'moved_mbytes_per_step': head['moved_mbytes_per_step'],
+                         'hbm_frac_moved_note': 'whole step against 8 TB/s on the bytes the design has to move (adjacency once, one sector per '
+                                                'bond and relation channel, bond codes, activation minimum): bench.py moved_bytes()',
                          'traffic': None if traffic is None else round(traffic),
                          'traffic_note': None if traffic is None else
                          'bytes per launch, memory-side FETCH_SIZE x2 + WRITE_SIZE from %s' % traffic_src,
@@ -530,6 +553,21 @@ def main():
                 c1 = dict(WORKLOADS['tox21_c2'], nclass=1)
                 mb1 = make_batch(B=64, n_max=c1['n_max'], n_med=c1['n_med'], rel_channels=rel_channels(c1), seed=4321, n_tasks=1, task='class')
                 out['cpu_baseline_configs0'] = cpu_baseline(c1, mb1, args.dropout, bce_w_of(c1), steps=args.cpu_steps)
+                # the north-star batch (BASELINE.json north_star quotes its >= 10x target at batch 1024): two timed steps at the thread
+                # count found above (a step is ~10 s of CPU work)
+                mb2 = make_batch(B=1024, n_max=cfg['n_max'], n_med=cfg['n_med'], rel_channels=rel_channels(cfg), seed=1234, n_tasks=cfg['nclass'], task=cfg['task'])
+                out['cpu_baseline_b1024'] = cpu_baseline(cfg, mb2, args.dropout, bce_w_of(cfg), steps=2, warmup=1, threads=out['cpu_baseline']['cores'])
+        # the numbers DESIGN.md quotes, compact, at the END of the line (the driver keeps the tail of long lines)
+        summ = {'c2': [out['ms_per_step'], out['value']], 'roofline_frac': out['roofline']['frac'], 'dominant_kernel_us': out['roofline']['avg_launch_us'],
+                'step_frac': out['roofline']['step_frac'], 'hbm_frac_moved': out['roofline']['hbm_frac_moved']}
+        for k, e in out.get('extra', {}).items():
+            summ[k] = [e['ms_per_step'], e['value']]
+        for k in ('cpu_baseline', 'cpu_baseline_configs0', 'cpu_baseline_b1024'):
+            if k in out:
+                summ[k] = [round(out[k]['value'], 1), out[k]['cores']]
+        if 'cpu_baseline_b1024' in out and 'extra' in out and 'b1024' in out['extra']:
+            summ['b1024_gpu_over_cpu'] = round(out['extra']['b1024']['value'] / out['cpu_baseline_b1024']['value'], 1)
+        out['extra_summary'] = summ
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         # orderly teardown: no captured graph (they hold RCCL kernels) and no pending collective outlives the communicator

@@ -600,8 +600,11 @@ __device__ __forceinline__ void agg_body(const AggArgs& a, const int bx, const i
     }
 }
 
+// (register budget: 128 = four waves per SIMD up to six column tiles; the software pipeline of agg_wave_body needs more from seven tiles
+//  on -- at 128 the 9-tile instantiations that BASELINE's wide layers run spilled inside their MFMA loops -- and gets
+//  168 = three waves per SIMD there; EAGCN_AGG_WIDE_REGS in tools/r5_agg_regs.sh is the A/B)
 template <int CT, bool TRANS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg_wave_kernel(AggArgs a) { agg_wave_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT >= 7 ? 3 : 4, 8))) void agg_wave_kernel(AggArgs a) { agg_wave_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 template <int CT, bool TRANS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg_kernel(AggArgs a) { agg_body<CT, TRANS>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 // two waves per workgroup: most tiles have one or two column groups, so two of four waves would idle
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(256) void edge_grad_kernel(EdgeArgs a) { edge_grad_
 // alone -- side by side they overlap instead of running back to back.  Workgroups [0, agg_gx) of every grid row
 // run the aggregation, the rest the edge gradients (grid rows beyond the view count have none).
 template <int CT, bool KSPLIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void agg_edge_kernel(AggArgs a, EdgeArgs e, int agg_gx) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT >= 7 && !KSPLIT) ? 3 : 4, 8))) void agg_edge_kernel(AggArgs a, EdgeArgs e, int agg_gx) {
     const int bx = blockIdx.x;
     if (bx < agg_gx) {
         if constexpr (KSPLIT) agg_body<CT, true>(a, bx, blockIdx.y, agg_gx);

@@ -1,4 +1,4 @@
-// Exact-fp32 layer products at the bf16 matrix rate: operands arrive as THREE bf16 PLANES written by their producers.
+// fp32-EQUIVALENT layer products at the bf16 matrix rate (exact operand split; piece products to 3 x 2^-24 |a b|; fp32 accumulate): operands arrive as THREE bf16 PLANES written by their producers.
 //
 // An fp32 value splits exactly into three bf16 pieces, x = x0 + x1 + x2 (8 + 8 + 8 significand bits, by truncation; bx3_split
 // below), and a product is rebuilt from the six piece products of weight >= 2^-16 with fp32 accumulation,
@@ -235,18 +235,18 @@ __device__ __forceinline__ void bx_compute(const BxProb& p, const BxStream& st, 
         const int row = 8 * (b >> 1) + (c >> 2), ch = 2 * (b & 1) + ((c & 3) >> 1), half = 8 * (c & 1);
         const int lo_off = row * 64 + ((ch ^ (2 * (b >> 1))) << 4) + half;
         const int hi_off = (row + 4) * 64 + ((ch ^ (2 * (b >> 1) + 1)) << 4) + half;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            fa[t] = (2 * wm + t) * 2048 + lo_off; fah[t] = (2 * wm + t) * 2048 + hi_off;
-            fb[t] = (2 * wn + t) * 2048 + lo_off; fbh[t] = (2 * wn + t) * 2048 + hi_off;
-        }
+        // (tile t of a wave = panel 2 w + t: + t * 2048 bytes, a compile-time offset of the read -- only FOUR offset registers live
+        //  across the k-loop; eight put the 128 x 128 kernel two registers over its 256 and it re-loaded them from scratch every k-tile)
+        fa[0] = (2 * wm) * 2048 + lo_off; fah[0] = (2 * wm) * 2048 + hi_off;
+        fb[0] = (2 * wn) * 2048 + lo_off; fbh[0] = (2 * wn) * 2048 + hi_off;
+        fa[1] = fb[1] = fah[1] = fbh[1] = 0;
     }
     auto frag = [&](const unsigned char* plane, int t, int s, bool is_a) __attribute__((always_inline)) -> bx_bf16x8 {
         if constexpr (!TN) {
             const int off = (is_a ? fa[s] : fb[s]) + t * 32 * 64;
             return __builtin_bit_cast(bx_bf16x8, *reinterpret_cast<const bx_u32x4*>(plane + off));
         } else {
-            const int off = (is_a ? fa[t] : fb[t]) + 16 * s * 64, offh = (is_a ? fah[t] : fbh[t]) + 16 * s * 64;
+            const int off = (is_a ? fa[0] : fb[0]) + t * 2048 + 16 * s * 64, offh = (is_a ? fah[0] : fbh[0]) + t * 2048 + 16 * s * 64;
             const bx_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bx_s16x4 __attribute__((address_space(3)))*)(plane + off));
             const bx_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bx_s16x4 __attribute__((address_space(3)))*)(plane + offh));
             typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -259,7 +259,7 @@ __device__ __forceinline__ void bx_compute(const BxProb& p, const BxStream& st, 
     // 100 000; the fp32 MFMA stays at 1e-9), because every one of the six piece products of a k-step costs the running sum a
     // truncation at ITS magnitude.  Five of the six carry a weight of 2^-8 or less: they go to `lo`, whose own magnitude is 2^-8
     // of the result (its truncations are worth 2^-32 of the result), and `hi` sees ONE instruction per k-step -- the exact
-    // products a0.b0 -- i.e. a sixth of the truncations and of the drift (about -4e-8 over the 8192-row k-chunks the host
+    // products a0.b0 -- i.e. a sixth of the truncations and of the drift (about -2e-8 over the 4096-row k-chunks the host
     // cuts a weight gradient into).  hi + lo (v_add_f32: round to nearest even) is formed once, in the epilogue.
     bx_f32x16 acc[2][2], lo[2][2];
     auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -524,7 +524,7 @@ static int bx3_launch_cfg(const BxProb& p0, const BxProb* p1, hipStream_t s) {
     return EAGCN_OK;
 }
 
-// np = 3: exact products; np = 1: plain bf16 operands (one plane, one product)
+// np = 3: fp32-equivalent products (three planes); np = 1: plain bf16 operands (one plane, one product)
 int launch_bx3(const BxProb& p0, const BxProb* p1, int np, hipStream_t s, double work, int prof_tag, int wide) {
     EAGCN_CHECK_ARG(bx3_ok(p0) && (!p1 || bx3_ok(*p1)), "bx3 gemm: operands not aligned / extents unsupported");
     EAGCN_CHECK_ARG(np == 1 || np == 3, "bx3 gemm: 1 or 3 planes");

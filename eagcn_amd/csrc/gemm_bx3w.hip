@@ -210,18 +210,18 @@ __device__ __forceinline__ void bw_wave(const BxProb& p, const BwStream& st, con
         const int row = 8 * (b >> 1) + (c >> 2), ch = 2 * (b & 1) + ((c & 3) >> 1), half = 8 * (c & 1);
         const int lo_off = row * 64 + ((ch ^ (2 * (b >> 1))) << 4) + half;
         const int hi_off = (row + 4) * 64 + ((ch ^ (2 * (b >> 1) + 1)) << 4) + half;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            fa[t] = (2 * wr + t) * 2048 + lo_off; fah[t] = (2 * wr + t) * 2048 + hi_off;
-            fb[t] = (2 * G + t) * 2048 + lo_off; fbh[t] = (2 * G + t) * 2048 + hi_off;
-        }
+        // (tile t of a wave = panel 2 w + t: + t * 2048 bytes, a compile-time offset of the read -- only FOUR offset registers live
+        //  across the k-loop; eight put the 128 x 128 kernel two registers over its 256 and it re-loaded them from scratch every k-tile)
+        fa[0] = (2 * wr) * 2048 + lo_off; fah[0] = (2 * wr) * 2048 + hi_off;
+        fb[0] = (2 * G) * 2048 + lo_off; fbh[0] = (2 * G) * 2048 + hi_off;
+        fa[1] = fb[1] = fah[1] = fbh[1] = 0;
     }
     auto frag = [&](const unsigned char* plane, int t, int s, bool is_a) __attribute__((always_inline)) -> bw_bf16x8 {
         if constexpr (!TN) {
             const int off = (is_a ? fa[s] : fb[s]) + t * 32 * 64;
             return __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const bw_u32x4*>(plane + off));
         } else {
-            const int off = (is_a ? fa[t] : fb[t]) + 16 * s * 64, offh = (is_a ? fah[t] : fbh[t]) + 16 * s * 64;
+            const int off = (is_a ? fa[0] : fb[0]) + t * 2048 + 16 * s * 64, offh = (is_a ? fah[0] : fbh[0]) + t * 2048 + 16 * s * 64;
             const bw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bw_s16x4 __attribute__((address_space(3)))*)(plane + off));
             const bw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bw_s16x4 __attribute__((address_space(3)))*)(plane + offh));
             typedef short s16x8 __attribute__((ext_vector_type(8)));

@@ -198,16 +198,22 @@ extern "C" int eagcn_mse_loss(const float* pred, const float* target, int n, flo
 //     g += wd p ; m = m + (1 - b1)(g - m) ; v = b2 v + (1 - b2) g g ; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // Capturable: the hyper-parameters and the step count live in DEVICE memory (a replayed graph re-reads them; a learning-rate
 // schedule writes one float), the step count is advanced by the workgroup that finishes last (every workgroup has read it by
-// then).  hyper = {lr, beta1, beta2, eps, weight_decay}.
+// then).  hyper = {lr, beta1, beta2, eps, weight_decay} as DOUBLES (torch's scalars are doubles).  ticket_dev == NULL: update this range,
+// do not advance the count (FlatAdam's autograd mode updates the parameters that HAVE a gradient range by range and advances with the last).
 namespace eagcn {
 __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                        float* __restrict__ v, size_t n4, const float* __restrict__ hyper,
-                                                        long long* __restrict__ step, unsigned* __restrict__ done) {
-    const long long t = *step + 1;
-    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
-    // (torch forms the bias corrections on the host in double precision)
-    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
-    const float step_size = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+                                                        float* __restrict__ v, size_t n4, const double* __restrict__ hyper,
+                                                        long long* step, unsigned* done) {
+    // (every workgroup reads the count before the last one to finish advances it: a volatile read, `step` is not restrict)
+    const long long t = *reinterpret_cast<volatile long long*>(step) + 1;
+    // torch.optim.Adam forms every scalar in double precision on the host and hands the kernels fp32 images of them: 1 - beta2 from
+    // the fp32 image of 0.999 is off by 1.7e-5 relative
+    const double b1d = hyper[1], b2d = hyper[2];
+    const float b1 = (float)b1d, b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
+    const float eps = (float)hyper[3], wd = (float)hyper[4];
+    const double bc1 = 1.0 - pow(b1d, (double)t), bc2 = 1.0 - pow(b2d, (double)t);
+    const float step_size = (float)(hyper[0] / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    (void)b1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
         const float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -215,13 +221,14 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float gr = ge[e] + wd * pe[e];
-            me[e] = me[e] + (1.0f - b1) * (gr - me[e]);
-            ve[e] = b2 * ve[e] + (1.0f - b2) * gr * gr;
+            me[e] = me[e] + omb1 * (gr - me[e]);
+            ve[e] = b2 * ve[e] + omb2 * gr * gr;
             const float denom = sqrtf(ve[e]) * inv_sqrt_bc2 + eps;
             pe[e] = pe[e] - step_size * (me[e] / denom);
         }
         reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
     }
+    if (!done) return;                                 // (a partial update: the caller advances the count with its last range)
     __shared__ unsigned ticket;
     __syncthreads();
     if (threadIdx.x == 0) ticket = atomicAdd(done, 1u);
@@ -230,9 +237,9 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
 }
 }  // namespace eagcn
 
-extern "C" int eagcn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper_dev,
+extern "C" int eagcn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const double* hyper_dev,
                                int64_t* step_dev, uint32_t* ticket_dev, void* stream) {
-    EAGCN_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && hyper_dev && step_dev && ticket_dev, "eagcn_adam_step: null argument");
+    EAGCN_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && hyper_dev && step_dev, "eagcn_adam_step: null argument");
     EAGCN_CHECK_ARG(n >= 0 && (n & 3) == 0, "eagcn_adam_step: the flat buffers hold a multiple of 4 floats (ModelPlan pads every parameter)");
     EAGCN_CHECK_ARG(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
                       reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0, "eagcn_adam_step: buffers must be 16-byte aligned");

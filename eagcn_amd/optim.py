@@ -41,7 +41,7 @@ class FlatAdam:
                 p.data = view                      # the module's parameter now IS a slice of the flat buffer
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay], dtype=torch.float32, device=dev)
+        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay], dtype=torch.float64, device=dev)   # (torch's scalars are doubles)
         self.step_count = torch.zeros((), dtype=torch.int64, device=dev)
         self.ticket = torch.zeros((), dtype=torch.int32, device=dev)
         self._gather = None
@@ -60,31 +60,55 @@ class FlatAdam:
         self.hyper[0] = float(lr)                  # (a device write: a captured step graph picks it up at its next replay)
         self.param_groups[0]['lr'] = float(lr)
 
-    def _flat_grads(self):
-        flat = self.model.flat_grad_buffer()
-        if flat is not None and flat.numel() == self.flat.numel():
-            return flat
-        # autograd mode: the gradients are separate tensors -> one staging buffer of the same layout
-        if self._gather is None:
-            self._gather = torch.zeros_like(self.flat)
-        views = self.plan.grad_views(self._gather)
-        live = [(v, p.grad) for v, p in zip(views, self.plan.params) if p.requires_grad and p.grad is not None]
-        self._gather.zero_()
-        if live:
-            torch._foreach_copy_([v for v, _ in live], [g for _, g in live])
-        return self._gather
+    def _check_homes(self):
+        """The module's parameters must still BE slices of the flat buffer (a later ``model.to()`` / ``.float()`` / assignment to
+        ``p.data`` re-homes them and would leave this optimizer updating memory nobody reads)."""
+        lo = self.flat.data_ptr()
+        hi = lo + 4 * self.flat.numel()
+        for p in self.param_groups[0]['params']:
+            if not (lo <= p.data_ptr() < hi):
+                raise L.EagcnHipError('FlatAdam: a parameter of the model no longer lives in the optimizer\'s flat buffer (the model was moved '
+                                      'or a parameter\'s .data was re-assigned after the optimizer was built): build a new FlatAdam')
+
+    def _launch(self, off, n, flat_grad, advance):
+        lib = L.load()
+        L.check(lib.eagcn_adam_step(C.c_void_p(self.flat.data_ptr() + 4 * off), C.c_void_p(flat_grad.data_ptr() + 4 * off),
+                                    C.c_void_p(self.exp_avg.data_ptr() + 4 * off), C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * off), n,
+                                    C.c_void_p(self.hyper.data_ptr()), C.c_void_p(self.step_count.data_ptr()),
+                                    C.c_void_p(self.ticket.data_ptr()) if advance else C.c_void_p(0),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'eagcn_adam_step')
 
     def launch(self, flat_grad):
-        """The update as one launch on the current stream (capturable)."""
-        lib = L.load()
-        L.check(lib.eagcn_adam_step(C.c_void_p(self.flat.data_ptr()), C.c_void_p(flat_grad.data_ptr()), C.c_void_p(self.exp_avg.data_ptr()),
-                                    C.c_void_p(self.exp_avg_sq.data_ptr()), self.flat.numel(), C.c_void_p(self.hyper.data_ptr()),
-                                    C.c_void_p(self.step_count.data_ptr()), C.c_void_p(self.ticket.data_ptr()),
-                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'eagcn_adam_step')
+        """The update as one launch on the current stream (capturable): every slot of the flat buffer has a gradient (graph /
+        direct mode: the hot path produces all of them in every backward)."""
+        self._check_homes()
+        self._launch(0, self.flat.numel(), flat_grad, True)
 
     @torch.no_grad()
     def step(self):
-        self.launch(self._flat_grads())
+        flat = self.model.flat_grad_buffer()
+        if flat is not None and flat.numel() == self.flat.numel():
+            return self.launch(flat)
+        # autograd mode: the gradients are separate tensors.  torch.optim.Adam SKIPS a parameter whose .grad is None (no weight decay,
+        # no moment update): the parameters that have one are gathered into a staging buffer of the flat layout and updated range by
+        # range (adjacent live parameters share a launch); only the last launch advances the step count
+        self._check_homes()
+        if self._gather is None:
+            self._gather = torch.zeros_like(self.flat)
+        views = self.plan.grad_views(self._gather)
+        offs = self.plan.offsets
+        live = [(i, v, p.grad) for i, (v, p) in enumerate(zip(views, self.plan.params)) if p.requires_grad and p.grad is not None]
+        if not live:
+            return
+        torch._foreach_copy_([v for _, v, _ in live], [g for _, _, g in live])
+        ranges = []
+        for i, _, _ in live:
+            if ranges and ranges[-1][1] == offs[i]:
+                ranges[-1][1] = offs[i + 1]
+            else:
+                ranges.append([offs[i], offs[i + 1]])
+        for j, (a, b) in enumerate(ranges):
+            self._launch(a, b - a, self._gather, j == len(ranges) - 1)
 
     def state_dict(self):
         return {'exp_avg': self.exp_avg.clone(), 'exp_avg_sq': self.exp_avg_sq.clone(), 'step': int(self.step_count),
@@ -94,4 +118,4 @@ class FlatAdam:
         self.exp_avg.copy_(sd['exp_avg'])
         self.exp_avg_sq.copy_(sd['exp_avg_sq'])
         self.step_count.fill_(int(sd['step']))
-        self.hyper.copy_(sd['hyper'])
+        self.hyper.copy_(sd['hyper'].to(self.hyper.dtype))

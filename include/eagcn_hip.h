@@ -415,10 +415,11 @@ int eagcn_mse_loss(const float* pred, const float* target, int n, float* loss, f
 
 /* ---- optimizer step (train.py:303 `optim.Adam(..., weight_decay=wd)`, train.py:334) as ONE launch over flat fp32 buffers: every
  * hot-path parameter in one buffer, gradients / first / second moments in buffers of the same layout (n floats, a multiple of 4,
- * 16-byte aligned).  torch.optim.Adam arithmetic.  hyper_dev = {lr, beta1, beta2, eps, weight_decay} and the step count *step_dev
- * (advanced by the launch) live in device memory, so the launch can sit in a captured graph; *ticket_dev must be 0 on entry
- * (the launch leaves it 0). */
-int eagcn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper_dev,
+ * 16-byte aligned).  torch.optim.Adam arithmetic.  hyper_dev = {lr, beta1, beta2, eps, weight_decay} as DOUBLES (torch's scalars
+ * are Python doubles: 1 - beta2 formed from an fp32 0.999 is off by 1.7e-5) and the step count *step_dev (advanced by the launch)
+ * live in device memory, so the launch can sit in a captured graph; *ticket_dev must be 0 on entry (the launch leaves it 0).
+ * ticket_dev == NULL: the range is updated and the count NOT advanced (several ranges of one step: the last call brings the ticket). */
+int eagcn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const double* hyper_dev,
                     int64_t* step_dev, uint32_t* ticket_dev, void* stream);
 
 /* ---- evaluation outputs (train.py:130-211): append one batch to device-resident [cap][T] buffers at row `row_offset`:
@@ -431,7 +432,7 @@ int eagcn_eval_append(const float* logits, const float* labels, int B, int T, in
  *   1 = every fp32 operand split into three bf16 pieces by the CONSUMER on its way into LDS, six bf16 MFMA products
  *       accumulated in fp32 (csrc/gemm_x6.h; kept for comparison);
  *   2 = operands rounded to bf16 by the consumer, ONE product (csrc/gemm_x6.h; NOT the parity path);
- *   3 = exact fp32 products at the bf16 matrix rate: the PRODUCERS of a matrix (BatchNorm apply, transposed aggregation,
+ *   3 = fp32-equivalent products at the bf16 matrix rate (exact operand split, piece products to 3 x 2^-24 |a b|, fp32 accumulate): the PRODUCERS of a matrix (BatchNorm apply, transposed aggregation,
  *       parameter packing) write it as three bf16 planes, the products run from them by LDS-DMA (csrc/gemm_bx3.hip);
  *   4 = the same kernels on ONE bf16 plane (operands rounded to bf16, fp32 accumulation): BASELINE configs[1] "bf16".
  * The mode is read when a model's buffers are sized: set it before the first forward.  Returns the previous mode. */

@@ -187,3 +187,42 @@ def test_flat_adam_kernel_matches_torch_adam(wd):
     m0 = plan_a.grad_views(opt_a.exp_avg)[i0]
     assert torch.allclose(m0, st['exp_avg'], rtol=1e-5, atol=1e-12)
     assert int(opt_a.step_count) == 20
+
+
+def test_flat_adam_skips_parameters_without_gradient_and_notices_rehomed_parameters():
+    """torch.optim.Adam skips a parameter whose .grad is None -- no weight decay, no moment update (FlatAdam zero-filled
+    such slots and decayed them); and a parameter whose .data was re-assigned after the optimizer was built no longer lives in the
+    flat buffer: the step must refuse instead of updating memory nobody reads."""
+    from eagcn_amd import EAGCN, _lib as L
+    from eagcn_amd.optim import FlatAdam
+    w1, w2 = [16, 12, 8, 8, 8], [24, 12, 12, 12, 12]
+    torch.manual_seed(5)
+    a = EAGCN(9, 24, *w1, *w2, 32, 16, 3, 0.0, n_layers=2).cuda()
+    b = EAGCN(9, 24, *w1, *w2, 32, 16, 3, 0.0, n_layers=2).cuda()
+    b.load_state_dict(a.state_dict())
+    plan_a, plan_b = a.plan(), b.plan()
+    opt_a = FlatAdam(a, lr=1e-2, weight_decay=1e-2)
+    live_b = [p for p in plan_b.params if p.requires_grad]
+    opt_b = torch.optim.Adam(live_b, lr=1e-2, weight_decay=1e-2)
+    g = torch.Generator(device='cuda').manual_seed(1)
+    before = [p.detach().clone() for p in plan_a.params]
+    for step in range(3):
+        for i, (pa, pb) in enumerate(zip(plan_a.params, plan_b.params)):
+            pa.grad = pb.grad = None
+            if pa.requires_grad and i % 3 != 1:               # every third parameter never receives a gradient
+                gr = torch.randn(pa.shape, device='cuda', generator=g)
+                pa.grad, pb.grad = gr.clone(), gr.clone()
+        opt_a.step()
+        opt_b.step()
+    assert int(opt_a.step_count) == 3
+    for i, (pa, pb, p0) in enumerate(zip(plan_a.params, plan_b.params, before)):
+        if not pa.requires_grad:
+            continue
+        if i % 3 == 1:
+            assert torch.equal(pa.detach(), p0), 'parameter %d has no gradient and must not move (weight decay 1e-2)' % i
+        else:
+            assert (pa - pb).abs().max().item() <= 2e-6 * max(pb.abs().max().item(), 1e-3), i
+    victim = next(p for p in plan_a.params if p.requires_grad)
+    victim.data = victim.data.clone()
+    with pytest.raises(L.EagcnHipError):
+        opt_a.step()
