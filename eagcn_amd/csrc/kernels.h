@@ -17,6 +17,10 @@ struct AggArgs {
     int nchunk;
     int xcd = 0;                 // wave-per-tile variant: tiles handed out so that an XCD works on CONTIGUOUS tiles (agg.hip)
     BxOut planes = {nullptr, 0, 0, 0};   // transposed: dP leaves as bf16 planes INSTEAD of the fp32 matrix (only the plane GEMMs read it)
+    // transposed, lagg.hip only: `src` holds dH (the BatchNorm's upstream gradient), not dY': the BatchNorm backward's second pass
+    //     dY' = sc (dH - c1 - (Y' - mu) inv c2)      (layer.hip bn_bwd_apply_kernel)
+    // is evaluated while the rows are staged (bn = the layer's [4][Fp] table, cc = [2][Fp] {c1, c2}, Y' = EdgeArgs.Y); null: src is dY'
+    const float* bn_tab = nullptr; const float* bn_cc = nullptr; int bn_fp = 0;
 };
 int agg_grid_x(const eagcn_batch* b);
 bool agg_ksplit(const eagcn_batch* b);

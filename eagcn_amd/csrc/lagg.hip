@@ -40,7 +40,7 @@ constexpr int LG_CW = 32;                    // columns per workgroup
 constexpr int LG_LPR = LG_CW / 4;            // lanes per row (16 bytes each)
 constexpr int LG_G = 256 / LG_LPR;           // row groups per workgroup (32)
 constexpr int LG_U = LAGG_RB / LG_G;         // staging loads per lane (8)
-constexpr int LG_ECAP = 1024;                // list entries of a block staged in LDS (the rest is read from memory)
+constexpr int LG_ECAP = 768;                 // list entries of a block staged in LDS (the rest is read from memory)
 constexpr int LG_EPT = LG_ECAP / 256;
 
 __device__ __forceinline__ void lg_fma(float4& acc, float w, const float4& v) {
@@ -54,21 +54,36 @@ __device__ __forceinline__ float lg_gsum(float v) {
     return v;
 }
 
+// list entries of a block in LDS: {atom inside its molecule, sigma, bond-type code}
+struct LgLists {
+    unsigned short nb[LG_ECAP];
+    float w[LG_ECAP];
+    unsigned char cd[LG_ECAP];
+};
+// ... and what overwrites them once every row's RECORD is built (transposed form; the forward has room for both):
+//   forward     [0] = w_0..3 = sc (sigma_e - 1e-9)          [1] = { sc r m_i, sc, src_0..3 (bytes), meta }
+//   transposed  [0] = w_0..3 = s_src (sigma_e - 1e-9)       [1] = h_0..3 = s_src sigma_e (1 - sigma_e)      [2] = { s_j, src_0..3, code_0..3, meta }
+//   meta = first list entry (16 bits, relative to the block) | bonds << 16 (8 bits) | molecule << 24 (4 bits) | SLOW << 28
+//   SLOW rows (more than four bonds, or -- transposed -- a self bond) take the general loop over the lists instead
+constexpr uint32_t LG_SLOW = 1u << 28;
+
 template <bool TRANS>
-__global__ __launch_bounds__(256) void lagg_kernel(AggArgs a, EdgeArgs ed) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void lagg_kernel(AggArgs a, EdgeArgs ed) {
+    constexpr int NREC = TRANS ? 3 : 2;
     __shared__ float4 buf[LAGG_RB][LG_LPR];          // the block's operand rows x this chunk's columns (32 KB)
-    __shared__ int2 s_ptr[LAGG_RB];                  // per row: {first list entry relative to the block, count}
-    __shared__ float s_rs[LAGG_RB];                  // forward: m_i; transposed: s_i = m_i / rowsum_i
+    __shared__ float4 s_rec[LAGG_RB][NREC];          // row records (8 / 12 KB)
+    __shared__ __attribute__((aligned(16))) unsigned char s_lists_raw[TRANS ? 16 : sizeof(LgLists)];   // forward: the staged lists
+    __shared__ float s_rs[TRANS ? LAGG_RB : 1];      // transposed: s_i = m_i / rowsum_i
     __shared__ float s_rd[TRANS ? LAGG_RB : 1];      // transposed: this chunk's part of rowdot_i = <dY'_i, Y'_i>
     __shared__ unsigned char s_rm[LAGG_RB];          // molecule of the row (index inside the block)
     __shared__ float4 s_S[LAGG_MAXM][LG_LPR];        // S_b / G_b per molecule
-    __shared__ unsigned short s_nb[LG_ECAP];         // list entry: atom inside its molecule
-    __shared__ float s_w[LG_ECAP];                   //             sigma of the bond
-    __shared__ unsigned char s_cd[TRANS ? LG_ECAP : 1];   //        bond-type code (edge gradients)
     __shared__ float sig_s[256];
-    __shared__ unsigned short s_mo[LAGG_RB];         // first row of the row's molecule inside the block
     __shared__ double st_s[TRANS ? 1 : 4][TRANS ? 1 : LG_LPR][8];   // forward: per wave: BatchNorm partial sums of a lane's four columns
+    __shared__ float4 s_bn[TRANS ? 3 : 1][LG_LPR];   // transposed + BatchNorm fusion: three constants per column of this chunk
     __shared__ double h_s[TRANS ? 264 : 1];          // transposed: bond-type histogram of d w_k, [256] = d self_r
+    // transposed: the lists live in the record array until the records are built (LDS: 51 KB = three workgroups per CU either way)
+    static_assert(sizeof(LgLists) <= sizeof(float4) * LAGG_RB * 3, "lists alias the transposed record array");
+    LgLists& L = *reinterpret_cast<LgLists*>(TRANS ? reinterpret_cast<unsigned char*>(&s_rec[0][0]) : s_lists_raw);
 
     const eagcn_batch& bt = a.bt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -83,227 +98,320 @@ __global__ __launch_bounds__(256) void lagg_kernel(AggArgs a, EdgeArgs ed) {
     const int col = cc * LG_CW + 4 * l;                               // this lane's first column inside the view
     const bool col_ok = col < wk;
     const int c0 = a.vc.off[k] + col;
+    const int c0s = col_ok ? c0 : a.vc.off[k];                        // (a legal column for the lanes beyond the view's width)
     const float* rsk = a.rscale + (size_t)k * bt.T;
     const int2* ptrs = reinterpret_cast<const int2*>(TRANS ? bt.col_ptr : bt.row_ptr);
     const int32_t* nbr = TRANS ? bt.tnbr : bt.nbr;
     const uint64_t* codes = TRANS ? bt.tcode : bt.ecode;
     if constexpr (TRANS) { h_s[tid] = 0.0; if (tid < 8) h_s[256 + tid] = 0.0; }
     double dr_acc = 0.0;
-    // (the grid's y extent is an estimate of the block count: a workgroup takes blocks q, q + gridDim.y, ...)
     const int dbg = a.xcd;                                            // (probe mask, EAGCN_LAGG_DBG: wrong results)
     const int4* blk4 = reinterpret_cast<const int4*>(bt.blk);
     const int4* rinfo = reinterpret_cast<const int4*>(bt.row_info);
+    // transposed with the BatchNorm backward's second pass folded in (AggArgs.bn_tab): this lane's five per-column constants
+    const bool fuse_bn = TRANS && a.bn_tab != nullptr;
+    if constexpr (TRANS) {
+        if (fuse_bn && tid < LG_CW) {
+            // dY' = sc (dH - c1 - (Y' - mu) inv c2) (bn_bwd_apply_kernel) as A dH + Bc Y' + Cc: three constants per column, kept in LDS
+            // (twenty registers across the block loop otherwise); the regrouping moves the result by an ulp of its largest term
+            const int cl = cc * LG_CW + tid < wk ? a.vc.off[k] + cc * LG_CW + tid : a.vc.off[k];
+            const float sc = a.bn_tab[(size_t)BN_SC * a.bn_fp + cl], mu = a.bn_tab[(size_t)BN_MU * a.bn_fp + cl];
+            const float iv = a.bn_tab[(size_t)BN_INV * a.bn_fp + cl], c1 = a.bn_cc[cl], c2 = a.bn_cc[a.bn_fp + cl];
+            float* sb = reinterpret_cast<float*>(&s_bn[0][0]);
+            sb[tid] = sc;
+            sb[LG_CW + tid] = -sc * iv * c2;
+            sb[2 * LG_CW + tid] = sc * (mu * iv * c2 - c1);
+        }
+    }
     // A workgroup takes the blocks q, q + gridDim.y, ... (the grid's y extent is an estimate of the block count).  Measured and
     // dropped: a software pipeline over a workgroup's blocks (the next block's rows in flight into registers while this one is worked
-    // on, a persistent grid of three workgroups per CU): 212 / 238 registers = two workgroups per CU instead of three, and slower --
-    // 613 / 1242 us forward / backward against 420 / 792 at the HIV widths, 1151 / 1954 against 1040 / 1229 at 256 atoms: the phases
-    // between the barriers are chains of dependent LDS reads that only MORE resident workgroups hide.
-    const int c0s = col_ok ? c0 : a.vc.off[k];                        // (a legal column for the lanes beyond the view's width)
+    // on, a persistent grid of three workgroups per CU): 212 / 238 registers = two workgroups per CU instead of three, and slower.
     for (int q = blockIdx.y; q < nblk; q += gridDim.y) {
-    // the block: {first molecule, molecules, first packed row, rows} {first list entry, entries} -- one dependent load, then everything
-    const int4 b0 = blk4[2 * q], b1 = blk4[2 * q + 1];
-    const int m0 = b0.x, R0 = b0.z, rows = min(b0.w, LAGG_RB), E0 = b1.x, ne = b1.y;
-    if (rows <= 0) {                                                  // (uniform) nothing stored: the slab still has to be defined
-        if constexpr (!TRANS) {
-            const int fp = a.vc.off[a.vc.K];
-            if (tid < LG_CW && cc * LG_CW + tid < wk)
-                *reinterpret_cast<double2*>(a.stats + ((size_t)q * fp + a.vc.off[k] + cc * LG_CW + tid) * 2) = make_double2(0.0, 0.0);
+        // the block: {first molecule, molecules, first packed row, rows} {first list entry, entries} -- one dependent load, then everything
+        const int4 b0 = blk4[2 * q], b1 = blk4[2 * q + 1];
+        const int m0 = b0.x, R0 = b0.z, rows = min(b0.w, LAGG_RB), E0 = b1.x, ne = b1.y;
+        if (rows <= 0) {                                              // (uniform) nothing stored: the slab still has to be defined
+            if constexpr (!TRANS) {
+                const int fp = a.vc.off[a.vc.K];
+                if (tid < LG_CW && cc * LG_CW + tid < wk)
+                    *reinterpret_cast<double2*>(a.stats + ((size_t)q * fp + a.vc.off[k] + cc * LG_CW + tid) * 2) = make_double2(0.0, 0.0);
+            }
+            continue;
         }
-        continue;
-    }
-    // ---- ONE batch of independent loads: operand rows, (transposed) the rows' own Y', row descriptors, list headers, list entries.
-    //      Every load is unconditional on a clamped address (a load under a per-lane condition compiles to a branch and, behind it, a
-    //      wait per load); what a lane must not use is zeroed afterwards.
-    float4 v[LG_U], yv[TRANS ? LG_U : 1];
+        // ---- ONE batch of independent loads: operand rows, (transposed) the rows' own Y', row descriptors, list headers, list entries.
+        //      Every load is unconditional on a clamped address (a load under a per-lane condition compiles to a branch and, behind it,
+        //      a wait per load); what a lane must not use is zeroed afterwards.
+        float4 v[LG_U], yv[TRANS ? LG_U : 1];
 #pragma unroll
-    for (int u = 0; u < LG_U; ++u) {
-        const int rc = min(g + LG_G * u, rows - 1);
-        v[u] = *reinterpret_cast<const float4*>(a.src + (size_t)(R0 + rc) * a.lds + c0s);
-        if constexpr (TRANS) yv[u] = *reinterpret_cast<const float4*>(ed.Y + (size_t)(R0 + rc) * ed.ld + c0s);
-    }
-    const int tr = R0 + min(tid, rows - 1);
-    const int2 pt = ptrs[tr];
-    const float rsv = TRANS ? rsk[tr] : bt.row_m[tr];
-    const int4 ri = rinfo[tr];                                        // {molecule, atom, nat, first row of the molecule}
-    int e_jn[LG_EPT];
-    uint64_t e_cd[LG_EPT];
-    const int nst = min(ne, LG_ECAP);
-    if (nst > 0) {                                                    // (uniform)
-#pragma unroll
-        for (int u = 0; u < LG_EPT; ++u) {
-            const int ec = E0 + min(tid + 256 * u, nst - 1);
-            e_jn[u] = nbr[ec];
-            e_cd[u] = codes[ec];
+        for (int u = 0; u < LG_U; ++u) {
+            const int rc = min(g + LG_G * u, rows - 1);
+            v[u] = *reinterpret_cast<const float4*>(a.src + (size_t)(R0 + rc) * a.lds + c0s);
+            if constexpr (TRANS) yv[u] = *reinterpret_cast<const float4*>(ed.Y + (size_t)(R0 + rc) * ed.ld + c0s);
         }
-    }
-    __syncthreads();                                                  // (LDS of the previous block is free)
-    if (tid < LAGG_MAXM * LG_LPR) (&s_S[0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int tr = R0 + min(tid, rows - 1);
+        const int2 pt = ptrs[tr];
+        const float rsv = TRANS ? rsk[tr] : bt.row_m[tr];             // forward: m_i; transposed: s_j
+        const int4 ri = rinfo[tr];                                    // {molecule, atom, nat, first row of the molecule}
+        int e_jn[LG_EPT];
+        uint64_t e_cd[LG_EPT];
+        const int nst = min(ne, LG_ECAP);
+        if (nst > 0) {                                                // (uniform)
 #pragma unroll
-    for (int u = 0; u < LG_U; ++u) {
-        const int rr = g + LG_G * u;
-        if (!col_ok) { v[u] = make_float4(0.f, 0.f, 0.f, 0.f); if constexpr (TRANS) yv[u] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        if (rr < rows) buf[rr][l] = v[u];
-        if constexpr (TRANS) {
-            // this chunk's part of rowdot_i (the operands are in registers)
-            const float d = lg_gsum(lg_dot(v[u], yv[u]));
-            if (rr < rows && l == 0) s_rd[rr] = d;
-        }
-    }
-    if (tid < rows) {
-        s_ptr[tid] = make_int2(pt.x - E0, pt.y);
-        s_rs[tid] = rsv;
-        s_rm[tid] = (unsigned char)min(max(ri.x - m0, 0), LAGG_MAXM - 1);
-        s_mo[tid] = (unsigned short)(ri.w - R0);
-    }
-    if (nst > 0) {
-#pragma unroll
-        for (int u = 0; u < LG_EPT; ++u) {
-            const int e = tid + 256 * u;
-            if (e < nst) {
-                const uint32_t c = (uint32_t)(e_cd[u] >> (8 * k)) & 255u;
-                s_nb[e] = (unsigned short)e_jn[u];
-                s_w[e] = sig_s[c];
-                if constexpr (TRANS) s_cd[e] = (unsigned char)c;
+            for (int u = 0; u < LG_EPT; ++u) {
+                const int ec = E0 + min(tid + 256 * u, nst - 1);
+                e_jn[u] = nbr[ec];
+                e_cd[u] = codes[ec];
             }
         }
-    }
-    __syncthreads();                                                  // B2
-    // ---- S_b (forward) / G_b = sum_i s_i dY'_i (transposed): group g sums a contiguous range of the block's rows -------------------
-    if (!(dbg & 1)) {
-        const int per = (rows + LG_G - 1) / LG_G;
-        const int ra = g * per, rb = min(rows, ra + per);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int cur = -1;
-        auto flush = [&]() {
-            if (cur >= 0) {
-                float* dst = reinterpret_cast<float*>(&s_S[cur][l]);
-                atomicAdd(dst + 0, acc.x); atomicAdd(dst + 1, acc.y); atomicAdd(dst + 2, acc.z); atomicAdd(dst + 3, acc.w);
-            }
-        };
-        for (int rr = ra; rr < rb; ++rr) {
-            const int m = s_rm[rr];
-            if (m != cur) { flush(); acc = make_float4(0.f, 0.f, 0.f, 0.f); cur = m; }
-            if constexpr (TRANS) lg_fma(acc, s_rs[rr], buf[rr][l]); else lg_add(acc, buf[rr][l]);
-        }
-        flush();
-    }
-    __syncthreads();                                                  // B3
-    // entry `el` of the block's lists: {atom inside its molecule, sigma, code}
-    auto entry = [&](int el, int& jn, float& w, uint32_t& c) __attribute__((always_inline)) {
-        if (el < LG_ECAP) {
-            jn = s_nb[el]; w = s_w[el];
-            if constexpr (TRANS) c = s_cd[el]; else c = 0u;
-        } else {                                                      // (beyond the staged part: memory)
-            jn = nbr[E0 + el];
-            c = (uint32_t)(codes[E0 + el] >> (8 * k)) & 255u;
-            w = sig_s[c];
-        }
-    };
-    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-    // ---- the rows: 8 lanes own a row ---------------------------------------------------------------------------------------------------
-    for (int rr = g; rr < rows; rr += LG_G) {
-        int2 p = s_ptr[rr];
-        if (dbg & 2) p.y = 0;                                         // (probe: no gathers)
-        const int m = s_rm[rr];
-        const int moff = s_mo[rr];                                    // first row of the molecule inside the block
-        const float mrow = s_rs[rr];                                  // forward: m_i; transposed: s_j
-        const float4 self = buf[rr][l];
-        const float4 S = s_S[m][l];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), bs = make_float4(0.f, 0.f, 0.f, 0.f);
-        float wsum = 0.0f;
-        float4 pj = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (TRANS) {
-            pj = *reinterpret_cast<const float4*>(ed.P + (size_t)(R0 + rr) * ed.ld + c0s);
-            if (!col_ok) pj = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        for (int e0 = 0; e0 < p.y; e0 += 4) {
-            int jn[4]; float ww[4]; uint32_t cd[4]; float4 vv[4]; float sw[4];
+        __syncthreads();                                              // B1: the LDS of the previous block is free
+        if (tid < LAGG_MAXM * LG_LPR) (&s_S[0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                jn[d] = 0; ww[d] = 0.0f; cd[d] = 0u; sw[d] = 0.0f;
-                if (e0 + d < p.y) entry(p.x + e0 + d, jn[d], ww[d], cd[d]);
-                const int src_row = min(moff + jn[d], LAGG_RB - 1);
-                vv[d] = buf[src_row][l];
-                if constexpr (TRANS) sw[d] = (e0 + d < p.y) ? s_rs[src_row] : 0.0f;
+        for (int u = 0; u < LG_U; ++u) {
+            const int rr = g + LG_G * u;
+            if constexpr (TRANS) {
+                if (fuse_bn) {                                        // dY' from dH and Y'
+                    const float4 bA = s_bn[0][l], bB = s_bn[1][l], bC = s_bn[2][l];
+                    v[u].x = fmaf(bA.x, v[u].x, fmaf(bB.x, yv[u].x, bC.x));
+                    v[u].y = fmaf(bA.y, v[u].y, fmaf(bB.y, yv[u].y, bC.y));
+                    v[u].z = fmaf(bA.z, v[u].z, fmaf(bB.z, yv[u].z, bC.z));
+                    v[u].w = fmaf(bA.w, v[u].w, fmaf(bB.w, yv[u].w, bC.w));
+                }
             }
+            if (!col_ok) { v[u] = make_float4(0.f, 0.f, 0.f, 0.f); if constexpr (TRANS) yv[u] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            if (rr < rows) buf[rr][l] = v[u];
+            if constexpr (TRANS) {
+                const float d = lg_gsum(lg_dot(v[u], yv[u]));         // this chunk's part of rowdot_i (the operands are in registers)
+                if (rr < rows && l == 0) s_rd[rr] = d;
+            }
+        }
+        const int my_mol = min(max(ri.x - m0, 0), LAGG_MAXM - 1), my_off = ri.w - R0;      // (of row `tid`, tid < rows)
+        if (tid < rows) {
+            s_rm[tid] = (unsigned char)my_mol;
+            if constexpr (TRANS) s_rs[tid] = rsv;
+        }
+        if (nst > 0) {
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                if constexpr (!TRANS) {
-                    lg_fma(acc, ww[d], vv[d]);
-                    if (e0 + d < p.y) lg_add(bs, vv[d]);
-                    wsum += ww[d];
-                } else {
-                    lg_fma(acc, ww[d] * sw[d], vv[d]);
-                    lg_fma(bs, sw[d], vv[d]);                         // (what the 1e-9 term must NOT count: s_i dY'_i of the bonded rows)
-                    // edge gradient of bond (i -> j): dU = s_i (<dY'_i, P_j> - rowdot_i), this chunk's share
-                    const float gd = lg_gsum(lg_dot(vv[d], pj));
-                    if (e0 + d < p.y && l == 0 && sw[d] != 0.0f) {
-                        const int src_row = min(moff + jn[d], LAGG_RB - 1);
-                        const float dU = sw[d] * (gd - s_rd[src_row]);
-                        if (cd[d]) atomicAdd(&h_s[cd[d]], (double)(dU * ww[d] * (1.0f - ww[d])));
-                        if (src_row == rr) dr_acc += (double)dU;      // (a self bond: the diagonal term below is NOT taken again)
-                    }
+            for (int u = 0; u < LG_EPT; ++u) {
+                const int e = tid + 256 * u;
+                if (e < nst) {
+                    const uint32_t c = (uint32_t)(e_cd[u] >> (8 * k)) & 255u;
+                    L.nb[e] = (unsigned short)e_jn[u];
+                    L.w[e] = sig_s[c];
+                    L.cd[e] = (unsigned char)c;
                 }
             }
         }
-        const int row = R0 + rr;
-        float4 y;
-        if constexpr (!TRANS) {
-            // rowsum_i = sum sigma + r m_i + 1e-9 (columns without a bond, padding included)
-            const float d = wsum + r * mrow + TINY * (float)(nlog - p.y);
-            const float sc = mrow > 0.0f ? 1.0f / d : 0.0f;
-            if (cc == 0 && l == 0) a.rscale[(size_t)k * bt.T + row] = sc;
-            const float rm = r * mrow;
-            y.x = sc * (acc.x + rm * self.x + TINY * (S.x - bs.x));
-            y.y = sc * (acc.y + rm * self.y + TINY * (S.y - bs.y));
-            y.z = sc * (acc.z + rm * self.z + TINY * (S.z - bs.z));
-            y.w = sc * (acc.w + rm * self.w + TINY * (S.w - bs.w));
-            s1[0] += (double)y.x; s2[0] += (double)y.x * (double)y.x;
-            s1[1] += (double)y.y; s2[1] += (double)y.y * (double)y.y;
-            s1[2] += (double)y.z; s2[2] += (double)y.z * (double)y.z;
-            s1[3] += (double)y.w; s2[3] += (double)y.w * (double)y.w;
-        } else {
-            const float rs = r * mrow;                                // s_j r
-            y.x = acc.x + rs * self.x + TINY * (S.x - bs.x);
-            y.y = acc.y + rs * self.y + TINY * (S.y - bs.y);
-            y.z = acc.z + rs * self.z + TINY * (S.z - bs.z);
-            y.w = acc.w + rs * self.w + TINY * (S.w - bs.w);
-            // the diagonal of the edge gradients (always part of d self_r; agg.hip edge_grad_body)
-            const float gd = lg_gsum(lg_dot(self, pj));
-            if (l == 0 && mrow != 0.0f) {
-                bool self_bond = false;                               // (already counted above when the list holds (j, j))
-                for (int e = 0; e < p.y; ++e) { int jn; float w; uint32_t c; entry(p.x + e, jn, w, c); self_bond = self_bond || (moff + jn == rr); }
-                if (!self_bond) dr_acc += (double)(mrow * (gd - s_rd[rr]));
+        __syncthreads();                                              // B2: rows, lists, scales are in LDS
+        // entry `el` of the block's lists: {atom inside its molecule, sigma, code}; from LDS while the lists are there, else from memory
+        auto entry = [&](int el, bool lds_ok, int& jn, float& w, uint32_t& c) __attribute__((always_inline)) {
+            if (lds_ok && el < LG_ECAP) {
+                jn = L.nb[el]; w = L.w[el]; c = L.cd[el];
+            } else {
+                jn = nbr[E0 + el];
+                c = (uint32_t)(codes[E0 + el] >> (8 * k)) & 255u;
+                w = sig_s[c];
+            }
+        };
+        // ---- the row RECORDS: thread t builds row t's (header comment of the struct above).  The first version of this kernel read a
+        //      row's state from five LDS arrays and walked its list entries in a dynamic loop with a running rowsum and a second
+        //      accumulator for the filler -- it was bound by instruction ISSUE (SQ_ACTIVE 30 % per wave at three waves per SIMD,
+        //      profiles/r05_lagg_sq.txt).  With the scale and the filler folded into the weights,
+        //          forward      y_i  = sum_e w_e P[src_e] + (sc r m_i) P[i] + (sc 1e-9) S_b
+        //          transposed   dP_j = sum_e w_e Z[src_e] + (r s_j) Z[j] + 1e-9 G_b ,   d w[code_e] += h_e (<Z[src_e], P_j> - rowdot_src)
+        //      the row loop is two or three LDS reads, five gathers and a few dozen FMAs without a branch.
+        const int first = pt.x - E0, cnt = (dbg & 2) ? 0 : pt.y;
+        float4 rec[NREC];
+        if (tid < rows) {
+            float we[4] = {0.f, 0.f, 0.f, 0.f}, he[4] = {0.f, 0.f, 0.f, 0.f};
+            uint32_t srcs = 0u, cds = 0u, slow = cnt > 4 ? LG_SLOW : 0u;
+            float wsum = 0.0f;
+            double hd = 0.0;
+            for (int e = 0; e < cnt; ++e) {
+                int jn; float w; uint32_t c;
+                entry(first + e, true, jn, w, c);
+                wsum += w;
+                const int src = min(my_off + jn, LAGG_RB - 1);
+                if constexpr (TRANS) { if (src == tid) slow = LG_SLOW; }      // (a self bond: the diagonal of the edge gradients is this entry)
+                if (e < 4) {
+                    const float ss = TRANS ? s_rs[src] : 1.0f;
+                    we[e] = ss * (w - TINY);
+                    srcs |= (uint32_t)src << (8 * e);
+                    if constexpr (TRANS) { he[e] = ss * w * (1.0f - w); cds |= c << (8 * e); }
+                }
+            }
+            for (int e = min(cnt, 4); e < 4; ++e) srcs |= (uint32_t)tid << (8 * e);       // (weight 0: any legal row)
+            const uint32_t meta = (uint32_t)(first & 0xFFFF) | ((uint32_t)min(cnt, 255) << 16) | ((uint32_t)my_mol << 24) | slow;
+            if constexpr (!TRANS) {
+                const float d = wsum + r * rsv + TINY * (float)(nlog - cnt);           // rowsum: sum sigma + r m_i + 1e-9 (columns without a bond)
+                const float sc = rsv > 0.0f ? 1.0f / d : 0.0f;
+                if (cc == 0) a.rscale[(size_t)k * bt.T + R0 + tid] = sc;
+                rec[0] = make_float4(sc * we[0], sc * we[1], sc * we[2], sc * we[3]);
+                rec[1] = make_float4(sc * r * rsv, sc, __uint_as_float(srcs), __uint_as_float(meta));
+            } else {
+                rec[0] = make_float4(we[0], we[1], we[2], we[3]);
+                rec[1] = make_float4(he[0], he[1], he[2], he[3]);
+                rec[NREC - 1] = make_float4(rsv, __uint_as_float(srcs), __uint_as_float(cds), __uint_as_float(meta));
+                // the part of the edge gradients that needs no column data: - h_e rowdot_src per bond, - s_j rowdot_j on the diagonal
+                if (!slow) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t c = (cds >> (8 * e)) & 255u;
+                        if (c && he[e] != 0.0f) atomicAdd(&h_s[c], -(double)(he[e] * s_rd[(srcs >> (8 * e)) & 255u]));
+                    }
+                    if (rsv != 0.0f) hd = -(double)(rsv * s_rd[tid]);
+                }
+                dr_acc += hd;
             }
         }
-        if (col_ok && !(dbg & 4)) {
-            if (TRANS && a.planes.p) bx_store4(a.planes, row, c0, y);
-            else *reinterpret_cast<float4*>(a.dst + (size_t)row * a.ldd + c0) = y;
+        // ---- S_b (forward) / G_b = sum_i s_i dY'_i (transposed): group g sums a contiguous range of the block's rows ------------------
+        if (!(dbg & 1)) {
+            const int per = (rows + LG_G - 1) / LG_G;
+            const int ra = g * per, rb = min(rows, ra + per);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int cur = -1;
+            auto flush = [&]() {
+                if (cur >= 0) {
+                    float* dst = reinterpret_cast<float*>(&s_S[cur][l]);
+                    atomicAdd(dst + 0, acc.x); atomicAdd(dst + 1, acc.y); atomicAdd(dst + 2, acc.z); atomicAdd(dst + 3, acc.w);
+                }
+            };
+            for (int rr = ra; rr < rb; ++rr) {
+                const int m = s_rm[rr];
+                if (m != cur) { flush(); acc = make_float4(0.f, 0.f, 0.f, 0.f); cur = m; }
+                if constexpr (TRANS) lg_fma(acc, s_rs[rr], buf[rr][l]); else lg_add(acc, buf[rr][l]);
+            }
+            flush();
         }
-    }
-    if constexpr (!TRANS) {
-        // BatchNorm partial sums: the eight groups of a wave hold the same columns -> wave sum, then the four waves through LDS
+        if constexpr (TRANS) __syncthreads();                         // B2b: every thread is done with the lists: the records take their place
+        if (tid < rows) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+            for (int i = 0; i < NREC; ++i) s_rec[tid][i] = rec[i];
+        }
+        // transposed: row j's own P row for the edge gradients, requested two rows ahead of its use (a load inside the row's own
+        // iteration is a memory round trip in front of every row; all eight up front cost 32 registers = the third workgroup of the CU)
+        float4 pjn[TRANS ? 2 : 1];
+        auto pj_load = [&](int u) __attribute__((always_inline)) {
+            int rc = R0 + min(g + LG_G * u, rows - 1);
+            asm volatile("" : "+v"(rc));                              // (else the eight 64-bit row offsets of the staging loads stay live for this)
+            return *reinterpret_cast<const float4*>(ed.P + (size_t)rc * ed.ld + c0s);
+        };
+        if constexpr (TRANS) { pjn[0] = pj_load(0); pjn[1] = pj_load(1); }
+        __syncthreads();                                              // B3: records and S_b / G_b are complete
+        double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+        // ---- the rows: 8 lanes own a row -----------------------------------------------------------------------------------------------
 #pragma unroll
-            for (int o = LG_LPR; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o); s2[e] += __shfl_xor(s2[e], o); }
+        for (int u = 0; u < LG_U; ++u) {
+            const int rr = g + LG_G * u;
+            if (rr >= rows) break;
+            const float4 r0 = s_rec[rr][0], r1 = s_rec[rr][1], rl = s_rec[rr][NREC - 1];
+            const uint32_t srcs = __float_as_uint(TRANS ? rl.y : rl.z), meta = __float_as_uint(rl.w);
+            const int cnt_r = (int)((meta >> 16) & 255u), first_r = (int)(meta & 0xFFFFu);
+            const float4 self = buf[rr][l];
+            const float4 S = s_S[(meta >> 24) & 15u][l];
+            const float4 v0 = buf[srcs & 255u][l], v1 = buf[(srcs >> 8) & 255u][l], v2 = buf[(srcs >> 16) & 255u][l], v3 = buf[srcs >> 24][l];
+            float4 y;
+            if constexpr (!TRANS) {
+                const float wS = r1.y * TINY;
+                y.x = fmaf(r0.x, v0.x, fmaf(r0.y, v1.x, fmaf(r0.z, v2.x, fmaf(r0.w, v3.x, fmaf(r1.x, self.x, wS * S.x)))));
+                y.y = fmaf(r0.x, v0.y, fmaf(r0.y, v1.y, fmaf(r0.z, v2.y, fmaf(r0.w, v3.y, fmaf(r1.x, self.y, wS * S.y)))));
+                y.z = fmaf(r0.x, v0.z, fmaf(r0.y, v1.z, fmaf(r0.z, v2.z, fmaf(r0.w, v3.z, fmaf(r1.x, self.z, wS * S.z)))));
+                y.w = fmaf(r0.x, v0.w, fmaf(r0.y, v1.w, fmaf(r0.z, v2.w, fmaf(r0.w, v3.w, fmaf(r1.x, self.w, wS * S.w)))));
+                if (meta & LG_SLOW) {                                 // (more than four bonds: the rest from the staged lists)
+                    int jn0; float w0; uint32_t cq;
+                    entry(first_r, true, jn0, w0, cq);
+                    const int moff = (int)(srcs & 255u) - jn0;        // first row of the molecule inside the block
+                    for (int e = 4; e < cnt_r; ++e) {
+                        int jn; float w;
+                        entry(first_r + e, true, jn, w, cq);
+                        lg_fma(y, r1.y * (w - TINY), buf[min(moff + jn, LAGG_RB - 1)][l]);
+                    }
+                }
+                s1[0] += (double)y.x; s2[0] += (double)y.x * (double)y.x;
+                s1[1] += (double)y.y; s2[1] += (double)y.y * (double)y.y;
+                s1[2] += (double)y.z; s2[2] += (double)y.z * (double)y.z;
+                s1[3] += (double)y.w; s2[3] += (double)y.w * (double)y.w;
+                if (col_ok && !(dbg & 4)) *reinterpret_cast<float4*>(a.dst + (size_t)(R0 + rr) * a.ldd + c0) = y;
+            } else {
+                const float sj = rl.x, rs = r * sj;
+                const float4 pj = col_ok ? pjn[u & 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (u + 2 < LG_U) pjn[u & 1] = pj_load(u + 2);
+                if (!(meta & LG_SLOW)) {
+                    y.x = fmaf(r0.x, v0.x, fmaf(r0.y, v1.x, fmaf(r0.z, v2.x, fmaf(r0.w, v3.x, fmaf(rs, self.x, TINY * S.x)))));
+                    y.y = fmaf(r0.x, v0.y, fmaf(r0.y, v1.y, fmaf(r0.z, v2.y, fmaf(r0.w, v3.y, fmaf(rs, self.y, TINY * S.y)))));
+                    y.z = fmaf(r0.x, v0.z, fmaf(r0.y, v1.z, fmaf(r0.z, v2.z, fmaf(r0.w, v3.z, fmaf(rs, self.z, TINY * S.z)))));
+                    y.w = fmaf(r0.x, v0.w, fmaf(r0.y, v1.w, fmaf(r0.z, v2.w, fmaf(r0.w, v3.w, fmaf(rs, self.w, TINY * S.w)))));
+                    // edge gradients of the bonds into j (this chunk's columns), and the diagonal
+                    const float g0 = lg_gsum(lg_dot(v0, pj)), g1 = lg_gsum(lg_dot(v1, pj)), g2 = lg_gsum(lg_dot(v2, pj)), g3 = lg_gsum(lg_dot(v3, pj));
+                    const float gs = lg_gsum(lg_dot(self, pj));
+                    if (l == 0) {
+                        const uint32_t cds = __float_as_uint(rl.z);
+                        if (r1.x != 0.0f && (cds & 255u)) atomicAdd(&h_s[cds & 255u], (double)(r1.x * g0));
+                        if (r1.y != 0.0f && ((cds >> 8) & 255u)) atomicAdd(&h_s[(cds >> 8) & 255u], (double)(r1.y * g1));
+                        if (r1.z != 0.0f && ((cds >> 16) & 255u)) atomicAdd(&h_s[(cds >> 16) & 255u], (double)(r1.z * g2));
+                        if (r1.w != 0.0f && (cds >> 24)) atomicAdd(&h_s[cds >> 24], (double)(r1.w * g3));
+                        dr_acc += (double)(sj * gs);
+                    }
+                } else {
+                    // the general loop (more than four bonds / a self bond): lists from memory (their LDS copy is gone)
+                    int jn0; float w0; uint32_t cq;
+                    entry(first_r, false, jn0, w0, cq);
+                    const int moff = cnt_r > 0 ? (int)(srcs & 255u) - jn0 : 0;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), bs = acc;
+                    bool self_bond = false;
+                    for (int e = 0; e < cnt_r; ++e) {
+                        int jn; float w; uint32_t c;
+                        entry(first_r + e, false, jn, w, c);
+                        const int src = min(moff + jn, LAGG_RB - 1);
+                        const float sw = s_rs[src];
+                        const float4 vv = buf[src][l];
+                        lg_fma(acc, w * sw, vv);
+                        lg_fma(bs, sw, vv);                           // (what the 1e-9 term must NOT count: s_i dY'_i of the bonded rows)
+                        const float gd = lg_gsum(lg_dot(vv, pj));
+                        if (l == 0 && sw != 0.0f) {
+                            const float dU = sw * (gd - s_rd[src]);
+                            if (c) atomicAdd(&h_s[c], (double)(dU * w * (1.0f - w)));
+                            if (src == rr) dr_acc += (double)dU;      // (a self bond: the diagonal term below is NOT taken again)
+                        }
+                        self_bond = self_bond || src == rr;
+                    }
+                    y.x = acc.x + rs * self.x + TINY * (S.x - bs.x);
+                    y.y = acc.y + rs * self.y + TINY * (S.y - bs.y);
+                    y.z = acc.z + rs * self.z + TINY * (S.z - bs.z);
+                    y.w = acc.w + rs * self.w + TINY * (S.w - bs.w);
+                    const float gs = lg_gsum(lg_dot(self, pj));
+                    if (l == 0 && sj != 0.0f && !self_bond) dr_acc += (double)(sj * (gs - s_rd[rr]));
+                }
+                if (col_ok && !(dbg & 4)) {
+                    int cs = c0;
+                    asm volatile("" : "+v"(cs));                      // (no per-lane 64-bit store bases held across the block loop)
+                    if (a.planes.p) bx_store4(a.planes, R0 + rr, cs, y);
+                    else *reinterpret_cast<float4*>(a.dst + (size_t)(R0 + rr) * a.ldd + cs) = y;
+                }
+            }
         }
-        if (lane < LG_LPR) {
+        if constexpr (!TRANS) {
+            // BatchNorm partial sums: the eight groups of a wave hold the same columns -> wave sum, then the four waves through LDS
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { st_s[wave][lane][2 * e] = s1[e]; st_s[wave][lane][2 * e + 1] = s2[e]; }
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int o = LG_LPR; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o); s2[e] += __shfl_xor(s2[e], o); }
+            }
+            if (lane < LG_LPR) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { st_s[wave][lane][2 * e] = s1[e]; st_s[wave][lane][2 * e + 1] = s2[e]; }
+            }
+            __syncthreads();
+            if (tid < LG_CW && cc * LG_CW + tid < wk) {
+                const int fp = a.vc.off[a.vc.K];
+                const int ll = tid >> 2, e = tid & 3;
+                const double t1 = (st_s[0][ll][2 * e] + st_s[1][ll][2 * e]) + (st_s[2][ll][2 * e] + st_s[3][ll][2 * e]);
+                const double t2 = (st_s[0][ll][2 * e + 1] + st_s[1][ll][2 * e + 1]) + (st_s[2][ll][2 * e + 1] + st_s[3][ll][2 * e + 1]);
+                *reinterpret_cast<double2*>(a.stats + ((size_t)q * fp + a.vc.off[k] + cc * LG_CW + tid) * 2) = make_double2(t1, t2);
+            }
         }
-        __syncthreads();
-        if (tid < LG_CW && cc * LG_CW + tid < wk) {
-            const int fp = a.vc.off[a.vc.K];
-            const int ll = tid >> 2, e = tid & 3;
-            const double t1 = (st_s[0][ll][2 * e] + st_s[1][ll][2 * e]) + (st_s[2][ll][2 * e] + st_s[3][ll][2 * e]);
-            const double t2 = (st_s[0][ll][2 * e + 1] + st_s[1][ll][2 * e + 1]) + (st_s[2][ll][2 * e + 1] + st_s[3][ll][2 * e + 1]);
-            *reinterpret_cast<double2*>(a.stats + ((size_t)q * fp + a.vc.off[k] + cc * LG_CW + tid) * 2) = make_double2(t1, t2);
-        }
-    }
     }                                                                 // (blocks)
     if constexpr (TRANS) {
-        if (l == 0 && dr_acc != 0.0) atomicAdd(&h_s[256], dr_acc);
+        if (dr_acc != 0.0) atomicAdd(&h_s[256], dr_acc);
         __syncthreads();
         // non-zero bins -> one of the shared accumulator slabs (kernels.h EDGE_COPIES; drained by unpack_grads)
         double* out = ed.datt + ((size_t)((blockIdx.y + blockIdx.x) & (EDGE_COPIES - 1)) * ed.vc.K + k) * EDGE_SLAB;

@@ -1121,6 +1121,12 @@ static int apply_launch_(const eagcn_batch* b, const eagcn_layer_params* p, cons
 // write and a read of T x Fp floats (HIV widths: 9.74 -> 9.53 ms per step).  Concate: the upstream gradient is as wide as dH
 // and the plain elementwise pass is the lighter kernel (B = 256: 0.456 vs 0.459 ms; B = 1024: equal).
 // EAGCN_BWD_STORE_DH=1 / 0 forces one or the other.
+// the elementwise second pass of the BatchNorm backward disappears into lagg.hip's staging whenever that kernel consumes dY' (it is
+// the ONLY consumer then: transposed aggregation and edge gradients in one launch); EAGCN_LAGG_FUSE_BN=0 keeps the pass
+static bool lagg_fuses_bn() {
+    static const bool on = [] { const char* v = getenv("EAGCN_LAGG_FUSE_BN"); return !(v && v[0] == '0'); }();
+    return on;
+}
 static bool bn_bwd_two_pass(bool weighted) {
     static const int force = [] { const char* v = getenv("EAGCN_BWD_STORE_DH"); return v ? (v[0] == '1' ? 1 : 0) : -1; }();
     return force < 0 ? weighted : force == 0;
@@ -1213,6 +1219,16 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     if (drain_in && drain_in->eacc) ba.drain = *drain_in; else memset(&ba.drain, 0, sizeof(ba.drain));
     const int rows = b->T + ba.nvirt;
     const int gxb = std::max(1, std::min(rows, d.gxb));
+    bool fused_bn_apply = false;
+    // the LDS-staged aggregation (lagg.hip) runs this layer's transposed aggregation + edge gradients: decided ONCE, here, because the
+    // BatchNorm backward below leaves its second pass to that kernel (the edge gradients must then leave through the shared accumulators)
+    bool lagg_bwd = false;
+    {
+        static const bool edge_atomic0 = [] { const char* v = getenv("EAGCN_EDGE_SLABS"); return !(v && v[0] == '1'); }();
+        bool general0 = false;
+        for (int k = 0; k < p->K; ++k) general0 = general0 || pp.rel_vec[k] != nullptr;
+        lagg_bwd = b->T > 0 && lagg_use(b) && (lagg_parts() & 2) && edge_atomic0 && !general0;
+    }
     const double M = (double)b->B * (double)b->N;
     {
         ProfScope ps(PROF_BN, s);
@@ -1248,6 +1264,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             // second pass of the same kernel body: dH formed again, dY' written (sc.dY)
             const bool wt = p->structure == EAGCN_STRUCT_WEIGHTED, dg = ba.rg.dg != nullptr, dr = ba.do_drop != 0;
             if (bn_bwd_two_pass(wt)) launch_bn_bwd_pass(true, wt, dg, dr, dim3(std::max(1, std::min(b->T, d.gxb)), ny), ba, s);
+            else if (lagg_bwd && lagg_fuses_bn()) fused_bn_apply = true;      // the LDS-staged aggregation forms dY' from the stored dH while it stages its rows
             else bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
             EAGCN_LAUNCH_CHECK();
         }
@@ -1295,7 +1312,8 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         if (edge_atomic && !general_rel) { e.datt = sc.eacc; e.atomic = 1; }
         static const bool colaunch = [] { const char* v = getenv("EAGCN_NO_COLAUNCH"); return !(v && v[0] == '1'); }();
         nedge = e.atomic ? -EDGE_COPIES : edge_grid_x(b);
-        if (lagg_use(b) && e.atomic && (lagg_parts() & 2)) {                     // transposed aggregation + edge gradients from the same LDS gathers
+        if (lagg_bwd && e.atomic) {                                              // transposed aggregation + edge gradients from the same LDS gathers
+            if (fused_bn_apply) { a.bn_tab = w->bn; a.bn_cc = sc.cc; a.bn_fp = d.fp; }
             rc = launch_lagg_bwd(a, e, s);
             if (rc) return rc;
         } else if (sagg_use(b)) {                                                // bond-list aggregation (sagg.hip)
