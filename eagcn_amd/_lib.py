@@ -139,6 +139,7 @@ SIGNATURES = {
     'eagcn_stream_wait_counter': (C.c_int, [_fp, C.c_uint32, _fp]),
     'eagcn_adam_step': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     'eagcn_agg_wants_bond_lists': (C.c_int, [C.c_int, C.c_int]),
+    'eagcn_agg_wants_bond_lists_for': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'eagcn_bx3_used_splits': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'eagcn_set_bx3_wide': (C.c_int, [C.c_int]),
     'eagcn_bx3_pair_used_splits': (C.c_int, [C.c_int] * 7),

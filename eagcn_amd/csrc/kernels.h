@@ -35,7 +35,8 @@ constexpr int LAGG_RB = 256;                 // packed rows per block (= the lar
 constexpr int LAGG_MAXM = 16;                // molecules per block
 struct EdgeArgs;
 int lagg_parts();
-bool lagg_use(const eagcn_batch* b);         // this batch takes that path (policy + the index carries bond lists and row blocks)
+bool lagg_use(const eagcn_batch* b, int dir, bool absorbs_bn);   // this batch takes that path (policy per direction + the index carries bond lists and row blocks)
+bool lagg_wanted(int B, int N, int structure);
 int lagg_slabs(const eagcn_batch* b);        // capacity of its BatchNorm partial slabs (one per row block; meta[NBLK] of them are live)
 int launch_lagg_fwd(AggArgs a, hipStream_t s);
 int launch_lagg_bwd(AggArgs a, const EdgeArgs& e, hipStream_t s);   // transposed aggregation + edge gradients (e.atomic must be set)

@@ -422,15 +422,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 }
 
 // ---- policy ------------------------------------------------------------------------------------------------------------------------------
-// EAGCN_AGG = lds (always, N <= 256) | dense | sparse (sagg.hip); default: by shape.  Measured on MI355X (profiles/r05_lagg_*; us per launch,
-// forward / backward with the edge gradients, against agg_wave + agg_edge of agg.hip):
-//     K = 8, N = 256, all molecules 256 atoms, B = 1024 (BASELINE configs[4]):   1040 / 1230  against  1340 / 2180   (step 14.6 -> 12.5 ms)
-//     HIV widths (5 x 1250 columns), molecules of 24 atoms on average, N = 222:     420 /  790  against   380 /  840   (equal)
-//     Tox21 batch 1024 (19 atoms on average, N = 132):                                52 /  114  against    38 /   90   (slower)
-//     Tox21 batch 256:                                                                21 /   38  against    21 /   35   (equal; its bond
-//                                                   lists cost the side stream 0.2 ms per batch that a 0.45 ms step cannot hide)
-// i.e. it pays where the dense block is mostly filler: LARGE molecules.  The lists are built (and the path taken) for padded sizes from
-// EAGCN_LAGG_MIN_N (240) and, once the rows batches of the shape really hold are known (eagcn_batch.t_hint), 96 atoms per molecule.
+// EAGCN_AGG = lds (always, N <= 256) | dense | sparse (sagg.hip); default: by shape and DIRECTION.  Measured on MI355X, whole step in ms
+// with this path forced in the backward only / in both directions against the matrix-core kernels of agg.hip (tools/r5_lagg_parts.sh,
+// profiles/r05_lagg_policy.txt; the transposed kernel also absorbs bn_bwd_apply for the Concate layers):
+//     K = 8, N = 256, all molecules 256 atoms, B = 1024 (BASELINE configs[4]):          - / 10.6      against 14.6
+//     Tox21 (19 atoms on average, N = 132) B = 256, Concate (configs[1]):           0.442 / 0.428    against 0.447
+//     Tox21 B = 1024:                                                               0.898 / 0.906    against 0.922
+//     Lipo 3-layer Concate B = 512:                                                 1.350 / 1.357    against 1.401
+//     HIV Weighted_sum (24 atoms on average, N = 222, 5 x 1250 columns), B = 1024:   7.19 / 7.15     against 6.94
+// -> forward: LARGE molecules (padded size from EAGCN_LAGG_MIN_N = 240 and -- once the rows the batches of the shape really hold are
+//    known, eagcn_batch.t_hint -- 96 atoms per molecule on average), or batches of up to 256 molecules (where agg.hip runs its
+//    one-workgroup-per-tile form); backward: large molecules, or any layer whose BatchNorm backward leaves its second pass to this kernel
+//    (Concate).  Weighted_sum layers of small molecules stay on the matrix cores.
 static int lagg_policy() {
     static const int v = [] {
         const char* e = getenv("EAGCN_AGG");
@@ -444,21 +447,31 @@ static int lagg_min_n() {
     static const int v = [] { const char* e = getenv("EAGCN_LAGG_MIN_N"); return e ? atoi(e) : 240; }();
     return v;
 }
-bool lagg_wanted(int B, int N) {
+static int lagg_fwd_maxb() {
+    static const int v = [] { const char* e = getenv("EAGCN_LAGG_FWD_MAXB"); return e ? atoi(e) : 256; }();
+    return v;
+}
+// should the index of batches of this shape carry bond lists and row blocks?  structure: EAGCN_STRUCT_* of the layers, or -1 (not known)
+bool lagg_wanted(int B, int N, int structure) {
     const int p = lagg_policy();
     if (p == 0 || N > LAGG_RB) return false;
     if (p == 1) return true;
-    return N >= lagg_min_n();
+    return N >= lagg_min_n() || B <= lagg_fwd_maxb() || structure != EAGCN_STRUCT_WEIGHTED;
 }
 int lagg_parts() {                                    // (debug switch) bit 0: forward, bit 1: backward on this path
     static const int v = [] { const char* e = getenv("EAGCN_LAGG_PARTS"); return e ? atoi(e) : 3; }();
     return v;
 }
-bool lagg_use(const eagcn_batch* b) {
-    if (!(b->build_lists && b->blk && b->mol_info && b->row_ptr && b->col_ptr && b->nbr && b->tnbr && b->ecode && b->tcode && b->row_info &&
-          lagg_wanted(b->B, b->N))) return false;
-    if (lagg_policy() == 2 && b->t_hint > 0 && (long)b->t_hint < 96L * b->B) return false;       // small molecules in a large padding
-    return true;
+// does this batch take the path?  dir 0: forward, 1: backward; absorbs_bn: the layer's BatchNorm backward would leave its second pass here
+bool lagg_use(const eagcn_batch* b, int dir, bool absorbs_bn) {
+    if (!(b->build_lists && b->blk && b->mol_info && b->row_ptr && b->col_ptr && b->nbr && b->tnbr && b->ecode && b->tcode && b->row_info))
+        return false;
+    const int p = lagg_policy();
+    if (p == 0 || b->N > LAGG_RB || !(lagg_parts() & (dir ? 2 : 1))) return false;
+    if (p == 1) return true;
+    const bool large = b->N >= lagg_min_n() && !(b->t_hint > 0 && (long)b->t_hint < 96L * b->B);
+    if (large) return true;
+    return dir ? absorbs_bn : b->B <= lagg_fwd_maxb();
 }
 int lagg_slabs(const eagcn_batch* b) { return std::max(1, b->B); }
 

@@ -764,7 +764,7 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     d.fin = layout_width(&p->in);
     d.ldo = p->structure == EAGCN_STRUCT_CONCATE ? d.fp : pad16(p->width[0]);
     d.gx = agg_grid_x(b);
-    d.gslab = std::max(d.gx, lagg_use(b) ? lagg_slabs(b) : 0);
+    d.gslab = std::max(d.gx, lagg_use(b, 0, false) ? lagg_slabs(b) : 0);
     // row-partial slabs of the BatchNorm backward: 7 rows per workgroup, at most 2048 workgroups and at most
     // 32 MB of fp64 partials (wide layers: Fp = 6320 -> 331 workgroups).  Fewer, longer workgroups were measured
     // slower (the kernel is bound by its instruction stream and one memory round trip per 7-row batch, not by the
@@ -1050,7 +1050,7 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
             AggArgs a;
             a.bt = *b; a.vc = d.vc; a.src = w->P; a.lds = d.fp; a.dst = w->Y; a.ldd = d.fp;
             a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = sc.stats; a.nchunk = 1;
-            if (lagg_use(b) && (lagg_parts() & 1)) {           // LDS-staged bond-list aggregation (lagg.hip): one slab per row block
+            if (lagg_use(b, 0, false)) {                       // LDS-staged bond-list aggregation (lagg.hip): one slab per row block
                 rc = launch_lagg_fwd(a, s);
                 nslab = lagg_slabs(b);
                 tiles_per_wg = -1;
@@ -1227,7 +1227,8 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         static const bool edge_atomic0 = [] { const char* v = getenv("EAGCN_EDGE_SLABS"); return !(v && v[0] == '1'); }();
         bool general0 = false;
         for (int k = 0; k < p->K; ++k) general0 = general0 || pp.rel_vec[k] != nullptr;
-        lagg_bwd = b->T > 0 && lagg_use(b) && (lagg_parts() & 2) && edge_atomic0 && !general0;
+        const bool absorbs = !bn_bwd_two_pass(p->structure == EAGCN_STRUCT_WEIGHTED) && lagg_fuses_bn();
+        lagg_bwd = b->T > 0 && edge_atomic0 && !general0 && lagg_use(b, 1, absorbs);
     }
     const double M = (double)b->B * (double)b->N;
     {

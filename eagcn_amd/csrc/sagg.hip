@@ -254,5 +254,5 @@ int launch_sagg(AggArgs a, bool trans, hipStream_t s) {
 
 /* 1 when batches of this shape take the bond-list aggregation (csrc/sagg.hip): the caller's index must then carry bond lists
  * (eagcn_batch.build_lists = 1 before eagcn_index_rows) */
-namespace eagcn { bool lagg_wanted(int B, int N); }
-extern "C" int eagcn_agg_wants_bond_lists(int B, int N) { return (eagcn::sagg_wanted(B, N) || eagcn::lagg_wanted(B, N)) ? 1 : 0; }
+extern "C" int eagcn_agg_wants_bond_lists(int B, int N) { return (eagcn::sagg_wanted(B, N) || eagcn::lagg_wanted(B, N, -1)) ? 1 : 0; }
+extern "C" int eagcn_agg_wants_bond_lists_for(int B, int N, int structure) { return (eagcn::sagg_wanted(B, N) || eagcn::lagg_wanted(B, N, structure)) ? 1 : 0; }

@@ -66,7 +66,7 @@ def _drain_collectives(device):
 class StaticIndex:
     """BatchIndex-compatible view of the runner's static index buffers (capacities, no host values)."""
 
-    def __init__(self, B, N, channels, device, row_cap, edge_cap=None, rel_c=None):
+    def __init__(self, B, N, channels, device, row_cap, edge_cap=None, rel_c=None, structure=-1):
         K = len(channels)
         self.device, self.B, self.N, self.K = device, B, N, K
         self.channels = list(channels)
@@ -99,9 +99,9 @@ class StaticIndex:
         ob = rb + 16 * T + 16 * self.n_tiles
         c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = ob, ob + 4 * T, ob + 8 * T, ob + 12 * T, ob + 16 * T
         L.set_bond_lists(c, base + 4 * (B * N + 3 * B + 2 + L.META_WORDS), self._ptrs, self._edges, self.E)
-        # bond lists: built when the library takes the bond-list form of the aggregation for this shape (csrc/sagg.hip); the GAT
-        # runner sets the flag itself
-        self.bond_lists = bool(L.load().eagcn_agg_wants_bond_lists(B, N))
+        # bond lists + row blocks: built when the library takes a bond-list form of the aggregation for this shape and layer structure
+        # (csrc/lagg.hip, csrc/sagg.hip); the GAT runner sets the flag itself
+        self.bond_lists = bool(L.load().eagcn_agg_wants_bond_lists_for(B, N, int(structure)))
         c.build_lists = 1 if self.bond_lists else 0
         # general relation vectors (layers.py:82 with arbitrary channel values): a static 255-row code book per view
         self.relvec = None
@@ -127,7 +127,8 @@ class GraphRunner:
         self.static_outputs = bool(static_outputs)
         self.validate = validate
         self.key = (B, N, tuple(channels))
-        self.slots = [StaticIndex(B, N, channels, device, row_cap if row_cap else B * N, edge_cap, rel_c) for _ in range(2)]
+        structure = plan.specs[0].structure if getattr(plan, 'specs', None) else -1
+        self.slots = [StaticIndex(B, N, channels, device, row_cap if row_cap else B * N, edge_cap, rel_c, structure) for _ in range(2)]
         self.rel_vectors = None        # per batch: the code books of a general batch (set by EAGCN._graph_runner)
         self.index = self.slots[0]
         self.graphs = [[None, None, None], [None, None, None]]   # per slot: [forward, backward, whole step (fused loss)]

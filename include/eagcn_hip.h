@@ -209,10 +209,14 @@ typedef struct eagcn_layer_grads {
     float* dave_w;                          /* [K] or NULL                                      */
 } eagcn_layer_grads;
 
-/* 1 when batches of this shape take the bond-list form of the aggregation (csrc/sagg.hip: gather over the bonds + one rank-one
- * term per molecule instead of the dense nat x nat block; opt-in: EAGCN_AGG=sparse, padded sizes up to 256 atoms): the index must
- * then carry bond lists -- set eagcn_batch.build_lists = 1 before eagcn_index_rows. */
+/* 1 when batches of this shape take a bond-list form of the aggregation in either direction (csrc/lagg.hip: a block of up to 256
+ * packed rows staged in LDS, each row gathers its bonded rows, one rank-one term per molecule -- instead of the dense nat x nat
+ * block on the matrix cores; default for large molecules, for batches of up to 256 molecules and for the backward of Concate
+ * layers, padded sizes up to 256 atoms; csrc/sagg.hip: opt-in, EAGCN_AGG=sparse): the index must then carry bond lists and row
+ * blocks -- set eagcn_batch.build_lists = 1 (and eagcn_batch.blk) before eagcn_index_rows.  `structure`: EAGCN_STRUCT_* of the
+ * layers the index will serve, -1 when not known (the two-argument form). */
 int eagcn_agg_wants_bond_lists(int B, int N);
+int eagcn_agg_wants_bond_lists_for(int B, int N, int structure);
 
 /* ---- library ------------------------------------------------------------------------------- */
 int eagcn_abi_version(void);           /* 5 (round 5); bumped with every struct-layout / signature change */
