@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void index_rows_kernel(eagcn_batch bt) {
 // batch).  Block q is described by two int4 records, blk[2q] = {first molecule, molecules, first packed row, rows} and blk[2q+1] =
 // {first list entry, list entries, 0, 0} -- everything a workgroup needs to request its data with ONE dependent load.  The packing is
 // sequential by nature; ONE wavefront does it 64 molecules at a time (prefix sum of the row counts, then one ballot per closed block).
-__global__ __launch_bounds__(64) void index_blocks_kernel(eagcn_batch bt) {
+__global__ __launch_bounds__(64) void index_blocks_kernel(eagcn_batch bt, const int rb) {     // rb: rows a block may hold (<= LAGG_RB)
     const int lane = threadIdx.x;
     const int T = bt.meta[EAGCN_META_T];
     int4* out = reinterpret_cast<int4*>(bt.blk);
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(64) void index_blocks_kernel(eagcn_batch bt) {
             // a run of molecules none of which can share a block with its successor (batches of large molecules: every molecule its own
             // block) is closed by its lanes in parallel -- one closure per loop trip was 0.5 ms for 1024 molecules of 256 atoms
             if (cnt == 0) {
-                const bool solo = lane >= pos && lane < nv - 1 && n > 0 && n + n_next > LAGG_RB;
+                const bool solo = lane >= pos && lane < nv - 1 && n > 0 && n + n_next > rb;
                 const unsigned long long stop = ~__ballot(solo) & (~0ull << pos);
                 const int run_end = min(stop ? __ffsll((long long)stop) - 1 : 64, nv - 1);
                 if (run_end > pos) {
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(64) void index_blocks_kernel(eagcn_batch bt) {
             // lanes pos .. fit into the open block as long as rows and molecule count allow (monotone in the lane); an EMPTY block
             // takes its first molecule whatever its size
             const bool fits = lane >= pos && lane < nv &&
-                              ((rows + pre - before <= LAGG_RB && cnt + lane - pos + 1 <= LAGG_MAXM) || (cnt == 0 && lane == pos));
+                              ((rows + pre - before <= rb && cnt + lane - pos + 1 <= LAGG_MAXM) || (cnt == 0 && lane == pos));
             const int nfit = __popcll(__ballot(fits));
             if (nfit > 0) {
                 if (cnt == 0) { start = base + pos; start_r0 = __shfl(r0v, pos); start_e0 = __shfl(e0v, pos); }
@@ -874,7 +874,7 @@ extern "C" int eagcn_index_rows(const eagcn_batch* b, void* stream) {
     EAGCN_LAUNCH_CHECK();
     if (!b->build_lists) return EAGCN_OK;   // bond lists: GAT layers (gat.hip), bond-list aggregation (lagg.hip)
     if (b->blk) {
-        index_blocks_kernel<<<1, 64, 0, s>>>(*b);
+        index_blocks_kernel<<<1, 64, 0, s>>>(*b, lagg_block_rows(b));
         EAGCN_LAUNCH_CHECK();
     }
     const int W = (b->N + 31) / 32;

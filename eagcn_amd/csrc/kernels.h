@@ -37,6 +37,7 @@ struct EdgeArgs;
 int lagg_parts();
 bool lagg_use(const eagcn_batch* b, int dir, bool absorbs_bn);   // this batch takes that path (policy per direction + the index carries bond lists and row blocks)
 bool lagg_wanted(int B, int N, int structure);
+int lagg_block_rows(const eagcn_batch* b);     // rows per row block for batches of this shape (index_blocks_kernel; <= LAGG_RB)
 int lagg_slabs(const eagcn_batch* b);        // capacity of its BatchNorm partial slabs (one per row block; meta[NBLK] of them are live)
 int launch_lagg_fwd(AggArgs a, hipStream_t s);
 int launch_lagg_bwd(AggArgs a, const EdgeArgs& e, hipStream_t s);   // transposed aggregation + edge gradients (e.atomic must be set)

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         if (tid < LAGG_MAXM * LG_LPR) (&s_S[0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < LG_U; ++u) {
-            const int rr = g + LG_G * u;
+            const int rr = g + LG_G * u;                              // (consecutive groups = consecutive rows: no LDS bank conflicts)
+            const bool mine = rr < rows;
             if constexpr (TRANS) {
                 if (fuse_bn) {                                        // dY' from dH and Y'
                     const float4 bA = s_bn[0][l], bB = s_bn[1][l], bC = s_bn[2][l];
@@ -178,10 +179,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 }
             }
             if (!col_ok) { v[u] = make_float4(0.f, 0.f, 0.f, 0.f); if constexpr (TRANS) yv[u] = make_float4(0.f, 0.f, 0.f, 0.f); }
-            if (rr < rows) buf[rr][l] = v[u];
+            if (mine) buf[rr][l] = v[u];
             if constexpr (TRANS) {
                 const float d = lg_gsum(lg_dot(v[u], yv[u]));         // this chunk's part of rowdot_i (the operands are in registers)
-                if (rr < rows && l == 0) s_rd[rr] = d;
+                if (mine && l == 0) s_rd[rr] = d;
             }
         }
         const int my_mol = min(max(ri.x - m0, 0), LAGG_MAXM - 1), my_off = ri.w - R0;      // (of row `tid`, tid < rows)
@@ -202,6 +203,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
         }
         __syncthreads();                                              // B2: rows, lists, scales are in LDS
+        // ---- S_b (forward) / G_b = sum_i s_i dY'_i (transposed) per molecule: group g sums the contiguous rows [g per, (g + 1) per) -- all
+        //      of them read from LDS in ONE batch, then added up in registers (row by row behind the data-dependent molecule test the
+        //      reads cost 4 us of an 18 us launch at configs[1]; contiguous OWNERSHIP of rows -- sums straight from the staging
+        //      registers -- puts the eight groups of a wave on the same banks in every other phase: C5 11.0 -> 12.2 ms)
+        if (!(dbg & 1)) {
+            const int per = (rows + LG_G - 1) / LG_G, ra = g * per;
+            int mu[LG_U];
+            float wu[TRANS ? LG_U : 1];
+            float4 bu[LG_U];
+#pragma unroll
+            for (int u = 0; u < LG_U; ++u) {
+                const int rc = min(ra + u, rows - 1);
+                mu[u] = s_rm[rc];
+                bu[u] = buf[rc][l];
+                if constexpr (TRANS) wu[u] = s_rs[rc];
+            }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int cur = -1;
+            auto flush = [&]() {
+                if (cur >= 0) {
+                    float* dst = reinterpret_cast<float*>(&s_S[cur][l]);
+                    atomicAdd(dst + 0, acc.x); atomicAdd(dst + 1, acc.y); atomicAdd(dst + 2, acc.z); atomicAdd(dst + 3, acc.w);
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < LG_U; ++u) {
+                if (u < per && ra + u < rows) {
+                    if (mu[u] != cur) { flush(); acc = make_float4(0.f, 0.f, 0.f, 0.f); cur = mu[u]; }
+                    if constexpr (TRANS) lg_fma(acc, wu[u], bu[u]); else lg_add(acc, bu[u]);
+                }
+            }
+            flush();
+        }
         // entry `el` of the block's lists: {atom inside its molecule, sigma, code}; from LDS while the lists are there, else from memory
         auto entry = [&](int el, bool lds_ok, int& jn, float& w, uint32_t& c) __attribute__((always_inline)) {
             if (lds_ok && el < LG_ECAP) {
@@ -225,7 +259,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             float we[4] = {0.f, 0.f, 0.f, 0.f}, he[4] = {0.f, 0.f, 0.f, 0.f};
             uint32_t srcs = 0u, cds = 0u, slow = cnt > 4 ? LG_SLOW : 0u;
             float wsum = 0.0f;
-            double hd = 0.0;
             for (int e = 0; e < cnt; ++e) {
                 int jn; float w; uint32_t c;
                 entry(first + e, true, jn, w, c);
@@ -251,36 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 rec[0] = make_float4(we[0], we[1], we[2], we[3]);
                 rec[1] = make_float4(he[0], he[1], he[2], he[3]);
                 rec[NREC - 1] = make_float4(rsv, __uint_as_float(srcs), __uint_as_float(cds), __uint_as_float(meta));
-                // the part of the edge gradients that needs no column data: - h_e rowdot_src per bond, - s_j rowdot_j on the diagonal
-                if (!slow) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const uint32_t c = (cds >> (8 * e)) & 255u;
-                        if (c && he[e] != 0.0f) atomicAdd(&h_s[c], -(double)(he[e] * s_rd[(srcs >> (8 * e)) & 255u]));
-                    }
-                    if (rsv != 0.0f) hd = -(double)(rsv * s_rd[tid]);
-                }
-                dr_acc += hd;
             }
-        }
-        // ---- S_b (forward) / G_b = sum_i s_i dY'_i (transposed): group g sums a contiguous range of the block's rows ------------------
-        if (!(dbg & 1)) {
-            const int per = (rows + LG_G - 1) / LG_G;
-            const int ra = g * per, rb = min(rows, ra + per);
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int cur = -1;
-            auto flush = [&]() {
-                if (cur >= 0) {
-                    float* dst = reinterpret_cast<float*>(&s_S[cur][l]);
-                    atomicAdd(dst + 0, acc.x); atomicAdd(dst + 1, acc.y); atomicAdd(dst + 2, acc.z); atomicAdd(dst + 3, acc.w);
-                }
-            };
-            for (int rr = ra; rr < rb; ++rr) {
-                const int m = s_rm[rr];
-                if (m != cur) { flush(); acc = make_float4(0.f, 0.f, 0.f, 0.f); cur = m; }
-                if constexpr (TRANS) lg_fma(acc, s_rs[rr], buf[rr][l]); else lg_add(acc, buf[rr][l]);
-            }
-            flush();
         }
         if constexpr (TRANS) __syncthreads();                         // B2b: every thread is done with the lists: the records take their place
         if (tid < rows) {
@@ -299,11 +303,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         __syncthreads();                                              // B3: records and S_b / G_b are complete
         double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
         // ---- the rows: 8 lanes own a row -----------------------------------------------------------------------------------------------
+        // (the NEXT row's record is read while this row's gathers are in flight: a row is a chain record -> gathers -> FMAs -> store, and
+        //  the early exit keeps the compiler from overlapping two rows on its own)
+        //  (forward only: the transposed kernel has no registers to spare at three workgroups per CU)
+        constexpr bool AHEAD = !TRANS;
+        float4 nrec[NREC];
+        if constexpr (AHEAD) {
+#pragma unroll
+            for (int i = 0; i < NREC; ++i) nrec[i] = s_rec[min(g, rows - 1)][i];
+        }
 #pragma unroll
         for (int u = 0; u < LG_U; ++u) {
             const int rr = g + LG_G * u;
             if (rr >= rows) break;
-            const float4 r0 = s_rec[rr][0], r1 = s_rec[rr][1], rl = s_rec[rr][NREC - 1];
+            if constexpr (!AHEAD) {
+#pragma unroll
+                for (int i = 0; i < NREC; ++i) nrec[i] = s_rec[rr][i];
+            }
+            const float4 r0 = nrec[0], r1 = nrec[1], rl = nrec[NREC - 1];
+            if (AHEAD && u + 1 < LG_U) {
+#pragma unroll
+                for (int i = 0; i < NREC; ++i) nrec[i] = s_rec[min(rr + LG_G, rows - 1)][i];
+            }
             const uint32_t srcs = __float_as_uint(TRANS ? rl.y : rl.z), meta = __float_as_uint(rl.w);
             const int cnt_r = (int)((meta >> 16) & 255u), first_r = (int)(meta & 0xFFFFu);
             const float4 self = buf[rr][l];
@@ -343,13 +364,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     // edge gradients of the bonds into j (this chunk's columns), and the diagonal
                     const float g0 = lg_gsum(lg_dot(v0, pj)), g1 = lg_gsum(lg_dot(v1, pj)), g2 = lg_gsum(lg_dot(v2, pj)), g3 = lg_gsum(lg_dot(v3, pj));
                     const float gs = lg_gsum(lg_dot(self, pj));
-                    if (l == 0) {
+                    // d w[code_e] += h_e (g_e - rowdot_src): lane e (< 4) of the row's eight adds bond e's term, lane 4 the diagonal's
+                    {
                         const uint32_t cds = __float_as_uint(rl.z);
-                        if (r1.x != 0.0f && (cds & 255u)) atomicAdd(&h_s[cds & 255u], (double)(r1.x * g0));
-                        if (r1.y != 0.0f && ((cds >> 8) & 255u)) atomicAdd(&h_s[(cds >> 8) & 255u], (double)(r1.y * g1));
-                        if (r1.z != 0.0f && ((cds >> 16) & 255u)) atomicAdd(&h_s[(cds >> 16) & 255u], (double)(r1.z * g2));
-                        if (r1.w != 0.0f && (cds >> 24)) atomicAdd(&h_s[cds >> 24], (double)(r1.w * g3));
-                        dr_acc += (double)(sj * gs);
+                        const int e4 = l & 3;
+                        const float hv = e4 == 0 ? r1.x : e4 == 1 ? r1.y : e4 == 2 ? r1.z : r1.w;
+                        const float gv = e4 == 0 ? g0 : e4 == 1 ? g1 : e4 == 2 ? g2 : g3;
+                        const uint32_t cv = (cds >> (8 * e4)) & 255u, sv = (srcs >> (8 * e4)) & 255u;
+                        if (l < 4 && hv != 0.0f && cv) atomicAdd(&h_s[cv], (double)hv * ((double)gv - (double)s_rd[sv]));
+                        if (l == 4) dr_acc += (double)sj * ((double)gs - (double)s_rd[rr]);
                     }
                 } else {
                     // the general loop (more than four bonds / a self bond): lists from memory (their LDS copy is gone)
@@ -473,17 +496,26 @@ bool lagg_use(const eagcn_batch* b, int dir, bool absorbs_bn) {
     if (large) return true;
     return dir ? absorbs_bn : b->B <= lagg_fwd_maxb();
 }
+// Rows per block: always LAGG_RB.  Measured (EAGCN_LAGG_RB = 256 / 128 / 64 / 32, whole step in ms): Tox21 B = 256 0.423 / 0.431 / 0.458 /
+// 0.541, B = 1024 0.889 / 0.906 / 0.991 / 1.172, Lipo B = 512 1.348 / 1.375 / 1.518 / 1.641 -- more, smaller blocks (more workgroups per CU
+// to hide a block's barrier-separated phases) lose: a block's fixed cost (eight clamped row loads per thread whatever the row count, the
+// record pass, four barriers) is what a launch pays per block, and the per-molecule column sums stop being shared.
+int lagg_block_rows(const eagcn_batch* b) {
+    static const int fixed = [] { const char* e = getenv("EAGCN_LAGG_RB"); return e ? atoi(e) : 0; }();
+    (void)b;
+    return fixed > 0 ? std::min(fixed, LAGG_RB) : LAGG_RB;
+}
 int lagg_slabs(const eagcn_batch* b) { return std::max(1, b->B); }
 
 static int lagg_grid(const AggArgs& a, dim3* grid, int* nchunk) {
     int wmax = 0;
     for (int k = 0; k < a.vc.K; ++k) wmax = std::max(wmax, a.vc.off[k + 1] - a.vc.off[k]);
     *nchunk = cdiv(wmax, LG_CW);
-    // y: an ESTIMATE of the block count from the rows batches of this shape hold (two consecutive blocks together exceed LAGG_RB rows
-    // or LAGG_MAXM molecules); the kernel loops, so any count is handled, and a tight grid spares the launch thousands of workgroups
+    // y: an ESTIMATE of the block count from the rows batches of this shape hold (a block closes at LAGG_RB rows or LAGG_MAXM molecules:
+    // 1.25 x the larger of the two quotients); the kernel loops, so any count is handled, and a tight grid spares the launch thousands of workgroups
     // that would only find out that they have no block
     const int rows = a.bt.t_hint > 0 ? std::min(a.bt.t_hint, a.bt.T) : a.bt.T;
-    const int est = 2 * (rows / LAGG_RB + a.bt.B / LAGG_MAXM) + 2;
+    const int est = 5 * std::max(rows / lagg_block_rows(&a.bt), a.bt.B / LAGG_MAXM) / 4 + 2;
     *grid = dim3((unsigned)(a.vc.K * *nchunk), (unsigned)std::max(1, std::min(std::min(a.bt.B, est), 65535)));
     return EAGCN_OK;
 }
