@@ -634,17 +634,18 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
                                           bx_per > 0 ? ((meta[EAGCN_META_T] + bxm - 1) / bxm) * ((ld_in + bxn - 1) / bxn) : 0, max(1, (fp + 31) >> 5), bx_per)
                         : max(1, min(nsplit, meta[EAGCN_META_T] >> 7));
     if ((int)blockIdx.x < wblocks) {
-        // split-K slabs: FOUR lanes per element, each adds every fourth slab (the first layer's weight gradient leaves gemm.hip
-        // as up to 146 slabs: one thread per element was a chain of 37 dependent load rounds, 14 us at B = 1024)
+        // split-K slabs: FOUR lanes per group of four adjacent elements (one 16-byte load per slab: a wavefront covers 256 contiguous
+        // bytes of four slabs), each lane adds every fourth slab (the first layer's weight gradient leaves gemm.hip as up to 146 slabs:
+        // one thread per element was a chain of 37 dependent load rounds, 14 us at B = 1024; four lanes per SINGLE element, 64-byte
+        // pieces: 15 us for the 14 slabs of configs[1]'s hidden layer)
         const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-        const int sub = xk_G > 0 ? 0 : (tid & 3);
-        const int e = xk_G > 0 ? tid : (tid >> 2);
-        if (e >= ld_in * fp) return;
-        const int ip = e / fp, cp = e % fp;
-        const int k = col_view(vc, cp), f = cp - vc.off[k];
-        const int fi = packed_to_exact(in, ip);
-        if (fi < 0 || f >= vc.width[k]) return;
         if (xk_G > 0) {
+            const int e = tid;
+            if (e >= ld_in * fp) return;
+            const int ip = e / fp, cp = e % fp;
+            const int k = col_view(vc, cp), f = cp - vc.off[k];
+            const int fi = packed_to_exact(in, ip);
+            if (fi < 0 || f >= vc.width[k]) return;
             // partial slabs of the XCD-local paired GEMM (gemm3.hip, kernels.h g3_plan): slab x exists iff segment x holds
             // k-steps of the dW product; summed in segment order (deterministic)
             const int T = meta[EAGCN_META_T];
@@ -660,18 +661,32 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(GradPtrs gp, ParamPtr
             gp.dW[k][(size_t)fi * vc.width[k] + f] = T > 0 ? t : 0.0f;
             return;
         }
-        float s0 = 0.0f, s1 = 0.0f;
+        const int sub = tid & 3;
+        const int e = (tid >> 2) * 4;                                // (fp is a multiple of 16: the four elements share row and view)
+        if (e >= ld_in * fp) return;
+        const int ip = e / fp, cp = e % fp;
+        const int k = col_view(vc, cp), f = cp - vc.off[k];
+        const int fi = packed_to_exact(in, ip);
+        if (fi < 0 || f >= vc.width[k]) return;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
         int z = sub;
 #pragma unroll 4
         for (; z + 4 < nsplit; z += 8) {
-            s0 += dWcat[(size_t)z * slab + e];
-            s1 += dWcat[(size_t)(z + 4) * slab + e];
+            const float4 a0 = *reinterpret_cast<const float4*>(dWcat + (size_t)z * slab + e);
+            const float4 a1 = *reinterpret_cast<const float4*>(dWcat + (size_t)(z + 4) * slab + e);
+            s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+            s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
         }
-        if (z < nsplit) s0 += dWcat[(size_t)z * slab + e];
-        float t = s0 + s1;
-        t += __shfl_xor(t, 1);
-        t += __shfl_xor(t, 2);
-        if (sub == 0) gp.dW[k][(size_t)fi * vc.width[k] + f] = t;
+        if (z < nsplit) {
+            const float4 a0 = *reinterpret_cast<const float4*>(dWcat + (size_t)z * slab + e);
+            s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+        }
+        float t[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t[j] += __shfl_xor(t[j], 1); t[j] += __shfl_xor(t[j], 2); }
+        // lane j of the four stores element j
+        const float tv = sub == 0 ? t[0] : sub == 1 ? t[1] : sub == 2 ? t[2] : t[3];
+        if (f + sub < vc.width[k]) gp.dW[k][(size_t)fi * vc.width[k] + f + sub] = tv;
         return;
     }
     // edge-gradient partials [nedge][K][EDGE_SLAB]: entry c in 1..C_k -> d att_w[c-1]; entry 256 -> self term.
@@ -1380,7 +1395,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             { int rcz = zero_fill(gp.dW[k], (size_t)d.fin * p->width[k] * sizeof(float), side); if (rcz) return rcz; }
     }
     {
-        const int wblocks = nsplit > 0 ? cdiv((int)d.wslab * (xk_G > 0 ? 1 : 4), 256) : 0;     // (four lanes per element, unpack_grads)
+        const int wblocks = nsplit > 0 ? cdiv((int)d.wslab, 256) : 0;     // (one thread per element: four lanes per four elements, unpack_grads)
         double* edge_src = nedge == -EDGE_COPIES ? sc.eacc : sc.datt;
         const int edge_drain = edge_src == sc.eacc ? 1 : 0;       // shared accumulators: zeroed again by the threads that read them
         static const bool defer_env = [] { const char* v = getenv("EAGCN_NO_EDGE_DEFER"); return !(v && v[0] == '1'); }();
