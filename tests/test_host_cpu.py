@@ -320,3 +320,30 @@ def test_pad_row_binomial_thresholds_are_the_binomial_cdf():
         ref = np.floor(binom.cdf(np.arange(m + 1), m, q) * 2.0 ** 32)
         assert np.abs(t - np.minimum(ref, 4294967295.0)).max() <= 1.0, (m, q)
         assert (np.diff(t) >= 0).all() and t[-1] == 4294967295.0
+
+
+def test_bond_list_policy_by_shape_and_structure():
+    """Which batch shapes carry bond lists / row blocks for the LDS-staged aggregation (csrc/lagg.hip lagg_wanted; no kernel runs):
+    large padded sizes, batches of up to 256 molecules, and every Concate shape; Weighted_sum layers of small molecules in large
+    batches stay on the matrix-core kernels; nothing beyond 256 atoms.  In a subprocess: the policy reads EAGCN_AGG once."""
+    import subprocess
+    import sys
+    code = r'''
+import os
+for k in ('EAGCN_AGG', 'EAGCN_LAGG_MIN_N', 'EAGCN_LAGG_FWD_MAXB'):
+    os.environ.pop(k, None)
+from eagcn_amd import _lib as L
+lib = L.load()
+f = lib.eagcn_agg_wants_bond_lists_for
+C, W = L.STRUCT_CONCATE, L.STRUCT_WEIGHTED
+got = [f(256, 132, C), f(1024, 132, C), f(1024, 222, W), f(256, 222, W), f(1024, 256, W), f(64, 300, C), f(1024, 222, -1),
+       lib.eagcn_agg_wants_bond_lists(1024, 222), lib.eagcn_agg_wants_bond_lists(8, 257)]
+print(got)
+assert got == [1, 1, 0, 1, 1, 0, 1, 1, 0], got
+'''
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout + r.stderr
+    forced = subprocess.run([sys.executable, '-c', code.replace("os.environ.pop(k, None)", "os.environ.pop(k, None)\nos.environ['EAGCN_AGG'] = 'dense'")
+                             .replace("assert got == [1, 1, 0, 1, 1, 0, 1, 1, 0], got", "assert got == [0] * 9, got")],
+                            capture_output=True, text=True, cwd=str(ROOT))
+    assert forced.returncode == 0, forced.stdout + forced.stderr
