@@ -1,6 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) vs the committed golden vectors of the unmodified
 reference and vs the CPU oracle on the same seeded inputs.  fp32, tolerance 1e-5 relative
 (max|d| / max|ref|), as BASELINE.json's north_star states."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -26,7 +27,8 @@ def _hip_model(meta, n_layers=4):
 # gradient than the reference's own fp32 gradient is, each held to its measured ratio x 1.1.  Every other gradient of every
 # case is either within 1e-5 of the fp32 reference (relative to the tensor's own largest entry) or at most as far from the
 # float64 gradient as the fp32 reference is (ratio <= 1).  A tensor regressing beyond its entry fails its test.
-KNOWN_FARTHER = {
+_KNOWN_FARTHER_DENSE = {
+    # ONLY with the dense aggregation forced (EAGCN_AGG=dense, the default path of rounds 1-4 for these cases):
     # both evaluations of a 28-row BatchNorm four layers deep: 1.7e-5 vs 5.0e-6 of the tensor's own max (measured ratio 3.65)
     # (round 3 held this WHOLE case to 4x; the tensors beyond 1x, each with its measured ratio x 1.1 -- layer widths 27 / 32: the
     #  fp32-MFMA products, not the plane GEMMs)
@@ -34,11 +36,26 @@ KNOWN_FARTHER = {
                                'layer3.block1.graph_conv.weight': 1.6, 'layer4.block1.batch_norm.bn.bias': 1.9},
     # a view whose BatchNorm sees 3 x 270 rows: 1.4e-3 vs 4.2e-4 (measured ratio 3.3)
     'tox21_shape[Concate-2-3-270]': {'layer2.block4.graph_conv.weight': 3.7},
+}
+# Round 5, where the entries above come from (VERDICT round 4 item 9 asked: the analytic pad-row term or the fp64 -> fp32 finalize?):
+# neither -- the arithmetic of the DENSE AGGREGATION kernels.  The same fixtures through the list form (lagg.hip, the default for these
+# batch sizes since round 5; everything else of the step unchanged): layer2.block4.batch_norm.bn.weight is within 1e-5 of the fp32
+# reference outright (dense: 3.65x farther from float64 than the reference), the two weight gradients are CLOSER to float64 than the
+# reference (0.85, 0.82; dense 1.18, 1.46), the 3 x 270-row case needs no exception, and one tensor stays marginally farther (1.13;
+# dense 1.72).  agg.hip accumulates a row of A^ over ALL columns of the molecule's block on the fp32 matrix core -- the nat - deg filler
+# terms of 1e-9 one by one next to the O(1) bond weights, and the edge gradients' dot products in the same blocked order; lagg.hip adds the
+# filler as ONE rank-one term per molecule and a row's few bonds in a single FMA chain.  The same effect, larger, at 256-atom
+# molecules: d att.weight 6e-4 (dense) against 1e-6 (lists) of its scale from float64 (tests/test_gpu_lagg.py,
+# profiles/r05_lagg_vs_dense.txt).  EAGCN_AGG=dense reproduces the old ratios exactly (and this table then includes them).
+KNOWN_FARTHER = {
+    'model_concate_isolated': {'layer4.block1.batch_norm.bn.bias': 1.3},
     # ONLY in gemm mode 0 (EAGCN_GEMM_X6=0: the fp32-MFMA stream-K kernel of round 3): one weight gradient of the configs[0] shape is
     # 2.3x farther from the float64 gradient than the reference's own fp32 one (3.1e-5 vs 1.3e-5 of its own max); the default plane
     # GEMM (mode 3) is inside 1x on every tensor of this case
     'configs0@mode0': {'layer2.block2.graph_conv.weight': 2.6},
 }
+if os.environ.get('EAGCN_AGG') == 'dense':
+    KNOWN_FARTHER.update(_KNOWN_FARTHER_DENSE)
 
 
 def _gemm_mode():
