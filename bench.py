@@ -136,6 +136,19 @@ def moved_bytes(cfg, mb):
     return adj + gathered + codes + algorithmic_bytes(cfg, mb.sizes, mb.N)[1]
 
 
+def aggregation_bytes(cfg, rows):
+    """Algorithmic bytes per step of the aggregation kernels (what `roofline_aggregation` prices against 8 TB/s): per layer and packed
+    row the forward reads P and writes Y' (8 B per column), the backward reads dH, Y' and P and writes dP (16 B per column; the dP
+    planes of the plane GEMM are 6 B instead of 4: not counted).  Exact widths; bond lists / codes are < 2 % of it."""
+    K = len(cfg['widths1'])
+    w1, w2 = list(cfg['widths1']), list(cfg['widths2'])
+    if cfg['structure'] == 'Weighted_sum':
+        w1, w2 = [sum(w1)] * K, [sum(w2)] * K
+    w3 = [2 * w for w in w2]
+    cols = sum(sum(ws) for ws in [w1, w2, w3, w3][:cfg['n_layers']])
+    return (8.0 + 16.0) * float(rows) * cols
+
+
 def committed_traffic(kernel_substr):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of this command
     (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json; rocprofv3 cannot run inside bench.py)."""
@@ -489,6 +502,17 @@ def main():
                          'launches': int(g_n), 'avg_launch_us': round(g_ms * 1e3 / max(g_n, 1), 3),
                          'measured': 'HIP events on the launch stream, %s' % ('inside the timed region' if res['profile_in_loop'] else
                                      '%d eager steps of the same workload right after the timed graph-replay region' % prof_steps)},
+            # second roofline object: the aggregation kernels of all layers, both directions, as one class (HIP events: PROF_AGG)
+            'roofline_aggregation': {
+                'kernel': 'lagg_kernel<false|true> / agg_kernel / agg_wave_kernel / agg_edge_kernel: every aggregation launch of the step '
+                          '(forward Y\' = A^.P, backward dP = A^T.dY\' + edge gradients [+ BatchNorm-backward second pass])',
+                'bound': 'hbm', 'unit': 'GB/s', 'peak': PEAK_HBM_GBS,
+                'achieved': round(aggregation_bytes(cfg, mb.sizes.sum()) / 1e9 / max(kern['agg'][0] / prof_steps * 1e-3, 1e-12), 1),
+                'frac': round(aggregation_bytes(cfg, mb.sizes.sum()) / 1e9 / max(kern['agg'][0] / prof_steps * 1e-3, 1e-12) / PEAK_HBM_GBS, 4),
+                'algorithmic_mbytes_per_step': round(aggregation_bytes(cfg, mb.sizes.sum()) / 1e6, 1),
+                'ms_per_step': round(kern['agg'][0] / prof_steps, 4), 'launches_per_step': int(kern['agg'][2] / max(prof_steps, 1)),
+                'note': 'at Tox21 batch sizes these launches are a few workgroups per CU, each working ONE block of rows through its '
+                        'barrier-separated phases: latency, not bytes (DESIGN.md 9 item 1)'},
             'layer_gemm_tflops_all': round(((kern['gemm'][1] + kern.get('gemm_pair', (0, 0, 0))[1]) /
                                             max((kern['gemm'][0] + kern.get('gemm_pair', (0, 0, 0))[0]) * 1e-3, 1e-12)) / 1e12, 3),
             'kernel_ms_per_step': {k: round(v[0] / prof_steps, 4) for k, v in kern.items()},
@@ -559,7 +583,8 @@ def main():
                 out['cpu_baseline_b1024'] = cpu_baseline(cfg, mb2, args.dropout, bce_w_of(cfg), steps=2, warmup=1, threads=out['cpu_baseline']['cores'])
         # the numbers DESIGN.md quotes, compact, at the END of the line (the driver keeps the tail of long lines)
         summ = {'c2': [out['ms_per_step'], out['value']], 'roofline_frac': out['roofline']['frac'], 'dominant_kernel_us': out['roofline']['avg_launch_us'],
-                'step_frac': out['roofline']['step_frac'], 'hbm_frac_moved': out['roofline']['hbm_frac_moved']}
+                'step_frac': out['roofline']['step_frac'], 'hbm_frac_moved': out['roofline']['hbm_frac_moved'],
+                'agg_hbm_frac': out['roofline_aggregation']['frac']}
         for k, e in out.get('extra', {}).items():
             summ[k] = [e['ms_per_step'], e['value']]
         for k in ('cpu_baseline', 'cpu_baseline_configs0', 'cpu_baseline_b1024'):
