@@ -16,9 +16,11 @@
 //   * it loads the block's rows of the operand (one 16-byte load per lane and row: 128 contiguous bytes per row), the rows' list
 //     headers and the block's list entries (contiguous: the entries of molecule b live in [edge0[b], edge0[b+1])) in ONE batch of
 //     independent loads, and puts them into LDS (32 KB of operand; list entries as {atom, sigma});
-//   * S_b: 32 groups of 8 lanes sum contiguous row ranges and add them to the molecule's LDS slot;
-//   * then 8 lanes own a row: deg + 1 `ds_read_b128` gathers, a handful of FMAs, one 16-byte store.  BatchNorm partial sums (fp64)
-//     are carried per lane and leave as one slab per row block (layer.hip bn_finalize counts the live blocks from meta[NBLK]).
+//   * one thread per row turns the row's list into a RECORD -- four bond weights with the row scale and the filler folded in, the
+//     source rows, the self / rank-one weights (struct comment below) -- so that the row loop has no list walk and no branch;
+//   * S_b: 32 groups of 8 lanes sum contiguous row ranges (one batch of LDS reads) and add them to the molecule's LDS slot;
+//   * then 8 lanes own a row: 2-3 record reads, five `ds_read_b128` gathers, 24 FMAs, one 16-byte store.  BatchNorm partial sums
+//     (fp64) are carried per lane and leave as one slab per row block (layer.hip bn_finalize counts the live blocks from meta[NBLK]).
 // Every operand element is read from memory once and every result written once; the matrix cores are not involved (there is no
 // dense block to multiply).
 // Backward (one kernel): the transposed aggregation dP[j,:] = sum_{bonds (i,j)} s_i sigma_ij dY'[i,:] + s_j r dY'[j,:] + 1e-9 (G_b -
@@ -27,6 +29,11 @@
 //     dA^[i,j] = <dY'[i,:], P[j,:]> ,  rowdot_i = <dY'[i,:], Y'[i,:]> ,  dU[i,j] = s_i (dA^[i,j] - rowdot_i)
 // are partial sums over the workgroup's 32 columns (everything is linear in them): d w_k[c] += dU s (1 - s) by bond type through an
 // LDS histogram, d self_r from the diagonal, flushed with fp64 atomics into the shared accumulator slabs (kernels.h EDGE_COPIES).
+// The BatchNorm backward's second pass (layer.hip bn_bwd_apply_kernel: dY' from dH, Y' and five per-column constants) is applied to the
+// rows while they are staged (AggArgs.bn_tab; Concate layers): that launch, and a write and a read of T x Fp floats, are gone -- which
+// is what makes this kernel the faster BACKWARD for every Concate configuration, small molecules included (policy: lagg_use below).
+// Accuracy: the filler enters as one exact rank-one term per molecule instead of nat - deg products of 1e-9 summed one by one on the
+// fp32 matrix core: against float64 d att.weight is off by 1e-6 of its scale at 256-atom molecules where agg.hip is off by up to 6e-4.
 #include <stdlib.h>
 
 #include <algorithm>
