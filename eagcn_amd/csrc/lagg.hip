@@ -73,12 +73,19 @@ struct LgLists {
 //   meta = first list entry (16 bits, relative to the block) | bonds << 16 (8 bits) | molecule << 24 (4 bits) | SLOW << 28
 //   SLOW rows (more than four bonds, or -- transposed -- a self bond) take the general loop over the lists instead
 constexpr uint32_t LG_SLOW = 1u << 28;
+//   rows with five to eight bonds: bonds 4..7 in an OVERFLOW record of the same layout (LG_NOVF slots per block, handed out by an LDS
+//   counter; meta's low 16 bits then hold the slot): the row stays in the branch-light first pass.  Beyond eight bonds, a self bond
+//   (transposed) or no slot left: SLOW.
+constexpr uint32_t LG_OVF = 1u << 29;
+constexpr int LG_NOVF = 32;
 
 template <bool TRANS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void lagg_kernel(AggArgs a, EdgeArgs ed) {
     constexpr int NREC = TRANS ? 3 : 2;
     __shared__ float4 buf[LAGG_RB][LG_LPR];          // the block's operand rows x this chunk's columns (32 KB)
     __shared__ float4 s_rec[LAGG_RB][NREC];          // row records (8 / 12 KB)
+    __shared__ float4 s_ovf[LG_NOVF][NREC];          // overflow records (bonds 4..7 of the rows that have them)
+    __shared__ int s_novf;
     __shared__ __attribute__((aligned(16))) unsigned char s_lists_raw[TRANS ? 16 : sizeof(LgLists)];   // forward: the staged lists
     __shared__ float s_rs[TRANS ? LAGG_RB : 1];      // transposed: s_i = m_i / rowsum_i
     __shared__ float s_rd[TRANS ? LAGG_RB : 1];      // transposed: this chunk's part of rowdot_i = <dY'_i, Y'_i>
@@ -91,17 +98,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     // transposed: the lists live in the record array until the records are built (LDS: 51 KB = three workgroups per CU either way)
     static_assert(sizeof(LgLists) <= sizeof(float4) * LAGG_RB * 3, "lists alias the transposed record array");
     LgLists& L = *reinterpret_cast<LgLists*>(TRANS ? reinterpret_cast<unsigned char*>(&s_rec[0][0]) : s_lists_raw);
-
     const eagcn_batch& bt = a.bt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = blockIdx.x / a.nchunk, cc = blockIdx.x - k * a.nchunk;
     const int wk = a.vc.off[k + 1] - a.vc.off[k];                    // padded width of the view (a multiple of 16)
     if (cc * LG_CW >= wk) return;                                     // (uniform)
+    // the first block's record is requested together with the block count it is checked against (the index is inside the record
+    // array's capacity -- one record per molecule and gridDim.y <= B): one memory round trip at the head of the workgroup, not two
+    const int4* blk4 = reinterpret_cast<const int4*>(bt.blk);
+    int4 b0n = blk4[2 * blockIdx.y], b1n = blk4[2 * blockIdx.y + 1];
     const int nblk = bt.meta[EAGCN_META_NBLK];
     const int nlog = dev_n(bt);
     const float r = a.rsig[k];
     sig_s[tid] = a.sig[k * 256 + tid];                               // (made visible by the first barrier of the block loop)
-    const int l = tid & (LG_LPR - 1), g = tid / LG_LPR;
+    const int l = tid & (LG_LPR - 1);
+    int g = tid / LG_LPR;                                             // (row group; re-declared opaque per block below)
     const int col = cc * LG_CW + 4 * l;                               // this lane's first column inside the view
     const bool col_ok = col < wk;
     const int c0 = a.vc.off[k] + col;
@@ -113,7 +124,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     if constexpr (TRANS) { h_s[tid] = 0.0; if (tid < 8) h_s[256 + tid] = 0.0; }
     double dr_acc = 0.0;
     const int dbg = a.xcd;                                            // (probe mask, EAGCN_LAGG_DBG: wrong results)
-    const int4* blk4 = reinterpret_cast<const int4*>(bt.blk);
     const int4* rinfo = reinterpret_cast<const int4*>(bt.row_info);
     // transposed with the BatchNorm backward's second pass folded in (AggArgs.bn_tab): this lane's five per-column constants
     const bool fuse_bn = TRANS && a.bn_tab != nullptr;
@@ -135,7 +145,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     // on, a persistent grid of three workgroups per CU): 212 / 238 registers = two workgroups per CU instead of three, and slower.
     for (int q = blockIdx.y; q < nblk; q += gridDim.y) {
         // the block: {first molecule, molecules, first packed row, rows} {first list entry, entries} -- one dependent load, then everything
-        const int4 b0 = blk4[2 * q], b1 = blk4[2 * q + 1];
+        const int4 b0 = b0n, b1 = b1n;
+        asm volatile("" : "+v"(g));                                   // (a workgroup has ONE block as a rule: per-thread row indices and LDS
+                                                                      //  addresses hoisted out of this loop only cost registers -- and spilled)
+        if (q + (int)gridDim.y < nblk) { b0n = blk4[2 * (q + gridDim.y)]; b1n = blk4[2 * (q + gridDim.y) + 1]; }      // (only when the grid was an underestimate)
         const int m0 = b0.x, R0 = b0.z, rows = min(b0.w, LAGG_RB), E0 = b1.x, ne = b1.y;
         if (rows <= 0) {                                              // (uniform) nothing stored: the slab still has to be defined
             if constexpr (!TRANS) {
@@ -171,7 +184,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
         }
         __syncthreads();                                              // B1: the LDS of the previous block is free
-        if (tid < LAGG_MAXM * LG_LPR) (&s_S[0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < LAGG_MAXM * LG_LPR) {
+            float z;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z));                // (made here: hoisted out of the block loop the zero vector is spilled)
+            (&s_S[0][0])[tid] = make_float4(z, z, z, z);
+        }
+        if (tid == 0) s_novf = 0;
 #pragma unroll
         for (int u = 0; u < LG_U; ++u) {
             const int rr = g + LG_G * u;                              // (consecutive groups = consecutive rows: no LDS bank conflicts)
@@ -263,34 +281,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         const int first = pt.x - E0, cnt = (dbg & 2) ? 0 : pt.y;
         float4 rec[NREC];
         if (tid < rows) {
-            float we[4] = {0.f, 0.f, 0.f, 0.f}, he[4] = {0.f, 0.f, 0.f, 0.f};
-            uint32_t srcs = 0u, cds = 0u, slow = cnt > 4 ? LG_SLOW : 0u;
+            float we[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, he[TRANS ? 8 : 1] = {0.f};
+            uint32_t srcs = 0u, cds = 0u, srcs2 = 0u, cds2 = 0u, slow = cnt > 8 ? LG_SLOW : 0u;
             float wsum = 0.0f;
-            for (int e = 0; e < cnt; ++e) {
-                int jn; float w; uint32_t c;
-                entry(first + e, true, jn, w, c);
-                wsum += w;
+            if constexpr (TRANS) {
+#pragma unroll
+                for (int e = 1; e < 8; ++e) he[e] = 0.0f;
+            }
+            auto take = [&](int e, int jn, float w, uint32_t c, float ss) __attribute__((always_inline)) {
                 const int src = min(my_off + jn, LAGG_RB - 1);
                 if constexpr (TRANS) { if (src == tid) slow = LG_SLOW; }      // (a self bond: the diagonal of the edge gradients is this entry)
-                if (e < 4) {
-                    const float ss = TRANS ? s_rs[src] : 1.0f;
-                    we[e] = ss * (w - TINY);
-                    srcs |= (uint32_t)src << (8 * e);
-                    if constexpr (TRANS) { he[e] = ss * w * (1.0f - w); cds |= c << (8 * e); }
+                const float wv = ss * (w - TINY), hv = TRANS ? ss * w * (1.0f - w) : 0.0f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)                           // (constant register indices)
+                    if (q == e) { we[q] = wv; if constexpr (TRANS) he[q] = hv; }
+                if (e < 4) { srcs |= (uint32_t)src << (8 * e); if constexpr (TRANS) cds |= c << (8 * e); }
+                else { srcs2 |= (uint32_t)src << (8 * (e - 4)); if constexpr (TRANS) cds2 |= c << (8 * (e - 4)); }
+            };
+            if (first + 8 <= LG_ECAP) {
+                // the row's first eight list slots in ONE batch of LDS reads (slots beyond its count: any legal slot, not used), the scales
+                // of their source rows in a second: two LDS round trips per row instead of two per bond
+                int jn8[8]; float w8[8], ss8[8]; uint32_t c8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { jn8[e] = L.nb[first + e]; w8[e] = L.w[first + e]; c8[e] = L.cd[first + e]; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss8[e] = TRANS ? s_rs[min(my_off + jn8[e], LAGG_RB - 1)] : 1.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < cnt) { wsum += w8[e]; take(e, jn8[e], w8[e], c8[e], ss8[e]); }
+                for (int e = 8; e < cnt; ++e) {                       // (a SLOW row: only its row sum is needed here)
+                    int jn; float w; uint32_t c;
+                    entry(first + e, true, jn, w, c);
+                    wsum += w;
+                }
+            } else {
+                for (int e = 0; e < cnt; ++e) {
+                    int jn; float w; uint32_t c;
+                    entry(first + e, true, jn, w, c);
+                    wsum += w;
+                    if (e < 8) take(e, jn, w, c, TRANS ? s_rs[min(my_off + jn, LAGG_RB - 1)] : 1.0f);
+                    else if constexpr (TRANS) { if (min(my_off + jn, LAGG_RB - 1) == tid) slow = LG_SLOW; }
                 }
             }
             for (int e = min(cnt, 4); e < 4; ++e) srcs |= (uint32_t)tid << (8 * e);       // (weight 0: any legal row)
-            const uint32_t meta = (uint32_t)(first & 0xFFFF) | ((uint32_t)min(cnt, 255) << 16) | ((uint32_t)my_mol << 24) | slow;
+            for (int e = min(max(cnt, 4), 8); e < 8; ++e) srcs2 |= (uint32_t)tid << (8 * (e - 4));
+            int slot = 0;
+            if (cnt > 4 && !slow) {
+                slot = atomicAdd(&s_novf, 1);
+                if (slot >= LG_NOVF) slow = LG_SLOW;
+            }
+            const bool ovf = cnt > 4 && !slow;
+            const uint32_t meta = (uint32_t)((ovf ? slot : first) & 0xFFFF) | ((uint32_t)min(cnt, 255) << 16) | ((uint32_t)my_mol << 24) | slow | (ovf ? LG_OVF : 0u);
             if constexpr (!TRANS) {
                 const float d = wsum + r * rsv + TINY * (float)(nlog - cnt);           // rowsum: sum sigma + r m_i + 1e-9 (columns without a bond)
                 const float sc = rsv > 0.0f ? 1.0f / d : 0.0f;
                 if (cc == 0) a.rscale[(size_t)k * bt.T + R0 + tid] = sc;
                 rec[0] = make_float4(sc * we[0], sc * we[1], sc * we[2], sc * we[3]);
                 rec[1] = make_float4(sc * r * rsv, sc, __uint_as_float(srcs), __uint_as_float(meta));
+                if (ovf) {
+                    s_ovf[slot][0] = make_float4(sc * we[4], sc * we[5], sc * we[6], sc * we[7]);
+                    s_ovf[slot][1] = make_float4(0.f, 0.f, __uint_as_float(srcs2), 0.f);
+                }
             } else {
                 rec[0] = make_float4(we[0], we[1], we[2], we[3]);
                 rec[1] = make_float4(he[0], he[1], he[2], he[3]);
                 rec[NREC - 1] = make_float4(rsv, __uint_as_float(srcs), __uint_as_float(cds), __uint_as_float(meta));
+                if (ovf) {
+                    s_ovf[slot][0] = make_float4(we[4], we[5], we[6], we[7]);
+                    s_ovf[slot][1] = make_float4(he[4], he[5], he[6], he[7]);
+                    s_ovf[slot][NREC - 1] = make_float4(0.f, __uint_as_float(srcs2), __uint_as_float(cds2), 0.f);
+                }
             }
         }
         if constexpr (TRANS) __syncthreads();                         // B2b: every thread is done with the lists: the records take their place
@@ -298,94 +358,161 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
             for (int i = 0; i < NREC; ++i) s_rec[tid][i] = rec[i];
         }
-        // transposed: row j's own P row for the edge gradients, requested two rows ahead of its use (a load inside the row's own
-        // iteration is a memory round trip in front of every row; all eight up front cost 32 registers = the third workgroup of the CU)
-        float4 pjn[TRANS ? 2 : 1];
+        // transposed: row j's own P row for the edge gradients: all eight of a group requested HERE, in front of the barrier, and used by
+        // a loop of their own below that issues no store (with loads and stores in one loop the compiler cannot count the memory
+        // operations in flight and waits for ALL of them in every iteration: 3 900 cycles per row, measured with s_memtime stamps)
         auto pj_load = [&](int u) __attribute__((always_inline)) {
             int rc = R0 + min(g + LG_G * u, rows - 1);
             asm volatile("" : "+v"(rc));                              // (else the eight 64-bit row offsets of the staging loads stay live for this)
             return *reinterpret_cast<const float4*>(ed.P + (size_t)rc * ed.ld + c0s);
         };
-        if constexpr (TRANS) { pjn[0] = pj_load(0); pjn[1] = pj_load(1); }
+        float4 pjv[TRANS ? LG_U : 1];
+        if constexpr (TRANS) {                                        // (the first half here, the second at the head of the edge loop:
+#pragma unroll                                                        //  all eight in front of the barrier are five registers too many)
+            for (int u = 0; u < LG_U / 2; ++u) pjv[u] = pj_load(u);
+        }
         __syncthreads();                                              // B3: records and S_b / G_b are complete
+        if constexpr (TRANS) {
+            // ---- edge gradients of the rows with a record (this chunk's columns): d w[code_e] += h_e (<Z[src_e], P_j> - rowdot_src), the
+            //      diagonal into d self_r.  Lane e (< 4) of the row's eight adds bond e's term, lane 4 the diagonal's.
+            const int nu = (rows + LG_G - 1) / LG_G;
+#pragma unroll
+            for (int u = LG_U / 2; u < LG_U; ++u) pjv[u] = pj_load(u);
+#pragma unroll
+            for (int u = 0; u < LG_U; ++u) {
+                if (u >= nu) break;                                   // (uniform; rows beyond the block's / of the second pass: nothing added)
+                const int rr = min(g + LG_G * u, rows - 1);
+                const float4 r1 = s_rec[rr][1], rl = s_rec[rr][2];
+                const uint32_t srcs = __float_as_uint(rl.y), cds = __float_as_uint(rl.z), meta = __float_as_uint(rl.w);
+                const bool fast = g + LG_G * u < rows && !(meta & LG_SLOW);
+                const float4 pj = col_ok ? pjv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 self = buf[rr][l];
+                const float4 v0 = buf[srcs & 255u][l], v1 = buf[(srcs >> 8) & 255u][l], v2 = buf[(srcs >> 16) & 255u][l], v3 = buf[srcs >> 24][l];
+                const float g0 = lg_gsum(lg_dot(v0, pj)), g1 = lg_gsum(lg_dot(v1, pj)), g2 = lg_gsum(lg_dot(v2, pj)), g3 = lg_gsum(lg_dot(v3, pj));
+                const float gs = lg_gsum(lg_dot(self, pj));
+                const int e4 = l & 3;
+                const float hv = e4 == 0 ? r1.x : e4 == 1 ? r1.y : e4 == 2 ? r1.z : r1.w;
+                const float gv = e4 == 0 ? g0 : e4 == 1 ? g1 : e4 == 2 ? g2 : g3;
+                const uint32_t cv = (cds >> (8 * e4)) & 255u, sv = (srcs >> (8 * e4)) & 255u;
+                if (fast && l < 4 && hv != 0.0f && cv) atomicAdd(&h_s[cv], (double)hv * ((double)gv - (double)s_rd[sv]));
+                if (fast && l == 4) dr_acc += (double)rl.x * ((double)gs - (double)s_rd[rr]);
+                if (fast && (meta & LG_OVF)) {                        // (bonds 4..7: same, from the overflow record)
+                    const int slot = (int)(meta & 0xFFFFu);
+                    const float4 q1 = s_ovf[slot][1], ql = s_ovf[slot][2];
+                    const uint32_t sr2 = __float_as_uint(ql.y), cd2 = __float_as_uint(ql.z);
+                    const float4 b0 = buf[sr2 & 255u][l], b1 = buf[(sr2 >> 8) & 255u][l], b2 = buf[(sr2 >> 16) & 255u][l], b3 = buf[sr2 >> 24][l];
+                    const float f0 = lg_gsum(lg_dot(b0, pj)), f1 = lg_gsum(lg_dot(b1, pj)), f2 = lg_gsum(lg_dot(b2, pj)), f3 = lg_gsum(lg_dot(b3, pj));
+                    const float hv2 = e4 == 0 ? q1.x : e4 == 1 ? q1.y : e4 == 2 ? q1.z : q1.w;
+                    const float gv2 = e4 == 0 ? f0 : e4 == 1 ? f1 : e4 == 2 ? f2 : f3;
+                    const uint32_t cv2 = (cd2 >> (8 * e4)) & 255u, sv2 = (sr2 >> (8 * e4)) & 255u;
+                    if (l < 4 && hv2 != 0.0f && cv2) atomicAdd(&h_s[cv2], (double)hv2 * ((double)gv2 - (double)s_rd[sv2]));
+                }
+            }
+        }
         double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
         // ---- the rows: 8 lanes own a row -----------------------------------------------------------------------------------------------
-        // (the NEXT row's record is read while this row's gathers are in flight: a row is a chain record -> gathers -> FMAs -> store, and
-        //  the early exit keeps the compiler from overlapping two rows on its own)
-        //  (forward only: the transposed kernel has no registers to spare at three workgroups per CU)
-        constexpr bool AHEAD = !TRANS;
-        float4 nrec[NREC];
-        if constexpr (AHEAD) {
-#pragma unroll
-            for (int i = 0; i < NREC; ++i) nrec[i] = s_rec[min(g, rows - 1)][i];
-        }
-#pragma unroll
-        for (int u = 0; u < LG_U; ++u) {
-            const int rr = g + LG_G * u;
-            if (rr >= rows) break;
-            if constexpr (!AHEAD) {
-#pragma unroll
-                for (int i = 0; i < NREC; ++i) nrec[i] = s_rec[rr][i];
-            }
-            const float4 r0 = nrec[0], r1 = nrec[1], rl = nrec[NREC - 1];
-            if (AHEAD && u + 1 < LG_U) {
-#pragma unroll
-                for (int i = 0; i < NREC; ++i) nrec[i] = s_rec[min(rr + LG_G, rows - 1)][i];
-            }
-            const uint32_t srcs = __float_as_uint(TRANS ? rl.y : rl.z), meta = __float_as_uint(rl.w);
-            const int cnt_r = (int)((meta >> 16) & 255u), first_r = (int)(meta & 0xFFFFu);
-            const float4 self = buf[rr][l];
-            const float4 S = s_S[(meta >> 24) & 15u][l];
-            const float4 v0 = buf[srcs & 255u][l], v1 = buf[(srcs >> 8) & 255u][l], v2 = buf[(srcs >> 16) & 255u][l], v3 = buf[srcs >> 24][l];
-            float4 y;
+        // Two passes over the group's rows.  The FIRST takes the rows with a complete record and contains no memory load at all: LDS reads,
+        // FMAs, stores.  Rows with more than four bonds (transposed: or a self bond) are left to the SECOND pass, whose general loop
+        // reads list entries (and, transposed, the row's P) from memory.  In ONE loop the compiler cannot count the memory operations
+        // in flight across the rare branch and waits for ALL of them -- the previous row's stores included -- in every iteration:
+        // 1 400 (forward) / 2 800 (transposed) cycles per row, measured with s_memtime stamps.
+        auto finish = [&](int rr, const float4& y) __attribute__((always_inline)) {
             if constexpr (!TRANS) {
-                const float wS = r1.y * TINY;
-                y.x = fmaf(r0.x, v0.x, fmaf(r0.y, v1.x, fmaf(r0.z, v2.x, fmaf(r0.w, v3.x, fmaf(r1.x, self.x, wS * S.x)))));
-                y.y = fmaf(r0.x, v0.y, fmaf(r0.y, v1.y, fmaf(r0.z, v2.y, fmaf(r0.w, v3.y, fmaf(r1.x, self.y, wS * S.y)))));
-                y.z = fmaf(r0.x, v0.z, fmaf(r0.y, v1.z, fmaf(r0.z, v2.z, fmaf(r0.w, v3.z, fmaf(r1.x, self.z, wS * S.z)))));
-                y.w = fmaf(r0.x, v0.w, fmaf(r0.y, v1.w, fmaf(r0.z, v2.w, fmaf(r0.w, v3.w, fmaf(r1.x, self.w, wS * S.w)))));
-                if (meta & LG_SLOW) {                                 // (more than four bonds: the rest from the staged lists)
-                    int jn0; float w0; uint32_t cq;
-                    entry(first_r, true, jn0, w0, cq);
-                    const int moff = (int)(srcs & 255u) - jn0;        // first row of the molecule inside the block
-                    for (int e = 4; e < cnt_r; ++e) {
-                        int jn; float w;
-                        entry(first_r + e, true, jn, w, cq);
-                        lg_fma(y, r1.y * (w - TINY), buf[min(moff + jn, LAGG_RB - 1)][l]);
-                    }
-                }
                 s1[0] += (double)y.x; s2[0] += (double)y.x * (double)y.x;
                 s1[1] += (double)y.y; s2[1] += (double)y.y * (double)y.y;
                 s1[2] += (double)y.z; s2[2] += (double)y.z * (double)y.z;
                 s1[3] += (double)y.w; s2[3] += (double)y.w * (double)y.w;
                 if (col_ok && !(dbg & 4)) *reinterpret_cast<float4*>(a.dst + (size_t)(R0 + rr) * a.ldd + c0) = y;
             } else {
-                const float sj = rl.x, rs = r * sj;
-                const float4 pj = col_ok ? pjn[u & 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (u + 2 < LG_U) pjn[u & 1] = pj_load(u + 2);
-                if (!(meta & LG_SLOW)) {
-                    y.x = fmaf(r0.x, v0.x, fmaf(r0.y, v1.x, fmaf(r0.z, v2.x, fmaf(r0.w, v3.x, fmaf(rs, self.x, TINY * S.x)))));
-                    y.y = fmaf(r0.x, v0.y, fmaf(r0.y, v1.y, fmaf(r0.z, v2.y, fmaf(r0.w, v3.y, fmaf(rs, self.y, TINY * S.y)))));
-                    y.z = fmaf(r0.x, v0.z, fmaf(r0.y, v1.z, fmaf(r0.z, v2.z, fmaf(r0.w, v3.z, fmaf(rs, self.z, TINY * S.z)))));
-                    y.w = fmaf(r0.x, v0.w, fmaf(r0.y, v1.w, fmaf(r0.z, v2.w, fmaf(r0.w, v3.w, fmaf(rs, self.w, TINY * S.w)))));
-                    // edge gradients of the bonds into j (this chunk's columns), and the diagonal
-                    const float g0 = lg_gsum(lg_dot(v0, pj)), g1 = lg_gsum(lg_dot(v1, pj)), g2 = lg_gsum(lg_dot(v2, pj)), g3 = lg_gsum(lg_dot(v3, pj));
-                    const float gs = lg_gsum(lg_dot(self, pj));
-                    // d w[code_e] += h_e (g_e - rowdot_src): lane e (< 4) of the row's eight adds bond e's term, lane 4 the diagonal's
-                    {
-                        const uint32_t cds = __float_as_uint(rl.z);
-                        const int e4 = l & 3;
-                        const float hv = e4 == 0 ? r1.x : e4 == 1 ? r1.y : e4 == 2 ? r1.z : r1.w;
-                        const float gv = e4 == 0 ? g0 : e4 == 1 ? g1 : e4 == 2 ? g2 : g3;
-                        const uint32_t cv = (cds >> (8 * e4)) & 255u, sv = (srcs >> (8 * e4)) & 255u;
-                        if (l < 4 && hv != 0.0f && cv) atomicAdd(&h_s[cv], (double)hv * ((double)gv - (double)s_rd[sv]));
-                        if (l == 4) dr_acc += (double)sj * ((double)gs - (double)s_rd[rr]);
+                if (col_ok && !(dbg & 4)) {
+                    int cs = c0;
+                    asm volatile("" : "+v"(cs));                      // (no per-lane 64-bit store bases held across the block loop)
+                    if (a.planes.p) bx_store4(a.planes, R0 + rr, cs, y);
+                    else *reinterpret_cast<float4*>(a.dst + (size_t)(R0 + rr) * a.ldd + cs) = y;
+                }
+            }
+        };
+        bool any_slow = false;
+        {
+            // (forward: the NEXT row's record is read while this row's gathers are in flight; the transposed kernel has no registers to
+            //  spare for that at three workgroups per CU)
+            constexpr bool AHEAD = !TRANS;
+            float4 nrec[NREC];
+            if constexpr (AHEAD) {
+#pragma unroll
+                for (int i = 0; i < NREC; ++i) nrec[i] = s_rec[min(g, rows - 1)][i];
+            }
+            // (no divergent branch in this loop but the one around a row's store: the trip count is uniform, rows beyond the block's
+            //  and rows of the second pass are computed on clamped indices and not stored)
+            const int nu = (rows + LG_G - 1) / LG_G;
+#pragma unroll
+            for (int u = 0; u < LG_U; ++u) {
+                if (u >= nu) break;                                   // (uniform)
+                const int rr = min(g + LG_G * u, rows - 1);
+                const bool valid = g + LG_G * u < rows;
+                if constexpr (!AHEAD) {
+#pragma unroll
+                    for (int i = 0; i < NREC; ++i) nrec[i] = s_rec[rr][i];
+                }
+                const float4 r0 = nrec[0], r1 = nrec[1], rl = nrec[NREC - 1];
+                if (AHEAD && u + 1 < LG_U) {
+#pragma unroll
+                    for (int i = 0; i < NREC; ++i) nrec[i] = s_rec[min(rr + LG_G, rows - 1)][i];
+                }
+                const uint32_t srcs = __float_as_uint(TRANS ? rl.y : rl.z), meta = __float_as_uint(rl.w);
+                const bool fast = valid && !(meta & LG_SLOW);
+                any_slow = any_slow || (valid && (meta & LG_SLOW));
+                const float4 self = buf[rr][l];
+                const float4 S = s_S[(meta >> 24) & 15u][l];
+                const float4 v0 = buf[srcs & 255u][l], v1 = buf[(srcs >> 8) & 255u][l], v2 = buf[(srcs >> 16) & 255u][l], v3 = buf[srcs >> 24][l];
+                const float ws = TRANS ? r * rl.x : r1.x;                      // weight of the row's own operand row
+                const float wS = TRANS ? TINY : r1.y * TINY;                   // ... and of the molecule's column sum
+                float4 y;
+                y.x = fmaf(r0.x, v0.x, fmaf(r0.y, v1.x, fmaf(r0.z, v2.x, fmaf(r0.w, v3.x, fmaf(ws, self.x, wS * S.x)))));
+                y.y = fmaf(r0.x, v0.y, fmaf(r0.y, v1.y, fmaf(r0.z, v2.y, fmaf(r0.w, v3.y, fmaf(ws, self.y, wS * S.y)))));
+                y.z = fmaf(r0.x, v0.z, fmaf(r0.y, v1.z, fmaf(r0.z, v2.z, fmaf(r0.w, v3.z, fmaf(ws, self.z, wS * S.z)))));
+                y.w = fmaf(r0.x, v0.w, fmaf(r0.y, v1.w, fmaf(r0.z, v2.w, fmaf(r0.w, v3.w, fmaf(ws, self.w, wS * S.w)))));
+                if (fast && (meta & LG_OVF)) {                        // (bonds 4..7)
+                    const int slot = (int)(meta & 0xFFFFu);
+                    const float4 q0 = s_ovf[slot][0];
+                    const uint32_t sr2 = __float_as_uint(TRANS ? s_ovf[slot][NREC - 1].y : s_ovf[slot][NREC - 1].z);
+                    lg_fma(y, q0.x, buf[sr2 & 255u][l]); lg_fma(y, q0.y, buf[(sr2 >> 8) & 255u][l]);
+                    lg_fma(y, q0.z, buf[(sr2 >> 16) & 255u][l]); lg_fma(y, q0.w, buf[sr2 >> 24][l]);
+                }
+                if (fast) finish(rr, y);
+            }
+        }
+        if (any_slow) {
+#pragma unroll 1
+            for (int u = 0; u < LG_U; ++u) {
+                const int rr = g + LG_G * u;
+                if (rr >= rows) break;
+                const float4 r1 = s_rec[rr][1], rl = s_rec[rr][NREC - 1];
+                const uint32_t srcs = __float_as_uint(TRANS ? rl.y : rl.z), meta = __float_as_uint(rl.w);
+                if (!(meta & LG_SLOW)) continue;
+                const int cnt_r = (int)((meta >> 16) & 255u), first_r = (int)(meta & 0xFFFFu);
+                const float4 self = buf[rr][l];
+                const float4 S = s_S[(meta >> 24) & 15u][l];
+                int jn0; float w0; uint32_t cq;
+                entry(first_r, !TRANS, jn0, w0, cq);                  // (transposed: the lists' LDS copy is gone)
+                const int moff = cnt_r > 0 ? (int)(srcs & 255u) - jn0 : 0;        // first row of the molecule inside the block
+                float4 y;
+                if constexpr (!TRANS) {
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int e = 0; e < cnt_r; ++e) {
+                        int jn; float w;
+                        entry(first_r + e, true, jn, w, cq);
+                        lg_fma(acc, r1.y * (w - TINY), buf[min(moff + jn, LAGG_RB - 1)][l]);
                     }
+                    const float wS = r1.y * TINY;
+                    y.x = acc.x + fmaf(r1.x, self.x, wS * S.x);
+                    y.y = acc.y + fmaf(r1.x, self.y, wS * S.y);
+                    y.z = acc.z + fmaf(r1.x, self.z, wS * S.z);
+                    y.w = acc.w + fmaf(r1.x, self.w, wS * S.w);
                 } else {
-                    // the general loop (more than four bonds / a self bond): lists from memory (their LDS copy is gone)
-                    int jn0; float w0; uint32_t cq;
-                    entry(first_r, false, jn0, w0, cq);
-                    const int moff = cnt_r > 0 ? (int)(srcs & 255u) - jn0 : 0;
+                    // aggregation and edge gradients together
+                    const float sj = rl.x, rs = r * sj;
+                    const float4 pj = col_ok ? pj_load(u) : make_float4(0.f, 0.f, 0.f, 0.f);
                     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), bs = acc;
                     bool self_bond = false;
                     for (int e = 0; e < cnt_r; ++e) {
@@ -411,12 +538,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     const float gs = lg_gsum(lg_dot(self, pj));
                     if (l == 0 && sj != 0.0f && !self_bond) dr_acc += (double)(sj * (gs - s_rd[rr]));
                 }
-                if (col_ok && !(dbg & 4)) {
-                    int cs = c0;
-                    asm volatile("" : "+v"(cs));                      // (no per-lane 64-bit store bases held across the block loop)
-                    if (a.planes.p) bx_store4(a.planes, R0 + rr, cs, y);
-                    else *reinterpret_cast<float4*>(a.dst + (size_t)(R0 + rr) * a.ldd + cs) = y;
-                }
+                finish(rr, y);
             }
         }
         if constexpr (!TRANS) {
