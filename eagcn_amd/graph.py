@@ -633,6 +633,8 @@ class GraphRunner:
                 if not in_graph:
                     raise
                 captured, failure = False, e
+                if optimizer is not None:
+                    optimizer.reset_ticket()                  # (an aborted capture must not leave the update's last-workgroup ticket half counted)
             if in_graph:
                 # every rank must replay the SAME collective sequence: a rank whose capture failed while the others replay
                 # in-graph all-reduces would hang them.  One MIN-reduction of the success flag decides for all ranks.

@@ -60,6 +60,11 @@ class FlatAdam:
         self.hyper[0] = float(lr)                  # (a device write: a captured step graph picks it up at its next replay)
         self.param_groups[0]['lr'] = float(lr)
 
+    def reset_ticket(self):
+        """After an aborted launch / failed capture: the kernel's last-workgroup ticket starts from zero again (it resets itself at the end
+        of every COMPLETED launch; left half counted, later launches would never advance the step count)."""
+        self.ticket.zero_()
+
     def _check_homes(self):
         """The module's parameters must still BE slices of the flat buffer (a later ``model.to()`` / ``.float()`` / assignment to
         ``p.data`` re-homes them and would leave this optimizer updating memory nobody reads)."""
