@@ -490,8 +490,9 @@ __global__ __launch_bounds__(256) void index_rows_kernel(eagcn_batch bt) {
 // batch).  Block q is described by two int4 records, blk[2q] = {first molecule, molecules, first packed row, rows} and blk[2q+1] =
 // {first list entry, list entries, 0, 0} -- everything a workgroup needs to request its data with ONE dependent load.  The packing is
 // sequential by nature; ONE wavefront does it 64 molecules at a time (prefix sum of the row counts, then one ballot per closed block).
-__global__ __launch_bounds__(64) void index_blocks_kernel(eagcn_batch bt, const int rb) {     // rb: rows a block may hold (<= LAGG_RB)
-    const int lane = threadIdx.x;
+// (runs as ONE extra workgroup of index_csr_kernel's grid -- its first wavefront: the two are independent, and a launch of its own was
+//  10 us + a launch gap on the side stream's chain, which a step waits for when the host does not run far enough ahead)
+__device__ __forceinline__ void index_blocks_body(const eagcn_batch& bt, const int rb, const int lane) {     // rb: rows a block may hold (<= LAGG_RB)
     const int T = bt.meta[EAGCN_META_T];
     int4* out = reinterpret_cast<int4*>(bt.blk);
     int nb = 0, start = 0, rows = 0, cnt = 0;                        // the open block: first molecule, rows and molecules so far
@@ -561,10 +562,14 @@ __global__ __launch_bounds__(64) void index_blocks_kernel(eagcn_batch bt, const 
 // global memory is one dependent single-byte load per row (measured 256 us at the Tox21 shape).  Molecules beyond 512
 // atom slots (bitmap > 32 KB) read the byte map directly.
 template <bool BITMAP>
-__global__ __launch_bounds__(256) void index_csr_kernel(eagcn_batch bt, int W) {
+__global__ __launch_bounds__(256) void index_csr_kernel(eagcn_batch bt, int W, const int rb) {
     extern __shared__ uint32_t bits[];
     __shared__ int s_cnt[1024], s_ccnt[1024], s_scan[256];
     __shared__ unsigned char s_live[1024];
+    if (rb > 0 && blockIdx.x == gridDim.x - 1) {                      // the extra workgroup: the row blocks of lagg.hip (index_blocks_body)
+        if (threadIdx.x < 64) index_blocks_body(bt, rb, (int)threadIdx.x);
+        return;
+    }
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = bt.nat[b], r0 = bt.row0[b], e0 = bt.edge0[b];
     if (bt.meta[EAGCN_META_T] == 0 || n == 0 || r0 + n > bt.T) return;    // empty / overflowing batch: nothing is read
@@ -873,13 +878,10 @@ extern "C" int eagcn_index_rows(const eagcn_batch* b, void* stream) {
     index_rows_kernel<<<b->B, 256, 0, s>>>(*b);
     EAGCN_LAUNCH_CHECK();
     if (!b->build_lists) return EAGCN_OK;   // bond lists: GAT layers (gat.hip), bond-list aggregation (lagg.hip)
-    if (b->blk) {
-        index_blocks_kernel<<<1, 64, 0, s>>>(*b, lagg_block_rows(b));
-        EAGCN_LAUNCH_CHECK();
-    }
+    const int rb = b->blk ? lagg_block_rows(b) : 0;                  // > 0: one more workgroup builds the row blocks
     const int W = (b->N + 31) / 32;
-    if (b->N <= 512) index_csr_kernel<true><<<b->B, 256, (size_t)2 * b->N * W * sizeof(uint32_t), s>>>(*b, W);
-    else index_csr_kernel<false><<<b->B, 256, 0, s>>>(*b, W);
+    if (b->N <= 512) index_csr_kernel<true><<<b->B + (rb > 0 ? 1 : 0), 256, (size_t)2 * b->N * W * sizeof(uint32_t), s>>>(*b, W, rb);
+    else index_csr_kernel<false><<<b->B + (rb > 0 ? 1 : 0), 256, 0, s>>>(*b, W, rb);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
