@@ -347,3 +347,24 @@ assert got == [1, 1, 0, 1, 1, 0, 1, 1, 0], got
                              .replace("assert got == [1, 1, 0, 1, 1, 0, 1, 1, 0], got", "assert got == [0] * 9, got")],
                             capture_output=True, text=True, cwd=str(ROOT))
     assert forced.returncode == 0, forced.stdout + forced.stderr
+
+
+def test_bond_list_buffers_are_laid_out_without_overlap():
+    """_lib.set_bond_lists: row / column list headers, per-molecule records and the row-block records (two int4 per block, at most one
+    block per molecule, 16-byte aligned) inside ONE int32 buffer of bond_ptrs_len(T, B) words; list entries with their 64-bit codes
+    8-byte aligned inside the edge buffer."""
+    from eagcn_amd import _lib as L
+    for T, B, E in ((4809, 256, 10331), (7, 3, 5), (262144, 1024, 1100000), (1, 1, 1)):
+        ptrs = torch.zeros(L.bond_ptrs_len(T, B) + 3, dtype=torch.int32)[3:]          # (a deliberately 4-byte aligned start)
+        edges = torch.zeros(6 * E + 2, dtype=torch.int32)
+        c = L.Batch()
+        c.T, c.B = T, B
+        L.set_bond_lists(c, 4096, ptrs, edges, E)
+        lo, hi = ptrs.data_ptr(), ptrs.data_ptr() + 4 * ptrs.numel()
+        assert c.row_ptr == lo and c.col_ptr == lo + 8 * T and c.mol_info == lo + 16 * T
+        assert c.blk % 16 == 0 and c.blk >= c.mol_info + 16 * B
+        assert c.blk + 32 * B <= hi                        # B blocks of two int4 records
+        elo, ehi = edges.data_ptr(), edges.data_ptr() + 4 * edges.numel()
+        assert c.nbr == elo and c.tnbr == elo + 4 * E
+        assert c.ecode % 8 == 0 and c.ecode >= c.tnbr + 4 * E and c.tcode == c.ecode + 8 * E and c.tcode + 8 * E <= ehi
+        assert c.ecnt == 4096 and c.edge0 == 4096 + 4 * B
