@@ -117,6 +117,10 @@ class Model(C.Structure):
                 ('stats_world', C.c_int32), ('fuse_readout', C.c_int32), ('fwd_signal', _fp)]
 
 
+class StepLoss(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('labels', _fp), ('class_weight', _fp), ('loss', _fp), ('scale', _fp), ('dout', _fp)]
+
+
 # int hook(double* buf, int n, void* stream, void* user): cross-rank sum in place (sync-BatchNorm, eagcn_hip.h)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
 
@@ -204,6 +208,8 @@ SIGNATURES = {
                                        _fp, _fp, C.POINTER(LayerGrads), C.POINTER(HeadGrads), _fp]),
     'eagcn_model_backward_range': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, C.c_size_t, _fp, C.c_size_t,
                                              _fp, _fp, C.POINTER(LayerGrads), C.POINTER(HeadGrads), C.c_int, C.c_int, C.c_int, _fp]),
+    'eagcn_model_forward_step': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, _fp, C.c_size_t, _fp, C.c_size_t, _fp, _fp,
+                                           C.POINTER(StepLoss), _fp, C.POINTER(HeadGrads), _fp]),
     'eagcn_bce_loss': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     'eagcn_mse_loss': (C.c_int, [_fp, _fp, C.c_int, _fp, _fp, _fp]),
     'eagcn_eval_append': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int64, _fp]),
@@ -221,7 +227,7 @@ class EagcnHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5    # include/eagcn_hip.h eagcn_abi_version(): struct layouts + signatures this binding was written against
+ABI_VERSION = 6    # include/eagcn_hip.h eagcn_abi_version(): struct layouts + signatures this binding was written against
 
 
 def load():
@@ -242,7 +248,8 @@ def load():
         fn = getattr(lib, name)        # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    for which, cls in enumerate((Batch, Layout, LayerParams, LayerBufs, LayerGrads, HeadParams, HeadGrads, Model)):
+    for which, cls in ((0, Batch), (1, Layout), (2, LayerParams), (3, LayerBufs), (4, LayerGrads), (5, HeadParams), (6, HeadGrads),
+                       (7, Model), (10, StepLoss)):
         if lib.eagcn_struct_size(which) != C.sizeof(cls):
             raise EagcnHipError('ABI mismatch: %s is %d bytes here, %d in libeagcn_hip.so'
                                 % (cls.__name__, C.sizeof(cls), lib.eagcn_struct_size(which)))

@@ -41,8 +41,13 @@ def build_library(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     flags = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-munsafe-fp-atomics']
 
+    hdr_time = _newest([os.path.join(CSRC, h) for h in HEADERS if os.path.exists(os.path.join(CSRC, h))])
+
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
+        # an object newer than its source and every header is kept (the library is relinked from all objects)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_time, os.path.getmtime(os.path.join(CSRC, src))):
+            return obj
         cmd = [hipcc] + flags + ['-c', os.path.join(CSRC, src), '-o', obj]
         if src.endswith('.cpp'):
             cmd = [hipcc, '-O2', '-std=c++17', '-fPIC', '-c', os.path.join(CSRC, src), '-o', obj]

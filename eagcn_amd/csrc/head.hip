@@ -112,6 +112,7 @@ struct ModelScratch {
     float *da2, *da1, *dgn, *dg, *dxa, *dxb, *dpad;
     float* hdw; int hdw_ks;      // row-chunk partials of the head's weight gradients (HeadBwd.ks): [ks][F n1 + n1 n2 + n2 nclass]
     double* hst; int n_hst;      // BatchNorm sums of the head: [f_in + n_den1 + n_den2][2], forward ...
+    double* hws;                 // HEAD_WS doubles behind them (same cleared block): barrier words / label count / loss sum of head_all
     double* hsb;                 // ... and backward.  Both are cleared by the forward's parameter-packing launch; the backward clears
                                  // its own again on the way out (bn_bwd_reduce of the top layer), for a second backward call
     void* layer; size_t layer_bytes;
@@ -124,8 +125,9 @@ static size_t carve_scratch(void* base, const eagcn_batch* b, const eagcn_model*
     // three segments [2 w sums | row count | pad], one per BatchNorm of the head (the count rides with the sums through the
     // sync-BatchNorm hook)
     s.n_hst = 2 * (h->f_in + h->n_den1 + h->n_den2) + 6;
-    s.hst = c.take<double>((size_t)(HEAD_COPIES + 1) * s.n_hst);     // HEAD_COPIES replicas of the forward sums (kernels.h)
+    s.hst = c.take<double>((size_t)(HEAD_COPIES + 1) * s.n_hst + HEAD_WS);     // HEAD_COPIES replicas of the forward sums (kernels.h)
     s.hsb = s.hst + (size_t)HEAD_COPIES * s.n_hst;
+    s.hws = s.hsb + s.n_hst;
     s.da2 = c.take<float>(B * h->n_den2);
     s.da1 = c.take<float>(B * h->n_den1);
     s.dgn = c.take<float>(B * h->f_in);
@@ -237,21 +239,92 @@ extern "C" int eagcn_model_pack_input(const eagcn_batch* b, const eagcn_model* m
     return eagcn_pack_rows(b, afm, layout_width(&m->layer[0].in), &m->layer[0].in, sv.x0, stream);
 }
 
-extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, const float* afm,
-                                   const int64_t* size, void* saved, size_t saved_bytes, void* scratch,
-                                   size_t scratch_bytes, float* out, float* graph_rep, void* stream) {
+// descriptors of the head's stages (head2.hip), shared by the separate launches and by the one-launch training head
+struct HeadPlan {
+    HeadFwd f1, f2, f3;
+    HeadBwd b3, b2, b1;
+    HeadGbn bg;
+    double *st_g, *st_1, *st_2, *sb_g, *sb_1, *sb_2;
+    bool sync;
+};
+static HeadPlan head_plan(const eagcn_batch* b, const eagcn_model* m, const ModelSaved& sv, const ModelScratch& sc, float* out,
+                          float* graph_rep, const float* dout, const float* dgraph_rep, const eagcn_head_grads* hg) {
+    HeadPlan P;
+    const eagcn_head_params* h = &m->head;
+    const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
+    P.st_g = sc.hst; P.st_1 = sc.hst + 2 * F + 2; P.st_2 = sc.hst + 2 * (F + n1) + 4;
+    P.sb_g = sc.hsb; P.sb_1 = sc.hsb + 2 * F + 2; P.sb_2 = sc.hsb + 2 * (F + n1) + 4;
+    P.sync = m->stats_hook && m->training;
+    // replicas of the forward sums (one with sync-BatchNorm: the hook all-reduces the first block in place)
+    const int copies = P.sync ? 1 : HEAD_COPIES;
+    HeadDrop nodrop{0, 0u, 1.0f, 0, nullptr}, drop1 = nodrop;
+    {
+        int on; uint32_t thr; float inv_keep;
+        fill_drop(h->dropout, m->training, &on, &thr, &inv_keep);
+        drop1 = HeadDrop{on, thr, inv_keep, m->head_seed, m->head_seed_dev};
+    }
+    P.f1 = HeadFwd{B, F, n1, sv.g, P.st_g, h->gbn_w, h->gbn_b, h->gbn_rm, h->gbn_rv, sv.bn_g, h->den1_w, sv.h1, nullptr, P.st_1,
+                   m->training, 0, h->bn_eps, h->bn_momentum, nodrop};
+    P.f2 = HeadFwd{B, n1, n2, sv.h1, P.st_1, h->bn1_w, h->bn1_b, h->bn1_rm, h->bn1_rv, sv.bn_1, h->den2_w, sv.h2, graph_rep, P.st_2,
+                   m->training, 1, h->bn_eps, h->bn_momentum, drop1};
+    P.f3 = HeadFwd{B, n2, nc, sv.h2, P.st_2, h->bn2_w, h->bn2_b, h->bn2_rm, h->bn2_rv, sv.bn_2, h->den3_w, out, nullptr, nullptr,
+                   m->training, 1, h->bn_eps, h->bn_momentum, nodrop};
+    if (P.sync) { P.f1.cnt_in = P.st_g + 2 * F; P.f2.cnt_in = P.st_1 + 2 * n1; P.f3.cnt_in = P.st_2 + 2 * n2; }
+    P.f1.st_copies = P.f2.st_copies = P.f3.st_copies = copies;
+    P.f1.st_stride = P.f2.st_stride = P.f3.st_stride = sc.n_hst;
+    if (!hg) return P;
+    // backward: den3 -> bn_den2 -> den2 -> bn_den1 -> den1 -> Graph_BN, one stage per dense layer (d input + d weight), each
+    // BatchNorm's backward sums taken by the stage in front of it.  sync-BatchNorm: the global row counts are the ones the forward
+    // left behind its statistics (same scratch block)
+    const double *cn_g = sc.hst + 2 * F, *cn_1 = sc.hst + 2 * F + 2 + 2 * n1, *cn_2 = sc.hst + 2 * (F + n1) + 4 + 2 * n2;
+    const float gscale = P.sync && m->stats_world > 1 ? 1.0f / (float)m->stats_world : 1.0f;
+    // dense 3: y = out (no BatchNorm behind it), input a2 = relu(bn_den2(h2))
+    P.b3 = HeadBwd{B, n2, nc, sv.h2, sv.bn_2, 1, nodrop, h->den3_w, dout, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                   sc.da2, P.sb_2, hg->d_den3_w, m->training};
+    // dense 2: y = h2 followed by bn_den2 (+ the gradient that reaches graph_representation directly), input a1
+    P.b2 = HeadBwd{B, n1, n2, sv.h1, sv.bn_1, 1, drop1, h->den2_w, sc.da2, sv.h2, sv.bn_2, P.sb_2, dgraph_rep, hg->d_bn2_w, hg->d_bn2_b,
+                   sc.da1, P.sb_1, hg->d_den2_w, m->training};
+    // dense 1: y = h1 followed by bn_den1, input gn = Graph_BN(g)
+    P.b1 = HeadBwd{B, F, n1, sv.g, sv.bn_g, 0, nodrop, h->den1_w, sc.da1, sv.h1, sv.bn_1, P.sb_1, nullptr, hg->d_bn1_w, hg->d_bn1_b,
+                   sc.dgn, P.sb_g, hg->d_den1_w, m->training};
+    if (P.sync) { P.b2.cnt_y = cn_2; P.b2.gscale = gscale; P.b1.cnt_y = cn_1; P.b1.gscale = gscale; }
+    // large batches: the weight gradients leave as row-chunk partials, summed with the Graph_BN backward
+    const int ks = sc.hdw_ks;
+    float* part3 = sc.hdw;
+    float* part2 = part3 + (size_t)ks * n2 * nc;
+    float* part1 = part2 + (size_t)ks * n1 * n2;
+    if (ks > 1) {
+        P.b3.ks = ks; P.b3.dW_part = part3;
+        P.b2.ks = ks; P.b2.dW_part = part2;
+        P.b1.ks = ks; P.b1.dW_part = part1;
+    }
+    // (folding Graph_BN's backward into the top layer's first backward kernel was measured: a wash at B = 256, +11 us at
+    //  B = 1024 -- every packed row then gathers two molecule rows instead of one)
+    P.bg = HeadGbn{B, F, sc.dgn, sv.g, sv.bn_g, P.sb_g, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training};
+    if (P.sync) { P.bg.cnt = cn_g; P.bg.gscale = gscale; }
+    if (ks > 1) {
+        P.bg.sum[0] = HeadDwSum{hg->d_den3_w, part3, n2 * nc, ks};
+        P.bg.sum[1] = HeadDwSum{hg->d_den2_w, part2, n1 * n2, ks};
+        P.bg.sum[2] = HeadDwSum{hg->d_den1_w, part1, F * n1, ks};
+        P.bg.nsum = 3;
+    }
+    return P;
+}
+
+// pack -> layers -> read-out (everything in front of the head): fills sv / sc
+static int model_forward_trunk(const eagcn_batch* b, const eagcn_model* m, const float* afm, const int64_t* size, void* saved,
+                               size_t saved_bytes, void* scratch, size_t scratch_bytes, ModelSaved& sv, ModelScratch& sc,
+                               void* stream, const char* who) {
     hipStream_t s = (hipStream_t)stream;
-    RC(check_model(b, m, "eagcn_model_forward"));
-    EAGCN_CHECK_GEMM3("eagcn_model_forward");
-    EAGCN_CHECK_ARG((afm || m->input_packed) && saved && scratch && out && graph_rep, "eagcn_model_forward: null buffer");
-    EAGCN_CHECK_ARG(m->molfp_mode == 0 || size, "eagcn_model_forward: 'ave' read-out needs size");
-    ModelSaved sv;
-    ModelScratch sc;
-    EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "eagcn_model_forward: saved block too small");
-    EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_forward: scratch too small");
+    RC(check_model(b, m, who));
+    EAGCN_CHECK_GEMM3(who);
+    EAGCN_CHECK_ARG((afm || m->input_packed) && saved && scratch, "%s: null buffer", who);
+    EAGCN_CHECK_ARG(m->molfp_mode == 0 || size, "%s: 'ave' read-out needs size", who);
+    EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "%s: saved block too small", who);
+    EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "%s: scratch too small", who);
     const eagcn_head_params* h = &m->head;
     ZeroJob zj;                                   // hand-off flags + the head's sums: cleared by the packing launch below
-    RC(gemm3_zero_job(sc.layer, sc.layer_bytes, sc.hst, (HEAD_COPIES + 1) * sc.n_hst, &zj));
+    RC(gemm3_zero_job(sc.layer, sc.layer_bytes, sc.hst, (HEAD_COPIES + 1) * sc.n_hst + HEAD_WS, &zj));
     if (!m->input_packed)
         RC(eagcn_pack_rows(b, afm, layout_width(&m->layer[0].in), &m->layer[0].in, sv.x0, stream));
     const float* x = sv.x0;
@@ -276,9 +349,8 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
     const LayerSaved& LL = sv.L[m->n_layers - 1];
     const eagcn_layout lay = out_layout(last);
-    const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
+    const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2;
     double *st_g = sc.hst, *st_1 = sc.hst + 2 * F + 2, *st_2 = sc.hst + 2 * (F + n1) + 4;
-    // replicas of the forward sums (one with sync-BatchNorm: the hook all-reduces the first block in place)
     const int copies = (m->stats_hook && m->training) ? 1 : HEAD_COPIES;
     if (fused_readout(m)) {
         // relu / dropout / mask of the top layer applied while the atoms are summed; Graph_BN's column sums in the same launch
@@ -300,43 +372,125 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
         fwd_signal_kernel<<<1, 64, 0, s>>>(m->fwd_signal);
         EAGCN_LAUNCH_CHECK();
     }
-    // head (head2.hip): every BatchNorm's sums come from the kernel that produces its input, its normalisation is
-    // applied by the product that consumes it
-    const bool sync = m->stats_hook && m->training;
-    auto hook = [&](double* buf, int n) -> int {
-        if (!sync) return EAGCN_OK;
-        if (m->stats_hook(buf, n, stream, m->stats_user)) {
-            set_error("eagcn_model: the sync-BatchNorm all-reduce hook failed");
-            return EAGCN_ERR_HIP;
-        }
-        return EAGCN_OK;
-    };
     if (!fused_readout(m)) RC(head_colstats(sv.g, B, F, st_g, s, st_g + 2 * F, st_1 + 2 * n1, st_2 + 2 * n2));
-    RC(hook(st_g, 2 * F + 1));
-    HeadDrop nodrop{0, 0u, 1.0f, 0, nullptr}, drop1 = nodrop;
-    {
-        int on; uint32_t thr; float inv_keep;
-        fill_drop(h->dropout, m->training, &on, &thr, &inv_keep);
-        drop1 = HeadDrop{on, thr, inv_keep, m->head_seed, m->head_seed_dev};
-    }
-    HeadFwd f1{B, F, n1, sv.g, st_g, h->gbn_w, h->gbn_b, h->gbn_rm, h->gbn_rv, sv.bn_g, h->den1_w, sv.h1, nullptr, st_1,
-               m->training, 0, h->bn_eps, h->bn_momentum, nodrop};
-    if (sync) f1.cnt_in = st_g + 2 * F;
-    f1.st_copies = copies; f1.st_stride = sc.n_hst;
-    RC(head_fwd(f1, s));
-    RC(hook(st_1, 2 * n1 + 1));
-    HeadFwd f2{B, n1, n2, sv.h1, st_1, h->bn1_w, h->bn1_b, h->bn1_rm, h->bn1_rv, sv.bn_1, h->den2_w, sv.h2, graph_rep, st_2,
-               m->training, 1, h->bn_eps, h->bn_momentum, drop1};
-    if (sync) f2.cnt_in = st_1 + 2 * n1;
-    f2.st_copies = copies; f2.st_stride = sc.n_hst;
-    RC(head_fwd(f2, s));
-    RC(hook(st_2, 2 * n2 + 1));
-    HeadFwd f3{B, n2, nc, sv.h2, st_2, h->bn2_w, h->bn2_b, h->bn2_rm, h->bn2_rv, sv.bn_2, h->den3_w, out, nullptr, nullptr,
-               m->training, 1, h->bn_eps, h->bn_momentum, nodrop};
-    if (sync) f3.cnt_in = st_2 + 2 * n2;
-    f3.st_copies = copies; f3.st_stride = sc.n_hst;
-    RC(head_fwd(f3, s));
     return EAGCN_OK;
+}
+
+static int stats_hook_call(const eagcn_model* m, bool sync, double* buf, int n, void* stream) {
+    if (!sync) return EAGCN_OK;
+    if (m->stats_hook(buf, n, stream, m->stats_user)) {
+        set_error("eagcn_model: the sync-BatchNorm all-reduce hook failed");
+        return EAGCN_ERR_HIP;
+    }
+    return EAGCN_OK;
+}
+
+// head forward as separate launches (head2.hip): every BatchNorm's sums come from the kernel that produces its input, its
+// normalisation is applied by the product that consumes it
+static int head_forward_launches(const eagcn_model* m, const HeadPlan& P, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const eagcn_head_params* h = &m->head;
+    RC(stats_hook_call(m, P.sync, P.st_g, 2 * h->f_in + 1, stream));
+    RC(head_fwd(P.f1, s));
+    RC(stats_hook_call(m, P.sync, P.st_1, 2 * h->n_den1 + 1, stream));
+    RC(head_fwd(P.f2, s));
+    RC(stats_hook_call(m, P.sync, P.st_2, 2 * h->n_den2 + 1, stream));
+    RC(head_fwd(P.f3, s));
+    return EAGCN_OK;
+}
+// ... and the head backward (sync-BatchNorm: the backward sums of every head BatchNorm are summed across the ranks before the
+// launch that consumes them)
+static int head_backward_launches(const eagcn_model* m, const HeadPlan& P, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const eagcn_head_params* h = &m->head;
+    RC(head_bwd(P.b3, s));
+    RC(stats_hook_call(m, P.sync, P.sb_2, 2 * h->n_den2, stream));
+    RC(head_bwd(P.b2, s));
+    RC(stats_hook_call(m, P.sync, P.sb_1, 2 * h->n_den1, stream));
+    RC(head_bwd(P.b1, s));
+    RC(stats_hook_call(m, P.sync, P.sb_g, 2 * h->f_in, stream));
+    RC(head_gbn_bwd(P.bg, s));
+    return EAGCN_OK;
+}
+// read-out backward: evaluated inside the last layer's first backward kernel (ReadoutGrad); only the gradient of the common
+// non-stored row of Weighted_sum needs a (tiny) launch of its own
+static int readout_pad_backward(const eagcn_batch* b, const eagcn_model* m, const int64_t* size, const ModelSaved& sv,
+                                const ModelScratch& sc, void* stream) {
+    const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
+    const eagcn_layout lay = out_layout(last);
+    const int F = m->head.f_in;
+    if (pad_sampled(m)) return readout_backward_pad_views(b, sc.dg, &lay, size, m->molfp_mode, F, last->K, sv.pad_cnt, last->dropout, sc.dpad, stream);
+    if (last->structure == EAGCN_STRUCT_WEIGHTED) return readout_backward_pad(b, sc.dg, &lay, size, m->molfp_mode, F, sc.dpad, stream);
+    return EAGCN_OK;
+}
+
+extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, const float* afm,
+                                   const int64_t* size, void* saved, size_t saved_bytes, void* scratch,
+                                   size_t scratch_bytes, float* out, float* graph_rep, void* stream) {
+    EAGCN_CHECK_ARG(out && graph_rep, "eagcn_model_forward: null buffer");
+    ModelSaved sv;
+    ModelScratch sc;
+    RC(model_forward_trunk(b, m, afm, size, saved, saved_bytes, scratch, scratch_bytes, sv, sc, stream, "eagcn_model_forward"));
+    const HeadPlan P = head_plan(b, m, sv, sc, out, graph_rep, nullptr, nullptr, nullptr);
+    return head_forward_launches(m, P, stream);
+}
+
+namespace eagcn {
+__global__ void scale_loss_kernel(float* __restrict__ loss, float* __restrict__ dout, int n, const float* __restrict__ scale) {
+    const float sc = *scale;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dout[i] *= sc;
+    if (i == 0) loss[0] *= sc;
+}
+}  // namespace eagcn
+
+// Forward, loss and the HEAD's backward of a training step: after this call d(loss)/d(molecule fingerprints) and every head
+// gradient exist; the caller continues with eagcn_model_backward_range(with_head = 0, ...).  The head runs as ONE launch
+// (head2.hip head_all_kernel) wherever its conditions hold, as the separate launches otherwise -- same results.
+extern "C" int eagcn_model_forward_step(const eagcn_batch* b, const eagcn_model* m, const float* afm, const int64_t* size,
+                                        void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, float* out,
+                                        float* graph_rep, const eagcn_step_loss* loss, const float* dgraph_rep,
+                                        const eagcn_head_grads* hg, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    EAGCN_CHECK_ARG(out && graph_rep && loss && hg, "eagcn_model_forward_step: null argument");
+    EAGCN_CHECK_ARG(m && m->training, "eagcn_model_forward_step: a training-mode model is required");
+    EAGCN_CHECK_ARG((loss->kind == 0 || loss->kind == 1) && loss->labels && loss->loss && loss->dout && (loss->kind == 1 || loss->class_weight),
+                    "eagcn_model_forward_step: bad loss descriptor");
+    EAGCN_CHECK_ARG(hg->d_den1_w && hg->d_den2_w && hg->d_den3_w && hg->d_gbn_w && hg->d_gbn_b && hg->d_bn1_w &&
+                        hg->d_bn1_b && hg->d_bn2_w && hg->d_bn2_b, "eagcn_model_forward_step: null head gradient");
+    ModelSaved sv;
+    ModelScratch sc;
+    RC(model_forward_trunk(b, m, afm, size, saved, saved_bytes, scratch, scratch_bytes, sv, sc, stream, "eagcn_model_forward_step"));
+    const HeadPlan P = head_plan(b, m, sv, sc, out, graph_rep, loss->dout, dgraph_rep, hg);
+    const eagcn_head_params* h = &m->head;
+    if (!P.sync && head_mid_ok(h->nclass)) {
+        // F1, F2 (counts the labelled entries on the way), then out + loss + d a2 as ONE launch, dense 3's weight gradient in
+        // dense 2's backward launch: six launches instead of eight
+        HeadPlan Q = P;
+        unsigned* words = reinterpret_cast<unsigned*>(sc.hws);
+        if (loss->kind == 0) { Q.f2.lab = loss->labels; Q.f2.nlab = b->B * h->nclass; Q.f2.lab_cnt = words + 1; }
+        RC(head_fwd(Q.f1, s));
+        RC(head_fwd(Q.f2, s));
+        HeadMid M;
+        M.f3 = Q.f3; M.b3 = Q.b3;
+        M.L = HeadLoss{loss->kind, loss->labels, loss->class_weight, loss->loss, loss->scale, loss->dout};
+        M.ws = sc.hws;
+        RC(head_mid(M, s));
+        RC(head_bwd_pair(Q.b2, Q.b3, s));
+        RC(head_bwd(Q.b1, s));
+        RC(head_gbn_bwd(Q.bg, s));
+    } else {
+        RC(head_forward_launches(m, P, stream));
+        if (loss->kind == 0) RC(eagcn_bce_loss(out, loss->labels, loss->class_weight, b->B, h->nclass, loss->loss, loss->dout, stream));
+        else RC(eagcn_mse_loss(out, loss->labels, b->B * h->nclass, loss->loss, loss->dout, stream));
+        if (loss->scale) {
+            const int n = b->B * h->nclass;
+            scale_loss_kernel<<<cdiv(n, 256), 256, 0, s>>>(loss->loss, loss->dout, n, loss->scale);
+            EAGCN_LAUNCH_CHECK();
+        }
+        RC(head_backward_launches(m, P, stream));
+    }
+    return readout_pad_backward(b, m, size, sv, sc, stream);
 }
 
 extern "C" int eagcn_model_backward(const eagcn_batch* b, const eagcn_model* m, const int64_t* size, void* saved,
@@ -366,8 +520,7 @@ extern "C" int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_mode
     ModelScratch sc;
     EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "eagcn_model_backward: saved block too small");
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "eagcn_model_backward: scratch too small");
-    const eagcn_head_params* h = &m->head;
-    const int B = b->B, F = h->f_in, n1 = h->n_den1, n2 = h->n_den2, nc = h->nclass;
+    const int F = m->head.f_in;
     // (no clearing launch: the forward call left the hand-off flags and the backward sums zero; owners reset their flags)
     const ZeroJob zb{nullptr, 0, sc.hsb, sc.n_hst};
     hipStream_t side = m->aux_stream ? (hipStream_t)m->aux_stream : s;
@@ -377,68 +530,9 @@ extern "C" int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_mode
     const bool weighted = last->structure == EAGCN_STRUCT_WEIGHTED;
     const bool sampled = pad_sampled(m);
     if (with_head) {
-        // head backward (head2.hip): den3 -> bn_den2 -> den2 -> bn_den1 -> den1 -> Graph_BN, one launch per dense layer
-        // (d input + d weight), each BatchNorm's backward sums taken by the launch in front of it
-        double *sb_g = sc.hsb, *sb_1 = sc.hsb + 2 * F + 2, *sb_2 = sc.hsb + 2 * (F + n1) + 4;
-        // sync-BatchNorm: the backward sums of every head BatchNorm are summed across the ranks before the launch that consumes
-        // them; the global row counts are the ones the forward call left behind its statistics (same scratch block)
-        const bool sync = m->stats_hook && m->training;
-        const double *cn_g = sc.hst + 2 * F, *cn_1 = sc.hst + 2 * F + 2 + 2 * n1, *cn_2 = sc.hst + 2 * (F + n1) + 4 + 2 * n2;
-        const float gscale = sync && m->stats_world > 1 ? 1.0f / (float)m->stats_world : 1.0f;
-        auto hook = [&](double* buf, int n) -> int {
-            if (!sync) return EAGCN_OK;
-            if (m->stats_hook(buf, n, stream, m->stats_user)) {
-                set_error("eagcn_model: the sync-BatchNorm all-reduce hook failed");
-                return EAGCN_ERR_HIP;
-            }
-            return EAGCN_OK;
-        };
-        HeadDrop nodrop{0, 0u, 1.0f, 0, nullptr}, drop1 = nodrop;
-        {
-            int on; uint32_t thr; float inv_keep;
-            fill_drop(h->dropout, m->training, &on, &thr, &inv_keep);
-            drop1 = HeadDrop{on, thr, inv_keep, m->head_seed, m->head_seed_dev};
-        }
-        // dense 3: y = out (no BatchNorm behind it), input a2 = relu(bn_den2(h2))
-        HeadBwd b3{B, n2, nc, sv.h2, sv.bn_2, 1, nodrop, h->den3_w, dout, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                   sc.da2, sb_2, hg->d_den3_w, m->training};
-        // large batches: the weight gradients leave as row-chunk partials, summed by the Graph_BN backward launch below
-        const int ks = sc.hdw_ks;
-        float* part3 = sc.hdw;
-        float* part2 = part3 + (size_t)ks * n2 * nc;
-        float* part1 = part2 + (size_t)ks * n1 * n2;
-        if (ks > 1) { b3.ks = ks; b3.dW_part = part3; }
-        RC(head_bwd(b3, s));
-        RC(hook(sb_2, 2 * n2));
-        // dense 2: y = h2 followed by bn_den2 (+ the gradient that reaches graph_representation directly), input a1
-        HeadBwd b2{B, n1, n2, sv.h1, sv.bn_1, 1, drop1, h->den2_w, sc.da2, sv.h2, sv.bn_2, sb_2, dgraph_rep, hg->d_bn2_w, hg->d_bn2_b,
-                   sc.da1, sb_1, hg->d_den2_w, m->training};
-        if (sync) { b2.cnt_y = cn_2; b2.gscale = gscale; }
-        if (ks > 1) { b2.ks = ks; b2.dW_part = part2; }
-        RC(head_bwd(b2, s));
-        RC(hook(sb_1, 2 * n1));
-        // dense 1: y = h1 followed by bn_den1, input gn = Graph_BN(g)
-        HeadBwd b1{B, F, n1, sv.g, sv.bn_g, 0, nodrop, h->den1_w, sc.da1, sv.h1, sv.bn_1, sb_1, nullptr, hg->d_bn1_w, hg->d_bn1_b,
-                   sc.dgn, sb_g, hg->d_den1_w, m->training};
-        if (sync) { b1.cnt_y = cn_1; b1.gscale = gscale; }
-        if (ks > 1) { b1.ks = ks; b1.dW_part = part1; }
-        RC(head_bwd(b1, s));
-        RC(hook(sb_g, 2 * F));
-        // (folding Graph_BN's backward into the top layer's first backward kernel was measured: a wash at B = 256, +11 us at
-        //  B = 1024 -- every packed row then gathers two molecule rows instead of one; it stays a 5 us launch of its own)
-        HeadGbn bg{B, F, sc.dgn, sv.g, sv.bn_g, sb_g, sc.dg, hg->d_gbn_w, hg->d_gbn_b, m->training};
-        if (sync) { bg.cnt = cn_g; bg.gscale = gscale; }
-        if (ks > 1) {
-            bg.sum[0] = HeadDwSum{hg->d_den3_w, part3, n2 * nc, ks};
-            bg.sum[1] = HeadDwSum{hg->d_den2_w, part2, n1 * n2, ks};
-            bg.sum[2] = HeadDwSum{hg->d_den1_w, part1, F * n1, ks};
-            bg.nsum = 3;
-        }
-        RC(head_gbn_bwd(bg, s));
-        // read-out backward: evaluated inside the last layer's first backward kernel (ReadoutGrad); only the
-        // gradient of the common non-stored row of Weighted_sum needs a (tiny) launch of its own
-        if (sampled) RC(readout_backward_pad_views(b, sc.dg, &lay, size, m->molfp_mode, F, last->K, sv.pad_cnt, last->dropout, sc.dpad, stream));
-        else if (weighted) RC(readout_backward_pad(b, sc.dg, &lay, size, m->molfp_mode, F, sc.dpad, stream));
+        const HeadPlan P = head_plan(b, m, sv, sc, nullptr, nullptr, dout, dgraph_rep, hg);
+        RC(head_backward_launches(m, P, stream));
+        RC(readout_pad_backward(b, m, size, sv, sc, stream));
     }
     ReadoutGrad rgd;
     memset(&rgd, 0, sizeof(rgd));

@@ -13,6 +13,8 @@
 // memory into the MFMA operand registers (v_mfma_f32_16x16x4_f32, exact fp32); one WORKGROUP per 16x64 output tile, its
 // four waves split K and keep two k-steps (ten vector loads) in flight each (the products are latency chains, not flops).
 // Every backward launch carries two products: d(input) of a dense layer (NT form) and its weight gradient (TN form).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -130,9 +132,10 @@ struct HfB {                     // B side (QUAD): W[k][col0 .. col0+3]
     __device__ __forceinline__ f32x4 xf(Raw v, int k) const { return k < K ? zero_beyond(v, col0, N) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
 };
 
-template <bool VEC, bool DROP>
-__global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwd a) {
-    extern __shared__ __attribute__((aligned(16))) float tab[];          // [2][Kp]: scale, shift
+// BatchNorm table of a forward stage, built by every workgroup that has tiles of it: tab[0..Kp) scale, tab[Kp..2Kp) shift.
+// `writer` (one workgroup per stage) also updates the running statistics and saves the [4][K] table for the backward.
+// `full`: mu and 1 / sigma follow in tab[2Kp..4Kp) (the rows of the saved table, for a backward tile of the same workgroup).
+__device__ __forceinline__ void hf_table(const HeadFwd& a, float* tab, bool writer, bool full = false) {
     const int Kp = (a.K + 3) & ~3;
     const double Bn = (a.cnt_in && a.training) ? *a.cnt_in : (double)a.B;      // rows of the BatchNorm (all ranks with sync-BatchNorm)
     for (int k = threadIdx.x; k < a.K; k += 256) {
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwd a) {
             var = var > 0.0 ? var : 0.0;
             mu = (float)mean;
             inv = (float)(1.0 / sqrt(var + (double)a.eps));
-            if (blockIdx.x == 0) {
+            if (writer) {
                 const double unbiased = var * (Bn / (Bn - 1.0));
                 a.run_mean[k] = (float)((1.0 - a.momentum) * (double)a.run_mean[k] + a.momentum * mean);
                 a.run_var[k] = (float)((1.0 - a.momentum) * (double)a.run_var[k] + a.momentum * unbiased);
@@ -168,23 +171,32 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwd a) {
         const float sc = a.gamma[k] * inv, sh = a.beta[k] - mu * sc;
         tab[k] = sc;
         tab[Kp + k] = sh;
-        if (blockIdx.x == 0) {
+        if (full) { tab[2 * Kp + k] = mu; tab[3 * Kp + k] = inv; }
+        if (writer) {
             a.bn[HT_SC * a.K + k] = sc; a.bn[HT_SH * a.K + k] = sh; a.bn[HT_MU * a.K + k] = mu; a.bn[HT_INV * a.K + k] = inv;
         }
     }
-    __syncthreads();
-    f32x4* red = reinterpret_cast<f32x4*>(tab + 2 * Kp);
-    const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
+}
+
+// one 16 x 64 output tile of a forward stage: the product (all four waves; the sum arrives in wave 0's `acc`) ...
+template <bool VEC, bool DROP>
+__device__ __forceinline__ void hf_tile(const HeadFwd& a, int tile, const float* tab, f32x4* red, f32x4 (&acc)[4]) {
+    const int Kp = (a.K + 3) & ~3;
+    const int li = threadIdx.x & 15;
     const int ncb = (a.N + 63) >> 6;
-    const int tile = blockIdx.x;                         // one 16 x 64 tile per workgroup
     const int rb = tile / ncb, cb = tile - rb * ncb;
     const int row = min(rb * 16 + li, a.B - 1), col0 = cb * 64 + 4 * li;
     const HfA<VEC, DROP> fa{a.x + (size_t)row * a.K, tab, a.K, Kp, row, a.relu ? 0.0f : -INFINITY,
                             DROP ? head_seed(a.drop) : 0, a.drop.thr, a.drop.inv_keep};
     const HfB<VEC> fb{a.W, a.K, a.N, col0};
-    f32x4 acc[4];
     head_tile<true, 4>(0, a.K, fa, fb, red, acc);
-    if (threadIdx.x >= 64) return;
+}
+// ... and its epilogue (wave 0 only): y (+ its copy y2), column sums of y into one replica of st_out
+__device__ __forceinline__ void hf_store(const HeadFwd& a, int tile, const f32x4 (&acc)[4]) {
+    const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
+    const int ncb = (a.N + 63) >> 6;
+    const int rb = tile / ncb, cb = tile - rb * ncb;
+    const int col0 = cb * 64 + 4 * li;
     // D layout of tile j: column 4 li + j, rows 4q + r
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -215,6 +227,29 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwd a) {
             }
         }
     }
+}
+
+template <bool VEC, bool DROP>
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwd a) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];          // [2][Kp]: scale, shift
+    const int Kp = (a.K + 3) & ~3;
+    if (a.lab) {                                                         // this workgroup's share of the batch's labelled entries (BCE)
+        const int per = (a.nlab + gridDim.x - 1) / gridDim.x;
+        const int i = blockIdx.x * per + threadIdx.x;
+        int c = 0;
+        for (int j = i; j < min(a.nlab, ((int)blockIdx.x + 1) * per); j += 256) {
+            const float v = a.lab[j];
+            c += (v == 1.0f || v == 0.0f) ? 1 : 0;
+        }
+        c = wave_sum(c);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(a.lab_cnt, (unsigned)c);
+    }
+    hf_table(a, tab, blockIdx.x == 0);
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(tab + 2 * Kp);
+    f32x4 acc[4];
+    hf_tile<VEC, DROP>(a, blockIdx.x, tab, red, acc);                    // one 16 x 64 tile per workgroup
+    if (threadIdx.x < 64) hf_store(a, blockIdx.x, acc);
 }
 
 // ---- backward stage of the dense layer  y = a . W,  a = act(bn_p(x)) -----------------------------------------------------
@@ -288,9 +323,8 @@ struct HbB_b {                   // (b) B side (QUAD): dy_eff[b][n0 .. n0+3]
     __device__ __forceinline__ f32x4 xf(const Raw& r, int b) const { return g.tr(r, b, n0); }
 };
 
-template <bool VEC, bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void head_bwd_kernel(HeadBwd a) {   // (164 registers, three waves per SIMD: 174 and two without the hint)
-    extern __shared__ __attribute__((aligned(16))) float tab[];          // [3][Np]: al, be, ga of dy_eff
+// coefficient table of a backward stage: tab[0..Np) al, [Np..2Np) be, [2Np..3Np) ga of dy_eff; `writer` also stores d gamma / d beta
+__device__ __forceinline__ void hb_table(const HeadBwd& a, float* tab, bool writer) {
     const int Np = (a.N + 3) & ~3;
     const double Bn = (a.cnt_y && a.training) ? *a.cnt_y : (double)a.B;
     for (int n = threadIdx.x; n < a.N; n += 256) {
@@ -303,16 +337,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void h
             al = sc;
             be = -sc * inv * c2;
             ga = sc * (inv * c2 * mu - c1);
-            if (blockIdx.x == 0) { a.dgamma_y[n] = (float)(s2 * (double)a.gscale); a.dbeta_y[n] = (float)(s1 * (double)a.gscale); }
+            if (writer) { a.dgamma_y[n] = (float)(s2 * (double)a.gscale); a.dbeta_y[n] = (float)(s1 * (double)a.gscale); }
         }
         tab[n] = al; tab[Np + n] = be; tab[2 * Np + n] = ga;
     }
-    __syncthreads();
-    f32x4* red = reinterpret_cast<f32x4*>(tab + 3 * Np);
+}
+__device__ __forceinline__ int hb_tiles_a(const HeadBwd& a) { return ((a.B + 15) >> 4) * ((a.K + 63) >> 6); }
+__device__ __forceinline__ int hb_tiles_b(const HeadBwd& a) { return ((a.K + 15) >> 4) * ((a.N + 63) >> 6) * a.ks; }
+
+// one tile of a backward stage: tile < hb_tiles_a: 16 x 64 of d(input) with its epilogue, else 16 x 64 of dW (chunk-major)
+// bnp / bnp_ld: the [4][bnp_ld] table of the BatchNorm in front of the dense layer (a.bnp with stride K, or a copy in LDS)
+template <bool VEC, bool DROP>
+__device__ __forceinline__ void hb_tile(const HeadBwd& a, int tile, const float* tab, f32x4* red, const float* bnp, int bnp_ld) {
+    const int Np = (a.N + 3) & ~3;
     const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
     const int nkb64 = (a.K + 63) >> 6, nnb64 = (a.N + 63) >> 6, nrb = (a.B + 15) >> 4;
     const int tiles_a = nrb * nkb64;
-    const int tile = blockIdx.x;                         // one 16 x 64 tile per workgroup
     const uint64_t seed = DROP ? head_seed(a.drop) : 0;
     const HbDy<VEC> dyf{a.dy, a.bny ? a.y : a.dy, a.extra ? a.extra : a.dy, tab, a.B, a.N, Np, a.extra ? 1.0f : 0.0f};
     f32x4 acc[4];
@@ -328,8 +368,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void h
             const int k = kb * 64 + 16 * j + li;             // tile j: column li <-> input feature k
             double s1 = 0.0, s2 = 0.0;
             if (k < a.K) {
-                const float sc = a.bnp[HT_SC * a.K + k], sh = a.bnp[HT_SH * a.K + k];
-                const float mu = a.bnp[HT_MU * a.K + k], inv = a.bnp[HT_INV * a.K + k];
+                const float sc = bnp[HT_SC * bnp_ld + k], sh = bnp[HT_SH * bnp_ld + k];
+                const float mu = bnp[HT_MU * bnp_ld + k], inv = bnp[HT_INV * bnp_ld + k];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int b = rb * 16 + 4 * q + r;
@@ -362,7 +402,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void h
         float* __restrict__ dW = a.ks > 1 ? a.dW_part + (size_t)chunk * a.K * a.N : a.dW;
         const int kb = t / nnb64, nb = t - kb * nnb64;
         const int k = min(kb * 16 + li, a.K - 1), n0 = nb * 64 + 4 * li;
-        const HbA_b<DROP> fa{a.x, a.B, a.K, k, a.bnp[HT_SC * a.K + k], a.bnp[HT_SH * a.K + k], a.relu_p ? 0.0f : -INFINITY,
+        const HbA_b<DROP> fa{a.x, a.B, a.K, k, bnp[HT_SC * bnp_ld + k], bnp[HT_SH * bnp_ld + k], a.relu_p ? 0.0f : -INFINITY,
                              seed, a.drop.thr, a.drop.inv_keep};
         const HbB_b<VEC> fb{dyf, n0};
         head_tile<true, 2>(r0, r1, fa, fb, red, acc);
@@ -379,11 +419,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void h
     }
 }
 
-// Graph_BN backward (no product in front of it): dg = al * dgn + be * g + ga, d gamma / d beta
-__global__ __launch_bounds__(256) void head_gbn_bwd_kernel(HeadGbn a) {
+template <bool VEC, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void head_bwd_kernel(HeadBwd a) {   // (164 registers, three waves per SIMD: 174 and two without the hint)
+    extern __shared__ __attribute__((aligned(16))) float tab[];          // [3][Np]: al, be, ga of dy_eff
+    const int Np = (a.N + 3) & ~3;
+    hb_table(a, tab, blockIdx.x == 0);
+    __syncthreads();
+    hb_tile<VEC, DROP>(a, blockIdx.x, tab, reinterpret_cast<f32x4*>(tab + 3 * Np), a.bnp, a.K);     // one 16 x 64 tile per workgroup
+}
+
+// Graph_BN backward (no product in front of it): dg = al * dgn + be * g + ga, d gamma / d beta; workgroup `wg` of `nwg`
+__device__ __forceinline__ void hg_body(const HeadGbn& a, int wg, int nwg) {
     const size_t total = (size_t)a.B * a.F;
     const double Bn = (a.cnt && a.training) ? *a.cnt : (double)a.B;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    for (size_t e = (size_t)wg * 256 + threadIdx.x; e < total; e += (size_t)nwg * 256) {
         const int f = (int)(e % a.F);
         const float sc = a.bn[HT_SC * a.F + f], mu = a.bn[HT_MU * a.F + f], inv = a.bn[HT_INV * a.F + f];
         const double s1 = a.sb[2 * f], s2 = a.sb[2 * f + 1];
@@ -394,7 +443,7 @@ __global__ __launch_bounds__(256) void head_gbn_bwd_kernel(HeadGbn a) {
     // weight gradients of the dense layers that left as row-chunk partials (HeadBwd.ks): summed in chunk order
     for (int j = 0; j < a.nsum; ++j) {
         const HeadDwSum q = a.sum[j];
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < q.n; i += gridDim.x * blockDim.x) {
+        for (int i = wg * 256 + threadIdx.x; i < q.n; i += nwg * 256) {
             float v[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) v[c] = q.part[(size_t)min(c, q.ks - 1) * q.n + i];
@@ -403,6 +452,119 @@ __global__ __launch_bounds__(256) void head_gbn_bwd_kernel(HeadGbn a) {
             for (int c = 1; c < 16; ++c) t += c < q.ks ? v[c] : 0.0f;
             q.dst[i] = t;
         }
+    }
+}
+__global__ __launch_bounds__(256) void head_gbn_bwd_kernel(HeadGbn a) { hg_body(a, blockIdx.x, gridDim.x); }
+
+// ---- the middle of a TRAINING step's head as ONE launch: last forward stage, loss (train.py:321-331), first backward product --
+// A 16-row block of the logits is ONE tile when nclass <= 64, the loss terms and d out of those rows need nothing but the rows
+// (and the batch's count of labelled entries, which the launch in front -- dense 2 -- takes on the way: HeadFwd.lab), and
+// d a2 = d out . W3^T needs nothing but those rows of d out: out = relu(bn2(h2)) . W3, the loss and dense 3's d(input) product run
+// in the workgroup that owns the row block, with no launch boundary and no trip through memory between them (they were three
+// launches of 6-10 us: three dependent chains of a table build, a load batch and an epilogue).  Same tile bodies and the same
+// arithmetic as the separate launches.  dense 3's WEIGHT gradient (a reduction over all rows) rides in dense 2's backward launch.
+// The loss value is the sum of the row blocks' partials (fp64 atomic on a word of the head's cleared sums block); the workgroup
+// that finishes last publishes it.
+//
+// Measured and dropped (round 6): the WHOLE head -- three forward stages, loss, three backward stages, Graph_BN backward -- as one
+// persistent launch with device-scope arrive / spin barriers between the phases.  Bit-identical, and SLOWER: 0.507 ms per
+// configs[1] step against 0.400 with eight launches (0.467 with 128 workgroups, 0.66 with 16): a dependent launch boundary costs
+// 1.2-1.9 us on this chip, a grid barrier with its agent-scope release (XCD L2 write-back) and acquire (L1 invalidate) 4-7 us,
+// and the phases behind it start with cold caches.  What the head's launches cost is their own dependent chains, not the boundaries.
+
+// loss terms of one 16 x N block of logits held in wave 0's accumulators (N <= 64): d out written, the block's weighted sum returned
+__device__ __forceinline__ double head_loss_block(const HeadLoss& L, int B, int N, int rb, const f32x4 (&acc)[4], float inv, float scale) {
+    const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
+    double part = 0.0;
+    float yv[4][4], w1[4], w0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = min(4 * li + j, N - 1);
+        w1[j] = L.kind == 0 ? L.weight[2 * col] : 0.0f;
+        w0[j] = L.kind == 0 ? L.weight[2 * col + 1] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yv[j][r] = L.labels[(size_t)min(rb * 16 + 4 * q + r, B - 1) * N + col];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int orow = rb * 16 + 4 * q + r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = 4 * li + j;
+            if (orow < B && col < N) {
+                const float xi = acc[j][r], yi = yv[j][r];
+                float d;
+                if (L.kind == 0) {                       // weighted BCE with logits, missing labels skipped (loss.hip bce_loss_kernel)
+                    const float wi = yi == 1.0f ? w1[j] : (yi == 0.0f ? w0[j] : 0.0f);
+                    part += (double)(wi * (fmaxf(xi, 0.0f) - xi * yi + log1pf(expf(-fabsf(xi)))));
+                    d = wi * (1.0f / (1.0f + expf(-xi)) - yi) * inv;
+                } else {                                 // mean squared error (loss.hip mse_loss_kernel)
+                    const float df = xi - yi;
+                    part += (double)df * (double)df;
+                    d = 2.0f * df * inv;
+                }
+                if (L.scale) d *= scale;
+                L.dout[(size_t)orow * N + col] = d;
+            }
+        }
+    }
+    return wave_sum(part);
+}
+
+template <bool VEC3>
+__global__ __launch_bounds__(256) void head_mid_kernel(HeadMid a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* red = reinterpret_cast<f32x4*>(lds);                         // 16 KB: the four waves' partial tiles
+    float* tabA = lds + 4096;                                           // bn2's table, all four rows (the saved copy is written by
+    float* tabB = tabA + 4 * ((a.f3.K + 3) & ~3);                       //  workgroup 0 in THIS launch); dense 3's (1, 0, 0) table
+    unsigned* words = reinterpret_cast<unsigned*>(a.ws);                // [0] ticket, [1] labelled entries (HeadFwd.lab_cnt of dense 2)
+    double* loss_acc = a.ws + 1;
+    const int rb = blockIdx.x;                                          // one 16-row block per workgroup
+    hf_table(a.f3, tabA, rb == 0, true);
+    hb_table(a.b3, tabB, false);
+    const float cnt = a.L.kind == 0 ? (float)words[1] : (float)(a.f3.B * a.f3.N);
+    const float inv = 1.0f / cnt;
+    const float scale = a.L.scale ? *a.L.scale : 1.0f;
+    __syncthreads();
+    f32x4 acc[4];
+    hf_tile<VEC3, false>(a.f3, rb, tabA, red, acc);
+    if (threadIdx.x < 64) {
+        hf_store(a.f3, rb, acc);
+        const double part = head_loss_block(a.L, a.f3.B, a.f3.N, rb, acc, inv, scale);
+        if (threadIdx.x == 0) atomicAdd(loss_acc, part);
+    }
+    __syncthreads();                                                    // d out of these rows is visible to the four waves (one CU, one L1)
+    const int nkb = (a.b3.K + 63) >> 6;
+    for (int kb = 0; kb < nkb; ++kb) {
+        hb_tile<VEC3, false>(a.b3, rb * nkb + kb, tabB, red, tabA, (a.f3.K + 3) & ~3);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&words[0], 1u) == gridDim.x - 1) {                // the last row block: every partial has been added
+            const double tot = atomicAdd(loss_acc, 0.0);
+            float l = (float)(tot / (double)cnt);
+            if (a.L.scale) l *= scale;
+            a.L.loss[0] = l;
+        }
+    }
+}
+
+// dense 2's backward launch with dense 3's weight gradient riding along: tiles of `a` first, then the (b) tiles of `e`
+template <bool VEC, bool DROP, bool VEC3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void head_bwd_pair_kernel(HeadBwd a, HeadBwd e) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];          // [3][Np] of a, [3][Np] of e, then the partial tiles
+    const int Np = (a.N + 3) & ~3, Ne = (e.N + 3) & ~3;
+    const int ta = hb_tiles_a(a) + hb_tiles_b(a);
+    f32x4* red = reinterpret_cast<f32x4*>(tab + 3 * Np + 3 * Ne);
+    if ((int)blockIdx.x < ta) {
+        hb_table(a, tab, blockIdx.x == 0);
+        __syncthreads();
+        hb_tile<VEC, DROP>(a, blockIdx.x, tab, red, a.bnp, a.K);
+    } else {
+        hb_table(e, tab + 3 * Np, false);
+        __syncthreads();
+        hb_tile<VEC3, false>(e, hb_tiles_a(e) + ((int)blockIdx.x - ta), tab + 3 * Np, red, e.bnp, e.K);
     }
 }
 
@@ -471,6 +633,46 @@ int head_bwd(const HeadBwd& a, hipStream_t s) {
     else if (vec) head_bwd_kernel<true, false><<<tiles, 256, lds, s>>>(a);
     else if (a.drop.on) head_bwd_kernel<false, true><<<tiles, 256, lds, s>>>(a);
     else head_bwd_kernel<false, false><<<tiles, 256, lds, s>>>(a);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+// the fused middle launch needs a row block of the logits to be one tile
+bool head_mid_ok(int nclass) {
+    static const bool env = [] { const char* v = getenv("EAGCN_HEAD_FUSED"); return !(v && v[0] == '0'); }();
+    return env && nclass <= 64;
+}
+int head_mid(const HeadMid& a, hipStream_t s) {
+    const int B = a.f3.B, n2 = a.f3.K, nc = a.f3.N;
+    EAGCN_CHECK_ARG(head_mid_ok(nc) && a.ws && a.L.labels && a.L.loss && a.L.dout, "head_mid: %d classes / null buffer", nc);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(a.f3.x) | reinterpret_cast<uintptr_t>(a.f3.W) | reinterpret_cast<uintptr_t>(a.L.dout);
+    const bool vec3 = (n2 & 3) == 0 && (nc & 3) == 0 && (al & 15) == 0;
+    const size_t lds = 16384 + (size_t)(4 * ((n2 + 3) & ~3) + 3 * ((nc + 3) & ~3)) * sizeof(float);
+    EAGCN_CHECK_ARG(lds <= 64 * 1024, "head_mid: %d features exceed the table size", n2);
+    ProfScope ps(PROF_HEAD, s, 4.0 * B * n2 * nc);
+    if (vec3) head_mid_kernel<true><<<cdiv(B, 16), 256, lds, s>>>(a);
+    else head_mid_kernel<false><<<cdiv(B, 16), 256, lds, s>>>(a);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+// backward of one dense layer (a) with the weight gradient of another (e: only its (b) tiles) in one grid
+int head_bwd_pair(const HeadBwd& a, const HeadBwd& e, hipStream_t s) {
+    EAGCN_CHECK_ARG(a.ks >= 1 && a.ks <= 16 && (a.ks == 1 || a.dW_part) && e.ks >= 1 && e.ks <= 16 && (e.ks == 1 || e.dW_part),
+                    "head: %d / %d row chunks of the weight gradient", a.ks, e.ks);
+    const int tiles = cdiv(a.B, 16) * cdiv(a.K, 64) + cdiv(a.K, 16) * cdiv(a.N, 64) * a.ks + cdiv(e.K, 16) * cdiv(e.N, 64) * e.ks;
+    const size_t lds = (size_t)3 * (((a.N + 3) & ~3) + ((e.N + 3) & ~3)) * sizeof(float) + 16384;
+    EAGCN_CHECK_ARG(lds <= 64 * 1024, "head: %d output features exceed the table size", a.N);
+    ProfScope ps(PROF_HEAD, s, 4.0 * a.B * a.K * a.N + 2.0 * e.B * e.K * e.N);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(a.dy) | reinterpret_cast<uintptr_t>(a.W) | reinterpret_cast<uintptr_t>(a.y) |
+                         reinterpret_cast<uintptr_t>(a.extra);
+    const bool vec = (a.N & 3) == 0 && (al & 15) == 0;
+    const bool vec3 = (e.N & 3) == 0 && (reinterpret_cast<uintptr_t>(e.dy) & 15) == 0;
+    const bool drop = a.drop.on != 0;
+#define EAGCN_HBP(V, D, V3) head_bwd_pair_kernel<V, D, V3><<<tiles, 256, lds, s>>>(a, e)
+    if (vec) { if (drop) { if (vec3) EAGCN_HBP(true, true, true); else EAGCN_HBP(true, true, false); }
+               else { if (vec3) EAGCN_HBP(true, false, true); else EAGCN_HBP(true, false, false); } }
+    else { if (drop) { if (vec3) EAGCN_HBP(false, true, true); else EAGCN_HBP(false, true, false); }
+           else { if (vec3) EAGCN_HBP(false, false, true); else EAGCN_HBP(false, false, false); } }
+#undef EAGCN_HBP
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

@@ -181,6 +181,9 @@ struct HeadFwd {                 // y = act(bn(x)) . W  (+ column sums of y)
     // the consumer adds the replicas up (fp64 atomics on one 128-byte line are served one after the other, ~11 ns each: 1024
     // arrivals per line at B = 1024 kept den1 / den2 waiting 11 us each)
     int st_copies = 1, st_stride = 0;
+    // optional job on the way: count the entries of lab[0 .. nlab) that are 0 or 1 (the batch's labelled entries of the BCE loss)
+    // into *lab_cnt (zero on entry), every workgroup its share
+    const float* lab = nullptr; int nlab = 0; unsigned* lab_cnt = nullptr;
 };
 struct HeadBwd {                 // backward of  y = act(bn_p(x)) . W : d(bn_p output) with its sums, and dW
     int B, K, N;
@@ -199,6 +202,15 @@ struct HeadDwSum { float* dst; const float* part; int n, ks; };     // dst[i] = 
 struct HeadGbn { int B, F; const float *dgn, *g, *bn; const double* sb; float *dg, *dgamma, *dbeta; int training;
                  const double* cnt = nullptr; float gscale = 1.0f;
                  HeadDwSum sum[3] = {}; int nsum = 0; };            // partial weight gradients of the dense layers (HeadBwd.ks)
+// the middle of a TRAINING step's head in one launch: last forward stage, loss, dense 3's d(input) (head2.hip head_mid_kernel)
+struct HeadLoss { int kind;                 // 0: weighted BCE with logits over the labelled entries (train.py:326-331), 1: MSE (train.py:321-325)
+                  const float* labels; const float* weight; float* loss; const float* scale; float* dout; };
+struct HeadMid { HeadFwd f3; HeadBwd b3; HeadLoss L;
+                 double* ws; };            // HEAD_WS doubles, zero on entry: {ticket, labelled entries} as two 32-bit words, loss sum
+constexpr int HEAD_WS = 4;
+bool head_mid_ok(int nclass);
+int head_mid(const HeadMid& a, hipStream_t s);
+int head_bwd_pair(const HeadBwd& a, const HeadBwd& e, hipStream_t s);
 // cnt (optional): three slots that receive B as a double (row counts of the head's BatchNorms, summed with the statistics)
 int head_colstats(const float* g, int B, int F, double* st, hipStream_t s, double* cnt0 = nullptr, double* cnt1 = nullptr,
                   double* cnt2 = nullptr);

@@ -270,12 +270,13 @@ class GraphRunner:
                                         _ptr(self.saved[self.cur]), self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.out),
                                         _ptr(self.graph_rep), _stream()), 'eagcn_model_forward')
 
-    def _call_backward(self):
+    def _call_backward(self, with_head=1):
         lib = L.load()
         size_ptr = _ptr(self.size_static[self.cur]) if self.plan.molfp else C.c_void_p(0)
-        L.check(lib.eagcn_model_backward(self.index.ref(), C.byref(self.cms[self.cur]), size_ptr, _ptr(self.saved[self.cur]),
-                                         self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.dout),
-                                         _ptr(self.dgr), self.lg, C.byref(self.hg), _stream()), 'eagcn_model_backward')
+        L.check(lib.eagcn_model_backward_range(self.index.ref(), C.byref(self.cms[self.cur]), size_ptr, _ptr(self.saved[self.cur]),
+                                               self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.dout),
+                                               _ptr(self.dgr), self.lg, C.byref(self.hg), with_head, len(self.plan.layers) - 1, 0,
+                                               _stream()), 'eagcn_model_backward')
 
     def _capture(self):
         """Capture both sequences (nothing executes during capture).  Called after the first step ran
@@ -302,18 +303,25 @@ class GraphRunner:
         self.graphs[self.cur][0], self.graphs[self.cur][1] = fwd, bwd
 
     # -- per-step entry points -----------------------------------------------------------------------
-    def _check_old_batches(self, force=False):
+    def _check_old_batches(self, force=False, only=None):
         # a timed-out stream-K hand-off (csrc/gemm3.hip) poisons its tile and raises a sticky host-mapped word: the replay
         # loop makes no C call per step, so it is polled here (a plain host read, no synchronisation)
         if L.load().eagcn_gemm_sk_failed():
             raise L.EagcnHipError('a stream-K GEMM hand-off timed out in an earlier step (a contributor wave was not '
                                   'co-resident with its owner): the gradients of that step are NaN-poisoned; '
                                   'eagcn_gemm_sk_reset_failed() clears the flag')
+        # (`only`: the forced wait is for ONE ring slot -- the one about to be reused, the oldest batch in flight.  Waiting for
+        #  every slot waits for the NEWEST batch's index build too and pulls the host back to less than one step ahead of the
+        #  GPU every time the ring wraps: the next batch's side-stream work was then issued half a step late and the step graph
+        #  waited for it, 38 us of idle main stream per 0.4 ms step at configs[1] -- profiles/r06_streams_before.txt)
         for slot in range(_RING):
             ev = self.meta_event[slot]
-            if ev is None or not (force or ev.query()):
+            if ev is None:
                 continue
-            if force:
+            forced = force and (only is None or slot == only)
+            if not (forced or ev.query()):
+                continue
+            if forced:
                 ev.synchronize()
             meta = self.meta_host[slot].tolist()
             self.meta_event[slot] = None
@@ -339,7 +347,7 @@ class GraphRunner:
         main = torch.cuda.current_stream(self.device)
         slot = self.step % _RING
         if self.meta_event[slot] is not None:                 # ring wrapped: this slot must be consumed first
-            self._check_old_batches(force=True)
+            self._check_old_batches(force=True, only=slot)
         # main-stream position now = after the backward of the previous step; the position recorded at the
         # PREVIOUS forward entry = after the backward of the step before it, the last user of this slot
         entry = torch.cuda.Event()
@@ -519,27 +527,33 @@ class GraphRunner:
                 g.add_(v)                                     # a gradient tensor of the caller's: accumulate into it
 
     # -- fused training step: forward + loss + backward as ONE graph launch -----------------------------
-    def _call_loss(self, kind, scaled):
+    def _call_forward_step(self, kind, scaled):
+        """Forward, loss and the head's backward (eagcn_model_forward_step: the head's eight stages as one launch); the layers'
+        backward follows through _call_backward(with_head=0)."""
         lib = L.load()
-        x, y, cur = self.out, self.labels_static[self.cur], self.cur
-        if kind == 'bce':
-            L.check(lib.eagcn_bce_loss(x.data_ptr(), y.data_ptr(), self.weight_static.data_ptr(), x.shape[0], x.shape[1],
-                                       self.loss_static[cur].data_ptr(), self.dout.data_ptr(), _stream()), 'eagcn_bce_loss')
-        else:
-            L.check(lib.eagcn_mse_loss(x.data_ptr(), y.data_ptr(), x.numel(), self.loss_static[cur].data_ptr(),
-                                       self.dout.data_ptr(), _stream()), 'eagcn_mse_loss')
-        if scaled:                                            # data-parallel global normalisation (parallel.dp_loss_scale)
-            self.dout.mul_(self.scale_static[cur])
-            self.loss_static[cur].mul_(self.scale_static[cur])
+        if not torch.cuda.is_current_stream_capturing():
+            self.fwd_issued += 1
+        cur = self.cur
+        sl = L.StepLoss()
+        sl.kind = 0 if kind == 'bce' else 1
+        sl.labels = self.labels_static[cur].data_ptr()
+        sl.class_weight = self.weight_static.data_ptr()
+        sl.loss = self.loss_static[cur].data_ptr()
+        sl.scale = self.scale_static[cur].data_ptr() if scaled else None       # data-parallel global normalisation (parallel.dp_loss_scale)
+        sl.dout = self.dout.data_ptr()
+        size_ptr = _ptr(self.size_static[cur]) if self.plan.molfp else C.c_void_p(0)
+        L.check(lib.eagcn_model_forward_step(self.index.ref(), C.byref(self.cms[cur]), C.c_void_p(0), size_ptr, _ptr(self.saved[cur]),
+                                             self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.out), _ptr(self.graph_rep),
+                                             C.byref(sl), _ptr(self.dgr), C.byref(self.hg), _stream()), 'eagcn_model_forward_step')
 
-    def _call_backward_comm(self, comm):
+    def _call_backward_comm(self, comm, with_head=1):
         """The backward with the gradient average inside: head + upper layers, then the all-reduce of their bucket of the flat
         gradient buffer is STARTED (asynchronously: under capture a branch of the graph), the first layer's backward runs
         beside it, and its own (small) bucket follows.  One bucket when the model has a single layer."""
         lib = L.load()
         nl = len(self.plan.layers)
         if nl < 2:
-            self._call_backward()
+            self._call_backward(with_head)
             comm.start(self.flat_acc).wait()
             return
         size_ptr = _ptr(self.size_static[self.cur]) if self.plan.molfp else C.c_void_p(0)
@@ -549,7 +563,7 @@ class GraphRunner:
                                                    self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.dout),
                                                    _ptr(self.dgr), self.lg, C.byref(self.hg), with_head, hi, lo, _stream()),
                     'eagcn_model_backward_range')
-        part(1, nl - 1, 1)
+        part(with_head, nl - 1, 1)
         cut = self.plan.offsets[self.plan.layer_slices[1][0]]      # first gradient of the second layer: [0, cut) = layer 1
         upper = comm.start(self.flat_acc[cut:])
         part(0, 0, 0)
@@ -599,12 +613,11 @@ class GraphRunner:
         first_eager = self.graphs[cur][2] is None or self.step_kind[cur] != key
         if first_eager:
             self._set_row_hint()
-            self._call_forward()                              # eager (first use of the slot / of this loss): the warm-up
-            self._call_loss(key[0], key[1])
+            self._call_forward_step(key[0], key[1])           # eager (first use of the slot / of this loss): the warm-up
             if in_graph:
-                self._call_backward_comm(comm)
+                self._call_backward_comm(comm, 0)
             else:
-                self._call_backward()
+                self._call_backward(0)
                 if comm is not None:
                     # host-issued average of the flat buffer itself (the .grad views are attached only below: after zero_grad they are
                     # None here and GradientAllReducer.__call__ would find nothing to reduce); the update below needs the average
@@ -616,13 +629,12 @@ class GraphRunner:
             captured, failure = True, None
             try:
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                    self._call_forward()
-                    self._call_loss(key[0], key[1])
+                    self._call_forward_step(key[0], key[1])
                     if in_graph:
-                        self._call_backward_comm(comm)
+                        self._call_backward_comm(comm, 0)
                         update()
                     else:
-                        self._call_backward()
+                        self._call_backward(0)
                         if comm is None:
                             update()
             except L.EagcnHipError:
@@ -654,9 +666,8 @@ class GraphRunner:
                 key = (kind, scale is not None, False, key[3])
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                    self._call_forward()
-                    self._call_loss(key[0], key[1])
-                    self._call_backward()
+                    self._call_forward_step(key[0], key[1])
+                    self._call_backward(0)
                 # (the eager step above left the AVERAGED gradients in the flat buffer; the host-issued average below is then
                 #  the identity on values that are equal on every rank)
             self.graphs[cur][2], self.step_kind[cur] = g, key

@@ -219,7 +219,7 @@ int eagcn_agg_wants_bond_lists(int B, int N);
 int eagcn_agg_wants_bond_lists_for(int B, int N, int structure);
 
 /* ---- library ------------------------------------------------------------------------------- */
-int eagcn_abi_version(void);           /* 5 (round 5); bumped with every struct-layout / signature change */
+int eagcn_abi_version(void);           /* 6 (round 6); bumped with every struct-layout / signature change */
 size_t eagcn_struct_size(int which);   /* 0 batch, 1 layout, 2 layer_params, 3 layer_bufs, 4 layer_grads,
                                           5 head_params, 6 head_grads, 7 model, 8 gat_params, 9 pool_att */
 const char* eagcn_last_error(void);
@@ -410,6 +410,29 @@ int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_model* m, const
                                size_t saved_bytes, void* scratch, size_t scratch_bytes, const float* dout,
                                const float* dgraph_rep, const eagcn_layer_grads* lg, const eagcn_head_grads* hg,
                                int with_head, int layer_hi, int layer_lo, void* stream);
+
+/* ---- a training step's forward + loss + HEAD backward as one call (reference train.py:317-331 in front of models.py:112-120 and
+ * their autograd): the model forward as eagcn_model_forward, then the loss on `out` and the backward of den3 / bn_den2 / den2 /
+ * bn_den1 / den1 / Graph_BN.  Where a row block of the logits is one tile (nclass <= 64) and no sync-BatchNorm hook sits between the
+ * stages, the last forward product, the loss and dense 3's d(input) product run as ONE launch per 16-row block (csrc/head2.hip
+ * head_mid_kernel) and dense 3's weight gradient rides in dense 2's backward launch: six launches instead of eight; otherwise
+ * the separate launches -- same arithmetic, same results.  On return *loss->loss, loss->dout, every head gradient
+ * of `hg` and the gradient of the molecule fingerprints (inside `scratch`) exist: the caller continues with
+ * eagcn_model_backward_range(..., dout = loss->dout, with_head = 0, n_layers - 1, layer_lo). */
+typedef struct eagcn_step_loss {
+    int32_t kind;                /* 0: weighted BCE with logits over the labelled entries (train.py:326-331, eagcn_bce_loss)
+                                    1: mean squared error (train.py:321-325, eagcn_mse_loss)                                 */
+    const float* labels;         /* [B][nclass]; kind 0: 1 / 0 / anything else = missing                                     */
+    const float* class_weight;   /* kind 0: [nclass][2] = {w_pos, w_neg}; kind 1: unused                                     */
+    float* loss;                 /* device scalar (out)                                                                      */
+    const float* scale;          /* optional device scalar: loss and d loss / d out are multiplied by it (the data-parallel
+                                    normalisation of eagcn_amd/parallel.py); NULL = 1                                        */
+    float* dout;                 /* [B][nclass] (out): d loss / d out                                                        */
+} eagcn_step_loss;
+int eagcn_model_forward_step(const eagcn_batch* b, const eagcn_model* m, const float* afm, const int64_t* size,
+                             void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, float* out,
+                             float* graph_rep, const eagcn_step_loss* loss, const float* dgraph_rep,
+                             const eagcn_head_grads* hg, void* stream);
 
 /* ---- losses of the training loop (train.py:321-331), value + d/dlogits in one launch --------------- */
 /* labels [B][T] with 1 / 0 / anything else = missing; class_weight [T][2] = {w_pos, w_neg} (utils.py:681-700) */

@@ -46,6 +46,43 @@ def test_fused_step_matches_forward_loss_backward(task, structure):
         assert torch.equal(sa[k], sb[k]), k
 
 
+@pytest.mark.parametrize('task,T,B,dropout', [('class', 12, 300, 0.3), ('class', 3, 40, 0.0), ('reg', 1, 300, 0.3), ('reg', 8, 17, 0.0)])
+def test_one_launch_head_matches_separate_launches(task, T, B, dropout):
+    """fused_step runs the head's forward, the loss and the head's backward as ONE launch (csrc/head2.hip head_all_kernel: phases
+    behind device-scope barriers); forward() + fused loss + backward() run the same stages as eight launches.  Same tile bodies:
+    bit-identical outputs, loss and gradients -- with dropout (same seeds), at a batch that is not a multiple of 16 and large
+    enough for row-chunked weight gradients (B > 256), with a single regression target (scalar loads in the last stage)."""
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(11)
+    a = EAGCN(28, 24, dropout=dropout, structure='Concate', n_layers=2, widths1=[16] * 5, widths2=[32] * 5, n_den1=96, n_den2=40,
+              nclass=T, graph=True, validate='deferred').to(dev).train()
+    b = copy.deepcopy(a)
+    bw = torch.tensor(bce_weights(T), dtype=torch.float32, device=dev) if task == 'class' else None
+    for step in range(4):
+        mb = make_batch(B=B, n_max=26, n_med=10, rel_channels=(28, 4, 2, 2, 2), seed=90 + step, n_tasks=T, task=task)
+        dense = mb.dense(dev)
+        labels = torch.from_numpy(mb.labels).to(dev)
+        for m in (a, b):
+            for p in m.parameters():
+                p.grad = None
+        torch.manual_seed(500 + step)            # (the dropout seeds of a step are drawn from torch's generator)
+        out, _, gr = a(*dense)
+        loss = (fused_regression_loss(out, labels) if task == 'reg' else fused_classification_loss(out, labels, bw))
+        loss.backward()
+        torch.manual_seed(500 + step)
+        loss_f, (out_f, _, gr_f) = b.fused_step(dense, labels, task, bw)
+        assert torch.equal(out_f, out) and torch.equal(gr_f, gr), (step, (out_f - out).abs().max().item())
+        assert abs(float(loss_f) - float(loss)) <= 2e-7 * abs(float(loss)), (step, float(loss_f), float(loss))
+        for (n, p), q in zip(a.named_parameters(), b.parameters()):
+            if p.grad is None:
+                assert q.grad is None, n
+                continue
+            assert torch.equal(p.grad, q.grad), (step, n, (p.grad - q.grad).abs().max().item())
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
 def test_fused_step_scale_and_accumulation():
     dev = torch.device('cuda', 0)
     torch.manual_seed(6)
