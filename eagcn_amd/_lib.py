@@ -114,7 +114,7 @@ class Model(C.Structure):
     _fields_ = [('n_layers', C.c_int32), ('molfp_mode', C.c_int32), ('training', C.c_int32),
                 ('head_seed', C.c_uint64), ('head_seed_dev', _fp), ('input_packed', C.c_int32), ('aux_stream', _fp),
                 ('layer', LayerParams * 4), ('head', HeadParams), ('stats_hook', _fp), ('stats_user', _fp),
-                ('stats_world', C.c_int32), ('fuse_readout', C.c_int32), ('fwd_signal', _fp)]
+                ('stats_world', C.c_int32), ('fuse_readout', C.c_int32), ('fwd_signal', _fp), ('wait_flag', _fp), ('done_signal', _fp)]
 
 
 class StepLoss(C.Structure):
@@ -141,6 +141,10 @@ SIGNATURES = {
     'eagcn_index_rows': (C.c_int, [C.POINTER(Batch), _fp]),
     'eagcn_set_gemm_mode': (C.c_int, [C.c_int]),
     'eagcn_stream_wait_counter': (C.c_int, [_fp, C.c_uint32, _fp]),
+    'eagcn_stream_signal_flag': (C.c_int, [_fp, _fp]),
+    'eagcn_stream_wait_flag': (C.c_int, [_fp, C.c_double, _fp]),
+    'eagcn_stream_wait_timeouts': (C.c_int, []),
+    'eagcn_stream_wait_reset': (None, []),
     'eagcn_adam_step': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     'eagcn_agg_wants_bond_lists': (C.c_int, [C.c_int, C.c_int]),
     'eagcn_agg_wants_bond_lists_for': (C.c_int, [C.c_int, C.c_int, C.c_int]),

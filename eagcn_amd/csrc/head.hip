@@ -23,14 +23,65 @@ namespace eagcn {
 __global__ void fwd_signal_kernel(uint32_t* __restrict__ word) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void wait_counter_kernel(const uint32_t* __restrict__ word, uint32_t value) {
+// (gives up after `budget_ticks` of the 100 MHz clock and raises the sticky word `err`: a poll must never hang the queue)
+__global__ void wait_counter_kernel(const uint32_t* __restrict__ word, uint32_t value, int* __restrict__ err,
+                                    unsigned long long budget_ticks) {
     if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
         // (signed distance: the counter may wrap)
-        while ((int32_t)(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) __builtin_amdgcn_s_sleep(64);
+        while ((int32_t)(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+            __builtin_amdgcn_s_sleep(64);
+            if (wall_clock64() - t0 > budget_ticks) {
+                if (err) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
     }
 }
 
 
+
+// batch-ready flag (eagcn_model.wait_flag, eagcn_stream_signal_flag): the stream that prepares a batch sets the word behind its
+// last kernel, the step's first launch polls it and clears it.  Replaces hipStreamWaitEvent between the two streams, which costs
+// the WAITING stream ~40 us per step on ROCm 7.2 even when the event completed long ago (tools/replay_probe.py: the captured
+// configs[1] step replays in 355 us back to back, 395 us behind a cross-stream event wait).  A waiter that is never signalled
+// (both streams on one hardware queue: the poll would block the signal) gives up after its budget and raises a sticky,
+// host-visible word -- the caller checks it and falls back to events.
+static int* g_wait_err_host = nullptr;
+static int* g_wait_err_dev = nullptr;
+static int* wait_err_word() {
+    if (!g_wait_err_dev) {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+        memset(h, 0, 64);
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) return nullptr;
+        g_wait_err_host = (int*)h;
+        g_wait_err_dev = (int*)d;
+    }
+    return g_wait_err_dev;
+}
+__global__ void signal_flag_kernel(uint32_t* __restrict__ flag) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void wait_flag_kernel(uint32_t* __restrict__ flag, int* __restrict__ err, unsigned long long budget_ticks) {
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();                   // 100 MHz
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > budget_ticks) {
+                if (err) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+static int launch_wait_flag(uint32_t* flag, double budget_s, hipStream_t s) {
+    wait_flag_kernel<<<1, 64, 0, s>>>(flag, wait_err_word(), (unsigned long long)(budget_s * 1e8));
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
 
 // ---- carving of the saved-for-backward block and of the transient scratch ---------------------------
 struct Carver2 {
@@ -323,6 +374,7 @@ static int model_forward_trunk(const eagcn_batch* b, const eagcn_model* m, const
     EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "%s: saved block too small", who);
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "%s: scratch too small", who);
     const eagcn_head_params* h = &m->head;
+    if (m->wait_flag) RC(launch_wait_flag(m->wait_flag, 2.0, s));       // the batch's index / packed input are complete
     ZeroJob zj;                                   // hand-off flags + the head's sums: cleared by the packing launch below
     RC(gemm3_zero_job(sc.layer, sc.layer_bytes, sc.hst, (HEAD_COPIES + 1) * sc.n_hst + HEAD_WS, &zj));
     if (!m->input_packed)
@@ -463,7 +515,7 @@ extern "C" int eagcn_model_forward_step(const eagcn_batch* b, const eagcn_model*
     RC(model_forward_trunk(b, m, afm, size, saved, saved_bytes, scratch, scratch_bytes, sv, sc, stream, "eagcn_model_forward_step"));
     const HeadPlan P = head_plan(b, m, sv, sc, out, graph_rep, loss->dout, dgraph_rep, hg);
     const eagcn_head_params* h = &m->head;
-    if (!P.sync && head_mid_ok(h->nclass)) {
+    if (!P.sync && head_mid_ok(h->n_den2, h->nclass)) {
         // F1, F2 (counts the labelled entries on the way), then out + loss + d a2 as ONE launch, dense 3's weight gradient in
         // dense 2's backward launch: six launches instead of eight
         HeadPlan Q = P;
@@ -476,7 +528,7 @@ extern "C" int eagcn_model_forward_step(const eagcn_batch* b, const eagcn_model*
         M.L = HeadLoss{loss->kind, loss->labels, loss->class_weight, loss->loss, loss->scale, loss->dout};
         M.ws = sc.hws;
         RC(head_mid(M, s));
-        RC(head_bwd_pair(Q.b2, Q.b3, s));
+        RC(head_bwd_pair(Q.b2, Q.b3, HeadLossFin{loss->loss, sc.hws, loss->scale, loss->kind, b->B * h->nclass}, s));
         RC(head_bwd(Q.b1, s));
         RC(head_gbn_bwd(Q.bg, s));
     } else {
@@ -566,12 +618,33 @@ extern "C" int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_mode
         if (l == layer_lo) pend_in.eacc = nullptr;
     }
     if (forked) RC(stream_after(s, side));                       // join: every gradient is complete on s
+    if (m->done_signal && layer_lo == 0) {                       // (include/eagcn_hip.h eagcn_model.done_signal)
+        fwd_signal_kernel<<<1, 64, 0, s>>>(m->done_signal);
+        EAGCN_LAUNCH_CHECK();
+    }
     return EAGCN_OK;
+}
+
+extern "C" int eagcn_stream_signal_flag(uint32_t* flag, void* stream) {
+    EAGCN_CHECK_ARG(flag != nullptr, "eagcn_stream_signal_flag: null flag");
+    eagcn::signal_flag_kernel<<<1, 64, 0, (hipStream_t)stream>>>(flag);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+extern "C" int eagcn_stream_wait_flag(uint32_t* flag, double budget_seconds, void* stream) {
+    EAGCN_CHECK_ARG(flag != nullptr && budget_seconds > 0.0, "eagcn_stream_wait_flag: null flag / no budget");
+    return eagcn::launch_wait_flag(flag, budget_seconds, (hipStream_t)stream);
+}
+extern "C" int eagcn_stream_wait_timeouts(void) {
+    return eagcn::g_wait_err_host ? __atomic_load_n(eagcn::g_wait_err_host, __ATOMIC_RELAXED) : 0;
+}
+extern "C" void eagcn_stream_wait_reset(void) {
+    if (eagcn::g_wait_err_host) __atomic_store_n(eagcn::g_wait_err_host, 0, __ATOMIC_RELAXED);
 }
 
 extern "C" int eagcn_stream_wait_counter(const uint32_t* counter, uint32_t value, void* stream) {
     EAGCN_CHECK_ARG(counter != nullptr, "eagcn_stream_wait_counter: null counter");
-    eagcn::wait_counter_kernel<<<1, 64, 0, (hipStream_t)stream>>>(counter, value);
+    eagcn::wait_counter_kernel<<<1, 64, 0, (hipStream_t)stream>>>(counter, value, eagcn::wait_err_word(), 200000000ull);   // 2 s
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

@@ -472,87 +472,160 @@ __global__ __launch_bounds__(256) void head_gbn_bwd_kernel(HeadGbn a) { hg_body(
 // 1.2-1.9 us on this chip, a grid barrier with its agent-scope release (XCD L2 write-back) and acquire (L1 invalidate) 4-7 us,
 // and the phases behind it start with cold caches.  What the head's launches cost is their own dependent chains, not the boundaries.
 
-// loss terms of one 16 x N block of logits held in wave 0's accumulators (N <= 64): d out written, the block's weighted sum returned
-__device__ __forceinline__ double head_loss_block(const HeadLoss& L, int B, int N, int rb, const f32x4 (&acc)[4], float inv, float scale) {
-    const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
-    double part = 0.0;
-    float yv[4][4], w1[4], w0[4];
+// The loss of a 16 x N block of logits (N <= 64), one element per thread and pass (wave 0 alone, which holds the tile, took sixteen
+// divergent passes through expf / log1pf: 9 of the launch's 20 us): labels and class weights are requested with the launch's
+// first batch of loads (head_loss_load), the logits come from the workgroup's LDS copy `ol` [16][N]; d out goes to the global
+// matrix and to `dl` [16][N]; the block's weighted sum is added to *loss_acc by every wave.
+constexpr int LOSS_U = 4;                  // 16 x 64 elements / 256 threads
+struct LossRegs { float y[LOSS_U], w1[LOSS_U], w0[LOSS_U]; };
+__device__ __forceinline__ LossRegs head_loss_load(const HeadLoss& L, int Bl, int N, int rb) {
+    LossRegs R;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = min(4 * li + j, N - 1);
-        w1[j] = L.kind == 0 ? L.weight[2 * col] : 0.0f;
-        w0[j] = L.kind == 0 ? L.weight[2 * col + 1] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) yv[j][r] = L.labels[(size_t)min(rb * 16 + 4 * q + r, B - 1) * N + col];
+    for (int u = 0; u < LOSS_U; ++u) {
+        const int e = min((int)threadIdx.x + u * 256, Bl * N - 1);
+        const int c = e % N;
+        R.y[u] = L.labels[(size_t)rb * 16 * N + e];
+        R.w1[u] = L.kind == 0 ? L.weight[2 * c] : 0.0f;
+        R.w0[u] = L.kind == 0 ? L.weight[2 * c + 1] : 0.0f;
     }
+    return R;
+}
+__device__ __forceinline__ void head_loss_block(const HeadLoss& L, const LossRegs& R, int Bl, int N, int rb, const float* ol, float inv,
+                                                float scale, float* dl, double* loss_acc) {
+    double part = 0.0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int orow = rb * 16 + 4 * q + r;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = 4 * li + j;
-            if (orow < B && col < N) {
-                const float xi = acc[j][r], yi = yv[j][r];
-                float d;
-                if (L.kind == 0) {                       // weighted BCE with logits, missing labels skipped (loss.hip bce_loss_kernel)
-                    const float wi = yi == 1.0f ? w1[j] : (yi == 0.0f ? w0[j] : 0.0f);
-                    part += (double)(wi * (fmaxf(xi, 0.0f) - xi * yi + log1pf(expf(-fabsf(xi)))));
-                    d = wi * (1.0f / (1.0f + expf(-xi)) - yi) * inv;
-                } else {                                 // mean squared error (loss.hip mse_loss_kernel)
-                    const float df = xi - yi;
-                    part += (double)df * (double)df;
-                    d = 2.0f * df * inv;
-                }
-                if (L.scale) d *= scale;
-                L.dout[(size_t)orow * N + col] = d;
+    for (int u = 0; u < LOSS_U; ++u) {
+        const int e = (int)threadIdx.x + u * 256;
+        if (e < Bl * N) {
+            const float xi = ol[e], yi = R.y[u];
+            float d;
+            if (L.kind == 0) {                           // weighted BCE with logits, missing labels skipped (loss.hip bce_loss_kernel)
+                const float wi = yi == 1.0f ? R.w1[u] : (yi == 0.0f ? R.w0[u] : 0.0f);
+                part += (double)(wi * (fmaxf(xi, 0.0f) - xi * yi + log1pf(expf(-fabsf(xi)))));
+                d = wi * (1.0f / (1.0f + expf(-xi)) - yi) * inv;
+            } else {                                     // mean squared error (loss.hip mse_loss_kernel)
+                const float df = xi - yi;
+                part += (double)df * (double)df;
+                d = 2.0f * df * inv;
             }
+            if (L.scale) d *= scale;
+            L.dout[(size_t)rb * 16 * N + e] = d;
+            dl[e] = d;
         }
     }
-    return wave_sum(part);
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0 && part != 0.0) atomicAdd(loss_acc, part);
 }
 
+// Everything the row block needs is requested in ONE batch at the start -- bn2's sums, the block's 16 rows of h2, the whole of
+// W3, labels, class weights, the label count -- and copied to LDS in the layouts the global matrices have; the two tiles then run
+// the SAME bodies as the separate launches (hf_tile / hb_tile on descriptors that point into the workgroup's copies, rows
+// renumbered from 0), d out goes from the loss to dense 3's product through LDS.  Three dependent chains (table, operand batch,
+// epilogue -- each behind a launch) become one: 23 -> 9 us at configs[1].
 template <bool VEC3>
 __global__ __launch_bounds__(256) void head_mid_kernel(HeadMid a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int K = a.f3.K, N = a.f3.N, Kp = (K + 3) & ~3, Np = (N + 3) & ~3;
     f32x4* red = reinterpret_cast<f32x4*>(lds);                         // 16 KB: the four waves' partial tiles
     float* tabA = lds + 4096;                                           // bn2's table, all four rows (the saved copy is written by
-    float* tabB = tabA + 4 * ((a.f3.K + 3) & ~3);                       //  workgroup 0 in THIS launch); dense 3's (1, 0, 0) table
-    unsigned* words = reinterpret_cast<unsigned*>(a.ws);                // [0] ticket, [1] labelled entries (HeadFwd.lab_cnt of dense 2)
+    float* tabB = tabA + 4 * Kp;                                        //  workgroup 0 in THIS launch); dense 3's (1, 0, 0) table
+    float* xs = tabB + 3 * Np;                                          // [16][K]   rows rb*16 .. of h2 (clamped to the batch)
+    float* Ws = xs + 16 * Kp;                                           // [K][N]    W3 (K*N rounded up to 4)
+    float* dl = Ws + ((K * N + 3) & ~3);                                // [16][N]   d out of the block
+    float* ol = dl + 16 * Np;                                           // [16][N]   logits of the block
+    const unsigned* words = reinterpret_cast<const unsigned*>(a.ws);    // [1] labelled entries (HeadFwd.lab_cnt of dense 2)
     double* loss_acc = a.ws + 1;
-    const int rb = blockIdx.x;                                          // one 16-row block per workgroup
+    const int rb = blockIdx.x, B = a.f3.B;                              // one 16-row block per workgroup
+    const int Bl = min(16, B - rb * 16);
+    // ---- one batch of loads
+    const bool vx = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(a.f3.x) & 15) == 0;
+    const bool vw = ((K * N) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.f3.W) & 15) == 0;
+    constexpr int XU = 4, WU = 4;                                       // float4 (or scalar) slots per thread and pass
+    for (int p0 = 0; p0 < 16 * Kp / 4; p0 += 256 * XU) {                // h2 rows (K <= 2048: a few passes at most)
+        f32x4 v[XU];
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = min(p0 + u * 256 + (int)threadIdx.x, 16 * Kp / 4 - 1);
+            const int r = i / (Kp / 4), c4 = i - r * (Kp / 4);
+            const float* src = a.f3.x + (size_t)min(rb * 16 + r, B - 1) * K;
+            if (vx) v[u] = *reinterpret_cast<const f32x4*>(src + 4 * c4);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = src[min(4 * c4 + e, K - 1)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = p0 + u * 256 + (int)threadIdx.x;
+            if (i < 16 * Kp / 4) {
+                const int r = i / (Kp / 4), c4 = i - r * (Kp / 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * c4 + e < K) xs[r * K + 4 * c4 + e] = v[u][e];
+            }
+        }
+    }
+    const int nw4 = (K * N + 3) >> 2;
+    for (int p0 = 0; p0 < nw4; p0 += 256 * WU) {
+        f32x4 v[WU];
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int i = min(p0 + u * 256 + (int)threadIdx.x, nw4 - 1);
+            if (vw) v[u] = *reinterpret_cast<const f32x4*>(a.f3.W + 4 * i);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = a.f3.W[min(4 * i + e, K * N - 1)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int i = p0 + u * 256 + (int)threadIdx.x;
+            if (i < nw4) *reinterpret_cast<f32x4*>(Ws + 4 * i) = v[u];
+        }
+    }
+    const LossRegs R = head_loss_load(a.L, Bl, N, rb);
+    const float cnt = a.L.kind == 0 ? (float)words[1] : (float)(B * N);
+    const float scale = a.L.scale ? *a.L.scale : 1.0f;
     hf_table(a.f3, tabA, rb == 0, true);
     hb_table(a.b3, tabB, false);
-    const float cnt = a.L.kind == 0 ? (float)words[1] : (float)(a.f3.B * a.f3.N);
     const float inv = 1.0f / cnt;
-    const float scale = a.L.scale ? *a.L.scale : 1.0f;
     __syncthreads();
+    // ---- the block's descriptors: rows renumbered from 0, operands in LDS
+    HeadFwd f = a.f3;
+    f.B = Bl; f.x = xs; f.W = Ws; f.y = a.f3.y + (size_t)rb * 16 * N; f.y2 = nullptr; f.st_out = nullptr;
+    HeadBwd g = a.b3;
+    g.B = Bl; g.x = xs; g.W = Ws; g.dy = dl; g.dyp = a.b3.dyp + (size_t)rb * 16 * K;
     f32x4 acc[4];
-    hf_tile<VEC3, false>(a.f3, rb, tabA, red, acc);
+    hf_tile<VEC3, false>(f, 0, tabA, red, acc);
     if (threadIdx.x < 64) {
-        hf_store(a.f3, rb, acc);
-        const double part = head_loss_block(a.L, a.f3.B, a.f3.N, rb, acc, inv, scale);
-        if (threadIdx.x == 0) atomicAdd(loss_acc, part);
+        hf_store(f, 0, acc);
+        const int li = threadIdx.x & 15, q = threadIdx.x >> 4;         // D layout of tile j: column 4 li + j, rows 4q + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * li + j < N) ol[(4 * q + r) * N + 4 * li + j] = acc[j][r];
     }
-    __syncthreads();                                                    // d out of these rows is visible to the four waves (one CU, one L1)
-    const int nkb = (a.b3.K + 63) >> 6;
+    __syncthreads();
+    head_loss_block(a.L, R, Bl, N, rb, ol, inv, scale, dl, loss_acc);
+    __syncthreads();                                                    // d out of these rows is in LDS
+    const int nkb = (K + 63) >> 6;
     for (int kb = 0; kb < nkb; ++kb) {
-        hb_tile<VEC3, false>(a.b3, rb * nkb + kb, tabB, red, tabA, (a.f3.K + 3) & ~3);
+        hb_tile<VEC3, false>(g, kb, tabB, red, tabA, Kp);
         __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&words[0], 1u) == gridDim.x - 1) {                // the last row block: every partial has been added
-            const double tot = atomicAdd(loss_acc, 0.0);
-            float l = (float)(tot / (double)cnt);
-            if (a.L.scale) l *= scale;
-            a.L.loss[0] = l;
-        }
     }
 }
 
 // dense 2's backward launch with dense 3's weight gradient riding along: tiles of `a` first, then the (b) tiles of `e`
+// (and the loss value published from the row blocks' partial sums: workgroup 0, HeadLossFin)
 template <bool VEC, bool DROP, bool VEC3>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void head_bwd_pair_kernel(HeadBwd a, HeadBwd e) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void head_bwd_pair_kernel(HeadBwd a, HeadBwd e, HeadLossFin lf) {
+    if (lf.loss && blockIdx.x == 0 && threadIdx.x == 0) {
+        const double cnt = lf.kind == 0 ? (double)(float)reinterpret_cast<const unsigned*>(lf.ws)[1] : (double)(float)lf.n;
+        float l = (float)(lf.ws[1] / cnt);
+        if (lf.scale) l *= *lf.scale;
+        lf.loss[0] = l;
+    }
     extern __shared__ __attribute__((aligned(16))) float tab[];          // [3][Np] of a, [3][Np] of e, then the partial tiles
     const int Np = (a.N + 3) & ~3, Ne = (e.N + 3) & ~3;
     const int ta = hb_tiles_a(a) + hb_tiles_b(a);
@@ -637,17 +710,24 @@ int head_bwd(const HeadBwd& a, hipStream_t s) {
     return EAGCN_OK;
 }
 // the fused middle launch needs a row block of the logits to be one tile
-bool head_mid_ok(int nclass) {
+bool head_mid_ok(int n2, int nclass) {
     static const bool env = [] { const char* v = getenv("EAGCN_HEAD_FUSED"); return !(v && v[0] == '0'); }();
-    return env && nclass <= 64;
+    const size_t lds = 16384 + (size_t)(20 * ((n2 + 3) & ~3) + 35 * ((nclass + 3) & ~3) + n2 * nclass + 4) * sizeof(float);
+    return env && nclass <= 64 && lds <= 150 * 1024;
 }
 int head_mid(const HeadMid& a, hipStream_t s) {
     const int B = a.f3.B, n2 = a.f3.K, nc = a.f3.N;
-    EAGCN_CHECK_ARG(head_mid_ok(nc) && a.ws && a.L.labels && a.L.loss && a.L.dout, "head_mid: %d classes / null buffer", nc);
+    EAGCN_CHECK_ARG(head_mid_ok(n2, nc) && a.ws && a.L.labels && a.L.loss && a.L.dout, "head_mid: %d classes / null buffer", nc);
     const uintptr_t al = reinterpret_cast<uintptr_t>(a.f3.x) | reinterpret_cast<uintptr_t>(a.f3.W) | reinterpret_cast<uintptr_t>(a.L.dout);
     const bool vec3 = (n2 & 3) == 0 && (nc & 3) == 0 && (al & 15) == 0;
-    const size_t lds = 16384 + (size_t)(4 * ((n2 + 3) & ~3) + 3 * ((nc + 3) & ~3)) * sizeof(float);
-    EAGCN_CHECK_ARG(lds <= 64 * 1024, "head_mid: %d features exceed the table size", n2);
+    const int Kp = (n2 + 3) & ~3, Np = (nc + 3) & ~3;
+    const size_t lds = 16384 + (size_t)(4 * Kp + 3 * Np + 16 * Kp + ((n2 * nc + 3) & ~3) + 32 * Np) * sizeof(float);
+    static bool attr = [] {
+        bool ok = hipFuncSetAttribute((const void*)head_mid_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess;
+        return hipFuncSetAttribute((const void*)head_mid_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess && ok;
+    }();
+    (void)attr;
+    EAGCN_CHECK_ARG(lds <= 150 * 1024, "head_mid: %d x %d weights exceed LDS", n2, nc);
     ProfScope ps(PROF_HEAD, s, 4.0 * B * n2 * nc);
     if (vec3) head_mid_kernel<true><<<cdiv(B, 16), 256, lds, s>>>(a);
     else head_mid_kernel<false><<<cdiv(B, 16), 256, lds, s>>>(a);
@@ -655,7 +735,7 @@ int head_mid(const HeadMid& a, hipStream_t s) {
     return EAGCN_OK;
 }
 // backward of one dense layer (a) with the weight gradient of another (e: only its (b) tiles) in one grid
-int head_bwd_pair(const HeadBwd& a, const HeadBwd& e, hipStream_t s) {
+int head_bwd_pair(const HeadBwd& a, const HeadBwd& e, const HeadLossFin& lf, hipStream_t s) {
     EAGCN_CHECK_ARG(a.ks >= 1 && a.ks <= 16 && (a.ks == 1 || a.dW_part) && e.ks >= 1 && e.ks <= 16 && (e.ks == 1 || e.dW_part),
                     "head: %d / %d row chunks of the weight gradient", a.ks, e.ks);
     const int tiles = cdiv(a.B, 16) * cdiv(a.K, 64) + cdiv(a.K, 16) * cdiv(a.N, 64) * a.ks + cdiv(e.K, 16) * cdiv(e.N, 64) * e.ks;
@@ -667,7 +747,7 @@ int head_bwd_pair(const HeadBwd& a, const HeadBwd& e, hipStream_t s) {
     const bool vec = (a.N & 3) == 0 && (al & 15) == 0;
     const bool vec3 = (e.N & 3) == 0 && (reinterpret_cast<uintptr_t>(e.dy) & 15) == 0;
     const bool drop = a.drop.on != 0;
-#define EAGCN_HBP(V, D, V3) head_bwd_pair_kernel<V, D, V3><<<tiles, 256, lds, s>>>(a, e)
+#define EAGCN_HBP(V, D, V3) head_bwd_pair_kernel<V, D, V3><<<tiles, 256, lds, s>>>(a, e, lf)
     if (vec) { if (drop) { if (vec3) EAGCN_HBP(true, true, true); else EAGCN_HBP(true, true, false); }
                else { if (vec3) EAGCN_HBP(true, false, true); else EAGCN_HBP(true, false, false); } }
     else { if (drop) { if (vec3) EAGCN_HBP(false, true, true); else EAGCN_HBP(false, true, false); }

@@ -206,11 +206,12 @@ struct HeadGbn { int B, F; const float *dgn, *g, *bn; const double* sb; float *d
 struct HeadLoss { int kind;                 // 0: weighted BCE with logits over the labelled entries (train.py:326-331), 1: MSE (train.py:321-325)
                   const float* labels; const float* weight; float* loss; const float* scale; float* dout; };
 struct HeadMid { HeadFwd f3; HeadBwd b3; HeadLoss L;
-                 double* ws; };            // HEAD_WS doubles, zero on entry: {ticket, labelled entries} as two 32-bit words, loss sum
+                 double* ws; };            // HEAD_WS doubles, zero on entry: {unused, labelled entries} as two 32-bit words, loss sum
 constexpr int HEAD_WS = 4;
-bool head_mid_ok(int nclass);
+struct HeadLossFin { float* loss; const double* ws; const float* scale; int kind, n; };   // loss value = ws[1] / count (* scale); loss == null: no job
+bool head_mid_ok(int n_den2, int nclass);
 int head_mid(const HeadMid& a, hipStream_t s);
-int head_bwd_pair(const HeadBwd& a, const HeadBwd& e, hipStream_t s);
+int head_bwd_pair(const HeadBwd& a, const HeadBwd& e, const HeadLossFin& lf, hipStream_t s);
 // cnt (optional): three slots that receive B as a double (row counts of the head's BatchNorms, summed with the statistics)
 int head_colstats(const float* g, int B, int F, double* st, hipStream_t s, double* cnt0 = nullptr, double* cnt1 = nullptr,
                   double* cnt2 = nullptr);

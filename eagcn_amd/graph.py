@@ -54,6 +54,38 @@ _COMM_IN_GRAPH = os.environ.get('EAGCN_COMM_IN_GRAPH', '1') != '0'
 _CAPTURE_DRAIN_S = float(os.environ.get('EAGCN_CAPTURE_DRAIN_S', '0.35'))
 
 
+# The batch-ready hand-off from the side stream to the step: a device flag that the step's first launch polls
+# (eagcn_model.wait_flag) instead of main.wait_event(side event).  hipStreamWaitEvent across two streams costs the waiting stream
+# ~40 us per step on ROCm 7.2 even when the event completed long ago (tools/replay_probe.py: 355 us per configs[1] step with
+# nothing between the replays, 395 us with an event wait in front of each).  EAGCN_READY_FLAG=0: events.
+_READY_FLAG = os.environ.get('EAGCN_READY_FLAG', '1') != '0'
+_flag_tested = {}
+
+
+def _ready_flag_ok(device):
+    """Once per device: do the current stream and the index stream really run concurrently?  (Streams that share a hardware queue
+    would park the poll in front of its own signal.)  A 50-ms poll on the main stream, the signal on the side stream."""
+    if not _READY_FLAG:
+        return False
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _flag_tested:
+        lib = L.load()
+        flag = torch.zeros(1, dtype=torch.int32, device=device)
+        torch.cuda.synchronize(device)
+        main, side = torch.cuda.current_stream(device), _index_stream(device)
+        L.check(lib.eagcn_stream_wait_flag(C.c_void_p(flag.data_ptr()), 0.05, C.c_void_p(main.cuda_stream)), 'eagcn_stream_wait_flag')
+        L.check(lib.eagcn_stream_signal_flag(C.c_void_p(flag.data_ptr()), C.c_void_p(side.cuda_stream)), 'eagcn_stream_signal_flag')
+        torch.cuda.synchronize(device)
+        ok = lib.eagcn_stream_wait_timeouts() == 0
+        if not ok:
+            import warnings
+            lib.eagcn_stream_wait_reset()
+            warnings.warn('eagcn_amd: the index stream does not run beside the current stream on this device (shared hardware '
+                          'queue?): batch hand-off through stream events instead of a device flag', RuntimeWarning)
+        _flag_tested[key] = ok
+    return _flag_tested[key]
+
+
 def _drain_collectives(device):
     """Before capturing a graph in a process with an initialised process group (see _CAPTURE_DRAIN_S)."""
     import torch.distributed as dist
@@ -152,6 +184,18 @@ class GraphRunner:
         if os.environ.get('EAGCN_AUX_STREAM', '0') == '1':
             self.aux = torch.cuda.Stream(device=self.device)
         self.fwd_sig = torch.zeros(1, dtype=torch.int32, device=device)     # bumped by every executed forward (eagcn_model.fwd_signal)
+        # per slot: "this slot's batch is prepared" -- set behind the batch's last preparatory kernel, polled and cleared by the
+        # step's first launch (eagcn_model.wait_flag)
+        self.ready = torch.zeros(2, dtype=torch.int32, device=device)
+        self.use_flag = _ready_flag_ok(device)
+        # ... and the other direction: every backward adds 1 to `done_word` behind its last launch (eagcn_model.done_signal); the
+        # side stream waits for the COUNT of the step that used a slot last instead of for an event recorded on the main stream
+        # between two step graphs.  markers[k]: what "the main stream's work up to the step before (k = 1) / before that (k = 0)
+        # is done" means -- ('count', n) after a fused step, ('event', ev) otherwise
+        self.done_word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.done_issued = 0
+        self.counted = False              # the last step issued was a fused step (its end is the done_issued-th signal)
+        self.markers = [None, None]
         self.fwd_issued = 0                                                  # ... and the number of forwards issued so far
         self.cms = [self._cmodel(i) for i in range(2)]
         m = self.cms[0]
@@ -230,6 +274,9 @@ class GraphRunner:
             m.layer[l].seed_dev = sd + 8 * l
         m.head_seed_dev = sd + 8 * 4
         m.input_packed = 1
+        if self.use_flag:
+            m.wait_flag = self.ready.data_ptr() + 4 * slot
+            m.done_signal = self.done_word.data_ptr()
         if _SIDE_PLACED:
             m.fwd_signal = self.fwd_sig.data_ptr()
         if self.aux is not None:
@@ -272,6 +319,8 @@ class GraphRunner:
 
     def _call_backward(self, with_head=1):
         lib = L.load()
+        if not torch.cuda.is_current_stream_capturing():
+            self.done_issued += 1                             # (the backward's last launch bumps done_word: eagcn_model.done_signal)
         size_ptr = _ptr(self.size_static[self.cur]) if self.plan.molfp else C.c_void_p(0)
         L.check(lib.eagcn_model_backward_range(self.index.ref(), C.byref(self.cms[self.cur]), size_ptr, _ptr(self.saved[self.cur]),
                                                self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.dout),
@@ -306,6 +355,10 @@ class GraphRunner:
     def _check_old_batches(self, force=False, only=None):
         # a timed-out stream-K hand-off (csrc/gemm3.hip) poisons its tile and raises a sticky host-mapped word: the replay
         # loop makes no C call per step, so it is polled here (a plain host read, no synchronisation)
+        if L.load().eagcn_stream_wait_timeouts():
+            raise L.EagcnHipError('a step waited 2 s for its batch-ready flag (the index stream did not run beside the step: shared '
+                                  'hardware queue?): results of that step are invalid; set EAGCN_READY_FLAG=0 (stream events) and '
+                                  'call eagcn_stream_wait_reset()')
         if L.load().eagcn_gemm_sk_failed():
             raise L.EagcnHipError('a stream-K GEMM hand-off timed out in an earlier step (a contributor wave was not '
                                   'co-resident with its owner): the gradients of that step are NaN-poisoned; '
@@ -350,14 +403,21 @@ class GraphRunner:
             self._check_old_batches(force=True, only=slot)
         # main-stream position now = after the backward of the previous step; the position recorded at the
         # PREVIOUS forward entry = after the backward of the step before it, the last user of this slot
-        entry = torch.cuda.Event()
-        entry.record(main)
-        slot_free = self.entry_events[1]
-        self.entry_events = [self.entry_events[1], entry]
+        if self.use_flag and self.counted:
+            entry = ('count', self.done_issued)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            entry = ('event', ev)
+        slot_free = self.markers[1]
+        self.markers = [self.markers[1], entry]
         if overlap:
             side = _index_stream(self.device)
-            if slot_free is not None:
-                side.wait_event(slot_free)
+            if slot_free is not None and slot_free[0] == 'event':
+                side.wait_event(slot_free[1])
+            elif slot_free is not None:
+                L.check(lib.eagcn_stream_wait_counter(C.c_void_p(self.done_word.data_ptr()), slot_free[1] & 0xFFFFFFFF,
+                                                      C.c_void_p(side.cuda_stream)), 'eagcn_stream_wait_counter')
             # ... and it is held back until the FORWARD of the previous step has finished: from there on the main
             # stream runs the caller's loss and the head's backward -- short kernels on a few CUs -- under which
             # the HBM-streaming index scan costs nothing (at the start of a step it would compete with the
@@ -433,7 +493,10 @@ class GraphRunner:
                 if overlap:
                     main.wait_stream(side)
                 raise L.EagcnHipError(bad)
-        if overlap:
+        if self.use_flag:
+            # (behind everything above, torch's copies included; the step's first launch waits for it on the device)
+            L.check(lib.eagcn_stream_signal_flag(C.c_void_p(self.ready.data_ptr() + 4 * cur), istream), 'eagcn_stream_signal_flag')
+        elif overlap:
             done = torch.cuda.Event()
             done.record(side)
             main.wait_event(done)
@@ -455,16 +518,30 @@ class GraphRunner:
         t = int(self.meta_host[slot][L.META_T])
         self.index.c.t_hint = max(1, min(t, self.index.T)) if t > 0 else 0
 
+    def _reset_ready(self):
+        """A step failed between its batch-ready signal and the launch that consumes it: no flag may stay set."""
+        if self.use_flag:
+            torch.cuda.synchronize(self.device)
+            self.ready.zero_()
+            v = self.done_issued & 0xFFFFFFFF
+            self.done_word.fill_(v - 2 ** 32 if v >= 2 ** 31 else v)  # (an int32 tensor: the count as the device word holds it)
+            torch.cuda.synchronize(self.device)
+
     def forward(self, adj, rels, afm, size, seed, overlap=False, bonds=None):
         main = self._prepare(adj, rels, afm, size, seed, overlap, bonds)
         cur = self.cur
-        if self.graphs[cur][0] is None:
-            self._set_row_hint()
-            self._call_forward()                              # first use of a slot: eager (and the capture warm-up)
-            self._capture()
-        else:
-            self.graphs[cur][0].replay()
-            self.fwd_issued += 1
+        try:
+            if self.graphs[cur][0] is None:
+                self._set_row_hint()
+                self._call_forward()                          # first use of a slot: eager (and the capture warm-up)
+                self._capture()
+            else:
+                self.graphs[cur][0].replay()
+                self.fwd_issued += 1
+        except BaseException:
+            self._reset_ready()
+            raise
+        self.counted = False              # (a forward is in flight behind the last counted backward)
         if overlap:
             self.fwd_done = torch.cuda.Event()
             self.fwd_done.record(main)
@@ -495,6 +572,7 @@ class GraphRunner:
             self._call_backward()
         else:
             self.graphs[self.cur][1].replay()
+            self.done_issued += 1
         self._attach_grads(keep, grads)
 
     def _before_grads(self):
@@ -557,6 +635,8 @@ class GraphRunner:
             comm.start(self.flat_acc).wait()
             return
         size_ptr = _ptr(self.size_static[self.cur]) if self.plan.molfp else C.c_void_p(0)
+        if not torch.cuda.is_current_stream_capturing():
+            self.done_issued += 1
 
         def part(with_head, hi, lo):
             L.check(lib.eagcn_model_backward_range(self.index.ref(), C.byref(self.cms[self.cur]), size_ptr, _ptr(self.saved[self.cur]),
@@ -610,70 +690,76 @@ class GraphRunner:
         def update():
             if optimizer is not None:
                 optimizer.launch(self.flat_acc)
-        first_eager = self.graphs[cur][2] is None or self.step_kind[cur] != key
-        if first_eager:
-            self._set_row_hint()
-            self._call_forward_step(key[0], key[1])           # eager (first use of the slot / of this loss): the warm-up
-            if in_graph:
-                self._call_backward_comm(comm, 0)
-            else:
-                self._call_backward(0)
-                if comm is not None:
-                    # host-issued average of the flat buffer itself (the .grad views are attached only below: after zero_grad they are
-                    # None here and GradientAllReducer.__call__ would find nothing to reduce); the update below needs the average
-                    comm.start(self.flat_acc).wait()
-            update()
-            _drain_collectives(self.device)
-            L.load().eagcn_prof_enable(0)
-            g = torch.cuda.CUDAGraph()
-            captured, failure = True, None
-            try:
-                with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                    self._call_forward_step(key[0], key[1])
-                    if in_graph:
-                        self._call_backward_comm(comm, 0)
-                        update()
-                    else:
-                        self._call_backward(0)
-                        if comm is None:
-                            update()
-            except L.EagcnHipError:
+        try:
+            first_eager = self.graphs[cur][2] is None or self.step_kind[cur] != key
+            if first_eager:
+                self._set_row_hint()
+                self._call_forward_step(key[0], key[1])           # eager (first use of the slot / of this loss): the warm-up
                 if in_graph:
-                    comm.agree(False)                         # (the other ranks are waiting in agree() below: fail with them, not hang them)
-                raise                                         # one of OUR launches failed: never hidden behind a re-capture
-            except Exception as e:                            # noqa: BLE001 -- the capture of the collective failed on this stack
-                if not in_graph:
-                    raise
-                captured, failure = False, e
-                if optimizer is not None:
-                    optimizer.reset_ticket()                  # (an aborted capture must not leave the update's last-workgroup ticket half counted)
-            if in_graph:
-                # every rank must replay the SAME collective sequence: a rank whose capture failed while the others replay
-                # in-graph all-reduces would hang them.  One MIN-reduction of the success flag decides for all ranks.
-                ok = comm.agree(captured)
-                if ok:
-                    self.comm_in_graph = True
-                elif _REQUIRE_IN_GRAPH:
-                    raise L.EagcnHipError('the gradient all-reduce could not be captured into the step graph on every rank '
-                                          '(EAGCN_REQUIRE_IN_GRAPH_ALLREDUCE=1): %r' % (failure,))
-            if in_graph and not self.comm_in_graph:
-                import warnings
-                warnings.warn('eagcn_amd: the gradient all-reduce could not be captured into the step graph (%r); falling back '
-                              'to one host-issued all-reduce behind every replay' % (failure,), RuntimeWarning)
-                # the collective could not be captured: step graph without it, host-issued all-reduce behind every replay
-                _drain_collectives(self.device)
-                self.comm_in_graph, in_graph = False, False
-                key = (kind, scale is not None, False, key[3])
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                    self._call_forward_step(key[0], key[1])
+                    self._call_backward_comm(comm, 0)
+                else:
                     self._call_backward(0)
-                # (the eager step above left the AVERAGED gradients in the flat buffer; the host-issued average below is then
-                #  the identity on values that are equal on every rank)
-            self.graphs[cur][2], self.step_kind[cur] = g, key
-        else:
-            self.graphs[cur][2].replay()
-            self.fwd_issued += 1
+                    if comm is not None:
+                        # host-issued average of the flat buffer itself (the .grad views are attached only below: after zero_grad they are
+                        # None here and GradientAllReducer.__call__ would find nothing to reduce); the update below needs the average
+                        comm.start(self.flat_acc).wait()
+                update()
+                _drain_collectives(self.device)
+                L.load().eagcn_prof_enable(0)
+                g = torch.cuda.CUDAGraph()
+                captured, failure = True, None
+                try:
+                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                        self._call_forward_step(key[0], key[1])
+                        if in_graph:
+                            self._call_backward_comm(comm, 0)
+                            update()
+                        else:
+                            self._call_backward(0)
+                            if comm is None:
+                                update()
+                except L.EagcnHipError:
+                    if in_graph:
+                        comm.agree(False)                         # (the other ranks are waiting in agree() below: fail with them, not hang them)
+                    raise                                         # one of OUR launches failed: never hidden behind a re-capture
+                except Exception as e:                            # noqa: BLE001 -- the capture of the collective failed on this stack
+                    if not in_graph:
+                        raise
+                    captured, failure = False, e
+                    if optimizer is not None:
+                        optimizer.reset_ticket()                  # (an aborted capture must not leave the update's last-workgroup ticket half counted)
+                if in_graph:
+                    # every rank must replay the SAME collective sequence: a rank whose capture failed while the others replay
+                    # in-graph all-reduces would hang them.  One MIN-reduction of the success flag decides for all ranks.
+                    ok = comm.agree(captured)
+                    if ok:
+                        self.comm_in_graph = True
+                    elif _REQUIRE_IN_GRAPH:
+                        raise L.EagcnHipError('the gradient all-reduce could not be captured into the step graph on every rank '
+                                              '(EAGCN_REQUIRE_IN_GRAPH_ALLREDUCE=1): %r' % (failure,))
+                if in_graph and not self.comm_in_graph:
+                    import warnings
+                    warnings.warn('eagcn_amd: the gradient all-reduce could not be captured into the step graph (%r); falling back '
+                                  'to one host-issued all-reduce behind every replay' % (failure,), RuntimeWarning)
+                    # the collective could not be captured: step graph without it, host-issued all-reduce behind every replay
+                    _drain_collectives(self.device)
+                    self.comm_in_graph, in_graph = False, False
+                    key = (kind, scale is not None, False, key[3])
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                        self._call_forward_step(key[0], key[1])
+                        self._call_backward(0)
+                    # (the eager step above left the AVERAGED gradients in the flat buffer; the host-issued average below is then
+                    #  the identity on values that are equal on every rank)
+                self.graphs[cur][2], self.step_kind[cur] = g, key
+            else:
+                self.graphs[cur][2].replay()
+                self.fwd_issued += 1
+                self.done_issued += 1
+            self.counted = True
+        except BaseException:
+            self._reset_ready()
+            raise
         self.fwd_done = None            # (no launch boundary after the forward any more: the next index build only waits
                                         #  for its slot and runs under this step's kernels)
         self._attach_grads(keep, grads)

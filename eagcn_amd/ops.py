@@ -47,7 +47,7 @@ def _index_stream(device):
     host keeps running one step ahead of the GPU."""
     key = device.index
     if key not in _index_streams:
-        _index_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get('EAGCN_SIDE_PRIORITY', '-1')))
+        _index_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get('EAGCN_SIDE_PRIORITY', '0')))
     return _index_streams[key]
 
 

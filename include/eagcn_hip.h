@@ -374,11 +374,30 @@ typedef struct eagcn_model {
                                                stream can wait for a count with eagcn_stream_wait_counter: the caller's batch
                                                preparation for the NEXT step is placed under those kernels instead of beside the
                                                persistent GEMMs (eagcn_amd/graph.py).  NULL: no signal                        */
+    uint32_t* wait_flag;                    /* optional device word: the forward's FIRST launch polls it until it is non-zero and
+                                               clears it -- the batch-ready hand-off from the stream that built the index and packed
+                                               the input (eagcn_stream_signal_flag behind its last kernel) without a
+                                               hipStreamWaitEvent, whose cross-queue dependency costs the waiting stream ~40 us per
+                                               step on ROCm 7.2.  The signal must already be enqueued when the forward is issued
+                                               (on a stream that runs concurrently with this one).  NULL: no wait               */
+    uint32_t* done_signal;                  /* optional device word: the backward adds 1 to it behind its last launch (layer_lo = 0):
+                                               the step no longer reads its batch index / saved block.  The stream that prepares the
+                                               batch after next waits for the count (eagcn_stream_wait_counter) instead of for a
+                                               stream event recorded between two step graphs (recording one that another stream
+                                               waits for costs the recording stream ~27 us per step on ROCm 7.2).  NULL: no signal */
 } eagcn_model;
 
-/* `stream` does not run anything issued behind this call until *counter (device memory, see eagcn_model.fwd_signal) >= value:
- * one parked wavefront that polls the word.  The signalling work must already be enqueued (or be enqueued without waiting for
- * this stream), otherwise the wait never ends. */
+/* *flag = 1 behind everything issued on `stream` so far (release, device scope) */
+int eagcn_stream_signal_flag(uint32_t* flag, void* stream);
+/* one parked wavefront on `stream` that polls *flag until it is non-zero, then clears it (what eagcn_model.wait_flag does in front of a
+ * forward); after budget_seconds without a signal it gives up and raises the sticky word below */
+int eagcn_stream_wait_flag(uint32_t* flag, double budget_seconds, void* stream);
+int eagcn_stream_wait_timeouts(void);   /* non-zero once any flag wait gave up (host-mapped word, no synchronisation) */
+void eagcn_stream_wait_reset(void);
+
+/* `stream` does not run anything issued behind this call until *counter (device memory, see eagcn_model.fwd_signal / done_signal)
+ * >= value: one parked wavefront that polls the word.  The signalling work must already be enqueued (or be enqueued without
+ * waiting for this stream); after 2 s without it the poll gives up and raises the sticky word of eagcn_stream_wait_timeouts. */
 int eagcn_stream_wait_counter(const uint32_t* counter, uint32_t value, void* stream);
 
 size_t eagcn_model_saved_bytes(const eagcn_batch* b, const eagcn_model* m);    /* kept forward -> backward */
