@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libeagcn_hip.so')
-HIP_SOURCES = ['index.hip', 'gemm.hip', 'gemm3.hip', 'gemm_bx3.hip', 'gemm_bx3w.hip', 'agg.hip', 'sagg.hip', 'lagg.hip', 'gat.hip', 'pool.hip', 'layer.hip', 'readout.hip', 'head.hip', 'head2.hip', 'loss.hip']
+HIP_SOURCES = ['index.hip', 'gemm.hip', 'gemm3.hip', 'gemm_bx3.hip', 'gemm_bx3w.hip', 'agg.hip', 'lagg.hip', 'gat.hip', 'pool.hip', 'layer.hip', 'readout.hip', 'head.hip', 'head2.hip', 'loss.hip']
 CPP_SOURCES = ['api.cpp']
 HEADERS = ['common.h', 'kernels.h', 'gemm_x6.h', 'bx3.h', os.path.join('..', '..', 'include', 'eagcn_hip.h')]
 ARCH = 'gfx950'

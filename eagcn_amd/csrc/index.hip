@@ -384,6 +384,26 @@ __global__ __launch_bounds__(256) void index_bonds_kernel(const int32_t* __restr
     }
 }
 
+// the small accumulators of an index build (meta, nat, ecnt; deg_bn when the scan does not visit every row) cleared by ONE launch:
+// three or four hipMemsetAsync calls were seven runtime fill kernels of 5 us each at the head of the side stream's chain
+struct ClearJob { int32_t* p[4]; int n[4]; };
+__global__ __launch_bounds__(256) void index_clear_kernel(ClearJob j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < j.n[r]; i += gridDim.x * 256) j.p[r][i] = 0;
+}
+static int index_clear(int32_t* meta, int32_t* nat, int32_t* ecnt, int B, int32_t* deg_bn, long ndeg, hipStream_t s) {
+    ClearJob j;
+    j.p[0] = meta; j.n[0] = EAGCN_META_WORDS;
+    j.p[1] = nat; j.n[1] = B;
+    j.p[2] = ecnt; j.n[2] = ecnt ? B : 0;
+    j.p[3] = deg_bn; j.n[3] = deg_bn ? (int)ndeg : 0;
+    const long most = std::max<long>(B, j.n[3]);
+    index_clear_kernel<<<(unsigned)std::min<long>(std::max<long>(1, (most + 255) / 256), 1024), 256, 0, s>>>(j);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
 // single workgroup: exclusive prefix sums of nat[] and ceil(nat/16) -> row0, tile0, totals
 __global__ __launch_bounds__(1024) void index_offsets_kernel(const int32_t* __restrict__ nat, int B,
                                                               const int32_t* __restrict__ deg_bn, int BN,
@@ -787,11 +807,12 @@ extern "C" int eagcn_index_build(const float* adj, const float* const* rel, eagc
     const int Nin = b->n_logical > 0 ? b->n_logical : b->N;      // padded size (and row stride) of the caller's tensors
     EAGCN_CHECK_ARG(Nin <= b->N, "eagcn_index_build: n_logical %d exceeds the capacity N=%d", Nin, b->N);
     ProfScope ps(PROF_INDEX, s);
-    EAGCN_HIP(hipMemsetAsync(b->meta, 0, EAGCN_META_WORDS * sizeof(int32_t), s));
-    EAGCN_HIP(hipMemsetAsync(b->nat, 0, (size_t)b->B * sizeof(int32_t), s));
     EAGCN_CHECK_ARG(b->ecnt && b->edge0, "eagcn_index_build: bond-list buffers not allocated");
-    EAGCN_HIP(hipMemsetAsync(b->ecnt, 0, (size_t)b->B * sizeof(int32_t), s));
-    if (Nin < b->N) EAGCN_HIP(hipMemsetAsync(b->deg_bn, 0, (size_t)b->B * b->N * sizeof(int32_t), s));   // rows the scan does not visit
+    EAGCN_CHECK_ARG((long)b->B * b->N < (1L << 31), "eagcn_index_build: B * N = %ld rows", (long)b->B * b->N);
+    {   // (deg_bn: only the rows the scan does not visit)
+        const int rcz = index_clear(b->meta, b->nat, b->ecnt, b->B, Nin < b->N ? b->deg_bn : nullptr, (long)b->B * b->N, s);
+        if (rcz) return rcz;
+    }
     const long rows = (long)b->B * Nin;
     // rows per wavefront: 4 was measured SLOWER (0.18 vs 0.09 ms at B=256, 1.12 vs 0.97 ms at B=4096), and so was
     // a streaming degree pass followed by a per-molecule code pass over the bonded rows (0.39-0.71 vs 0.07 ms at
@@ -846,11 +867,12 @@ extern "C" int eagcn_index_from_bonds(const int32_t* bond_mol, const int32_t* bo
     RelPtrs rp;
     for (int k = 0; k < EAGCN_MAX_VIEWS; ++k) { rp.p[k] = nullptr; rp.c[k] = k < b->K ? b->channels[k] : 0; }
     ProfScope ps(PROF_INDEX, s);
-    EAGCN_HIP(hipMemsetAsync(b->meta, 0, EAGCN_META_WORDS * sizeof(int32_t), s));
-    EAGCN_HIP(hipMemsetAsync(b->nat, 0, (size_t)b->B * sizeof(int32_t), s));
-    EAGCN_HIP(hipMemsetAsync(b->deg_bn, 0, (size_t)b->B * b->N * sizeof(int32_t), s));
     EAGCN_CHECK_ARG(b->ecnt && b->edge0, "eagcn_index_from_bonds: bond-list buffers not allocated");
-    EAGCN_HIP(hipMemsetAsync(b->ecnt, 0, (size_t)b->B * sizeof(int32_t), s));
+    EAGCN_CHECK_ARG((long)b->B * b->N < (1L << 31), "eagcn_index_from_bonds: B * N = %ld rows", (long)b->B * b->N);
+    {
+        const int rcz = index_clear(b->meta, b->nat, b->ecnt, b->B, b->deg_bn, (long)b->B * b->N, s);
+        if (rcz) return rcz;
+    }
     EAGCN_HIP(hipMemsetAsync(b->code, 0, (size_t)b->K * b->B * b->N * b->ldc, s));
     if (E > 0) {
         const int grid = (int)std::min<long>((E + 255) / 256, 4096);
@@ -880,7 +902,21 @@ extern "C" int eagcn_index_rows(const eagcn_batch* b, void* stream) {
     if (!b->build_lists) return EAGCN_OK;   // bond lists: GAT layers (gat.hip), bond-list aggregation (lagg.hip)
     const int rb = b->blk ? lagg_block_rows(b) : 0;                  // > 0: one more workgroup builds the row blocks
     const int W = (b->N + 31) / 32;
-    if (b->N <= 512) index_csr_kernel<true><<<b->B + (rb > 0 ? 1 : 0), 256, (size_t)2 * b->N * W * sizeof(uint32_t), s>>>(*b, W, rb);
+    // the transposed-bitmap form asks for 2 N W words of dynamic LDS on top of ~10 KB static: beyond 64 KB in total (N from ~465) the
+    // launch needs the opt-in, and the device has to have that much (gfx950: 160 KB); otherwise the column scan
+    const size_t dyn = (size_t)2 * b->N * W * sizeof(uint32_t);
+    static const size_t lds_cap = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) v = 64 * 1024;
+        size_t cap = (size_t)v > 12 * 1024 ? (size_t)v - 12 * 1024 : 0;
+        if (cap > 52 * 1024 &&
+            hipFuncSetAttribute((const void*)index_csr_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess) {
+            (void)hipGetLastError();
+            cap = 52 * 1024;
+        }
+        return cap;
+    }();
+    if (b->N <= 512 && dyn <= lds_cap) index_csr_kernel<true><<<b->B + (rb > 0 ? 1 : 0), 256, dyn, s>>>(*b, W, rb);
     else index_csr_kernel<false><<<b->B + (rb > 0 ? 1 : 0), 256, 0, s>>>(*b, W, rb);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;

@@ -25,12 +25,7 @@ struct AggArgs {
 int agg_grid_x(const eagcn_batch* b);
 bool agg_ksplit(const eagcn_batch* b);
 int launch_agg(AggArgs a, bool trans, hipStream_t s);
-// the same operator over the bond lists of the index (sagg.hip): gather + one rank-one term per molecule instead of the dense block
-bool sagg_use(const eagcn_batch* b);          // this batch takes that path (policy + the index carries bond lists)
-int sagg_grid_x(const eagcn_batch* b);        // its workgroups along x = BatchNorm partial slabs, all of them written
-int launch_sagg(AggArgs a, bool trans, hipStream_t s);
-
-// ... and LDS-staged (lagg.hip): a workgroup owns a ROW BLOCK of whole molecules (eagcn_batch.blk) x a 32-column chunk of one view
+// the same operator over the bond lists of the index, LDS-staged (lagg.hip): a workgroup owns a ROW BLOCK of whole molecules (eagcn_batch.blk) x a 32-column chunk of one view
 constexpr int LAGG_RB = 256;                 // packed rows per block (= the largest molecule the path takes)
 constexpr int LAGG_MAXM = 16;                // molecules per block
 struct EdgeArgs;

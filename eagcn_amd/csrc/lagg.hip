@@ -1,14 +1,14 @@
-// Edge-attention aggregation over bond lists with the operand STAGED IN LDS: the operator of agg.hip / sagg.hip (reference
+// Edge-attention aggregation over bond lists with the operand STAGED IN LDS: the operator of agg.hip (reference
 // layers.py:82-92 with the masks of layers.py:294-304), per molecule b and view k
 //     U[i,j]  = sigmoid(w_k[type(i,j)]) adj[i,j] + sigmoid(self_r) m_i [i == j] + 1e-9 (1 - adj[i,j])
 //     A^[i,j] = m_i U[i,j] / sum_j' U[i,j'] ,   Y'[i,:] = sum_j A^[i,j] P_k[j,:]
 // evaluated as what it is -- sigma at the two to four bonds of an atom, sigma(self_r) on the diagonal, the constant 1e-9 elsewhere:
 //     sum_j U[i,j] P[j,:] = sum_{bonds (i,j)} sigma_ij P[j,:] + r m_i P[i,:] + 1e-9 ( S_b - sum_{bonds (i,j)} P[j,:] ),   S_b = sum_{j < nat} P[j,:]
-// a gather of deg + 1 rows plus one rank-one term per molecule (exact, filler included: sagg.hip).
+// a gather of deg + 1 rows plus one rank-one term per molecule (exact, filler included).
 //
 // Why a third form.  The matrix-core kernels (agg.hip) multiply the full nat x nat block: at 256 atoms
 // 99 % of their MFMAs multiply by 1e-9, and over small molecules with wide layers (HIV: 1250 columns per view) they re-read every
-// operand row once per 16-row tile and stream at 1-1.7 TB/s.  The bond-list kernel of round 4 (sagg.hip) did 64x fewer multiply-adds
+// operand row once per 16-row tile and stream at 1-1.7 TB/s.  The bond-list kernel of round 4 (sagg.hip, removed in round 6) did 64x fewer multiply-adds
 // and lost anyway: a wavefront owned a molecule and gathered its neighbour rows from L2, every batch of rows one memory round trip
 // behind the previous one.  Here the round trips are taken ONCE per workgroup, for everything, and the gathers are LDS reads:
 //   * a workgroup owns a ROW BLOCK -- whole molecules, greedily packed to <= 256 packed rows / 16 molecules (eagcn_batch.blk, built
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 }
 
 // ---- policy ------------------------------------------------------------------------------------------------------------------------------
-// EAGCN_AGG = lds (always, N <= 256) | dense | sparse (sagg.hip); default: by shape and DIRECTION.  Measured on MI355X, whole step in ms
+// EAGCN_AGG = lds (always, N <= 256) | dense; default: by shape and DIRECTION.  Measured on MI355X, whole step in ms
 // with this path forced in the backward only / in both directions against the matrix-core kernels of agg.hip (tools/r5_lagg_parts.sh,
 // profiles/r05_lagg_policy.txt; the transposed kernel also absorbs bn_bwd_apply for the Concate layers):
 //     K = 8, N = 256, all molecules 256 atoms, B = 1024 (BASELINE configs[4]):          - / 10.6      against 14.6
@@ -590,7 +590,7 @@ static int lagg_policy() {
     static const int v = [] {
         const char* e = getenv("EAGCN_AGG");
         if (e && !strcmp(e, "lds")) return 1;
-        if (e && (!strcmp(e, "dense") || !strcmp(e, "sparse"))) return 0;
+        if (e && !strcmp(e, "dense")) return 0;
         return 2;                                     // by shape
     }();
     return v;
@@ -679,3 +679,6 @@ int launch_lagg_bwd(AggArgs a, const EdgeArgs& e, hipStream_t s) {
 }
 
 }  // namespace eagcn
+
+extern "C" int eagcn_agg_wants_bond_lists(int B, int N) { return eagcn::lagg_wanted(B, N, -1) ? 1 : 0; }
+extern "C" int eagcn_agg_wants_bond_lists_for(int B, int N, int structure) { return eagcn::lagg_wanted(B, N, structure) ? 1 : 0; }

@@ -1069,10 +1069,6 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
                 rc = launch_lagg_fwd(a, s);
                 nslab = lagg_slabs(b);
                 tiles_per_wg = -1;
-            } else if (sagg_use(b)) {                          // bond-list aggregation (sagg.hip): every slab is written
-                rc = launch_sagg(a, false, s);
-                nslab = sagg_grid_x(b);
-                tiles_per_wg = 0;
             } else {
                 rc = launch_agg(a, false, s);
                 nslab = d.gx;
@@ -1331,12 +1327,6 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         if (lagg_bwd && e.atomic) {                                              // transposed aggregation + edge gradients from the same LDS gathers
             if (fused_bn_apply) { a.bn_tab = w->bn; a.bn_cc = sc.cc; a.bn_fp = d.fp; }
             rc = launch_lagg_bwd(a, e, s);
-            if (rc) return rc;
-        } else if (sagg_use(b)) {                                                // bond-list aggregation (sagg.hip)
-            if (forked) { rc = stream_after(side, s); if (rc) return rc; }
-            rc = launch_edge_grad(e, side);
-            if (rc) return rc;
-            rc = launch_sagg(a, true, s);
             if (rc) return rc;
         } else if (!forked && colaunch) {
             rc = launch_agg_edge(a, e, s);                                       // one grid for both

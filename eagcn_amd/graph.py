@@ -39,7 +39,11 @@ _SIDE_AFTER_FWD = os.environ.get('EAGCN_SIDE_AFTER_FWD', '1') == '1'
 # two runs each): B = 1024 0.936 -> 0.970 ms, HIV 8.10 -> 8.86, C5 15.97 -> 17.38, Lipo 1.434 -> 1.465, B = 256 unchanged -- the
 # index build is 0.14-2.4 ms of side-stream work that needs the WHOLE previous step to hide in; holding it back until that step's
 # forward is over puts its tail on the critical path.  Being slowed down by co-runners is cheaper than not overlapping.
-_SIDE_PLACED = os.environ.get('EAGCN_SIDE_PLACED', '0') == '1'
+# Round 6 (batch hand-off through device flags, the index build's clears in one launch): the placed form wins where the index chain
+# FITS under the head: configs[1] 0.378 -> 0.372 ms (the chain no longer meets the forward plane GEMM, which needs empty CUs), and
+# still loses where it does not (B = 1024: 0.829 -> 0.870).  Default: by the padded rows of the batch (EAGCN_SIDE_PLACED=auto | 0 | 1).
+_SIDE_PLACED = os.environ.get('EAGCN_SIDE_PLACED', 'auto')
+_SIDE_PLACED_MAX_ROWS = int(os.environ.get('EAGCN_SIDE_PLACED_MAX_ROWS', '40000'))
 # a data-parallel step whose gradient all-reduce cannot be captured into the step graph is an ERROR instead of a (warned)
 # fallback to a host-issued collective: bench.py --require-in-graph-allreduce, tools/run_scale.sh
 _REQUIRE_IN_GRAPH = os.environ.get('EAGCN_REQUIRE_IN_GRAPH_ALLREDUCE', '0') == '1'
@@ -132,7 +136,7 @@ class StaticIndex:
         c.row_mol, c.row_loc, c.row_deg, c.row_m, c.tile_mol = ob, ob + 4 * T, ob + 8 * T, ob + 12 * T, ob + 16 * T
         L.set_bond_lists(c, base + 4 * (B * N + 3 * B + 2 + L.META_WORDS), self._ptrs, self._edges, self.E)
         # bond lists + row blocks: built when the library takes a bond-list form of the aggregation for this shape and layer structure
-        # (csrc/lagg.hip, csrc/sagg.hip); the GAT runner sets the flag itself
+        # (csrc/lagg.hip); the GAT runner sets the flag itself
         self.bond_lists = bool(L.load().eagcn_agg_wants_bond_lists_for(B, N, int(structure)))
         c.build_lists = 1 if self.bond_lists else 0
         # general relation vectors (layers.py:82 with arbitrary channel values): a static 255-row code book per view
@@ -174,6 +178,7 @@ class GraphRunner:
         self.meta_event = [None] * _RING
         self.step = 0
         self.cur = 0
+        self.t_hint = None             # packed rows of the first batch (_set_row_hint): the size hint of every captured launch
         self.n_in = N                  # padded size of the current batch's tensors (EAGCN(n_bucket=...): may be < N)
         self.generation = 0
         self.size_static = [torch.ones(B, dtype=torch.int64, device=device) for _ in range(2)]
@@ -184,6 +189,8 @@ class GraphRunner:
         if os.environ.get('EAGCN_AUX_STREAM', '0') == '1':
             self.aux = torch.cuda.Stream(device=self.device)
         self.fwd_sig = torch.zeros(1, dtype=torch.int32, device=device)     # bumped by every executed forward (eagcn_model.fwd_signal)
+        # the next batch's index build held back until this step's forward has passed its read-out (module comment at _SIDE_PLACED)
+        self.side_placed = _SIDE_PLACED == '1' or (_SIDE_PLACED == 'auto' and B * N <= _SIDE_PLACED_MAX_ROWS)
         # per slot: "this slot's batch is prepared" -- set behind the batch's last preparatory kernel, polled and cleared by the
         # step's first launch (eagcn_model.wait_flag)
         self.ready = torch.zeros(2, dtype=torch.int32, device=device)
@@ -277,7 +284,7 @@ class GraphRunner:
         if self.use_flag:
             m.wait_flag = self.ready.data_ptr() + 4 * slot
             m.done_signal = self.done_word.data_ptr()
-        if _SIDE_PLACED:
+        if self.side_placed:
             m.fwd_signal = self.fwd_sig.data_ptr()
         if self.aux is not None:
             m.aux_stream = self.aux.cuda_stream
@@ -424,7 +431,7 @@ class GraphRunner:
             # layer GEMMs and aggregations)
             if self.fwd_done is not None and _SIDE_AFTER_FWD:
                 side.wait_event(self.fwd_done)
-            elif _SIDE_PLACED and self.fwd_issued > 0:
+            elif self.side_placed and self.fwd_issued > 0:
                 # fused steps: until the forward of the step issued last has passed its read-out (it is already enqueued on the
                 # main stream, and the main stream never waits for anything issued behind this point of the side stream)
                 L.check(lib.eagcn_stream_wait_counter(C.c_void_p(self.fwd_sig.data_ptr()), self.fwd_issued & 0xFFFFFFFF,
@@ -507,16 +514,22 @@ class GraphRunner:
         return main
 
     def _set_row_hint(self):
-        """Before a slot's sequences are captured: tell the library how many packed rows THIS batch holds (eagcn_batch.t_hint).
+        """Before a slot's sequences are captured: tell the library how many packed rows batches of this shape hold (eagcn_batch.t_hint).
         The captured launches are fixed for every later batch of the shape; the buffers are sized for row_cap (default B * N, 7x
-        the rows of a Tox21 batch), and the size-dependent kernel choices (the plane GEMM's tile shape) should follow the rows
-        batches of this shape really have.  One host wait, once per slot."""
-        slot = (self.step - 1) % _RING
-        ev = self.meta_event[slot]
-        if ev is not None:
-            ev.synchronize()
-        t = int(self.meta_host[slot][L.META_T])
-        self.index.c.t_hint = max(1, min(t, self.index.T)) if t > 0 else 0
+        the rows of a Tox21 batch), and the size-dependent kernel choices (the plane GEMM's tile shape, the aggregation form, the
+        grid of the bond-list aggregation, the slab layout of the layer scratch) should follow the rows batches of this shape really
+        have.  ONE hint per runner -- the rows of the FIRST batch it sees -- for both slots and every kind of captured graph, fixed from
+        then on: a slot that captured under another batch's count would freeze other kernels than its twin (even and odd steps would
+        differ in timing and rounding).  One host wait, once per runner."""
+        if self.t_hint is None:
+            slot = (self.step - 1) % _RING
+            ev = self.meta_event[slot]
+            if ev is not None:
+                ev.synchronize()
+            t = int(self.meta_host[slot][L.META_T])
+            self.t_hint = max(1, min(t, self.index.T)) if t > 0 else 0
+        for sl in self.slots:
+            sl.c.t_hint = self.t_hint
 
     def _reset_ready(self):
         """A step failed between its batch-ready signal and the launch that consumes it: no flag may stay set."""

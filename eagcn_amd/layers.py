@@ -172,7 +172,7 @@ class GraphConv_Layer(nn.Module):
         if len(rels) != self.K:
             raise EagcnHipError('expected %d relation tensors, got %d' % (self.K, len(rels)))
         if index is None:
-            index = ops.BatchIndex(adjs, rels)
+            index = ops.BatchIndex(adjs, rels, structure={'Concate': 0, 'Weighted_sum': 1}.get(self.structure, -1))
         in_layout = ops.ColLayout.single(self.node_feature_in)
         x = ops.pack_rows(index, in_layout, afms)
         xout, pad_row, out_layout = self.forward_packed(index, x, in_layout)

@@ -419,7 +419,8 @@ class EAGCN(nn.Module):
         if self.graph and (self.training and torch.is_grad_enabled() or not self.training and not torch.is_grad_enabled()):
             return self._graph_forward(adjs, afms, rels, size)       # training step, or eval under no_grad (train.py:130-211)
         self._check_channels([int(r.shape[1]) for r in rels])
-        index = ops.BatchIndex(adjs, rels, overlap=self.overlap_index)   # once per batch, shared by all layers
+        index = ops.BatchIndex(adjs, rels, overlap=self.overlap_index,    # once per batch, shared by all layers
+                               structure={'Concate': 0, 'Weighted_sum': 1}.get(self.structure, -1))
         return self._forward_index(index, afms, size)
 
     def forward_compact(self, bonds, afms, size):
@@ -507,7 +508,7 @@ class EAGCN(nn.Module):
         *rels, size = rels_and_size
         if self.structure in ('GCN', 'GAT'):
             rels = rels[:1]
-        index = ops.BatchIndex(adjs, rels, bond_lists=(self.structure == 'GAT'))
+        index = ops.BatchIndex(adjs, rels, bond_lists=(self.structure == 'GAT'), structure={'Concate': 0, 'Weighted_sum': 1}.get(self.structure, -1))
         return self._forward_composed_index(index, afms, size)
 
     def _forward_composed_index(self, index, afms, size, seeds=None):

@@ -100,13 +100,16 @@ class BatchIndex:
                     bonds=(bond_mol, bond_i, bond_j, bond_code))
         return self
 
-    def __init__(self, adj, rels, overlap=False, row_cap=None, bond_lists=False):
-        """row_cap: size every packed buffer / grid for `row_cap` rows instead of the exact packed row
+    def __init__(self, adj, rels, overlap=False, row_cap=None, bond_lists=False, structure=-1):
+        """structure: EAGCN_STRUCT_* of the layers the index will serve (-1: not known): whether the library takes a bond-list form
+        of the aggregation -- and the index has to carry bond lists and row blocks -- depends on it (eagcn_agg_wants_bond_lists_for).
+        row_cap: size every packed buffer / grid for `row_cap` rows instead of the exact packed row
         count (kernels read the exact count from device memory); used by tests and by graph mode.
         overlap=True: the inputs are already materialised in HBM (prefetched batches), so the index
         kernels may run on a side stream WITHOUT waiting for the main stream's backlog; the host then
         only waits for those two kernels and keeps running one step ahead of the GPU.  Default False:
         the side stream first waits for everything queued on the current stream (always safe)."""
+        self.structure = int(structure)
         lib = L.load()
         adj = _need_cuda_f32(adj, 'adjs')
         rels = [_need_cuda_f32(r, 'relation tensor %d' % i) for i, r in enumerate(rels)]
@@ -217,8 +220,8 @@ class BatchIndex:
         self._ptrs = torch.zeros(L.bond_ptrs_len(T, B), **i32)
         self._edges = torch.empty(6 * self.E + 2, **i32)
         L.set_bond_lists(c, base + 4 * (B * N + 3 * B + 2 + L.META_WORDS), self._ptrs, self._edges, self.E)
-        # bond lists: the GAT layers, and the bond-list form of the aggregation where the library picks it (csrc/sagg.hip)
-        if lib.eagcn_agg_wants_bond_lists(B, N):
+        # bond lists: the GAT layers, and the bond-list form of the aggregation where the library picks it (csrc/lagg.hip)
+        if lib.eagcn_agg_wants_bond_lists_for(B, N, int(getattr(self, 'structure', -1))):
             self.bond_lists = True
         c.build_lists = 1 if getattr(self, 'bond_lists', False) else 0
         L.check(lib.eagcn_index_rows(C.byref(c), C.c_void_p(main.cuda_stream)), 'eagcn_index_rows')

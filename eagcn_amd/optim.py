@@ -116,11 +116,31 @@ class FlatAdam:
             self._launch(a, b - a, self._gather, j == len(ranges) - 1)
 
     def state_dict(self):
+        g = self.param_groups[0]
         return {'exp_avg': self.exp_avg.clone(), 'exp_avg_sq': self.exp_avg_sq.clone(), 'step': int(self.step_count),
-                'hyper': self.hyper.clone()}
+                'hyper': self.hyper.clone(),
+                # the hyper-parameters as the Python floats they were given as (what load_state_dict restores from)
+                'param_group': {'lr': float(g['lr']), 'betas': tuple(float(b) for b in g['betas']), 'eps': float(g['eps']),
+                                'weight_decay': float(g['weight_decay'])}}
 
     def load_state_dict(self, sd):
+        """The hyper-parameters are rebuilt in DOUBLE precision from the saved Python floats; a checkpoint that only holds the device
+        tensor (older rounds) is taken as it is when it is float64 -- a float32 one (round 4) holds fp32 IMAGES of the values
+        (0.99900001287...: exactly the 1.7e-5 error in 1 - beta2 the double hypers exist to avoid), so its entries are rounded
+        back to the shortest decimal that has that image.
+        One step count for the whole buffer: torch.optim.Adam keeps a count per PARAMETER; with the range-by-range update of the
+        autograd mode a parameter whose first gradient arrives in a later step gets the global count's bias correction here."""
         self.exp_avg.copy_(sd['exp_avg'])
         self.exp_avg_sq.copy_(sd['exp_avg_sq'])
         self.step_count.fill_(int(sd['step']))
-        self.hyper.copy_(sd['hyper'].to(self.hyper.dtype))
+        if 'param_group' in sd:
+            g = sd['param_group']
+            vals = [g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay']]
+        else:
+            h = sd['hyper']
+            vals = [float(v) for v in h.double().cpu()]
+            if h.dtype == torch.float32:
+                import numpy as np
+                vals = [float(np.format_float_positional(np.float32(v), unique=True, trim='-')) if np.isfinite(v) else v for v in vals]
+        self.hyper.copy_(torch.tensor(vals, dtype=torch.float64))
+        self.param_groups[0].update(lr=vals[0], betas=(vals[1], vals[2]), eps=vals[3], weight_decay=vals[4])

@@ -124,8 +124,8 @@ typedef struct eagcn_batch {
     int32_t* tnbr;                          /* [E] column lists: atom index i inside the molecule            */
     uint64_t* ecode;                        /* [E] row lists: byte k = bond-type code of view k (1-based)    */
     uint64_t* tcode;                        /* [E] column lists: the same for bond (i,j)                     */
-    int32_t build_lists;                    /* HOST input of eagcn_index_rows: build the bond lists (GAT layers; the
-                                               opt-in sparse aggregation builds them regardless)               */
+    int32_t build_lists;                    /* HOST input of eagcn_index_rows: build the bond lists (GAT layers, the
+                                               LDS-staged bond-list aggregation of csrc/lagg.hip)              */
     int32_t t_hint;                         /* HOST hint: about how many packed rows batches of this shape really hold (0: unknown ->
                                                T).  Only steers size-dependent kernel CHOICES whose launch is baked into a captured
                                                graph (the plane GEMM's tile shape); every kernel is correct for any actual count.   */
@@ -212,7 +212,7 @@ typedef struct eagcn_layer_grads {
 /* 1 when batches of this shape take a bond-list form of the aggregation in either direction (csrc/lagg.hip: a block of up to 256
  * packed rows staged in LDS, each row gathers its bonded rows, one rank-one term per molecule -- instead of the dense nat x nat
  * block on the matrix cores; default for large molecules, for batches of up to 256 molecules and for the backward of Concate
- * layers, padded sizes up to 256 atoms; csrc/sagg.hip: opt-in, EAGCN_AGG=sparse): the index must then carry bond lists and row
+ * layers, padded sizes up to 256 atoms): the index must then carry bond lists and row
  * blocks -- set eagcn_batch.build_lists = 1 (and eagcn_batch.blk) before eagcn_index_rows.  `structure`: EAGCN_STRUCT_* of the
  * layers the index will serve, -1 when not known (the two-argument form). */
 int eagcn_agg_wants_bond_lists(int B, int N);

@@ -196,10 +196,11 @@ def test_model_in_plane_mode_against_fp32_mfma_mode(structure, wide):
         assert d <= 1e-5 * v.abs().max().item() + 2e-6 * scale, (k, d, v.abs().max().item(), scale)
 
 
-def test_bond_list_aggregation_opt_in_matches_the_dense_kernels():
-    """csrc/sagg.hip (EAGCN_AGG=sparse, opt-in): the aggregation as a gather over the bond lists plus ONE rank-one term per molecule
-    -- the same operator as the matrix-core kernels of agg.hip (reference layers.py:82-92), exact including the 1e-9 filler.
-    Run in a subprocess (the policy is read once per process): outputs and every gradient against the default path."""
+def test_bond_list_aggregation_matches_the_dense_kernels():
+    """csrc/lagg.hip forced everywhere (EAGCN_AGG=lds) against the matrix-core kernels forced everywhere (EAGCN_AGG=dense): the
+    aggregation as a gather over the bond lists plus ONE rank-one term per molecule is the same operator as the dense block of
+    agg.hip (reference layers.py:82-92), exact including the 1e-9 filler -- for both layer structures, whatever the default policy
+    picks per direction.  Run in subprocesses (the policy is read once per process): outputs and every gradient."""
     import os
     import subprocess
     import sys
@@ -223,14 +224,14 @@ torch.save({'out': out.detach().cpu(), 'g': {k: p.grad.cpu() for k, p in m.named
     res = {}
     with tempfile.TemporaryDirectory() as d:
         for structure in ('Concate', 'Weighted_sum'):
-            for mode in ('dense', 'sparse'):
+            for mode in ('dense', 'lds'):
                 path = os.path.join(d, '%s_%s.pt' % (structure, mode))
                 env = dict(os.environ, EAGCN_AGG=mode)
                 r = subprocess.run([sys.executable, '-c', code, structure, path], env=env, capture_output=True, text=True, timeout=300)
                 assert r.returncode == 0, r.stderr[-2000:]
                 res[(structure, mode)] = torch.load(path)
     for structure in ('Concate', 'Weighted_sum'):
-        a, b = res[(structure, 'dense')], res[(structure, 'sparse')]
+        a, b = res[(structure, 'dense')], res[(structure, 'lds')]
         assert ((a['out'] - b['out']).abs().max() / a['out'].abs().max()).item() < 1e-5
         scale = max(v.abs().max().item() for v in a['g'].values())
         for k, v in a['g'].items():

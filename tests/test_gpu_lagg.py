@@ -1,6 +1,7 @@
 """The LDS-staged bond-list aggregation (csrc/lagg.hip; reference layers.py:82-92 forward, and its autograd: transposed aggregation
 + the edge gradients of att.weight / self_r): the same operator as the matrix-core kernels of csrc/agg.hip, exact including the 1e-9
-filler.  By default it is taken for large molecules only (padded size >= 240 with >= 96 atoms per molecule); here it is FORCED
+filler.  By default it is the BACKWARD of every Concate layer, the forward for batches of up to 256 molecules and both directions for large molecules
+(padded size >= 240 with >= 96 atoms per molecule; csrc/lagg.hip lagg_use); here it is FORCED everywhere
 (EAGCN_AGG=lds, read once per process: subprocesses) over small / ragged / isolated-atom / self-loop batches, both merges, widths
 that end in a half chunk, eager and graph mode -- against the dense kernels and against the CPU oracle."""
 import os

@@ -109,11 +109,28 @@ def test_layer_golden(name):
     (y * torch.from_numpy(g.z['gout']).cuda()).sum().backward()
     grads = g.group('grad/')
     scale = max(np.abs(v).max() for v in grads.values())
-    assert_grad_close(x_in.grad, grads.pop('x_in'), scale, 'x_in', rtol=2e-5)
+    # every gradient (d input included): 1e-5 of the tensor's own largest entry against the reference's fixture, or as close to the
+    # float64 oracle's gradient as the reference's own fp32 one is (the three-way comparison of the model fixtures)
+    f64 = {}
+
+    def exact(k):
+        if not f64:
+            from helpers import build_oracle_layer
+            twin = build_oracle_layer(m, g.batch.rel_channels).double()
+            twin.load_state_dict({kk: v.double() for kk, v in g.state_dict().items()}, strict=True)
+            twin.train(m['training'])
+            cpu = g.batch.dense()
+            xin = torch.from_numpy(g.z['x_in'].copy()).double().requires_grad_(True)
+            yy, _ = twin(cpu[0].double(), xin, *[r.double() for r in cpu[2:-1]])
+            (yy * torch.from_numpy(g.z['gout']).double()).sum().backward()
+            f64.update({kk: p.grad for kk, p in twin.named_parameters() if p.grad is not None})
+            f64['x_in'] = xin.grad
+        return f64[k]
     params = dict(layer.named_parameters())
+    got = {k: (x_in.grad if k == 'x_in' else params[k].grad) for k in grads}
     for k, ref in grads.items():
-        assert params[k].grad is not None, k
-        assert_grad_close(params[k].grad, ref, scale, k, rtol=2e-5)
+        assert got[k] is not None, k
+        assert_grad_parity(got[k], ref, lambda k=k: exact(k), scale, k, rtol=1e-5, floor=1e-6, slack=1.0, known=KNOWN_FARTHER.get(name))
     sd = layer.state_dict()
     for k, ref in g.group('sd_after/').items():
         assert rel_err(sd[k].double().cpu(), ref) < TOL, k
@@ -903,8 +920,8 @@ def test_model_vs_oracle_baseline_widths(name, graph):
             assert set(gh) == set(p32)
             scale = max(v.abs().max().item() for v in p32.values())
             for k in gh:
-                assert_grad_parity(gh[k], p32[k], lambda k=k: p64[k], scale, '%s %s' % (tag, k), rtol=1e-5, floor=1e-6, slack=2.0,
-                                   note=' [seed %d]' % seed)
+                assert_grad_parity(gh[k], p32[k], lambda k=k: p64[k], scale, '%s %s' % (tag, k), rtol=1e-5, floor=1e-6, slack=1.0,
+                                   note=' [seed %d]' % seed, known=KNOWN_FARTHER.get('baseline_widths:' + name))
         if not flips:
             print('baseline widths [%s, %s]: gradients compared on the instance of seed %d (instances skipped for a pre-activation on '
                   'the relu boundary: %s)' % (name, 'graph' if graph else 'eager', seed, [t for t in tried[:-1]]))
