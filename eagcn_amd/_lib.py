@@ -114,7 +114,7 @@ class Model(C.Structure):
     _fields_ = [('n_layers', C.c_int32), ('molfp_mode', C.c_int32), ('training', C.c_int32),
                 ('head_seed', C.c_uint64), ('head_seed_dev', _fp), ('input_packed', C.c_int32), ('aux_stream', _fp),
                 ('layer', LayerParams * 4), ('head', HeadParams), ('stats_hook', _fp), ('stats_user', _fp),
-                ('stats_world', C.c_int32), ('fuse_readout', C.c_int32), ('fwd_signal', _fp), ('wait_flag', _fp), ('done_signal', _fp)]
+                ('stats_world', C.c_int32), ('fuse_readout', C.c_int32), ('fwd_signal', _fp), ('wait_flag', _fp), ('start_signal', _fp)]
 
 
 class StepLoss(C.Structure):

@@ -77,6 +77,9 @@ __global__ void wait_flag_kernel(uint32_t* __restrict__ flag, int* __restrict__ 
         __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+__global__ void handoff_kernel(HandOff h) {
+    if (threadIdx.x == 0) handoff_body(h);
+}
 static int launch_wait_flag(uint32_t* flag, double budget_s, hipStream_t s) {
     wait_flag_kernel<<<1, 64, 0, s>>>(flag, wait_err_word(), (unsigned long long)(budget_s * 1e8));
     EAGCN_LAUNCH_CHECK();
@@ -374,7 +377,14 @@ static int model_forward_trunk(const eagcn_batch* b, const eagcn_model* m, const
     EAGCN_CHECK_ARG(carve_saved(saved, b, m, &sv) <= saved_bytes, "%s: saved block too small", who);
     EAGCN_CHECK_ARG(carve_scratch(scratch, b, m, &sc) <= scratch_bytes, "%s: scratch too small", who);
     const eagcn_head_params* h = &m->head;
-    if (m->wait_flag) RC(launch_wait_flag(m->wait_flag, 2.0, s));       // the batch's index / packed input are complete
+    // stream hand-offs (eagcn_model.start_signal / wait_flag): in the parameter-packing launch, which reads nothing of the batch --
+    // unless the input is packed HERE, in front of it
+    HandOff ho{m->start_signal, m->wait_flag, wait_err_word(), 200000000ull};
+    if (!m->input_packed && (m->wait_flag || m->start_signal)) {
+        handoff_kernel<<<1, 64, 0, s>>>(ho);
+        EAGCN_LAUNCH_CHECK();
+        ho.start = nullptr; ho.flag = nullptr;
+    }
     ZeroJob zj;                                   // hand-off flags + the head's sums: cleared by the packing launch below
     RC(gemm3_zero_job(sc.layer, sc.layer_bytes, sc.hst, (HEAD_COPIES + 1) * sc.n_hst + HEAD_WS, &zj));
     if (!m->input_packed)
@@ -385,7 +395,7 @@ static int model_forward_trunk(const eagcn_batch* b, const eagcn_model* m, const
         void* pk[4];
         size_t pkb[4];
         for (int l = 0; l < m->n_layers; ++l) { ps[l] = &m->layer[l]; pk[l] = sv.L[l].packed; pkb[l] = sv.L[l].packed_bytes; }
-        RC(pack_params_all(b, ps, pk, pkb, m->n_layers, stream, &zj));
+        RC(pack_params_all(b, ps, pk, pkb, m->n_layers, stream, &zj, &ho));
     }
     for (int l = 0; l < m->n_layers; ++l) {
         LayerSaved& L = sv.L[l];
@@ -618,10 +628,6 @@ extern "C" int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_mode
         if (l == layer_lo) pend_in.eacc = nullptr;
     }
     if (forked) RC(stream_after(s, side));                       // join: every gradient is complete on s
-    if (m->done_signal && layer_lo == 0) {                       // (include/eagcn_hip.h eagcn_model.done_signal)
-        fwd_signal_kernel<<<1, 64, 0, s>>>(m->done_signal);
-        EAGCN_LAUNCH_CHECK();
-    }
     return EAGCN_OK;
 }
 

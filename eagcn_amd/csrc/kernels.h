@@ -153,6 +153,23 @@ int gemm_mode();             // 0 fp32 MFMA | 1 exact bf16 x 6, split by the con
                              // 3 exact bf16 x 3 PLANES written by the producers | 4 ONE bf16 plane (gemm_bx3.hip)
 inline int gemm_planes() { const int m = gemm_mode(); return m == 3 ? 3 : m == 4 ? 1 : 0; }
 struct ZeroJob { unsigned* u; int nu; double* d; int nd; };
+// stream hand-offs that ride in a step's first launch (eagcn_model.start_signal / wait_flag): +1 on `start`, then a poll of `flag`
+// until it is non-zero (cleared afterwards); after `budget` ticks of the 100 MHz clock the poll gives up and raises *err
+struct HandOff { uint32_t* start; uint32_t* flag; int* err; unsigned long long budget; };
+__device__ __forceinline__ void handoff_body(const HandOff& h) {
+    if (h.start) __hip_atomic_fetch_add(h.start, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (h.flag) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(h.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > h.budget) {
+                if (h.err) __hip_atomic_store(h.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        __hip_atomic_store(h.flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 int gemm3_zero_job(void* workspace, size_t bytes, double* zero, int nzero, ZeroJob* out);
 // zero-fill by a kernel (memset NODES of a captured graph are not ordered with their neighbours on replay, ROCm 7.x): for every
 // clear that can sit inside a captured sequence
@@ -233,7 +250,7 @@ int layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const 
 // relu / dropout / mask / view merge of a layer from its saved Y and BatchNorm table (what layer_forward_impl ends with)
 int layer_apply_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, void* stream);
 int pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const* ps, void* const* packed,
-                    const size_t* packed_bytes, int n, void* stream, const ZeroJob* zj = nullptr);
+                    const size_t* packed_bytes, int n, void* stream, const ZeroJob* zj = nullptr, const HandOff* ho = nullptr);
 struct ReadoutBn {
     const float* Y; int ldy;                 // [T][Fp] pre-BatchNorm (bias-free) aggregation output
     const float* bn; int fp;                 // [4][Fp] scale / shift / ...

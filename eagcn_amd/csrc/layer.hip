@@ -146,7 +146,7 @@ struct PackJob {
     BxOut wp, wtp;
 };
 struct PackJobs { PackJob j0, j1, j2, j3; };
-__global__ __launch_bounds__(256) void pack_params_multi_kernel(PackJobs jobs, ZeroJob zj) {
+__global__ __launch_bounds__(256) void pack_params_multi_kernel(PackJobs jobs, ZeroJob zj, HandOff ho) {
     // the call prologue of the model engine rides along: hand-off flags of gemm3.hip and the head's fp64 BatchNorm sums
     if (blockIdx.y == 0) {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < max(zj.nu, zj.nd); i += gridDim.x * blockDim.x) {
@@ -159,6 +159,8 @@ __global__ __launch_bounds__(256) void pack_params_multi_kernel(PackJobs jobs, Z
     else if (blockIdx.y == 1) pack_params_body(jobs.j1.pp, jobs.j1.vc, jobs.j1.in, jobs.j1.ld_in, jobs.j1.fp, jobs.j1.Wcat, jobs.j1.WcatT, jobs.j1.colp, jobs.j1.sig, jobs.j1.rsig, jobs.j1.wp, jobs.j1.wtp);
     else if (blockIdx.y == 2) pack_params_body(jobs.j2.pp, jobs.j2.vc, jobs.j2.in, jobs.j2.ld_in, jobs.j2.fp, jobs.j2.Wcat, jobs.j2.WcatT, jobs.j2.colp, jobs.j2.sig, jobs.j2.rsig, jobs.j2.wp, jobs.j2.wtp);
     else pack_params_body(jobs.j3.pp, jobs.j3.vc, jobs.j3.in, jobs.j3.ld_in, jobs.j3.fp, jobs.j3.Wcat, jobs.j3.WcatT, jobs.j3.colp, jobs.j3.sig, jobs.j3.rsig, jobs.j3.wp, jobs.j3.wtp);
+    // ... and the step's stream hand-offs (kernels.h HandOff): this launch reads parameters only, the batch is needed from the next one on
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) handoff_body(ho);
 }
 
 // sum of per-workgroup partial pairs slab[s][cp][0..1] over s, L (16 or 64) lanes per column: with hundreds of
@@ -962,7 +964,7 @@ extern "C" int eagcn_layer_forward(const eagcn_batch* b, const eagcn_layer_param
 
 // parameters of up to four layers re-laid into their `packed` blocks by ONE launch (model engine)
 int eagcn::pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const* ps, void* const* packed,
-                           const size_t* packed_bytes, int n, void* stream, const ZeroJob* zj) {
+                           const size_t* packed_bytes, int n, void* stream, const ZeroJob* zj, const HandOff* ho) {
     hipStream_t s = (hipStream_t)stream;
     EAGCN_CHECK_ARG(n >= 1 && n <= 4, "pack_params_all: 1..4 layers");
     PackJob jobs[4];
@@ -988,7 +990,8 @@ int eagcn::pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const
     PackJobs pj{jobs[0], jobs[1], jobs[2], jobs[3]};
     ProfScope ps_(PROF_PACK, s);
     const ZeroJob none{nullptr, 0, nullptr, 0};
-    pack_params_multi_kernel<<<dim3(ew_grid(wmax), n), 256, 0, s>>>(pj, zj ? *zj : none);
+    const HandOff noho{nullptr, nullptr, nullptr, 0};
+    pack_params_multi_kernel<<<dim3(ew_grid(wmax), n), 256, 0, s>>>(pj, zj ? *zj : none, ho ? *ho : noho);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

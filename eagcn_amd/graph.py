@@ -169,7 +169,6 @@ class GraphRunner:
         self.index = self.slots[0]
         self.graphs = [[None, None, None], [None, None, None]]   # per slot: [forward, backward, whole step (fused loss)]
         self.step_kind = [None, None]
-        self.entry_events = [None, None]                      # main-stream position at the last two forward entries
         self.fwd_done = None                                  # main-stream position after the last forward graph
         self.dropout = float(dropout)
         self.seeds_dev = [torch.zeros(8, dtype=torch.int64, device=device) for _ in range(2)]
@@ -195,13 +194,13 @@ class GraphRunner:
         # step's first launch (eagcn_model.wait_flag)
         self.ready = torch.zeros(2, dtype=torch.int32, device=device)
         self.use_flag = _ready_flag_ok(device)
-        # ... and the other direction: every backward adds 1 to `done_word` behind its last launch (eagcn_model.done_signal); the
-        # side stream waits for the COUNT of the step that used a slot last instead of for an event recorded on the main stream
-        # between two step graphs.  markers[k]: what "the main stream's work up to the step before (k = 1) / before that (k = 0)
-        # is done" means -- ('count', n) after a fused step, ('event', ev) otherwise
-        self.done_word = torch.zeros(1, dtype=torch.int32, device=device)
-        self.done_issued = 0
-        self.counted = False              # the last step issued was a fused step (its end is the done_issued-th signal)
+        # ... and the other direction: every forward adds 1 to `start_word` in its first launch (eagcn_model.start_signal): when the
+        # n-th forward issued on the main stream has STARTED, everything issued before it -- the steps that used the slots last -- is
+        # done.  The side stream waits for that count instead of for an event recorded on the main stream between two step graphs.
+        # markers[k]: what "the main stream's work up to the step before (k = 1) / before that (k = 0) is done" means:
+        # ('count', n) or, without the flags, ('event', ev)
+        self.start_word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.starts_issued = 0
         self.markers = [None, None]
         self.fwd_issued = 0                                                  # ... and the number of forwards issued so far
         self.cms = [self._cmodel(i) for i in range(2)]
@@ -283,7 +282,7 @@ class GraphRunner:
         m.input_packed = 1
         if self.use_flag:
             m.wait_flag = self.ready.data_ptr() + 4 * slot
-            m.done_signal = self.done_word.data_ptr()
+            m.start_signal = self.start_word.data_ptr()
         if self.side_placed:
             m.fwd_signal = self.fwd_sig.data_ptr()
         if self.aux is not None:
@@ -319,6 +318,7 @@ class GraphRunner:
         lib = L.load()
         if not torch.cuda.is_current_stream_capturing():
             self.fwd_issued += 1                              # (a captured forward counts when its graph is replayed)
+            self.starts_issued += 1
         size_ptr = _ptr(self.size_static[self.cur]) if self.plan.molfp else C.c_void_p(0)
         L.check(lib.eagcn_model_forward(self.index.ref(), C.byref(self.cms[self.cur]), C.c_void_p(0), size_ptr,
                                         _ptr(self.saved[self.cur]), self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.out),
@@ -326,8 +326,6 @@ class GraphRunner:
 
     def _call_backward(self, with_head=1):
         lib = L.load()
-        if not torch.cuda.is_current_stream_capturing():
-            self.done_issued += 1                             # (the backward's last launch bumps done_word: eagcn_model.done_signal)
         size_ptr = _ptr(self.size_static[self.cur]) if self.plan.molfp else C.c_void_p(0)
         L.check(lib.eagcn_model_backward_range(self.index.ref(), C.byref(self.cms[self.cur]), size_ptr, _ptr(self.saved[self.cur]),
                                                self.saved_bytes, _ptr(self.scratch), self.scratch_bytes, _ptr(self.dout),
@@ -410,20 +408,23 @@ class GraphRunner:
             self._check_old_batches(force=True, only=slot)
         # main-stream position now = after the backward of the previous step; the position recorded at the
         # PREVIOUS forward entry = after the backward of the step before it, the last user of this slot
-        if self.use_flag and self.counted:
-            entry = ('count', self.done_issued)
+        if self.use_flag:
+            # the slot's last user is the step before the previous one: it is done once the forward issued LAST (the previous step's)
+            # has started -- the count of forwards issued up to now
+            slot_free = ('count', self.starts_issued) if self.starts_issued >= 2 else None
         else:
+            # main-stream position now = after the backward of the previous step; the position recorded at the PREVIOUS forward
+            # entry = after the backward of the step before it, the last user of this slot
             ev = torch.cuda.Event()
             ev.record(main)
-            entry = ('event', ev)
-        slot_free = self.markers[1]
-        self.markers = [self.markers[1], entry]
+            slot_free = self.markers[1]
+            self.markers = [self.markers[1], ('event', ev)]
         if overlap:
             side = _index_stream(self.device)
             if slot_free is not None and slot_free[0] == 'event':
                 side.wait_event(slot_free[1])
             elif slot_free is not None:
-                L.check(lib.eagcn_stream_wait_counter(C.c_void_p(self.done_word.data_ptr()), slot_free[1] & 0xFFFFFFFF,
+                L.check(lib.eagcn_stream_wait_counter(C.c_void_p(self.start_word.data_ptr()), slot_free[1] & 0xFFFFFFFF,
                                                       C.c_void_p(side.cuda_stream)), 'eagcn_stream_wait_counter')
             # ... and it is held back until the FORWARD of the previous step has finished: from there on the main
             # stream runs the caller's loss and the head's backward -- short kernels on a few CUs -- under which
@@ -536,8 +537,8 @@ class GraphRunner:
         if self.use_flag:
             torch.cuda.synchronize(self.device)
             self.ready.zero_()
-            v = self.done_issued & 0xFFFFFFFF
-            self.done_word.fill_(v - 2 ** 32 if v >= 2 ** 31 else v)  # (an int32 tensor: the count as the device word holds it)
+            v = self.starts_issued & 0xFFFFFFFF
+            self.start_word.fill_(v - 2 ** 32 if v >= 2 ** 31 else v)  # (an int32 tensor: the count as the device word holds it)
             torch.cuda.synchronize(self.device)
 
     def forward(self, adj, rels, afm, size, seed, overlap=False, bonds=None):
@@ -551,10 +552,10 @@ class GraphRunner:
             else:
                 self.graphs[cur][0].replay()
                 self.fwd_issued += 1
+                self.starts_issued += 1
         except BaseException:
             self._reset_ready()
             raise
-        self.counted = False              # (a forward is in flight behind the last counted backward)
         if overlap:
             self.fwd_done = torch.cuda.Event()
             self.fwd_done.record(main)
@@ -585,7 +586,6 @@ class GraphRunner:
             self._call_backward()
         else:
             self.graphs[self.cur][1].replay()
-            self.done_issued += 1
         self._attach_grads(keep, grads)
 
     def _before_grads(self):
@@ -624,6 +624,7 @@ class GraphRunner:
         lib = L.load()
         if not torch.cuda.is_current_stream_capturing():
             self.fwd_issued += 1
+            self.starts_issued += 1
         cur = self.cur
         sl = L.StepLoss()
         sl.kind = 0 if kind == 'bce' else 1
@@ -648,8 +649,6 @@ class GraphRunner:
             comm.start(self.flat_acc).wait()
             return
         size_ptr = _ptr(self.size_static[self.cur]) if self.plan.molfp else C.c_void_p(0)
-        if not torch.cuda.is_current_stream_capturing():
-            self.done_issued += 1
 
         def part(with_head, hi, lo):
             L.check(lib.eagcn_model_backward_range(self.index.ref(), C.byref(self.cms[self.cur]), size_ptr, _ptr(self.saved[self.cur]),
@@ -768,8 +767,7 @@ class GraphRunner:
             else:
                 self.graphs[cur][2].replay()
                 self.fwd_issued += 1
-                self.done_issued += 1
-            self.counted = True
+                self.starts_issued += 1
         except BaseException:
             self._reset_ready()
             raise

@@ -380,11 +380,13 @@ typedef struct eagcn_model {
                                                hipStreamWaitEvent, whose cross-queue dependency costs the waiting stream ~40 us per
                                                step on ROCm 7.2.  The signal must already be enqueued when the forward is issued
                                                (on a stream that runs concurrently with this one).  NULL: no wait               */
-    uint32_t* done_signal;                  /* optional device word: the backward adds 1 to it behind its last launch (layer_lo = 0):
-                                               the step no longer reads its batch index / saved block.  The stream that prepares the
-                                               batch after next waits for the count (eagcn_stream_wait_counter) instead of for a
-                                               stream event recorded between two step graphs (recording one that another stream
-                                               waits for costs the recording stream ~27 us per step on ROCm 7.2).  NULL: no signal */
+    uint32_t* start_signal;                 /* optional device word: the forward's FIRST launch adds 1 to it -- everything issued on the
+                                               stream before this forward (the previous steps: their index / saved blocks are free) has
+                                               completed.  The stream that prepares the batch after next waits for the count
+                                               (eagcn_stream_wait_counter) instead of for a stream event recorded between two step
+                                               graphs (recording one that another stream waits for costs the recording stream ~27 us
+                                               per step on ROCm 7.2).  NULL: no signal.  Both hand-offs ride in the parameter-packing
+                                               launch (no launch of their own) when the input arrives packed (input_packed = 1)       */
 } eagcn_model;
 
 /* *flag = 1 behind everything issued on `stream` so far (release, device scope) */
@@ -395,7 +397,7 @@ int eagcn_stream_wait_flag(uint32_t* flag, double budget_seconds, void* stream);
 int eagcn_stream_wait_timeouts(void);   /* non-zero once any flag wait gave up (host-mapped word, no synchronisation) */
 void eagcn_stream_wait_reset(void);
 
-/* `stream` does not run anything issued behind this call until *counter (device memory, see eagcn_model.fwd_signal / done_signal)
+/* `stream` does not run anything issued behind this call until *counter (device memory, see eagcn_model.fwd_signal / start_signal)
  * >= value: one parked wavefront that polls the word.  The signalling work must already be enqueued (or be enqueued without
  * waiting for this stream); after 2 s without it the poll gives up and raises the sticky word of eagcn_stream_wait_timeouts. */
 int eagcn_stream_wait_counter(const uint32_t* counter, uint32_t value, void* stream);

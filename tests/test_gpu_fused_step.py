@@ -83,6 +83,44 @@ def test_one_launch_head_matches_separate_launches(task, T, B, dropout):
         assert torch.equal(sa[k], sb[k]), k
 
 
+def test_pipelined_steps_equal_synchronous_steps():
+    """Sixteen fused steps issued back to back WITHOUT a synchronisation -- the host runs ahead, the index build of batch k + 1 / k + 2
+    runs on the side stream under step k, slots and ring entries are reused, the batch-ready flag and the start counter
+    (eagcn_model.wait_flag / start_signal) order the two streams -- over four different batches taken round-robin: every step's
+    loss and the last step's gradients equal those of the same steps issued one at a time with a device synchronisation after each
+    (a side stream that started one step early would clear the index of the running step: it showed as a FASTER step, not as a
+    failing test, until this one)."""
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(21)
+    a = EAGCN(28, 24, dropout=0.0, structure='Concate', n_layers=2, widths1=[32] * 5, widths2=[48] * 5, n_den1=64, n_den2=32,
+              nclass=6, graph=True, validate='deferred').to(dev).train()
+    b = copy.deepcopy(a)
+    bw = torch.tensor(bce_weights(6), dtype=torch.float32, device=dev)
+    batches = []
+    for j in range(4):
+        mb = make_batch(B=192, n_max=100, n_med=24, rel_channels=(28, 4, 2, 2, 2), seed=300 + j, n_tasks=6)
+        batches.append((mb.dense(dev), torch.from_numpy(mb.labels).to(dev)))
+    torch.cuda.synchronize()
+    losses_a, losses_b = [], []
+    for step in range(16):                      # (a): one at a time
+        dense, labels = batches[step % 4]
+        for p in a.parameters():
+            p.grad = None
+        losses_a.append(a.fused_step(dense, labels, 'class', bw)[0].clone())
+        torch.cuda.synchronize()
+    for step in range(16):                      # (b): pipelined
+        dense, labels = batches[step % 4]
+        for p in b.parameters():
+            p.grad = None
+        losses_b.append(b.fused_step(dense, labels, 'class', bw)[0].clone())
+    torch.cuda.synchronize()
+    for step, (la, lb) in enumerate(zip(losses_a, losses_b)):
+        assert torch.equal(la, lb), (step, float(la), float(lb))
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad), (n, (p.grad - q.grad).abs().max().item())
+
+
 def test_fused_step_scale_and_accumulation():
     dev = torch.device('cuda', 0)
     torch.manual_seed(6)
