@@ -324,6 +324,7 @@ static HeadPlan head_plan(const eagcn_batch* b, const eagcn_model* m, const Mode
     P.f3 = HeadFwd{B, n2, nc, sv.h2, P.st_2, h->bn2_w, h->bn2_b, h->bn2_rm, h->bn2_rv, sv.bn_2, h->den3_w, out, nullptr, nullptr,
                    m->training, 1, h->bn_eps, h->bn_momentum, nodrop};
     if (P.sync) { P.f1.cnt_in = P.st_g + 2 * F; P.f2.cnt_in = P.st_1 + 2 * n1; P.f3.cnt_in = P.st_2 + 2 * n2; }
+    P.f3.nw = 8;                         // (dense 3 adds in the order of the fused middle launch, whatever the batch size)
     P.f1.st_copies = P.f2.st_copies = P.f3.st_copies = copies;
     P.f1.st_stride = P.f2.st_stride = P.f3.st_stride = sc.n_hst;
     if (!hg) return P;
@@ -342,6 +343,7 @@ static HeadPlan head_plan(const eagcn_batch* b, const eagcn_model* m, const Mode
     P.b1 = HeadBwd{B, F, n1, sv.g, sv.bn_g, 0, nodrop, h->den1_w, sc.da1, sv.h1, sv.bn_1, P.sb_1, nullptr, hg->d_bn1_w, hg->d_bn1_b,
                    sc.dgn, P.sb_g, hg->d_den1_w, m->training};
     if (P.sync) { P.b2.cnt_y = cn_2; P.b2.gscale = gscale; P.b1.cnt_y = cn_1; P.b1.gscale = gscale; }
+    P.b3.nw = 8;
     // large batches: the weight gradients leave as row-chunk partials, summed with the Graph_BN backward
     const int ks = sc.hdw_ks;
     float* part3 = sc.hdw;

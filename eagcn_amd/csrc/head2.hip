@@ -35,24 +35,31 @@ __device__ __forceinline__ uint64_t head_seed(const HeadDrop& d) { return d.seed
 //   QUAD: fb.load(k) = B[k][n0 + 4 li .. + 3], one k, four adjacent columns: component j feeds column tile j (tile j
 //         holds the columns 4c + j; 16 lanes read 256 contiguous bytes of a [K][N] operand);
 //   NT:   fb.load(j, kq) = the four values k = kq .. kq+3 of column 16 j + li (an operand stored [N][K]).
-// The four waves split the k-steps; the partial tiles are summed through LDS and returned to wave 0.
+// The waves of the workgroup split the k-steps; the partial tiles are summed through LDS and returned to wave 0.
 __device__ __forceinline__ void keep(f32x4& v) { asm volatile("" : "+v"(v)); }   // the load feeding v is not sunk / predicated
 
 // The reduction runs over k0 <= k < k1 (k0 a multiple of 16; the functors zero whatever lies beyond the operands' extents).
-template <bool QUAD, int STEPS, class FA, class FB>
-__device__ __forceinline__ void head_tile(int k0, int k1, const FA& fa, const FB& fb, f32x4* red, f32x4 (&acc)[4]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4;
-    const int nsteps = max(0, (k1 - k0 + 15) >> 4);
-    const int per = (((nsteps + 3) >> 2) + STEPS - 1) / STEPS * STEPS;      // k-steps per wave, a multiple of STEPS
-    const int sb = wave * per, se = min(nsteps, sb + per);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int st = sb; st < se; st += STEPS) {
-        typename FA::Raw ra[STEPS];
-        typename FB::Raw rb[STEPS][4];
+// A workgroup is HT_NW = 8 waves (round 6; four before): wave w takes the k-steps [w per, (w + 1) per), per = ceil(steps / 8) -- the
+// 700-wide first product is ONE batch of loads per wave instead of three, the 256-long reductions of the backward one instead
+// of two.  begin() requests a wave's first batch, finish() transforms, multiplies, walks the remaining batches and adds the
+// waves' partial tiles up in wave 0 (a fixed tree): the kernels put their BatchNorm table build BETWEEN the two, so that the
+// table's own loads (the fp64 sums) and the first operand batch are one memory round trip, not two.
+// NW = 4 where a launch has more tiles than the chip has CUs (eight waves of these register counts are one workgroup per CU: dense 1's
+// backward, 352 tiles at configs[1], took two rounds and 19.6 instead of 14.7 us); the stages the fused middle launch shares
+// with the separate launches (dense 3) are always 8 wide, so that both forms add in the same order (HeadFwd.nw / HeadBwd.nw).
+constexpr int HT_NW = 8;
+constexpr int HT_NT = 64 * HT_NW;            // threads per workgroup (the wide form)
+constexpr int HT_RED = HT_NW * 1024;         // floats of the partial-tile buffer (4 tiles x 64 lanes x 4 per wave)
+template <bool QUAD, int STEPS, int NW, class FA, class FB>
+struct HeadTile {
+    typename FA::Raw ra[STEPS];
+    typename FB::Raw rb[STEPS][4];
+    int k0, sb, se;
+    __device__ __forceinline__ void issue(int st, const FA& fa, const FB& fb) {
+        const int q = (threadIdx.x & 63) >> 4;
 #pragma unroll
         for (int u = 0; u < STEPS; ++u) {
-            const int kq = k0 + (st + u) * 16 + 4 * q;
+            const int kq = k0 + (st + u) * 16 + 4 * q;     // (steps beyond the wave's range: clamped addresses, never multiplied)
             ra[u] = fa.load(kq);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -60,33 +67,56 @@ __device__ __forceinline__ void head_tile(int k0, int k1, const FA& fa, const FB
                 else rb[u][t] = fb.load(t, kq);                   // t = column tile j
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void begin(int k0_, int k1, const FA& fa, const FB& fb) {
+        const int wave = threadIdx.x >> 6;
+        const int nsteps = max(0, (k1 - k0_ + 15) >> 4);
+        const int per = (nsteps + NW - 1) / NW;
+        k0 = k0_;
+        sb = wave * per;
+        se = min(nsteps, sb + per);
+        if (sb < se) issue(sb, fa, fb);
+    }
+    __device__ __forceinline__ void finish(const FA& fa, const FB& fb, f32x4* red, f32x4 (&acc)[4]) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4;
 #pragma unroll
-        for (int u = 0; u < STEPS; ++u) {
-            const int kq = k0 + (st + u) * 16 + 4 * q;
-            const f32x4 a = fa.xf(ra[u], kq);
-            f32x4 b[4];
+        for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int st = sb; st < se; st += STEPS) {
+            if (st != sb) issue(st, fa, fb);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if constexpr (QUAD) b[t] = fb.xf(rb[u][t], kq + t);
-                else b[t] = fb.xf(rb[u][t], t, kq);
+            for (int u = 0; u < STEPS; ++u) {
+                if (st + u < se) {                            // (wave-uniform)
+                    const int kq = k0 + (st + u) * 16 + 4 * q;
+                    const f32x4 a = fa.xf(ra[u], kq);
+                    f32x4 b[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if constexpr (QUAD) b[t] = fb.xf(rb[u][t], kq + t);
+                        else b[t] = fb.xf(rb[u][t], t, kq);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], QUAD ? b[s][j] : b[j][s], acc[j], 0, 0, 0);
+                }
             }
+        }
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < 4; ++j) red[(j * NW + wave) * 64 + lane] = acc[j];
+        __syncthreads();
+        if (wave == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], QUAD ? b[s][j] : b[j][s], acc[j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                const f32x4* r = red + (j * NW) * 64 + lane;
+                if constexpr (NW == 8) acc[j] = ((r[0] + r[64]) + (r[128] + r[192])) + ((r[256] + r[320]) + (r[384] + r[448]));
+                else acc[j] = (r[0] + r[64]) + (r[128] + r[192]);
+            }
         }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) red[(j * 4 + wave) * 64 + lane] = acc[j];
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc[j] = (red[(j * 4) * 64 + lane] + red[(j * 4 + 1) * 64 + lane]) + (red[(j * 4 + 2) * 64 + lane] + red[(j * 4 + 3) * 64 + lane]);
-    }
-}
+};
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
 
 // raw load of p[i .. i+3] at a clamped (always valid) index; VEC: i and n multiples of 4, row 16-byte aligned
 template <bool VEC>
@@ -138,7 +168,7 @@ struct HfB {                     // B side (QUAD): W[k][col0 .. col0+3]
 __device__ __forceinline__ void hf_table(const HeadFwd& a, float* tab, bool writer, bool full = false) {
     const int Kp = (a.K + 3) & ~3;
     const double Bn = (a.cnt_in && a.training) ? *a.cnt_in : (double)a.B;      // rows of the BatchNorm (all ranks with sync-BatchNorm)
-    for (int k = threadIdx.x; k < a.K; k += 256) {
+    for (int k = threadIdx.x; k < a.K; k += (int)blockDim.x) {
         float mu, inv;
         if (a.training) {
             double v1[HEAD_COPIES], v2[HEAD_COPIES];                  // all replicas' loads in flight together
@@ -179,8 +209,11 @@ __device__ __forceinline__ void hf_table(const HeadFwd& a, float* tab, bool writ
 }
 
 // one 16 x 64 output tile of a forward stage: the product (all four waves; the sum arrives in wave 0's `acc`) ...
-template <bool VEC, bool DROP>
-__device__ __forceinline__ void hf_tile(const HeadFwd& a, int tile, const float* tab, f32x4* red, f32x4 (&acc)[4]) {
+// (`mid` runs between the request of the first operand batch and its use: the kernels' table build + barrier)
+// (STEPS: k-steps of a wave requested together -- six cover the 700-wide first product in one batch; three where the dropout hash or
+//  scalar loads need the registers)
+template <bool VEC, bool DROP, int STEPS = 3, int NW = HT_NW, class Mid = NoMid>
+__device__ __forceinline__ void hf_tile(const HeadFwd& a, int tile, const float* tab, f32x4* red, f32x4 (&acc)[4], Mid mid = Mid()) {
     const int Kp = (a.K + 3) & ~3;
     const int li = threadIdx.x & 15;
     const int ncb = (a.N + 63) >> 6;
@@ -189,7 +222,10 @@ __device__ __forceinline__ void hf_tile(const HeadFwd& a, int tile, const float*
     const HfA<VEC, DROP> fa{a.x + (size_t)row * a.K, tab, a.K, Kp, row, a.relu ? 0.0f : -INFINITY,
                             DROP ? head_seed(a.drop) : 0, a.drop.thr, a.drop.inv_keep};
     const HfB<VEC> fb{a.W, a.K, a.N, col0};
-    head_tile<true, 4>(0, a.K, fa, fb, red, acc);
+    HeadTile<true, STEPS, NW, HfA<VEC, DROP>, HfB<VEC>> t;
+    t.begin(0, a.K, fa, fb);
+    mid();
+    t.finish(fa, fb, red, acc);
 }
 // ... and its epilogue (wave 0 only): y (+ its copy y2), column sums of y into one replica of st_out
 __device__ __forceinline__ void hf_store(const HeadFwd& a, int tile, const f32x4 (&acc)[4]) {
@@ -229,26 +265,27 @@ __device__ __forceinline__ void hf_store(const HeadFwd& a, int tile, const f32x4
     }
 }
 
-template <bool VEC, bool DROP>
-__global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwd a) {
+template <bool VEC, bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW) void head_fwd_kernel(HeadFwd a) {
     extern __shared__ __attribute__((aligned(16))) float tab[];          // [2][Kp]: scale, shift
     const int Kp = (a.K + 3) & ~3;
     if (a.lab) {                                                         // this workgroup's share of the batch's labelled entries (BCE)
         const int per = (a.nlab + gridDim.x - 1) / gridDim.x;
         const int i = blockIdx.x * per + threadIdx.x;
         int c = 0;
-        for (int j = i; j < min(a.nlab, ((int)blockIdx.x + 1) * per); j += 256) {
+        for (int j = i; j < min(a.nlab, ((int)blockIdx.x + 1) * per); j += 64 * NW) {
             const float v = a.lab[j];
             c += (v == 1.0f || v == 0.0f) ? 1 : 0;
         }
         c = wave_sum(c);
         if ((threadIdx.x & 63) == 0 && c) atomicAdd(a.lab_cnt, (unsigned)c);
     }
-    hf_table(a, tab, blockIdx.x == 0);
-    __syncthreads();
     f32x4* red = reinterpret_cast<f32x4*>(tab + 2 * Kp);
     f32x4 acc[4];
-    hf_tile<VEC, DROP>(a, blockIdx.x, tab, red, acc);                    // one 16 x 64 tile per workgroup
+    hf_tile<VEC, DROP, (VEC && !DROP && NW == 8) ? 6 : 3, NW>(a, blockIdx.x, tab, red, acc, [&]() {      // one 16 x 64 tile per workgroup
+        hf_table(a, tab, blockIdx.x == 0);
+        __syncthreads();
+    });
     if (threadIdx.x < 64) hf_store(a, blockIdx.x, acc);
 }
 
@@ -327,7 +364,7 @@ struct HbB_b {                   // (b) B side (QUAD): dy_eff[b][n0 .. n0+3]
 __device__ __forceinline__ void hb_table(const HeadBwd& a, float* tab, bool writer) {
     const int Np = (a.N + 3) & ~3;
     const double Bn = (a.cnt_y && a.training) ? *a.cnt_y : (double)a.B;
-    for (int n = threadIdx.x; n < a.N; n += 256) {
+    for (int n = threadIdx.x; n < a.N; n += (int)blockDim.x) {
         float al = 1.0f, be = 0.0f, ga = 0.0f;
         if (a.bny) {
             const float sc = a.bny[HT_SC * a.N + n], mu = a.bny[HT_MU * a.N + n], inv = a.bny[HT_INV * a.N + n];
@@ -347,8 +384,8 @@ __device__ __forceinline__ int hb_tiles_b(const HeadBwd& a) { return ((a.K + 15)
 
 // one tile of a backward stage: tile < hb_tiles_a: 16 x 64 of d(input) with its epilogue, else 16 x 64 of dW (chunk-major)
 // bnp / bnp_ld: the [4][bnp_ld] table of the BatchNorm in front of the dense layer (a.bnp with stride K, or a copy in LDS)
-template <bool VEC, bool DROP>
-__device__ __forceinline__ void hb_tile(const HeadBwd& a, int tile, const float* tab, f32x4* red, const float* bnp, int bnp_ld) {
+template <bool VEC, bool DROP, int STEPS = (VEC ? 2 : 1), int NW = HT_NW, class Mid = NoMid>
+__device__ __forceinline__ void hb_tile(const HeadBwd& a, int tile, const float* tab, f32x4* red, const float* bnp, int bnp_ld, Mid mid = Mid()) {
     const int Np = (a.N + 3) & ~3;
     const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
     const int nkb64 = (a.K + 63) >> 6, nnb64 = (a.N + 63) >> 6, nrb = (a.B + 15) >> 4;
@@ -361,7 +398,10 @@ __device__ __forceinline__ void hb_tile(const HeadBwd& a, int tile, const float*
         const int rb = tile / nkb64, kb = tile - rb * nkb64;
         const HbA_a<VEC> fa{dyf, min(rb * 16 + li, a.B - 1)};
         const HbB_a<VEC> fb{a.W, a.K, a.N, kb * 64 + li};
-        head_tile<false, 2>(0, a.N, fa, fb, red, acc);
+        HeadTile<false, STEPS, NW, HbA_a<VEC>, HbB_a<VEC>> t;
+        t.begin(0, a.N, fa, fb);
+        mid();
+        t.finish(fa, fb, red, acc);
         if (threadIdx.x >= 64) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -405,7 +445,10 @@ __device__ __forceinline__ void hb_tile(const HeadBwd& a, int tile, const float*
         const HbA_b<DROP> fa{a.x, a.B, a.K, k, bnp[HT_SC * bnp_ld + k], bnp[HT_SH * bnp_ld + k], a.relu_p ? 0.0f : -INFINITY,
                              seed, a.drop.thr, a.drop.inv_keep};
         const HbB_b<VEC> fb{dyf, n0};
-        head_tile<true, 2>(r0, r1, fa, fb, red, acc);
+        HeadTile<true, STEPS, NW, HbA_b<DROP>, HbB_b<VEC>> ht;
+        ht.begin(r0, r1, fa, fb);
+        mid();
+        ht.finish(fa, fb, red, acc);
         if (threadIdx.x >= 64) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -419,13 +462,15 @@ __device__ __forceinline__ void hb_tile(const HeadBwd& a, int tile, const float*
     }
 }
 
-template <bool VEC, bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void head_bwd_kernel(HeadBwd a) {   // (164 registers, three waves per SIMD: 174 and two without the hint)
+// (two waves per SIMD: with NW = 4 two workgroups per CU, the whole of a 352-tile launch resident at once)
+template <bool VEC, bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) void head_bwd_kernel(HeadBwd a) {
     extern __shared__ __attribute__((aligned(16))) float tab[];          // [3][Np]: al, be, ga of dy_eff
     const int Np = (a.N + 3) & ~3;
-    hb_table(a, tab, blockIdx.x == 0);
-    __syncthreads();
-    hb_tile<VEC, DROP>(a, blockIdx.x, tab, reinterpret_cast<f32x4*>(tab + 3 * Np), a.bnp, a.K);     // one 16 x 64 tile per workgroup
+    hb_tile<VEC, DROP, (VEC ? 2 : 1), NW>(a, blockIdx.x, tab, reinterpret_cast<f32x4*>(tab + 3 * Np), a.bnp, a.K, [&]() {     // one 16 x 64 tile per workgroup
+        hb_table(a, tab, blockIdx.x == 0);
+        __syncthreads();
+    });
 }
 
 // Graph_BN backward (no product in front of it): dg = al * dgn + be * g + ga, d gamma / d beta; workgroup `wg` of `nwg`
@@ -476,13 +521,13 @@ __global__ __launch_bounds__(256) void head_gbn_bwd_kernel(HeadGbn a) { hg_body(
 // divergent passes through expf / log1pf: 9 of the launch's 20 us): labels and class weights are requested with the launch's
 // first batch of loads (head_loss_load), the logits come from the workgroup's LDS copy `ol` [16][N]; d out goes to the global
 // matrix and to `dl` [16][N]; the block's weighted sum is added to *loss_acc by every wave.
-constexpr int LOSS_U = 4;                  // 16 x 64 elements / 256 threads
+constexpr int LOSS_U = 2;                  // 16 x 64 elements / 512 threads
 struct LossRegs { float y[LOSS_U], w1[LOSS_U], w0[LOSS_U]; };
 __device__ __forceinline__ LossRegs head_loss_load(const HeadLoss& L, int Bl, int N, int rb) {
     LossRegs R;
 #pragma unroll
     for (int u = 0; u < LOSS_U; ++u) {
-        const int e = min((int)threadIdx.x + u * 256, Bl * N - 1);
+        const int e = min((int)threadIdx.x + u * HT_NT, Bl * N - 1);
         const int c = e % N;
         R.y[u] = L.labels[(size_t)rb * 16 * N + e];
         R.w1[u] = L.kind == 0 ? L.weight[2 * c] : 0.0f;
@@ -495,7 +540,7 @@ __device__ __forceinline__ void head_loss_block(const HeadLoss& L, const LossReg
     double part = 0.0;
 #pragma unroll
     for (int u = 0; u < LOSS_U; ++u) {
-        const int e = (int)threadIdx.x + u * 256;
+        const int e = (int)threadIdx.x + u * HT_NT;
         if (e < Bl * N) {
             const float xi = ol[e], yi = R.y[u];
             float d;
@@ -523,11 +568,11 @@ __device__ __forceinline__ void head_loss_block(const HeadLoss& L, const LossReg
 // renumbered from 0), d out goes from the loss to dense 3's product through LDS.  Three dependent chains (table, operand batch,
 // epilogue -- each behind a launch) become one: 23 -> 9 us at configs[1].
 template <bool VEC3>
-__global__ __launch_bounds__(256) void head_mid_kernel(HeadMid a) {
+__global__ __launch_bounds__(HT_NT) void head_mid_kernel(HeadMid a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K = a.f3.K, N = a.f3.N, Kp = (K + 3) & ~3, Np = (N + 3) & ~3;
-    f32x4* red = reinterpret_cast<f32x4*>(lds);                         // 16 KB: the four waves' partial tiles
-    float* tabA = lds + 4096;                                           // bn2's table, all four rows (the saved copy is written by
+    f32x4* red = reinterpret_cast<f32x4*>(lds);                         // 32 KB: the waves' partial tiles
+    float* tabA = lds + HT_RED;                                         // bn2's table, all four rows (the saved copy is written by
     float* tabB = tabA + 4 * Kp;                                        //  workgroup 0 in THIS launch); dense 3's (1, 0, 0) table
     float* xs = tabB + 3 * Np;                                          // [16][K]   rows rb*16 .. of h2 (clamped to the batch)
     float* Ws = xs + 16 * Kp;                                           // [K][N]    W3 (K*N rounded up to 4)
@@ -540,12 +585,12 @@ __global__ __launch_bounds__(256) void head_mid_kernel(HeadMid a) {
     // ---- one batch of loads
     const bool vx = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(a.f3.x) & 15) == 0;
     const bool vw = ((K * N) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.f3.W) & 15) == 0;
-    constexpr int XU = 4, WU = 4;                                       // float4 (or scalar) slots per thread and pass
-    for (int p0 = 0; p0 < 16 * Kp / 4; p0 += 256 * XU) {                // h2 rows (K <= 2048: a few passes at most)
+    constexpr int XU = 2, WU = 2;                                       // float4 (or scalar) slots per thread and pass
+    for (int p0 = 0; p0 < 16 * Kp / 4; p0 += HT_NT * XU) {                // h2 rows (K <= 2048: a few passes at most)
         f32x4 v[XU];
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int i = min(p0 + u * 256 + (int)threadIdx.x, 16 * Kp / 4 - 1);
+            const int i = min(p0 + u * HT_NT + (int)threadIdx.x, 16 * Kp / 4 - 1);
             const int r = i / (Kp / 4), c4 = i - r * (Kp / 4);
             const float* src = a.f3.x + (size_t)min(rb * 16 + r, B - 1) * K;
             if (vx) v[u] = *reinterpret_cast<const f32x4*>(src + 4 * c4);
@@ -556,7 +601,7 @@ __global__ __launch_bounds__(256) void head_mid_kernel(HeadMid a) {
         }
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int i = p0 + u * 256 + (int)threadIdx.x;
+            const int i = p0 + u * HT_NT + (int)threadIdx.x;
             if (i < 16 * Kp / 4) {
                 const int r = i / (Kp / 4), c4 = i - r * (Kp / 4);
 #pragma unroll
@@ -566,11 +611,11 @@ __global__ __launch_bounds__(256) void head_mid_kernel(HeadMid a) {
         }
     }
     const int nw4 = (K * N + 3) >> 2;
-    for (int p0 = 0; p0 < nw4; p0 += 256 * WU) {
+    for (int p0 = 0; p0 < nw4; p0 += HT_NT * WU) {
         f32x4 v[WU];
 #pragma unroll
         for (int u = 0; u < WU; ++u) {
-            const int i = min(p0 + u * 256 + (int)threadIdx.x, nw4 - 1);
+            const int i = min(p0 + u * HT_NT + (int)threadIdx.x, nw4 - 1);
             if (vw) v[u] = *reinterpret_cast<const f32x4*>(a.f3.W + 4 * i);
             else {
 #pragma unroll
@@ -579,7 +624,7 @@ __global__ __launch_bounds__(256) void head_mid_kernel(HeadMid a) {
         }
 #pragma unroll
         for (int u = 0; u < WU; ++u) {
-            const int i = p0 + u * 256 + (int)threadIdx.x;
+            const int i = p0 + u * HT_NT + (int)threadIdx.x;
             if (i < nw4) *reinterpret_cast<f32x4*>(Ws + 4 * i) = v[u];
         }
     }
@@ -611,7 +656,7 @@ __global__ __launch_bounds__(256) void head_mid_kernel(HeadMid a) {
     __syncthreads();                                                    // d out of these rows is in LDS
     const int nkb = (K + 63) >> 6;
     for (int kb = 0; kb < nkb; ++kb) {
-        hb_tile<VEC3, false>(g, kb, tabB, red, tabA, Kp);
+        hb_tile<VEC3, false, 1>(g, kb, tabB, red, tabA, Kp);
         __syncthreads();
     }
 }
@@ -619,7 +664,7 @@ __global__ __launch_bounds__(256) void head_mid_kernel(HeadMid a) {
 // dense 2's backward launch with dense 3's weight gradient riding along: tiles of `a` first, then the (b) tiles of `e`
 // (and the loss value published from the row blocks' partial sums: workgroup 0, HeadLossFin)
 template <bool VEC, bool DROP, bool VEC3>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void head_bwd_pair_kernel(HeadBwd a, HeadBwd e, HeadLossFin lf) {
+__global__ __launch_bounds__(HT_NT) void head_bwd_pair_kernel(HeadBwd a, HeadBwd e, HeadLossFin lf) {
     if (lf.loss && blockIdx.x == 0 && threadIdx.x == 0) {
         const double cnt = lf.kind == 0 ? (double)(float)reinterpret_cast<const unsigned*>(lf.ws)[1] : (double)(float)lf.n;
         float l = (float)(lf.ws[1] / cnt);
@@ -631,13 +676,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void h
     const int ta = hb_tiles_a(a) + hb_tiles_b(a);
     f32x4* red = reinterpret_cast<f32x4*>(tab + 3 * Np + 3 * Ne);
     if ((int)blockIdx.x < ta) {
-        hb_table(a, tab, blockIdx.x == 0);
-        __syncthreads();
-        hb_tile<VEC, DROP>(a, blockIdx.x, tab, red, a.bnp, a.K);
+        hb_tile<VEC, DROP>(a, blockIdx.x, tab, red, a.bnp, a.K, [&]() {
+            hb_table(a, tab, blockIdx.x == 0);
+            __syncthreads();
+        });
     } else {
-        hb_table(e, tab + 3 * Np, false);
-        __syncthreads();
-        hb_tile<VEC3, false>(e, hb_tiles_a(e) + ((int)blockIdx.x - ta), tab + 3 * Np, red, e.bnp, e.K);
+        hb_tile<VEC3, false>(e, hb_tiles_a(e) + ((int)blockIdx.x - ta), tab + 3 * Np, red, e.bnp, e.K, [&]() {
+            hb_table(e, tab + 3 * Np, false);
+            __syncthreads();
+        });
     }
 }
 
@@ -679,40 +726,56 @@ int head_colstats(const float* g, int B, int F, double* st, hipStream_t s, doubl
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
+// waves per workgroup of a stage: HeadFwd.nw / HeadBwd.nw if set, else 8 while the launch is one round of one workgroup per CU
+static int head_nw(int want, int tiles) {
+    static const int cus = [] {
+        int d = 0, n = 0;
+        if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    if (want == 4 || want == 8) return want;
+    return tiles <= cus ? 8 : 4;
+}
 int head_fwd(const HeadFwd& a, hipStream_t s) {
     EAGCN_CHECK_ARG(a.st_copies >= 1 && a.st_copies <= HEAD_COPIES, "head: %d replicas of the BatchNorm sums", a.st_copies);
     const int tiles = cdiv(a.B, 16) * cdiv(a.N, 64);
-    const size_t lds = (size_t)2 * ((a.K + 3) & ~3) * sizeof(float) + 16384;
+    const int nw = head_nw(a.nw, tiles);
+    const size_t lds = (size_t)(2 * ((a.K + 3) & ~3) + nw * 1024) * sizeof(float);
     EAGCN_CHECK_ARG(lds <= 64 * 1024, "head: %d input features exceed the table size", a.K);
     ProfScope ps(PROF_HEAD, s, 2.0 * a.B * a.K * a.N);
     const bool vec = (a.K & 3) == 0 && (a.N & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.W)) & 15) == 0;
-    if (vec && a.drop.on) head_fwd_kernel<true, true><<<tiles, 256, lds, s>>>(a);
-    else if (vec) head_fwd_kernel<true, false><<<tiles, 256, lds, s>>>(a);
-    else if (a.drop.on) head_fwd_kernel<false, true><<<tiles, 256, lds, s>>>(a);
-    else head_fwd_kernel<false, false><<<tiles, 256, lds, s>>>(a);
+#define EAGCN_HF(V, D) do { if (nw == 8) head_fwd_kernel<V, D, 8><<<tiles, 512, lds, s>>>(a); else head_fwd_kernel<V, D, 4><<<tiles, 256, lds, s>>>(a); } while (0)
+    if (vec && a.drop.on) EAGCN_HF(true, true);
+    else if (vec) EAGCN_HF(true, false);
+    else if (a.drop.on) EAGCN_HF(false, true);
+    else EAGCN_HF(false, false);
+#undef EAGCN_HF
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
 int head_bwd(const HeadBwd& a, hipStream_t s) {
     EAGCN_CHECK_ARG(a.ks >= 1 && a.ks <= 16 && (a.ks == 1 || a.dW_part), "head: %d row chunks of the weight gradient", a.ks);
     const int tiles = cdiv(a.B, 16) * cdiv(a.K, 64) + cdiv(a.K, 16) * cdiv(a.N, 64) * a.ks;
-    const size_t lds = (size_t)3 * ((a.N + 3) & ~3) * sizeof(float) + 16384;
+    const int nw = head_nw(a.nw, tiles);
+    const size_t lds = (size_t)(3 * ((a.N + 3) & ~3) + nw * 1024) * sizeof(float);
     EAGCN_CHECK_ARG(lds <= 64 * 1024, "head: %d output features exceed the table size", a.N);
     ProfScope ps(PROF_HEAD, s, 4.0 * a.B * a.K * a.N);
     const uintptr_t al = reinterpret_cast<uintptr_t>(a.dy) | reinterpret_cast<uintptr_t>(a.W) | reinterpret_cast<uintptr_t>(a.y) |
                          reinterpret_cast<uintptr_t>(a.extra);
     const bool vec = (a.N & 3) == 0 && (al & 15) == 0;
-    if (vec && a.drop.on) head_bwd_kernel<true, true><<<tiles, 256, lds, s>>>(a);
-    else if (vec) head_bwd_kernel<true, false><<<tiles, 256, lds, s>>>(a);
-    else if (a.drop.on) head_bwd_kernel<false, true><<<tiles, 256, lds, s>>>(a);
-    else head_bwd_kernel<false, false><<<tiles, 256, lds, s>>>(a);
+#define EAGCN_HB(V, D) do { if (nw == 8) head_bwd_kernel<V, D, 8><<<tiles, 512, lds, s>>>(a); else head_bwd_kernel<V, D, 4><<<tiles, 256, lds, s>>>(a); } while (0)
+    if (vec && a.drop.on) EAGCN_HB(true, true);
+    else if (vec) EAGCN_HB(true, false);
+    else if (a.drop.on) EAGCN_HB(false, true);
+    else EAGCN_HB(false, false);
+#undef EAGCN_HB
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
 // the fused middle launch needs a row block of the logits to be one tile
 bool head_mid_ok(int n2, int nclass) {
     static const bool env = [] { const char* v = getenv("EAGCN_HEAD_FUSED"); return !(v && v[0] == '0'); }();
-    const size_t lds = 16384 + (size_t)(20 * ((n2 + 3) & ~3) + 35 * ((nclass + 3) & ~3) + n2 * nclass + 4) * sizeof(float);
+    const size_t lds = (size_t)(HT_RED + 20 * ((n2 + 3) & ~3) + 35 * ((nclass + 3) & ~3) + n2 * nclass + 4) * sizeof(float);
     return env && nclass <= 64 && lds <= 150 * 1024;
 }
 int head_mid(const HeadMid& a, hipStream_t s) {
@@ -721,7 +784,7 @@ int head_mid(const HeadMid& a, hipStream_t s) {
     const uintptr_t al = reinterpret_cast<uintptr_t>(a.f3.x) | reinterpret_cast<uintptr_t>(a.f3.W) | reinterpret_cast<uintptr_t>(a.L.dout);
     const bool vec3 = (n2 & 3) == 0 && (nc & 3) == 0 && (al & 15) == 0;
     const int Kp = (n2 + 3) & ~3, Np = (nc + 3) & ~3;
-    const size_t lds = 16384 + (size_t)(4 * Kp + 3 * Np + 16 * Kp + ((n2 * nc + 3) & ~3) + 32 * Np) * sizeof(float);
+    const size_t lds = (size_t)(HT_RED + 4 * Kp + 3 * Np + 16 * Kp + ((n2 * nc + 3) & ~3) + 32 * Np) * sizeof(float);
     static bool attr = [] {
         bool ok = hipFuncSetAttribute((const void*)head_mid_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess;
         return hipFuncSetAttribute((const void*)head_mid_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess && ok;
@@ -729,8 +792,8 @@ int head_mid(const HeadMid& a, hipStream_t s) {
     (void)attr;
     EAGCN_CHECK_ARG(lds <= 150 * 1024, "head_mid: %d x %d weights exceed LDS", n2, nc);
     ProfScope ps(PROF_HEAD, s, 4.0 * B * n2 * nc);
-    if (vec3) head_mid_kernel<true><<<cdiv(B, 16), 256, lds, s>>>(a);
-    else head_mid_kernel<false><<<cdiv(B, 16), 256, lds, s>>>(a);
+    if (vec3) head_mid_kernel<true><<<cdiv(B, 16), HT_NT, lds, s>>>(a);
+    else head_mid_kernel<false><<<cdiv(B, 16), HT_NT, lds, s>>>(a);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
@@ -739,7 +802,7 @@ int head_bwd_pair(const HeadBwd& a, const HeadBwd& e, const HeadLossFin& lf, hip
     EAGCN_CHECK_ARG(a.ks >= 1 && a.ks <= 16 && (a.ks == 1 || a.dW_part) && e.ks >= 1 && e.ks <= 16 && (e.ks == 1 || e.dW_part),
                     "head: %d / %d row chunks of the weight gradient", a.ks, e.ks);
     const int tiles = cdiv(a.B, 16) * cdiv(a.K, 64) + cdiv(a.K, 16) * cdiv(a.N, 64) * a.ks + cdiv(e.K, 16) * cdiv(e.N, 64) * e.ks;
-    const size_t lds = (size_t)3 * (((a.N + 3) & ~3) + ((e.N + 3) & ~3)) * sizeof(float) + 16384;
+    const size_t lds = (size_t)(3 * (((a.N + 3) & ~3) + ((e.N + 3) & ~3)) + HT_RED) * sizeof(float);
     EAGCN_CHECK_ARG(lds <= 64 * 1024, "head: %d output features exceed the table size", a.N);
     ProfScope ps(PROF_HEAD, s, 4.0 * a.B * a.K * a.N + 2.0 * e.B * e.K * e.N);
     const uintptr_t al = reinterpret_cast<uintptr_t>(a.dy) | reinterpret_cast<uintptr_t>(a.W) | reinterpret_cast<uintptr_t>(a.y) |
@@ -747,7 +810,7 @@ int head_bwd_pair(const HeadBwd& a, const HeadBwd& e, const HeadLossFin& lf, hip
     const bool vec = (a.N & 3) == 0 && (al & 15) == 0;
     const bool vec3 = (e.N & 3) == 0 && (reinterpret_cast<uintptr_t>(e.dy) & 15) == 0;
     const bool drop = a.drop.on != 0;
-#define EAGCN_HBP(V, D, V3) head_bwd_pair_kernel<V, D, V3><<<tiles, 256, lds, s>>>(a, e, lf)
+#define EAGCN_HBP(V, D, V3) head_bwd_pair_kernel<V, D, V3><<<tiles, HT_NT, lds, s>>>(a, e, lf)
     if (vec) { if (drop) { if (vec3) EAGCN_HBP(true, true, true); else EAGCN_HBP(true, true, false); }
                else { if (vec3) EAGCN_HBP(true, false, true); else EAGCN_HBP(true, false, false); } }
     else { if (drop) { if (vec3) EAGCN_HBP(false, true, true); else EAGCN_HBP(false, true, false); }

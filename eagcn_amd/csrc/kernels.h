@@ -196,6 +196,7 @@ struct HeadFwd {                 // y = act(bn(x)) . W  (+ column sums of y)
     // optional job on the way: count the entries of lab[0 .. nlab) that are 0 or 1 (the batch's labelled entries of the BCE loss)
     // into *lab_cnt (zero on entry), every workgroup its share
     const float* lab = nullptr; int nlab = 0; unsigned* lab_cnt = nullptr;
+    int nw = 0;                          // waves per workgroup that split the reduction: 4 / 8, 0 = by the launch's tile count
 };
 struct HeadBwd {                 // backward of  y = act(bn_p(x)) . W : d(bn_p output) with its sums, and dW
     int B, K, N;
@@ -208,6 +209,7 @@ struct HeadBwd {                 // backward of  y = act(bn_p(x)) . W : d(bn_p o
     // chunk c's partial goes to dW_part + c * K * N and head_gbn_bwd adds the partials up in chunk order (a tile's whole
     // reduction in one workgroup is a chain of B / 128 dependent load batches: 8 at B = 1024, the longest pole of the launch)
     int ks = 1; float* dW_part = nullptr;
+    int nw = 0;                          // (as HeadFwd.nw)
 };
 inline int head_dw_chunks(int B) { return B > 256 ? (B + 255) / 256 < 16 ? (B + 255) / 256 : 16 : 1; }
 struct HeadDwSum { float* dst; const float* part; int n, ks; };     // dst[i] = sum_c part[c * n + i]
