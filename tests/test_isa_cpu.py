@@ -30,8 +30,8 @@ def isa(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip('hipcc not found')
     tmp = str(tmp_path_factory.mktemp('isa'))
-    names = ['agg', 'lagg', 'gemm_bx3', 'gemm_bx3w']
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    names = ['agg', 'lagg', 'gemm_bx3', 'gemm_bx3w', 'head2']
+    with ThreadPoolExecutor(max_workers=5) as ex:
         return dict(zip(names, ex.map(lambda n: _isa(tmp, n), names)))
 
 
@@ -89,3 +89,17 @@ def test_plane_gemm_loops_do_not_touch_scratch(isa):
     for name, (scratch, vgpr) in ks.items():
         if 'bx3w_kernelILi3ELi4ELi0E' in name or 'bx3w_kernelILi1ELi4ELi0E' in name:
             assert scratch == 0 and vgpr <= 256, (name, scratch, vgpr)            # two compute waves per SIMD
+
+
+def test_head_kernels_have_no_scratch(isa):
+    """csrc/head2.hip (round 6: eight waves per workgroup, the first operand batch requested before the BatchNorm table is built -- more
+    registers live across the table build): every instantiation of the head's launches, the fused middle launch included, keeps its
+    operand batches in registers (six k-steps of the 700-wide first product are 120 of them); 256 registers = two waves per SIMD."""
+    ks = _kernels(isa['head2'])
+    seen = 0
+    for name, (scratch, vgpr) in ks.items():
+        if not re.search(r'head_(fwd|bwd|mid|bwd_pair|gbn_bwd)_kernel', name):
+            continue
+        seen += 1
+        assert scratch == 0 and vgpr <= 256, '%s: %d bytes of scratch per lane, %d VGPRs' % (name, scratch, vgpr)
+    assert seen >= 20
