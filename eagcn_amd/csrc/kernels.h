@@ -15,12 +15,18 @@ struct AggArgs {
     float* rscale;               // [K][T] m_i/rowsum_i: written by forward, read by transposed
     double* stats;               // forward: [grid.x][Fp][2] partial (sum y, sum y^2)
     int nchunk;
+    int cpw = 1;                 // lagg.hip: consecutive 32-column chunks a workgroup takes per block (nchunk then counts chunk GROUPS)
     int xcd = 0;                 // wave-per-tile variant: tiles handed out so that an XCD works on CONTIGUOUS tiles (agg.hip)
     BxOut planes = {nullptr, 0, 0, 0};   // transposed: dP leaves as bf16 planes INSTEAD of the fp32 matrix (only the plane GEMMs read it)
     // transposed, lagg.hip only: `src` holds dH (the BatchNorm's upstream gradient), not dY': the BatchNorm backward's second pass
     //     dY' = sc (dH - c1 - (Y' - mu) inv c2)      (layer.hip bn_bwd_apply_kernel)
     // is evaluated while the rows are staged (bn = the layer's [4][Fp] table, cc = [2][Fp] {c1, c2}, Y' = EdgeArgs.Y); null: src is dY'
     const float* bn_tab = nullptr; const float* bn_cc = nullptr; int bn_fp = 0;
+    // ... and for a Weighted_sum layer (w_aw != null, round 6) `src` is the layer's UPSTREAM gradient [T][lds], K times narrower than dH:
+    //     dH[r][off_k + f] = src[r][f] ave_w[off_k + f] dropout(r, off_k + f) [relu'(sc Y' + sh) > 0]   (layer.hip bn_bwd_reduce_kernel<true,...>)
+    // is re-formed in the staging as well -- neither dH nor dY' of the layer (T x K F floats each) ever exists in memory
+    const float* w_aw = nullptr;                 // [Fp] the view weight per packed column (colp row CP_AVEW)
+    int w_drop = 0; uint32_t w_thr = 0; float w_inv_keep = 1.0f; uint64_t w_seed = 0; const uint64_t* w_seed_dev = nullptr;
 };
 int agg_grid_x(const eagcn_batch* b);
 bool agg_ksplit(const eagcn_batch* b);
@@ -30,7 +36,8 @@ constexpr int LAGG_RB = 256;                 // packed rows per block (= the lar
 constexpr int LAGG_MAXM = 16;                // molecules per block
 struct EdgeArgs;
 int lagg_parts();
-bool lagg_use(const eagcn_batch* b, int dir, bool absorbs_bn);   // this batch takes that path (policy per direction + the index carries bond lists and row blocks)
+bool lagg_wfuse();                           // Weighted_sum layers: the transposed kernel re-forms dH from the upstream gradient (EAGCN_LAGG_WFUSE=0: off)
+bool lagg_use(const eagcn_batch* b, int dir, bool absorbs_bn, const ViewCols* vc = nullptr);   // this batch takes that path (policy per direction + the index carries bond lists and row blocks)
 bool lagg_wanted(int B, int N, int structure);
 int lagg_block_rows(const eagcn_batch* b);     // rows per row block for batches of this shape (index_blocks_kernel; <= LAGG_RB)
 int lagg_slabs(const eagcn_batch* b);        // capacity of its BatchNorm partial slabs (one per row block; meta[NBLK] of them are live)
@@ -82,6 +89,7 @@ struct ReadoutGrad {
     const int64_t* size; int mode;
     ColMapD map;                 // layout of the layer output (packed column -> exact column)
 };
+int launch_readout_bwd_rows(const eagcn_batch* b, const ReadoutGrad& rg, int ld, float* dx, hipStream_t s);   // readout.hip
 // ---- wave-autonomous balanced GEMM (gemm3.hip): NT (ta=0,tb=1) and TN (ta=1,tb=0) forms --------------------------------
 struct G2Prob {                  // one product C[M,N] = op(A).op(B) in one of the three operand forms of a layer
     const float* A; const float* B; float* C;

@@ -49,6 +49,7 @@ constexpr int LG_G = 256 / LG_LPR;           // row groups per workgroup (32)
 constexpr int LG_U = LAGG_RB / LG_G;         // staging loads per lane (8)
 constexpr int LG_ECAP = 768;                 // list entries of a block staged in LDS (the rest is read from memory)
 constexpr int LG_EPT = LG_ECAP / 256;
+constexpr int LG_PJ_EARLY = 4;             // transposed: P rows of the edge gradients requested in front of barrier B3 (the rest behind it: registers)
 
 __device__ __forceinline__ void lg_fma(float4& acc, float w, const float4& v) {
     acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
@@ -79,8 +80,11 @@ constexpr uint32_t LG_SLOW = 1u << 28;
 constexpr uint32_t LG_OVF = 1u << 29;
 constexpr int LG_NOVF = 32;
 
-template <bool TRANS>
+// MULTI: the workgroup takes several column chunks per block (a.cpw > 1; the single-chunk instantiation is the round-5 kernel)
+// WFUSE (transposed, Weighted_sum layers): a.src is the layer's upstream gradient; dH is formed in the staging (AggArgs.w_aw)
+template <bool TRANS, bool MULTI, bool WFUSE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void lagg_kernel(AggArgs a, EdgeArgs ed) {
+    static_assert(TRANS || !WFUSE, "the upstream-gradient form belongs to the transposed kernel");
     constexpr int NREC = TRANS ? 3 : 2;
     __shared__ float4 buf[LAGG_RB][LG_LPR];          // the block's operand rows x this chunk's columns (32 KB)
     __shared__ float4 s_rec[LAGG_RB][NREC];          // row records (8 / 12 KB)
@@ -93,16 +97,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     __shared__ float4 s_S[LAGG_MAXM][LG_LPR];        // S_b / G_b per molecule
     __shared__ float sig_s[256];
     __shared__ double st_s[TRANS ? 1 : 4][TRANS ? 1 : LG_LPR][8];   // forward: per wave: BatchNorm partial sums of a lane's four columns
-    __shared__ float4 s_bn[TRANS ? 3 : 1][LG_LPR];   // transposed + BatchNorm fusion: three constants per column of this chunk
+    __shared__ float4 s_bn[TRANS ? (WFUSE ? 5 : 3) : 1][LG_LPR];   // transposed + BatchNorm fusion: three (Weighted_sum: five) constants per column of this chunk
     __shared__ double h_s[TRANS ? 264 : 1];          // transposed: bond-type histogram of d w_k, [256] = d self_r
     // transposed: the lists live in the record array until the records are built (LDS: 51 KB = three workgroups per CU either way)
     static_assert(sizeof(LgLists) <= sizeof(float4) * LAGG_RB * 3, "lists alias the transposed record array");
     LgLists& L = *reinterpret_cast<LgLists*>(TRANS ? reinterpret_cast<unsigned char*>(&s_rec[0][0]) : s_lists_raw);
     const eagcn_batch& bt = a.bt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = blockIdx.x / a.nchunk, cc = blockIdx.x - k * a.nchunk;
+    // a workgroup takes a.cpw CONSECUTIVE 32-column chunks of its view for every block it owns (round 6): the block's lists and row
+    // records do not depend on the columns, so they are staged and built ONCE per block and the chunks only repeat the operand
+    // staging, the column sums and the row passes (with one chunk per workgroup a 1250-column view rebuilt the same records forty times)
+    const int k = blockIdx.x / a.nchunk, grp = blockIdx.x - k * a.nchunk;         // (a.nchunk: chunk GROUPS per view)
     const int wk = a.vc.off[k + 1] - a.vc.off[k];                    // padded width of the view (a multiple of 16)
-    if (cc * LG_CW >= wk) return;                                     // (uniform)
+    const int cc_lo = grp * a.cpw;
+    if (cc_lo * LG_CW >= wk) return;                                  // (uniform)
+    const int cc_hi = MULTI ? min(cc_lo + a.cpw, (wk + LG_CW - 1) / LG_CW) : cc_lo + 1;
     // the first block's record is requested together with the block count it is checked against (the index is inside the record
     // array's capacity -- one record per molecule and gridDim.y <= B): one memory round trip at the head of the workgroup, not two
     const int4* blk4 = reinterpret_cast<const int4*>(bt.blk);
@@ -113,10 +122,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     sig_s[tid] = a.sig[k * 256 + tid];                               // (made visible by the first barrier of the block loop)
     const int l = tid & (LG_LPR - 1);
     int g = tid / LG_LPR;                                             // (row group; re-declared opaque per block below)
-    const int col = cc * LG_CW + 4 * l;                               // this lane's first column inside the view
-    const bool col_ok = col < wk;
-    const int c0 = a.vc.off[k] + col;
-    const int c0s = col_ok ? c0 : a.vc.off[k];                        // (a legal column for the lanes beyond the view's width)
+    int col, c0, c0s;                                                 // this lane's first column inside the view / the matrix, per chunk
+    bool col_ok;
+    auto set_chunk = [&](int cc) __attribute__((always_inline)) {
+        col = cc * LG_CW + 4 * l;
+        col_ok = col < wk;
+        c0 = a.vc.off[k] + col;
+        c0s = col_ok ? c0 : a.vc.off[k];                              // (a legal column for the lanes beyond the view's width)
+    };
     const float* rsk = a.rscale + (size_t)k * bt.T;
     const int2* ptrs = reinterpret_cast<const int2*>(TRANS ? bt.col_ptr : bt.row_ptr);
     const int32_t* nbr = TRANS ? bt.tnbr : bt.nbr;
@@ -127,18 +140,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const int4* rinfo = reinterpret_cast<const int4*>(bt.row_info);
     // transposed with the BatchNorm backward's second pass folded in (AggArgs.bn_tab): this lane's five per-column constants
     const bool fuse_bn = TRANS && a.bn_tab != nullptr;
-    if constexpr (TRANS) {
-        if (fuse_bn && tid < LG_CW) {
-            // dY' = sc (dH - c1 - (Y' - mu) inv c2) (bn_bwd_apply_kernel) as A dH + Bc Y' + Cc: three constants per column, kept in LDS
-            // (twenty registers across the block loop otherwise); the regrouping moves the result by an ulp of its largest term
-            const int cl = cc * LG_CW + tid < wk ? a.vc.off[k] + cc * LG_CW + tid : a.vc.off[k];
-            const float sc = a.bn_tab[(size_t)BN_SC * a.bn_fp + cl], mu = a.bn_tab[(size_t)BN_MU * a.bn_fp + cl];
-            const float iv = a.bn_tab[(size_t)BN_INV * a.bn_fp + cl], c1 = a.bn_cc[cl], c2 = a.bn_cc[a.bn_fp + cl];
-            float* sb = reinterpret_cast<float*>(&s_bn[0][0]);
-            sb[tid] = sc;
-            sb[LG_CW + tid] = -sc * iv * c2;
-            sb[2 * LG_CW + tid] = sc * (mu * iv * c2 - c1);
+    // dY' = sc (dH - c1 - (Y' - mu) inv c2) (bn_bwd_apply_kernel) as A dH + Bc Y' + Cc: three constants per column of the chunk, kept in
+    // LDS (twenty registers across the block loop otherwise); the regrouping moves the result by an ulp of its largest term.  With
+    // several chunks per workgroup the NEXT chunk's constants are put there behind a chunk's last barrier (thirty-two lanes, one
+    // round trip to L2 beside the edge loop; holding them in registers from the head of the chunk spilled).
+    auto bn_consts = [&](int cc) __attribute__((always_inline)) {
+        const int cl = cc * LG_CW + tid < wk ? a.vc.off[k] + cc * LG_CW + tid : a.vc.off[k];
+        const float sc = a.bn_tab[(size_t)BN_SC * a.bn_fp + cl], mu = a.bn_tab[(size_t)BN_MU * a.bn_fp + cl];
+        const float iv = a.bn_tab[(size_t)BN_INV * a.bn_fp + cl], c1 = a.bn_cc[cl], c2 = a.bn_cc[a.bn_fp + cl];
+        float* sb = reinterpret_cast<float*>(&s_bn[0][0]);
+        sb[tid] = sc;
+        sb[LG_CW + tid] = -sc * iv * c2;
+        sb[2 * LG_CW + tid] = sc * (mu * iv * c2 - c1);
+        if constexpr (WFUSE) {
+            sb[3 * LG_CW + tid] = a.bn_tab[(size_t)BN_SH * a.bn_fp + cl];
+            sb[4 * LG_CW + tid] = a.w_aw[cl];
         }
+    };
+    const uint64_t wseed = WFUSE && a.w_drop ? (a.w_seed_dev ? *a.w_seed_dev : a.w_seed) : 0ull;
+    if constexpr (TRANS) {
+        if (fuse_bn && tid < LG_CW) bn_consts(cc_lo);
     }
     // A workgroup takes the blocks q, q + gridDim.y, ... (the grid's y extent is an estimate of the block count).  Measured and
     // dropped: a software pipeline over a workgroup's blocks (the next block's rows in flight into registers while this one is worked
@@ -153,11 +174,173 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         if (rows <= 0) {                                              // (uniform) nothing stored: the slab still has to be defined
             if constexpr (!TRANS) {
                 const int fp = a.vc.off[a.vc.K];
-                if (tid < LG_CW && cc * LG_CW + tid < wk)
-                    *reinterpret_cast<double2*>(a.stats + ((size_t)q * fp + a.vc.off[k] + cc * LG_CW + tid) * 2) = make_double2(0.0, 0.0);
+                for (int cc = cc_lo; cc < cc_hi; ++cc)
+                    if (tid < LG_CW && cc * LG_CW + tid < wk)
+                        *reinterpret_cast<double2*>(a.stats + ((size_t)q * fp + a.vc.off[k] + cc * LG_CW + tid) * 2) = make_double2(0.0, 0.0);
             }
             continue;
         }
+        const int nst = min(ne, LG_ECAP);
+        // ---- what does not depend on the columns: row descriptors, list headers, list entries -> LDS -> one RECORD per row.  One chunk
+        //      per workgroup: requested in the same batch as the operand rows and built beside their staging (one chain of round trips).
+        //      Several chunks (MULTI): a phase of its own in front of the chunk loop -- one more round trip per BLOCK, and nothing of it
+        //      is live inside the chunk loop (interleaved with the first chunk it cost the transposed kernel 44 bytes of scratch).
+        int2 pt;
+        float rsv;
+        int4 ri;
+        int e_jn[LG_EPT];
+        uint64_t e_cd[LG_EPT];
+        float4 rec[NREC];
+        int my_mol, my_off;
+        auto hdr_loads = [&]() __attribute__((always_inline)) {
+            const int tr = R0 + min(tid, rows - 1);
+            pt = ptrs[tr];
+            rsv = TRANS ? rsk[tr] : bt.row_m[tr];                     // forward: m_i; transposed: s_j
+            ri = rinfo[tr];                                           // {molecule, atom, nat, first row of the molecule}
+        };
+        auto list_loads = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < LG_EPT; ++u) {
+                const int ec = E0 + min(tid + 256 * u, nst - 1);
+                e_jn[u] = nbr[ec];
+                e_cd[u] = codes[ec];
+            }
+        };
+        auto lists_to_lds = [&]() __attribute__((always_inline)) {
+            my_mol = min(max(ri.x - m0, 0), LAGG_MAXM - 1);           // (of row `tid`, tid < rows)
+            my_off = ri.w - R0;
+            if (tid == 0) s_novf = 0;
+            if (tid < rows) {
+                s_rm[tid] = (unsigned char)my_mol;
+                if constexpr (TRANS) s_rs[tid] = rsv;
+            }
+            if (nst > 0) {
+#pragma unroll
+                for (int u = 0; u < LG_EPT; ++u) {
+                    const int e = tid + 256 * u;
+                    if (e < nst) {
+                        const uint32_t c = (uint32_t)(e_cd[u] >> (8 * k)) & 255u;
+                        L.nb[e] = (unsigned short)e_jn[u];
+                        L.w[e] = sig_s[c];
+                        L.cd[e] = (unsigned char)c;
+                    }
+                }
+            }
+        };
+        // entry `el` of the block's lists: {atom inside its molecule, sigma, code}; from LDS while the lists are there, else from memory
+        auto entry = [&](int el, bool lds_ok, int& jn, float& w, uint32_t& c) __attribute__((always_inline)) {
+            if (lds_ok && el < LG_ECAP) {
+                jn = L.nb[el]; w = L.w[el]; c = L.cd[el];
+            } else {
+                jn = nbr[E0 + el];
+                c = (uint32_t)(codes[E0 + el] >> (8 * k)) & 255u;
+                w = sig_s[c];
+            }
+        };
+        auto build_record = [&]() __attribute__((always_inline)) {
+            // ---- the row RECORDS: thread t builds row t's (header comment of the struct above).  The first version of this kernel read a
+            //      row's state from five LDS arrays and walked its list entries in a dynamic loop with a running rowsum and a second
+            //      accumulator for the filler -- it was bound by instruction ISSUE (SQ_ACTIVE 30 % per wave at three waves per SIMD,
+            //      profiles/r05_lagg_sq.txt).  With the scale and the filler folded into the weights,
+            //          forward      y_i  = sum_e w_e P[src_e] + (sc r m_i) P[i] + (sc 1e-9) S_b
+            //          transposed   dP_j = sum_e w_e Z[src_e] + (r s_j) Z[j] + 1e-9 G_b ,   d w[code_e] += h_e (<Z[src_e], P_j> - rowdot_src)
+            //      the row loop is two or three LDS reads, five gathers and a few dozen FMAs without a branch.
+            const int first = pt.x - E0, cnt = (dbg & 2) ? 0 : pt.y;
+            if (tid < rows) {
+                float we[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, he[TRANS ? 8 : 1] = {0.f};
+                uint32_t srcs = 0u, cds = 0u, srcs2 = 0u, cds2 = 0u, slow = cnt > 8 ? LG_SLOW : 0u;
+                float wsum = 0.0f;
+                if constexpr (TRANS) {
+    #pragma unroll
+                    for (int e = 1; e < 8; ++e) he[e] = 0.0f;
+                }
+                auto take = [&](int e, int jn, float w, uint32_t c, float ss) __attribute__((always_inline)) {
+                    const int src = min(my_off + jn, LAGG_RB - 1);
+                    if constexpr (TRANS) { if (src == tid) slow = LG_SLOW; }      // (a self bond: the diagonal of the edge gradients is this entry)
+                    const float wv = ss * (w - TINY), hv = TRANS ? ss * w * (1.0f - w) : 0.0f;
+    #pragma unroll
+                    for (int q = 0; q < 8; ++q)                           // (constant register indices)
+                        if (q == e) { we[q] = wv; if constexpr (TRANS) he[q] = hv; }
+                    if (e < 4) { srcs |= (uint32_t)src << (8 * e); if constexpr (TRANS) cds |= c << (8 * e); }
+                    else { srcs2 |= (uint32_t)src << (8 * (e - 4)); if constexpr (TRANS) cds2 |= c << (8 * (e - 4)); }
+                };
+                if (first + 8 <= LG_ECAP) {
+                    // the row's first eight list slots in ONE batch of LDS reads (slots beyond its count: any legal slot, not used), the scales
+                    // of their source rows in a second: two LDS round trips per row instead of two per bond
+                    int jn8[8]; float w8[8], ss8[8]; uint32_t c8[8];
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e) { jn8[e] = L.nb[first + e]; w8[e] = L.w[first + e]; c8[e] = L.cd[first + e]; }
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e) ss8[e] = TRANS ? s_rs[min(my_off + jn8[e], LAGG_RB - 1)] : 1.0f;
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e < cnt) { wsum += w8[e]; take(e, jn8[e], w8[e], c8[e], ss8[e]); }
+                    for (int e = 8; e < cnt; ++e) {                       // (a SLOW row: only its row sum is needed here)
+                        int jn; float w; uint32_t c;
+                        entry(first + e, true, jn, w, c);
+                        wsum += w;
+                    }
+                } else {
+                    for (int e = 0; e < cnt; ++e) {
+                        int jn; float w; uint32_t c;
+                        entry(first + e, true, jn, w, c);
+                        wsum += w;
+                        if (e < 8) take(e, jn, w, c, TRANS ? s_rs[min(my_off + jn, LAGG_RB - 1)] : 1.0f);
+                        else if constexpr (TRANS) { if (min(my_off + jn, LAGG_RB - 1) == tid) slow = LG_SLOW; }
+                    }
+                }
+                for (int e = min(cnt, 4); e < 4; ++e) srcs |= (uint32_t)tid << (8 * e);       // (weight 0: any legal row)
+                for (int e = min(max(cnt, 4), 8); e < 8; ++e) srcs2 |= (uint32_t)tid << (8 * (e - 4));
+                int slot = 0;
+                if (cnt > 4 && !slow) {
+                    slot = atomicAdd(&s_novf, 1);
+                    if (slot >= LG_NOVF) slow = LG_SLOW;
+                }
+                const bool ovf = cnt > 4 && !slow;
+                const uint32_t meta = (uint32_t)((ovf ? slot : first) & 0xFFFF) | ((uint32_t)min(cnt, 255) << 16) | ((uint32_t)my_mol << 24) | slow | (ovf ? LG_OVF : 0u);
+                if constexpr (!TRANS) {
+                    const float d = wsum + r * rsv + TINY * (float)(nlog - cnt);           // rowsum: sum sigma + r m_i + 1e-9 (columns without a bond)
+                    const float sc = rsv > 0.0f ? 1.0f / d : 0.0f;
+                    if (cc_lo == 0) a.rscale[(size_t)k * bt.T + R0 + tid] = sc;
+                    rec[0] = make_float4(sc * we[0], sc * we[1], sc * we[2], sc * we[3]);
+                    rec[1] = make_float4(sc * r * rsv, sc, __uint_as_float(srcs), __uint_as_float(meta));
+                    if (ovf) {
+                        s_ovf[slot][0] = make_float4(sc * we[4], sc * we[5], sc * we[6], sc * we[7]);
+                        s_ovf[slot][1] = make_float4(0.f, 0.f, __uint_as_float(srcs2), 0.f);
+                    }
+                } else {
+                    rec[0] = make_float4(we[0], we[1], we[2], we[3]);
+                    rec[1] = make_float4(he[0], he[1], he[2], he[3]);
+                    rec[NREC - 1] = make_float4(rsv, __uint_as_float(srcs), __uint_as_float(cds), __uint_as_float(meta));
+                    if (ovf) {
+                        s_ovf[slot][0] = make_float4(we[4], we[5], we[6], we[7]);
+                        s_ovf[slot][1] = make_float4(he[4], he[5], he[6], he[7]);
+                        s_ovf[slot][NREC - 1] = make_float4(0.f, __uint_as_float(srcs2), __uint_as_float(cds2), 0.f);
+                    }
+                }
+            }
+        };
+        auto write_record = [&]() __attribute__((always_inline)) {
+            if (tid < rows) {
+#pragma unroll
+                for (int i = 0; i < NREC; ++i) s_rec[tid][i] = rec[i];
+            }
+        };
+        if constexpr (MULTI) {
+            hdr_loads();
+            if (nst > 0) list_loads();                                // (uniform)
+            __syncthreads();                                          // R1: the LDS of the previous block is free
+            lists_to_lds();
+            __syncthreads();                                          // R2: lists and scales are in LDS
+            build_record();
+            if constexpr (TRANS) __syncthreads();                     // (the records take the lists' place)
+            write_record();                                           // (made visible by the chunk loop's barriers)
+        }
+        for (int cc = cc_lo; cc < cc_hi; ++cc) {                      // ---- chunks of the group
+        set_chunk(cc);
+        asm volatile("" : "+v"(g));                                   // (row indices / LDS addresses are NOT hoisted out of the chunk loop either)
+        const bool bn_next = MULTI && TRANS && fuse_bn && tid < LG_CW;
+
         // ---- ONE batch of independent loads: operand rows, (transposed) the rows' own Y', row descriptors, list headers, list entries.
         //      Every load is unconditional on a clamped address (a load under a per-lane condition compiles to a branch and, behind it,
         //      a wait per load); what a lane must not use is zeroed afterwards.
@@ -165,42 +348,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
         for (int u = 0; u < LG_U; ++u) {
             const int rc = min(g + LG_G * u, rows - 1);
-            v[u] = *reinterpret_cast<const float4*>(a.src + (size_t)(R0 + rc) * a.lds + c0s);
+            v[u] = *reinterpret_cast<const float4*>(a.src + (size_t)(R0 + rc) * a.lds + (WFUSE ? (col_ok ? col : 0) : c0s));
             if constexpr (TRANS) yv[u] = *reinterpret_cast<const float4*>(ed.Y + (size_t)(R0 + rc) * ed.ld + c0s);
         }
-        const int tr = R0 + min(tid, rows - 1);
-        const int2 pt = ptrs[tr];
-        const float rsv = TRANS ? rsk[tr] : bt.row_m[tr];             // forward: m_i; transposed: s_j
-        const int4 ri = rinfo[tr];                                    // {molecule, atom, nat, first row of the molecule}
-        int e_jn[LG_EPT];
-        uint64_t e_cd[LG_EPT];
-        const int nst = min(ne, LG_ECAP);
-        if (nst > 0) {                                                // (uniform)
+        if constexpr (!MULTI) {
+            hdr_loads();
+            if (nst > 0) list_loads();                                // (uniform)
+        }
+        // Weighted_sum form: the dropout draws of this lane's 8 x 4 elements as ONE mask register, hashed while the loads are in flight
+        uint32_t keep = 0xFFFFFFFFu;
+        if constexpr (WFUSE) {
+            if (a.w_drop) {                                           // (uniform)
+                keep = 0u;
+                const uint32_t t16 = a.w_thr >> 16;
 #pragma unroll
-            for (int u = 0; u < LG_EPT; ++u) {
-                const int ec = E0 + min(tid + 256 * u, nst - 1);
-                e_jn[u] = nbr[ec];
-                e_cd[u] = codes[ec];
+                for (int u = 0; u < LG_U; ++u) {
+                    // (drop_scale4 of element (row, c0s); the row is NOT clamped -- rows beyond the block's are not stored, and eight clamped
+                    //  row indices held for this cost the kernel eight registers and its third workgroup per CU)
+                    const uint64_t z = rng_u64(wseed, ((uint64_t)(R0 + g + LG_G * u) * a.bn_fp + c0s) >> 2);
+                    const uint32_t lo = (uint32_t)z, hi = (uint32_t)(z >> 32);
+                    keep |= ((lo & 0xFFFFu) >= t16 ? 1u : 0u) << (4 * u);
+                    keep |= ((lo >> 16) >= t16 ? 2u : 0u) << (4 * u);
+                    keep |= ((hi & 0xFFFFu) >= t16 ? 4u : 0u) << (4 * u);
+                    keep |= ((hi >> 16) >= t16 ? 8u : 0u) << (4 * u);
+                }
             }
         }
-        __syncthreads();                                              // B1: the LDS of the previous block is free
+        __syncthreads();                                              // B1: the LDS of the previous block / chunk is free
         if (tid < LAGG_MAXM * LG_LPR) {
             float z;
             asm volatile("v_mov_b32 %0, 0" : "=v"(z));                // (made here: hoisted out of the block loop the zero vector is spilled)
             (&s_S[0][0])[tid] = make_float4(z, z, z, z);
         }
-        if (tid == 0) s_novf = 0;
 #pragma unroll
         for (int u = 0; u < LG_U; ++u) {
             const int rr = g + LG_G * u;                              // (consecutive groups = consecutive rows: no LDS bank conflicts)
             const bool mine = rr < rows;
             if constexpr (TRANS) {
                 if (fuse_bn) {                                        // dY' from dH and Y'
-                    const float4 bA = s_bn[0][l], bB = s_bn[1][l], bC = s_bn[2][l];
-                    v[u].x = fmaf(bA.x, v[u].x, fmaf(bB.x, yv[u].x, bC.x));
-                    v[u].y = fmaf(bA.y, v[u].y, fmaf(bB.y, yv[u].y, bC.y));
-                    v[u].z = fmaf(bA.z, v[u].z, fmaf(bB.z, yv[u].z, bC.z));
-                    v[u].w = fmaf(bA.w, v[u].w, fmaf(bB.w, yv[u].w, bC.w));
+                    if constexpr (WFUSE) {
+                        // dH of this view from the upstream gradient, exactly as the reduction pass formed it (layer.hip bn_bwd_reduce_kernel):
+                        // dH = relu'(sc Y' + sh) keep (up ave_w) / (1 - p).  Three steps, each with its own constants read from LDS and an
+                        // order fixed by empty asm statements -- with all five constant vectors of a row in flight at once (twenty
+                        // registers) the kernel lost its third workgroup per CU; one select per element and no branch (`h > 0 ? x : 0`
+                        // per component put the LDS reads under exec-mask branches)
+                        int lq = l;
+                        asm volatile("" : "+v"(lq));
+                        uint32_t mb;
+                        {
+                            const float4 bA = s_bn[0][lq], sh = s_bn[3][lq];
+                            const uint32_t kb = keep >> (4 * u);
+                            mb = ((yv[u].x * bA.x + sh.x > 0.0f) ? (kb & 1u) : 0u) | ((yv[u].y * bA.y + sh.y > 0.0f) ? (kb & 2u) : 0u) |
+                                 ((yv[u].z * bA.z + sh.z > 0.0f) ? (kb & 4u) : 0u) | ((yv[u].w * bA.w + sh.w > 0.0f) ? (kb & 8u) : 0u);
+                        }
+                        asm volatile("" : "+v"(mb), "+v"(lq));
+                        {
+                            const float4 aw = s_bn[4][lq];
+                            const float ik = a.w_drop ? a.w_inv_keep : 1.0f;
+                            v[u].x = (v[u].x * aw.x) * ((mb & 1u) ? ik : 0.0f);
+                            v[u].y = (v[u].y * aw.y) * ((mb & 2u) ? ik : 0.0f);
+                            v[u].z = (v[u].z * aw.z) * ((mb & 4u) ? ik : 0.0f);
+                            v[u].w = (v[u].w * aw.w) * ((mb & 8u) ? ik : 0.0f);
+                        }
+                        asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w), "+v"(lq));
+                        const float4 bA = s_bn[0][lq], bB = s_bn[1][lq], bC = s_bn[2][lq];
+                        v[u].x = fmaf(bA.x, v[u].x, fmaf(bB.x, yv[u].x, bC.x));
+                        v[u].y = fmaf(bA.y, v[u].y, fmaf(bB.y, yv[u].y, bC.y));
+                        v[u].z = fmaf(bA.z, v[u].z, fmaf(bB.z, yv[u].z, bC.z));
+                        v[u].w = fmaf(bA.w, v[u].w, fmaf(bB.w, yv[u].w, bC.w));
+                    } else {
+                        const float4 bA = s_bn[0][l], bB = s_bn[1][l], bC = s_bn[2][l];
+                        v[u].x = fmaf(bA.x, v[u].x, fmaf(bB.x, yv[u].x, bC.x));
+                        v[u].y = fmaf(bA.y, v[u].y, fmaf(bB.y, yv[u].y, bC.y));
+                        v[u].z = fmaf(bA.z, v[u].z, fmaf(bB.z, yv[u].z, bC.z));
+                        v[u].w = fmaf(bA.w, v[u].w, fmaf(bB.w, yv[u].w, bC.w));
+                    }
                 }
             }
             if (!col_ok) { v[u] = make_float4(0.f, 0.f, 0.f, 0.f); if constexpr (TRANS) yv[u] = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -210,23 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 if (mine && l == 0) s_rd[rr] = d;
             }
         }
-        const int my_mol = min(max(ri.x - m0, 0), LAGG_MAXM - 1), my_off = ri.w - R0;      // (of row `tid`, tid < rows)
-        if (tid < rows) {
-            s_rm[tid] = (unsigned char)my_mol;
-            if constexpr (TRANS) s_rs[tid] = rsv;
-        }
-        if (nst > 0) {
-#pragma unroll
-            for (int u = 0; u < LG_EPT; ++u) {
-                const int e = tid + 256 * u;
-                if (e < nst) {
-                    const uint32_t c = (uint32_t)(e_cd[u] >> (8 * k)) & 255u;
-                    L.nb[e] = (unsigned short)e_jn[u];
-                    L.w[e] = sig_s[c];
-                    L.cd[e] = (unsigned char)c;
-                }
-            }
-        }
+        if constexpr (!MULTI) lists_to_lds();
         __syncthreads();                                              // B2: rows, lists, scales are in LDS
         // ---- S_b (forward) / G_b = sum_i s_i dY'_i (transposed) per molecule: group g sums the contiguous rows [g per, (g + 1) per) -- all
         //      of them read from LDS in ONE batch, then added up in registers (row by row behind the data-dependent molecule test the
@@ -261,102 +467,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
             flush();
         }
-        // entry `el` of the block's lists: {atom inside its molecule, sigma, code}; from LDS while the lists are there, else from memory
-        auto entry = [&](int el, bool lds_ok, int& jn, float& w, uint32_t& c) __attribute__((always_inline)) {
-            if (lds_ok && el < LG_ECAP) {
-                jn = L.nb[el]; w = L.w[el]; c = L.cd[el];
-            } else {
-                jn = nbr[E0 + el];
-                c = (uint32_t)(codes[E0 + el] >> (8 * k)) & 255u;
-                w = sig_s[c];
-            }
-        };
-        // ---- the row RECORDS: thread t builds row t's (header comment of the struct above).  The first version of this kernel read a
-        //      row's state from five LDS arrays and walked its list entries in a dynamic loop with a running rowsum and a second
-        //      accumulator for the filler -- it was bound by instruction ISSUE (SQ_ACTIVE 30 % per wave at three waves per SIMD,
-        //      profiles/r05_lagg_sq.txt).  With the scale and the filler folded into the weights,
-        //          forward      y_i  = sum_e w_e P[src_e] + (sc r m_i) P[i] + (sc 1e-9) S_b
-        //          transposed   dP_j = sum_e w_e Z[src_e] + (r s_j) Z[j] + 1e-9 G_b ,   d w[code_e] += h_e (<Z[src_e], P_j> - rowdot_src)
-        //      the row loop is two or three LDS reads, five gathers and a few dozen FMAs without a branch.
-        const int first = pt.x - E0, cnt = (dbg & 2) ? 0 : pt.y;
-        float4 rec[NREC];
-        if (tid < rows) {
-            float we[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, he[TRANS ? 8 : 1] = {0.f};
-            uint32_t srcs = 0u, cds = 0u, srcs2 = 0u, cds2 = 0u, slow = cnt > 8 ? LG_SLOW : 0u;
-            float wsum = 0.0f;
-            if constexpr (TRANS) {
-#pragma unroll
-                for (int e = 1; e < 8; ++e) he[e] = 0.0f;
-            }
-            auto take = [&](int e, int jn, float w, uint32_t c, float ss) __attribute__((always_inline)) {
-                const int src = min(my_off + jn, LAGG_RB - 1);
-                if constexpr (TRANS) { if (src == tid) slow = LG_SLOW; }      // (a self bond: the diagonal of the edge gradients is this entry)
-                const float wv = ss * (w - TINY), hv = TRANS ? ss * w * (1.0f - w) : 0.0f;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)                           // (constant register indices)
-                    if (q == e) { we[q] = wv; if constexpr (TRANS) he[q] = hv; }
-                if (e < 4) { srcs |= (uint32_t)src << (8 * e); if constexpr (TRANS) cds |= c << (8 * e); }
-                else { srcs2 |= (uint32_t)src << (8 * (e - 4)); if constexpr (TRANS) cds2 |= c << (8 * (e - 4)); }
-            };
-            if (first + 8 <= LG_ECAP) {
-                // the row's first eight list slots in ONE batch of LDS reads (slots beyond its count: any legal slot, not used), the scales
-                // of their source rows in a second: two LDS round trips per row instead of two per bond
-                int jn8[8]; float w8[8], ss8[8]; uint32_t c8[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { jn8[e] = L.nb[first + e]; w8[e] = L.w[first + e]; c8[e] = L.cd[first + e]; }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ss8[e] = TRANS ? s_rs[min(my_off + jn8[e], LAGG_RB - 1)] : 1.0f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (e < cnt) { wsum += w8[e]; take(e, jn8[e], w8[e], c8[e], ss8[e]); }
-                for (int e = 8; e < cnt; ++e) {                       // (a SLOW row: only its row sum is needed here)
-                    int jn; float w; uint32_t c;
-                    entry(first + e, true, jn, w, c);
-                    wsum += w;
-                }
-            } else {
-                for (int e = 0; e < cnt; ++e) {
-                    int jn; float w; uint32_t c;
-                    entry(first + e, true, jn, w, c);
-                    wsum += w;
-                    if (e < 8) take(e, jn, w, c, TRANS ? s_rs[min(my_off + jn, LAGG_RB - 1)] : 1.0f);
-                    else if constexpr (TRANS) { if (min(my_off + jn, LAGG_RB - 1) == tid) slow = LG_SLOW; }
-                }
-            }
-            for (int e = min(cnt, 4); e < 4; ++e) srcs |= (uint32_t)tid << (8 * e);       // (weight 0: any legal row)
-            for (int e = min(max(cnt, 4), 8); e < 8; ++e) srcs2 |= (uint32_t)tid << (8 * (e - 4));
-            int slot = 0;
-            if (cnt > 4 && !slow) {
-                slot = atomicAdd(&s_novf, 1);
-                if (slot >= LG_NOVF) slow = LG_SLOW;
-            }
-            const bool ovf = cnt > 4 && !slow;
-            const uint32_t meta = (uint32_t)((ovf ? slot : first) & 0xFFFF) | ((uint32_t)min(cnt, 255) << 16) | ((uint32_t)my_mol << 24) | slow | (ovf ? LG_OVF : 0u);
-            if constexpr (!TRANS) {
-                const float d = wsum + r * rsv + TINY * (float)(nlog - cnt);           // rowsum: sum sigma + r m_i + 1e-9 (columns without a bond)
-                const float sc = rsv > 0.0f ? 1.0f / d : 0.0f;
-                if (cc == 0) a.rscale[(size_t)k * bt.T + R0 + tid] = sc;
-                rec[0] = make_float4(sc * we[0], sc * we[1], sc * we[2], sc * we[3]);
-                rec[1] = make_float4(sc * r * rsv, sc, __uint_as_float(srcs), __uint_as_float(meta));
-                if (ovf) {
-                    s_ovf[slot][0] = make_float4(sc * we[4], sc * we[5], sc * we[6], sc * we[7]);
-                    s_ovf[slot][1] = make_float4(0.f, 0.f, __uint_as_float(srcs2), 0.f);
-                }
-            } else {
-                rec[0] = make_float4(we[0], we[1], we[2], we[3]);
-                rec[1] = make_float4(he[0], he[1], he[2], he[3]);
-                rec[NREC - 1] = make_float4(rsv, __uint_as_float(srcs), __uint_as_float(cds), __uint_as_float(meta));
-                if (ovf) {
-                    s_ovf[slot][0] = make_float4(we[4], we[5], we[6], we[7]);
-                    s_ovf[slot][1] = make_float4(he[4], he[5], he[6], he[7]);
-                    s_ovf[slot][NREC - 1] = make_float4(0.f, __uint_as_float(srcs2), __uint_as_float(cds2), 0.f);
-                }
-            }
-        }
-        if constexpr (TRANS) __syncthreads();                         // B2b: every thread is done with the lists: the records take their place
-        if (tid < rows) {
-#pragma unroll
-            for (int i = 0; i < NREC; ++i) s_rec[tid][i] = rec[i];
+        if constexpr (!MULTI) {
+            build_record();
+            if constexpr (TRANS) __syncthreads();                     // B2b: every thread is done with the lists: the records take their place
+            write_record();
         }
         // transposed: row j's own P row for the edge gradients: all eight of a group requested HERE, in front of the barrier, and used by
         // a loop of their own below that issues no store (with loads and stores in one loop the compiler cannot count the memory
@@ -369,15 +483,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         float4 pjv[TRANS ? LG_U : 1];
         if constexpr (TRANS) {                                        // (the first half here, the second at the head of the edge loop:
 #pragma unroll                                                        //  all eight in front of the barrier are five registers too many)
-            for (int u = 0; u < LG_U / 2; ++u) pjv[u] = pj_load(u);
+            for (int u = 0; u < LG_PJ_EARLY; ++u) pjv[u] = pj_load(u);
         }
         __syncthreads();                                              // B3: records and S_b / G_b are complete
+        if constexpr (TRANS) { if (bn_next) bn_consts(cc + 1 < cc_hi ? cc + 1 : cc_lo); }     // (the staging of THIS chunk has read s_bn)
         if constexpr (TRANS) {
             // ---- edge gradients of the rows with a record (this chunk's columns): d w[code_e] += h_e (<Z[src_e], P_j> - rowdot_src), the
             //      diagonal into d self_r.  Lane e (< 4) of the row's eight adds bond e's term, lane 4 the diagonal's.
             const int nu = (rows + LG_G - 1) / LG_G;
 #pragma unroll
-            for (int u = LG_U / 2; u < LG_U; ++u) pjv[u] = pj_load(u);
+            for (int u = LG_PJ_EARLY; u < LG_U; ++u) pjv[u] = pj_load(u);
 #pragma unroll
             for (int u = 0; u < LG_U; ++u) {
                 if (u >= nu) break;                                   // (uniform; rows beyond the block's / of the second pass: nothing added)
@@ -561,6 +676,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 *reinterpret_cast<double2*>(a.stats + ((size_t)q * fp + a.vc.off[k] + cc * LG_CW + tid) * 2) = make_double2(t1, t2);
             }
         }
+        }                                                             // (chunks)
     }                                                                 // (blocks)
     if constexpr (TRANS) {
         if (dr_acc != 0.0) atomicAdd(&h_s[256], dr_acc);
@@ -586,6 +702,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 //    known, eagcn_batch.t_hint -- 96 atoms per molecule on average), or batches of up to 256 molecules (where agg.hip runs its
 //    one-workgroup-per-tile form); backward: large molecules, or any layer whose BatchNorm backward leaves its second pass to this kernel
 //    (Concate).  Weighted_sum layers of small molecules stay on the matrix cores.
+static int lagg_cpw(const eagcn_batch& bt, const ViewCols& vc, bool trans);
 static int lagg_policy() {
     static const int v = [] {
         const char* e = getenv("EAGCN_AGG");
@@ -603,19 +720,23 @@ static int lagg_fwd_maxb() {
     static const int v = [] { const char* e = getenv("EAGCN_LAGG_FWD_MAXB"); return e ? atoi(e) : 256; }();
     return v;
 }
+bool lagg_wfuse() {
+    static const bool on = [] { const char* v = getenv("EAGCN_LAGG_WFUSE"); return !(v && v[0] == '0'); }();
+    return on;
+}
 // should the index of batches of this shape carry bond lists and row blocks?  structure: EAGCN_STRUCT_* of the layers, or -1 (not known)
 bool lagg_wanted(int B, int N, int structure) {
     const int p = lagg_policy();
     if (p == 0 || N > LAGG_RB) return false;
     if (p == 1) return true;
-    return N >= lagg_min_n() || B <= lagg_fwd_maxb() || structure != EAGCN_STRUCT_WEIGHTED;
+    return N >= lagg_min_n() || B <= lagg_fwd_maxb() || structure != EAGCN_STRUCT_WEIGHTED || lagg_wfuse();
 }
 int lagg_parts() {                                    // (debug switch) bit 0: forward, bit 1: backward on this path
     static const int v = [] { const char* e = getenv("EAGCN_LAGG_PARTS"); return e ? atoi(e) : 3; }();
     return v;
 }
 // does this batch take the path?  dir 0: forward, 1: backward; absorbs_bn: the layer's BatchNorm backward would leave its second pass here
-bool lagg_use(const eagcn_batch* b, int dir, bool absorbs_bn) {
+bool lagg_use(const eagcn_batch* b, int dir, bool absorbs_bn, const ViewCols* vc) {
     if (!(b->build_lists && b->blk && b->mol_info && b->row_ptr && b->col_ptr && b->nbr && b->tnbr && b->ecode && b->tcode && b->row_info))
         return false;
     const int p = lagg_policy();
@@ -623,7 +744,9 @@ bool lagg_use(const eagcn_batch* b, int dir, bool absorbs_bn) {
     if (p == 1) return true;
     const bool large = b->N >= lagg_min_n() && !(b->t_hint > 0 && (long)b->t_hint < 96L * b->B);
     if (large) return true;
-    return dir ? absorbs_bn : b->B <= lagg_fwd_maxb();
+    // forward of small molecules: batches of up to 256 molecules, or (round 6) launches of so many workgroups that each takes several
+    // chunks of a block and builds its records once (HIV widths: agg_wave 0.79 -> 0.70 ms)
+    return dir ? absorbs_bn : (b->B <= lagg_fwd_maxb() || (vc && lagg_cpw(*b, *vc, false) > 1));
 }
 // Rows per block: always LAGG_RB.  Measured (EAGCN_LAGG_RB = 256 / 128 / 64 / 32, whole step in ms): Tox21 B = 256 0.423 / 0.431 / 0.458 /
 // 0.541, B = 1024 0.889 / 0.906 / 0.991 / 1.172, Lipo B = 512 1.348 / 1.375 / 1.518 / 1.641 -- more, smaller blocks (more workgroups per CU
@@ -636,30 +759,50 @@ int lagg_block_rows(const eagcn_batch* b) {
 }
 int lagg_slabs(const eagcn_batch* b) { return std::max(1, b->B); }
 
-static int lagg_grid(const AggArgs& a, dim3* grid, int* nchunk) {
+// chunks of the widest view / an ESTIMATE of the block count from the rows batches of this shape hold (a block closes at LAGG_RB rows or
+// LAGG_MAXM molecules: 1.25 x the larger of the two quotients; the kernel loops, so any count is handled, and a tight grid spares the
+// launch thousands of workgroups that would only find out that they have no block)
+static void lagg_extent(const eagcn_batch& bt, const ViewCols& vc, int* chunks, int* gy) {
     int wmax = 0;
-    for (int k = 0; k < a.vc.K; ++k) wmax = std::max(wmax, a.vc.off[k + 1] - a.vc.off[k]);
-    *nchunk = cdiv(wmax, LG_CW);
-    // y: an ESTIMATE of the block count from the rows batches of this shape hold (a block closes at LAGG_RB rows or LAGG_MAXM molecules:
-    // 1.25 x the larger of the two quotients); the kernel loops, so any count is handled, and a tight grid spares the launch thousands of workgroups
-    // that would only find out that they have no block
-    const int rows = a.bt.t_hint > 0 ? std::min(a.bt.t_hint, a.bt.T) : a.bt.T;
-    const int est = 5 * std::max(rows / lagg_block_rows(&a.bt), a.bt.B / LAGG_MAXM) / 4 + 2;
-    *grid = dim3((unsigned)(a.vc.K * *nchunk), (unsigned)std::max(1, std::min(std::min(a.bt.B, est), 65535)));
+    for (int k = 0; k < vc.K; ++k) wmax = std::max(wmax, vc.off[k + 1] - vc.off[k]);
+    *chunks = cdiv(wmax, LG_CW);
+    const int rows = bt.t_hint > 0 ? std::min(bt.t_hint, bt.T) : bt.T;
+    const int est = 5 * std::max(rows / lagg_block_rows(&bt), bt.B / LAGG_MAXM) / 4 + 2;
+    *gy = std::max(1, std::min(std::min(bt.B, est), 65535));
+}
+// chunks per workgroup: 1 while the launch is a few rounds of the chip's ~768 resident workgroups (the step then wants as many short
+// workgroups as it can get: configs[1], B = 1024 and Lipo measured 3-5 % SLOWER with more), several where there are thousands (C5:
+// 41 k, HIV widths: 26 k / 10 k): forward up to 8 (C5 forward 681 -> 593 us), transposed up to 4 (C5 -2 %, HIV: no difference between 1, 4, 8)
+static int lagg_cpw(const eagcn_batch& bt, const ViewCols& vc, bool trans) {
+    static const int cpw_env = [] { const char* e = getenv("EAGCN_LAGG_CPW"); return e ? atoi(e) : 0; }();
+    static const int cpw_bwd = [] { const char* e = getenv("EAGCN_LAGG_CPW_BWD"); return e ? atoi(e) : 1; }();
+    int chunks, gy;
+    lagg_extent(bt, vc, &chunks, &gy);
+    const long wgs = (long)vc.K * chunks * gy;
+    int per = (trans && !cpw_bwd) ? 1 : cpw_env > 0 ? cpw_env : (int)std::min<long>(trans ? 4 : 8, std::max<long>(1, wgs / 3072));
+    return std::max(1, std::min(per, chunks));
+}
+static int lagg_grid(const AggArgs& a, dim3* grid, int* nchunk, int* cpw, bool trans) {
+    int chunks, gy;
+    lagg_extent(a.bt, a.vc, &chunks, &gy);
+    *cpw = lagg_cpw(a.bt, a.vc, trans);
+    *nchunk = cdiv(chunks, *cpw);
+    *grid = dim3((unsigned)(a.vc.K * *nchunk), (unsigned)gy);
     return EAGCN_OK;
 }
 
 int launch_lagg_fwd(AggArgs a, hipStream_t s) {
     if (a.bt.B == 0 || a.bt.T == 0) return EAGCN_OK;
     dim3 grid;
-    int rc = lagg_grid(a, &grid, &a.nchunk);
+    int rc = lagg_grid(a, &grid, &a.nchunk, &a.cpw, false);
     if (rc) return rc;
     ProfScope ps(PROF_AGG, s);
     EdgeArgs e;
     memset(&e, 0, sizeof(e));
     static const int dbgm = [] { const char* e = getenv("EAGCN_LAGG_DBG"); return e ? atoi(e) : 0; }();
     a.xcd = dbgm;
-    lagg_kernel<false><<<grid, 256, 0, s>>>(a, e);
+    if (a.cpw > 1) lagg_kernel<false, true><<<grid, 256, 0, s>>>(a, e);
+    else lagg_kernel<false, false><<<grid, 256, 0, s>>>(a, e);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
@@ -668,12 +811,20 @@ int launch_lagg_bwd(AggArgs a, const EdgeArgs& e, hipStream_t s) {
     if (a.bt.B == 0 || a.bt.T == 0) return EAGCN_OK;
     EAGCN_CHECK_ARG(e.atomic && e.datt, "lagg: the edge gradients leave through the shared accumulator slabs (EdgeArgs.atomic)");
     dim3 grid;
-    int rc = lagg_grid(a, &grid, &a.nchunk);
+    int rc = lagg_grid(a, &grid, &a.nchunk, &a.cpw, true);
     if (rc) return rc;
     ProfScope ps(PROF_AGG, s);
     static const int dbgm = [] { const char* e = getenv("EAGCN_LAGG_DBG"); return e ? atoi(e) : 0; }();
     a.xcd = dbgm;
-    lagg_kernel<true><<<grid, 256, 0, s>>>(a, e);
+    EAGCN_CHECK_ARG(!a.w_aw || a.bn_tab, "lagg: the upstream-gradient form needs the BatchNorm tables");
+    if (a.w_aw) {
+        // (one instantiation: with one chunk per workgroup the records of a block are simply built in front of its only chunk; the
+        //  single-chunk body with this form's staging needs 177 registers)
+        lagg_kernel<true, true, true><<<grid, 256, 0, s>>>(a, e);
+    } else {
+        if (a.cpw > 1) lagg_kernel<true, true><<<grid, 256, 0, s>>>(a, e);
+        else lagg_kernel<true, false><<<grid, 256, 0, s>>>(a, e);
+    }
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }

@@ -781,7 +781,7 @@ static LayerDims layer_dims(const eagcn_batch* b, const eagcn_layer_params* p) {
     d.fin = layout_width(&p->in);
     d.ldo = p->structure == EAGCN_STRUCT_CONCATE ? d.fp : pad16(p->width[0]);
     d.gx = agg_grid_x(b);
-    d.gslab = std::max(d.gx, lagg_use(b, 0, false) ? lagg_slabs(b) : 0);
+    d.gslab = std::max(d.gx, lagg_use(b, 0, false, &d.vc) ? lagg_slabs(b) : 0);
     // row-partial slabs of the BatchNorm backward: 7 rows per workgroup, at most 2048 workgroups and at most
     // 32 MB of fp64 partials (wide layers: Fp = 6320 -> 331 workgroups).  Fewer, longer workgroups were measured
     // slower (the kernel is bound by its instruction stream and one memory round trip per 7-row batch, not by the
@@ -1068,7 +1068,7 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
             AggArgs a;
             a.bt = *b; a.vc = d.vc; a.src = w->P; a.lds = d.fp; a.dst = w->Y; a.ldd = d.fp;
             a.sig = sc.sig; a.rsig = sc.rsig; a.rscale = w->rscale; a.stats = sc.stats; a.nchunk = 1;
-            if (lagg_use(b, 0, false)) {                       // LDS-staged bond-list aggregation (lagg.hip): one slab per row block
+            if (lagg_use(b, 0, false, &d.vc)) {                // LDS-staged bond-list aggregation (lagg.hip): one slab per row block
                 rc = launch_lagg_fwd(a, s);
                 nslab = lagg_slabs(b);
                 tiles_per_wg = -1;
@@ -1141,6 +1141,9 @@ static bool lagg_fuses_bn() {
     static const bool on = [] { const char* v = getenv("EAGCN_LAGG_FUSE_BN"); return !(v && v[0] == '0'); }();
     return on;
 }
+// Weighted_sum layers (round 6): lagg.hip re-forms dH from the K-times-narrower upstream gradient in its staging, so the second pass
+// (a read of Y' and a write of T x K F floats) and the read of dY' behind it disappear; EAGCN_LAGG_WFUSE=0 keeps the pass
+// (lagg_wfuse(): lagg.hip, where the policy lives)
 static bool bn_bwd_two_pass(bool weighted) {
     static const int force = [] { const char* v = getenv("EAGCN_BWD_STORE_DH"); return v ? (v[0] == '1' ? 1 : 0) : -1; }();
     return force < 0 ? weighted : force == 0;
@@ -1233,7 +1236,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     if (drain_in && drain_in->eacc) ba.drain = *drain_in; else memset(&ba.drain, 0, sizeof(ba.drain));
     const int rows = b->T + ba.nvirt;
     const int gxb = std::max(1, std::min(rows, d.gxb));
-    bool fused_bn_apply = false;
+    bool fused_bn_apply = false, fused_w_apply = false;
     // the LDS-staged aggregation (lagg.hip) runs this layer's transposed aggregation + edge gradients: decided ONCE, here, because the
     // BatchNorm backward below leaves its second pass to that kernel (the edge gradients must then leave through the shared accumulators)
     bool lagg_bwd = false;
@@ -1241,7 +1244,8 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         static const bool edge_atomic0 = [] { const char* v = getenv("EAGCN_EDGE_SLABS"); return !(v && v[0] == '1'); }();
         bool general0 = false;
         for (int k = 0; k < p->K; ++k) general0 = general0 || pp.rel_vec[k] != nullptr;
-        const bool absorbs = !bn_bwd_two_pass(p->structure == EAGCN_STRUCT_WEIGHTED) && lagg_fuses_bn();
+        const bool wt0 = p->structure == EAGCN_STRUCT_WEIGHTED;
+        const bool absorbs = lagg_fuses_bn() && (!bn_bwd_two_pass(wt0) || (wt0 && lagg_wfuse()));
         lagg_bwd = b->T > 0 && edge_atomic0 && !general0 && lagg_use(b, 1, absorbs);
     }
     const double M = (double)b->B * (double)b->N;
@@ -1278,7 +1282,13 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         if (b->T > 0) {
             // second pass of the same kernel body: dH formed again, dY' written (sc.dY)
             const bool wt = p->structure == EAGCN_STRUCT_WEIGHTED, dg = ba.rg.dg != nullptr, dr = ba.do_drop != 0;
-            if (bn_bwd_two_pass(wt)) launch_bn_bwd_pass(true, wt, dg, dr, dim3(std::max(1, std::min(b->T, d.gxb)), ny), ba, s);
+            if (bn_bwd_two_pass(wt) && wt && lagg_bwd && lagg_fuses_bn() && lagg_wfuse()) {
+                fused_w_apply = true;                                           // the LDS-staged aggregation forms dH AND dY' in its staging
+                if (dg) {                                                       // (per-molecule upstream gradient: its rows, once, K times narrower than dH)
+                    rc = launch_readout_bwd_rows(b, ba.rg, d.ldo, sc.dY, s);
+                    if (rc) return rc;
+                }
+            } else if (bn_bwd_two_pass(wt)) launch_bn_bwd_pass(true, wt, dg, dr, dim3(std::max(1, std::min(b->T, d.gxb)), ny), ba, s);
             else if (lagg_bwd && lagg_fuses_bn()) fused_bn_apply = true;      // the LDS-staged aggregation forms dY' from the stored dH while it stages its rows
             else bn_bwd_apply_kernel<<<ew_grid((size_t)b->T * d.fp / 4), 256, 0, s>>>(*b, d.fp, w->Y, d.fp, w->bn, sc.cc, sc.dY);
             EAGCN_LAUNCH_CHECK();
@@ -1328,7 +1338,12 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         static const bool colaunch = [] { const char* v = getenv("EAGCN_NO_COLAUNCH"); return !(v && v[0] == '1'); }();
         nedge = e.atomic ? -EDGE_COPIES : edge_grid_x(b);
         if (lagg_bwd && e.atomic) {                                              // transposed aggregation + edge gradients from the same LDS gathers
-            if (fused_bn_apply) { a.bn_tab = w->bn; a.bn_cc = sc.cc; a.bn_fp = d.fp; }
+            if (fused_bn_apply || fused_w_apply) { a.bn_tab = w->bn; a.bn_cc = sc.cc; a.bn_fp = d.fp; }
+            if (fused_w_apply) {
+                a.src = ba.rg.dg ? sc.dY : dxout; a.lds = d.ldo;
+                a.w_aw = sc.colp + (size_t)CP_AVEW * d.fp;
+                a.w_drop = ba.do_drop; a.w_thr = ba.thr; a.w_inv_keep = ba.inv_keep; a.w_seed = ba.seed; a.w_seed_dev = ba.seed_dev;
+            }
             rc = launch_lagg_bwd(a, e, s);
             if (rc) return rc;
         } else if (!forked && colaunch) {

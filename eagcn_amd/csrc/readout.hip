@@ -432,6 +432,15 @@ extern "C" int eagcn_readout_forward(const eagcn_batch* b, const float* x, const
     return EAGCN_OK;
 }
 
+// the rows of a per-molecule read-out gradient, [T][ld] (layer.hip: upstream gradient of a Weighted_sum top layer for lagg.hip's staging)
+int eagcn::launch_readout_bwd_rows(const eagcn_batch* b, const ReadoutGrad& rg, int ld, float* dx, hipStream_t s) {
+    const size_t total = (size_t)std::max(b->T, 1) * ld;
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 4096));
+    readout_bwd_kernel<<<grid, 256, 0, s>>>(*b, rg.dg, rg.map, ld, rg.size, rg.mode, rg.F, dx);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+
 extern "C" int eagcn_readout_backward(const eagcn_batch* b, const float* dg, const eagcn_layout* lay,
                                       const int64_t* size, int mode, int F, float* dx, float* dpad_row,
                                       void* stream) {

@@ -38,9 +38,9 @@ torch.save({'out': out.detach().cpu(), 'g': {k: p.grad.cpu() for k, p in m.named
 ''' % ROOT
 
 
-def _run(agg, args, d):
-    path = os.path.join(d, agg + '.pt')
-    r = subprocess.run([sys.executable, '-c', CODE, args[0], path] + [str(a) for a in args[1:]], env=dict(os.environ, EAGCN_AGG=agg),
+def _run(agg, args, d, tag='', **env):
+    path = os.path.join(d, agg + tag + '.pt')
+    r = subprocess.run([sys.executable, '-c', CODE, args[0], path] + [str(a) for a in args[1:]], env=dict(os.environ, EAGCN_AGG=agg, **env),
                        capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stderr[-3000:]
     return torch.load(path)
@@ -68,6 +68,23 @@ def test_lds_staged_aggregation_matches_the_dense_kernels(args):
         worst = max(worst, (dd / tol, k))
         assert dd <= tol, (k, dd, v.abs().max().item(), scale)
     print('worst gradient distance / tolerance %.2f (%s)' % worst)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('args', [('Concate', 40, 200, 60, 144, 80, 0, 0.0), ('Weighted_sum', 24, 70, 25, 48, 64, 0, 0.05)],
+                         ids=['concate-half-chunks', 'weighted-ragged'])
+def test_several_column_chunks_per_workgroup_change_no_bit(args):
+    """Forward launches with thousands of workgroups let one workgroup take several 32-column chunks of a block (its lists and row
+    records are built once; csrc/lagg.hip lagg_grid): the same arithmetic per chunk, so the outputs are bit-identical to
+    one chunk per workgroup.  Forced here (EAGCN_LAGG_CPW) at widths that end in a half chunk and in a partial group."""
+    with tempfile.TemporaryDirectory() as d:
+        one = _run('lds', args, d, tag='1', EAGCN_LAGG_CPW='1')
+        for cpw in ('2', '3'):
+            many = _run('lds', args, d, tag=cpw, EAGCN_LAGG_CPW=cpw, EAGCN_LAGG_CPW_BWD='1')
+            assert torch.equal(one['out'], many['out'])
+            scale = max(v.abs().max().item() for v in one['g'].values())
+            for k, v in one['g'].items():          # (the backward is the same kernel on bit-identical inputs; its fp64 atomics are unordered)
+                assert (v - many['g'][k]).abs().max().item() <= 1e-6 * scale, (cpw, k)
 
 
 @pytest.mark.timeout(900)

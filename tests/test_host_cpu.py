@@ -324,13 +324,15 @@ def test_pad_row_binomial_thresholds_are_the_binomial_cdf():
 
 def test_bond_list_policy_by_shape_and_structure():
     """Which batch shapes carry bond lists / row blocks for the LDS-staged aggregation (csrc/lagg.hip lagg_wanted; no kernel runs):
-    large padded sizes, batches of up to 256 molecules, and every Concate shape; Weighted_sum layers of small molecules in large
-    batches stay on the matrix-core kernels; nothing beyond 256 atoms.  In a subprocess: the policy reads EAGCN_AGG once."""
+    large padded sizes, batches of up to 256 molecules, every Concate shape and -- since round 6, when the transposed kernel re-forms
+    dH of a Weighted_sum layer from the upstream gradient in its staging -- Weighted_sum layers of small molecules in large batches
+    too (EAGCN_LAGG_WFUSE=0: those stay on the matrix-core kernels); nothing beyond 256 atoms.  In a subprocess: the policy reads
+    its environment once."""
     import subprocess
     import sys
     code = r'''
 import os
-for k in ('EAGCN_AGG', 'EAGCN_LAGG_MIN_N', 'EAGCN_LAGG_FWD_MAXB'):
+for k in ('EAGCN_AGG', 'EAGCN_LAGG_MIN_N', 'EAGCN_LAGG_FWD_MAXB', 'EAGCN_LAGG_WFUSE'):
     os.environ.pop(k, None)
 from eagcn_amd import _lib as L
 lib = L.load()
@@ -339,14 +341,18 @@ C, W = L.STRUCT_CONCATE, L.STRUCT_WEIGHTED
 got = [f(256, 132, C), f(1024, 132, C), f(1024, 222, W), f(256, 222, W), f(1024, 256, W), f(64, 300, C), f(1024, 222, -1),
        lib.eagcn_agg_wants_bond_lists(1024, 222), lib.eagcn_agg_wants_bond_lists(8, 257)]
 print(got)
-assert got == [1, 1, 0, 1, 1, 0, 1, 1, 0], got
+assert got == [1, 1, 1, 1, 1, 0, 1, 1, 0], got
 '''
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout + r.stderr
     forced = subprocess.run([sys.executable, '-c', code.replace("os.environ.pop(k, None)", "os.environ.pop(k, None)\nos.environ['EAGCN_AGG'] = 'dense'")
-                             .replace("assert got == [1, 1, 0, 1, 1, 0, 1, 1, 0], got", "assert got == [0] * 9, got")],
+                             .replace("assert got == [1, 1, 1, 1, 1, 0, 1, 1, 0], got", "assert got == [0] * 9, got")],
                             capture_output=True, text=True, cwd=str(ROOT))
     assert forced.returncode == 0, forced.stdout + forced.stderr
+    off = subprocess.run([sys.executable, '-c', code.replace("os.environ.pop(k, None)", "os.environ.pop(k, None)\nos.environ['EAGCN_LAGG_WFUSE'] = '0'")
+                          .replace("assert got == [1, 1, 1, 1, 1, 0, 1, 1, 0], got", "assert got == [1, 1, 0, 1, 1, 0, 1, 1, 0], got")],
+                         capture_output=True, text=True, cwd=str(ROOT))
+    assert off.returncode == 0, off.stdout + off.stderr
 
 
 def test_bond_list_buffers_are_laid_out_without_overlap():
