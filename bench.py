@@ -53,7 +53,7 @@ GEMM_MODES = {0: 'f32 (fp32 MFMA v_mfma_f32_16x16x4_f32, exact fp32 products)',
                  'piece products per 16 k rebuild the fp32 product (csrc/gemm_bx3.hip); aggregation, BatchNorm, head, first layer fp32',
               4: 'bf16 operands (ONE plane, round to nearest even), fp32 accumulate: BASELINE configs[1] as written; NOT the parity path'}
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = next((os.path.join('profiles', f) for f in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
+PMC_FILE = next((os.path.join('profiles', f) for f in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
                  if os.path.exists(os.path.join(ROOT, 'profiles', f))), os.path.join('profiles', 'r04_pmc_traffic.json'))
 
 

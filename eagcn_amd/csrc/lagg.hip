@@ -57,8 +57,15 @@ __device__ __forceinline__ void lg_fma(float4& acc, float w, const float4& v) {
 __device__ __forceinline__ void lg_add(float4& acc, const float4& v) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
 __device__ __forceinline__ float lg_dot(const float4& a, const float4& b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
 // sum over the LG_LPR lanes of a row group (the groups are aligned 8-lane runs of a wavefront)
+// (DPP operands, no LDS traffic: quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror -- lane i of an aligned run of eight
+//  meets lane 7 - i, which is in the OTHER quad and holds that quad's sum.  Same additions in the same order as three xor shuffles;
+//  those compile to ds_bpermute_b32: ~150 LDS-pipe operations per lane and chunk in the transposed kernel, three dependent ones per sum)
+template <int CTRL>
+__device__ __forceinline__ float lg_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float lg_gsum(float v) {
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    v += lg_dpp<0xB1>(v); v += lg_dpp<0x4E>(v); v += lg_dpp<0x141>(v);
     return v;
 }
 
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     // staging, the column sums and the row passes (with one chunk per workgroup a 1250-column view rebuilt the same records forty times)
     const int k = blockIdx.x / a.nchunk, grp = blockIdx.x - k * a.nchunk;         // (a.nchunk: chunk GROUPS per view)
     const int wk = a.vc.off[k + 1] - a.vc.off[k];                    // padded width of the view (a multiple of 16)
-    const int cc_lo = grp * a.cpw;
+    const int cc_lo = MULTI ? grp * a.cpw : grp;
     if (cc_lo * LG_CW >= wk) return;                                  // (uniform)
     const int cc_hi = MULTI ? min(cc_lo + a.cpw, (wk + LG_CW - 1) / LG_CW) : cc_lo + 1;
     // the first block's record is requested together with the block count it is checked against (the index is inside the record

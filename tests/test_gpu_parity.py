@@ -835,6 +835,10 @@ FULL_WIDTH_CASES = {
     'c5_synth': dict(structure='Concate', n_layers=2, w1=[64] * 8, w2=[128] * 8, dens=(256, 64), nclass=1,
                      chans=[32, 4, 2, 2, 2, 2, 2, 2], B=8, n_max=256, n_med=None, all_full=True),
     # configs[1] Tox21 widths with the reference's 4-layer stack (parity mode P of SURVEY 8: 80/140/280/280)
+    # configs[1] ITSELF, full size: Tox21 12-task 2-layer 5-view Concate 80 / 140, B = 256, N_pad 132 (what bench.py times; the
+    # oracle takes a few seconds per pass on the GPU box's host cores)
+    'tox21_c2_full': dict(structure='Concate', n_layers=2, w1=[80] * 5, w2=[140] * 5, dens=(256, 64), nclass=12,
+                          chans=[28, 4, 2, 2, 2], B=256, n_max=132, n_med=16, all_full=False),
     'tox21_p4': dict(structure='Concate', n_layers=4, w1=[80] * 5, w2=[140] * 5, dens=(256, 64), nclass=12,
                      chans=[28, 4, 2, 2, 2], B=10, n_max=60, n_med=16, all_full=False),
 }
