@@ -49,6 +49,7 @@ constexpr int LG_G = 256 / LG_LPR;           // row groups per workgroup (32)
 constexpr int LG_U = LAGG_RB / LG_G;         // staging loads per lane (8)
 constexpr int LG_ECAP = 768;                 // list entries of a block staged in LDS (the rest is read from memory)
 constexpr int LG_EPT = LG_ECAP / 256;
+constexpr bool LG_MERGE = true;              // transposed: edge gradients inside the row loop (false: the round-5 loop of their own)
 constexpr int LG_PJ_EARLY = 4;             // transposed: P rows of the edge gradients requested in front of barrier B3 (the rest behind it: registers)
 
 __device__ __forceinline__ void lg_fma(float4& acc, float w, const float4& v) {
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     __shared__ float4 s_S[LAGG_MAXM][LG_LPR];        // S_b / G_b per molecule
     __shared__ float sig_s[256];
     __shared__ double st_s[TRANS ? 1 : 4][TRANS ? 1 : LG_LPR][8];   // forward: per wave: BatchNorm partial sums of a lane's four columns
-    __shared__ float4 s_bn[TRANS ? (WFUSE ? 5 : 3) : 1][LG_LPR];   // transposed + BatchNorm fusion: three (Weighted_sum: five) constants per column of this chunk
+    __shared__ float4 s_bn[TRANS ? (WFUSE ? 4 : 3) : 1][LG_LPR];   // transposed + BatchNorm fusion: three (Weighted_sum: four) constants per column of this chunk
     __shared__ double h_s[TRANS ? 264 : 1];          // transposed: bond-type histogram of d w_k, [256] = d self_r
     // transposed: the lists live in the record array until the records are built (LDS: 51 KB = three workgroups per CU either way)
     static_assert(sizeof(LgLists) <= sizeof(float4) * LAGG_RB * 3, "lists alias the transposed record array");
@@ -159,11 +160,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         sb[tid] = sc;
         sb[LG_CW + tid] = -sc * iv * c2;
         sb[2 * LG_CW + tid] = sc * (mu * iv * c2 - c1);
-        if constexpr (WFUSE) {
-            sb[3 * LG_CW + tid] = a.bn_tab[(size_t)BN_SH * a.bn_fp + cl];
-            sb[4 * LG_CW + tid] = a.w_aw[cl];
-        }
+        if constexpr (WFUSE) sb[3 * LG_CW + tid] = a.bn_tab[(size_t)BN_SH * a.bn_fp + cl];
     };
+    // (Ave_multi_view.weight is one scalar per view, layers.py:423: uniform for the workgroup.  A fifth constant row in LDS would be
+    //  the 256 bytes that cost the third workgroup per CU: 3 x 54 472 bytes fill the CU's 160 KB to 424 bytes)
+    const float w_ave = WFUSE ? a.w_aw[a.vc.off[k]] : 0.0f;
     const uint64_t wseed = WFUSE && a.w_drop ? (a.w_seed_dev ? *a.w_seed_dev : a.w_seed) : 0ull;
     if constexpr (TRANS) {
         if (fuse_bn && tid < LG_CW) bn_consts(cc_lo);
@@ -408,14 +409,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                             mb = ((yv[u].x * bA.x + sh.x > 0.0f) ? (kb & 1u) : 0u) | ((yv[u].y * bA.y + sh.y > 0.0f) ? (kb & 2u) : 0u) |
                                  ((yv[u].z * bA.z + sh.z > 0.0f) ? (kb & 4u) : 0u) | ((yv[u].w * bA.w + sh.w > 0.0f) ? (kb & 8u) : 0u);
                         }
-                        asm volatile("" : "+v"(mb), "+v"(lq));
+                        asm volatile("" : "+v"(mb));
                         {
-                            const float4 aw = s_bn[4][lq];
                             const float ik = a.w_drop ? a.w_inv_keep : 1.0f;
-                            v[u].x = (v[u].x * aw.x) * ((mb & 1u) ? ik : 0.0f);
-                            v[u].y = (v[u].y * aw.y) * ((mb & 2u) ? ik : 0.0f);
-                            v[u].z = (v[u].z * aw.z) * ((mb & 4u) ? ik : 0.0f);
-                            v[u].w = (v[u].w * aw.w) * ((mb & 8u) ? ik : 0.0f);
+                            v[u].x = (v[u].x * w_ave) * ((mb & 1u) ? ik : 0.0f);
+                            v[u].y = (v[u].y * w_ave) * ((mb & 2u) ? ik : 0.0f);
+                            v[u].z = (v[u].z * w_ave) * ((mb & 4u) ? ik : 0.0f);
+                            v[u].w = (v[u].w * w_ave) * ((mb & 8u) ? ik : 0.0f);
                         }
                         asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w), "+v"(lq));
                         const float4 bA = s_bn[0][lq], bB = s_bn[1][lq], bC = s_bn[2][lq];
@@ -494,7 +494,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         }
         __syncthreads();                                              // B3: records and S_b / G_b are complete
         if constexpr (TRANS) { if (bn_next) bn_consts(cc + 1 < cc_hi ? cc + 1 : cc_lo); }     // (the staging of THIS chunk has read s_bn)
-        if constexpr (TRANS) {
+        if constexpr (TRANS && LG_MERGE) {
+#pragma unroll
+            for (int u = LG_PJ_EARLY; u < LG_U; ++u) pjv[u] = pj_load(u);
+        }
+        if constexpr (TRANS && !LG_MERGE) {
             // ---- edge gradients of the rows with a record (this chunk's columns): d w[code_e] += h_e (<Z[src_e], P_j> - rowdot_src), the
             //      diagonal into d self_r.  Lane e (< 4) of the row's eight adds bond e's term, lane 4 the diagonal's.
             const int nu = (rows + LG_G - 1) / LG_G;
@@ -594,12 +598,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 y.y = fmaf(r0.x, v0.y, fmaf(r0.y, v1.y, fmaf(r0.z, v2.y, fmaf(r0.w, v3.y, fmaf(ws, self.y, wS * S.y)))));
                 y.z = fmaf(r0.x, v0.z, fmaf(r0.y, v1.z, fmaf(r0.z, v2.z, fmaf(r0.w, v3.z, fmaf(ws, self.z, wS * S.z)))));
                 y.w = fmaf(r0.x, v0.w, fmaf(r0.y, v1.w, fmaf(r0.z, v2.w, fmaf(r0.w, v3.w, fmaf(ws, self.w, wS * S.w)))));
+                if constexpr (TRANS && LG_MERGE) {
+                    // the row's edge gradients from the SAME gathers (round 6: the separate loop read the record, the row and its four
+                    // sources from LDS a second time -- 7 of 17 16-byte LDS reads per row and lane, and the LDS pipe is what
+                    // workgroups that share a CU compete for): d w[code_e] += h_e (<Z[src_e], P_j> - rowdot_src), lane e (< 4) of
+                    // the row's eight adds bond e's term, lane 4 the diagonal's (into d self_r)
+                    const float4 pj = col_ok ? pjv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const uint32_t cds = __float_as_uint(rl.z);
+                    const float g0 = lg_gsum(lg_dot(v0, pj)), g1 = lg_gsum(lg_dot(v1, pj)), g2 = lg_gsum(lg_dot(v2, pj)), g3 = lg_gsum(lg_dot(v3, pj));
+                    const float gs = lg_gsum(lg_dot(self, pj));
+                    const int e4 = l & 3;
+                    const float hv = e4 == 0 ? r1.x : e4 == 1 ? r1.y : e4 == 2 ? r1.z : r1.w;
+                    const float gv = e4 == 0 ? g0 : e4 == 1 ? g1 : e4 == 2 ? g2 : g3;
+                    const uint32_t cv = (cds >> (8 * e4)) & 255u, sv = (srcs >> (8 * e4)) & 255u;
+                    if (fast && l < 4 && hv != 0.0f && cv) atomicAdd(&h_s[cv], (double)hv * ((double)gv - (double)s_rd[sv]));
+                    if (fast && l == 4) dr_acc += (double)rl.x * ((double)gs - (double)s_rd[rr]);
+                }
                 if (fast && (meta & LG_OVF)) {                        // (bonds 4..7)
                     const int slot = (int)(meta & 0xFFFFu);
                     const float4 q0 = s_ovf[slot][0];
                     const uint32_t sr2 = __float_as_uint(TRANS ? s_ovf[slot][NREC - 1].y : s_ovf[slot][NREC - 1].z);
-                    lg_fma(y, q0.x, buf[sr2 & 255u][l]); lg_fma(y, q0.y, buf[(sr2 >> 8) & 255u][l]);
-                    lg_fma(y, q0.z, buf[(sr2 >> 16) & 255u][l]); lg_fma(y, q0.w, buf[sr2 >> 24][l]);
+                    const float4 b0 = buf[sr2 & 255u][l], b1 = buf[(sr2 >> 8) & 255u][l], b2 = buf[(sr2 >> 16) & 255u][l], b3 = buf[sr2 >> 24][l];
+                    lg_fma(y, q0.x, b0); lg_fma(y, q0.y, b1); lg_fma(y, q0.z, b2); lg_fma(y, q0.w, b3);
+                    if constexpr (TRANS && LG_MERGE) {
+                        const float4 pj = col_ok ? pjv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 q1 = s_ovf[slot][1];
+                        const uint32_t cd2 = __float_as_uint(s_ovf[slot][2].z);
+                        const float f0 = lg_gsum(lg_dot(b0, pj)), f1 = lg_gsum(lg_dot(b1, pj)), f2 = lg_gsum(lg_dot(b2, pj)), f3 = lg_gsum(lg_dot(b3, pj));
+                        const int e4 = l & 3;
+                        const float hv2 = e4 == 0 ? q1.x : e4 == 1 ? q1.y : e4 == 2 ? q1.z : q1.w;
+                        const float gv2 = e4 == 0 ? f0 : e4 == 1 ? f1 : e4 == 2 ? f2 : f3;
+                        const uint32_t cv2 = (cd2 >> (8 * e4)) & 255u, sv2 = (sr2 >> (8 * e4)) & 255u;
+                        if (l < 4 && hv2 != 0.0f && cv2) atomicAdd(&h_s[cv2], (double)hv2 * ((double)gv2 - (double)s_rd[sv2]));
+                    }
                 }
                 if (fast) finish(rr, y);
             }

@@ -45,6 +45,12 @@ def _kernels(text):
     return out
 
 
+def _lds_bytes(text):
+    """{mangled name: group_segment_fixed_size}"""
+    return {re.search(r'\.name:\s+(\S+)', m.group(0)).group(1): int(re.search(r'\.group_segment_fixed_size:\s+(\d+)', m.group(0)).group(1))
+            for m in re.finditer(r'- \.agpr_count:.*?(?=\n  - \.agpr_count:|\namdhsa\.target|\Z)', text, re.S)}
+
+
 def test_dispatched_aggregation_kernels_have_no_scratch(isa):
     ks = _kernels(isa['agg'])
     seen = 0
@@ -63,6 +69,10 @@ def test_dispatched_aggregation_kernels_have_no_scratch(isa):
     for name, (scratch, vgpr) in _kernels(isa['lagg']).items():
         if 'lagg_kernel' in name:
             assert scratch == 0 and vgpr <= 168, (name, scratch, vgpr)       # three waves per SIMD (LDS allows three workgroups per CU)
+    lds = {n: b for n, b in _lds_bytes(isa['lagg']).items() if 'lagg_kernel' in n}
+    assert len(lds) == 5                      # forward / transposed x one / several chunks, + the Weighted_sum staging (several chunks only)
+    for name, b in lds.items():
+        assert 3 * b <= 160 * 1024, (name, b)                                # ... and three workgroups' LDS fit the CU's 160 KB
 
 
 def _mfma_blocks_with_scratch(text, kernel):
