@@ -19,10 +19,7 @@
 
 namespace eagcn {
 
-// step-position signal / wait (eagcn_model.fwd_signal, eagcn_stream_wait_counter)
-__global__ void fwd_signal_kernel(uint32_t* __restrict__ word) {
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
+// step-position wait (eagcn_stream_wait_counter; the signal itself -- eagcn_model.fwd_signal -- is raised by the head's first launch, HeadFwd.signal)
 // (gives up after `budget_ticks` of the 100 MHz clock and raises the sticky word `err`: a poll must never hang the queue)
 __global__ void wait_counter_kernel(const uint32_t* __restrict__ word, uint32_t value, int* __restrict__ err,
                                     unsigned long long budget_ticks) {
@@ -325,6 +322,7 @@ static HeadPlan head_plan(const eagcn_batch* b, const eagcn_model* m, const Mode
                    m->training, 1, h->bn_eps, h->bn_momentum, nodrop};
     if (P.sync) { P.f1.cnt_in = P.st_g + 2 * F; P.f2.cnt_in = P.st_1 + 2 * n1; P.f3.cnt_in = P.st_2 + 2 * n2; }
     P.f3.nw = 8;                         // (dense 3 adds in the order of the fused middle launch, whatever the batch size)
+    P.f1.signal = m->fwd_signal;         // (the forward has passed its read-out: said by the head's first launch)
     P.f1.st_copies = P.f2.st_copies = P.f3.st_copies = copies;
     P.f1.st_stride = P.f2.st_stride = P.f3.st_stride = sc.n_hst;
     if (!hg) return P;
@@ -432,10 +430,7 @@ static int model_forward_trunk(const eagcn_batch* b, const eagcn_model* m, const
     else
         RC(eagcn_readout_forward(b, LL.xout, &lay, last->structure == EAGCN_STRUCT_WEIGHTED ? LL.pad_row : nullptr,
                                  size, m->molfp_mode, sv.g, F, stream));
-    if (m->fwd_signal) {                              // (include/eagcn_hip.h eagcn_model.fwd_signal)
-        fwd_signal_kernel<<<1, 64, 0, s>>>(m->fwd_signal);
-        EAGCN_LAUNCH_CHECK();
-    }
+    // (eagcn_model.fwd_signal: bumped by the head's first launch -- head_plan sets HeadFwd.signal; both callers launch it next)
     if (!fused_readout(m)) RC(head_colstats(sv.g, B, F, st_g, s, st_g + 2 * F, st_1 + 2 * n1, st_2 + 2 * n2));
     return EAGCN_OK;
 }

@@ -269,6 +269,8 @@ template <bool VEC, bool DROP, int NW>
 __global__ __launch_bounds__(64 * NW) void head_fwd_kernel(HeadFwd a) {
     extern __shared__ __attribute__((aligned(16))) float tab[];          // [2][Kp]: scale, shift
     const int Kp = (a.K + 3) & ~3;
+    // (relaxed: the word only PLACES the side stream's work, nothing it guards is read through it)
+    if (a.signal && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.lab) {                                                         // this workgroup's share of the batch's labelled entries (BCE)
         const int per = (a.nlab + gridDim.x - 1) / gridDim.x;
         const int i = blockIdx.x * per + threadIdx.x;

@@ -205,6 +205,8 @@ struct HeadFwd {                 // y = act(bn(x)) . W  (+ column sums of y)
     // into *lab_cnt (zero on entry), every workgroup its share
     const float* lab = nullptr; int nlab = 0; unsigned* lab_cnt = nullptr;
     int nw = 0;                          // waves per workgroup that split the reduction: 4 / 8, 0 = by the launch's tile count
+    uint32_t* signal = nullptr;          // optional: a device word bumped by the launch's first workgroup (eagcn_model.fwd_signal: "the forward
+                                         // has passed its read-out" -- a launch of its own cost the step 4.6 us on the main stream)
 };
 struct HeadBwd {                 // backward of  y = act(bn_p(x)) . W : d(bn_p output) with its sums, and dW
     int B, K, N;
