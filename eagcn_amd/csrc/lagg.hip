@@ -736,10 +736,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 //     Tox21 B = 1024:                                                               0.898 / 0.906    against 0.922
 //     Lipo 3-layer Concate B = 512:                                                 1.350 / 1.357    against 1.401
 //     HIV Weighted_sum (24 atoms on average, N = 222, 5 x 1250 columns), B = 1024:   7.19 / 7.15     against 6.94
-// -> forward: LARGE molecules (padded size from EAGCN_LAGG_MIN_N = 240 and -- once the rows the batches of the shape really hold are
-//    known, eagcn_batch.t_hint -- 96 atoms per molecule on average), or batches of up to 256 molecules (where agg.hip runs its
-//    one-workgroup-per-tile form); backward: large molecules, or any layer whose BatchNorm backward leaves its second pass to this kernel
-//    (Concate).  Weighted_sum layers of small molecules stay on the matrix cores.
+// -> round-5 policy: forward for LARGE molecules (padded size from EAGCN_LAGG_MIN_N = 240 and -- once the rows the batches of the shape
+//    really hold are known, eagcn_batch.t_hint -- 96 atoms per molecule on average) or batches of up to 256 molecules; backward: large
+//    molecules, or any layer whose BatchNorm backward leaves its second pass to this kernel (Concate); Weighted_sum layers of small
+//    molecules on the matrix cores.
+// Round 6 (group sums through DPP, edge gradients inside the row loop, several chunks per workgroup, the Weighted_sum staging; same-box
+// A/B against the round-5 kernels, tools/r6_ab_lib2.sh): HIV 6.90 -> 6.10 ms with BOTH directions here, Tox21 B = 1024 and Lipo equal
+// or faster with the forward here as well -> every layer of every structure takes this path in both directions whenever the
+// padded size allows it (N <= 256); agg.hip serves larger molecules, code-book relations and EAGCN_AGG=dense.
 static int lagg_cpw(const eagcn_batch& bt, const ViewCols& vc, bool trans);
 static int lagg_policy() {
     static const int v = [] {
@@ -755,7 +759,10 @@ static int lagg_min_n() {
     return v;
 }
 static int lagg_fwd_maxb() {
-    static const int v = [] { const char* e = getenv("EAGCN_LAGG_FWD_MAXB"); return e ? atoi(e) : 256; }();
+    // (round 6: no limit by default.  Up to round 5 batches of more than 256 small molecules took the matrix-core forward of agg.hip;
+    //  measured again with this round's kernels the step is equal or faster on this path -- Tox21 B = 1024 0.828 -> 0.822 ms, Lipo
+    //  1.254 -> 1.258 -- and the default forward no longer sums the 1e-9 filler products one by one in fp32)
+    static const int v = [] { const char* e = getenv("EAGCN_LAGG_FWD_MAXB"); return e ? atoi(e) : 0x7FFFFFFF; }();
     return v;
 }
 bool lagg_wfuse() {

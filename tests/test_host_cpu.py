@@ -326,7 +326,7 @@ def test_bond_list_policy_by_shape_and_structure():
     """Which batch shapes carry bond lists / row blocks for the LDS-staged aggregation (csrc/lagg.hip lagg_wanted; no kernel runs):
     large padded sizes, batches of up to 256 molecules, every Concate shape and -- since round 6, when the transposed kernel re-forms
     dH of a Weighted_sum layer from the upstream gradient in its staging -- Weighted_sum layers of small molecules in large batches
-    too (EAGCN_LAGG_WFUSE=0: those stay on the matrix-core kernels); nothing beyond 256 atoms.  In a subprocess: the policy reads
+    too (EAGCN_LAGG_WFUSE=0 with the round-5 forward limit EAGCN_LAGG_FWD_MAXB=256: those stay on the matrix-core kernels); nothing beyond 256 atoms.  In a subprocess: the policy reads
     its environment once."""
     import subprocess
     import sys
@@ -349,7 +349,7 @@ assert got == [1, 1, 1, 1, 1, 0, 1, 1, 0], got
                              .replace("assert got == [1, 1, 1, 1, 1, 0, 1, 1, 0], got", "assert got == [0] * 9, got")],
                             capture_output=True, text=True, cwd=str(ROOT))
     assert forced.returncode == 0, forced.stdout + forced.stderr
-    off = subprocess.run([sys.executable, '-c', code.replace("os.environ.pop(k, None)", "os.environ.pop(k, None)\nos.environ['EAGCN_LAGG_WFUSE'] = '0'")
+    off = subprocess.run([sys.executable, '-c', code.replace("os.environ.pop(k, None)", "os.environ.pop(k, None)\nos.environ['EAGCN_LAGG_WFUSE'] = '0'\nos.environ['EAGCN_LAGG_FWD_MAXB'] = '256'")
                           .replace("assert got == [1, 1, 1, 1, 1, 0, 1, 1, 0], got", "assert got == [1, 1, 0, 1, 1, 0, 1, 1, 0], got")],
                          capture_output=True, text=True, cwd=str(ROOT))
     assert off.returncode == 0, off.stdout + off.stderr
