@@ -1236,7 +1236,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     if (drain_in && drain_in->eacc) ba.drain = *drain_in; else memset(&ba.drain, 0, sizeof(ba.drain));
     const int rows = b->T + ba.nvirt;
     const int gxb = std::max(1, std::min(rows, d.gxb));
-    bool fused_bn_apply = false, fused_w_apply = false;
+    bool fused_bn_apply = false, fused_w_apply = false, w_rows = false;
     // the LDS-staged aggregation (lagg.hip) runs this layer's transposed aggregation + edge gradients: decided ONCE, here, because the
     // BatchNorm backward below leaves its second pass to that kernel (the edge gradients must then leave through the shared accumulators)
     bool lagg_bwd = false;
@@ -1253,10 +1253,22 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         ProfScope ps(PROF_BN, s);
         const int ny = cdiv(d.fp, 1024);
         {
-            const bool wt = p->structure == EAGCN_STRUCT_WEIGHTED, dg = ba.rg.dg != nullptr, dr = ba.do_drop != 0;
+            const bool wt = p->structure == EAGCN_STRUCT_WEIGHTED, dr = ba.do_drop != 0;
+            bool dg = ba.rg.dg != nullptr;
             const dim3 grid(gxb, ny);
             ba.cc = sc.cc;
             ba.store_dh = bn_bwd_two_pass(wt) ? 0 : 1;
+            // Weighted_sum top layer whose dH is re-formed in lagg.hip's staging: that kernel wants the per-molecule read-out gradient as
+            // ROWS ([T][ldo], K times narrower than dH) -- written first, so that this pass reads them with 16-byte loads as well
+            // instead of gathering dg[molecule] element by element (fingerprint widths are not multiples of four: HIV 250)
+            static const bool rows_first = [] { const char* v = getenv("EAGCN_W_ROWS_FIRST"); return !(v && v[0] == '0'); }();
+            if (wt && dg && b->T > 0 && bn_bwd_two_pass(wt) && lagg_bwd && lagg_fuses_bn() && lagg_wfuse() && rows_first) {
+                rc = launch_readout_bwd_rows(b, ba.rg, d.ldo, sc.dY, s);
+                if (rc) return rc;
+                w_rows = true;
+                ba.dxout = sc.dY;
+                dg = false;
+            }
             launch_bn_bwd_pass(false, wt, dg, dr, grid, ba, s);
         }
         EAGCN_LAUNCH_CHECK();
@@ -1284,7 +1296,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
             const bool wt = p->structure == EAGCN_STRUCT_WEIGHTED, dg = ba.rg.dg != nullptr, dr = ba.do_drop != 0;
             if (bn_bwd_two_pass(wt) && wt && lagg_bwd && lagg_fuses_bn() && lagg_wfuse()) {
                 fused_w_apply = true;                                           // the LDS-staged aggregation forms dH AND dY' in its staging
-                if (dg) {                                                       // (per-molecule upstream gradient: its rows, once, K times narrower than dH)
+                if (dg && !w_rows) {                                                       // (per-molecule upstream gradient: its rows, once, K times narrower than dH)
                     rc = launch_readout_bwd_rows(b, ba.rg, d.ldo, sc.dY, s);
                     if (rc) return rc;
                 }
@@ -1340,7 +1352,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
         if (lagg_bwd && e.atomic) {                                              // transposed aggregation + edge gradients from the same LDS gathers
             if (fused_bn_apply || fused_w_apply) { a.bn_tab = w->bn; a.bn_cc = sc.cc; a.bn_fp = d.fp; }
             if (fused_w_apply) {
-                a.src = ba.rg.dg ? sc.dY : dxout; a.lds = d.ldo;
+                a.src = (ba.rg.dg || w_rows) ? sc.dY : dxout; a.lds = d.ldo;
                 a.w_aw = sc.colp + (size_t)CP_AVEW * d.fp;
                 a.w_drop = ba.do_drop; a.w_thr = ba.thr; a.w_inv_keep = ba.inv_keep; a.w_seed = ba.seed; a.w_seed_dev = ba.seed_dev;
             }
