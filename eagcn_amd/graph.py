@@ -41,8 +41,11 @@ _SIDE_AFTER_FWD = os.environ.get('EAGCN_SIDE_AFTER_FWD', '1') == '1'
 # forward is over puts its tail on the critical path.  Being slowed down by co-runners is cheaper than not overlapping.
 # Round 6 (batch hand-off through device flags, the index build's clears in one launch): the placed form wins where the index chain
 # FITS under the head: configs[1] 0.378 -> 0.372 ms (the chain no longer meets the forward plane GEMM, which needs empty CUs), and
-# still loses where it does not (B = 1024: 0.829 -> 0.870).  Default: by the padded rows of the batch (EAGCN_SIDE_PLACED=auto | 0 | 1).
-_SIDE_PLACED = os.environ.get('EAGCN_SIDE_PLACED', 'auto')
+# still loses where it does not (B = 1024: 0.829 -> 0.870).  `auto` = by the padded rows of the batch.
+# Measured again at the end of round 6 (shorter aggregation launches, the signal raised by the head's first launch), same-box A/B on two
+# boxes, tools/r6_env_ab.sh: configs[1] 0.374 -> 0.361 and 0.388 -> 0.376 ms WITHOUT the placement -- the unplaced index build again
+# hides under the whole step.  Default: off (EAGCN_SIDE_PLACED=0 | auto | 1).
+_SIDE_PLACED = os.environ.get('EAGCN_SIDE_PLACED', '0')
 _SIDE_PLACED_MAX_ROWS = int(os.environ.get('EAGCN_SIDE_PLACED_MAX_ROWS', '40000'))
 # a data-parallel step whose gradient all-reduce cannot be captured into the step graph is an ERROR instead of a (warned)
 # fallback to a host-issued collective: bench.py --require-in-graph-allreduce, tools/run_scale.sh
