@@ -728,7 +728,7 @@ int head_colstats(const float* g, int B, int F, double* st, hipStream_t s, doubl
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
-// waves per workgroup of a stage: HeadFwd.nw / HeadBwd.nw if set, else 8 while the launch is at most two workgroups per CU
+// waves per workgroup of a stage: HeadFwd.nw / HeadBwd.nw if set, else 8 while the launch is one round of one workgroup per CU
 static int head_nw(int want, int tiles) {
     static const int cus = [] {
         int d = 0, n = 0;
@@ -738,9 +738,10 @@ static int head_nw(int want, int tiles) {
     if (want == 4 || want == 8) return want;
     static const int env = [] { const char* e = getenv("EAGCN_HEAD_NW"); return e ? atoi(e) : 0; }();
     if (env == 4 || env == 8) return env;
-    // (round 6: up to TWO workgroups per CU: dense 1's backward at 256 molecules is 352 tiles; step 0.387 -> 0.383 ms at configs[1],
-    //  no difference at B = 1024 where every launch is beyond the limit; 8 everywhere costs 3 % there.  EAGCN_HEAD_NW = 4 | 8 | 8 x rounds)
-    return tiles <= cus * (env > 8 ? env / 8 : 2) ? 8 : 4;
+    // (round 6: eight waves up to TWO workgroups per CU -- dense 1's backward at 256 molecules is 352 tiles -- measured -1 % at
+    //  configs[1] while the side stream's index build was held back behind the forward, and +1.6 % (0.366 -> 0.372 ms) once it was
+    //  not: one round it stays.  EAGCN_HEAD_NW = 4 | 8 | 8 x rounds + 1)
+    return tiles <= cus * (env > 8 ? env / 8 : 1) ? 8 : 4;
 }
 int head_fwd(const HeadFwd& a, hipStream_t s) {
     EAGCN_CHECK_ARG(a.st_copies >= 1 && a.st_copies <= HEAD_COPIES, "head: %d replicas of the BatchNorm sums", a.st_copies);

@@ -368,7 +368,8 @@ typedef struct eagcn_model {
                                                instead of bn_apply + read-out + column statistics).  The matrix
                                                (atom_representations, models.py:102) is built on request by
                                                eagcn_model_atom_rep_materialize.  Ignored for other structures.            */
-    uint32_t* fwd_signal;                   /* optional device word: the forward adds 1 to it behind the read-out, i.e. when the
+    uint32_t* fwd_signal;                   /* optional device word: the forward adds 1 to it behind the read-out (the head's first
+                                               launch does, with a relaxed atomic: the word places work, it guards no data), i.e. when the
                                                layer products / aggregations of the step have been issued and only short kernels
                                                follow for a while (head, loss, head backward, the top BatchNorm backward).  Another
                                                stream can wait for a count with eagcn_stream_wait_counter: the caller's batch

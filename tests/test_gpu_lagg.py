@@ -1,9 +1,9 @@
 """The LDS-staged bond-list aggregation (csrc/lagg.hip; reference layers.py:82-92 forward, and its autograd: transposed aggregation
 + the edge gradients of att.weight / self_r): the same operator as the matrix-core kernels of csrc/agg.hip, exact including the 1e-9
-filler.  By default it is the BACKWARD of every Concate layer, the forward for batches of up to 256 molecules and both directions for large molecules
-(padded size >= 240 with >= 96 atoms per molecule; csrc/lagg.hip lagg_use); here it is FORCED everywhere
-(EAGCN_AGG=lds, read once per process: subprocesses) over small / ragged / isolated-atom / self-loop batches, both merges, widths
-that end in a half chunk, eager and graph mode -- against the dense kernels and against the CPU oracle."""
+filler.  Since round 6 it is the DEFAULT in both directions for every layer whose padded size is at most 256 atoms (csrc/lagg.hip
+lagg_use; Weighted_sum layers re-form dH from the upstream gradient in its staging); here it is compared with the dense kernels
+(EAGCN_AGG=lds against EAGCN_AGG=dense, read once per process: subprocesses) over small / ragged / isolated-atom / self-loop batches,
+both merges, widths that end in a half chunk, eager and graph mode, one and several column chunks per workgroup -- and with the CPU oracle."""
 import os
 import subprocess
 import sys
