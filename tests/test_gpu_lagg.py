@@ -124,7 +124,7 @@ worst = (0.0, '')
 for (k, p), (_, q) in zip(ref.named_parameters(), hip.named_parameters()):
     if p.grad is None: continue
     dd = (q.grad.detach().cpu().double() - p.grad).abs().max().item()
-    tol = 2e-5 * p.grad.abs().max().item() + 4e-6 * scale
+    tol = 1e-5 * p.grad.abs().max().item() + 2e-6 * scale      # (north-star 1e-5; round 6: was 2e-5 + 4e-6, achieved 0.09 of that)
     worst = max(worst, (dd / tol, k))
     assert dd <= tol, (k, dd, tol)
 print('LAGG_ORACLE_OK out %%.1e worst grad / tol %%.2f (%%s)' %% (err, worst[0], worst[1]))
@@ -181,7 +181,7 @@ torch.save({'sd': {k: v.cpu() for k, v in m.state_dict().items()}, 'cot': cot.cp
             if p.grad is None:
                 continue
             dd = (got['g'][k].double() - p.grad).abs().max().item()
-            tol = 2e-5 * p.grad.abs().max().item() + 4e-6 * scale
+            tol = 1e-5 * p.grad.abs().max().item() + 2e-6 * scale      # (round 6: was 2e-5 + 4e-6, achieved 0.08-0.11 of that)
             worst = max(worst, (dd / tol, k))
             assert dd <= tol, (structure, k, dd, tol)
         print('%s: worst gradient distance to the float64 oracle / tolerance %.2f (%s)' % (structure, worst[0], worst[1]))

@@ -870,7 +870,7 @@ def test_model_vs_oracle_baseline_widths(name, graph):
     """Every BASELINE.json config at its own widths, view count and padding (small B so the CPU oracle takes
     seconds), eager engine and graph replay.  Outputs and BatchNorm buffers to 1e-5; every parameter gradient either
     within 1e-5 of the fp32 oracle (relative to the tensor's own largest entry) or -- where fp32 itself is not that
-    reproducible -- at most 2x as far from the fp64 oracle as the fp32 oracle is.  Instances with an activation on the
+    reproducible -- at most as far from the fp64 oracle as the fp32 oracle is (slack 1; named exceptions in KNOWN_FARTHER).  Instances with an activation on the
     relu boundary (see _relu_flips) are compared in their outputs only and the next seed is taken for the gradients."""
     from eagcn_amd import EAGCN
     from eagcn_amd.synthetic import make_batch
@@ -964,8 +964,15 @@ def test_fused_losses_golden(name, graph):
         loss.backward()
         got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
         assert set(got) == set(grads)
+        f64 = {}
+
+        def exact(k):                     # (the float64 oracle's gradients of the case, evaluated when a tensor needs them)
+            if not f64:
+                f64.update(_f64_grads(g))
+            return f64[k]
         for k, ref in grads.items():
-            assert_grad_close(got[k], ref, scale, '%s rep%d' % (k, rep), rtol=2e-5, floor=2e-6)
+            assert_grad_parity(got[k], ref, lambda k=k: exact(k), scale, '%s rep%d' % (k, rep), rtol=1e-5, floor=2e-6, slack=1.0,
+                               known=KNOWN_FARTHER.get(name))
 
 
 @pytest.mark.parametrize('graph', [False, True])
@@ -1153,11 +1160,11 @@ def test_training_dropout_masks_injected_into_oracle(structure, graph):
             scale = max(v.abs().max().item() for v in p32.values())
             for k in gh:
                 try:
-                    assert_grad_close(gh[k], p32[k], scale, '%s %s' % (tag, k), rtol=2e-5, floor=2e-6)
+                    assert_grad_close(gh[k], p32[k], scale, '%s %s' % (tag, k), rtol=1e-5, floor=2e-6)
                 except AssertionError:
                     e_ref = (p32[k].double() - p64[k]).abs().max().item()
                     e_hip = (gh[k].double().cpu() - p64[k]).abs().max().item()
-                    if e_hip > 4.0 * e_ref + 2e-6 * scale:
+                    if e_hip > 1.0 * e_ref + 2e-6 * scale:
                         ok = False                      # an activation on the relu boundary: next seed
                         break
             if not ok:
@@ -1284,8 +1291,8 @@ def test_gat_layer_training_mode_with_injected_dropout_masks():
     Wg, ag = ref_layer.graph_conv.W.grad, ref_layer.graph_conv.a.grad
     assert rel_err(got.detach().cpu(), ref.detach(), 'GAT layer, training mode, injected masks, vs oracle.RefGAT') < 1e-5
     scale = max(Wg.abs().max().item(), ag.abs().max().item())
-    assert_grad_close(layer.graph_conv.W.grad.cpu(), Wg.numpy(), scale, 'graph_conv.W', rtol=2e-5, floor=2e-6)
-    assert_grad_close(layer.graph_conv.a.grad.cpu(), ag.numpy(), scale, 'graph_conv.a', rtol=2e-5, floor=2e-6)
+    assert_grad_close(layer.graph_conv.W.grad.cpu(), Wg.numpy(), scale, 'graph_conv.W', rtol=1e-5, floor=2e-6)
+    assert_grad_close(layer.graph_conv.a.grad.cpu(), ag.numpy(), scale, 'graph_conv.a', rtol=1e-5, floor=2e-6)
 
 
 @pytest.mark.gpu
