@@ -839,6 +839,11 @@ FULL_WIDTH_CASES = {
     # oracle takes a few seconds per pass on the GPU box's host cores)
     'tox21_c2_full': dict(structure='Concate', n_layers=2, w1=[80] * 5, w2=[140] * 5, dens=(256, 64), nclass=12,
                           chans=[28, 4, 2, 2, 2], B=256, n_max=132, n_med=16, all_full=False),
+    # ... the same model at the north-star batch (B = 1024), and configs[3] (Lipophilicity) at its full per-GPU size (B = 512, N_pad 115)
+    'tox21_c2_b1024': dict(structure='Concate', n_layers=2, w1=[80] * 5, w2=[140] * 5, dens=(256, 64), nclass=12,
+                           chans=[28, 4, 2, 2, 2], B=1024, n_max=132, n_med=16, all_full=False),
+    'lipo_c4_full': dict(structure='Concate', n_layers=3, w1=[60] * 5, w2=[100] * 5, dens=(128, 64), nclass=1,
+                         chans=[18, 4, 2, 2, 2], B=512, n_max=115, n_med=27, all_full=False),
     'tox21_p4': dict(structure='Concate', n_layers=4, w1=[80] * 5, w2=[140] * 5, dens=(256, 64), nclass=12,
                      chans=[28, 4, 2, 2, 2], B=10, n_max=60, n_med=16, all_full=False),
 }
@@ -876,6 +881,10 @@ def test_model_vs_oracle_baseline_widths(name, graph):
     from eagcn_amd.synthetic import make_batch
     from oracle.eagcn_ref import RefEAGCN, weights_init_
     c = FULL_WIDTH_CASES[name]
+    # (the oracle takes ~100 s per case at these sizes -- fp32 and fp64 passes of 1024 x 132 / 512 x 115 padded rows: the default run keeps
+    #  the north-star batch through graph replay, what bench.py times; EAGCN_TEST_HEAVY=1 runs all four.  Last run: all green, round 6)
+    if (name == 'lipo_c4_full' or (name == 'tox21_c2_b1024' and not graph)) and os.environ.get('EAGCN_TEST_HEAVY', '0') != '1':
+        pytest.skip('full-size oracle case: EAGCN_TEST_HEAVY=1')
     kw = dict(structure=c['structure'], n_layers=c['n_layers'], rel_channels=c['chans'])
     tried = []
     for seed in (23, 24, 25, 26):
