@@ -214,6 +214,12 @@ SIGNATURES = {
                                              _fp, _fp, C.POINTER(LayerGrads), C.POINTER(HeadGrads), C.c_int, C.c_int, C.c_int, _fp]),
     'eagcn_model_forward_step': (C.c_int, [C.POINTER(Batch), C.POINTER(Model), _fp, _fp, _fp, C.c_size_t, _fp, C.c_size_t, _fp, _fp,
                                            C.POINTER(StepLoss), _fp, C.POINTER(HeadGrads), _fp]),
+    'eagcn_head_saved_bytes': (C.c_size_t, [C.POINTER(HeadParams), C.c_int]),
+    'eagcn_head_scratch_bytes': (C.c_size_t, [C.POINTER(HeadParams), C.c_int]),
+    'eagcn_head_forward': (C.c_int, [C.POINTER(HeadParams), C.c_int, C.c_int, C.c_uint64, _fp, _fp, _fp, C.c_size_t, _fp, C.c_size_t,
+                                     _fp, _fp, _fp]),
+    'eagcn_head_backward': (C.c_int, [C.POINTER(HeadParams), C.c_int, C.c_int, C.c_uint64, _fp, _fp, _fp, C.c_size_t, _fp, C.c_size_t,
+                                      _fp, _fp, C.POINTER(HeadGrads), _fp, _fp]),
     'eagcn_bce_loss': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     'eagcn_mse_loss': (C.c_int, [_fp, _fp, C.c_int, _fp, _fp, _fp]),
     'eagcn_eval_append': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int64, _fp]),
@@ -231,7 +237,7 @@ class EagcnHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 6    # include/eagcn_hip.h eagcn_abi_version(): struct layouts + signatures this binding was written against
+ABI_VERSION = 7    # include/eagcn_hip.h eagcn_abi_version(): struct layouts + signatures this binding was written against
 
 
 def load():

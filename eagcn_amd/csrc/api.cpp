@@ -89,7 +89,7 @@ extern "C" int eagcn_prof_read(int tag, double* total_ms, double* work, int64_t*
 
 // bumped whenever a struct of include/eagcn_hip.h changes its layout or an entry point its signature (round 4: plane fields of
 // eagcn_layer_bufs, eagcn_model.fwd_signal, row capacities of the plane-GEMM entry points); eagcn_amd/_lib.py refuses another version
-extern "C" int eagcn_abi_version(void) { return 6; }
+extern "C" int eagcn_abi_version(void) { return 7; }
 /* sizeof() of the ABI structs, so a binding can verify its own struct layout (which: 0 batch,
  * 1 layout, 2 layer_params, 3 layer_bufs, 4 layer_grads) */
 extern "C" size_t eagcn_struct_size(int which) {

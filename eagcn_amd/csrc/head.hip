@@ -494,6 +494,115 @@ extern "C" int eagcn_model_forward(const eagcn_batch* b, const eagcn_model* m, c
     return head_forward_launches(m, P, stream);
 }
 
+// ---- the head alone (include/eagcn_hip.h eagcn_head_*): the GAT baseline and the Diff_Pooling read-out form the molecule
+//      fingerprints through the layer-level entry points and hand them over here; stages and launch order are head_plan's ----------
+namespace eagcn {
+static int check_head(const eagcn_head_params* h, int B, int training, const char* who) {
+    EAGCN_CHECK_ARG(h, "%s: null argument", who);
+    EAGCN_CHECK_ARG(B >= 1 && h->f_in >= 1 && h->n_den1 >= 1 && h->n_den2 >= 1 && h->nclass >= 1, "%s: bad head sizes", who);
+    EAGCN_CHECK_ARG(h->den1_w && h->den2_w && h->den3_w && h->gbn_w && h->gbn_b && h->gbn_rm && h->gbn_rv && h->bn1_w && h->bn1_b &&
+                        h->bn1_rm && h->bn1_rv && h->bn2_w && h->bn2_b && h->bn2_rm && h->bn2_rv, "%s: null head parameter", who);
+    EAGCN_CHECK_ARG(!training || B > 1, "%s: BatchNorm in training mode needs more than one molecule", who);
+    return EAGCN_OK;
+}
+static size_t carve_head_saved(void* base, const eagcn_head_params* h, int B, ModelSaved* out) {
+    Carver2 c(base);
+    ModelSaved s;
+    memset(&s, 0, sizeof(s));
+    s.h1 = c.take<float>((size_t)B * h->n_den1);
+    s.h2 = c.take<float>((size_t)B * h->n_den2);
+    s.bn_g = c.take<float>((size_t)4 * h->f_in);
+    s.bn_1 = c.take<float>((size_t)4 * h->n_den1);
+    s.bn_2 = c.take<float>((size_t)4 * h->n_den2);
+    if (out) *out = s;
+    return c.off;
+}
+static size_t carve_head_scratch(void* base, const eagcn_head_params* h, int B, ModelScratch* out) {
+    Carver2 c(base);
+    ModelScratch s;
+    memset(&s, 0, sizeof(s));
+    s.n_hst = 2 * (h->f_in + h->n_den1 + h->n_den2) + 6;
+    s.hst = c.take<double>((size_t)(HEAD_COPIES + 1) * s.n_hst + HEAD_WS);
+    s.hsb = s.hst + (size_t)HEAD_COPIES * s.n_hst;
+    s.hws = s.hsb + s.n_hst;
+    s.da2 = c.take<float>((size_t)B * h->n_den2);
+    s.da1 = c.take<float>((size_t)B * h->n_den1);
+    s.dgn = c.take<float>((size_t)B * h->f_in);
+    s.hdw_ks = head_dw_chunks(B);
+    s.hdw = c.take<float>(s.hdw_ks > 1 ? (size_t)s.hdw_ks * ((size_t)h->f_in * h->n_den1 + (size_t)h->n_den1 * h->n_den2 +
+                                                             (size_t)h->n_den2 * h->nclass) : 1);
+    if (out) *out = s;
+    return c.off;
+}
+// (a kernel, not hipMemsetAsync: inside a captured step every node of the chain is then a kernel node)
+__global__ __launch_bounds__(256) void head_zero_kernel(double* __restrict__ p, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0.0;
+}
+static int head_zero(double* p, size_t n, hipStream_t s) {
+    head_zero_kernel<<<(unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 64)), 256, 0, s>>>(p, (int)n);
+    EAGCN_LAUNCH_CHECK();
+    return EAGCN_OK;
+}
+// the pieces of eagcn_batch / eagcn_model that head_plan reads
+static void head_alone_model(const eagcn_head_params* h, int B, int training, uint64_t seed, const uint64_t* seed_dev,
+                             eagcn_batch* b, eagcn_model* m) {
+    memset(b, 0, sizeof(*b));
+    memset(m, 0, sizeof(*m));
+    b->B = B;
+    m->head = *h; m->training = training ? 1 : 0; m->head_seed = seed; m->head_seed_dev = seed_dev;
+}
+}  // namespace eagcn
+
+extern "C" size_t eagcn_head_saved_bytes(const eagcn_head_params* h, int B) { return h ? carve_head_saved(nullptr, h, B, nullptr) : 0; }
+extern "C" size_t eagcn_head_scratch_bytes(const eagcn_head_params* h, int B) { return h ? carve_head_scratch(nullptr, h, B, nullptr) : 0; }
+
+extern "C" int eagcn_head_forward(const eagcn_head_params* h, int B, int training, uint64_t seed, const uint64_t* seed_dev,
+                                  const float* g, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, float* out,
+                                  float* graph_rep, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    RC(check_head(h, B, training, "eagcn_head_forward"));
+    EAGCN_CHECK_GEMM3("eagcn_head_forward");
+    EAGCN_CHECK_ARG(g && saved && scratch && out && graph_rep, "eagcn_head_forward: null buffer");
+    ModelSaved sv;
+    ModelScratch sc;
+    EAGCN_CHECK_ARG(carve_head_saved(saved, h, B, &sv) <= saved_bytes, "eagcn_head_forward: saved block too small");
+    EAGCN_CHECK_ARG(carve_head_scratch(scratch, h, B, &sc) <= scratch_bytes, "eagcn_head_forward: scratch too small");
+    eagcn_batch b;
+    eagcn_model m;
+    head_alone_model(h, B, training, seed, seed_dev, &b, &m);
+    sv.g = const_cast<float*>(g);                   // (read only: the stages take the fingerprints where the caller holds them)
+    const int F = h->f_in, n1 = h->n_den1, n2 = h->n_den2;
+    RC(head_zero(sc.hst, (size_t)(HEAD_COPIES + 1) * sc.n_hst + HEAD_WS, s));
+    double *st_g = sc.hst, *st_1 = sc.hst + 2 * F + 2, *st_2 = sc.hst + 2 * (F + n1) + 4;
+    RC(head_colstats(g, B, F, st_g, s, st_g + 2 * F, st_1 + 2 * n1, st_2 + 2 * n2));
+    const HeadPlan P = head_plan(&b, &m, sv, sc, out, graph_rep, nullptr, nullptr, nullptr);
+    return head_forward_launches(&m, P, stream);
+}
+
+extern "C" int eagcn_head_backward(const eagcn_head_params* h, int B, int training, uint64_t seed, const uint64_t* seed_dev,
+                                   const float* g, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                                   const float* dout, const float* dgraph_rep, const eagcn_head_grads* hg, float* dg, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    RC(check_head(h, B, training, "eagcn_head_backward"));
+    EAGCN_CHECK_GEMM3("eagcn_head_backward");
+    EAGCN_CHECK_ARG(g && saved && scratch && dout && hg && dg, "eagcn_head_backward: null buffer");
+    EAGCN_CHECK_ARG(hg->d_den1_w && hg->d_den2_w && hg->d_den3_w && hg->d_gbn_w && hg->d_gbn_b && hg->d_bn1_w && hg->d_bn1_b &&
+                        hg->d_bn2_w && hg->d_bn2_b, "eagcn_head_backward: null head gradient");
+    ModelSaved sv;
+    ModelScratch sc;
+    EAGCN_CHECK_ARG(carve_head_saved(saved, h, B, &sv) <= saved_bytes, "eagcn_head_backward: saved block too small");
+    EAGCN_CHECK_ARG(carve_head_scratch(scratch, h, B, &sc) <= scratch_bytes, "eagcn_head_backward: scratch too small");
+    eagcn_batch b;
+    eagcn_model m;
+    head_alone_model(h, B, training, seed, seed_dev, &b, &m);
+    sv.g = const_cast<float*>(g);
+    sc.dg = dg;
+    // (the scratch is transient: nothing of the forward call is expected in it; the backward sums start from zero)
+    RC(head_zero(sc.hsb, (size_t)sc.n_hst, s));
+    const HeadPlan P = head_plan(&b, &m, sv, sc, nullptr, nullptr, dout, dgraph_rep, hg);
+    return head_backward_launches(&m, P, stream);
+}
+
 namespace eagcn {
 __global__ void scale_loss_kernel(float* __restrict__ loss, float* __restrict__ dout, int n, const float* __restrict__ scale) {
     const float sc = *scale;

@@ -2,8 +2,8 @@
 and the Diff_Pooling read-out (molfp_mode='pool', models.py:104-106, layers.py:492-506).
 
 These models have no model-level C plan (eagcn_model_forward / _backward know the edge-attention layers and the sum / ave
-read-out); their step is the sequence of layer-level entry points `EAGCN._forward_composed_index` issues, the head as torch
-ops, autograd in between.  Every kernel of that sequence takes its row counts from device memory and its grid from static
+read-out); their step is the sequence of layer-level entry points `EAGCN._forward_composed_index` issues -- the layers, the
+read-out, the head (eagcn_head_forward / _backward) -- with autograd in between.  Every kernel of that sequence takes its row counts from device memory and its grid from static
 capacities, so for a fixed (model, B, N) the whole step -- forward, fused loss, autograd backward -- is captured ONCE into a
 HIP graph over static buffers and replayed:
 
@@ -47,7 +47,7 @@ class ComposedRunner:
         self.scale = torch.ones((), **f32)
         self.scale_is_one = True
         self.seeds = torch.zeros(8, dtype=torch.int64, device=device)
-        self.seed_views = [self.seeds[i:i + 1] for i in range(4)]
+        self.seed_views = [self.seeds[i:i + 1] for i in range(5)]          # four layers + the head's dropout
         self.seeds_host = torch.zeros(8, dtype=torch.int64).pin_memory()
         self.meta_host = torch.zeros(L.META_WORDS, dtype=torch.int32).pin_memory()
         self.pending = None            # event after the last batch's index build + uploads (its meta words are valid behind it)
@@ -100,7 +100,8 @@ class ComposedRunner:
             sn = self.seeds_host.numpy()
             for l in range(4):
                 sn[l] = (base + 7919 * (l + 1)) & (2 ** 63 - 1)
-            self.last_seeds = [int(v) for v in sn[:4]]
+            sn[4] = (base + 0x51ED27) & (2 ** 63 - 1)
+            self.last_seeds = [int(v) for v in sn[:5]]
             self.seeds.copy_(self.seeds_host, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(stream)

@@ -518,12 +518,27 @@ class EAGCN(nn.Module):
             g = self.pool1.pooled_sum(index, layout, x, pad, self.graph_layers()[-1])
         else:
             g = ops.readout(index, layout, x, pad, self.molfp_mode, size)  # models.py:108-111
+        out, graph_representation = self.head_forward(g, None if seeds is None else seeds[4])
+        return out, LazyAtomRep(index, layout, x, pad), graph_representation
+
+    def head_forward(self, g, seed=None):
+        """models.py:112-120 on molecule fingerprints g [B, f_last] -> (out, graph_representation): the head's kernels
+        (csrc/head2.hip through eagcn_head_forward / eagcn_head_backward, hand-written backward) -- the same stages the model-level
+        engine runs behind its read-out.  ``seed``: dropout seed (int, or a 1-element int64 device tensor in graph mode); default: drawn."""
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (self.training and self.dropout > 0) else 0
+        mods = {n: getattr(self, n) for n in ('den1', 'den2', 'den3', 'Graph_BN', 'bn_den1', 'bn_den2')}
+        return ops.head_forward(mods, g, self.training, seed, self.dropout)
+
+    def head_forward_torch(self, g):
+        """The same head as torch ops (BatchNorm1d / relu / dropout modules around the Dense products): kept as the cross-check of
+        ``head_forward`` in tests/test_gpu_head.py; no product path calls it."""
         g = self.Graph_BN(g)
         h = F.relu(self.bn_den1(self.den1(g)))
         h = F.dropout(h, p=self.dropout, training=self.training)
         graph_representation = self.den2(h)
         out = self.den3(F.relu(self.bn_den2(graph_representation)))
-        return out, LazyAtomRep(index, layout, x, pad), graph_representation
+        return out, graph_representation
 
 
 class Concate_GCN(EAGCN):

@@ -737,6 +737,22 @@ def gemm(a, b, ta=False, tb=False, rows_of=None, which=0):
 # ------------------------------------------------------------------------------------------------
 # whole model: one C call forward, one backward
 # ------------------------------------------------------------------------------------------------
+def fill_head_params(hp, h, dropout):
+    """eagcn_head_params (include/eagcn_hip.h) of the head modules h = {den1, den2, den3, Graph_BN, bn_den1, bn_den2}."""
+    hp.f_in, hp.n_den1 = h['den1'].weight.shape
+    hp.n_den2, hp.nclass = h['den3'].weight.shape
+    hp.dropout = float(dropout)
+    hp.bn_eps, hp.bn_momentum = float(h['Graph_BN'].eps), float(h['Graph_BN'].momentum)
+    hp.den1_w, hp.den2_w, hp.den3_w = (h['den1'].weight.data_ptr(), h['den2'].weight.data_ptr(),
+                                       h['den3'].weight.data_ptr())
+    for pre, mod in (('gbn', h['Graph_BN']), ('bn1', h['bn_den1']), ('bn2', h['bn_den2'])):
+        setattr(hp, pre + '_w', mod.weight.data_ptr())
+        setattr(hp, pre + '_b', mod.bias.data_ptr())
+        setattr(hp, pre + '_rm', mod.running_mean.data_ptr())
+        setattr(hp, pre + '_rv', mod.running_var.data_ptr())
+    return hp
+
+
 _scratch_cache = {}
 
 
@@ -854,18 +870,7 @@ class ModelPlan:
                               'run_mean': bn.running_mean, 'run_var': bn.running_var})
             ave = layer.ave.weight if layer.structure == 'Weighted_sum' else None
             m.layer[l] = spec.cparams(training, (int(seed) + 7919 * (l + 1)) & (2 ** 63 - 1), views, ave)
-        h, hp = self.head, m.head
-        hp.f_in, hp.n_den1 = h['den1'].weight.shape
-        hp.n_den2, hp.nclass = h['den3'].weight.shape
-        hp.dropout = float(dropout)
-        hp.bn_eps, hp.bn_momentum = float(h['Graph_BN'].eps), float(h['Graph_BN'].momentum)
-        hp.den1_w, hp.den2_w, hp.den3_w = (h['den1'].weight.data_ptr(), h['den2'].weight.data_ptr(),
-                                           h['den3'].weight.data_ptr())
-        for pre, mod in (('gbn', h['Graph_BN']), ('bn1', h['bn_den1']), ('bn2', h['bn_den2'])):
-            setattr(hp, pre + '_w', mod.weight.data_ptr())
-            setattr(hp, pre + '_b', mod.bias.data_ptr())
-            setattr(hp, pre + '_rm', mod.running_mean.data_ptr())
-            setattr(hp, pre + '_rv', mod.running_var.data_ptr())
+        fill_head_params(m.head, self.head, dropout)
         m.fuse_readout = int(self.fuse_readout)
         if self.stats is not None:                    # sync-BatchNorm: cross-rank sums through eagcn_amd.parallel.StatsAllReducer
             m.stats_hook = C.cast(self.stats.cfn, C.c_void_p)
@@ -980,3 +985,77 @@ def model_forward(plan, index, holder, training, seed, dropout, size, afm, direc
             plan.trigger = torch.zeros((), dtype=torch.float32, device=afm.device, requires_grad=True)
         return _ModelFn.apply(plan, index, holder, training, seed, dropout, size, afm, plan.trigger)
     return _ModelFn.apply(plan, index, holder, training, seed, dropout, size, afm, None, *plan.params)
+
+
+# ------------------------------------------------------------------------------------------------
+# the head alone (reference models.py:112-120) behind fingerprints formed by layer-level ops: GAT baseline, Diff_Pooling read-out
+# ------------------------------------------------------------------------------------------------
+HEAD_PARAMS = (('den1', 'weight'), ('den2', 'weight'), ('den3', 'weight'), ('Graph_BN', 'weight'), ('Graph_BN', 'bias'),
+               ('bn_den1', 'weight'), ('bn_den1', 'bias'), ('bn_den2', 'weight'), ('bn_den2', 'bias'))
+
+
+class _HeadFn(torch.autograd.Function):
+    """(g [B, f_in], the nine head parameters) -> (out, graph_representation): one call into eagcn_head_forward (csrc/head.hip:
+    Graph_BN statistics + three fused BatchNorm / product stages of csrc/head2.hip), one into eagcn_head_backward; running
+    statistics are updated in place by the kernels."""
+
+    @staticmethod
+    def forward(ctx, mods, training, seed, dropout, g, *params):
+        lib = L.load()
+        g = _need_cuda_f32(g, 'molecule fingerprints')
+        for (mn, pn), t in zip(HEAD_PARAMS, params):
+            if t is not getattr(mods[mn], pn):
+                raise L.EagcnHipError('head: parameter %s.%s is not the module\'s own tensor' % (mn, pn))
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                raise L.EagcnHipError('head: %s.%s must be a contiguous fp32 device tensor' % (mn, pn))
+        for mn in ('den1', 'den2', 'den3'):
+            if getattr(mods[mn], 'bias', None) is not None:
+                raise L.EagcnHipError('head: Dense layers with a bias are not supported (models.py:86-88 builds them without)')
+        hp = fill_head_params(L.HeadParams(), mods, dropout)
+        B = int(g.shape[0])
+        if g.shape != (B, hp.f_in):
+            raise L.EagcnHipError('head: fingerprints are %s, den1 expects [B, %d]' % (tuple(g.shape), hp.f_in))
+        host_seed, seed_dev = _seed_fields(seed)
+        dev = g.device
+        sbytes, wbytes = lib.eagcn_head_saved_bytes(C.byref(hp), B), lib.eagcn_head_scratch_bytes(C.byref(hp), B)
+        saved = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+        scratch = _scratch(dev, wbytes)
+        out = torch.empty((B, hp.nclass), dtype=torch.float32, device=dev)
+        graph_rep = torch.empty((B, hp.n_den2), dtype=torch.float32, device=dev)
+        L.check(lib.eagcn_head_forward(C.byref(hp), B, int(bool(training)), host_seed, C.c_void_p(seed_dev or 0), _ptr(g),
+                                       _ptr(saved), sbytes, _ptr(scratch), scratch.numel(), _ptr(out), _ptr(graph_rep),
+                                       _stream()), 'eagcn_head_forward')
+        if training:
+            torch._foreach_add_([mods[n].num_batches_tracked for n in ('Graph_BN', 'bn_den1', 'bn_den2')], 1)
+        ctx.hp, ctx.B, ctx.training, ctx.seed, ctx.seed_keep = hp, B, int(bool(training)), (host_seed, seed_dev), seed
+        ctx.saved_blob = saved
+        ctx.save_for_backward(g, *params)
+        return out, graph_rep
+
+    @staticmethod
+    def backward(ctx, dout, dgraph_rep):
+        lib = L.load()
+        g, *params = ctx.saved_tensors                 # (version check of the parameters by autograd)
+        hp, B, saved = ctx.hp, ctx.B, ctx.saved_blob
+        dev = g.device
+        dout = dout.contiguous()
+        dgr = dgraph_rep.contiguous() if dgraph_rep is not None else None
+        grads = [torch.empty_like(p) for p in params]
+        hg = L.HeadGrads()
+        for name, t in zip(('d_den1_w', 'd_den2_w', 'd_den3_w', 'd_gbn_w', 'd_gbn_b', 'd_bn1_w', 'd_bn1_b', 'd_bn2_w', 'd_bn2_b'),
+                           grads):
+            setattr(hg, name, t.data_ptr())
+        dg = torch.empty_like(g)
+        scratch = _scratch(dev, lib.eagcn_head_scratch_bytes(C.byref(hp), B))
+        host_seed, seed_dev = ctx.seed
+        L.check(lib.eagcn_head_backward(C.byref(hp), B, ctx.training, host_seed, C.c_void_p(seed_dev or 0), _ptr(g), _ptr(saved),
+                                        saved.numel(), _ptr(scratch), scratch.numel(), _ptr(dout), _ptr(dgr), C.byref(hg),
+                                        _ptr(dg), _stream()), 'eagcn_head_backward')
+        return (None, None, None, None, dg, *grads)
+
+
+def head_forward(mods, g, training, seed, dropout):
+    """out, graph_representation of the head modules ``mods`` on the fingerprints ``g``; ``seed``: an int or a 1-element int64
+    device tensor (graph mode)."""
+    params = [getattr(mods[mn], pn) for mn, pn in HEAD_PARAMS]
+    return _HeadFn.apply(mods, training, seed, dropout, g, *params)

@@ -219,7 +219,7 @@ int eagcn_agg_wants_bond_lists(int B, int N);
 int eagcn_agg_wants_bond_lists_for(int B, int N, int structure);
 
 /* ---- library ------------------------------------------------------------------------------- */
-int eagcn_abi_version(void);           /* 6 (round 6); bumped with every struct-layout / signature change */
+int eagcn_abi_version(void);           /* 7 (round 6, second half: eagcn_head_*); bumped with every struct-layout / signature change */
 size_t eagcn_struct_size(int which);   /* 0 batch, 1 layout, 2 layer_params, 3 layer_bufs, 4 layer_grads,
                                           5 head_params, 6 head_grads, 7 model, 8 gat_params, 9 pool_att */
 const char* eagcn_last_error(void);
@@ -455,6 +455,23 @@ int eagcn_model_forward_step(const eagcn_batch* b, const eagcn_model* m, const f
                              void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, float* out,
                              float* graph_rep, const eagcn_step_loss* loss, const float* dgraph_rep,
                              const eagcn_head_grads* hg, void* stream);
+
+/* ---- the head ALONE (models.py:112-120: Graph_BN -> den1 -> bn_den1 -> relu -> dropout -> den2 = graph_representation ->
+ * bn_den2 -> relu -> den3) for callers that form the molecule fingerprints g [B][f_in] themselves: the GAT baseline
+ * (models.py:69-73) and the Diff_Pooling read-out (models.py:104-106), whose layers run through the layer-level entry points.
+ * Same kernels, same launch sequence as the head inside eagcn_model_forward / eagcn_model_backward (four launches + one clear
+ * per direction).  saved: eagcn_head_saved_bytes, written by the forward, read by the backward (the caller keeps g as well);
+ * scratch: eagcn_head_scratch_bytes, transient per call.  training != 0 updates the running statistics in place and needs B > 1.
+ * seed / seed_dev: the head's dropout stream (seed_dev: a device-resident seed, read by the kernels -- captured launches).
+ * The backward writes d loss / d g into dg [B][f_in] and every head gradient through hg. */
+size_t eagcn_head_saved_bytes(const eagcn_head_params* h, int B);
+size_t eagcn_head_scratch_bytes(const eagcn_head_params* h, int B);
+int eagcn_head_forward(const eagcn_head_params* h, int B, int training, uint64_t seed, const uint64_t* seed_dev, const float* g,
+                       void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, float* out, float* graph_rep,
+                       void* stream);
+int eagcn_head_backward(const eagcn_head_params* h, int B, int training, uint64_t seed, const uint64_t* seed_dev, const float* g,
+                        void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, const float* dout,
+                        const float* dgraph_rep, const eagcn_head_grads* hg, float* dg, void* stream);
 
 /* ---- losses of the training loop (train.py:321-331), value + d/dlogits in one launch --------------- */
 /* labels [B][T] with 1 / 0 / anything else = missing; class_weight [T][2] = {w_pos, w_neg} (utils.py:681-700) */

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'libeagcn_hip.so does not export %s' % name
     assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
-    assert lib.eagcn_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.eagcn_abi_version() == _lib.ABI_VERSION == 7
     assert lib.eagcn_pad16(140) == 144 and lib.eagcn_pad16(80) == 80
 
 
