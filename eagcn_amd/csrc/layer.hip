@@ -265,6 +265,9 @@ struct ApplyArgs {
     float* pad_row;
     int do_drop; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
     BxOut planes;                // optional: the operand planes of the next layer's products (gemm_bx3.hip), written here
+    int tile_map;                // element -> lane map: 0: row-major groups of four columns (a wavefront = 256 columns of one row: eight
+                                 // 64-byte pieces per plane image); 1: a wavefront = 8 rows x one 32-column panel = 512 CONTIGUOUS bytes
+                                 // of every plane image (bx3.h: panel-major) and eight 128-byte row segments of the fp32 matrices
 };
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
@@ -285,10 +288,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
     const int T = dev_rows(a.bt);
     // (element index -> (row, column group) with a 32-bit division: T * columns / 4 of any batch that fits the index fits 31 bits)
     if (a.structure == EAGCN_STRUCT_CONCATE) {
-        const uint32_t g4 = fp / 4;
-        const uint32_t total = (uint32_t)T * g4;
+        const uint32_t g4 = a.tile_map ? ((uint32_t)(fp + 31) >> 5) : fp / 4;
+        const uint32_t total = a.tile_map ? (((uint32_t)T + 7) >> 3) * g4 * 64u : (uint32_t)T * g4;
         for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-            const int r = (int)(e / g4), c = (int)(e - (uint32_t)r * g4) * 4;
+            int r, c;
+            if (a.tile_map) {                        // 64 lanes = 8 rows x one 32-column panel (see ApplyArgs.tile_map)
+                const uint32_t it = e >> 6, rg = it / g4;
+                r = (int)(rg * 8u + ((e >> 3) & 7u)); c = (int)((it - rg * g4) * 32u + (e & 7u) * 4u);
+                if (r >= T || c >= fp) continue;
+            } else {
+                r = (int)(e / g4); c = (int)(e - (uint32_t)r * g4) * 4;
+            }
             const float4 y = *reinterpret_cast<const float4*>(a.Y + (size_t)r * a.ldy + c);
             const float4 sc = *reinterpret_cast<const float4*>(a.bn + BN_SC * fp + c);
             const float4 sh = *reinterpret_cast<const float4*>(a.bn + BN_SH * fp + c);
@@ -309,10 +319,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
     } else {
         // weighted sum over the views: a thread owns four adjacent output columns, the K view loads of a row are independent
         // 16-byte loads (view column ranges and the output pitch are multiples of 16)
-        const uint32_t g4 = a.ldo / 4;
-        const uint32_t total = (uint32_t)T * g4;
+        const uint32_t g4 = a.tile_map ? ((uint32_t)(a.ldo + 31) >> 5) : a.ldo / 4;
+        const uint32_t total = a.tile_map ? (((uint32_t)T + 7) >> 3) * g4 * 64u : (uint32_t)T * g4;
         for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-            const int r = (int)(e / g4), f = (int)(e - (uint32_t)r * g4) * 4;
+            int r, f;
+            if (a.tile_map) {
+                const uint32_t it = e >> 6, rg = it / g4;
+                r = (int)(rg * 8u + ((e >> 3) & 7u)); f = (int)((it - rg * g4) * 32u + (e & 7u) * 4u);
+                if (r >= T || f >= a.ldo) continue;
+            } else {
+                r = (int)(e / g4); f = (int)(e - (uint32_t)r * g4) * 4;
+            }
             float4 y[EAGCN_MAX_VIEWS];
 #pragma unroll
             for (int k = 0; k < EAGCN_MAX_VIEWS; ++k)
@@ -1125,7 +1142,10 @@ static int apply_launch_(const eagcn_batch* b, const eagcn_layer_params* p, cons
     aa.seed = p->seed;
     aa.seed_dev = p->seed_dev;
     aa.planes = BxOut{gemm_planes() ? w->xout_planes : nullptr, bx_plane_elems(b->T, d.ldo), gemm_planes(), b->T};
-    bn_apply_kernel<<<ew_grid((size_t)std::max(b->T, 1) * d.ldo / 4), 256, 0, s>>>(aa);
+    static const int map_env = [] { const char* v = getenv("EAGCN_BN_APPLY_MAP"); return v ? atoi(v) : -1; }();
+    aa.tile_map = map_env >= 0 ? map_env : (aa.planes.p ? 1 : 0);
+    const size_t nthr = aa.tile_map ? (size_t)cdiv(std::max(b->T, 1), 8) * cdiv(d.ldo, 32) * 64 : (size_t)std::max(b->T, 1) * d.ldo / 4;
+    bn_apply_kernel<<<ew_grid(nthr), 256, 0, s>>>(aa);
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
