@@ -239,6 +239,11 @@ static bool fused_readout(const eagcn_model* m) {
     return env && m->fuse_readout && m->layer[m->n_layers - 1].structure == EAGCN_STRUCT_CONCATE;
 }
 
+// layer l's output is needed as plane images only: it has them, and the layer above reads nothing else (forward and backward)
+static bool hidden_planes_only(const eagcn_batch* b, const eagcn_model* m, const ModelSaved& sv, int l) {
+    return l + 1 < m->n_layers && sv.L[l].xout_planes && layer_reads_planes_only(b, &m->layer[l + 1], m->aux_stream != nullptr);
+}
+
 static void fill_drop(float p, int training, int* do_drop, uint32_t* thr, float* inv_keep) {
     *do_drop = (training && p > 0.0f) ? 1 : 0;
     *thr = (uint32_t)std::min(4294967295.0, (double)p * 4294967296.0);
@@ -405,8 +410,10 @@ static int model_forward_trunk(const eagcn_batch* b, const eagcn_model* m, const
         w.scratch = sc.layer; w.scratch_bytes = sc.layer_bytes; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
         w.stats_hook = m->stats_hook; w.stats_user = m->stats_user;
         w.x_planes = l > 0 ? sv.L[l - 1].xout_planes : nullptr; w.xout_planes = L.xout_planes;
-        RC(layer_forward_impl(b, &m->layer[l], &w, stream, true, l == m->n_layers - 1 && fused_readout(m)));
-        x = L.xout;
+        // a hidden layer whose consumer reads plane images in both directions leaves no fp32 output (layer.hip bn_apply)
+        const bool po = hidden_planes_only(b, m, sv, l);
+        RC(layer_forward_impl(b, &m->layer[l], &w, stream, true, l == m->n_layers - 1 && fused_readout(m), po));
+        x = po ? nullptr : L.xout;
     }
     const eagcn_layer_params* last = &m->layer[m->n_layers - 1];
     const LayerSaved& LL = sv.L[m->n_layers - 1];
@@ -717,7 +724,7 @@ extern "C" int eagcn_model_backward_range(const eagcn_batch* b, const eagcn_mode
         LayerSaved& L = sv.L[l];
         eagcn_layer_bufs w;
         memset(&w, 0, sizeof(w));
-        w.x = l == 0 ? sv.x0 : sv.L[l - 1].xout;
+        w.x = l == 0 ? sv.x0 : (hidden_planes_only(b, m, sv, l - 1) ? nullptr : sv.L[l - 1].xout);
         w.P = L.P; w.Y = L.Y; w.rscale = L.rscale; w.bn = L.bn; w.xout = L.xout; w.pad_row = L.pad_row;
         w.scratch = sc.layer; w.scratch_bytes = sc.layer_bytes; w.packed = L.packed; w.packed_bytes = L.packed_bytes;
         w.aux_stream = m->aux_stream;

@@ -257,8 +257,14 @@ int layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const
                         const eagcn_layer_grads* g, void* stream, bool dpad_views = false,
                         const ZeroJob* zero_after = nullptr, const EdgeDrain* drain_in = nullptr, EdgeDrain* drain_out = nullptr);
 // skip_apply: stop after the BatchNorm table (the caller applies it while it consumes Y: fused read-out of the top layer)
+// planes_only: the output leaves as the operand planes of the next layer's products ONLY (w->xout_planes; the fp32 matrix w->xout
+// is not written): the model engine asks for it when layer_reads_planes_only() holds for the layer above
 int layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, void* stream,
-                       bool prepacked, bool skip_apply = false);
+                       bool prepacked, bool skip_apply = false, bool planes_only = false);
+// true when BOTH directions of layer p take their input x from its bf16 plane images and never from the fp32 matrix (forward
+// product and the dX / dW pair on gemm_bx3.hip: the same conditions layer_forward_impl / layer_backward_impl test); a layer that
+// is then handed w->x == nullptr fails loudly if it reaches a fallback
+bool layer_reads_planes_only(const eagcn_batch* b, const eagcn_layer_params* p, bool aux_stream);
 // relu / dropout / mask / view merge of a layer from its saved Y and BatchNorm table (what layer_forward_impl ends with)
 int layer_apply_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, void* stream);
 int pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const* ps, void* const* packed,

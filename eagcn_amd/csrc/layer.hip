@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
                 drop_scale4(seed, (uint64_t)r * fp + c, a.thr, a.inv_keep, ds);
                 o.x *= ds[0]; o.y *= ds[1]; o.z *= ds[2]; o.w *= ds[3];
             }
-            *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + c) = o;
+            if (a.out) *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + c) = o;
             if (a.planes.p) bx_store4(a.planes, r, c, o);
         }
     } else {
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
                     }
                     acc.x += w.x * p.x; acc.y += w.y * p.y; acc.z += w.z * p.z; acc.w += w.w * p.w;
                 }
-            *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + f) = acc;
+            if (a.out) *reinterpret_cast<float4*>(a.out + (size_t)r * a.ldo + f) = acc;
             if (a.planes.p) bx_store4(a.planes, r, f, acc);
         }
     }
@@ -946,7 +946,7 @@ static inline int ew_grid(size_t n) { return (int)std::max<size_t>(1, std::min<s
 }  // namespace eagcn
 
 static int apply_launch_(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, const eagcn::LayerDims& d,
-                         const float* colp, hipStream_t s);
+                         const float* colp, hipStream_t s, bool planes_only = false);
 #define apply_launch apply_launch_
 
 using namespace eagcn;
@@ -1014,12 +1014,14 @@ int eagcn::pack_params_all(const eagcn_batch* b, const eagcn_layer_params* const
 }
 
 int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w,
-                              void* stream, bool prepacked, bool skip_apply) {
+                              void* stream, bool prepacked, bool skip_apply, bool planes_only) {
     hipStream_t s = (hipStream_t)stream;
     int rc = check_layer(b, p, "eagcn_layer_forward");
     if (rc) return rc;
     EAGCN_CHECK_ARG(w && w->bn && w->xout && w->pad_row && w->scratch, "eagcn_layer_forward: null buffer");
-    EAGCN_CHECK_ARG(b->T == 0 || (w->x && w->P && w->Y && w->rscale), "eagcn_layer_forward: null activation buffer");
+    // (w->x may be null when the layer below wrote plane images only: every fp32 fallback below then refuses)
+    EAGCN_CHECK_ARG(b->T == 0 || ((w->x || w->x_planes) && w->P && w->Y && w->rscale), "eagcn_layer_forward: null activation buffer");
+    EAGCN_CHECK_ARG(!planes_only || (w->xout_planes && gemm_planes()), "eagcn_layer_forward: planes-only output without plane images");
     const LayerDims d = layer_dims(b, p);
     FwdScratch sc;
     const size_t need = carve_fwd(w->scratch, b, d, &sc);
@@ -1064,6 +1066,7 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
             const size_t xstride = bx_plane_elems(b->T, d.ld_in);
             const uint16_t* xp = w->x_planes;
             if (!xp) {
+                EAGCN_CHECK_ARG(w->x, "eagcn_layer_forward: neither an fp32 input nor its plane images");
                 rc = launch_bx3_split(w->x, b->T, b->meta + EAGCN_META_T, d.ld_in, sc.xp, xstride, b->T, d.np, s);
                 if (rc) return rc;
                 xp = sc.xp;
@@ -1073,6 +1076,9 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
         }
         if (d.np && bx3_ok(bp)) {
             rc = launch_bx3(bp, nullptr, d.np, s, gemm_work, PROF_GEMM, bx3_pick_wide(bp, nullptr, b->t_hint));
+        } else if (!w->x) {
+            set_error("eagcn_layer_forward: the input exists as plane images only and the plane product does not apply");
+            return EAGCN_ERR_ARG;
         } else if (gemm3_layer(d.ld_in) && gemm3_ok(g3)) {
             rc = launch_gemm3(g3, nullptr, sc.gws, gemm3_workspace_bytes(), s);
         } else {
@@ -1119,7 +1125,29 @@ int eagcn::layer_forward_impl(const eagcn_batch* b, const eagcn_layer_params* p,
     EAGCN_LAUNCH_CHECK();
     }
     if (skip_apply) return EAGCN_OK;
-    return apply_launch(b, p, w, d, sc.colp, s);
+    return apply_launch(b, p, w, d, sc.colp, s, planes_only);
+}
+
+bool eagcn::layer_reads_planes_only(const eagcn_batch* b, const eagcn_layer_params* p, bool aux_stream) {
+    static const bool on = [] { const char* v = getenv("EAGCN_PLANES_ONLY"); return !(v && v[0] == '0'); }();
+    if (!on || aux_stream || !b || !p || b->T <= 0) return false;
+    const LayerDims d = layer_dims(b, p);
+    if (!d.np) return false;
+    // the three products exactly as layer_forward_impl / layer_backward_impl describe them (bx3_ok looks at alignment, strides
+    // and extents: the operands below stand for the 256-byte aligned pieces those functions carve)
+    const uint16_t* pl = reinterpret_cast<const uint16_t*>(static_cast<uintptr_t>(4096));
+    float* fo = reinterpret_cast<float*>(static_cast<uintptr_t>(4096));
+    const size_t xstride = bx_plane_elems(b->T, d.ld_in), pstride = bx_plane_elems(b->T, d.fp);
+    BxProb bp, bx, bw;
+    memset(&bp, 0, sizeof(bp)); memset(&bx, 0, sizeof(bx)); memset(&bw, 0, sizeof(bw));
+    bp.A = BxPlanes{pl, xstride, d.ld_in, b->T}; bp.B = BxPlanes{pl, d.wtpslab, d.ld_in, d.fp}; bp.C = fo; bp.ldc = d.fp;
+    bp.M = b->T; bp.N = d.fp; bp.K = d.ld_in; bp.M_dev = b->meta + EAGCN_META_T; bp.tn = 0; bp.splits = 1;
+    bx.A = BxPlanes{pl, pstride, d.fp, b->T}; bx.B = BxPlanes{pl, d.wpslab, d.fp, d.ld_in}; bx.C = fo; bx.ldc = d.ld_in;
+    bx.M = b->T; bx.N = d.ld_in; bx.K = d.fp; bx.M_dev = b->meta + EAGCN_META_T; bx.tn = 0; bx.splits = 1;
+    bw.A = BxPlanes{pl, xstride, d.ld_in, b->T}; bw.B = BxPlanes{pl, pstride, d.fp, b->T};
+    bw.C = fo; bw.ldc = d.fp; bw.M = d.ld_in; bw.N = d.fp; bw.K = b->T; bw.K_dev = b->meta + EAGCN_META_T; bw.tn = 1;
+    bw.splits = d.bx_splits; bw.slab = d.wslab;
+    return bx3_ok(bp) && bx3_ok(bw) && bx3_ok(bx);
 }
 
 int eagcn::layer_apply_impl(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, void* stream) {
@@ -1131,7 +1159,7 @@ int eagcn::layer_apply_impl(const eagcn_batch* b, const eagcn_layer_params* p, c
 }
 
 static int apply_launch_(const eagcn_batch* b, const eagcn_layer_params* p, const eagcn_layer_bufs* w, const LayerDims& d,
-                         const float* colp, hipStream_t s) {
+                         const float* colp, hipStream_t s, bool planes_only) {
     ProfScope psbn(PROF_BN, s);
     ApplyArgs aa;
     aa.bt = *b; aa.vc = d.vc; aa.structure = p->structure; aa.fp = d.fp; aa.Y = w->Y; aa.ldy = d.fp;
@@ -1142,6 +1170,7 @@ static int apply_launch_(const eagcn_batch* b, const eagcn_layer_params* p, cons
     aa.seed = p->seed;
     aa.seed_dev = p->seed_dev;
     aa.planes = BxOut{gemm_planes() ? w->xout_planes : nullptr, bx_plane_elems(b->T, d.ldo), gemm_planes(), b->T};
+    if (planes_only && aa.planes.p) aa.out = nullptr;        // (the only reader is the layer above, through the planes)
     static const int map_env = [] { const char* v = getenv("EAGCN_BN_APPLY_MAP"); return v ? atoi(v) : -1; }();
     aa.tile_map = map_env >= 0 ? map_env : (aa.planes.p ? 1 : 0);
     const size_t nthr = aa.tile_map ? (size_t)cdiv(std::max(b->T, 1), 8) * cdiv(d.ldo, 32) * 64 : (size_t)std::max(b->T, 1) * d.ldo / 4;
@@ -1199,7 +1228,7 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
     int rc = check_layer(b, p, "eagcn_layer_backward");
     if (rc) return rc;
     EAGCN_CHECK_ARG(w && g && w->bn && w->scratch, "eagcn_layer_backward: null buffer");
-    EAGCN_CHECK_ARG(b->T == 0 || ((dxout || rg) && w->x && w->P && w->Y && w->rscale), "eagcn_layer_backward: null activation buffer");
+    EAGCN_CHECK_ARG(b->T == 0 || ((dxout || rg) && (w->x || w->x_planes) && w->P && w->Y && w->rscale), "eagcn_layer_backward: null activation buffer");
     for (int k = 0; k < p->K; ++k)
         EAGCN_CHECK_ARG(g->dW[k] && g->dbias[k] && g->dgamma[k] && g->dbeta[k] && g->datt_w[k] && g->dself_r[k],
                         "eagcn_layer_backward: view %d has a null gradient buffer", k);
@@ -1359,6 +1388,9 @@ int eagcn::layer_backward_impl(const eagcn_batch* b, const eagcn_layer_params* p
                 rc = launch_bx3_split(w->x, b->T, b->meta + EAGCN_META_T, d.ld_in, sc.xp, xstride, b->T, d.np, s);
                 if (rc) return rc;
             }
+        } else if (!w->x) {
+            set_error("eagcn_layer_backward: the input exists as plane images only and the plane products do not apply");
+            return EAGCN_ERR_ARG;
         }
         EdgeArgs e;
         e.bt = *b; e.vc = d.vc; e.dY = sc.dY; e.Y = w->Y; e.P = w->P; e.ld = d.fp; e.sig = sc.sig;
