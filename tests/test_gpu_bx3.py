@@ -237,3 +237,56 @@ torch.save({'out': out.detach().cpu(), 'g': {k: p.grad.cpu() for k, p in m.named
         for k, v in a['g'].items():
             dd = (b['g'][k] - v).abs().max().item()
             assert dd <= 1e-5 * v.abs().max().item() + 2e-6 * scale, (structure, k, dd, v.abs().max().item(), scale)
+
+
+def test_hidden_layers_without_fp32_twin_are_bit_identical():
+    """Round 6: where the layer above reads its input from the plane images in both directions, a hidden layer stores no fp32 output
+    (csrc/layer.hip layer_reads_planes_only, bn_apply).  EAGCN_PLANES_ONLY=0 keeps the fp32 twin: the same arithmetic either way, so
+    outputs and every gradient must be BIT-identical -- eager engine and captured step, three layers (two hidden outputs), widths
+    that take the plane path (>= 128 columns) and, as the control, widths that do not (the switch then changes nothing at all).
+    Subprocesses: the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, torch
+sys.path.insert(0, %r)
+from eagcn_amd import EAGCN
+from eagcn_amd.synthetic import bce_weights, make_batch
+w1, graph = int(sys.argv[1]), sys.argv[2] == 'graph'
+mb = make_batch(B=40, n_max=50, n_med=18, rel_channels=(28, 4, 2, 2, 2), seed=33, n_tasks=3)
+dense = [t.cuda() for t in mb.dense()]
+labels = torch.from_numpy(mb.labels).cuda()
+bw = torch.tensor(bce_weights(3), dtype=torch.float32, device='cuda')
+torch.manual_seed(3)
+m = EAGCN(28, 24, *[w1] * 5, *[w1 + 16] * 5, 64, 32, 3, 0.25, structure=sys.argv[3], n_layers=3, grad_mode='direct', graph=graph).cuda().train()
+torch.manual_seed(11)                       # (the dropout seeds of the step come from the host generator)
+loss, (out, _, gr) = m.fused_step(dense, labels, 'class', bw) if graph else (None, m(*dense))
+if not graph:
+    from eagcn_amd.losses import fused_classification_loss
+    loss = fused_classification_loss(out, labels, bw)
+    loss.backward()
+torch.cuda.synchronize()
+torch.save({'loss': loss.detach().cpu(), 'out': out.detach().cpu(), 'g': {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}}, sys.argv[4])
+''' % root
+    with tempfile.TemporaryDirectory() as d:
+        for structure in ('Concate', 'Weighted_sum'):
+            # input columns of the layers above: Concate 5 x 48 = 240 / 320 (planes), 5 x 16 = 80 (none: the control);
+            # Weighted_sum: the merged width itself, 128 / 144 (planes)
+            for w1 in ((48, 16) if structure == 'Concate' else (128,)):
+                for mode in ('eager', 'graph'):
+                    res = {}
+                    for sw in ('1', '0'):
+                        path = os.path.join(d, 'r_%s_%d_%s_%s.pt' % (structure, w1, mode, sw))
+                        env = dict(os.environ, EAGCN_PLANES_ONLY=sw)
+                        r = subprocess.run([sys.executable, '-c', code, str(w1), mode, structure, path], env=env, capture_output=True,
+                                           text=True, timeout=300)
+                        assert r.returncode == 0, r.stderr[-2000:]
+                        res[sw] = torch.load(path)
+                    a, b = res['1'], res['0']
+                    assert torch.equal(a['out'], b['out']) and torch.equal(a['loss'], b['loss']), (structure, w1, mode)
+                    assert a['g'].keys() == b['g'].keys()
+                    for k in a['g']:
+                        assert torch.equal(a['g'][k], b['g'][k]), (structure, w1, mode, k)
