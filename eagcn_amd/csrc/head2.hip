@@ -475,6 +475,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
     });
 }
 
+// multi-round launches (B >= 1024: 1 400 tiles of dense 1's backward on 512 resident workgroups): ONE k-step in flight per wave
+// instead of two -> 150 instead of 250 registers -> three workgroups per CU instead of two (the 16-byte-load form only: the scalar form spills)
+template <bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void head_bwd_light_kernel(HeadBwd a) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];
+    const int Np = (a.N + 3) & ~3;
+    hb_tile<true, DROP, 1, 4>(a, blockIdx.x, tab, reinterpret_cast<f32x4*>(tab + 3 * Np), a.bnp, a.K, [&]() {
+        hb_table(a, tab, blockIdx.x == 0);
+        __syncthreads();
+    });
+}
+
 // Graph_BN backward (no product in front of it): dg = al * dgn + be * g + ga, d gamma / d beta; workgroup `wg` of `nwg`
 __device__ __forceinline__ void hg_body(const HeadGbn& a, int wg, int nwg) {
     const size_t total = (size_t)a.B * a.F;
@@ -728,6 +740,14 @@ int head_colstats(const float* g, int B, int F, double* st, hipStream_t s, doubl
     EAGCN_LAUNCH_CHECK();
     return EAGCN_OK;
 }
+static int head_cus() {
+    static const int cus = [] {
+        int d = 0, n = 0;
+        if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    return cus;
+}
 // waves per workgroup of a stage: HeadFwd.nw / HeadBwd.nw if set, else 8 while the launch is one round of one workgroup per CU
 static int head_nw(int want, int tiles) {
     static const int cus = [] {
@@ -770,7 +790,10 @@ int head_bwd(const HeadBwd& a, hipStream_t s) {
     const uintptr_t al = reinterpret_cast<uintptr_t>(a.dy) | reinterpret_cast<uintptr_t>(a.W) | reinterpret_cast<uintptr_t>(a.y) |
                          reinterpret_cast<uintptr_t>(a.extra);
     const bool vec = (a.N & 3) == 0 && (al & 15) == 0;
-#define EAGCN_HB(V, D) do { if (nw == 8) head_bwd_kernel<V, D, 8><<<tiles, 512, lds, s>>>(a); else head_bwd_kernel<V, D, 4><<<tiles, 256, lds, s>>>(a); } while (0)
+    static const int light_env = [] { const char* e = getenv("EAGCN_HEAD_LIGHT"); return e ? atoi(e) : 1; }();     // rounds (of 2 workgroups per CU) from which the light kernel is taken; 0: never
+    const bool light = light_env > 0 && nw == 4 && a.nw == 0 && tiles > 2 * light_env * head_cus();
+#define EAGCN_HB(V, D) do { if (nw == 8) head_bwd_kernel<V, D, 8><<<tiles, 512, lds, s>>>(a); else if (light && V) head_bwd_light_kernel<D><<<tiles, 256, lds, s>>>(a); \
+                            else head_bwd_kernel<V, D, 4><<<tiles, 256, lds, s>>>(a); } while (0)
     if (vec && a.drop.on) EAGCN_HB(true, true);
     else if (vec) EAGCN_HB(true, false);
     else if (a.drop.on) EAGCN_HB(false, true);

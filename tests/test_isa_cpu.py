@@ -113,3 +113,8 @@ def test_head_kernels_have_no_scratch(isa):
         seen += 1
         assert scratch == 0 and vgpr <= 256, '%s: %d bytes of scratch per lane, %d VGPRs' % (name, scratch, vgpr)
     assert seen >= 20
+    # round 6: dense 1's backward at large batches with one k-step in flight: three 4-wave workgroups per CU (170 registers)
+    light = {n: v for n, v in ks.items() if 'head_bwd_light_kernel' in n}
+    assert len(light) == 2
+    for name, (scratch, vgpr) in light.items():
+        assert scratch == 0 and vgpr <= 168, (name, scratch, vgpr)
